@@ -1,0 +1,80 @@
+"""ctypes binding of the C-ABI library (include/exl2_hip.h).
+
+The product library is `exllamav2_amd/libexl2_hip.so` (gfx950 code objects, built by `__graft_entry__.build()`).
+There is NO CPU fallback: `hip_lib()` raises if the library is missing.  `Lib(path)` can bind any library exporting the
+same ABI; the test-suite uses that to drive the CPU *emulation build of the same sources* (tests/emu) for host-logic
+tests -- the package itself never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "libexl2_hip.so")
+
+vp = C.c_void_p
+ci = C.c_int
+cf = C.c_float
+cll = C.c_longlong
+
+# name -> (restype, argtypes).  Every symbol declared in include/exl2_hip.h appears here (tests check both ways).
+PROTOTYPES = {
+    "exl2_last_error": (C.c_char_p, []),
+    "exl2_abi_version": (ci, []),
+    # q_matrix
+    "exl2_make_q_matrix": (ci, [C.POINTER(vp), ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
+    "exl2_free_q_matrix": (ci, [vp]),
+    "exl2_q_matrix_info": (ci, [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(cll)]),
+    "exl2_reconstruct": (ci, [vp, vp, vp]),
+    "exl2_gemm_half_q_half": (ci, [vp, vp, vp, ci, ci, vp, ci, ci, vp]),
+    "exl2_make_group_map": (ci, [vp, ci, ci, vp, ci]),
+}
+
+
+class Exl2Error(RuntimeError):
+    pass
+
+
+class Lib:
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise Exl2Error(
+                f"{path} not found: the HIP library is not built. Run `python -c \"import __graft_entry__ as g; "
+                f"g.build()\"` at the repo root (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        self.path = path
+        self.dll = C.CDLL(path)
+        self.missing = []
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(self.dll, name)
+            except AttributeError:
+                self.missing.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+        if self.missing:
+            raise Exl2Error(f"{path} does not export: {', '.join(self.missing)}")
+
+    def last_error(self) -> str:
+        return (self.exl2_last_error() or b"").decode("utf-8", "replace")
+
+    def check(self, rc: int) -> int:
+        if rc < 0:
+            raise Exl2Error(self.last_error() or f"exl2 error {rc}")
+        return rc
+
+
+_hip = None
+_lock = threading.Lock()
+
+
+def hip_lib() -> Lib:
+    global _hip
+    if _hip is None:
+        with _lock:
+            if _hip is None:
+                _hip = Lib(HIP_LIB_PATH)
+    return _hip

@@ -1,0 +1,130 @@
+// hw.h -- the gfx950 (CDNA4, wave64) primitives every kernel in this library is written against.
+//
+// Kernels use clang-native vector types (`_Float16` ext vectors) instead of hip_fp16.h so that packed
+// fp16 math lowers directly to v_pk_{add,mul,fma}_f16 and the MFMA builtin takes the fragments as they are.
+// tests/emu/hw.h provides the same names for the CPU emulation build used by the GPU-less host-logic tests;
+// the product library is only ever built from THIS header (no dual paths in kernel sources).
+#ifndef EXL2_HW_H
+#define EXL2_HW_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t  i32;
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float    f32x2 __attribute__((ext_vector_type(2)));
+typedef float    f32x4 __attribute__((ext_vector_type(4)));
+typedef u32      u32x2 __attribute__((ext_vector_type(2)));
+typedef u32      u32x4 __attribute__((ext_vector_type(4)));
+
+#define DEV  __device__ __forceinline__
+#define HD   __host__ __device__ __forceinline__
+#define KERNEL __global__
+
+#define WAVE 64
+
+// ---- bit casts ------------------------------------------------------------------------------------------------------
+DEV f16x2 as_h2(u32 x)   { return __builtin_bit_cast(f16x2, x); }
+DEV u32   as_u32(f16x2 x) { return __builtin_bit_cast(u32, x); }
+DEV f16   as_h(u16 x)    { return __builtin_bit_cast(f16, x); }
+DEV u16   as_u16(f16 x)  { return __builtin_bit_cast(u16, x); }
+DEV float as_f32(u32 x)  { return __builtin_bit_cast(float, x); }
+DEV u32   f32_bits(float x) { return __builtin_bit_cast(u32, x); }
+
+// ---- packed fp16 math (single instructions on gfx950) ---------------------------------------------------------------
+DEV f16x2 h2_fma(f16x2 a, f16x2 b, f16x2 c) { return __builtin_elementwise_fma(a, b, c); }
+DEV f16x2 h2_dup(f16 x) { return (f16x2){x, x}; }
+DEV f16   h_fma(f16 a, f16 b, f16 c) { return __builtin_fmaf16(a, b, c); }
+
+// ---- thread / wave identity (all kernels use 1-D blocks whose size is a multiple of 64) -----------------------------
+DEV int lane_id() { return threadIdx.x & 63; }
+DEV int wave_id() { return threadIdx.x >> 6; }
+DEV int tid()     { return threadIdx.x; }
+DEV int nthreads(){ return blockDim.x; }
+DEV int bid_x()   { return blockIdx.x; }
+DEV int bid_y()   { return blockIdx.y; }
+DEV int bid_z()   { return blockIdx.z; }
+DEV int gdim_x()  { return gridDim.x; }
+DEV int gdim_y()  { return gridDim.y; }
+
+DEV void block_sync() { __syncthreads(); }
+
+// value of lane 0's copy, provably wave-uniform to the compiler (lets it live in SGPRs)
+DEV u32 uniform(u32 x) { return __builtin_amdgcn_readfirstlane(x); }
+DEV int uniform(int x) { return (int)__builtin_amdgcn_readfirstlane((u32)x); }
+
+// ---- cross-lane ----------------------------------------------------------------------------------------------------
+// butterfly exchange within a wave: value held by lane (lane ^ mask).  Masks 1,2 map to DPP quad_perm, 4/8 to
+// row_half_mirror / row_mirror AFTER the lower steps of an all-reduce made the halves uniform; the generic form
+// goes through ds_bpermute (LDS crossbar, no LDS memory).
+DEV u32 shfl_xor_u32(u32 v, int mask) {
+    return (u32)__builtin_amdgcn_ds_bpermute(((lane_id() ^ mask) << 2), (int)v);
+}
+DEV float shfl_xor_f32(float v, int mask) { return as_f32(shfl_xor_u32(f32_bits(v), mask)); }
+DEV u32 shfl_idx_u32(u32 v, int src_lane) { return (u32)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
+DEV float shfl_idx_f32(float v, int src_lane) { return as_f32(shfl_idx_u32(f32_bits(v), src_lane)); }
+
+// all-reduce (sum) over each aligned group of 16 lanes, 4 DPP adds, result in every lane of the group
+DEV float row16_allreduce_add(float v) {
+    v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+DEV float row16_allreduce_max(float v) {
+    v = fmaxf(v, as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x140, 0xF, 0xF, true)));
+    return v;
+}
+// all-reduce over the whole wave (64 lanes)
+DEV float wave_allreduce_add(float v) {
+    v = row16_allreduce_add(v);
+    v += shfl_xor_f32(v, 16);
+    v += shfl_xor_f32(v, 32);
+    return v;
+}
+DEV float wave_allreduce_max(float v) {
+    v = row16_allreduce_max(v);
+    v = fmaxf(v, shfl_xor_f32(v, 16));
+    v = fmaxf(v, shfl_xor_f32(v, 32));
+    return v;
+}
+
+// ---- matrix core ---------------------------------------------------------------------------------------------------
+// D[16x16] += A[16x32] * B[32x16], fp16 in / fp32 accumulate.  Lane l holds A[i = l&15][k-slot (l>>4, e=0..7)],
+// B[k-slot (l>>4, e)][j = l&15]; D: column j = l&15, rows (l>>4)*4 + r, r = 0..3.
+DEV f32x4 mfma_16x16x32_f16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// ---- memory --------------------------------------------------------------------------------------------------------
+// streamed-once data (packed weights, KV pages): non-temporal so it does not displace the activation vector / tables
+template <typename T> DEV T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
+template <typename T> DEV void st_nt(T* p, T v) { __builtin_nontemporal_store(v, p); }
+
+DEV float atomic_add_f32(float* p, float v) { return atomicAdd(p, v); }
+DEV u32 atomic_add_u32(u32* p, u32 v) { return atomicAdd(p, v); }
+
+// dynamic LDS (16-byte aligned base, guide G17)
+#define DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define SHARED __shared__
+
+// fast math
+DEV float fast_exp(float x) { return __expf(x); }
+DEV float fast_rsqrt(float x) { return rsqrtf(x); }
+DEV float fast_rcp(float x) { return __frcp_rn(x); }
+
+// ---- launch --------------------------------------------------------------------------------------------------------
+#define LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+#endif  // EXL2_HW_H

@@ -1,0 +1,238 @@
+// hw_emu.h -- CPU emulation of the primitives in exllamav2_amd/csrc/hw.h plus the handful of HIP runtime calls the
+// library's host code makes.  TEST INFRASTRUCTURE ONLY: it lets the GPU-less `-m "not gpu"` tests drive the very same
+// kernel and host sources (force-included ahead of hw.h, whose include guard it pre-empts) on tiny shapes, so indexing /
+// layout / host-logic bugs surface before any GPU time is spent.  It is never built into, nor loadable by, the product
+// package (exllamav2_amd/_lib.py loads only the gfx950 library and raises if it is missing).
+//
+// Model: one workgroup runs at a time; its blockDim.x threads are OS threads; __syncthreads is a barrier over the live
+// threads of the block; wave64 cross-lane operations go through a per-wave exchange buffer with a per-wave barrier.
+#ifndef EXL2_HW_H
+#define EXL2_HW_H
+#define EXL2_EMU 1
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <mutex>
+#include <condition_variable>
+#include <thread>
+#include <vector>
+#include <functional>
+#include <algorithm>
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t  i32;
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float    f32x2 __attribute__((ext_vector_type(2)));
+typedef float    f32x4 __attribute__((ext_vector_type(4)));
+typedef u32      u32x2 __attribute__((ext_vector_type(2)));
+typedef u32      u32x4 __attribute__((ext_vector_type(4)));
+
+#define DEV  inline
+#define HD   inline
+#define KERNEL static
+#define __launch_bounds__(...)
+#define WAVE 64
+
+using std::min;
+using std::max;
+
+// ---- runtime model ---------------------------------------------------------------------------------------------------
+struct EmuBarrier
+{
+    std::mutex m;
+    std::condition_variable cv;
+    int live = 0, arrived = 0;
+    unsigned gen = 0;
+    void reset(int n) { live = n; arrived = 0; }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned g = gen;
+        if (++arrived >= live) { arrived = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+    void leave()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        live--;
+        if (live > 0 && arrived >= live) { arrived = 0; gen++; cv.notify_all(); }
+    }
+};
+
+struct EmuWave
+{
+    EmuBarrier bar;
+    alignas(16) unsigned char slot[64][64];
+};
+
+struct EmuDim { unsigned x, y, z; };
+
+struct EmuCtx
+{
+    EmuBarrier block_bar;
+    EmuBarrier done_bar;
+    EmuWave wave[16];
+    unsigned char* dyn_smem;
+    EmuDim grid, block;
+};
+
+struct dim3
+{
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+extern thread_local int emu_tid_;
+extern thread_local EmuDim emu_bid_;
+extern EmuCtx* emu_ctx_;
+void emu_launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+
+DEV int lane_id() { return emu_tid_ & 63; }
+DEV int wave_id() { return emu_tid_ >> 6; }
+DEV int tid()     { return emu_tid_; }
+DEV int nthreads(){ return (int)emu_ctx_->block.x; }
+DEV int bid_x()   { return (int)emu_bid_.x; }
+DEV int bid_y()   { return (int)emu_bid_.y; }
+DEV int bid_z()   { return (int)emu_bid_.z; }
+DEV int gdim_x()  { return (int)emu_ctx_->grid.x; }
+DEV int gdim_y()  { return (int)emu_ctx_->grid.y; }
+
+DEV void block_sync() { emu_ctx_->block_bar.wait(); }
+DEV u32 uniform(u32 x) { return x; }
+DEV int uniform(int x) { return x; }
+
+// ---- bit casts / math ------------------------------------------------------------------------------------------------
+DEV f16x2 as_h2(u32 x)   { return __builtin_bit_cast(f16x2, x); }
+DEV u32   as_u32(f16x2 x) { return __builtin_bit_cast(u32, x); }
+DEV f16   as_h(u16 x)    { return __builtin_bit_cast(f16, x); }
+DEV u16   as_u16(f16 x)  { return __builtin_bit_cast(u16, x); }
+DEV float as_f32(u32 x)  { return __builtin_bit_cast(float, x); }
+DEV u32   f32_bits(float x) { return __builtin_bit_cast(u32, x); }
+
+DEV f16 h_fma(f16 a, f16 b, f16 c) { return (f16)((double)a * (double)b + (double)c); }
+DEV f16x2 h2_fma(f16x2 a, f16x2 b, f16x2 c) { return (f16x2){h_fma(a.x, b.x, c.x), h_fma(a.y, b.y, c.y)}; }
+DEV f16x2 h2_dup(f16 x) { return (f16x2){x, x}; }
+
+DEV float fast_exp(float x) { return expf(x); }
+DEV float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
+DEV float fast_rcp(float x) { return 1.0f / x; }
+
+// ---- cross-lane ------------------------------------------------------------------------------------------------------
+template <typename T> DEV T emu_wave_read(T mine, int src_lane)
+{
+    static_assert(sizeof(T) <= 64, "exchange slot too small");
+    EmuWave& w = emu_ctx_->wave[wave_id()];
+    memcpy(w.slot[lane_id()], &mine, sizeof(T));
+    w.bar.wait();
+    T r;
+    memcpy(&r, w.slot[src_lane & 63], sizeof(T));
+    w.bar.wait();
+    return r;
+}
+DEV u32 shfl_xor_u32(u32 v, int mask) { return emu_wave_read(v, lane_id() ^ mask); }
+DEV float shfl_xor_f32(float v, int mask) { return emu_wave_read(v, lane_id() ^ mask); }
+DEV u32 shfl_idx_u32(u32 v, int src) { return emu_wave_read(v, src); }
+DEV float shfl_idx_f32(float v, int src) { return emu_wave_read(v, src); }
+
+DEV int emu_half_mirror(int l) { return (l & ~7) | (7 - (l & 7)); }
+DEV int emu_row_mirror(int l)  { return (l & ~15) | (15 - (l & 15)); }
+DEV float row16_allreduce_add(float v)
+{
+    const int l = lane_id();
+    v += emu_wave_read(v, l ^ 1);
+    v += emu_wave_read(v, l ^ 2);
+    v += emu_wave_read(v, emu_half_mirror(l));
+    v += emu_wave_read(v, emu_row_mirror(l));
+    return v;
+}
+DEV float row16_allreduce_max(float v)
+{
+    const int l = lane_id();
+    v = fmaxf(v, emu_wave_read(v, l ^ 1));
+    v = fmaxf(v, emu_wave_read(v, l ^ 2));
+    v = fmaxf(v, emu_wave_read(v, emu_half_mirror(l)));
+    v = fmaxf(v, emu_wave_read(v, emu_row_mirror(l)));
+    return v;
+}
+DEV float wave_allreduce_add(float v) { v = row16_allreduce_add(v); v += shfl_xor_f32(v, 16); v += shfl_xor_f32(v, 32); return v; }
+DEV float wave_allreduce_max(float v)
+{
+    v = row16_allreduce_max(v); v = fmaxf(v, shfl_xor_f32(v, 16)); v = fmaxf(v, shfl_xor_f32(v, 32)); return v;
+}
+
+// ---- matrix core: v_mfma_f32_16x16x32_f16 ----------------------------------------------------------------------------
+DEV f32x4 mfma_16x16x32_f16(f16x8 a, f16x8 b, f32x4 c)
+{
+    EmuWave& w = emu_ctx_->wave[wave_id()];
+    const int l = lane_id();
+    memcpy(w.slot[l], &a, 16);
+    memcpy(w.slot[l] + 16, &b, 16);
+    w.bar.wait();
+    const int col = l & 15;
+    f32x4 d = c;
+    for (int r = 0; r < 4; r++)
+    {
+        const int row = (l >> 4) * 4 + r;
+        float acc = d[r];
+        for (int j = 0; j < 4; j++)
+        {
+            f16x8 av, bv;
+            memcpy(&av, w.slot[row + 16 * j], 16);
+            memcpy(&bv, w.slot[col + 16 * j] + 16, 16);
+            for (int e = 0; e < 8; e++) acc += (float)av[e] * (float)bv[e];
+        }
+        d[r] = acc;
+    }
+    w.bar.wait();
+    return d;
+}
+
+// ---- memory ----------------------------------------------------------------------------------------------------------
+template <typename T> DEV T ld_nt(const T* p) { return *p; }
+template <typename T> DEV void st_nt(T* p, T v) { *p = v; }
+DEV float atomic_add_f32(float* p, float v)
+{
+    static std::mutex m; std::lock_guard<std::mutex> g(m); const float o = *p; *p = o + v; return o;
+}
+DEV u32 atomic_add_u32(u32* p, u32 v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+
+#define DYN_SMEM(name) unsigned char* name = emu_ctx_->dyn_smem
+#define SHARED static
+
+#define LAUNCH(kernel, grid, block, smem, stream, ...) \
+    emu_launch(grid, block, smem, [&]() { kernel(__VA_ARGS__); })
+
+// ---- HIP runtime shims used by host code -----------------------------------------------------------------------------
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyHostToHost = 0 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+struct hipDeviceProp_t { int multiProcessorCount; };
+
+DEV hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
+DEV hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+DEV hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
+DEV hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+DEV hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+DEV hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+DEV hipError_t hipDeviceSynchronize() { return hipSuccess; }
+DEV hipError_t hipGetLastError() { return hipSuccess; }
+DEV hipError_t hipSetDevice(int) { return hipSuccess; }
+DEV hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+DEV hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+DEV const char* hipGetErrorString(hipError_t) { return "emu"; }
+DEV hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 4; return hipSuccess; }
+DEV hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+
+#endif  // EXL2_HW_H
