@@ -30,6 +30,35 @@ PROTOTYPES = {
     "exl2_reconstruct": (ci, [vp, vp, vp]),
     "exl2_gemm_half_q_half": (ci, [vp, vp, vp, ci, ci, vp, ci, ci, vp]),
     "exl2_make_group_map": (ci, [vp, ci, ci, vp, ci]),
+    # norm / rope / activation
+    "exl2_rms_norm": (ci, [vp, vp, vp, cf, ci, ci, ci, ci, ci, vp]),
+    "exl2_rope_qk": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, ci, vp]),
+    "exl2_act_mul": (ci, [vp, vp, ci, ci, ci, vp, ci, vp]),
+    # decode-loop utilities
+    "exl2_embed_rows": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "exl2_argmax_rows": (ci, [vp, vp, ci, ci, ci, vp]),
+    "exl2_add_i32": (ci, [vp, ci, ci, vp]),
+    # quantized KV cache
+    "exl2_fp16_to_q_kv": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, ci, vp]),
+    "exl2_q_to_fp16_kv": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, ci, vp]),
+    # attention
+    "exl2_paged_attn_scratch_bytes": (cll, [ci, ci, ci]),
+    "exl2_paged_attn": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, vp, cll, vp]),
+    "exl2_rope_kv_append": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, vp]),
+    # fused modules
+    "exl2_make_q_attn": (ci, [C.POINTER(vp), vp, vp, ci, ci, cf, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci,
+                              ci, vp, vp, vp, vp, ci, ci]),
+    "exl2_free_q_attn": (ci, [vp]),
+    "exl2_q_attn_forward_1": (ci, [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
+    "exl2_q_attn_forward_2": (ci, [vp, vp, vp, ci, ci, vp]),
+    "exl2_make_q_mlp": (ci, [C.POINTER(vp), vp, vp, ci, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, ci, ci]),
+    "exl2_free_q_mlp": (ci, [vp]),
+    "exl2_q_mlp_forward": (ci, [vp, vp, ci, vp]),
+    # graphs
+    "exl2_graph_begin_capture": (ci, [vp]),
+    "exl2_graph_end_capture": (ci, [vp, C.POINTER(vp)]),
+    "exl2_graph_launch": (ci, [vp, vp]),
+    "exl2_graph_free": (ci, [vp]),
 }
 
 

@@ -1,0 +1,408 @@
+// attn.hip -- paged / contiguous KV attention for gfx950 that needs no flash-attn, + RoPE-and-append, + C ABI.
+//
+// Reference: the attention step between q_attn_forward_1 and _2 is third-party in the reference
+// (flash_attn_with_kvcache, attn.py:602-613; torch fallback _attn_torch attn.py:869-937).  This kernel implements the
+// same contract: softmax(q k^T * scale + causal bottom-right) v with GQA, keys addressed through a
+// block table [batch, pages] over a cache viewed as [pages, page_size, kv_heads, head_dim], fp32 softmax.
+//
+// Decode-shaped design (flash-decoding): grid = (kv_head, split, batch); a workgroup streams its slice of the keys once
+// for ALL query heads that share the kv head (GQA) and all q_len query tokens, 16 bytes per lane per K and per V row
+// (HDIM/8 lanes per key -> each key/value row is one contiguous 2*HDIM-byte read), every (wave, lane-group) running an
+// independent online-softmax stream; streams are merged through LDS, splits through a small combine kernel.  HBM-bound:
+// algorithmic bytes = 2 * ctx * kv_heads * head_dim * 2 per layer per token.
+#include "hw.h"
+#include "errors.h"
+#include <string.h>
+
+#define ATT_WAVES 4
+#define NEG_BIG (-1.0e30f)
+
+struct AttnArgs
+{
+    const f16* q;                 // [b, s, H, hd]
+    const f16* k_cache;           // [pages, page_size, KVH, hd]  (block_table == null: [b, page_size, KVH, hd])
+    const f16* v_cache;
+    const int* cache_seqlens;     // [b] or null
+    const int* block_table;       // [b, pages_per_seq] or null
+    f16* out;                     // [b, s, H, hd]
+    float* part_o;                // [b*s*H, nsplit, hd]
+    float* part_ml;               // [b*s*H, nsplit, 2]
+    int b, s, H, KVH;
+    int page_size, page_shift, pages_per_seq;
+    int len_const, len_offset;    // total keys = (cache_seqlens ? cache_seqlens[b] : len_const) + len_offset
+    int nsplit, causal;
+    float scale;
+};
+
+template <int LPK> DEV float group_allreduce_add(float v)
+{
+    if constexpr (LPK == 8) return row8_allreduce_add(v);
+    else if constexpr (LPK == 16) return row16_allreduce_add(v);
+    else { v = row16_allreduce_add(v); return v + as_f32(swz_xor_u32<16>(f32_bits(v))); }
+}
+
+template <int HDIM, int RB>
+KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_decode_kernel(const AttnArgs a)
+{
+    DYN_SMEM(smem);
+    constexpr int LPK = HDIM / 8;               // lanes per key
+    constexpr int KPW = 64 / LPK;             // keys per wave step
+    constexpr int NSTREAM = ATT_WAVES * KPW;
+    constexpr int ROWF = HDIM + 2;              // floats per (stream, row) in LDS
+
+    const int kh = bid_x();
+    const int split = bid_y();
+    const int b = bid_z() / ((a.s * (a.H / a.KVH) + RB - 1) / RB);
+    const int rblk = bid_z() % ((a.s * (a.H / a.KVH) + RB - 1) / RB);
+    const int G = a.H / a.KVH;
+    const int R = a.s * G;                    // query rows sharing this kv head
+    const int r0 = rblk * RB;
+    const int nrows = min(RB, R - r0);
+
+    const int lane = lane_id();
+    const int wv = wave_id();
+    const int group = lane / LPK;
+    const int dl = lane % LPK;
+
+    const int total = (a.cache_seqlens ? a.cache_seqlens[b] : a.len_const) + a.len_offset;
+    int kps = (total + a.nsplit - 1) / a.nsplit;
+    kps = (kps + 15) & ~15;
+    const int k_start = split * kps;
+    const int k_end = min(total, k_start + kps);
+
+    // query fragments + causal limits
+    f16x8 qf[RB];
+    int limit[RB];
+    #pragma unroll
+    for (int r = 0; r < RB; r++)
+    {
+        const int rr = r0 + (r < nrows ? r : 0);
+        const int j = rr / G, g = rr - j * G;
+        qf[r] = *(const f16x8*)(a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM + dl * 8);
+        limit[r] = a.causal ? (total - a.s + j + 1) : total;
+    }
+
+    float m[RB], l[RB], o[RB][8];
+    #pragma unroll
+    for (int r = 0; r < RB; r++)
+    {
+        m[r] = NEG_BIG; l[r] = 0.0f;
+        #pragma unroll
+        for (int e = 0; e < 8; e++) o[r][e] = 0.0f;
+    }
+
+    const size_t row_stride = (size_t)a.KVH * HDIM;          // elements between consecutive token slots
+    for (int base = k_start + wv * KPW; base < k_end; base += ATT_WAVES * KPW)
+    {
+        const int kpos = base + group;
+        const bool in_range = kpos < k_end;
+        const int kp = in_range ? kpos : k_start;           // keep the address valid, mask the score
+        size_t tok;
+        if (a.block_table)
+            tok = (size_t)a.block_table[(size_t)b * a.pages_per_seq + (kp >> a.page_shift)] * a.page_size
+                  + (kp & (a.page_size - 1));
+        else
+            tok = (size_t)b * a.page_size + kp;
+        const size_t off = tok * row_stride + (size_t)kh * HDIM + dl * 8;
+        const f16x8 kf = ld_nt((const f16x8*)(a.k_cache + off));
+        const f16x8 vf = ld_nt((const f16x8*)(a.v_cache + off));
+
+        #pragma unroll
+        for (int r = 0; r < RB; r++)
+        {
+            if (r < nrows)
+            {
+                float d = 0.0f;
+                #pragma unroll
+                for (int e = 0; e < 4; e++)
+                    d = dot2_f32_f16((f16x2){qf[r][2 * e], qf[r][2 * e + 1]}, (f16x2){kf[2 * e], kf[2 * e + 1]}, d);
+                d = group_allreduce_add<LPK>(d);
+                const float sc = d * a.scale;
+                const bool valid = in_range && kpos < limit[r];
+                const float m_new = valid ? fmaxf(m[r], sc) : m[r];
+                const float alpha = fast_exp(m[r] - m_new);
+                const float p = valid ? fast_exp(sc - m_new) : 0.0f;
+                m[r] = m_new;
+                l[r] = l[r] * alpha + p;
+                #pragma unroll
+                for (int e = 0; e < 8; e++) o[r][e] = o[r][e] * alpha + p * (float)vf[e];
+            }
+        }
+    }
+
+    // merge the NSTREAM independent softmax streams of this workgroup
+    float* st = (float*)smem;
+    const int stream = wv * KPW + group;
+    #pragma unroll
+    for (int r = 0; r < RB; r++)
+    {
+        if (r < nrows)
+        {
+            float* p = st + ((size_t)stream * RB + r) * ROWF;
+            #pragma unroll
+            for (int e = 0; e < 8; e++) p[dl * 8 + e] = o[r][e];
+            if (dl == 0) { p[HDIM] = m[r]; p[HDIM + 1] = l[r]; }
+        }
+    }
+    block_sync();
+    for (int idx = tid(); idx < nrows * HDIM; idx += nthreads())
+    {
+        const int r = idx / HDIM, d = idx - r * HDIM;
+        float M = NEG_BIG;
+        for (int s2 = 0; s2 < NSTREAM; s2++) M = fmaxf(M, st[((size_t)s2 * RB + r) * ROWF + HDIM]);
+        float L = 0.0f, O = 0.0f;
+        for (int s2 = 0; s2 < NSTREAM; s2++)
+        {
+            const float* p = st + ((size_t)s2 * RB + r) * ROWF;
+            const float w = fast_exp(p[HDIM] - M);
+            L += p[HDIM + 1] * w;
+            O += p[d] * w;
+        }
+        const int rr = r0 + r;
+        const int j = rr / G, g = rr - j * G;
+        const size_t qrow = ((size_t)b * a.s + j) * a.H + kh * G + g;
+        if (a.nsplit == 1)
+        {
+            a.out[qrow * HDIM + d] = (f16)(L > 0.0f ? O / L : 0.0f);
+        }
+        else
+        {
+            a.part_o[(qrow * a.nsplit + split) * HDIM + d] = O;
+            if (d == 0)
+            {
+                a.part_ml[(qrow * a.nsplit + split) * 2 + 0] = M;
+                a.part_ml[(qrow * a.nsplit + split) * 2 + 1] = L;
+            }
+        }
+    }
+}
+
+KERNEL void __launch_bounds__(256) attn_combine_kernel(const AttnArgs a, int hd)
+{
+    const size_t qrow = bid_x();
+    for (int d = tid(); d < hd; d += nthreads())
+    {
+        float M = NEG_BIG;
+        for (int s2 = 0; s2 < a.nsplit; s2++) M = fmaxf(M, a.part_ml[(qrow * a.nsplit + s2) * 2]);
+        float L = 0.0f, O = 0.0f;
+        for (int s2 = 0; s2 < a.nsplit; s2++)
+        {
+            const float w = fast_exp(a.part_ml[(qrow * a.nsplit + s2) * 2] - M);
+            L += a.part_ml[(qrow * a.nsplit + s2) * 2 + 1] * w;
+            O += a.part_o[(qrow * a.nsplit + s2) * hd + d] * w;
+        }
+        a.out[qrow * hd + d] = (f16)(L > 0.0f ? O / L : 0.0f);
+    }
+}
+
+// ---- RoPE on q / new k + append of new k, v into the (paged) cache at device-side positions ---------------------------
+
+struct RopeAppendArgs
+{
+    f16* q; f16* k_new; const f16* v_new;       // [b, s, H|KVH, hd]
+    f16* k_cache; f16* v_cache;                 // nullable: no append
+    const f16* sin; const f16* cos;             // [max_seq, sincos_size]
+    const int* past_lens;                       // [b] or null
+    const int* block_table;                     // [b, pages_per_seq] or null
+    int b, s, H, KVH, hd;
+    int past_len, neox, sincos_size, rope;      // rope == 0: no rotation (append only)
+    int page_size, page_shift, pages_per_seq;
+};
+
+KERNEL void __launch_bounds__(64) rope_append_kernel(const RopeAppendArgs a)
+{
+    // one 64-thread workgroup per (token, head slot); slot < H: q ; < H + KVH: k ; else v
+    const int slot = bid_x();
+    const int j = bid_y();
+    const int b = bid_z();
+    int past = a.past_len;
+    if (past == -1) { past = a.past_lens[b]; past = past > 0 ? past : 0; }
+    else if (a.past_lens) past += a.past_lens[b];
+    const int pos = past + j;
+
+    size_t tok = 0;
+    if (a.k_cache)
+    {
+        if (a.block_table)
+            tok = (size_t)a.block_table[(size_t)b * a.pages_per_seq + (pos >> a.page_shift)] * a.page_size
+                  + (pos & (a.page_size - 1));
+        else
+            tok = (size_t)b * a.page_size + pos;
+    }
+
+    const int t = tid();
+    if (slot >= a.H + a.KVH)
+    {
+        if (!a.v_cache) return;
+        const int h = slot - a.H - a.KVH;
+        const f16* src = a.v_new + (((size_t)b * a.s + j) * a.KVH + h) * a.hd;
+        f16* dst = a.v_cache + (tok * a.KVH + h) * a.hd;
+        for (int i = t; i < (a.hd >> 3); i += 64) ((f16x8*)dst)[i] = ((const f16x8*)src)[i];
+        return;
+    }
+    const bool is_k = slot >= a.H;
+    const int h = is_k ? slot - a.H : slot;
+    f16* x = is_k ? a.k_new + (((size_t)b * a.s + j) * a.KVH + h) * a.hd
+                  : a.q + (((size_t)b * a.s + j) * a.H + h) * a.hd;
+    f16* dst = (is_k && a.k_cache) ? a.k_cache + (tok * a.KVH + h) * a.hd : nullptr;
+
+    const int srow = pos > 0 ? pos : 0;
+    const f16* sr = a.sin + (size_t)srow * a.sincos_size;
+    const f16* cr = a.cos + (size_t)srow * a.sincos_size;
+    const int half_dim = a.sincos_size >> 1;
+    // rotate: one thread per rotation pair
+    for (int c = t; c < (a.hd >> 1); c += 64)
+    {
+        if (a.neox)
+        {
+            // pairs (c, c + half_dim) for c < half_dim; columns >= sincos_size pass through
+            int c0, c1;
+            bool rot = a.rope && c < half_dim;
+            if (c < half_dim) { c0 = c; c1 = c + half_dim; }
+            else { c0 = a.sincos_size + 2 * (c - half_dim); c1 = c0 + 1; }      // unrotated tail, two columns per thread
+            f16 l = x[c0], r = x[c1];
+            if (rot)
+            {
+                const f16 cs = cr[c], sn = sr[c];
+                const f16 ls = r * (-sn);
+                const f16 rs = l * sn;
+                const f16 l2 = h_fma(l, cs, ls);
+                const f16 r2 = h_fma(r, cs, rs);
+                l = l2; r = r2;
+                x[c0] = l; x[c1] = r;
+            }
+            if (dst) { dst[c0] = l; dst[c1] = r; }
+        }
+        else
+        {
+            const int c0 = 2 * c, c1 = 2 * c + 1;
+            f16 x0 = x[c0], x1 = x[c1];
+            if (a.rope && c0 < a.sincos_size)
+            {
+                const f16 r0 = h_fma(x1, -sr[c0], x0 * cr[c0]);
+                const f16 r1 = h_fma(x0, sr[c1], x1 * cr[c1]);
+                x0 = r0; x1 = r1;
+                x[c0] = x0; x[c1] = x1;
+            }
+            if (dst) { dst[c0] = x0; dst[c1] = x1; }
+        }
+    }
+}
+
+// ---- host -----------------------------------------------------------------------------------------------------------
+
+static int ilog2_exact(int x) { int s = 0; while ((1 << s) < x) s++; return (1 << s) == x ? s : -1; }
+
+template <int HDIM>
+static void launch_decode(const AttnArgs& a, int rb, dim3 grid, void* stream)
+{
+    const int lpk = HDIM / 8, kpw = 64 / lpk;
+    const size_t lds = (size_t)ATT_WAVES * kpw * rb * (HDIM + 2) * 4;
+    static bool attr_done = false;
+    if (!attr_done)
+    {
+        (void)hipFuncSetAttribute((const void*)attn_decode_kernel<HDIM, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_decode_kernel<HDIM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    switch (rb)
+    {
+        case 1: LAUNCH((attn_decode_kernel<HDIM, 1>), grid, dim3(ATT_WAVES * 64), lds, stream, a); break;
+        case 2: LAUNCH((attn_decode_kernel<HDIM, 2>), grid, dim3(ATT_WAVES * 64), lds, stream, a); break;
+        case 4: LAUNCH((attn_decode_kernel<HDIM, 4>), grid, dim3(ATT_WAVES * 64), lds, stream, a); break;
+        default: LAUNCH((attn_decode_kernel<HDIM, 8>), grid, dim3(ATT_WAVES * 64), lds, stream, a); break;
+    }
+}
+
+extern "C" {
+
+// bytes of fp32 scratch exl2_paged_attn needs for (rows = b * s * H, nsplit)
+long long exl2_paged_attn_scratch_bytes(int rows, int head_dim, int nsplit)
+{
+    return nsplit <= 1 ? 0 : (long long)rows * nsplit * (head_dim + 2) * 4;
+}
+
+// Attention over a paged (block_table != null, page_size a power of two) or contiguous (block_table == null, cache
+// [b, page_size, KVH, hd]) fp16 KV cache that already holds all keys.  Keys per sequence = (cache_seqlens ?
+// cache_seqlens[i] : len_const) + len_offset; query token j attends keys [0, total - q_len + j + 1) when causal.
+// nsplit <= 0 picks a split count from the grid size.
+int exl2_paged_attn(const void* q, const void* k_cache, const void* v_cache, void* out,
+                    const int* cache_seqlens, const int* block_table,
+                    int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                    int page_size, int pages_per_seq, int len_const, int len_offset,
+                    float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes, void* stream)
+{
+    EXL2_REQUIRE(q && k_cache && v_cache && out, "paged_attn: null argument");
+    EXL2_REQUIRE(head_dim == 64 || head_dim == 128 || head_dim == 256, "paged_attn: head_dim %d unsupported (64/128/256)", head_dim);
+    EXL2_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged_attn: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
+    if (batch <= 0 || q_len <= 0) return EXL2_OK;
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = (const f16*)q; a.k_cache = (const f16*)k_cache; a.v_cache = (const f16*)v_cache; a.out = (f16*)out;
+    a.cache_seqlens = cache_seqlens; a.block_table = block_table;
+    a.b = batch; a.s = q_len; a.H = num_heads; a.KVH = num_kv_heads;
+    a.page_size = page_size; a.pages_per_seq = pages_per_seq;
+    a.page_shift = ilog2_exact(page_size);
+    EXL2_REQUIRE(!block_table || a.page_shift >= 0, "paged_attn: page_size %d must be a power of two", page_size);
+    a.len_const = len_const; a.len_offset = len_offset; a.causal = causal; a.scale = softmax_scale;
+
+    const int G = num_heads / num_kv_heads;
+    const int R = q_len * G;
+    const int rb = R >= 8 ? 8 : (R >= 4 ? 4 : (R >= 2 ? 2 : 1));
+    const int rblocks = (R + rb - 1) / rb;
+    if (nsplit <= 0)
+    {
+        // ~2 workgroups per CU
+        const long long base = (long long)num_kv_heads * batch * rblocks;
+        nsplit = (int)((512 + base - 1) / base);
+        if (nsplit > 16) nsplit = 16;
+        if (nsplit < 1) nsplit = 1;
+    }
+    const long long need = exl2_paged_attn_scratch_bytes(batch * q_len * num_heads, head_dim, nsplit);
+    if (need > scratch_bytes || (need > 0 && !scratch)) nsplit = 1;        // no scratch: single pass
+    a.nsplit = nsplit;
+    if (nsplit > 1)
+    {
+        a.part_o = (float*)scratch;
+        a.part_ml = a.part_o + (size_t)batch * q_len * num_heads * nsplit * head_dim;
+    }
+    dim3 grid((unsigned)num_kv_heads, (unsigned)nsplit, (unsigned)(batch * rblocks));
+    if (head_dim == 64) launch_decode<64>(a, rb, grid, stream);
+    else if (head_dim == 128) launch_decode<128>(a, rb, grid, stream);
+    else launch_decode<256>(a, rb, grid, stream);
+    if (nsplit > 1)
+        LAUNCH(attn_combine_kernel, dim3((unsigned)(batch * q_len * num_heads)), dim3(head_dim < 256 ? head_dim : 256), 0,
+               stream, a, head_dim);
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
+}
+
+// RoPE on q and k_new in place (rope.cu numerics) and, when caches are given, append of the rotated k_new and of v_new at
+// positions past_len (+ past_lens[b]) + j through the block table -- the "k = new_k, v = new_v" half of
+// flash_attn_with_kvcache, with positions read on the device so the launch can live in a HIP graph.
+int exl2_rope_kv_append(void* q, void* k_new, const void* v_new, void* k_cache, void* v_cache,
+                        const void* sin, const void* cos, int batch, int q_len, int num_heads, int num_kv_heads,
+                        int head_dim, int past_len, const int* past_lens, const int* block_table,
+                        int page_size, int pages_per_seq, int rope_style, int sincos_size, void* stream)
+{
+    EXL2_REQUIRE(q && k_new, "rope_kv_append: null argument");
+    EXL2_REQUIRE(rope_style == 0 || (sin && cos), "rope_kv_append: sin/cos tables missing");
+    EXL2_REQUIRE(past_len != -1 || past_lens, "rope_kv_append: past_len == -1 needs past_lens");
+    EXL2_REQUIRE(head_dim % 8 == 0, "rope_kv_append: bad head_dim");
+    if (batch <= 0 || q_len <= 0) return EXL2_OK;
+    RopeAppendArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = (f16*)q; a.k_new = (f16*)k_new; a.v_new = (const f16*)v_new; a.k_cache = (f16*)k_cache; a.v_cache = (f16*)v_cache;
+    a.sin = (const f16*)sin; a.cos = (const f16*)cos; a.past_lens = past_lens; a.block_table = block_table;
+    a.b = batch; a.s = q_len; a.H = num_heads; a.KVH = num_kv_heads; a.hd = head_dim;
+    a.past_len = past_len; a.neox = rope_style == 2; a.rope = rope_style != 0;      // ROPE_STYLE_* q_attn.cuh:13-15
+    a.sincos_size = sincos_size > 0 ? sincos_size : head_dim;
+    a.page_size = page_size; a.pages_per_seq = pages_per_seq; a.page_shift = ilog2_exact(page_size);
+    EXL2_REQUIRE(!block_table || a.page_shift >= 0, "rope_kv_append: page_size must be a power of two");
+    const int slots = num_heads + num_kv_heads + ((v_new && v_cache) ? num_kv_heads : 0);
+    LAUNCH(rope_append_kernel, dim3((unsigned)slots, (unsigned)q_len, (unsigned)batch), dim3(64), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// cache_q.hip -- quantized KV-cache codec (Q4 / Q6 / Q8) for gfx950 + C ABI.
+//
+// Reference: cache_q.cuh:4-185 (block = 512 consecutive fp16 elements, 256 threads x half2; 32-point Walsh-Hadamard
+// over lanes; absmax per 32 contiguous elements; RTN to 4 or 8 bits; fp16 scale), addressing cache.cu:143-223 (pack,
+// contiguous + paged) and :324-401 (unpack), bindings ext_cache.cpp:80-269.
+// The butterflies run over xor distances < 32, i.e. inside each half of a wave64, through ds_swizzle (no LDS memory);
+// arithmetic is fp16 exactly as the reference (v_pk_add_f16 / v_pk_fma_f16), so packed bytes and scales are
+// reproducible bit for bit by the oracle.
+#include "hw.h"
+#include "errors.h"
+#include <string.h>
+
+#define QBLOCK 512
+
+DEV f16x2 wht32(f16x2 w, int t)
+{
+    u32 wi = as_u32(w);
+    #define WHT_STEP(M) { const u32 p = swz_xor_u32<M>(wi); if (t & M) wi ^= 0x80008000u; wi = as_u32(as_h2(wi) + as_h2(p)); }
+    WHT_STEP(1) WHT_STEP(2) WHT_STEP(4) WHT_STEP(8) WHT_STEP(16)
+    #undef WHT_STEP
+    return as_h2(wi);
+}
+
+DEV f16 hmax(f16 a, f16 b) { return a > b ? a : b; }
+DEV f16 habs(f16 a) { return as_h((u16)(as_u16(a) & 0x7FFF)); }
+
+DEV int rint_clamp(f16 v, int hi)
+{
+    const float f = (float)v;
+    int q = (f != f) ? 0 : (int)rintf(f);          // __half2int_rn(NaN) == 0
+    q = q < 0 ? 0 : q;
+    return q > hi ? hi : q;
+}
+
+// pack one 512-element block; t = thread in block (0..255)
+template <int WBITS>
+DEV void fp16_to_q_block(int t, const f16* in, u8* out, f16* scales, size_t block_offset)
+{
+    f16x2 w = ((const f16x2*)(in + block_offset))[t];
+    w = wht32(w, t);
+
+    f16 am = hmax(habs(w.x), habs(w.y));
+    am = hmax(am, as_h((u16)swz_xor_u32<8>((u32)as_u16(am))));
+    am = hmax(am, as_h((u16)swz_xor_u32<4>((u32)as_u16(am))));
+    am = hmax(am, as_h((u16)swz_xor_u32<2>((u32)as_u16(am))));
+    am = hmax(am, as_h((u16)swz_xor_u32<1>((u32)as_u16(am))));
+    const f16x2 am2 = h2_dup(am);
+
+    if constexpr (WBITS == 4)
+    {
+        f16x2 n = w / am2;
+        n = h2_fma(n, h2_dup((f16)8.0f), h2_dup((f16)8.0f));
+        u32 q = (u32)rint_clamp(n.x, 15) | ((u32)rint_clamp(n.y, 15) << 4);
+        q |= shfl_idx_u32(q, lane_id() + 1) << 8;          // lanes t % 2 == 0 now hold 2 bytes
+        q |= shfl_idx_u32(q, lane_id() + 2) << 16;         // lanes t % 4 == 0 hold 4 bytes
+        if ((t & 3) == 0) ((u32*)(out + block_offset / 2))[t >> 2] = q;
+        if ((t & 15) == 0) scales[block_offset / 32 + (t >> 4)] = am * (f16)0.125f;
+    }
+    else
+    {
+        f16x2 n = w / am2;
+        n = h2_fma(n, h2_dup((f16)128.0f), h2_dup((f16)128.0f));
+        u32 q = (u32)rint_clamp(n.x, 255) | ((u32)rint_clamp(n.y, 255) << 8);
+        q |= shfl_idx_u32(q, lane_id() + 1) << 16;
+        if ((t & 1) == 0) ((u32*)(out + block_offset))[t >> 1] = q;
+        if ((t & 15) == 0) scales[block_offset / 32 + (t >> 4)] = am * (f16)0.0078125f;
+    }
+}
+
+template <int WBITS>
+DEV void q_to_fp16_block(int t, const u8* in, const f16* scales, f16* out, size_t block_offset)
+{
+    const f16 scale = scales[block_offset / 32 + (t >> 4)];
+    f16x2 w;
+    if constexpr (WBITS == 4)
+    {
+        const u32 q = ((const u32*)(in + block_offset / 2))[t >> 2];
+        const int sh = (t & 3) * 8;
+        w.x = (f16)(float)((int)((q >> sh) & 0xF) - 8);
+        w.y = (f16)(float)((int)((q >> (sh + 4)) & 0xF) - 8);
+    }
+    else
+    {
+        const u32 q = ((const u32*)(in + block_offset))[t >> 1];
+        const int sh = (t & 1) * 16;
+        w.x = (f16)(float)((int)((q >> sh) & 0xFF) - 128);
+        w.y = (f16)(float)((int)((q >> (sh + 8)) & 0xFF) - 128);
+    }
+    w = w * h2_dup(scale);
+    w = wht32(w, t);
+    w = w * h2_dup((f16)0.03125f);
+    ((f16x2*)(out + block_offset))[t] = w;
+}
+
+struct QKVArgs
+{
+    const void* k_in; void* k_out; void* k_scales;
+    const void* v_in; void* v_out; void* v_scales;
+    const int* cache_seqlens; const int* block_table;
+    int dim, offset, stride, blocks_x;          // contiguous mode (element units)
+    int pages_per_seq, page_size, q_len;        // paged mode
+    int wbits_k, wbits_v;
+};
+
+template <int DIR>      // 0: fp16 -> q ; 1: q -> fp16
+DEV void codec_block(const QKVArgs& a, int kv, size_t block_offset)
+{
+    const int t = tid();
+    const int wbits = kv ? a.wbits_v : a.wbits_k;
+    if (DIR == 0)
+    {
+        const f16* in = (const f16*)(kv ? a.v_in : a.k_in);
+        u8* out = (u8*)(kv ? a.v_out : a.k_out);
+        f16* sc = (f16*)(kv ? a.v_scales : a.k_scales);
+        if (wbits == 4) fp16_to_q_block<4>(t, in, out, sc, block_offset);
+        else            fp16_to_q_block<8>(t, in, out, sc, block_offset);
+    }
+    else
+    {
+        const u8* in = (const u8*)(kv ? a.v_in : a.k_in);
+        f16* out = (f16*)(kv ? a.v_out : a.k_out);
+        const f16* sc = (const f16*)(kv ? a.v_scales : a.k_scales);
+        if (wbits == 4) q_to_fp16_block<4>(t, in, sc, out, block_offset);
+        else            q_to_fp16_block<8>(t, in, sc, out, block_offset);
+    }
+}
+
+// contiguous: grid (width / 512, batch, 2)   (cache.cu:196-223, 375-401)
+template <int DIR>
+KERNEL void __launch_bounds__(256) kv_codec_kernel(const QKVArgs a)
+{
+    const int kv = bid_z();
+    const size_t block_offset = (size_t)a.offset + (size_t)bid_y() * a.stride + (size_t)bid_x() * QBLOCK;
+    codec_block<DIR>(a, kv, block_offset);
+}
+
+// paged: grid (pages_per_seq, blocks per page chunk, 2 * batch)   (cache.cu:143-195, 324-373)
+template <int DIR>
+KERNEL void __launch_bounds__(256) kv_codec_paged_kernel(const QKVArgs a)
+{
+    const int kv = bid_z() & 1;
+    const int y = bid_z() >> 1;
+    const int x = bid_x();
+    const int page = a.block_table[a.pages_per_seq * y + x];
+    const int seqlen = a.cache_seqlens[y];
+    const int vx_a = a.page_size * x;
+    int px_a, px_b;
+    if (DIR == 0) { px_a = seqlen - vx_a; px_b = px_a + a.q_len; }        // tokens being appended
+    else          { px_a = 0; px_b = seqlen - vx_a; }                      // everything valid in this page
+    if (a.dim % QBLOCK)
+    {
+        while (((long long)px_a * a.dim) % QBLOCK) px_a--;
+        while (((long long)px_b * a.dim) % QBLOCK) px_b++;
+    }
+    px_a = px_a > 0 ? px_a : 0;
+    px_b = px_b < a.page_size ? px_b : a.page_size;
+    const long long block_a = ((long long)page * a.page_size + px_a) * a.dim;
+    const long long block_b = ((long long)page * a.page_size + px_b) * a.dim;
+    for (long long j = block_a + (long long)bid_y() * QBLOCK; j < block_b; j += (long long)gdim_y() * QBLOCK)
+        codec_block<DIR>(a, kv, (size_t)j);
+}
+
+static int wbits_pair(int wbits, int* k, int* v)
+{
+    if (wbits == 4) { *k = 4; *v = 4; return 0; }
+    if (wbits == 6) { *k = 8; *v = 4; return 0; }       // cache.cu:259-276: Q6 = 8-bit keys, 4-bit values
+    if (wbits == 8) { *k = 8; *v = 8; return 0; }
+    return -1;
+}
+
+template <int DIR>
+static int kv_codec(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
+                    int batch_size, int dim, int seq_stride_tokens, int offset, int width, int page_size,
+                    const int* cache_seqlens, const int* block_table, int pages_per_seq, int wbits, void* stream)
+{
+    QKVArgs a;
+    memset(&a, 0, sizeof(a));
+    EXL2_REQUIRE(wbits_pair(wbits, &a.wbits_k, &a.wbits_v) == 0, "q cache: wbits must be 4, 6 or 8 (got %d)", wbits);
+    a.k_in = k_in; a.k_out = k_out; a.k_scales = k_scales; a.v_in = v_in; a.v_out = v_out; a.v_scales = v_scales;
+    a.dim = dim;
+    if (page_size)
+    {
+        EXL2_REQUIRE(cache_seqlens && block_table, "q cache: paged mode needs cache_seqlens and block_table");
+        a.cache_seqlens = cache_seqlens; a.block_table = block_table;
+        a.pages_per_seq = pages_per_seq; a.page_size = page_size; a.q_len = width;
+        long long per_page_blocks = ((long long)page_size * dim + QBLOCK - 1) / QBLOCK;
+        if (per_page_blocks > 256) per_page_blocks = 256;
+        dim3 grid((unsigned)pages_per_seq, (unsigned)per_page_blocks, (unsigned)(2 * batch_size));
+        if (DIR == 0) LAUNCH(kv_codec_paged_kernel<0>, grid, dim3(256), 0, stream, a);
+        else          LAUNCH(kv_codec_paged_kernel<1>, grid, dim3(256), 0, stream, a);
+    }
+    else
+    {
+        // ext_cache.cpp:148-155: widen [offset, offset + width) tokens to whole 512-element blocks
+        if (dim % QBLOCK)
+        {
+            while (((long long)offset * dim) % QBLOCK) offset--;
+            while (((long long)width * dim) % QBLOCK) width++;
+        }
+        a.offset = offset * dim; a.stride = seq_stride_tokens * dim;
+        const int blocks = (int)(((long long)width * dim) / QBLOCK);
+        if (blocks <= 0 || batch_size <= 0) return EXL2_OK;
+        dim3 grid((unsigned)blocks, (unsigned)batch_size, v_in ? 2u : 1u);
+        if (DIR == 0) LAUNCH(kv_codec_kernel<0>, grid, dim3(256), 0, stream, a);
+        else          LAUNCH(kv_codec_kernel<1>, grid, dim3(256), 0, stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
+}
+
+extern "C" {
+
+// fp16_to_q_kv (ext_cache.cpp:80-173).  Tensors are [batch | pages, seq | page_size, kv_heads, head_dim]; `dim` =
+// kv_heads * head_dim, `seq_stride_tokens` = size(1).  page_size == 0: contiguous range [offset, offset + width) tokens
+// of every batch row; page_size > 0: `width` = q_len tokens appended at cache_seqlens through block_table.
+int exl2_fp16_to_q_kv(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
+                      int batch_size, int dim, int seq_stride_tokens, int offset, int width, int page_size,
+                      const int* cache_seqlens, const int* block_table, int pages_per_seq, int wbits, void* stream)
+{
+    EXL2_REQUIRE(k_in && k_out && k_scales, "fp16_to_q_kv: null argument");
+    return kv_codec<0>(k_in, k_out, k_scales, v_in, v_out, v_scales, batch_size, dim, seq_stride_tokens, offset, width,
+                       page_size, cache_seqlens, block_table, pages_per_seq, wbits, stream);
+}
+
+// q_to_fp16_kv (ext_cache.cpp:175-269)
+int exl2_q_to_fp16_kv(const void* k_in, void* k_out, const void* k_scales, const void* v_in, void* v_out,
+                      const void* v_scales, int batch_size, int dim, int seq_stride_tokens, int offset, int width,
+                      int page_size, const int* cache_seqlens, const int* block_table, int pages_per_seq, int wbits,
+                      void* stream)
+{
+    EXL2_REQUIRE(k_in && k_out && k_scales, "q_to_fp16_kv: null argument");
+    return kv_codec<1>(k_in, k_out, (void*)k_scales, v_in, v_out, (void*)v_scales, batch_size, dim, seq_stride_tokens,
+                       offset, width, page_size, cache_seqlens, block_table, pages_per_seq, wbits, stream);
+}
+
+}  // extern "C"

@@ -71,12 +71,22 @@ DEV float shfl_xor_f32(float v, int mask) { return as_f32(shfl_xor_u32(f32_bits(
 DEV u32 shfl_idx_u32(u32 v, int src_lane) { return (u32)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
 DEV float shfl_idx_f32(float v, int src_lane) { return as_f32(shfl_idx_u32(f32_bits(v), src_lane)); }
 
+// exchange with lane ^ MASK for MASK < 32 (stays inside each 32-lane half): ds_swizzle bit-mask mode, no LDS memory
+template <int MASK> DEV u32 swz_xor_u32(u32 v) { return (u32)__builtin_amdgcn_ds_swizzle((int)v, (MASK << 10) | 0x1F); }
+
 // all-reduce (sum) over each aligned group of 16 lanes, 4 DPP adds, result in every lane of the group
 DEV float row16_allreduce_add(float v) {
     v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
     v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
     v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
     v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+// all-reduce (sum) over each aligned group of 8 lanes
+DEV float row8_allreduce_add(float v) {
+    v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0xB1, 0xF, 0xF, true));
+    v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x4E, 0xF, 0xF, true));
+    v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x141, 0xF, 0xF, true));
     return v;
 }
 DEV float row16_allreduce_max(float v) {
@@ -106,6 +116,9 @@ DEV float wave_allreduce_max(float v) {
 DEV f32x4 mfma_16x16x32_f16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+
+// fp32 += dot(half2, half2): v_dot2_f32_f16
+DEV float dot2_f32_f16(f16x2 a, f16x2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
 
 // ---- memory --------------------------------------------------------------------------------------------------------
 // streamed-once data (packed weights, KV pages): non-temporal so it does not displace the activation vector / tables

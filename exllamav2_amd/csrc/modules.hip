@@ -1,0 +1,245 @@
+// modules.hip -- fused module forwards (QAttn, QMLP) and HIP-graph helpers, + C ABI.
+//
+// Reference: QAttn (q_attn.cu:84-345, bindings ext_qattn.cpp:24-191), QMLP (q_mlp.cu:17-236, bindings
+// ext_qmlp.cpp:87-118).  The reference runs rms_norm -> q_gemm x3 -> rope as 5 launches (replayed from a CUDA graph) and
+// norm -> gate, up q_gemm -> act_mul -> down q_gemm as 5 more.  Here, for rows <= 16 (decode):
+//   attention part 1 = ONE launch (RMSNorm folded into the activation staging of a fused q|k|v kernel) + RoPE,
+//   MLP              = TWO launches (RMSNorm folded into gate|up; SiLU(gate)*up folded into down's staging, residual
+//                      added in down's epilogue).
+// Whole-token graphs are captured by the host with exl2_graph_* around these calls (all positions are read on the
+// device), instead of the reference's per-module graphs with patched kernel arguments (graph.cu:141-164).
+#include "qmatrix.h"
+#include "errors.h"
+#include <string.h>
+#include <stdlib.h>
+
+int qgemv_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream);
+
+extern "C" {
+int exl2_rms_norm(const void* x, const void* w, void* y, float epsilon, int rows, int dim,
+                  int add_residual, int input_fp32, int output_fp32, void* stream);
+int exl2_rope_qk(void* x_q, void* x_k, const void* sin, const void* cos, int batch_size,
+                 int rows_per_batch_q, int rows_per_batch_k, int head_dim, int num_heads_q, int num_heads_k,
+                 int past_len, const int* past_lens, int neox_style, int sincos_size, void* stream);
+int exl2_act_mul(void* x, const void* y, int rows, int width, int act_gelu,
+                 const void* r_weights, int r_weights_stride, void* stream);
+}
+
+static void fill_job(GemvJob& j, const QMatrix* qm, const f16* a, f16* c, int a_mode, int c_mode)
+{
+    memset(&j, 0, sizeof(j));
+    j.m = qm->dev;
+    j.a = a; j.c = c;
+    j.lda = qm->height; j.ldc = qm->width;
+    j.a_mode = a_mode; j.c_mode = c_mode;
+}
+
+#define LAUNCH_JOBS(jobs, n, M, gptq, stream, what) do { \
+    const int _rc = qgemv_launch(jobs, n, M, gptq, stream); \
+    if (_rc != 0) EXL2_FAIL(EXL2_E_INVALID, "%s: launch configuration rejected (%d)", what, _rc); \
+    HIP_TRY(hipGetLastError()); } while (0)
+
+// ---- QAttn ----------------------------------------------------------------------------------------------------------
+
+struct QAttn
+{
+    const f16* layernorm; const f16* layernorm_bias; bool layernorm_is_rms; bool headnorm_is_rms; float norm_epsilon;
+    QMatrix* q_proj; QMatrix* k_proj; QMatrix* v_proj; QMatrix* o_proj;
+    f16* temp_state; f16* temp_dq;
+    int max_rows, hidden_size, num_heads, num_kv_heads, head_dim, max_seq_len;
+    bool has_residual; int rope_style; int sincos_size;
+    const f16* q_norm; const f16* k_norm; const f16* post_layernorm; const f16* post_layernorm_bias;
+    bool residual_fp32; bool use_graphs;
+};
+
+struct QMLP
+{
+    const f16* layernorm; const f16* layernorm_bias; bool layernorm_is_rms; float norm_epsilon;
+    QMatrix* gate; QMatrix* up; QMatrix* down;
+    f16* temp_state; f16* temp_a; f16* temp_b; f16* temp_dq;
+    int max_rows; bool act_gelu; bool has_residual;
+    const f16* post_layernorm; const f16* post_layernorm_bias; bool residual_fp32; bool use_graphs;
+};
+
+extern "C" {
+
+// make_q_attn (ext_qattn.cpp:24-104); argument order = SURVEY.md A.5
+int exl2_make_q_attn(void** handle, const void* layernorm, const void* layernorm_bias, int layernorm_is_rms,
+                     int headnorm_is_rms, float norm_epsilon, void* q_q_proj, void* q_k_proj, void* q_v_proj,
+                     void* q_o_proj, void* temp_state, void* temp_dq, int max_rows, int hidden_size, int num_heads,
+                     int num_kv_heads, int head_dim, int max_seq_len, int has_residual, int rope_style, int sincos_size,
+                     const void* q_norm, const void* k_norm, const void* post_layernorm,
+                     const void* post_layernorm_bias, int residual_fp32, int use_graphs)
+{
+    EXL2_REQUIRE(handle && q_q_proj && q_k_proj && q_v_proj && q_o_proj, "make_q_attn: null projection handle");
+    EXL2_REQUIRE(!layernorm || layernorm_is_rms, "make_q_attn: only RMSNorm pre-norm is built (LayerNorm archs out of scope)");
+    EXL2_REQUIRE(!q_norm && !k_norm, "make_q_attn: q/k head norms are not built (non-Llama archs out of scope)");
+    EXL2_REQUIRE(!residual_fp32, "make_q_attn: fp32 residual stream is not built");
+    EXL2_REQUIRE(!layernorm || temp_state, "make_q_attn: temp_state required");
+    QAttn* a = (QAttn*)calloc(1, sizeof(QAttn));
+    if (!a) EXL2_FAIL(EXL2_E_OOM, "make_q_attn: host out of memory");
+    a->layernorm = (const f16*)layernorm; a->layernorm_bias = (const f16*)layernorm_bias;
+    a->layernorm_is_rms = layernorm_is_rms; a->headnorm_is_rms = headnorm_is_rms; a->norm_epsilon = norm_epsilon;
+    a->q_proj = (QMatrix*)q_q_proj; a->k_proj = (QMatrix*)q_k_proj; a->v_proj = (QMatrix*)q_v_proj; a->o_proj = (QMatrix*)q_o_proj;
+    a->temp_state = (f16*)temp_state; a->temp_dq = (f16*)temp_dq;
+    a->max_rows = max_rows; a->hidden_size = hidden_size; a->num_heads = num_heads; a->num_kv_heads = num_kv_heads;
+    a->head_dim = head_dim; a->max_seq_len = max_seq_len; a->has_residual = has_residual; a->rope_style = rope_style;
+    a->sincos_size = sincos_size;
+    a->post_layernorm = (const f16*)post_layernorm; a->post_layernorm_bias = (const f16*)post_layernorm_bias;
+    a->residual_fp32 = residual_fp32; a->use_graphs = use_graphs;
+    EXL2_REQUIRE(a->q_proj->height == hidden_size && a->k_proj->height == hidden_size && a->v_proj->height == hidden_size,
+                 "make_q_attn: projection heights do not match hidden_size %d", hidden_size);
+    *handle = a;
+    return EXL2_OK;
+}
+
+int exl2_free_q_attn(void* handle) { free(handle); return EXL2_OK; }
+
+// q_attn_forward_1 (ext_qattn.cpp:115-159 -> q_attn.cu:247-317): q,k,v = proj(rmsnorm(x)); RoPE(q, k) in place.
+// apply_rope = 0 skips the rotation (the caller fuses it with the KV append, exl2_rope_kv_append).
+int exl2_q_attn_forward_1(void* handle, const void* x, int batch_size, int q_len, int past_len, const int* past_lens,
+                          void* temp_q, void* temp_k, void* temp_v, const void* sin, const void* cos, int apply_rope,
+                          void* stream)
+{
+    EXL2_REQUIRE(handle && x && temp_q && temp_k && temp_v, "q_attn_forward_1: null argument");
+    QAttn* a = (QAttn*)handle;
+    const int rows = batch_size * q_len;
+    if (rows <= 0) return EXL2_OK;
+    const bool gptq = a->q_proj->is_gptq;
+    EXL2_REQUIRE(a->k_proj->is_gptq == gptq && a->v_proj->is_gptq == gptq, "q_attn_forward_1: mixed EXL2/GPTQ projections");
+    GemvJob jobs[3];
+    if (rows <= MAX_GEMV_ROWS)
+    {
+        const int mode = a->layernorm ? A_RMSNORM : A_PLAIN;
+        fill_job(jobs[0], a->q_proj, (const f16*)x, (f16*)temp_q, mode, C_STORE);
+        fill_job(jobs[1], a->k_proj, (const f16*)x, (f16*)temp_k, mode, C_STORE);
+        fill_job(jobs[2], a->v_proj, (const f16*)x, (f16*)temp_v, mode, C_STORE);
+        for (int i = 0; i < 3; i++) { jobs[i].norm_w = a->layernorm; jobs[i].norm_eps = a->norm_epsilon; }
+        LAUNCH_JOBS(jobs, 3, rows, gptq, stream, "q_attn_forward_1");
+    }
+    else
+    {
+        const f16* ns = (const f16*)x;
+        if (a->layernorm)
+        {
+            const int rc = exl2_rms_norm(x, a->layernorm, a->temp_state, a->norm_epsilon, rows, a->hidden_size, 0, 0, 0, stream);
+            if (rc) return rc;
+            ns = a->temp_state;
+        }
+        fill_job(jobs[0], a->q_proj, ns, (f16*)temp_q, A_PLAIN, C_STORE);
+        fill_job(jobs[1], a->k_proj, ns, (f16*)temp_k, A_PLAIN, C_STORE);
+        fill_job(jobs[2], a->v_proj, ns, (f16*)temp_v, A_PLAIN, C_STORE);
+        LAUNCH_JOBS(jobs, 3, rows, gptq, stream, "q_attn_forward_1");
+    }
+    if (apply_rope && a->rope_style != 0)
+    {
+        EXL2_REQUIRE(sin && cos, "q_attn_forward_1: sin/cos tables missing");
+        return exl2_rope_qk(temp_q, temp_k, sin, cos, batch_size, q_len * a->num_heads, q_len * a->num_kv_heads,
+                            a->head_dim, a->num_heads, a->num_kv_heads, past_len, past_lens, a->rope_style == 2,
+                            a->sincos_size, stream);
+    }
+    return EXL2_OK;
+}
+
+// q_attn_forward_2 (ext_qattn.cpp:161-191 -> q_attn.cu:319-345): x (+)= attn_output * Wo
+int exl2_q_attn_forward_2(void* handle, void* x, const void* attn_output, int batch_size, int q_len, void* stream)
+{
+    EXL2_REQUIRE(handle && x && attn_output, "q_attn_forward_2: null argument");
+    QAttn* a = (QAttn*)handle;
+    const int rows = batch_size * q_len;
+    if (rows <= 0) return EXL2_OK;
+    GemvJob j;
+    if (!a->post_layernorm)
+    {
+        fill_job(j, a->o_proj, (const f16*)attn_output, (f16*)x, A_PLAIN, a->has_residual ? C_ACCUM : C_STORE);
+        LAUNCH_JOBS(&j, 1, rows, a->o_proj->is_gptq, stream, "q_attn_forward_2");
+        return EXL2_OK;
+    }
+    fill_job(j, a->o_proj, (const f16*)attn_output, a->temp_state, A_PLAIN, C_STORE);
+    LAUNCH_JOBS(&j, 1, rows, a->o_proj->is_gptq, stream, "q_attn_forward_2");
+    return exl2_rms_norm(a->temp_state, a->post_layernorm, x, a->norm_epsilon, rows, a->hidden_size, 1, 0, 0, stream);
+}
+
+// make_q_mlp (ext_qmlp.h; call site mlp.py:204-223)
+int exl2_make_q_mlp(void** handle, const void* layernorm, const void* layernorm_bias, int layernorm_is_rms,
+                    float norm_epsilon, void* q_gate, void* q_up, void* q_down, void* temp_state, void* temp_a,
+                    void* temp_b, void* temp_dq, int max_rows, int act_gelu, int has_residual,
+                    const void* post_layernorm, const void* post_layernorm_bias, int residual_fp32, int use_graphs)
+{
+    EXL2_REQUIRE(handle && q_up && q_down, "make_q_mlp: null projection handle");
+    EXL2_REQUIRE(!layernorm || layernorm_is_rms, "make_q_mlp: only RMSNorm pre-norm is built (LayerNorm archs out of scope)");
+    EXL2_REQUIRE(!residual_fp32, "make_q_mlp: fp32 residual stream is not built");
+    EXL2_REQUIRE(temp_a && (!q_gate || temp_b), "make_q_mlp: temp buffers required");
+    QMLP* m = (QMLP*)calloc(1, sizeof(QMLP));
+    if (!m) EXL2_FAIL(EXL2_E_OOM, "make_q_mlp: host out of memory");
+    m->layernorm = (const f16*)layernorm; m->layernorm_bias = (const f16*)layernorm_bias; m->layernorm_is_rms = layernorm_is_rms;
+    m->norm_epsilon = norm_epsilon; m->gate = (QMatrix*)q_gate; m->up = (QMatrix*)q_up; m->down = (QMatrix*)q_down;
+    m->temp_state = (f16*)temp_state; m->temp_a = (f16*)temp_a; m->temp_b = (f16*)temp_b; m->temp_dq = (f16*)temp_dq;
+    m->max_rows = max_rows; m->act_gelu = act_gelu; m->has_residual = has_residual;
+    m->post_layernorm = (const f16*)post_layernorm; m->post_layernorm_bias = (const f16*)post_layernorm_bias;
+    m->residual_fp32 = residual_fp32; m->use_graphs = use_graphs;
+    *handle = m;
+    return EXL2_OK;
+}
+
+int exl2_free_q_mlp(void* handle) { free(handle); return EXL2_OK; }
+
+// q_mlp_forward_ (ext_qmlp.cpp:87-118 -> q_mlp.cu:153-236): x (+)= act(n Wg) * (n Wu) Wd, n = rmsnorm(x); in place on x
+int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream)
+{
+    EXL2_REQUIRE(handle && x, "q_mlp_forward_: null argument");
+    QMLP* m = (QMLP*)handle;
+    if (rows <= 0) return EXL2_OK;
+    const int hidden = m->up->height;
+    const bool gptq = m->up->is_gptq;
+    const bool skinny = rows <= MAX_GEMV_ROWS;
+    f16* down_dst = m->post_layernorm ? m->temp_state : (f16*)x;
+    const int down_mode = (m->post_layernorm || !m->has_residual) ? C_STORE : C_ACCUM;
+    GemvJob jobs[2];
+
+    const f16* ns = (const f16*)x;
+    int in_mode = A_PLAIN;
+    if (m->layernorm)
+    {
+        if (skinny) in_mode = A_RMSNORM;
+        else
+        {
+            const int rc = exl2_rms_norm(x, m->layernorm, m->temp_state, m->norm_epsilon, rows, hidden, 0, 0, 0, stream);
+            if (rc) return rc;
+            ns = m->temp_state;
+        }
+    }
+    int n = 0;
+    if (m->gate) { fill_job(jobs[n], m->gate, ns, m->temp_a, in_mode, C_STORE); n++; fill_job(jobs[n], m->up, ns, m->temp_b, in_mode, C_STORE); n++; }
+    else         { fill_job(jobs[n], m->up, ns, m->temp_a, in_mode, C_STORE); n++; }
+    for (int i = 0; i < n; i++) { jobs[i].norm_w = m->layernorm; jobs[i].norm_eps = m->norm_epsilon; }
+    LAUNCH_JOBS(jobs, n, rows, gptq, stream, "q_mlp_forward_");
+
+    GemvJob d;
+    if (skinny)
+    {
+        // activation folded into the staging of down's input (no intermediate round trip, one launch less)
+        const int amode = m->gate ? (m->act_gelu ? A_GELU_MUL : A_SILU_MUL) : (m->act_gelu ? A_GELU : A_SILU);
+        fill_job(d, m->down, m->temp_a, down_dst, amode, down_mode);
+        d.a2 = m->temp_b;
+    }
+    else
+    {
+        if (m->gate)
+        {
+            const int rc = exl2_act_mul(m->temp_a, m->temp_b, rows, m->up->width, m->act_gelu, nullptr, 0, stream);
+            if (rc) return rc;
+            fill_job(d, m->down, m->temp_a, down_dst, A_PLAIN, down_mode);
+        }
+        else
+        {
+            fill_job(d, m->down, m->temp_a, down_dst, m->act_gelu ? A_GELU : A_SILU, down_mode);
+        }
+    }
+    LAUNCH_JOBS(&d, 1, rows, m->down->is_gptq, stream, "q_mlp_forward_");
+    if (m->post_layernorm)
+        return exl2_rms_norm(m->temp_state, m->post_layernorm, x, m->norm_epsilon, rows, hidden, 1, 0, 0, stream);
+    return EXL2_OK;
+}
+
+}  // extern "C"

@@ -107,15 +107,17 @@ DEV int desc_rows(const QDesc* d)
     return d->in_tail ? (int)d->nvalid_last * 32 : (int)d->n_super * SUPER_ROWS;
 }
 
-DEV f16 silu_mul_h(f16 g, f16 u)
+DEV f16 clamp_h(f16 r)
 {
-    // mlp.py:486-494: F.silu(gate) (fp32 math, rounded to fp16) * up in fp16, clamped
-    const float gf = (float)g;
-    const f16 y = (f16)(gf / (1.0f + fast_exp(-gf)));
-    f16 r = y * u;
     r = r > (f16)65504.0f ? (f16)65504.0f : r;
-    r = r < (f16)-65504.0f ? (f16)-65504.0f : r;
-    return r;
+    return r < (f16)-65504.0f ? (f16)-65504.0f : r;
+}
+DEV f16 act_h(f16 g, bool gelu)
+{
+    // mlp.py:486-494 / q_mlp_activation.cuh: act in fp32, rounded to fp16
+    const float x = (float)g;
+    if (gelu) return (f16)(0.5f * x * (1.0f + tanhf(0.797884560803f * (x + 0.044715f * x * x * x))));
+    return (f16)(x / (1.0f + fast_exp(-x)));
 }
 
 template <bool GPTQ>
@@ -248,9 +250,13 @@ KERNEL void __launch_bounds__(1024) qgemv_kernel(const GemvArgs args)
                     float f = fmaxf(-65504.0f, fminf((float)x, 65504.0f));
                     x = (f16)((f * (float)job.norm_w[src[e]]) * rmf_lds[r]);
                 }
-                else if (job.a_mode == A_SILU_MUL)
+                else if (job.a_mode == A_SILU_MUL || job.a_mode == A_GELU_MUL)
                 {
-                    x = silu_mul_h(x, a2[off]);
+                    x = clamp_h(act_h(x, job.a_mode == A_GELU_MUL) * a2[off]);
+                }
+                else if (job.a_mode == A_SILU || job.a_mode == A_GELU)
+                {
+                    x = act_h(x, job.a_mode == A_GELU);
                 }
                 v[e] = x;
             }

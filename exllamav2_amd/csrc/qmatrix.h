@@ -41,7 +41,7 @@ struct QMatrix
 };
 
 // prologue transforms of the activation vector while it is staged into LDS
-enum { A_PLAIN = 0, A_RMSNORM = 1, A_SILU_MUL = 2 };
+enum { A_PLAIN = 0, A_RMSNORM = 1, A_SILU_MUL = 2, A_GELU_MUL = 3, A_SILU = 4, A_GELU = 5 };
 // epilogue
 enum { C_STORE = 0, C_ACCUM = 1 };
 

@@ -139,6 +139,197 @@ class ExtC:
         n = self.lib.check(self.lib.exl2_make_group_map(qg.data_ptr(), groups, int(num_qrows), out.data_ptr(), cap))
         return out[:n].clone()
 
+    # ---- norms / rope / activation (ext_norm.cpp, ext_rope.cpp) --------------------------------------------------------
+
+    def rms_norm(self, x, w, y, epsilon: float) -> None:
+        """ext_norm.cpp:22-56: y = rmsnorm(x) * w; x, y fp16 or fp32 [rows, dim]."""
+        if w.dtype != torch.float16: raise RuntimeError("rms_norm: w must be half")
+        if x.shape[-1] != w.shape[0] or x.shape != y.shape: raise RuntimeError("rms_norm: incompatible shapes")
+        dim = x.shape[-1]
+        rows = x.numel() // dim
+        self.lib.check(self.lib.exl2_rms_norm(self._ptr(x, None, "x"), self._ptr(w, torch.float16, "w"),
+                                              self._ptr(y, None, "y"), float(epsilon), rows, dim, 0,
+                                              int(x.dtype == torch.float32), int(y.dtype == torch.float32),
+                                              self._stream(x)))
+
+    def rms_norm_(self, x, w, epsilon: float) -> None:
+        """ext_norm.cpp:58-85 (in place)."""
+        self.rms_norm(x, w, x, epsilon)
+
+    def rope_(self, x, sin, cos, past_len: int, num_heads: int, head_dim: int, offsets, neox_style: bool) -> None:
+        """ext_rope.cpp:21-62: in-place rotary embedding on x [batch, ..., head_dim]."""
+        for t, n in ((x, "x"), (sin, "sin"), (cos, "cos")):
+            if t.dtype != torch.float16: raise RuntimeError(f"rope_: {n} must be half")
+        if cos.shape[-1] != sin.shape[-1]: raise RuntimeError("sin table does not cos table")
+        if not _is_none(offsets) and offsets.dtype != torch.int32: raise RuntimeError("rope_: offsets must be int32")
+        batch = x.shape[0]
+        rows_per_batch = x.numel() // head_dim // batch
+        self.lib.check(self.lib.exl2_rope_qk(self._ptr(x, torch.float16, "x"), None, self._ptr(sin), self._ptr(cos),
+                                             batch, rows_per_batch, 0, head_dim, num_heads, 0, int(past_len),
+                                             self._ptr(offsets), int(bool(neox_style)), cos.shape[-1], self._stream(x)))
+
+    def act_mul_(self, x, y, act_gelu: bool = False) -> None:
+        """x = act(x) * y in place (act_mul_kernel, q_mlp_activation.cuh:54-112)."""
+        width = x.shape[-1]
+        self.lib.check(self.lib.exl2_act_mul(self._ptr(x, torch.float16, "x"), self._ptr(y, torch.float16, "y"),
+                                             x.numel() // width, width, int(act_gelu), None, 0, self._stream(x)))
+
+    # ---- quantized KV cache (ext_cache.cpp:80-269) ---------------------------------------------------------------------
+
+    def _kv_codec(self, fn, k_in, k_out, k_scales, v_in, v_out, v_scales, batch_size, offset, width, page_size,
+                  cache_seqlens, block_table, wbits, half_side):
+        dim = half_side.shape[2] * half_side.shape[3]
+        stride_tokens = half_side.shape[1]
+        pages_per_seq = 0
+        if page_size:
+            batch_size = block_table.shape[0]
+            pages_per_seq = block_table.shape[1]
+            if cache_seqlens.shape[0] != batch_size: raise RuntimeError("q cache: cache_seqlens / block_table mismatch")
+        self.lib.check(fn(self._ptr(k_in), self._ptr(k_out), self._ptr(k_scales), self._ptr(v_in), self._ptr(v_out),
+                          self._ptr(v_scales), int(batch_size), dim, stride_tokens, int(offset), int(width),
+                          int(page_size), self._ptr(cache_seqlens), self._ptr(block_table), pages_per_seq, int(wbits),
+                          self._stream(k_in)))
+
+    def fp16_to_q_kv(self, k_in, k_out, k_scales, v_in, v_out, v_scales, batch_size, offset, width, page_size,
+                     cache_seqlens, block_table, wbits) -> None:
+        if k_in.dtype != torch.float16 or k_out.dtype != torch.uint8: raise RuntimeError("fp16_to_q_kv: bad dtypes")
+        self._kv_codec(self.lib.exl2_fp16_to_q_kv, k_in, k_out, k_scales, v_in, v_out, v_scales, batch_size, offset,
+                       width, page_size, cache_seqlens, block_table, wbits, k_in)
+
+    def q_to_fp16_kv(self, k_in, k_out, k_scales, v_in, v_out, v_scales, batch_size, offset, width, page_size,
+                     cache_seqlens, block_table, wbits) -> None:
+        if k_in.dtype != torch.uint8 or k_out.dtype != torch.float16: raise RuntimeError("q_to_fp16_kv: bad dtypes")
+        self._kv_codec(self.lib.exl2_q_to_fp16_kv, k_in, k_out, k_scales, v_in, v_out, v_scales, batch_size, offset,
+                       width, page_size, cache_seqlens, block_table, wbits, k_out)
+
+    # ---- attention (replaces flash_attn_with_kvcache / _attn_torch; SURVEY.md A.7) -------------------------------------
+
+    def paged_attn_scratch_bytes(self, rows: int, head_dim: int, nsplit: int) -> int:
+        return int(self.lib.exl2_paged_attn_scratch_bytes(rows, head_dim, nsplit))
+
+    def paged_attn(self, q, k_cache, v_cache, out, cache_seqlens, block_table, len_const: int = 0, len_offset: int = 0,
+                   softmax_scale: float | None = None, causal: bool = True, nsplit: int = 0, scratch=None) -> None:
+        """q [b, s, H, hd]; caches [pages, page_size, KVH, hd] (block_table [b, pages]) or [b, T, KVH, hd] (no table)."""
+        b, s, nh, hd = q.shape
+        kvh = k_cache.shape[2]
+        page_size = k_cache.shape[1]
+        pps = 0 if _is_none(block_table) else block_table.shape[1]
+        scale = hd ** -0.5 if softmax_scale is None else softmax_scale
+        sb = 0 if scratch is None else scratch.numel() * scratch.element_size()
+        self.lib.check(self.lib.exl2_paged_attn(
+            self._ptr(q, torch.float16, "q"), self._ptr(k_cache, torch.float16, "k_cache"),
+            self._ptr(v_cache, torch.float16, "v_cache"), self._ptr(out, torch.float16, "out"),
+            self._ptr(cache_seqlens, torch.int32, "cache_seqlens"), self._ptr(block_table, torch.int32, "block_table"),
+            b, s, nh, kvh, hd, page_size, pps, int(len_const), int(len_offset), float(scale), int(causal), int(nsplit),
+            self._ptr(scratch), sb, self._stream(q)))
+
+    def rope_kv_append(self, q, k_new, v_new, k_cache, v_cache, sin, cos, past_len: int, past_lens, block_table,
+                       rope_style: int, sincos_size: int = 0) -> None:
+        b, s, nh, hd = q.shape
+        kvh = k_new.shape[2]
+        page_size = 0 if _is_none(k_cache) else k_cache.shape[1]
+        pps = 0 if _is_none(block_table) else block_table.shape[1]
+        self.lib.check(self.lib.exl2_rope_kv_append(
+            self._ptr(q, torch.float16, "q"), self._ptr(k_new, torch.float16, "k_new"), self._ptr(v_new),
+            self._ptr(k_cache), self._ptr(v_cache), self._ptr(sin), self._ptr(cos), b, s, nh, kvh, hd, int(past_len),
+            self._ptr(past_lens), self._ptr(block_table), page_size, pps, int(rope_style), int(sincos_size),
+            self._stream(q)))
+
+    def flash_attn_with_kvcache(self, q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, block_table=None,
+                                causal: bool = True, softmax_scale: float | None = None, scratch=None):
+        """Drop-in for flash_attn.flash_attn_with_kvcache as the reference calls it (attn.py:602-613)."""
+        out = torch.empty_like(q)
+        s = q.shape[1]
+        if k is not None:
+            self.rope_kv_append(q, k, v, k_cache, v_cache, none_tensor, none_tensor, 0, cache_seqlens, block_table, 0)
+            self.paged_attn(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, s, softmax_scale, causal, 0, scratch)
+        else:
+            self.paged_attn(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, 0, softmax_scale, causal, 0, scratch)
+        return out
+
+    # ---- fused modules (ext_qattn.cpp, ext_qmlp.cpp) -------------------------------------------------------------------
+
+    def make_q_attn(self, layernorm, layernorm_bias, layernorm_is_rms, headnorm_is_rms, norm_epsilon, q_q_proj,
+                    q_k_proj, q_v_proj, q_o_proj, temp_state, temp_dq, max_rows, hidden_size, num_heads, num_kv_heads,
+                    head_dim, max_seq_len, has_residual, rope_style, sincos_size, q_norm, k_norm, post_layernorm,
+                    post_layernorm_bias, residual_fp32, use_graphs) -> int:
+        h = C.c_void_p()
+        self.lib.check(self.lib.exl2_make_q_attn(
+            C.byref(h), self._ptr(layernorm), self._ptr(layernorm_bias), int(layernorm_is_rms), int(headnorm_is_rms),
+            float(norm_epsilon), q_q_proj, q_k_proj, q_v_proj, q_o_proj, self._ptr(temp_state), self._ptr(temp_dq),
+            int(max_rows), int(hidden_size), int(num_heads), int(num_kv_heads), int(head_dim), int(max_seq_len),
+            int(has_residual), int(rope_style), int(sincos_size), self._ptr(q_norm), self._ptr(k_norm),
+            self._ptr(post_layernorm), self._ptr(post_layernorm_bias), int(residual_fp32), int(use_graphs)))
+        return int(h.value)
+
+    def free_q_attn(self, handle: int) -> None:
+        self.lib.check(self.lib.exl2_free_q_attn(handle))
+
+    def q_attn_forward_1(self, q_attn, x, batch_size, q_len, past_len, past_lens, q_temp, k_temp, v_temp, sin, cos,
+                         loras=None, loras_temp=None, apply_rope: bool = True) -> None:
+        if loras: raise RuntimeError("q_attn_forward_1: LoRA is out of scope of this build")
+        self.lib.check(self.lib.exl2_q_attn_forward_1(
+            q_attn, self._ptr(x, torch.float16, "x"), int(batch_size), int(q_len), int(past_len),
+            self._ptr(past_lens, torch.int32, "past_lens"), self._ptr(q_temp, torch.float16, "q_temp"),
+            self._ptr(k_temp, torch.float16, "k_temp"), self._ptr(v_temp, torch.float16, "v_temp"),
+            self._ptr(sin), self._ptr(cos), int(apply_rope), self._stream(x)))
+
+    def q_attn_forward_2(self, q_attn, x, attn_output, batch_size, q_len, loras=None, loras_temp=None) -> None:
+        if loras: raise RuntimeError("q_attn_forward_2: LoRA is out of scope of this build")
+        self.lib.check(self.lib.exl2_q_attn_forward_2(q_attn, self._ptr(x, torch.float16, "x"),
+                                                      self._ptr(attn_output, torch.float16, "attn_output"),
+                                                      int(batch_size), int(q_len), self._stream(x)))
+
+    def make_q_mlp(self, layernorm, layernorm_bias, layernorm_is_rms, norm_epsilon, q_gate, q_up, q_down, temp_state,
+                   temp_a, temp_b, temp_dq, max_rows, act_gelu, has_residual, post_layernorm, post_layernorm_bias,
+                   residual_fp32, use_graphs) -> int:
+        h = C.c_void_p()
+        self.lib.check(self.lib.exl2_make_q_mlp(
+            C.byref(h), self._ptr(layernorm), self._ptr(layernorm_bias), int(layernorm_is_rms), float(norm_epsilon),
+            q_gate or None, q_up, q_down, self._ptr(temp_state), self._ptr(temp_a), self._ptr(temp_b),
+            self._ptr(temp_dq), int(max_rows), int(act_gelu), int(has_residual), self._ptr(post_layernorm),
+            self._ptr(post_layernorm_bias), int(residual_fp32), int(use_graphs)))
+        return int(h.value)
+
+    def free_q_mlp(self, handle: int) -> None:
+        self.lib.check(self.lib.exl2_free_q_mlp(handle))
+
+    def q_mlp_forward_(self, q_mlp, x, loras=None, loras_temp=None) -> None:
+        if loras: raise RuntimeError("q_mlp_forward_: LoRA is out of scope of this build")
+        hidden = x.shape[-1]
+        self.lib.check(self.lib.exl2_q_mlp_forward(q_mlp, self._ptr(x, torch.float16, "x"), x.numel() // hidden,
+                                                   self._stream(x)))
+
+    # ---- decode-loop utilities + graphs (ours; no reference counterpart at the ext_c level) ----------------------------
+
+    def embed_rows(self, table, ids, out) -> None:
+        self.lib.check(self.lib.exl2_embed_rows(self._ptr(table, torch.float16, "table"),
+                                                self._ptr(ids, torch.int32, "ids"), self._ptr(out, torch.float16, "out"),
+                                                ids.numel(), table.shape[1], table.shape[0], self._stream(out)))
+
+    def argmax_rows(self, logits, out_ids, vocab: int | None = None) -> None:
+        ld = logits.shape[-1]
+        self.lib.check(self.lib.exl2_argmax_rows(self._ptr(logits, torch.float16, "logits"),
+                                                 self._ptr(out_ids, torch.int32, "out_ids"), logits.numel() // ld,
+                                                 int(vocab or ld), ld, self._stream(logits)))
+
+    def add_i32_(self, t, value: int) -> None:
+        self.lib.check(self.lib.exl2_add_i32(self._ptr(t, torch.int32, "t"), t.numel(), int(value), self._stream(t)))
+
+    def graph_begin_capture(self, stream: int | None) -> None:
+        self.lib.check(self.lib.exl2_graph_begin_capture(stream))
+
+    def graph_end_capture(self, stream: int | None) -> int:
+        h = C.c_void_p()
+        self.lib.check(self.lib.exl2_graph_end_capture(stream, C.byref(h)))
+        return int(h.value)
+
+    def graph_launch(self, graph: int, stream: int | None) -> None:
+        self.lib.check(self.lib.exl2_graph_launch(graph, stream))
+
+    def graph_free(self, graph: int) -> None:
+        self.lib.check(self.lib.exl2_graph_free(graph))
+
     # ---- python-level adapter (exllamav2/ext.py:325-410) --------------------------------------------------------------
 
     def make_q_matrix_from_dict(self, w: dict, temp_dq, key: str | None = None, prescale: float = 1,

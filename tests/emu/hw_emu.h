@@ -144,6 +144,8 @@ DEV float shfl_xor_f32(float v, int mask) { return emu_wave_read(v, lane_id() ^ 
 DEV u32 shfl_idx_u32(u32 v, int src) { return emu_wave_read(v, src); }
 DEV float shfl_idx_f32(float v, int src) { return emu_wave_read(v, src); }
 
+template <int MASK> DEV u32 swz_xor_u32(u32 v) { return emu_wave_read(v, lane_id() ^ MASK); }
+
 DEV int emu_half_mirror(int l) { return (l & ~7) | (7 - (l & 7)); }
 DEV int emu_row_mirror(int l)  { return (l & ~15) | (15 - (l & 15)); }
 DEV float row16_allreduce_add(float v)
@@ -153,6 +155,14 @@ DEV float row16_allreduce_add(float v)
     v += emu_wave_read(v, l ^ 2);
     v += emu_wave_read(v, emu_half_mirror(l));
     v += emu_wave_read(v, emu_row_mirror(l));
+    return v;
+}
+DEV float row8_allreduce_add(float v)
+{
+    const int l = lane_id();
+    v += emu_wave_read(v, l ^ 1);
+    v += emu_wave_read(v, l ^ 2);
+    v += emu_wave_read(v, emu_half_mirror(l));
     return v;
 }
 DEV float row16_allreduce_max(float v)
@@ -197,6 +207,8 @@ DEV f32x4 mfma_16x16x32_f16(f16x8 a, f16x8 b, f32x4 c)
     return d;
 }
 
+DEV float dot2_f32_f16(f16x2 a, f16x2 b, float c) { return c + (float)a.x * (float)b.x + (float)a.y * (float)b.y; }
+
 // ---- memory ----------------------------------------------------------------------------------------------------------
 template <typename T> DEV T ld_nt(const T* p) { return *p; }
 template <typename T> DEV void st_nt(T* p, T v) { *p = v; }
@@ -234,5 +246,16 @@ DEV hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 DEV const char* hipGetErrorString(hipError_t) { return "emu"; }
 DEV hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 4; return hipSuccess; }
 DEV hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+
+// graphs cannot be emulated: capture is refused, callers fall back to eager launches in the emu tests
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+enum { hipStreamCaptureModeRelaxed = 2 };
+DEV hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorInvalidValue; }
+DEV hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return hipErrorInvalidValue; }
+DEV hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorInvalidValue; }
+DEV hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+DEV hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorInvalidValue; }
+DEV hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 
 #endif  // EXL2_HW_H

@@ -1,0 +1,236 @@
+"""RMSNorm, RoPE, act*mul, Q-cache codec, attention, RoPE+append, decode utilities -- against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import modules as OM
+
+F16 = np.float16
+
+
+def _ulp_close(got, want, ulps=1):
+    """fp16 outputs equal up to `ulps` units in the last place (fp32 reduction order may move the pre-rounding value)."""
+    g = got.astype(np.float32)
+    w = want.astype(np.float32)
+    tol = np.maximum(np.abs(w) * 2.0 ** -10, 2.0 ** -24) * ulps
+    return np.all(np.abs(g - w) <= tol)
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 256), (3, 4096), (5, 5120)])
+def test_rms_norm(be, rows, dim):
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((rows, dim)) * 3).astype(F16)
+    w = (1 + 0.1 * rng.standard_normal(dim)).astype(F16)
+    y = torch.zeros((rows, dim), dtype=torch.float16, device=be.device)
+    be.ext.rms_norm(be.t(x), be.t(w), y, 1e-5)
+    assert _ulp_close(be.n(y), OM.rms_norm(x, w, 1e-5))
+    xt = be.t(x)
+    be.ext.rms_norm_(xt, be.t(w), 1e-5)
+    assert np.array_equal(be.n(xt), be.n(y))
+
+
+@pytest.mark.parametrize("neox", [True, False])
+@pytest.mark.parametrize("hd,heads", [(128, 4), (64, 2)])
+def test_rope(be, neox, hd, heads):
+    rng = np.random.default_rng(1)
+    b, s = 2, 3
+    x = rng.standard_normal((b, s, heads, hd)).astype(F16)
+    sin, cos = OM.rope_tables(64, hd, neox=neox)
+    offsets = np.array([5, 17], dtype=np.int32)
+    want = OM.rope_(x, sin, cos, offsets + 4, neox=neox)
+    xt = be.t(x)
+    be.ext.rope_(xt, be.t(sin), be.t(cos), 4, heads, hd, be.t(offsets), neox)
+    assert np.array_equal(be.n(xt).view(np.uint16), want.view(np.uint16))
+    # scalar past_len only, meta sentinel for offsets (attn.py:1113-1115)
+    from exllamav2_amd.ext import none_tensor
+    xt = be.t(x)
+    be.ext.rope_(xt, be.t(sin), be.t(cos), 9, heads, hd, none_tensor, neox)
+    want = OM.rope_(x, sin, cos, np.array([9, 9]), neox=neox)
+    assert np.array_equal(be.n(xt).view(np.uint16), want.view(np.uint16))
+
+
+def test_act_mul(be):
+    rng = np.random.default_rng(2)
+    g = (rng.standard_normal((3, 512)) * 2).astype(F16)
+    u = rng.standard_normal((3, 512)).astype(F16)
+    gt = be.t(g)
+    be.ext.act_mul_(gt, be.t(u))
+    assert _ulp_close(be.n(gt), OM.silu_mul(g, u), ulps=2)
+
+
+# ---- Q cache -----------------------------------------------------------------------------------------------------------
+
+def _q4_ref_tensor(x):
+    """x fp16 [b, T, KVH, hd] flattened per batch row -> packed uint8 [b, T, KVH, hd/2], scales [b, T, KVH, hd/32]."""
+    b = x.shape[0]
+    pk, sc = [], []
+    for i in range(b):
+        p, s = OM.q4_pack(x[i].reshape(-1))
+        pk.append(p); sc.append(s)
+    return np.stack(pk).reshape(*x.shape[:3], x.shape[3] // 2), np.stack(sc).reshape(*x.shape[:3], x.shape[3] // 32)
+
+
+def test_q4_cache_contiguous_roundtrip(be):
+    rng = np.random.default_rng(3)
+    b, T, kvh, hd = 2, 16, 2, 128
+    k = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    v = (rng.standard_normal((b, T, kvh, hd)) * 0.5).astype(F16)
+    kq = torch.zeros((b, T, kvh, hd // 2), dtype=torch.uint8, device=be.device)
+    vq = torch.zeros_like(kq)
+    ks = torch.zeros((b, T, kvh, hd // 32), dtype=torch.float16, device=be.device)
+    vs = torch.zeros_like(ks)
+    from exllamav2_amd.ext import none_tensor
+    # pack tokens [4, 12) of every row (dim = 256 -> 2 tokens per 512-block, aligned)
+    be.ext.fp16_to_q_kv(be.t(k), kq, ks, be.t(v), vq, vs, b, 4, 8, 0, none_tensor, none_tensor, 4)
+    kp, ksr = _q4_ref_tensor(k)
+    vp, vsr = _q4_ref_tensor(v)
+    got_k = be.n(kq); got_ks = be.n(ks)
+    codes_same = (got_k[:, 4:12] == kp[:, 4:12]).mean()
+    assert codes_same >= 0.999, codes_same                      # fp16 division may differ in the last place on rare ties
+    assert np.array_equal(got_ks[:, 4:12].view(np.uint16), ksr[:, 4:12].view(np.uint16))
+    assert np.all(got_k[:, :4] == 0) and np.all(got_k[:, 12:] == 0)
+    assert (be.n(vq)[:, 4:12] == vp[:, 4:12]).mean() >= 0.999
+    # unpack what the device packed and compare with the oracle's unpack of the same bytes (bit exact)
+    ko = torch.zeros((b, T, kvh, hd), dtype=torch.float16, device=be.device)
+    vo = torch.zeros_like(ko)
+    be.ext.q_to_fp16_kv(kq, ko, ks, vq, vo, vs, b, 4, 8, 0, none_tensor, none_tensor, 4)
+    for i in range(b):
+        want = OM.q4_unpack(got_k[i, 4:12].reshape(-1), got_ks[i, 4:12].reshape(-1)).reshape(8, kvh, hd)
+        assert np.array_equal(be.n(ko)[i, 4:12].view(np.uint16), want.view(np.uint16))
+    # 4-bit round trip error: |x - dq(q(x))| bounded by the quantization step (size-independent property)
+    err = np.abs(be.n(ko)[:, 4:12].astype(np.float32) - k[:, 4:12].astype(np.float32))
+    assert err.max() < 0.6 and err.mean() < 0.12
+
+
+def test_q4_cache_paged(be):
+    rng = np.random.default_rng(4)
+    pages, ps, kvh, hd = 6, 256, 1, 128
+    b, q_len = 2, 3
+    seqlens = np.array([254, 600], dtype=np.int32)           # first sequence crosses a page boundary
+    table = np.array([[3, 1, 0], [2, 4, 5]], dtype=np.int32)
+    k = rng.standard_normal((pages, ps, kvh, hd)).astype(F16)
+    v = rng.standard_normal((pages, ps, kvh, hd)).astype(F16)
+    kq = torch.zeros((pages, ps, kvh, hd // 2), dtype=torch.uint8, device=be.device)
+    vq = torch.zeros_like(kq)
+    ks = torch.zeros((pages, ps, kvh, hd // 32), dtype=torch.float16, device=be.device)
+    vs = torch.zeros_like(ks)
+    be.ext.fp16_to_q_kv(be.t(k), kq, ks, be.t(v), vq, vs, b, 0, q_len, ps, be.t(seqlens), be.t(table), 4)
+    got = be.n(kq)
+    touched = np.zeros((pages, ps), dtype=bool)
+    for i in range(b):
+        for pos in range(seqlens[i], seqlens[i] + q_len):
+            touched[table[i, pos // ps], pos % ps] = True
+    # dim = 128 -> 4 tokens per 512-element block: the kernel widens to whole blocks (cache.cu:169-176)
+    widened = touched.reshape(pages, ps // 4, 4).any(axis=-1).repeat(4, axis=-1)
+    nz = (got.reshape(pages, ps, -1) != 0).any(axis=-1)
+    assert np.all(nz[touched]) and not np.any(nz[~widened])
+    kp, _ = OM.q4_pack(k.reshape(-1))
+    kp = kp.reshape(pages, ps, -1)
+    assert (got.reshape(pages, ps, -1)[widened] == kp[widened]).mean() >= 0.999
+    # paged unpack: everything valid in each page
+    ko = torch.zeros((pages, ps, kvh, hd), dtype=torch.float16, device=be.device)
+    vo = torch.zeros_like(ko)
+    kq_full = be.t(kp.reshape(pages, ps, kvh, hd // 2))
+    _, ksc = OM.q4_pack(k.reshape(-1))
+    ks_full = be.t(ksc.reshape(pages, ps, kvh, hd // 32))
+    new_len = (seqlens + q_len).astype(np.int32)
+    be.ext.q_to_fp16_kv(kq_full, ko, ks_full, kq_full, vo, ks_full, b, 0, 0, ps, be.t(new_len), be.t(table), 4)
+    want_all = OM.q4_unpack(kp.reshape(-1), ksc).reshape(pages, ps, kvh, hd)
+    got_o = be.n(ko)
+    for i in range(b):
+        for pos in range(0, new_len[i]):
+            pg = table[i, pos // ps]
+            assert np.array_equal(got_o[pg, pos % ps].view(np.uint16), want_all[pg, pos % ps].view(np.uint16))
+
+
+# ---- attention ---------------------------------------------------------------------------------------------------------
+
+def _attn_tol(want):
+    return np.abs(want.astype(np.float32)) * 2.0 ** -9 + 2e-3
+
+
+@pytest.mark.parametrize("hd,nh,kvh,s", [(128, 4, 4, 1), (128, 8, 2, 1), (64, 4, 1, 2), (128, 2, 1, 5)])
+def test_attention_contiguous(be, hd, nh, kvh, s):
+    rng = np.random.default_rng(5)
+    b, T, past = 2, 96, 70
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    k = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    v = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    total = past + s
+    want = OM.attention(q, k[:, :total], v[:, :total])
+    for nsplit in (1, 3):
+        out = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+        scratch = torch.zeros((be.ext.paged_attn_scratch_bytes(b * s * nh, hd, nsplit) // 4 + 1,), dtype=torch.float32,
+                              device=be.device)
+        be.ext.paged_attn(be.t(q), be.t(k), be.t(v), out, None, None, len_const=past, len_offset=s, nsplit=nsplit,
+                          scratch=scratch)
+        got = be.n(out)
+        assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want)), nsplit
+
+
+def test_attention_paged_with_append(be):
+    """flash_attn_with_kvcache contract (attn.py:602-613): append new k/v at cache_seqlens through the block table,
+    attend bottom-right causal."""
+    rng = np.random.default_rng(6)
+    pages, ps, kvh, hd, nh = 5, 256, 2, 128, 4
+    b, s = 2, 2
+    seqlens = np.array([255, 300], dtype=np.int32)
+    table = np.array([[2, 0, 4], [1, 3, 4]], dtype=np.int32)
+    kc = rng.standard_normal((pages, ps, kvh, hd)).astype(F16)
+    vc = rng.standard_normal((pages, ps, kvh, hd)).astype(F16)
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    kn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    vn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    kc_ref, vc_ref = kc.copy(), vc.copy()
+    want = OM.paged_attention(q, kn, vn, kc_ref, vc_ref, seqlens, table)
+    kct, vct = be.t(kc), be.t(vc)
+    out = be.ext.flash_attn_with_kvcache(be.t(q), kct, vct, be.t(kn), be.t(vn), be.t(seqlens), be.t(table))
+    assert np.array_equal(be.n(kct).view(np.uint16), kc_ref.view(np.uint16))        # appended in place
+    assert np.array_equal(be.n(vct).view(np.uint16), vc_ref.view(np.uint16))
+    got = be.n(out)
+    assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want))
+
+
+@pytest.mark.parametrize("neox", [True, False])
+def test_rope_kv_append(be, neox):
+    rng = np.random.default_rng(7)
+    pages, ps, kvh, hd, nh = 3, 256, 2, 128, 4
+    b, s = 2, 2
+    past = np.array([10, 255], dtype=np.int32)
+    table = np.array([[2, 0], [1, 0]], dtype=np.int32)
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    kn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    vn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    sin, cos = OM.rope_tables(512, hd, neox=neox)
+    kc = torch.zeros((pages, ps, kvh, hd), dtype=torch.float16, device=be.device)
+    vc = torch.zeros_like(kc)
+    qt, kt = be.t(q), be.t(kn)
+    be.ext.rope_kv_append(qt, kt, be.t(vn), kc, vc, be.t(sin), be.t(cos), 0, be.t(past), be.t(table), 2 if neox else 1)
+    q_want = OM.rope_(q, sin, cos, past, neox=neox)
+    k_want = OM.rope_(kn, sin, cos, past, neox=neox)
+    assert np.array_equal(be.n(qt).view(np.uint16), q_want.view(np.uint16))
+    assert np.array_equal(be.n(kt).view(np.uint16), k_want.view(np.uint16))
+    kcn, vcn = be.n(kc), be.n(vc)
+    for i in range(b):
+        for j in range(s):
+            pos = past[i] + j
+            pg = table[i, pos // ps]
+            assert np.array_equal(kcn[pg, pos % ps].view(np.uint16), k_want[i, j].view(np.uint16))
+            assert np.array_equal(vcn[pg, pos % ps].view(np.uint16), vn[i, j].view(np.uint16))
+
+
+def test_decode_utilities(be):
+    rng = np.random.default_rng(8)
+    table = rng.standard_normal((50, 64)).astype(F16)
+    ids = np.array([3, 49, 0], dtype=np.int32)
+    out = torch.zeros((3, 64), dtype=torch.float16, device=be.device)
+    be.ext.embed_rows(be.t(table), be.t(ids), out)
+    assert np.array_equal(be.n(out), table[ids])
+    logits = rng.standard_normal((3, 1000)).astype(F16)
+    logits[1, 7] = logits[1, 900] = F16(9.0)            # tie -> first index, like torch.argmax
+    got = torch.zeros((3,), dtype=torch.int32, device=be.device)
+    be.ext.argmax_rows(be.t(logits), got)
+    assert np.array_equal(be.n(got), np.argmax(logits.astype(np.float32), axis=-1))
+    lens = be.t(np.array([5, 9], dtype=np.int32))
+    be.ext.add_i32_(lens, 3)
+    assert np.array_equal(be.n(lens), [8, 12])

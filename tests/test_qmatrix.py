@@ -1,0 +1,140 @@
+"""q_matrix: re-layout + reconstruct (bit-exact) and gemm_half_q_half (fp16 tolerance) against the oracle.
+
+Parity method = the reference's own (tests/test_gemv.py:136-165): kernel vs reconstruct+matmul on identity and randn
+inputs, for every bit width, mixed sections, partial super-chunks, act-order on/off, GPTQ with and without g_idx.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import exl2 as OX
+from tests.util import make_exl2, gptq_to_torch, half_tol
+
+SPECS = {
+    "b4_g128": (256, 32, [(4, 128, 256)]),
+    "b4_tail": (160, 32, [(4, 32, 160)]),
+    "b2": (192, 32, [(2, 64, 192)]),
+    "b3": (192, 32, [(3, 64, 192)]),
+    "b5": (192, 32, [(5, 32, 192)]),
+    "b6": (192, 32, [(6, 32, 192)]),
+    "b8": (192, 32, [(8, 32, 192)]),
+    "mixed_all": (800, 64, [(8, 32, 32), (6, 32, 96), (5, 64, 128), (4, 128, 256), (3, 64, 160), (2, 64, 128)]),
+    "mixed_5_4": (1024, 64, [(5, 128, 128), (4, 128, 896)]),
+    "long_runs": (2304, 32, [(4, 128, 2304)]),            # > QDESC_MAX_SUPER super-chunks: several descriptors
+}
+
+
+@pytest.mark.parametrize("name", list(SPECS))
+@pytest.mark.parametrize("act_order", [True, False])
+def test_reconstruct_bit_exact(be, name, act_order):
+    k, n, spec = SPECS[name]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=1, act_order=act_order)
+    out = torch.zeros((k, n), dtype=torch.float16, device=be.device)
+    be.ext.reconstruct(h, out)
+    got = be.n(out)
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
+    info = be.ext.q_matrix_info(h)
+    assert (info["height"], info["width"], info["is_gptq"]) == (k, n, False)
+    be.ext.free_q_matrix(h)
+
+
+@pytest.mark.parametrize("name", ["b4_g128", "b4_tail", "b3", "b6", "mixed_all", "long_runs"])
+@pytest.mark.parametrize("m", [1, 2, 5, 16])
+def test_gemm_vs_oracle(be, name, m):
+    k, n, spec = SPECS[name]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=2, act_order=True)
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((m, k)).astype(np.float16)
+    c = torch.zeros((m, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    want = OX.gemm_ref(a, ref, exact=True)
+    got = be.n(c).astype(np.float64)
+    assert np.all(np.abs(got - want) <= half_tol(want, k)), np.abs(got - want).max()
+    be.ext.free_q_matrix(h)
+
+
+def test_gemm_identity_equals_reconstruct(be):
+    """tests/test_gemv.py:155-159: gemm(I) must reproduce reconstruct() exactly (each output is one weight)."""
+    k, n, spec = SPECS["mixed_all"]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=4, act_order=True)
+    eye = np.eye(k, dtype=np.float16)
+    got = np.zeros((k, n), dtype=np.float16)
+    for r0 in range(0, k, 16):
+        a = be.t(eye[r0:r0 + 16])
+        c = torch.zeros((a.shape[0], n), dtype=torch.float16, device=be.device)
+        be.ext.gemm_half_q_half(a, h, c)
+        got[r0:r0 + 16] = be.n(c)
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
+    be.ext.free_q_matrix(h)
+
+
+def test_gemm_more_than_16_rows(be):
+    k, n, spec = SPECS["mixed_5_4"]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=5)
+    rng = np.random.default_rng(6)
+    m = 37
+    a = rng.standard_normal((m, k)).astype(np.float16)
+    c = torch.zeros((m, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    want = OX.gemm_ref(a, ref, exact=True)
+    assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= half_tol(want, k))
+    be.ext.free_q_matrix(h)
+
+
+def test_gemm_bias(be):
+    k, n, spec = SPECS["b4_g128"]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=7, bias=True)
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((3, k)).astype(np.float16)
+    c = torch.zeros((3, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    want = OX.gemm_ref(a, ref, bias=t["bias"], exact=True)
+    assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= half_tol(want, k))
+    be.ext.free_q_matrix(h)
+
+
+@pytest.mark.parametrize("k,n,gs,act", [(256, 32, 128, False), (256, 32, 64, True), (384, 48, 128, True), (160, 16, 32, False)])
+def test_gptq(be, k, n, gs, act):
+    t = OX.synth_gptq(k, n, gs, seed=9, act_order=act)
+    ref = OX.gptq_reconstruct(t)
+    w = gptq_to_torch(be, t)
+    h = be.ext.make_q_matrix_from_dict(w, None)
+    out = torch.zeros((k, n), dtype=torch.float16, device=be.device)
+    be.ext.reconstruct(h, out)
+    assert np.array_equal(be.n(out).view(np.uint16), ref.view(np.uint16))
+    if act:
+        xm, xi = OX.gptq_sequential_perm(t["g_idx"], k // gs)
+        assert np.array_equal(be.n(w["q_perm"]).astype(np.int64) & 0xFFFF, xm)
+        assert np.array_equal(be.n(w["q_invperm"]).astype(np.int64) & 0xFFFF, xi)
+    rng = np.random.default_rng(10)
+    a = rng.standard_normal((4, k)).astype(np.float16)
+    c = torch.zeros((4, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    want = OX.gemm_ref(a, ref, exact=True)
+    assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= half_tol(want, k))
+    assert be.ext.q_matrix_info(h)["is_gptq"]
+    be.ext.free_q_matrix(h)
+
+
+def test_make_group_map_matches_oracle(be):
+    t = OX.synth_exl2(800, 64, SPECS["mixed_all"][2], seed=11)
+    got = be.ext.make_group_map(torch.from_numpy(t["q_groups"]), t["q_weight"].shape[0]).numpy()
+    assert np.array_equal(got, OX.make_group_map(t["q_groups"], t["q_weight"].shape[0]))
+
+
+def test_errors_are_loud(be):
+    """Argument errors surface as RuntimeError (TORCH_CHECK convention, cpp/util.h:33-38)."""
+    t = OX.synth_exl2(256, 32, [(4, 128, 256)], seed=12)
+    from tests.util import exl2_to_torch
+    w = exl2_to_torch(be, t)
+    h = be.ext.make_q_matrix_from_dict(w, None)
+    with pytest.raises(RuntimeError):
+        be.ext.gemm_half_q_half(torch.zeros((1, 128), dtype=torch.float16, device=be.device), h,
+                                torch.zeros((1, 32), dtype=torch.float16, device=be.device))
+    with pytest.raises(RuntimeError):
+        be.ext.reconstruct(h, torch.zeros((256, 32), dtype=torch.float32, device=be.device))
+    be.ext.free_q_matrix(h)
+    bad = exl2_to_torch(be, OX.synth_exl2(256, 32, [(4, 128, 256)], seed=13))
+    bad["q_groups"][0] = 7      # unsupported bit width
+    with pytest.raises(RuntimeError):
+        be.ext.make_q_matrix_from_dict(bad, None)
