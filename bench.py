@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: greedy decode tokens/s of a synthetic Llama-2-7B EXL2 4.0bpw model (BASELINE.json configs[1]).
+
+Procedure = the reference's `test_inference.py -s` (test_inference.py:584-618): forward(ids[:, -1:], cache); argmax;
+append -- one "step" is one generated token; the whole step (embedding, 32 layers, head, greedy sampling, position
+bookkeeping) runs on the device as one HIP graph.  Inputs (weights, cache, first token) are resident in HBM when the
+timed region starts.  Rank 0 prints ONE JSON line.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--model llama2-7b|tinyllama|tiny] [--ctx C] [--no-cpu-baseline]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): layer-split ("gpu_split", model.py:176-263) as a pipeline:
+rank r owns layers [r L/N, (r+1) L/N); N independent sequences are in flight, one per stage, hidden states hop
+rank -> rank over RCCL point-to-point; value = all sequences' tokens / time (weak scaling: per-GPU work per token fixed).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=128)
+    p.add_argument("--warmup", type=int, default=16)
+    p.add_argument("--model", default="llama2-7b")
+    p.add_argument("--recipe", default="4.0bpw")
+    p.add_argument("--ctx", type=int, default=0, help="tokens already in the KV cache when timing starts")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-graph", action="store_true")
+    return p.parse_args()
+
+
+def make_cfg(name: str, max_seq_len: int):
+    from exllamav2_amd.config import ExLlamaV2Config
+    if name == "llama2-7b":
+        return ExLlamaV2Config.llama2_7b(max_seq_len=max_seq_len, max_input_len=256)
+    if name == "tinyllama":
+        return ExLlamaV2Config.tinyllama_1b(max_input_len=256)
+    if name == "tiny":
+        return ExLlamaV2Config.tiny_test(max_seq_len=max_seq_len)
+    raise SystemExit(f"unknown model {name}")
+
+
+def time_gemv_calls(model, dec, reps: int = 3):
+    """Duration of the q_gemm launches of one decode step, each API call bracketed by events on the launch stream.
+    Returns (total_ms, launches, algorithmic_bytes) averaged over `reps` passes (all 32 layers: weights are HBM-cold,
+    3.4 GB >> 256 MB Infinity Cache, the rotation tests/test_gemv.py:84-128 relies on)."""
+    import torch
+    from exllamav2_amd.ext import none_tensor
+    ext, cfg = model.ext, model.config
+    b = dec.b
+    x = dec.x
+    q = model.temp_q[:b].view(b, 1, cfg.num_attention_heads, cfg.head_dim)
+    k = model.temp_k[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
+    v = model.temp_v[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
+    ao = model.temp_attn[:b].view(b, 1, -1)
+    events = []
+
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        events.append((e0, e1))
+
+    launches = 0
+    nbytes = 0
+    for rep in range(reps + 1):
+        if rep == 1:
+            events.clear(); launches = 0; nbytes = 0            # pass 0 is a warm-up
+        for attn, mlp in model.layers:
+            timed(lambda: ext.q_attn_forward_1(attn.q_handle, x, b, 1, 0, none_tensor, q, k, v, model.sin, model.cos,
+                                               apply_rope=False))
+            timed(lambda: ext.q_attn_forward_2(attn.q_handle, x, ao, b, 1))
+            timed(lambda: ext.q_mlp_forward_(mlp.q_handle, x))
+            launches += 4
+            nbytes += sum(l.weight_bytes() for l in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj,
+                                                     mlp.gate_proj, mlp.up_proj, mlp.down_proj))
+        timed(lambda: ext.gemm_half_q_half(dec.xn.view(b, -1), model.lm_head.q_handle, dec.logits))
+        launches += 1
+        nbytes += model.lm_head.weight_bytes()
+    torch.cuda.synchronize()
+    total_ms = sum(e0.elapsed_time(e1) for e0, e1 in events)
+    return total_ms / reps, launches // reps, nbytes // reps
+
+
+def cpu_baseline(cfg, recipe: str, seed: int = 0):
+    """The oracle ("port": the reference has no CPU path) timed on the host cores: matmul(x,
+    reconstruct) with pre-dequantized fp32 weights (compute-fair variant B), bounded sample = ONE transformer layer's 7
+    linears x 8 tokens, extrapolated to layers + head."""
+    import numpy as np
+    import torch
+    from exllamav2_amd.synth import synth_linear, RECIPES
+    from oracle import exl2 as OX
+    rec = RECIPES[recipe]
+    gen = torch.Generator(device="cpu"); gen.manual_seed(seed)
+    h, inter = cfg.hidden_size, cfg.intermediate_size
+    qd, kvd = cfg.num_attention_heads * cfg.head_dim, cfg.num_key_value_heads * cfg.head_dim
+    shapes = [("q_proj", h, qd), ("k_proj", h, kvd), ("v_proj", h, kvd), ("o_proj", qd, h),
+              ("gate_proj", h, inter), ("up_proj", h, inter), ("down_proj", inter, h)]
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    ws = []
+    for name, k, n in shapes:
+        w = synth_linear(k, n, rec[name], "cpu", gen)
+        t = {kk: vv.numpy() for kk, vv in w.items() if kk != "q_perm"}
+        ws.append(torch.from_numpy(OX.exl2_reconstruct(t).astype(np.float32)))
+    tokens = 8
+    x = torch.randn(1, h)
+    t0 = time.perf_counter()
+    for _ in range(tokens):
+        q = x @ ws[0]; k = x @ ws[1]; v = x @ ws[2]; o = q @ ws[3]
+        g = x @ ws[4]; u = x @ ws[5]; d = (torch.nn.functional.silu(g) * u) @ ws[6]
+        x = x + 1e-3 * (o + d)
+    dt = (time.perf_counter() - t0) / tokens
+    head_scale = (h * cfg.vocab_size) / sum(k * n for _, k, n in shapes)
+    per_token = dt * (cfg.num_hidden_layers + head_scale)
+    return {"value": round(1.0 / per_token, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"1 of {cfg.num_hidden_layers} layers (7 linears, pre-dequantized fp32, torch.matmul) x {tokens} tokens, "
+                      f"extrapolated to {cfg.num_hidden_layers} layers + head"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    n_gpus = world
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(device)
+
+    from exllamav2_amd import ExLlamaV2, ExLlamaV2Cache, GreedyGraphDecoder
+    from exllamav2_amd.synth import synth_checkpoint
+
+    max_seq = max(2048, ((args.ctx + args.steps + args.warmup + 1 + 255) // 256) * 256)
+    cfg = make_cfg(args.model, max_seq)
+
+    if n_gpus > 1:
+        from exllamav2_amd.pipeline import run_layer_split_bench
+        result = run_layer_split_bench(cfg, args, rank, world, device)
+    else:
+        t_load = time.perf_counter()
+        ck = synth_checkpoint(cfg, device, recipe=args.recipe, seed=0)
+        model = ExLlamaV2(cfg, device=device).load(ck)
+        torch.cuda.synchronize()
+        t_load = time.perf_counter() - t_load
+        cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=max_seq)
+        dec = GreedyGraphDecoder(model, cache, batch_size=1)
+        if not args.no_graph:
+            dec.capture()
+        dec.reset(torch.tensor([1]), args.ctx)                 # KV of the first `ctx` positions = resident (zeros)
+        dec.run(args.warmup, use_graph=not args.no_graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dec.run(args.steps, use_graph=not args.no_graph)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        toks = dec.tokens(args.ctx + args.warmup, args.steps)
+        assert int(dec.cache_seqlens[0]) == args.ctx + args.warmup + args.steps
+        assert int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab_size
+
+        gemv_ms, launches, gemv_bytes = time_gemv_calls(model, dec)
+        kv_bytes = 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2 * (args.ctx + args.warmup + args.steps // 2)
+        achieved = gemv_bytes / (gemv_ms * 1e-3) / 1e9
+        result = {
+            "value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load,
+            "roofline": {
+                "bound": "hbm", "kernel": "qgemv_kernel<false> (all q_gemm launches of a decode step)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "bytes_per_step": gemv_bytes, "launches_per_step": launches,
+                "avg_launch_us": round(gemv_ms * 1e3 / launches, 2),
+                "step_frac_of_weight_roofline": round((gemv_bytes + kv_bytes) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            },
+        }
+        dec.free()
+
+    if rank == 0:
+        out = {
+            "metric": "decode tokens/s, Llama-2-7B EXL2 4.0bpw, bs=1 greedy" if args.model == "llama2-7b"
+                      else f"decode tokens/s, {args.model} EXL2 {args.recipe}, bs=1 greedy",
+            "value": round(result["value"], 2), "unit": "tokens/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(result["ms_per_step"], 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{args.model} EXL2 {args.recipe} (synthetic weights, act-order), greedy decode, "
+                                   f"bs=1 per sequence, ctx {args.ctx}+{args.warmup}..+{args.steps}, FP16 KV cache, "
+                                   f"whole step in one HIP graph",
+                       "parallelism": "single GPU" if n_gpus == 1 else f"layer-split pipeline x{n_gpus}, {n_gpus} sequences in flight"},
+        }
+        for k in ("roofline", "load_s"):
+            if k in result: out[k] = result[k]
+        if not args.no_cpu_baseline and n_gpus == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, args.recipe)
+            except Exception as e:  # baseline is informational; never lose the GPU number
+                out["cpu_baseline"] = {"value": None, "error": str(e)[:200]}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,5 +6,8 @@ HIP kernels behind a C-ABI shared library (include/exl2_hip.h), plus the thin Py
 module interface needed to drive it.
 """
 from .ext import ext_c, none_tensor, ExtC  # noqa: F401
+from .config import ExLlamaV2Config  # noqa: F401
+from .model import ExLlamaV2, GreedyGraphDecoder  # noqa: F401
+from .cache import ExLlamaV2Cache, ExLlamaV2Cache_Q4  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,77 @@
+"""ExLlamaV2Attention (reference attn.py:241-330 load/make_q_attn, :1017-1196 forward, :466-638 forward_paged)."""
+from __future__ import annotations
+
+import torch
+
+from .ext import none_tensor
+from .linear import ExLlamaV2Linear
+
+
+class ExLlamaV2Attention:
+    def __init__(self, model, key: str, layer_idx: int):
+        cfg = model.config
+        self.model, self.ext, self.key, self.layer_idx = model, model.ext, key, layer_idx
+        h = cfg.hidden_size
+        self.q_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.q_proj", h, cfg.num_attention_heads * cfg.head_dim)
+        self.k_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.k_proj", h, cfg.num_key_value_heads * cfg.head_dim)
+        self.v_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.v_proj", h, cfg.num_key_value_heads * cfg.head_dim)
+        self.o_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.o_proj", cfg.num_attention_heads * cfg.head_dim, h)
+        self.pre_layernorm = None
+        self.q_handle = None
+
+    def load(self, ck: dict):
+        cfg, m = self.model.config, self.model
+        for lin in (self.q_proj, self.k_proj, self.v_proj, self.o_proj):
+            lin.load(ck[lin.key])
+        self.pre_layernorm = ck[self.key + ".input_layernorm"]
+        self.q_handle = self.ext.make_q_attn(                                   # attn.py:300-330
+            self.pre_layernorm, none_tensor, True, False, cfg.norm_eps,
+            self.q_proj.q_handle, self.k_proj.q_handle, self.v_proj.q_handle, self.o_proj.q_handle,
+            m.temp_state, none_tensor, m.max_rows, cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads,
+            cfg.head_dim, cfg.max_seq_len, True, cfg.rope_style, cfg.head_dim, none_tensor, none_tensor, none_tensor,
+            none_tensor, False, False)
+        return self
+
+    def unload(self):
+        if self.q_handle is not None:
+            self.ext.free_q_attn(self.q_handle)                                  # attn handle before its linears
+            self.q_handle = None
+        for lin in (self.q_proj, self.k_proj, self.v_proj, self.o_proj):
+            lin.unload()
+
+    def forward(self, hidden_states: torch.Tensor, cache, past_len: int = 0, cache_seqlens=None, block_table=None):
+        """In place on hidden_states [b, q_len, hidden] (residual add in o_proj's epilogue).
+
+        Contiguous mode (attn.py:1017-1196): scalar `past_len`, cache viewed [b, max_seq_len, kvh, hd].
+        Paged mode (attn.py:466-638): `cache_seqlens` int32 [b] + `block_table` int32 [b, pages] on the device,
+        cache viewed [pages, 256, kvh, hd]; positions are read on the device (graph-capturable)."""
+        cfg, m, ext = self.model.config, self.model, self.ext
+        b, q_len, _ = hidden_states.shape
+        rows = b * q_len
+        q = m.temp_q[:rows].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
+        k = m.temp_k[:rows].view(b, q_len, cfg.num_key_value_heads, cfg.head_dim)
+        v = m.temp_v[:rows].view(b, q_len, cfg.num_key_value_heads, cfg.head_dim)
+        paged = block_table is not None
+        ext.q_attn_forward_1(self.q_handle, hidden_states, b, q_len, 0, none_tensor, q, k, v, m.sin, m.cos,
+                             apply_rope=False)
+        if cache is None:
+            raise RuntimeError("ExLlamaV2Attention.forward: a cache is required")
+        elif paged:
+            cache.get_kv_state(self.layer_idx, b, 0, 0, 256, cache_seqlens, block_table)
+            kc, vc = cache.paged_view(self.layer_idx)
+            ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, 0, cache_seqlens, block_table, cfg.rope_style)
+        else:
+            kc, vc = cache.get_kv_state(self.layer_idx, b, 0, past_len)
+            ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, past_len, none_tensor, none_tensor, cfg.rope_style)
+        attn_out = m.temp_attn[:rows].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
+        if False:
+            pass
+        elif paged:
+            ext.paged_attn(q, kc, vc, attn_out, cache_seqlens, block_table, len_const=0, len_offset=q_len,
+                           scratch=m.attn_scratch)
+            cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
+        else:
+            ext.paged_attn(q, kc, vc, attn_out, None, None, len_const=past_len, len_offset=q_len, scratch=m.attn_scratch)
+            cache.store_kv_state(self.layer_idx, b, past_len, q_len)
+        ext.q_attn_forward_2(self.q_handle, hidden_states, attn_out, b, q_len)
+        return hidden_states

@@ -265,7 +265,8 @@ KERNEL void __launch_bounds__(256) embed_rows_kernel(const f16* table, const int
     for (int i = tid(); i < (hidden >> 3); i += 256) dst[i] = src[i];
 }
 
-KERNEL void __launch_bounds__(1024) argmax_rows_kernel(const f16* logits, int* out_ids, int vocab, int ld)
+KERNEL void __launch_bounds__(1024) argmax_rows_kernel(const f16* logits, int* out_ids, int vocab, int ld,
+                                                       int* history, const int* hist_pos, int hist_stride)
 {
     SHARED float best_v[16];
     SHARED int best_i[16];
@@ -292,6 +293,7 @@ KERNEL void __launch_bounds__(1024) argmax_rows_kernel(const f16* logits, int* o
         for (int w = 1; w < nw; w++)
             if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) { bv = best_v[w]; bi = best_i[w]; }
         out_ids[row] = bi;
+        if (history) history[(size_t)row * hist_stride + hist_pos[row]] = bi;      // token log, position read on device
     }
 }
 
@@ -313,11 +315,13 @@ int exl2_embed_rows(const void* table, const int* ids, void* out, int rows, int 
     return EXL2_OK;
 }
 
-int exl2_argmax_rows(const void* logits, int* out_ids, int rows, int vocab, int ld, void* stream)
+int exl2_argmax_rows(const void* logits, int* out_ids, int rows, int vocab, int ld,
+                     int* history, const int* hist_pos, int hist_stride, void* stream)
 {
     EXL2_REQUIRE(logits && out_ids, "argmax_rows: null argument");
     if (rows <= 0) return EXL2_OK;
-    LAUNCH(argmax_rows_kernel, dim3((unsigned)rows), dim3(1024), 0, stream, (const f16*)logits, out_ids, vocab, ld);
+    LAUNCH(argmax_rows_kernel, dim3((unsigned)rows), dim3(1024), 0, stream, (const f16*)logits, out_ids, vocab, ld,
+           history, hist_pos, hist_stride);
     HIP_TRY(hipGetLastError());
     return EXL2_OK;
 }

@@ -1,0 +1,191 @@
+"""ExLlamaV2 model runtime for the Llama family (reference model.py:78-173 module list, :764-933 forward chunking,
+:936-1054 forward_chunk) on one device, plus the whole-step greedy decode graph used by the benchmark."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .attn import ExLlamaV2Attention
+from .cache import PAGE_SIZE
+from .config import ExLlamaV2Config
+from .ext import ext_c, none_tensor
+from .linear import ExLlamaV2Linear
+from .mlp import ExLlamaV2MLP
+from .rmsnorm import ExLlamaV2RMSNorm
+
+
+def rope_tables(cfg: ExLlamaV2Config, device):
+    """device.py:118-169: fp16 sin/cos [max_seq_len, head_dim]."""
+    inv_freq = 1.0 / (cfg.rotary_embedding_base ** (torch.arange(0, cfg.head_dim, 2, device=device).float() / cfg.head_dim))
+    t = torch.arange(cfg.max_seq_len, device=device, dtype=torch.float32)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1) if cfg.rope_style == 2 else torch.repeat_interleave(freqs, 2, dim=-1)
+    return emb.sin().half().contiguous(), emb.cos().half().contiguous()
+
+
+class ExLlamaV2:
+    def __init__(self, config: ExLlamaV2Config, device="cuda:0", ext=None):
+        self.config = config
+        self.device = torch.device(device)
+        self.ext = ext or ext_c
+        cfg = config
+        # per-device scratch arena (device.py:102-115): sized for one forward chunk
+        self.max_rows = max(cfg.max_input_len, cfg.max_batch_size)
+        r, dev = self.max_rows, self.device
+        self.temp_state = torch.empty((r, cfg.hidden_size), dtype=torch.float16, device=dev)
+        self.temp_a = torch.empty((r, cfg.intermediate_size), dtype=torch.float16, device=dev)
+        self.temp_b = torch.empty((r, cfg.intermediate_size), dtype=torch.float16, device=dev)
+        self.temp_q = torch.empty((r, cfg.num_attention_heads * cfg.head_dim), dtype=torch.float16, device=dev)
+        self.temp_k = torch.empty((r, cfg.num_key_value_heads * cfg.head_dim), dtype=torch.float16, device=dev)
+        self.temp_v = torch.empty((r, cfg.num_key_value_heads * cfg.head_dim), dtype=torch.float16, device=dev)
+        self.temp_attn = torch.empty((r, cfg.num_attention_heads * cfg.head_dim), dtype=torch.float16, device=dev)
+        sb = self.ext.paged_attn_scratch_bytes(min(r, 64) * cfg.num_attention_heads, cfg.head_dim, 16)
+        self.attn_scratch = torch.empty((sb // 4 + 16,), dtype=torch.float32, device=dev)
+        self.sin, self.cos = rope_tables(cfg, dev)
+        self.modules = []
+        self.layers = []
+        self.embed_tokens = None
+        self.norm = None
+        self.lm_head = None
+        self.loaded = False
+
+    def load(self, ck: dict):
+        """model.py:266-351 (single device): build every module's handles from a checkpoint dict."""
+        cfg = self.config
+        self.embed_tokens = ck["model.embed_tokens"]
+        for i in range(cfg.num_hidden_layers):
+            key = f"model.layers.{i}"
+            attn = ExLlamaV2Attention(self, key, i).load(ck)
+            mlp = ExLlamaV2MLP(self, key, i).load(ck)
+            self.layers.append((attn, mlp))
+            self.modules += [attn, mlp]
+        self.norm = ExLlamaV2RMSNorm(self.ext, "model.norm", ck["model.norm"], cfg.norm_eps)
+        vpad = (cfg.vocab_size + 31) // 32 * 32
+        self.lm_head = ExLlamaV2Linear(self.ext, "lm_head", cfg.hidden_size, vpad).load(ck["lm_head"])
+        self.vocab_padded = vpad
+        self.loaded = True
+        return self
+
+    def unload(self):
+        for attn, mlp in self.layers:
+            attn.unload(); mlp.unload()
+        if self.lm_head: self.lm_head.unload()
+        self.layers, self.modules, self.loaded = [], [], False
+
+    def weight_bytes(self) -> int:
+        """Algorithmic bytes one token streams through the linears."""
+        n = self.lm_head.weight_bytes()
+        for attn, mlp in self.layers:
+            for lin in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj):
+                n += lin.weight_bytes()
+        return n
+
+    # ---- forward ------------------------------------------------------------------------------------------------------
+
+    def forward_chunk(self, input_ids: torch.Tensor, cache, past_len: int = 0, cache_seqlens=None, block_table=None,
+                      last_id_only: bool = True, preprocess_only: bool = False):
+        """model.py:936-1054.  input_ids [b, q_len] (any device); returns logits [b, q_len | 1, vocab] or None."""
+        cfg = self.config
+        b, q_len = input_ids.shape
+        assert b * q_len <= self.max_rows, "chunk larger than the scratch arena"
+        x = self.embed_tokens[input_ids.to(self.device).view(-1)].view(b, q_len, cfg.hidden_size).contiguous()
+        for attn, mlp in self.layers:
+            attn.forward(x, cache, past_len, cache_seqlens, block_table)
+            mlp.forward(x)
+        if preprocess_only:
+            return None
+        if last_id_only:
+            x = x[:, -1:, :].contiguous()
+        x = self.norm.forward(x)
+        logits = self.lm_head.forward(x)
+        return logits[..., :cfg.vocab_size]
+
+    def forward(self, input_ids: torch.Tensor, cache, last_id_only: bool = True, preprocess_only: bool = False,
+                input_mask=None):
+        """model.py:764-933: contiguous-cache forward with chunked prefill; advances cache.current_seq_len."""
+        b, q_len = input_ids.shape
+        chunk = max(1, self.config.max_input_len // b)
+        past = cache.current_seq_len
+        assert past + q_len <= cache.max_seq_len, "sequence exceeds cache"
+        out = None
+        pos = 0
+        while pos < q_len:
+            n = min(chunk, q_len - pos)
+            last = pos + n == q_len
+            r = self.forward_chunk(input_ids[:, pos:pos + n], cache, past + pos,
+                                   last_id_only=last_id_only, preprocess_only=preprocess_only or (last_id_only and not last))
+            if r is not None:
+                out = r if (out is None or last_id_only) else torch.cat([out, r], dim=1)
+            pos += n
+        cache.current_seq_len = past + q_len
+        return out
+
+
+class GreedyGraphDecoder:
+    """One greedy decode step (embedding -> all layers -> norm -> head -> argmax -> advance positions) captured as a HIP
+    graph.  Procedure = test_inference.py:604-609 (forward(ids[:, -1:], cache); argmax; append) with the token feedback
+    and the position counters kept on the device, so a token costs one graph launch and no host synchronisation."""
+
+    def __init__(self, model: ExLlamaV2, cache, batch_size: int = 1, max_new_tokens: int = 4096):
+        self.model, self.cache, self.b = model, cache, batch_size
+        cfg, dev = model.config, model.device
+        pages_per_seq = cache.max_seq_len // PAGE_SIZE
+        assert cache.max_seq_len % PAGE_SIZE == 0
+        # contiguous cache rows seen through an identity block table (attn_params.py:241-257 "is_sequential")
+        self.block_table = (torch.arange(batch_size * pages_per_seq, dtype=torch.int32, device=dev)
+                            .view(batch_size, pages_per_seq).contiguous())
+        self.cache_seqlens = torch.zeros((batch_size,), dtype=torch.int32, device=dev)
+        self.ids = torch.zeros((batch_size,), dtype=torch.int32, device=dev)
+        self.history = torch.zeros((batch_size, cache.max_seq_len + 1), dtype=torch.int32, device=dev)
+        self.x = torch.zeros((batch_size, 1, cfg.hidden_size), dtype=torch.float16, device=dev)
+        self.xn = torch.zeros_like(self.x)
+        self.logits = torch.zeros((batch_size, model.vocab_padded), dtype=torch.float16, device=dev)
+        self.graph = None
+
+    def step_eager(self):
+        m, ext, cfg = self.model, self.model.ext, self.model.config
+        ext.embed_rows(m.embed_tokens, self.ids, self.x.view(self.b, cfg.hidden_size))
+        for attn, mlp in m.layers:
+            attn.forward(self.x, self.cache, 0, self.cache_seqlens, self.block_table)
+            mlp.forward(self.x)
+        ext.rms_norm(self.x.view(self.b, -1), m.norm.weight, self.xn.view(self.b, -1), cfg.norm_eps)
+        ext.gemm_half_q_half(self.xn.view(self.b, -1), m.lm_head.q_handle, self.logits)
+        ext.add_i32_(self.cache_seqlens, 1)
+        ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens)
+
+    def capture(self):
+        ext = self.model.ext
+        stream = torch.cuda.current_stream(self.model.device).cuda_stream
+        self.step_eager()                                   # warm-up: lazy one-time setup must not happen under capture
+        torch.cuda.synchronize()
+        saved = (self.cache_seqlens.clone(), self.ids.clone())
+        ext.graph_begin_capture(stream)
+        try:
+            self.step_eager()
+        finally:
+            self.graph = ext.graph_end_capture(stream)
+        self.cache_seqlens.copy_(saved[0]); self.ids.copy_(saved[1])
+        return self
+
+    def reset(self, first_ids: torch.Tensor, seq_len: int = 0):
+        self.ids.copy_(first_ids.to(torch.int32).view(-1))
+        self.cache_seqlens.fill_(seq_len)
+
+    def run(self, n_tokens: int, use_graph: bool = True):
+        ext = self.model.ext
+        stream = torch.cuda.current_stream(self.model.device).cuda_stream if self.model.device.type == "cuda" else None
+        for _ in range(n_tokens):
+            if use_graph and self.graph is not None:
+                ext.graph_launch(self.graph, stream)
+            else:
+                self.step_eager()
+
+    def tokens(self, start: int, n: int) -> torch.Tensor:
+        """tokens generated at positions start+1 .. start+n (history[b, pos] = token sampled after `pos` cached tokens)."""
+        return self.history[:, start + 1:start + 1 + n]
+
+    def free(self):
+        if self.graph is not None:
+            self.model.ext.graph_free(self.graph)
+            self.graph = None

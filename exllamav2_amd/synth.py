@@ -1,0 +1,101 @@
+"""Synthetic EXL2 checkpoints of a given architecture (no network, no real checkpoints on the box: BASELINE.md).
+
+Tensors are drawn directly in the on-disk format of SURVEY.md A.1 (uniform random codes == uniform random packed
+words, so no packing pass is needed) with the reference quantizer's own bit mixes (conversion/qparams.py:129-260).
+Returned dicts are exactly what the reference loader hands to `ext.make_q_matrix` (module.py:116-121), on `device`.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+# (bits list, proportions, group size) per linear role for a ~4.0 bpw model: qparams.py:193-198 ("[5,4] 0.1/0.9" attn),
+# :250-260 (MLP), lm_head 6 bit g128 (EXL2 "h6").
+RECIPES = {
+    "4.0bpw": {
+        "q_proj": ([5, 4], [0.1, 0.9], 128), "k_proj": ([5, 4], [0.1, 0.9], 128), "v_proj": ([5, 4], [0.1, 0.9], 64),
+        "o_proj": ([5, 4], [0.1, 0.9], 128), "gate_proj": ([4], [1.0], 128), "up_proj": ([4], [1.0], 32),
+        "down_proj": ([8, 4], [0.05, 0.95], [32, 128]), "lm_head": ([6], [1.0], 128),
+    },
+    "4.0bpw_plain": {k: ([4], [1.0], 128) for k in
+                     ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")} | {"lm_head": ([6], [1.0], 128)},
+    "2.5bpw": {
+        "q_proj": ([3, 2], [0.1, 0.9], 64), "k_proj": ([3, 2], [0.1, 0.9], 64), "v_proj": ([4, 3], [0.1, 0.9], 128),
+        "o_proj": ([3, 2], [0.1, 0.9], 64), "gate_proj": ([3, 2], [0.1, 0.9], 64), "up_proj": ([3, 2], [0.3, 0.7], 64),
+        "down_proj": ([5, 3], [0.05, 0.95], 32), "lm_head": ([6], [1.0], 128),
+    },
+}
+
+
+def group_plan(rows: int, bits: list, props: list, group_size) -> list:
+    """(bits, rows) per group, following QParams.total_bits / AdaptiveGPTQ.quantize (qparams.py:63-77)."""
+    gsz = group_size if isinstance(group_size, list) else [group_size] * len(bits)
+    plan = []
+    remaining = rows
+    for b, p, g in zip(bits, props, gsz):
+        n = math.ceil(min(rows * p, remaining) / g)
+        for _ in range(n):
+            r = min(g, remaining)
+            if r <= 0: break
+            plan.append((b, r))
+            remaining -= r
+    assert remaining == 0, (rows, bits, props, group_size)
+    return plan
+
+
+def synth_linear(k: int, n: int, recipe, device, gen: torch.Generator, sigma: float = 0.02, act_order: bool = True) -> dict:
+    bits, props, gs = recipe
+    plan = group_plan(k, bits, props, gs)
+    q_groups, smax = [], []
+    qrow = 0
+    for b, r in plan:
+        assert r % 32 == 0
+        q_groups += [b, qrow]
+        qrow += r * b // 32
+        smax.append(sigma * math.sqrt(12.0) / (1 << b) / 93.5 * 256.0)
+    g = len(plan)
+    assert qrow < 65536
+    dev = torch.device(device)
+    w = {
+        "q_weight": torch.randint(-2 ** 31, 2 ** 31 - 1, (qrow, n), dtype=torch.int32, device=dev, generator=gen),
+        "q_scale": torch.randint(-2 ** 31, 2 ** 31 - 1, (g, n // 8), dtype=torch.int32, device=dev, generator=gen),
+        "q_scale_max": (torch.tensor(smax, dtype=torch.float32, device=dev)
+                        * (0.5 + torch.rand(g, device=dev, generator=gen))).half(),
+        "q_groups": torch.tensor(q_groups, dtype=torch.int16, device=dev),
+    }
+    if act_order:
+        w["q_invperm"] = torch.randperm(k, device=dev, generator=gen).to(torch.int32)
+    else:
+        w["q_invperm"] = torch.arange(k, device=dev, dtype=torch.int32)
+    w["q_perm"] = torch.argsort(w["q_invperm"]).to(torch.int32)              # module.py:120
+    return w
+
+
+def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_order: bool = True) -> dict:
+    """{'model.layers.0.self_attn.q_proj': {...}, ..., 'model.norm': tensor, 'model.embed_tokens': tensor}"""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    rec = RECIPES[recipe]
+    h, inter = cfg.hidden_size, cfg.intermediate_size
+    qd = cfg.num_attention_heads * cfg.head_dim
+    kvd = cfg.num_key_value_heads * cfg.head_dim
+    ck = {}
+    s_attn = 1.0 / math.sqrt(h)
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}"
+        ck[f"{p}.self_attn.q_proj"] = synth_linear(h, qd, rec["q_proj"], device, gen, s_attn, act_order)
+        ck[f"{p}.self_attn.k_proj"] = synth_linear(h, kvd, rec["k_proj"], device, gen, s_attn, act_order)
+        ck[f"{p}.self_attn.v_proj"] = synth_linear(h, kvd, rec["v_proj"], device, gen, s_attn, act_order)
+        ck[f"{p}.self_attn.o_proj"] = synth_linear(qd, h, rec["o_proj"], device, gen, 0.5 / math.sqrt(qd), act_order)
+        ck[f"{p}.mlp.gate_proj"] = synth_linear(h, inter, rec["gate_proj"], device, gen, s_attn, act_order)
+        ck[f"{p}.mlp.up_proj"] = synth_linear(h, inter, rec["up_proj"], device, gen, s_attn, act_order)
+        # the reference folds down_proj's act-order into gate/up at load -> identity perm here
+        ck[f"{p}.mlp.down_proj"] = synth_linear(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
+        ck[f"{p}.input_layernorm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
+        ck[f"{p}.post_attention_layernorm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
+    ck["model.norm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
+    ck["model.embed_tokens"] = torch.randn(cfg.vocab_size, h, device=device, generator=gen).half()
+    vpad = (cfg.vocab_size + 31) // 32 * 32                                   # linear.py:82-88 pads out_features to x32
+    ck["lm_head"] = synth_linear(h, vpad, rec["lm_head"], device, gen, s_attn, act_order)
+    return ck

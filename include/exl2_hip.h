@@ -1,0 +1,131 @@
+/* exl2_hip.h -- C ABI of libexl2_hip.so: the MI355X (gfx950) implementation of ExLlamaV2's quantized forward path.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one binding of the reference's pybind module
+ * `exllamav2_ext` (reference file:line cited per function; all paths under exllamav2/exllamav2_ext/).  Signatures are
+ * plain C: device pointers as void*, sizes as int, the HIP stream as void* (hipStream_t; NULL = default stream).  No
+ * torch types cross this boundary.  Tensors are row-major and contiguous; "half" = IEEE fp16.
+ *
+ * Error convention: functions return 0 (EXL2_OK) or a negative EXL2_E_* code; exl2_last_error() returns the message of
+ * the calling thread's last failure (the reference throws c10::Error via TORCH_CHECK, cpp/util.h:33-38; allocation
+ * failures say "HIP out of memory", which the reference's autosplit string-matches, model.py:637-639).
+ * Kernels are asynchronous on `stream`; nothing synchronizes except exl2_make_q_matrix (like QMatrix's ctor,
+ * cuda/q_matrix.cu:123).  Ownership: all tensors stay owned by the caller; handles store raw device pointers.
+ */
+#ifndef EXL2_HIP_H
+#define EXL2_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXL2_OK             0
+#define EXL2_E_INVALID     -1
+#define EXL2_E_OOM         -2
+#define EXL2_E_HIP         -3
+#define EXL2_E_UNSUPPORTED -4
+
+const char* exl2_last_error(void);
+int exl2_abi_version(void);
+
+/* ---- q_matrix ------------------------------------------------------------------------------------------------- */
+
+/* make_q_matrix (ext_qmatrix.cpp:21-111 -> QMatrix ctor cuda/q_matrix.cu:49-196).
+ * EXL2: q_weight int32[R,N], q_perm/q_invperm uint16[K] (nullable), q_scale int32[G,N/8], q_scale_max half[G] (already
+ * multiplied by prescale/256, ext.py:336), q_groups uint16[2G] (device); gptq_* NULL.
+ * GPTQ: q_weight = qweight int32[K/8,N], gptq_qzeros int32[G,N/8], gptq_scales half[G,N], gptq_g_idx_host uint32[K] on
+ * the HOST or NULL (act-order: q_perm / q_invperm must then be writable uint16[K] buffers, filled here).
+ * q_weight is re-laid out IN PLACE (the reference shuffles in place too, q_matrix.cu:189-195). */
+int exl2_make_q_matrix(void** handle, int device, int height, int width, int groups,
+                       void* q_weight, void* q_perm, void* q_invperm, void* q_scale, void* q_scale_max, void* q_groups,
+                       void* gptq_qzeros, void* gptq_scales, const uint32_t* gptq_g_idx_host,
+                       void* bias, void* temp_dq, int max_dq_rows, void* stream);
+/* free_q_matrix (ext_qmatrix.cpp:184-193) */
+int exl2_free_q_matrix(void* handle);
+int exl2_q_matrix_info(void* handle, int* height, int* width, int* groups, int* is_gptq, long long* weight_bytes);
+/* reconstruct (ext_qmatrix.cpp:196-210): out half[K,N], original row order */
+int exl2_reconstruct(void* handle, void* out, void* stream);
+/* gemm_half_q_half (ext_qmatrix.cpp:213-247 -> gemm_half_q_half_cuda cuda/q_gemm.cu:201-313): c[M,N] (+)= a[M,K] W
+ * (+ bias).  clear = 0 accumulates into c (residual).  r_weights: optional MoE routing weights half[M, r_weights_stride]
+ * (zero weight -> row skipped; mul_r_weights -> result scaled; cuda/q_gemm_kernel.cuh:189-200,553-558). */
+int exl2_gemm_half_q_half(const void* a, void* handle, void* c, int size_m, int clear,
+                          const void* r_weights, int r_weights_stride, int mul_r_weights, void* stream);
+/* make_group_map (ext_qmatrix.cpp:341-361), host only: returns number of uint16 written (2K) or < 0 */
+int exl2_make_group_map(const uint16_t* q_groups_host, int groups, int num_qrows, uint16_t* out, int out_len);
+
+/* ---- norms, RoPE, activation ------------------------------------------------------------------------------------ */
+
+/* rms_norm / rms_norm_ (ext_norm.cpp:22-85 -> rms_norm_cuda cuda/rms_norm.cu:177-249) */
+int exl2_rms_norm(const void* x, const void* w, void* y, float epsilon, int rows, int dim,
+                  int add_residual, int input_fp32, int output_fp32, void* stream);
+/* rope_ (ext_rope.cpp:21-62 -> rope_cuda cuda/rope.cu:176-218) and rope_cuda_qk (:220-273); x_k may be NULL */
+int exl2_rope_qk(void* x_q, void* x_k, const void* sin, const void* cos, int batch_size,
+                 int rows_per_batch_q, int rows_per_batch_k, int head_dim, int num_heads_q, int num_heads_k,
+                 int past_len, const int* past_lens, int neox_style, int sincos_size, void* stream);
+/* act_mul_cuda (cuda/q_mlp.cu:238-258): x = act(x) * y */
+int exl2_act_mul(void* x, const void* y, int rows, int width, int act_gelu,
+                 const void* r_weights, int r_weights_stride, void* stream);
+
+/* ---- quantized KV cache --------------------------------------------------------------------------------------------- */
+
+/* fp16_to_q_kv / q_to_fp16_kv (ext_cache.cpp:80-269 -> cuda/cache.cu:143-497, cache_q.cuh).  wbits 4 | 6 | 8. */
+int exl2_fp16_to_q_kv(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
+                      int batch_size, int dim, int seq_stride_tokens, int offset, int width, int page_size,
+                      const int* cache_seqlens, const int* block_table, int pages_per_seq, int wbits, void* stream);
+int exl2_q_to_fp16_kv(const void* k_in, void* k_out, const void* k_scales, const void* v_in, void* v_out,
+                      const void* v_scales, int batch_size, int dim, int seq_stride_tokens, int offset, int width,
+                      int page_size, const int* cache_seqlens, const int* block_table, int pages_per_seq, int wbits,
+                      void* stream);
+
+/* ---- attention (replaces flash_attn_with_kvcache, attn.py:602-613, and _attn_torch, attn.py:869-937) ---------------- */
+
+long long exl2_paged_attn_scratch_bytes(int rows, int head_dim, int nsplit);
+int exl2_paged_attn(const void* q, const void* k_cache, const void* v_cache, void* out,
+                    const int* cache_seqlens, const int* block_table,
+                    int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                    int page_size, int pages_per_seq, int len_const, int len_offset,
+                    float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes, void* stream);
+/* RoPE(q, k_new) in place + append of k_new / v_new into the (paged) cache at device-side positions */
+int exl2_rope_kv_append(void* q, void* k_new, const void* v_new, void* k_cache, void* v_cache,
+                        const void* sin, const void* cos, int batch, int q_len, int num_heads, int num_kv_heads,
+                        int head_dim, int past_len, const int* past_lens, const int* block_table,
+                        int page_size, int pages_per_seq, int rope_style, int sincos_size, void* stream);
+
+/* ---- fused modules --------------------------------------------------------------------------------------------------- */
+
+/* make_q_attn (ext_qattn.cpp:24-104), q_attn_forward_1 (:115-159), q_attn_forward_2 (:161-191) */
+int exl2_make_q_attn(void** handle, const void* layernorm, const void* layernorm_bias, int layernorm_is_rms,
+                     int headnorm_is_rms, float norm_epsilon, void* q_q_proj, void* q_k_proj, void* q_v_proj,
+                     void* q_o_proj, void* temp_state, void* temp_dq, int max_rows, int hidden_size, int num_heads,
+                     int num_kv_heads, int head_dim, int max_seq_len, int has_residual, int rope_style, int sincos_size,
+                     const void* q_norm, const void* k_norm, const void* post_layernorm,
+                     const void* post_layernorm_bias, int residual_fp32, int use_graphs);
+int exl2_free_q_attn(void* handle);
+int exl2_q_attn_forward_1(void* handle, const void* x, int batch_size, int q_len, int past_len, const int* past_lens,
+                          void* temp_q, void* temp_k, void* temp_v, const void* sin, const void* cos, int apply_rope,
+                          void* stream);
+int exl2_q_attn_forward_2(void* handle, void* x, const void* attn_output, int batch_size, int q_len, void* stream);
+/* make_q_mlp (ext_qmlp.cpp:22-85), q_mlp_forward_ (:87-118) */
+int exl2_make_q_mlp(void** handle, const void* layernorm, const void* layernorm_bias, int layernorm_is_rms,
+                    float norm_epsilon, void* q_gate, void* q_up, void* q_down, void* temp_state, void* temp_a,
+                    void* temp_b, void* temp_dq, int max_rows, int act_gelu, int has_residual,
+                    const void* post_layernorm, const void* post_layernorm_bias, int residual_fp32, int use_graphs);
+int exl2_free_q_mlp(void* handle);
+int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream);
+
+/* ---- decode-loop utilities and graphs (replace cuda/graph.cu and the host-side embedding / argmax round trips) ------- */
+
+int exl2_embed_rows(const void* table, const int* ids, void* out, int rows, int hidden, int vocab, void* stream);
+int exl2_argmax_rows(const void* logits, int* out_ids, int rows, int vocab, int ld,
+                     int* history, const int* hist_pos, int hist_stride, void* stream);
+int exl2_add_i32(int* p, int n, int value, void* stream);
+int exl2_graph_begin_capture(void* stream);
+int exl2_graph_end_capture(void* stream, void** graph_exec);
+int exl2_graph_launch(void* graph_exec, void* stream);
+int exl2_graph_free(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXL2_HIP_H */

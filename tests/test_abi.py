@@ -1,0 +1,52 @@
+"""The C ABI: every symbol include/exl2_hip.h declares is exported by the built libraries and bound by the host layer."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from tests.conftest import ROOT, build_emu_if_needed
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "exl2_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(exl2_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from exllamav2_amd import _lib
+    assert declared_symbols() == sorted(_lib.PROTOTYPES)
+
+
+def test_emu_library_exports_every_symbol():
+    dll = ctypes.CDLL(build_emu_if_needed())
+    for s in declared_symbols():
+        assert hasattr(dll, s), s
+
+
+def test_hip_library_exports_every_symbol():
+    """Built by __graft_entry__.build() (hipcc cross-compiles here); no compute call is made without a GPU."""
+    from exllamav2_amd import _lib, build
+    path = build.build()
+    lib = _lib.Lib(path)
+    assert lib.exl2_abi_version() == 1
+    dll = ctypes.CDLL(path)
+    for s in declared_symbols():
+        assert hasattr(dll, s), s
+
+
+def test_product_path_refuses_cpu_tensors():
+    """No CPU fallback: the product operator surface rejects non-device tensors loudly."""
+    import torch
+    from exllamav2_amd.ext import ExtC
+    ext = ExtC()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ext.rms_norm(torch.zeros((1, 64), dtype=torch.float16), torch.ones((64,), dtype=torch.float16),
+                     torch.zeros((1, 64), dtype=torch.float16), 1e-5)
+
+
+def test_missing_library_is_loud(tmp_path):
+    from exllamav2_amd import _lib
+    with pytest.raises(_lib.Exl2Error, match="no CPU fallback"):
+        _lib.Lib(str(tmp_path / "libexl2_hip.so"))

@@ -1,0 +1,123 @@
+"""End-to-end: fused module forwards, contiguous + paged decode, greedy tokens -- tiny synthetic Llama vs the oracle.
+
+Greedy parity follows SURVEY.md 8d: random weights give near-flat logits, so token ids are compared only where the
+oracle's top-1/top-2 margin exceeds the stated fp16 tolerance; logits are compared everywhere within that tolerance.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from exllamav2_amd.cache import ExLlamaV2Cache, ExLlamaV2Cache_Q4
+from exllamav2_amd.config import ExLlamaV2Config
+from exllamav2_amd.model import ExLlamaV2, GreedyGraphDecoder
+from exllamav2_amd.synth import synth_checkpoint
+from oracle.model import OracleModel
+
+LOGIT_TOL = 0.03          # absolute, fp16 logits of magnitude ~1-4 after 2 layers (each linear rounds to fp16)
+
+
+def tiny_cfg(**kw):
+    d = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+             num_key_value_heads=1, head_dim=64, vocab_size=96, max_seq_len=256, max_input_len=32)
+    d.update(kw)
+    return ExLlamaV2Config(**d)
+
+
+def build(be, cfg, recipe="4.0bpw", seed=0):
+    ck = synth_checkpoint(cfg, be.device, recipe=recipe, seed=seed)
+    oracle = OracleModel(cfg, ck)                       # reconstructs from the on-disk tensors BEFORE the re-layout
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    return model, oracle
+
+
+def check_logits(got, want):
+    got = got.astype(np.float64)
+    assert np.all(np.abs(got - want) <= LOGIT_TOL + np.abs(want) * 2.0 ** -8), np.abs(got - want).max()
+
+
+def confident(want_logits):
+    top2 = np.sort(want_logits, axis=-1)[..., -2:]
+    return (top2[..., 1] - top2[..., 0]) > 4 * LOGIT_TOL
+
+
+def test_prefill_then_decode_contiguous(be):
+    cfg = tiny_cfg()
+    model, oracle = build(be, cfg)
+    cache = ExLlamaV2Cache(model, batch_size=2)
+    oracle.reset(2)
+    rng = np.random.default_rng(0)
+    ids = rng.integers(0, cfg.vocab_size, size=(2, 5))
+    logits = model.forward(torch.from_numpy(ids), cache, last_id_only=False)
+    want = oracle.forward(ids)
+    check_logits(be.n(logits), want)
+    nxt = np.argmax(want[:, -1], axis=-1)[:, None]
+    for _ in range(2):
+        logits = model.forward(torch.from_numpy(nxt), cache)
+        want = oracle.forward(nxt)
+        check_logits(be.n(logits), want)
+        got_tok = be.n(logits)[:, -1].argmax(-1)
+        conf = confident(want[:, -1])
+        assert np.array_equal(got_tok[conf], np.argmax(want[:, -1], -1)[conf])
+        nxt = np.argmax(want[:, -1], axis=-1)[:, None]
+    model.unload()
+
+
+def test_chunked_prefill_equals_oracle(be):
+    cfg = tiny_cfg(max_input_len=4)                      # forces 3 chunks (model.py:873-927)
+    model, oracle = build(be, cfg, seed=1)
+    cache = ExLlamaV2Cache(model, batch_size=1)
+    oracle.reset(1)
+    ids = np.random.default_rng(1).integers(0, cfg.vocab_size, size=(1, 10))
+    logits = model.forward(torch.from_numpy(ids), cache)                 # last_id_only
+    want = oracle.forward(ids)[:, -1:]
+    check_logits(be.n(logits), want)
+    assert cache.current_seq_len == 10
+    model.unload()
+
+
+def test_device_side_greedy_decode_paged(be):
+    """The benchmark's decode loop (GreedyGraphDecoder, eager on the emulator / graph on the GPU)."""
+    cfg = tiny_cfg()
+    model, oracle = build(be, cfg, seed=2)
+    cache = ExLlamaV2Cache(model, batch_size=1)
+    dec = GreedyGraphDecoder(model, cache, batch_size=1)
+    if not be.is_emu:
+        dec.capture()
+    n = 4
+    dec.reset(torch.tensor([7]), 0)
+    dec.run(n, use_graph=not be.is_emu)
+    got = be.n(dec.tokens(0, n))[0]
+    oracle.reset(1)
+    tok = 7
+    for i in range(n):
+        want = oracle.forward(np.array([[tok]]))[0, -1]
+        if confident(want[None])[0]:
+            assert got[i] == int(np.argmax(want)), (i, got, np.argmax(want))
+        tok = int(got[i])                                 # follow the device's own choice: each step is checked alone
+    assert be.n(dec.cache_seqlens)[0] == n
+    dec.free()
+    model.unload()
+
+
+def test_q4_cache_decode_close_to_fp16(be):
+    """Q4 KV path end to end (cache.py:409-606): logits stay close to the FP16-cache logits (doc/qcache_eval.md)."""
+    cfg = tiny_cfg()
+    ck = synth_checkpoint(cfg, be.device, seed=3)
+    ck2 = copy.deepcopy(ck)
+    m16 = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    m4 = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck2)
+    c16 = ExLlamaV2Cache(m16, batch_size=1)
+    c4 = ExLlamaV2Cache_Q4(m4, batch_size=1)
+    ids = torch.from_numpy(np.random.default_rng(3).integers(0, cfg.vocab_size, size=(1, 8)))
+    a = be.n(m16.forward(ids, c16)).astype(np.float64)
+    b = be.n(m4.forward(ids, c4)).astype(np.float64)
+    assert np.abs(a - b).max() < 1e-2                   # prefill attends over fp16 new tokens in both
+    nxt = torch.tensor([[5]])
+    a = be.n(m16.forward(nxt, c16)).astype(np.float64)
+    b = be.n(m4.forward(nxt, c4)).astype(np.float64)
+    d = np.abs(a - b)
+    assert d.max() < 0.5 and d.mean() < 0.1             # 4-bit keys/values: small but non-zero drift
+    assert np.any(d > 0)
+    m16.unload(); m4.unload()
