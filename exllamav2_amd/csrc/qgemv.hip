@@ -16,108 +16,92 @@
 //     rounding) and accumulated in fp32: results equal matmul(x, reconstruct()) up to fp32 summation order;
 //   * optional prologue fusions while the activations are staged: RMSNorm (rms_norm.cu numerics) or SiLU(gate)*up;
 //     optional epilogue: bias, accumulate into the residual (c += a*W), MoE routing weight.
-#include "qmatrix.h"
+#include "qgemv_common.h"
+#include <stdlib.h>
 
-struct PhaseCtx
+// ---- a wave's work list: the super-chunks g = g0 + wv, g0 + wv + nw, ... of the descriptors [d, de) ------------------
+// [d, de) is a run of descriptors with the SAME bit width (consecutive descriptors of one section are one contiguous
+// stream; they are only split so that M > 1 can stage the activations in phases).
+
+struct Item { const u32* ptr; int chunk0; int nvalid; };
+
+struct Cursor
 {
-    const f16* a_lds;       // staged activations of the current phase
-    const f16* sc_lds;      // [G][16] scales
-    const f16* zp_lds;      // [G][16] zero points (GPTQ)
-    int a_stride;
-    int phase_k0;
-    int M;
+    const QDesc* desc; const u32* qw; const u32* tail; int tile;
+    int d, de;          // current / end descriptor
+    int g, step;        // next global super-chunk index of this wave, stride
 };
 
-template <int BITS, bool GPTQ>
-DEV void gemv_super(const LaneWords<BITS>& lw, const QMatDev& m, const PhaseCtx& ph, int chunk0, int nvalid,
-                    int lane, f32x4& acc)
+// advance to this wave's next item; false when the list is exhausted.  Everything here is wave-uniform (SALU).
+template <int BITS>
+DEV bool next_item(Cursor& c, Item& it)
 {
-    const int c = lane & 15;
-    const int j = lane >> 4;
-
-    int grp[4];
-    f16 sc[4];
-    ZC zc[4];
-    #pragma unroll
-    for (int q = 0; q < 4; q++)
+    while (c.d < c.de)
     {
-        // padded chunks of a partial super-chunk reuse chunk 0's group (never multiplied in)
-        const int ci = q < nvalid ? chunk0 + q : chunk0;
-        grp[q] = m.chunk_group[ci];
-        sc[q] = ph.sc_lds[grp[q] * 16 + c];
-        if constexpr (GPTQ) zc[q] = make_zc(ph.zp_lds[grp[q] * 16 + c]);
+        const QDesc* dp = c.desc + c.d;
+        const int pre = uniform((int)dp->sc_prefix), n = uniform((int)dp->n_super);
+        if (c.g >= pre + n) { c.d++; continue; }
+        const int s = c.g - pre;
+        it.nvalid = (s == n - 1) ? uniform((int)dp->nvalid_last) : 4;
+        it.chunk0 = (uniform((int)dp->k_base) >> 5) + 4 * s;
+        it.ptr = (uniform((int)dp->in_tail) ? c.tail : c.qw) + uniform(dp->base_word)
+                 + (size_t)c.tile * uniform(dp->tile_stride) + (size_t)s * (64 * BITS);
+        c.g += c.step;
+        return true;
     }
-    if constexpr (!GPTQ)
+    return false;
+}
+
+// Stream the wave's items of one run in batches of four: the four vector loads of a batch are issued back to back,
+// unconditionally (missing items of the last batch re-read the batch's first item -- cache hits, results unused), so
+// the code is straight-line and the compiler's counted vmcnt lets item i decode while items i+1.. are still in flight.
+template <int BITS, bool GPTQ>
+DEV void gemv_run(Cursor cur, const PhaseCtx& ph, int lane, f32x4& acc)
+{
+    for (;;)
     {
-        const ZC z = make_zc((f16)(float)(1 << (BITS - 1)));
+        Item it[4];
+        int v = 0;
         #pragma unroll
-        for (int q = 0; q < 4; q++) zc[q] = z;
-    }
-
-    f16x2 p[16];
-    dequant_super<BITS>(lw.w, zc, p);
-
-    const int mrow = c;     // A fragment: lane (i = l & 15, j) holds row i, k-slot j
-    #pragma unroll
-    for (int q = 0; q < 4; q++)
-    {
-        if (q < nvalid)
+        for (int i = 0; i < 4; i++)
         {
-            const f16x2 s2 = h2_dup(sc[q]);
-            const f16x2 b0 = p[4 * q + 0] * s2, b1 = p[4 * q + 1] * s2, b2 = p[4 * q + 2] * s2, b3 = p[4 * q + 3] * s2;
-            const f16x8 b = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
-            f16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (mrow < ph.M)
-                a = *(const f16x8*)(ph.a_lds + mrow * ph.a_stride + ((chunk0 + q) * 32 - ph.phase_k0) + 8 * j);
-            acc = mfma_16x16x32_f16(a, b, acc);
+            if (v == i && next_item<BITS>(cur, it[i])) v = i + 1;
+            else it[i] = it[0];
         }
+        if (v == 0) return;
+        LaneWords<BITS> w[4];
+        #pragma unroll
+        for (int i = 0; i < 4; i++) load_lane_words<BITS>(it[i].ptr, lane, w[i]);
+        #pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (i < v) gemv_super<BITS, GPTQ, true>(w[i], ph, it[i].chunk0, 4, lane, acc);
+        if (v < 4) return;
+    }
+}
+
+// a partial super-chunk (at most one per bit-width section, its own descriptor): rare, no pipelining
+template <int BITS, bool GPTQ>
+DEV void gemv_tail(Cursor cur, const PhaseCtx& ph, int lane, f32x4& acc)
+{
+    Item it;
+    LaneWords<BITS> w;
+    while (next_item<BITS>(cur, it))
+    {
+        load_lane_words<BITS>(it.ptr, lane, w);
+        gemv_super<BITS, GPTQ, false>(w, ph, it.chunk0, it.nvalid, lane, acc);
     }
 }
 
 template <int BITS, bool GPTQ>
-DEV void gemv_run_desc(const QDesc* dp, const QMatDev& m, const PhaseCtx& ph, int tile, int wv, int nw, int lane,
-                       f32x4& acc)
+DEV void gemv_dispatch(const Cursor& cur, bool partial, const PhaseCtx& ph, int lane, f32x4& acc)
 {
-    const u32 base_word   = uniform(dp->base_word);
-    const u32 tile_stride = uniform(dp->tile_stride);
-    const int n_super     = uniform((int)dp->n_super);
-    const int k_base      = uniform((int)dp->k_base);
-    const int nvalid_last = uniform((int)dp->nvalid_last);
-    const int in_tail     = uniform((int)dp->in_tail);
-
-    const u32* base = (in_tail ? m.tail : m.qw) + base_word + (size_t)tile * tile_stride;
-
-    // two super-chunks in flight per wave: issue the next one's loads before decoding the current one
-    int s = wv;
-    LaneWords<BITS> cur, nxt;
-    if (s < n_super) load_lane_words<BITS>(base + (size_t)s * (64 * BITS), lane, cur);
-    while (s < n_super)
-    {
-        const int s2 = s + nw;
-        if (s2 < n_super) load_lane_words<BITS>(base + (size_t)s2 * (64 * BITS), lane, nxt);
-        const int nvalid = (s == n_super - 1) ? nvalid_last : 4;
-        gemv_super<BITS, GPTQ>(cur, m, ph, (k_base >> 5) + 4 * s, nvalid, lane, acc);
-        cur = nxt;
-        s = s2;
-    }
+    if (partial) gemv_tail<BITS, GPTQ>(cur, ph, lane, acc);
+    else         gemv_run<BITS, GPTQ>(cur, ph, lane, acc);
 }
 
 DEV int desc_rows(const QDesc* d)
 {
     return d->in_tail ? (int)d->nvalid_last * 32 : (int)d->n_super * SUPER_ROWS;
-}
-
-DEV f16 clamp_h(f16 r)
-{
-    r = r > (f16)65504.0f ? (f16)65504.0f : r;
-    return r < (f16)-65504.0f ? (f16)-65504.0f : r;
-}
-DEV f16 act_h(f16 g, bool gelu)
-{
-    // mlp.py:486-494 / q_mlp_activation.cuh: act in fp32, rounded to fp16
-    const float x = (float)g;
-    if (gelu) return (f16)(0.5f * x * (1.0f + tanhf(0.797884560803f * (x + 0.044715f * x * x * x))));
-    return (f16)(x / (1.0f + fast_exp(-x)));
 }
 
 template <bool GPTQ>
@@ -150,8 +134,18 @@ KERNEL void __launch_bounds__(1024) qgemv_kernel(const GemvArgs args)
     const f16* a  = job.a  + (size_t)row0 * job.lda;
     const f16* a2 = job.a2 ? job.a2 + (size_t)row0 * job.lda : nullptr;
 
-    // ---- scale / zero tables for this tile's 16 columns ---------------------------------------------------------------
+    QDesc* desc_lds = (QDesc*)(smem + job.lds_desc_off);
+    u16* cg_lds = (u16*)(smem + job.lds_cg_off);
+    float* rmf_lds = (float*)(smem + job.lds_rmf_off) + wv * 16;          // per-wave copy: no block barrier needed
+
+    // ---- prologue, part 1: every load below is independent of the others -> one memory latency for all of them ------
+    //   descriptors and the chunk->group map -> LDS (the streaming loop must not issue any vector-memory load besides
+    //   the weights); per-group scales / zero points of this tile's 16 columns -> LDS [G][16]
     {
+        const u32* src = (const u32*)m.desc;
+        u32* dst = (u32*)desc_lds;
+        for (int i = t; i < m.n_desc * (int)(sizeof(QDesc) / 4); i += nt) dst[i] = src[i];
+        for (int i = t; i < (m.K >> 5); i += nt) cg_lds[i] = m.chunk_group[i];
         const int n8 = m.N >> 3;
         for (int idx = t; idx < m.G * 16; idx += nt)
         {
@@ -171,120 +165,92 @@ KERNEL void __launch_bounds__(1024) qgemv_kernel(const GemvArgs args)
         }
     }
 
-    // ---- RMSNorm statistics (rms_norm.cu:68-76,118) -------------------------------------------------------------------
-    float* part = (float*)(smem + job.lds_zp_off + (GPTQ ? m.G * 32 : 0));   // [16 waves][16 rows] + rmf[16]
-    float* rmf_lds = part + 256;
+    // ---- RMSNorm statistics (rms_norm.cu:68-76,118): every wave reduces the whole row itself (L1/L2 hits), which
+    //      costs K/512 16-byte loads per lane and saves two workgroup barriers ------------------------------------------
     if (job.a_mode == A_RMSNORM)
     {
         for (int r = 0; r < M; r++)
         {
+            const f16x8* xr = (const f16x8*)(a + (size_t)r * job.lda);
             float ss = 0.0f;
-            for (int k = t; k < m.K; k += nt)
+            for (int i = lane; i < (m.K >> 3); i += 64)
             {
-                float f = (float)a[(size_t)r * job.lda + k];
-                f = fmaxf(-65504.0f, fminf(f, 65504.0f));
-                ss = fmaf(f, f, ss);
+                const f16x8 v = xr[i];
+                #pragma unroll
+                for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)); ss = fmaf(f, f, ss); }
             }
             ss = wave_allreduce_add(ss);
-            if (lane == 0) part[wv * 16 + r] = ss;
+            rmf_lds[r] = fast_rsqrt(ss * (1.0f / (float)m.K) + job.norm_eps);   // every lane stores the same value
         }
-        block_sync();
-        if (t < M)
-        {
-            float ss = 0.0f;
-            for (int w = 0; w < nw; w++) ss += part[w * 16 + t];
-            rmf_lds[t] = fast_rsqrt(ss * (1.0f / (float)m.K) + job.norm_eps);
-        }
-        // visibility of rmf_lds: the staging loop below runs after the next block_sync of the first phase? no --
-        // staging reads rmf_lds directly, so synchronise here
-        block_sync();
     }
 
     // ---- phases over K ------------------------------------------------------------------------------------------------
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     PhaseCtx ph;
-    ph.a_lds = a_lds; ph.sc_lds = sc_lds; ph.zp_lds = zp_lds; ph.a_stride = job.a_stride; ph.M = M;
+    ph.a_lds = a_lds; ph.sc_lds = sc_lds; ph.zp_lds = zp_lds; ph.cg_lds = cg_lds; ph.a_stride = job.a_stride; ph.M = M;
 
     int di = 0;
     bool first = true;
     while (di < m.n_desc)
     {
-        const int k0 = uniform((int)m.desc[di].k_base);
-        int rows = 0, de = di;
-        while (de < m.n_desc)
+        int k0, rows, de;
+        if (job.rows_per_phase >= m.K) { k0 = 0; rows = m.K; de = m.n_desc; }          // one phase (always for M = 1)
+        else
         {
-            const int r = uniform(desc_rows(m.desc + de));
-            if (de > di && rows + r > job.rows_per_phase) break;
-            rows += r; de++;
+            k0 = uniform((int)m.desc[di].k_base);
+            rows = 0; de = di;
+            while (de < m.n_desc)
+            {
+                const int r = uniform(desc_rows(m.desc + de));
+                if (de > di && rows + r > job.rows_per_phase) break;
+                rows += r; de++;
+            }
         }
 
         if (!first) block_sync();              // previous phase's A reads are done
         first = false;
 
-        // stage a[:, perm[k0 .. k0+rows)] into LDS, 8 K-values per thread per step
+        // stage a[:, perm[k0 .. k0+rows)] into LDS, 8 K-values per thread per step; the mode is uniform and hoisted so
+        // the 8 gathers of a step are issued back to back (one latency, not eight)
         const int oct = rows >> 3;
-        for (int idx = t; idx < M * oct; idx += nt)
+        switch (job.a_mode)
         {
-            const int r = idx / oct, o = idx - r * oct;
-            const int kk = o * 8;
-            u16 src[8];
-            if (m.perm)
-            {
-                const u32x4 pv = *(const u32x4*)(m.perm + k0 + kk);
-                src[0] = pv.x & 0xFFFF; src[1] = pv.x >> 16; src[2] = pv.y & 0xFFFF; src[3] = pv.y >> 16;
-                src[4] = pv.z & 0xFFFF; src[5] = pv.z >> 16; src[6] = pv.w & 0xFFFF; src[7] = pv.w >> 16;
-            }
-            else
-            {
-                #pragma unroll
-                for (int e = 0; e < 8; e++) src[e] = (u16)(k0 + kk + e);
-            }
-            f16x8 v;
-            #pragma unroll
-            for (int e = 0; e < 8; e++)
-            {
-                const size_t off = (size_t)r * job.lda + src[e];
-                f16 x = a[off];
-                if (job.a_mode == A_RMSNORM)
-                {
-                    float f = fmaxf(-65504.0f, fminf((float)x, 65504.0f));
-                    x = (f16)((f * (float)job.norm_w[src[e]]) * rmf_lds[r]);
-                }
-                else if (job.a_mode == A_SILU_MUL || job.a_mode == A_GELU_MUL)
-                {
-                    x = clamp_h(act_h(x, job.a_mode == A_GELU_MUL) * a2[off]);
-                }
-                else if (job.a_mode == A_SILU || job.a_mode == A_GELU)
-                {
-                    x = act_h(x, job.a_mode == A_GELU);
-                }
-                v[e] = x;
-            }
-            *(f16x8*)(a_lds + r * job.a_stride + kk) = v;
+            case A_PLAIN:    stage_rows<A_PLAIN>(job, m, a, a2, a_lds, rmf_lds, k0, oct, M, t, nt); break;
+            case A_RMSNORM:  stage_rows<A_RMSNORM>(job, m, a, a2, a_lds, rmf_lds, k0, oct, M, t, nt); break;
+            case A_SILU_MUL: stage_rows<A_SILU_MUL>(job, m, a, a2, a_lds, rmf_lds, k0, oct, M, t, nt); break;
+            case A_GELU_MUL: stage_rows<A_GELU_MUL>(job, m, a, a2, a_lds, rmf_lds, k0, oct, M, t, nt); break;
+            case A_SILU:     stage_rows<A_SILU>(job, m, a, a2, a_lds, rmf_lds, k0, oct, M, t, nt); break;
+            default:         stage_rows<A_GELU>(job, m, a, a2, a_lds, rmf_lds, k0, oct, M, t, nt); break;
         }
         block_sync();
 
         ph.phase_k0 = k0;
-        for (int d = di; d < de; d++)
+        // runs of descriptors with equal bit width (partial super-chunks are runs of their own)
+        for (int d = di; d < de; )
         {
-            const QDesc* dp = m.desc + d;
-            const int bits = uniform((int)dp->bits);
-            if constexpr (GPTQ)
-            {
-                gemv_run_desc<4, true>(dp, m, ph, tile, wv, nw, lane, acc);
-            }
+            const int bits = uniform((int)desc_lds[d].bits);
+            const bool partial = uniform((int)desc_lds[d].nvalid_last) != 4;
+            int e = d + 1;
+            if (!partial)
+                while (e < de && uniform((int)desc_lds[e].bits) == bits && uniform((int)desc_lds[e].nvalid_last) == 4) e++;
+            Cursor cur;
+            cur.desc = desc_lds; cur.qw = m.qw; cur.tail = m.tail; cur.tile = tile;
+            cur.d = d; cur.de = e; cur.step = nw;
+            cur.g = uniform((int)desc_lds[d].sc_prefix) + wv;
+            if constexpr (GPTQ) gemv_dispatch<4, true>(cur, partial, ph, lane, acc);
             else
             {
                 switch (bits)
                 {
-                    case 4: gemv_run_desc<4, false>(dp, m, ph, tile, wv, nw, lane, acc); break;
-                    case 8: gemv_run_desc<8, false>(dp, m, ph, tile, wv, nw, lane, acc); break;
-                    case 6: gemv_run_desc<6, false>(dp, m, ph, tile, wv, nw, lane, acc); break;
-                    case 5: gemv_run_desc<5, false>(dp, m, ph, tile, wv, nw, lane, acc); break;
-                    case 3: gemv_run_desc<3, false>(dp, m, ph, tile, wv, nw, lane, acc); break;
-                    case 2: gemv_run_desc<2, false>(dp, m, ph, tile, wv, nw, lane, acc); break;
+                    case 4: gemv_dispatch<4, false>(cur, partial, ph, lane, acc); break;
+                    case 8: gemv_dispatch<8, false>(cur, partial, ph, lane, acc); break;
+                    case 6: gemv_dispatch<6, false>(cur, partial, ph, lane, acc); break;
+                    case 5: gemv_dispatch<5, false>(cur, partial, ph, lane, acc); break;
+                    case 3: gemv_dispatch<3, false>(cur, partial, ph, lane, acc); break;
+                    default: gemv_dispatch<2, false>(cur, partial, ph, lane, acc); break;
                 }
             }
+            d = e;
         }
         di = de;
     }
@@ -340,7 +306,11 @@ static int pick_waves(long long tiles, int max_super_per_tile)
             g_num_cus = prop.multiProcessorCount;
         if (g_num_cus <= 0) g_num_cus = 256;
     }
-    const long long target = (long long)g_num_cus * 24;
+    const char* force = getenv("EXL2_GEMV_WAVES");
+    if (force && atoi(force) > 0) return atoi(force);
+    // keep >= ~16 wavefronts per CU streaming; prefer several small workgroups per CU (their prologues overlap each
+    // other's streaming) and only widen the workgroup when there are too few column tiles to go round
+    const long long target = (long long)g_num_cus * 16;
     int w = 4;
     while (w < 16 && tiles * w < target && w * 2 <= max_super_per_tile) w *= 2;
     return w;
@@ -363,16 +333,28 @@ static u32 plan_job_lds(GemvJob& j, int M, bool gptq, int nwaves)
     const u32 red_bytes = (u32)nwaves * 16 * 16 * 4;
     if (a_bytes < red_bytes) a_bytes = red_bytes;
     j.lds_scale_off = a_bytes;
-    j.lds_zp_off = j.lds_scale_off + align16((u32)j.m.G * 32);
+    j.lds_zp_off = j.lds_scale_off + align16((u32)j.m.G * 32);            // [G][16] halfs
     u32 total = j.lds_zp_off + (gptq ? align16((u32)j.m.G * 32) : 0);
-    total += 16 * 16 * 4 + 64;                                // RMSNorm partial sums + rmf[16]
+    j.lds_cg_off = total;
+    total += align16((u32)(j.m.K >> 5) * 2);
+    j.lds_rmf_off = total;
+    total += 16 * 16 * 4;                                                 // rmf[wave][16]
+    j.lds_desc_off = total;
+    total += align16((u32)j.m.n_desc * (u32)sizeof(QDesc));
     return total;
 }
 
 // Launch up to MAX_FUSED_MATS jobs (same M, same format family) as one grid.
+int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream);
+
 int qgemv_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream)
 {
     if (n_jobs < 1 || n_jobs > MAX_FUSED_MATS || M < 1) return -1;
+    {
+        // decode-shaped calls go to the streaming kernel (qgemv_stream.hip); this generic kernel handles the rest
+        const int rc = qgemv_stream_launch(jobs, n_jobs, M, gptq, stream);
+        if (rc <= 0) return rc;
+    }
     GemvArgs args;
     args.n_jobs = n_jobs;
     args.M = M;

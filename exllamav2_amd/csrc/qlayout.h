@@ -105,9 +105,24 @@ struct QDesc
     u8  nvalid_last;    // valid 32-row chunks in the LAST super-chunk of the run (1..4)
     u8  in_tail;        // 0: weight buffer, 1: tail buffer
     u8  pad0;
-    u32 pad1;
+    u32 sc_prefix;      // index of this run's first super-chunk among all super-chunks of the matrix (K order)
 };
 #define QDESC_MAX_SUPER 16
+
+// One bit-width section of the matrix (or its partial last super-chunk): a contiguous stream per 16-column tile.
+// Unlike QDesc these are not split for phased staging; they travel in the kernel arguments (scalar registers).
+struct QRun
+{
+    u32 base_word;      // word offset of (tile 0, super-chunk 0) in the weight buffer / tail buffer
+    u32 tile_stride;    // words between consecutive tiles
+    u16 n_super;        // super-chunks per tile in this run
+    u16 k_base;         // first packed K row
+    u8  bits;
+    u8  nvalid_last;    // valid chunks of the last super-chunk (4 unless this is a tail run)
+    u8  in_tail;
+    u8  pad;
+};
+#define MAX_RUNS 12
 
 #ifndef QLAYOUT_NO_DEVICE_DECODERS
 

@@ -20,6 +20,9 @@ struct QMatDev
     int n_desc;
     int K, N, G;
     int is_gptq;
+    int n_runs;                   // 0: too many sections for the streaming kernel (generic kernel only)
+    int main_run;                 // index of the largest full run
+    QRun runs[MAX_RUNS];
 };
 
 struct QMatrix
@@ -60,7 +63,7 @@ struct GemvJob
     int tile0;                    // first block index (x) of this job inside a fused launch
     int a_stride;                 // LDS row stride of the staged activations, in halfs
     int rows_per_phase;           // max K rows staged per phase
-    u32 lds_scale_off, lds_zp_off;   // byte offsets in dynamic LDS
+    u32 lds_scale_off, lds_zp_off, lds_cg_off, lds_rmf_off, lds_desc_off;   // byte offsets in dynamic LDS
 };
 
 struct GemvArgs

@@ -281,6 +281,8 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
         }
     }
 
+    { u32 pre = 0; for (QDesc& d : descs) { d.sc_prefix = pre; pre += d.n_super; } }
+
     QMatrix* qm = (QMatrix*)calloc(1, sizeof(QMatrix));
     if (!qm) EXL2_FAIL(EXL2_E_OOM, "make_q_matrix: host out of memory");
     qm->device = device; qm->height = K; qm->width = N; qm->groups = G; qm->is_gptq = is_gptq;
@@ -330,6 +332,43 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
     d.scale_src = is_gptq ? gptq_scales : q_scale_max;
     d.bias = bias;
     d.n_desc = (int)descs.size(); d.K = K; d.N = N; d.G = G; d.is_gptq = is_gptq ? 1 : 0;
+
+    // runs for the streaming kernel: one per section (+ one per partial super-chunk), in K order
+    {
+        std::vector<QRun> runs;
+        size_t tw = 0;
+        for (const Section& sec : sections)
+        {
+            const int F = sec.chunks / 4, tail = sec.chunks % 4;
+            if (F)
+            {
+                QRun r; memset(&r, 0, sizeof(r));
+                r.base_word = (u32)((size_t)sec.qrow0 * N); r.tile_stride = (u32)F * 64u * (u32)sec.bits;
+                r.n_super = (u16)F; r.k_base = (u16)sec.k0; r.bits = (u8)sec.bits; r.nvalid_last = 4; r.in_tail = 0;
+                runs.push_back(r);
+            }
+            if (tail)
+            {
+                QRun r; memset(&r, 0, sizeof(r));
+                r.base_word = (u32)tw; r.tile_stride = 64u * (u32)sec.bits; r.n_super = 1;
+                r.k_base = (u16)(sec.k0 + F * SUPER_ROWS); r.bits = (u8)sec.bits; r.nvalid_last = (u8)tail; r.in_tail = 1;
+                runs.push_back(r);
+                tw += (size_t)tiles * 64 * sec.bits;
+            }
+        }
+        d.n_runs = 0; d.main_run = 0;
+        if (runs.size() <= MAX_RUNS)
+        {
+            d.n_runs = (int)runs.size();
+            int best = -1;
+            for (int i = 0; i < d.n_runs; i++)
+            {
+                d.runs[i] = runs[i];
+                if (runs[i].nvalid_last == 4 && (best < 0 || runs[i].n_super > runs[best].n_super)) best = i;
+            }
+            d.main_run = best < 0 ? 0 : best;
+        }
+    }
 
     // algorithmic bytes of one pass over this matrix
     long long b = (long long)weight_words * 4;

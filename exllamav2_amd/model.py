@@ -137,11 +137,13 @@ class GreedyGraphDecoder:
                             .view(batch_size, pages_per_seq).contiguous())
         self.cache_seqlens = torch.zeros((batch_size,), dtype=torch.int32, device=dev)
         self.ids = torch.zeros((batch_size,), dtype=torch.int32, device=dev)
-        self.history = torch.zeros((batch_size, cache.max_seq_len + 1), dtype=torch.int32, device=dev)
+        self.history = torch.zeros((batch_size, cache.max_seq_len + 2), dtype=torch.int32, device=dev)
         self.x = torch.zeros((batch_size, 1, cfg.hidden_size), dtype=torch.float16, device=dev)
         self.xn = torch.zeros_like(self.x)
         self.logits = torch.zeros((batch_size, model.vocab_padded), dtype=torch.float16, device=dev)
         self.graph = None
+        # capture is not permitted on the legacy default stream: the decoder owns a stream (device.py:67-72 does too)
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
 
     def step_eager(self):
         m, ext, cfg = self.model, self.model.ext, self.model.config
@@ -154,32 +156,49 @@ class GreedyGraphDecoder:
         ext.add_i32_(self.cache_seqlens, 1)
         ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens)
 
+    def _on_stream(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def capture(self):
+        """Warm-up + capture run two throw-away steps; they are pointed at the LAST cache slot, whose K/V rows are
+        saved and restored, so capturing never disturbs a cache that already holds a prompt."""
         ext = self.model.ext
-        stream = torch.cuda.current_stream(self.model.device).cuda_stream
-        self.step_eager()                                   # warm-up: lazy one-time setup must not happen under capture
         torch.cuda.synchronize()
-        saved = (self.cache_seqlens.clone(), self.ids.clone())
-        ext.graph_begin_capture(stream)
-        try:
-            self.step_eager()
-        finally:
-            self.graph = ext.graph_end_capture(stream)
-        self.cache_seqlens.copy_(saved[0]); self.ids.copy_(saved[1])
+        scratch_pos = self.cache.max_seq_len - 1
+        with self._on_stream():
+            saved_state = (self.cache_seqlens.clone(), self.ids.clone())
+            saved_kv = [(k[:, scratch_pos].clone(), v[:, scratch_pos].clone())
+                        for k, v in zip(self.cache.key_states, self.cache.value_states)]
+            self.cache_seqlens.fill_(scratch_pos)
+            self.step_eager()                               # warm-up: lazy one-time setup must not happen under capture
+            self.cache_seqlens.fill_(scratch_pos)
+            self.stream.synchronize()
+            ext.graph_begin_capture(self.stream.cuda_stream)
+            try:
+                self.step_eager()
+            finally:
+                self.graph = ext.graph_end_capture(self.stream.cuda_stream)
+            self.cache_seqlens.copy_(saved_state[0]); self.ids.copy_(saved_state[1])
+            for (k, v), (sk, sv) in zip(zip(self.cache.key_states, self.cache.value_states), saved_kv):
+                k[:, scratch_pos].copy_(sk); v[:, scratch_pos].copy_(sv)
+            self.stream.synchronize()
         return self
 
     def reset(self, first_ids: torch.Tensor, seq_len: int = 0):
-        self.ids.copy_(first_ids.to(torch.int32).view(-1))
-        self.cache_seqlens.fill_(seq_len)
+        with self._on_stream():
+            self.ids.copy_(first_ids.to(torch.int32).view(-1))
+            self.cache_seqlens.fill_(seq_len)
 
     def run(self, n_tokens: int, use_graph: bool = True):
         ext = self.model.ext
-        stream = torch.cuda.current_stream(self.model.device).cuda_stream if self.model.device.type == "cuda" else None
-        for _ in range(n_tokens):
-            if use_graph and self.graph is not None:
-                ext.graph_launch(self.graph, stream)
-            else:
-                self.step_eager()
+        with self._on_stream():
+            sptr = self.stream.cuda_stream if self.stream is not None else None
+            for _ in range(n_tokens):
+                if use_graph and self.graph is not None:
+                    ext.graph_launch(self.graph, sptr)
+                else:
+                    self.step_eager()
 
     def tokens(self, start: int, n: int) -> torch.Tensor:
         """tokens generated at positions start+1 .. start+n (history[b, pos] = token sampled after `pos` cached tokens)."""
