@@ -42,11 +42,20 @@ def bench_gemv(k, n, recipe, m=1, min_bytes=600e6, iters=5, act_order=True):
     c = torch.empty((m, n), device="cuda", dtype=torch.float16)
     for h in handles: ext_c.gemm_half_q_half(a, h, c)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+    # replay the rotation from a HIP graph so the number is GPU time (kernel + launch boundary), not python overhead
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ext_c.graph_begin_capture(st.cuda_stream)
         for h in handles: ext_c.gemm_half_q_half(a, h, c)
-    e1.record(); torch.cuda.synchronize()
+        g = ext_c.graph_end_capture(st.cuda_stream)
+        ext_c.graph_launch(g, st.cuda_stream)
+        st.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(iters): ext_c.graph_launch(g, st.cuda_stream)
+        e1.record(st)
+        st.synchronize()
+    ext_c.graph_free(g)
     ms = e0.elapsed_time(e1) / (iters * len(handles))
     per = total / len(handles)
     for h in handles: ext_c.free_q_matrix(h)
