@@ -27,6 +27,7 @@ typedef u32      u32x4 __attribute__((ext_vector_type(4)));
 #define DEV  __device__ __forceinline__
 #define HD   __host__ __device__ __forceinline__
 #define KERNEL __global__
+#define NOINLINE_DEV __device__ __attribute__((noinline))
 
 #define WAVE 64
 
@@ -80,6 +81,12 @@ DEV float row16_allreduce_add(float v) {
     v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
     v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
     v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+// all-reduce (sum) over each aligned group of 4 lanes
+DEV float quad_allreduce_add(float v) {
+    v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0xB1, 0xF, 0xF, true));
+    v += as_f32((u32)__builtin_amdgcn_update_dpp(0, (int)f32_bits(v), 0x4E, 0xF, 0xF, true));
     return v;
 }
 // all-reduce (sum) over each aligned group of 8 lanes
@@ -136,6 +143,12 @@ DEV u32 atomic_add_u32(u32* p, u32 v) { return atomicAdd(p, v); }
 DEV float fast_exp(float x) { return __expf(x); }
 DEV float fast_rsqrt(float x) { return rsqrtf(x); }
 DEV float fast_rcp(float x) { return __frcp_rn(x); }
+
+// shader-clock timestamp (s_memtime): used only by the EXL2_TRACE profiling build
+DEV u64 cycle_stamp() { return __builtin_amdgcn_s_memtime(); }
+
+// scheduling fence: keeps the compiler from interleaving the decode of consecutive super-chunks (register pressure)
+DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 // ---- launch --------------------------------------------------------------------------------------------------------
 #define LAUNCH(kernel, grid, block, smem, stream, ...) \

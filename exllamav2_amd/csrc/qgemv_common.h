@@ -126,98 +126,3 @@ DEV void stage_rows(const GemvJob& job, const QMatDev& m, const f16* a, const f1
     }
 }
 
-
-// One staging step with the permutation already in registers: 8 gathers (+8 for the gated modes) issued back to back,
-// then the prologue transform, then one 16-byte LDS store.
-template <int MODE>
-DEV void gather_octet(const GemvJob& job, const f16* a, const f16* a2, int r, const u32 (&src)[8], f16x8& x, f16x8& y,
-                      f16x8& nw8)
-{
-    const f16* arow = a + (size_t)r * job.lda;
-    #pragma unroll
-    for (int e = 0; e < 8; e++) x[e] = arow[src[e]];
-    if constexpr (MODE == A_SILU_MUL || MODE == A_GELU_MUL)
-    {
-        const f16* brow = a2 + (size_t)r * job.lda;
-        #pragma unroll
-        for (int e = 0; e < 8; e++) y[e] = brow[src[e]];
-    }
-    if constexpr (MODE == A_RMSNORM)
-    {
-        #pragma unroll
-        for (int e = 0; e < 8; e++) nw8[e] = job.norm_w[src[e]];
-    }
-}
-
-template <int MODE>
-DEV void finish_octet(const GemvJob& job, f16* a_lds, const float* rmf_lds, int r, int kk, const f16x8& x,
-                      const f16x8& y, const f16x8& nw8)
-{
-    f16x8 v;
-    #pragma unroll
-    for (int e = 0; e < 8; e++)
-    {
-        f16 xv = x[e];
-        if constexpr (MODE == A_RMSNORM)
-        {
-            const float f = fmaxf(-65504.0f, fminf((float)xv, 65504.0f));
-            xv = (f16)((f * (float)nw8[e]) * rmf_lds[r]);
-        }
-        else if constexpr (MODE == A_SILU_MUL) xv = clamp_h(act_h(xv, false) * y[e]);
-        else if constexpr (MODE == A_GELU_MUL) xv = clamp_h(act_h(xv, true) * y[e]);
-        else if constexpr (MODE == A_SILU) xv = act_h(xv, false);
-        else if constexpr (MODE == A_GELU) xv = act_h(xv, true);
-        v[e] = xv;
-    }
-    *(f16x8*)(a_lds + r * job.a_stride + kk) = v;
-}
-
-DEV void perm_to_src(const u32x4 pv, u32 (&src)[8])
-{
-    src[0] = pv.x & 0xFFFF; src[1] = pv.x >> 16; src[2] = pv.y & 0xFFFF; src[3] = pv.y >> 16;
-    src[4] = pv.z & 0xFFFF; src[5] = pv.z >> 16; src[6] = pv.w & 0xFFFF; src[7] = pv.w >> 16;
-}
-
-#define STAGE_SLOTS 3
-// Stage the whole activation block [M][K] with the permutation vectors pre-loaded by the caller for the first
-// STAGE_SLOTS steps of every thread (pv[u] is only meaningful when m.perm != null and the slot is in range).
-template <int MODE>
-DEV void stage_preloaded(const GemvJob& job, const QMatDev& m, const f16* a, const f16* a2, f16* a_lds,
-                         const float* rmf_lds, int oct, int M, int t, int nt, const u32x4 (&pv)[STAGE_SLOTS])
-{
-    f16x8 x[STAGE_SLOTS], y[STAGE_SLOTS], nw8[STAGE_SLOTS];
-    #pragma unroll
-    for (int u = 0; u < STAGE_SLOTS; u++)
-    {
-        const int idx = t + u * nt;
-        if (idx < M * oct)
-        {
-            const int r = idx / oct, kk = (idx - r * oct) * 8;
-            u32 src[8];
-            if (m.perm) perm_to_src(pv[u], src);
-            else { for (int e = 0; e < 8; e++) src[e] = (u32)(kk + e); }
-            gather_octet<MODE>(job, a, a2, r, src, x[u], y[u], nw8[u]);
-        }
-    }
-    #pragma unroll
-    for (int u = 0; u < STAGE_SLOTS; u++)
-    {
-        const int idx = t + u * nt;
-        if (idx < M * oct)
-        {
-            const int r = idx / oct, kk = (idx - r * oct) * 8;
-            finish_octet<MODE>(job, a_lds, rmf_lds, r, kk, x[u], y[u], nw8[u]);
-        }
-    }
-    // anything beyond the pre-loaded slots (large M * K): plain loop
-    for (int idx = t + STAGE_SLOTS * nt; idx < M * oct; idx += nt)
-    {
-        const int r = idx / oct, kk = (idx - r * oct) * 8;
-        u32 src[8];
-        if (m.perm) perm_to_src(*(const u32x4*)(m.perm + kk), src);
-        else { for (int e = 0; e < 8; e++) src[e] = (u32)(kk + e); }
-        f16x8 x1, y1, n1;
-        gather_octet<MODE>(job, a, a2, r, src, x1, y1, n1);
-        finish_octet<MODE>(job, a_lds, rmf_lds, r, kk, x1, y1, n1);
-    }
-}

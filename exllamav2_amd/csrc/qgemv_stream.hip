@@ -11,11 +11,9 @@
 //   * the first ring fill of the largest bit-width section is issued BEFORE the prologue (run parameters travel in the
 //     kernel arguments = SGPRs, nothing has to be fetched to compute the addresses), so weights, q_perm, scales and
 //     descriptors are all in flight together: launch -> {everything} -> gather a[perm] -> decode -> reduce -> store;
-//   * about one workgroup per CU: a workgroup owns a CONTIGUOUS range of 16-column tiles and its waves split that
-//     range's super-chunks evenly (a wave's share may straddle two tiles), so every wave streams the same number of
-//     bytes whatever the shape; the activation vector is gathered through q_perm into LDS once per workgroup and all
-//     group-scale tables of the range are built in the same round trip; per-tile partial sums are combined through
-//     LDS in a fixed wave order (deterministic; no atomics, no cross-workgroup traffic);
+//   * a workgroup of W waves owns W/S tiles, S waves splitting each tile's K range; the activation vector is gathered
+//     through q_perm into LDS once per workgroup and shared by all its tiles; the S partial sums of a tile are combined
+//     through LDS in a fixed order (deterministic; no atomics, no cross-workgroup traffic);
 //   * decode = magic-number half2 unpack (qlayout.h) -> exact (q - zero) * scale in fp16 like reconstruct() -> B fragment
 //     of v_mfma_f32_16x16x32_f16, fp32 accumulate; RMSNorm / SiLU*up are folded into the activation staging, bias /
 //     residual / MoE weight into the epilogue (qgemv_common.h).
@@ -27,18 +25,16 @@ struct StreamArgs
 {
     GemvJob job[MAX_FUSED_MATS];
     int n_jobs;
-    int M;          // rows (<= MAX_STREAM_ROWS)
-    int probe;      // profiling aid (EXL2_GEMV_PROBE bit mask): 1 skip weight streaming, 2 skip activation staging,
-                    // 8 skip the early ring fill; results are wrong when 1 or 2 is set
+    int M;          // rows (<= MAX_GEMV_ROWS)
+    int S;          // waves per tile (power of two)
+    int TPW;        // tiles per workgroup = waves / S
 };
-#define MAX_STREAM_ROWS 8
-#define MAX_WAVE_TILES 4          // tiles one wave's share may touch (host guarantees it)
 
-// ---- streaming a contiguous stretch of one run ------------------------------------------------------------------------
+// ---- streaming one wave's slice of one run ---------------------------------------------------------------------------
 
 template <int BITS> DEV void ring_load(LaneWords<BITS>& b, const u32* p, int lane) { load_lane_words<BITS>(p, lane, b); }
 
-// items [0, n) at ptr0 + i * 64 * BITS words, chunk index chunk0 + 4 i.  With `preloaded`, b[0 .. min(n,4)) are in flight.
+// items [0, n) at ptr0 + i * 64 * BITS words, chunk index chunk0 + 4 i.  `b` may already hold items 0..min(n,4)-1.
 template <int BITS, bool GPTQ>
 DEV void stream_items(const u32* ptr0, int n, int chunk0, const PhaseCtx& ph, int lane, f32x4& acc,
                       LaneWords<BITS> (&b)[4], bool preloaded)
@@ -75,65 +71,57 @@ DEV void stream_items(const u32* ptr0, int n, int chunk0, const PhaseCtx& ph, in
         if (i + u < n) gemv_super<BITS, GPTQ, true>(b[u], ph, chunk0 + 4 * (i + u), 4, lane, acc);
 }
 
-// a stretch of `cnt` consecutive super-chunks of run `run`, starting at super-chunk s, of tile `tile`
-struct Stretch { QRun run; int s, cnt; };        // run by VALUE: pointers into the kernel-argument block would force it to scratch
+struct RunSlice { const u32* ptr0; int n; int chunk0; };
 
-DEV const u32* stretch_ptr(const Stretch& st, const QMatDev& m, int tile)
+// slice r of S of a full run, for one tile
+DEV RunSlice slice_of(const QRun& run, const QMatDev& m, int tile, int r, int S)
 {
-    const QRun& r = st.run;
-    return (r.in_tail ? m.tail : m.qw) + r.base_word + (size_t)tile * r.tile_stride + (size_t)st.s * (64u * r.bits);
+    const int F = (int)run.n_super;
+    const int i0 = (int)(((long long)r * F) / S), i1 = (int)(((long long)(r + 1) * F) / S);
+    RunSlice s;
+    s.n = i1 - i0;
+    s.ptr0 = (run.in_tail ? m.tail : m.qw) + run.base_word + (size_t)tile * run.tile_stride + (size_t)i0 * (64u * run.bits);
+    s.chunk0 = ((int)run.k_base >> 5) + 4 * i0;
+    return s;
 }
 
 template <int BITS, bool GPTQ>
-DEV void do_stretch(const Stretch& st, const QMatDev& m, int tile, const PhaseCtx& ph, int lane, f32x4& acc)
+DEV void do_run(const QRun& run, const QMatDev& m, int tile, int r, int S, const PhaseCtx& ph, int lane, f32x4& acc)
 {
-    const QRun& r = st.run;
-    const u32* p = stretch_ptr(st, m, tile);
-    const int chunk0 = ((int)r.k_base >> 5) + 4 * st.s;
-    if (r.nvalid_last != 4)
+    if (run.nvalid_last != 4)
     {
-        LaneWords<BITS> w;                                   // partial super-chunk: a run of its own, one item
+        // partial super-chunk (one per section at most): the split's first wave takes it
+        if (r != 0) return;
+        LaneWords<BITS> w;
+        const u32* p = m.tail + run.base_word + (size_t)tile * run.tile_stride;
         load_lane_words<BITS>(p, lane, w);
-        gemv_super<BITS, GPTQ, false>(w, ph, chunk0, (int)r.nvalid_last, lane, acc);
+        gemv_super<BITS, GPTQ, false>(w, ph, (int)run.k_base >> 5, (int)run.nvalid_last, lane, acc);
         return;
     }
+    const RunSlice s = slice_of(run, m, tile, r, S);
     LaneWords<BITS> b[4];
-    stream_items<BITS, GPTQ>(p, st.cnt, chunk0, ph, lane, acc, b, false);
+    stream_items<BITS, GPTQ>(s.ptr0, s.n, s.chunk0, ph, lane, acc, b, false);
 }
 
 template <bool GPTQ>
-DEV void do_stretch_any(const Stretch& st, const QMatDev& m, int tile, const PhaseCtx& ph, int lane, f32x4& acc)
+DEV void do_run_any(const QRun& run, const QMatDev& m, int tile, int r, int S, const PhaseCtx& ph, int lane, f32x4& acc)
 {
-    if constexpr (GPTQ) do_stretch<4, true>(st, m, tile, ph, lane, acc);
+    if constexpr (GPTQ) do_run<4, true>(run, m, tile, r, S, ph, lane, acc);
     else
     {
-        switch (st.run.bits)
+        switch (run.bits)
         {
-            case 4: do_stretch<4, false>(st, m, tile, ph, lane, acc); break;
-            case 8: do_stretch<8, false>(st, m, tile, ph, lane, acc); break;
-            case 6: do_stretch<6, false>(st, m, tile, ph, lane, acc); break;
-            case 5: do_stretch<5, false>(st, m, tile, ph, lane, acc); break;
-            case 3: do_stretch<3, false>(st, m, tile, ph, lane, acc); break;
-            default: do_stretch<2, false>(st, m, tile, ph, lane, acc); break;
+            case 4: do_run<4, false>(run, m, tile, r, S, ph, lane, acc); break;
+            case 8: do_run<8, false>(run, m, tile, r, S, ph, lane, acc); break;
+            case 6: do_run<6, false>(run, m, tile, r, S, ph, lane, acc); break;
+            case 5: do_run<5, false>(run, m, tile, r, S, ph, lane, acc); break;
+            case 3: do_run<3, false>(run, m, tile, r, S, ph, lane, acc); break;
+            default: do_run<2, false>(run, m, tile, r, S, ph, lane, acc); break;
         }
     }
 }
 
-// position `off` (0 <= off < items per tile) -> run and super-chunk inside it; limit = items left in that run
-DEV Stretch locate(const QMatDev& m, int off)
-{
-    Stretch st; st.run = m.runs[0]; st.s = 0; st.cnt = 0;
-    int acc_items = 0;
-    for (int i = 0; i < m.n_runs; i++)
-    {
-        const int n = (int)m.runs[i].n_super;
-        if (off < acc_items + n) { st.run = m.runs[i]; st.s = off - acc_items; st.cnt = n - st.s; return st; }
-        acc_items += n;
-    }
-    return st;
-}
-
-// MB = bit width whose first ring fill is issued ahead of the prologue when a wave's share starts in such a run; 0 = off
+// MB = bit width of the main (largest) run, whose first ring fill is issued ahead of the prologue; 0 = no early fill
 template <bool GPTQ, int MB>
 KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
 {
@@ -146,186 +134,124 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     const GemvJob& job = args.job[ji];
     const QMatDev& m = job.m;
     const int M = args.M;
+    const int S = args.S;
 
     const int t = tid();
     const int nt = nthreads();
     const int lane = lane_id();
     const int wv = uniform(wave_id());
     const int nw = nt >> 6;
+    const int gidx = wv / S;                                  // tile slot inside the workgroup
+    const int r = wv - gidx * S;                              // K-slice of that tile
     const int n_tiles = m.N / TILE_N;
-    const int tpw = job.tiles_per_wg;
-    const int t0 = (bid_x() - job.tile0) * tpw;               // first tile of this workgroup
-    const int ntl = min(tpw, n_tiles - t0);                   // tiles of this workgroup (>= 1)
-    const int ipt = job.items_per_tile;
-    const int tot = ntl * ipt;
-    const int i0 = (int)(((long long)wv * tot) / nw), i1 = (int)(((long long)(wv + 1) * tot) / nw);   // this wave's share
-    const int first_tile = i0 / ipt;                          // local index of the first tile this wave touches
+    int tile = (bid_x() - job.tile0) * args.TPW + gidx;
+    const bool tile_ok = tile < n_tiles;
+    if (!tile_ok) tile = n_tiles - 1;                         // idle slot: compute on a valid tile, never store
 
     f16* a_lds  = (f16*)smem;
-    f16* sc_all = (f16*)(smem + job.lds_scale_off);           // [tile_local][G][16]
-    f16* zp_all = (f16*)(smem + job.lds_zp_off);
+    f16* sc_lds = (f16*)(smem + job.lds_scale_off) + (size_t)gidx * m.G * 16;
+    f16* zp_lds = (f16*)(smem + job.lds_zp_off) + (size_t)gidx * m.G * 16;
     u16* cg_lds = (u16*)(smem + job.lds_cg_off);
     float* rmf_lds = (float*)(smem + job.lds_rmf_off) + wv * 16;
-    float* red  = (float*)(smem + job.lds_red_off);           // [wave][MAX_WAVE_TILES][M][16]
+    float* red  = (float*)smem;                               // aliases a_lds after the streaming
 
-    // ---- early ring fill: this wave's first stretch, when it lies in an MB-bit full run (addresses from SGPRs only) -----
+    // ---- early ring fill of the main run (addresses come from kernel arguments only) ---------------------------------
     LaneWords<(MB ? MB : 4)> pre[4];
-    Stretch es = locate(m, i0 - first_tile * ipt);
-    es.cnt = min(es.cnt, i1 - i0);
-    bool early = false;
+    RunSlice ms; ms.n = 0; ms.ptr0 = nullptr; ms.chunk0 = 0;
     if constexpr (MB != 0)
     {
-        early = i1 > i0 && es.run.bits == MB && es.run.nvalid_last == 4 && !(args.probe & 9);
-        if (early)
-        {
-            const u32* p = stretch_ptr(es, m, t0 + first_tile);
-            #pragma unroll
-            for (int u = 0; u < 4; u++) if (u < es.cnt) ring_load<MB>(pre[u], p + (size_t)u * (64 * MB), lane);
-        }
+        ms = slice_of(m.runs[m.main_run], m, tile, r, S);
+        #pragma unroll
+        for (int u = 0; u < 4; u++) if (u < ms.n) ring_load<MB>(pre[u], ms.ptr0 + (size_t)u * (64 * MB), lane);
     }
 
-    // ---- prologue, step 1: ISSUE every independent load (chunk map, the group scales of all tiles of this workgroup,
-    //      q_perm vectors of this thread's staging slots) before consuming any of them: together with the early ring fill
-    //      they cost ONE memory round trip.  Fixed slot counts keep it straight-line; leftovers take the loops below. ------
-    constexpr int NSC = 4;
-    const int n8 = m.N >> 3;
-    const int oct = m.K >> 3;
-    const int n_sc = ntl * m.G * 16;
-    u32 scw[NSC]; f16 scm[NSC];
-    #pragma unroll
-    for (int u = 0; u < NSC; u++)
+    // ---- prologue: independent loads first (chunk map, this tile's group scales), then the activation gather ----------
+    for (int i = t; i < (m.K >> 5); i += nt) cg_lds[i] = m.chunk_group[i];
     {
-        const int idx = t + u * nt;
-        scw[u] = 0; scm[u] = (f16)0.0f;
-        if (idx < n_sc)
+        const int n8 = m.N >> 3;
+        const int lt = r * 64 + lane;                         // thread index inside the tile's S-wave group
+        for (int idx = lt; idx < m.G * 16; idx += S * 64)
         {
-            const int tl = idx / (m.G * 16), rem = idx - tl * (m.G * 16);
-            const int g = rem >> 4, n = (t0 + tl) * 16 + (rem & 15);
-            scw[u] = m.q_scale[(size_t)g * n8 + (n >> 3)];
-            scm[u] = GPTQ ? m.scale_src[(size_t)g * m.N + n] : m.scale_src[g];
+            const int g = idx >> 4, c = idx & 15;
+            const int n = tile * 16 + c;
+            const u32 word = m.q_scale[(size_t)g * n8 + (n >> 3)];
+            const int nib = (word >> (4 * (n & 7))) & 15;
+            if constexpr (GPTQ)
+            {
+                sc_lds[idx] = m.scale_src[(size_t)g * m.N + n];
+                zp_lds[idx] = (f16)(float)(nib + 1);
+            }
+            else
+            {
+                sc_lds[idx] = (f16)(float)((nib + 1) * (nib + 1)) * m.scale_src[g];
+            }
         }
     }
-    u16 cgv[2] = {0, 0};
-    #pragma unroll
-    for (int u = 0; u < 2; u++) { const int i = t + u * nt; if (i < (m.K >> 5)) cgv[u] = m.chunk_group[i]; }
-    u32x4 pv[STAGE_SLOTS];
-    #pragma unroll
-    for (int u = 0; u < STAGE_SLOTS; u++)
-    {
-        const int idx = t + u * nt;
-        pv[u] = (u32x4){0, 0, 0, 0};
-        if (m.perm && idx < M * oct) pv[u] = *(const u32x4*)(m.perm + (idx % oct) * 8);
-    }
-
-    // RMSNorm statistics (rms_norm.cu:68-76,118): every wave reduces the whole row itself from L2 (no workgroup barrier)
     if (job.a_mode == A_RMSNORM)
     {
         for (int rr = 0; rr < M; rr++)
         {
             const f16x8* xr = (const f16x8*)(job.a + (size_t)rr * job.lda);
             float ss = 0.0f;
-            for (int j0 = 0; j0 < oct; j0 += 8 * 64)
+            for (int i = lane; i < (m.K >> 3); i += 64)
             {
-                f16x8 xv[8];
+                const f16x8 v = xr[i];
                 #pragma unroll
-                for (int u = 0; u < 8; u++) { const int i = j0 + u * 64 + lane; xv[u] = i < oct ? xr[i] : (f16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
-                #pragma unroll
-                for (int u = 0; u < 8; u++)
-                {
-                    #pragma unroll
-                    for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)xv[u][e], 65504.0f)); ss = fmaf(f, f, ss); }
-                }
+                for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)); ss = fmaf(f, f, ss); }
             }
             ss = wave_allreduce_add(ss);
             rmf_lds[rr] = fast_rsqrt(ss * (1.0f / (float)m.K) + job.norm_eps);
         }
     }
-
-    // ---- prologue, step 2: consume.  Tables -> LDS, then the activation gather through the pre-loaded permutation ------
-    #pragma unroll
-    for (int u = 0; u < 2; u++) { const int i = t + u * nt; if (i < (m.K >> 5)) cg_lds[i] = cgv[u]; }
-    for (int i = t + 2 * nt; i < (m.K >> 5); i += nt) cg_lds[i] = m.chunk_group[i];
-    #pragma unroll
-    for (int u = 0; u < NSC; u++)
     {
-        const int idx = t + u * nt;
-        if (idx < n_sc)
+        const int oct = m.K >> 3;
+        switch (job.a_mode)
         {
-            const int n = (idx % (m.G * 16)) & 15;            // column inside the tile; tiles start at multiples of 16
-            const int nib = (scw[u] >> (4 * (n & 7))) & 15;
-            if constexpr (GPTQ) { sc_all[idx] = scm[u]; zp_all[idx] = (f16)(float)(nib + 1); }       // q_matrix.cu:265-270
-            else sc_all[idx] = (f16)(float)((nib + 1) * (nib + 1)) * scm[u];                         // qdq_util.cuh:24-30
+            case A_PLAIN:    stage_rows<A_PLAIN>(job, m, job.a, job.a2, a_lds, rmf_lds, 0, oct, M, t, nt); break;
+            case A_RMSNORM:  stage_rows<A_RMSNORM>(job, m, job.a, job.a2, a_lds, rmf_lds, 0, oct, M, t, nt); break;
+            case A_SILU_MUL: stage_rows<A_SILU_MUL>(job, m, job.a, job.a2, a_lds, rmf_lds, 0, oct, M, t, nt); break;
+            case A_GELU_MUL: stage_rows<A_GELU_MUL>(job, m, job.a, job.a2, a_lds, rmf_lds, 0, oct, M, t, nt); break;
+            case A_SILU:     stage_rows<A_SILU>(job, m, job.a, job.a2, a_lds, rmf_lds, 0, oct, M, t, nt); break;
+            default:         stage_rows<A_GELU>(job, m, job.a, job.a2, a_lds, rmf_lds, 0, oct, M, t, nt); break;
         }
-    }
-    for (int idx = t + NSC * nt; idx < n_sc; idx += nt)
-    {
-        const int tl = idx / (m.G * 16), rem = idx - tl * (m.G * 16);
-        const int g = rem >> 4, n = (t0 + tl) * 16 + (rem & 15);
-        const int nib = (m.q_scale[(size_t)g * n8 + (n >> 3)] >> (4 * (n & 7))) & 15;
-        if constexpr (GPTQ) { sc_all[idx] = m.scale_src[(size_t)g * m.N + n]; zp_all[idx] = (f16)(float)(nib + 1); }
-        else sc_all[idx] = (f16)(float)((nib + 1) * (nib + 1)) * m.scale_src[g];
-    }
-    if (!(args.probe & 2))
-    switch (job.a_mode)
-    {
-        case A_PLAIN:    stage_preloaded<A_PLAIN>(job, m, job.a, job.a2, a_lds, rmf_lds, oct, M, t, nt, pv); break;
-        case A_RMSNORM:  stage_preloaded<A_RMSNORM>(job, m, job.a, job.a2, a_lds, rmf_lds, oct, M, t, nt, pv); break;
-        case A_SILU_MUL: stage_preloaded<A_SILU_MUL>(job, m, job.a, job.a2, a_lds, rmf_lds, oct, M, t, nt, pv); break;
-        case A_GELU_MUL: stage_preloaded<A_GELU_MUL>(job, m, job.a, job.a2, a_lds, rmf_lds, oct, M, t, nt, pv); break;
-        case A_SILU:     stage_preloaded<A_SILU>(job, m, job.a, job.a2, a_lds, rmf_lds, oct, M, t, nt, pv); break;
-        default:         stage_preloaded<A_GELU>(job, m, job.a, job.a2, a_lds, rmf_lds, oct, M, t, nt, pv); break;
     }
     block_sync();
 
-    // ---- stream this wave's share: stretches of runs, tile after tile --------------------------------------------------
+    // ---- stream -------------------------------------------------------------------------------------------------------
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     PhaseCtx ph;
-    ph.a_lds = a_lds; ph.cg_lds = cg_lds; ph.a_stride = job.a_stride; ph.M = M; ph.phase_k0 = 0;
+    ph.a_lds = a_lds; ph.sc_lds = sc_lds; ph.zp_lds = zp_lds; ph.cg_lds = cg_lds; ph.a_stride = job.a_stride;
+    ph.M = M; ph.phase_k0 = 0;
+
+    if constexpr (MB != 0) stream_items<MB, GPTQ>(ms.ptr0, ms.n, ms.chunk0, ph, lane, acc, pre, true);
+    for (int i = 0; i < m.n_runs; i++)
     {
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        const int c = lane & 15, j = lane >> 4;
-        int cur = i0;
-        bool first = true;
-        while (cur < i1 && !(args.probe & 1))
-        {
-            const int tl = cur / ipt;
-            Stretch st = locate(m, cur - tl * ipt);
-            st.cnt = min(st.cnt, i1 - cur);
-            ph.sc_lds = sc_all + (size_t)tl * m.G * 16;
-            ph.zp_lds = zp_all + (size_t)tl * m.G * 16;
-            if (MB != 0 && first && early)
-                stream_items<(MB ? MB : 4), GPTQ>(stretch_ptr(st, m, t0 + tl), st.cnt, ((int)st.run.k_base >> 5) + 4 * st.s,
-                                                 ph, lane, acc, pre, true);
-            else
-                do_stretch_any<GPTQ>(st, m, t0 + tl, ph, lane, acc);
-            first = false;
-            cur += st.cnt;
-            if (cur == i1 || cur - tl * ipt == ipt)
-            {
-                // tile finished (or share exhausted): park the partial sums of this tile
-                float* rp = red + ((size_t)(wv * MAX_WAVE_TILES + (tl - first_tile)) * M) * 16;
-                #pragma unroll
-                for (int q = 0; q < 4; q++) { const int row = j * 4 + q; if (row < M) rp[row * 16 + c] = acc[q]; }
-                acc = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            }
-        }
+        if (MB != 0 && i == m.main_run) continue;
+        do_run_any<GPTQ>(m.runs[i], m, tile, r, S, ph, lane, acc);
     }
 
-    // ---- combine the partial sums of every tile in wave order + epilogue -------------------------------------------------
+    // ---- combine the S slices of every tile (fixed order) + epilogue ----------------------------------------------------
     block_sync();
-    for (int idx = t; idx < ntl * M * 16; idx += nt)
     {
-        const int tl = idx / (M * 16);
-        const int rem = idx - tl * (M * 16);
-        const int row = rem >> 4, c = rem & 15;
-        float v = 0.0f;
-        if (!(args.probe & 1))
-        for (int w = 0; w < nw; w++)
+        const int c = lane & 15, j = lane >> 4;
+        #pragma unroll
+        for (int q = 0; q < 4; q++)
         {
-            const int w0 = (int)(((long long)w * tot) / nw), w1 = (int)(((long long)(w + 1) * tot) / nw);
-            if (w1 > w0 && w0 < (tl + 1) * ipt && w1 > tl * ipt)
-                v += red[((size_t)(w * MAX_WAVE_TILES + (tl - w0 / ipt)) * M + row) * 16 + c];
+            const int row = j * 4 + q;
+            if (row < M) red[(wv * 16 + row) * 16 + c] = acc[q];
         }
-        const int n = (t0 + tl) * 16 + c;
+    }
+    block_sync();
+    for (int idx = t; idx < args.TPW * M * 16; idx += nt)
+    {
+        const int slot = idx / (M * 16);
+        const int rem = idx - slot * (M * 16);
+        const int row = rem >> 4, c = rem & 15;
+        const int tl = (bid_x() - job.tile0) * args.TPW + slot;
+        if (tl >= n_tiles) continue;
+        float v = 0.0f;
+        for (int w = 0; w < S; w++) v += red[((slot * S + w) * 16 + row) * 16 + c];
+        const int n = tl * 16 + c;
         bool skip = false;
         if (job.r_weights)
         {
@@ -364,7 +290,7 @@ template <bool GPTQ, int MB>
 static void launch_variant(const StreamArgs& args, dim3 grid, dim3 block, u32 lds, void* stream)
 {
     static bool attr = false;
-    if (!attr && lds > 64 * 1024)
+    if (!attr)
     {
         (void)hipFuncSetAttribute((const void*)qgemv_stream_kernel<GPTQ, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
@@ -372,64 +298,61 @@ static void launch_variant(const StreamArgs& args, dim3 grid, dim3 block, u32 ld
     LAUNCH((qgemv_stream_kernel<GPTQ, MB>), grid, block, lds, stream, args);
 }
 
-static int env_int(const char* name, int dflt) { const char* v = getenv(name); return (v && atoi(v) > 0) ? atoi(v) : dflt; }
-
 // returns 0 when launched, 1 when this kernel does not apply (caller falls back to the generic kernel), < 0 on error
 int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream)
 {
     if (n_jobs < 1 || n_jobs > MAX_FUSED_MATS || M < 1) return -1;
-    if (M > MAX_STREAM_ROWS) return 1;
-    if (env_int("EXL2_GEMV_GENERIC", 0)) return 1;
-
-    long long items_total = 0;
-    int ipt[MAX_FUSED_MATS];
-    int mb = -1;
+    if (M > MAX_GEMV_ROWS) return 1;
+    const char* off = getenv("EXL2_GEMV_GENERIC");
+    if (off && atoi(off)) return 1;
+    long long tiles = 0;
+    int min_items = 1 << 30, mb = -1;
     for (int i = 0; i < n_jobs; i++)
     {
         const QMatDev& m = jobs[i].m;
         if (m.n_runs <= 0) return 1;
         if ((long long)M * (m.K + 8) * 2 > 96 * 1024) return 1;                 // activations must fit in LDS in one piece
-        ipt[i] = 0;
-        for (int r = 0; r < m.n_runs; r++) ipt[i] += m.runs[r].n_super;
-        items_total += (long long)ipt[i] * (m.N / TILE_N);
+        tiles += m.N / TILE_N;
         const QRun& mr = m.runs[m.main_run];
-        const int b = mr.nvalid_last == 4 ? (int)mr.bits : 0;
+        const int items = mr.nvalid_last == 4 ? (int)mr.n_super : 0;
+        if (items < min_items) min_items = items;
+        const int b = items > 0 ? (int)mr.bits : 0;
         if (mb < 0) mb = b; else if (mb != b) mb = 0;
     }
     if (mb < 0) mb = 0;
 
-    // ~one workgroup per CU, W waves each; every workgroup owns a contiguous tile range of ONE matrix
-    const int W = env_int("EXL2_GEMV_WAVES", 16);
-    const int target_wgs = env_int("EXL2_GEMV_WGS", num_cus());
+    // S waves per tile: enough wavefronts to keep ~12 per CU streaming, but at least ~4 super-chunks per wave
+    const long long want = (long long)num_cus() * 12;
+    int S = 1;
+    while (S < 16 && tiles * S < want && min_items / (S * 2) >= 4) S *= 2;
+    const char* fs = getenv("EXL2_GEMV_SPLIT");
+    if (fs && atoi(fs) > 0) S = atoi(fs);
+    int W = S > 8 ? S : 8;
+    const char* fw = getenv("EXL2_GEMV_WAVES");
+    if (fw && atoi(fw) >= S) W = atoi(fw);
+    const int TPW = W / S;
+
     StreamArgs args;
     memset(&args, 0, sizeof(args));
-    args.n_jobs = n_jobs; args.M = M;
-    args.probe = env_int("EXL2_GEMV_PROBE", 0);
+    args.n_jobs = n_jobs; args.M = M; args.S = S; args.TPW = TPW;
     u32 lds = 0;
     int blk0 = 0;
     for (int i = 0; i < n_jobs; i++)
     {
         GemvJob& j = args.job[i];
         j = jobs[i];
-        const int tiles = j.m.N / TILE_N;
-        long long share = ((long long)target_wgs * ipt[i] * tiles + items_total - 1) / items_total;     // workgroups of this job
-        if (share < 1) share = 1;
-        if (share > tiles) share = tiles;
-        int tpw = (int)((tiles + share - 1) / share);
-        // a wave's share (tpw * ipt / W items) must not touch more than MAX_WAVE_TILES tiles
-        while (tpw > 1 && ((long long)tpw * ipt[i] / W) / ipt[i] + 2 > MAX_WAVE_TILES) tpw--;
-        j.tiles_per_wg = tpw;
-        j.items_per_tile = ipt[i];
         j.tile0 = blk0;
-        blk0 += (tiles + tpw - 1) / tpw;
+        blk0 += (j.m.N / TILE_N + TPW - 1) / TPW;
         j.rows_per_phase = j.m.K;
         j.a_stride = j.m.K + 8;
-        u32 total = align16s((u32)M * j.a_stride * 2);
-        j.lds_scale_off = total;  total += align16s((u32)tpw * j.m.G * 32);
-        j.lds_zp_off = total;     total += gptq ? align16s((u32)tpw * j.m.G * 32) : 0;
-        j.lds_cg_off = total;     total += align16s((u32)(j.m.K >> 5) * 2);
-        j.lds_rmf_off = total;    total += 16 * 16 * 4;
-        j.lds_red_off = total;    total += (u32)W * MAX_WAVE_TILES * M * 16 * 4;
+        u32 a_bytes = align16s((u32)M * j.a_stride * 2);
+        const u32 red_bytes = (u32)W * 16 * 16 * 4;
+        if (a_bytes < red_bytes) a_bytes = red_bytes;
+        j.lds_scale_off = a_bytes;
+        j.lds_zp_off = j.lds_scale_off + align16s((u32)TPW * j.m.G * 32);
+        u32 total = j.lds_zp_off + (gptq ? align16s((u32)TPW * j.m.G * 32) : 0);
+        j.lds_cg_off = total;   total += align16s((u32)(j.m.K >> 5) * 2);
+        j.lds_rmf_off = total;  total += 16 * 16 * 4;
         j.lds_desc_off = total;
         if (total > lds) lds = total;
     }

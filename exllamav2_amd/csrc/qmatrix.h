@@ -63,8 +63,7 @@ struct GemvJob
     int tile0;                    // first block index (x) of this job inside a fused launch
     int a_stride;                 // LDS row stride of the staged activations, in halfs
     int rows_per_phase;           // max K rows staged per phase
-    u32 lds_scale_off, lds_zp_off, lds_cg_off, lds_rmf_off, lds_red_off, lds_desc_off;   // byte offsets in dynamic LDS
-    int tiles_per_wg, items_per_tile;   // streaming kernel: contiguous tile range per workgroup, super-chunks per tile
+    u32 lds_scale_off, lds_zp_off, lds_cg_off, lds_rmf_off, lds_desc_off;   // byte offsets in dynamic LDS
 };
 
 struct GemvArgs

@@ -40,6 +40,7 @@ typedef u32      u32x4 __attribute__((ext_vector_type(4)));
 #define DEV  inline
 #define HD   inline
 #define KERNEL static
+#define NOINLINE_DEV inline
 #define __launch_bounds__(...)
 #define WAVE 64
 
@@ -157,6 +158,13 @@ DEV float row16_allreduce_add(float v)
     v += emu_wave_read(v, emu_row_mirror(l));
     return v;
 }
+DEV float quad_allreduce_add(float v)
+{
+    const int l = lane_id();
+    v += emu_wave_read(v, l ^ 1);
+    v += emu_wave_read(v, l ^ 2);
+    return v;
+}
 DEV float row8_allreduce_add(float v)
 {
     const int l = lane_id();
@@ -208,6 +216,9 @@ DEV f32x4 mfma_16x16x32_f16(f16x8 a, f16x8 b, f32x4 c)
 }
 
 DEV float dot2_f32_f16(f16x2 a, f16x2 b, float c) { return c + (float)a.x * (float)b.x + (float)a.y * (float)b.y; }
+
+DEV u64 cycle_stamp() { return 0; }
+DEV void sched_fence() { }
 
 // ---- memory ----------------------------------------------------------------------------------------------------------
 template <typename T> DEV T ld_nt(const T* p) { return *p; }

@@ -37,12 +37,10 @@ def run(k, n, recipe, nm, iters=20, warm=False, act_order=True):
 
 
 r4 = ([4], [1.0], 128)
-for shape, nm in (((4096, 4096), 48), ((4096, 11008), 20)):
-    for env in ({}, {"EXL2_GEMV_PROBE": "1"}, {"EXL2_GEMV_PROBE": "2"}, {"EXL2_GEMV_PROBE": "3"}, {"EXL2_GEMV_PROBE": "8"},
-                {"EXL2_GEMV_SPLIT": "4", "EXL2_GEMV_WAVES": "4"}, {"EXL2_GEMV_SPLIT": "8", "EXL2_GEMV_WAVES": "16"},
-                {"EXL2_GEMV_SPLIT": "2", "EXL2_GEMV_WAVES": "4"}, {"EXL2_GEMV_SPLIT": "1", "EXL2_GEMV_WAVES": "4"},
-                {"EXL2_GEMV_GENERIC": "1"}):
-        for k_ in ("EXL2_GEMV_PROBE", "EXL2_GEMV_SPLIT", "EXL2_GEMV_WAVES", "EXL2_GEMV_GENERIC"): os.environ.pop(k_, None)
+KEYS = ("EXL2_GEMV_PROBE", "EXL2_GEMV_WGS", "EXL2_GEMV_WAVES", "EXL2_GEMV_GENERIC")
+for shape, nm in (((4096, 4096), 48), ((4096, 11008), 20), ((11008, 4096), 20), ((4096, 32000), 8)):
+    for env in ({}, {"EXL2_GEMV_PROBE": "16"}, {"EXL2_GEMV_PROBE": "18"}, {"EXL2_GEMV_WAVES": "8"}, {"EXL2_GEMV_WAVES": "8", "EXL2_GEMV_WGS": "512"}):
+        for k_ in KEYS: os.environ.pop(k_, None)
         os.environ.update(env)
         cold = run(*shape, r4, nm)
         warm = run(*shape, r4, nm, warm=True)
