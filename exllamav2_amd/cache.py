@@ -19,8 +19,9 @@ class ExLlamaV2Cache:
         self.max_seq_len = max_seq_len or cfg.max_seq_len
         self.current_seq_len = 0
         shape = (batch_size, self.max_seq_len, cfg.num_key_value_heads, cfg.head_dim)
-        self.key_states = [torch.zeros(shape, dtype=torch.float16, device=model.device) for _ in range(cfg.num_hidden_layers)]
-        self.value_states = [torch.zeros(shape, dtype=torch.float16, device=model.device) for _ in range(cfg.num_hidden_layers)]
+        n_layers = len(model.layers) if model.layers else cfg.num_hidden_layers          # layers held by this device
+        self.key_states = [torch.zeros(shape, dtype=torch.float16, device=model.device) for _ in range(n_layers)]
+        self.value_states = [torch.zeros(shape, dtype=torch.float16, device=model.device) for _ in range(n_layers)]
 
     def get_kv_state(self, layer_idx: int, batch_size: int, offset: int, width: int, page_size: int = 0,
                      cache_seqlens=None, block_table=None):
@@ -56,7 +57,7 @@ class ExLlamaV2Cache_Q4(ExLlamaV2Cache):
         kvh, hd, dev = cfg.num_key_value_heads, cfg.head_dim, model.device
         qshape = (batch_size, self.max_seq_len, kvh, hd // 2)
         sshape = (batch_size, self.max_seq_len, kvh, hd // 32)
-        L = cfg.num_hidden_layers
+        L = len(model.layers) if model.layers else cfg.num_hidden_layers
         self.key_states = [torch.zeros(qshape, dtype=torch.uint8, device=dev) for _ in range(L)]
         self.value_states = [torch.zeros(qshape, dtype=torch.uint8, device=dev) for _ in range(L)]
         self.key_scales = [torch.zeros(sshape, dtype=torch.float16, device=dev) for _ in range(L)]

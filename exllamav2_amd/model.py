@@ -50,20 +50,24 @@ class ExLlamaV2:
         self.lm_head = None
         self.loaded = False
 
-    def load(self, ck: dict):
-        """model.py:266-351 (single device): build every module's handles from a checkpoint dict."""
+    def load(self, ck: dict, layers=None):
+        """model.py:266-351: build the module handles from a checkpoint dict.  `layers` = the global layer indices this
+        device owns (layer split, model.py:176-263); embedding / final norm + head are built when their tensors are in
+        `ck`.  KV-cache slots are indexed by LOCAL layer position."""
         cfg = self.config
-        self.embed_tokens = ck["model.embed_tokens"]
-        for i in range(cfg.num_hidden_layers):
+        self.embed_tokens = ck.get("model.embed_tokens")
+        self.layer_ids = list(range(cfg.num_hidden_layers) if layers is None else layers)
+        for local_idx, i in enumerate(self.layer_ids):
             key = f"model.layers.{i}"
-            attn = ExLlamaV2Attention(self, key, i).load(ck)
-            mlp = ExLlamaV2MLP(self, key, i).load(ck)
+            attn = ExLlamaV2Attention(self, key, local_idx).load(ck)
+            mlp = ExLlamaV2MLP(self, key, local_idx).load(ck)
             self.layers.append((attn, mlp))
             self.modules += [attn, mlp]
-        self.norm = ExLlamaV2RMSNorm(self.ext, "model.norm", ck["model.norm"], cfg.norm_eps)
         vpad = (cfg.vocab_size + 31) // 32 * 32
-        self.lm_head = ExLlamaV2Linear(self.ext, "lm_head", cfg.hidden_size, vpad).load(ck["lm_head"])
         self.vocab_padded = vpad
+        if "lm_head" in ck:
+            self.norm = ExLlamaV2RMSNorm(self.ext, "model.norm", ck["model.norm"], cfg.norm_eps)
+            self.lm_head = ExLlamaV2Linear(self.ext, "lm_head", cfg.hidden_size, vpad).load(ck["lm_head"])
         self.loaded = True
         return self
 
@@ -75,7 +79,7 @@ class ExLlamaV2:
 
     def weight_bytes(self) -> int:
         """Algorithmic bytes one token streams through the linears."""
-        n = self.lm_head.weight_bytes()
+        n = self.lm_head.weight_bytes() if self.lm_head else 0
         for attn, mlp in self.layers:
             for lin in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj):
                 n += lin.weight_bytes()

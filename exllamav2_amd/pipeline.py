@@ -1,0 +1,179 @@
+"""Layer-split ("gpu_split", reference model.py:176-263) decode across ranks, one process per GPU.
+
+The reference keeps one process driving all GPUs and copies the hidden state device -> device at every split point
+(model.py:1014-1016, compat.py:53-139); only one GPU works at a time.  Here rank r owns layers [r L/N, (r+1) L/N) and
+N independent sequences are in flight, one per stage: at every tick each rank runs ITS layers on the sequence currently
+at its stage and hands the [hidden] fp16 vector to rank r+1 with one RCCL point-to-point send (xGMI is a point-to-point
+fabric: a ring of sends uses one link per hop, no collective is needed).  The last rank samples (greedy) and sends the
+token id to rank 0 in the same fixed-size message.  Per-GPU work per token is constant in N (weak scaling).
+
+Works with any torch.distributed backend: nccl (= RCCL) on GPUs, gloo in the CPU tests (with the emulation library).
+"""
+from __future__ import annotations
+
+import time
+
+import torch
+import torch.distributed as dist
+
+from .cache import ExLlamaV2Cache, PAGE_SIZE
+from .model import ExLlamaV2
+from .synth import synth_checkpoint
+
+
+def split_layers(n_layers: int, world: int, rank: int):
+    a = rank * n_layers // world
+    b = (rank + 1) * n_layers // world
+    return list(range(a, b))
+
+
+class PipelineStage:
+    """One rank's slice of the model + per-sequence decode state (device-side positions, like GreedyGraphDecoder)."""
+
+    def __init__(self, cfg, rank: int, world: int, device, n_seqs: int, max_seq_len: int, recipe: str = "4.0bpw",
+                 seed: int = 0, ext=None, use_graph: bool = True):
+        self.cfg, self.rank, self.world, self.n_seqs = cfg, rank, world, n_seqs
+        self.first, self.last = rank == 0, rank == world - 1
+        self.device = torch.device(device)
+        layers = split_layers(cfg.num_hidden_layers, world, rank)
+        ck = synth_checkpoint(cfg, device, recipe=recipe, seed=seed, layers=layers, with_embed=self.first,
+                              with_head=self.last)
+        self.model = ExLlamaV2(cfg, device=device, ext=ext).load(ck, layers=layers)
+        self.ext = self.model.ext
+        self.cache = ExLlamaV2Cache(self.model, batch_size=n_seqs, max_seq_len=max_seq_len)
+        pages = max_seq_len // PAGE_SIZE
+        dev = self.device
+        self.block_table = torch.arange(n_seqs * pages, dtype=torch.int32, device=dev).view(n_seqs, pages).contiguous()
+        self.seqlens = torch.zeros((n_seqs,), dtype=torch.int32, device=dev)
+        h = cfg.hidden_size
+        # message = [hidden] fp16; the last -> first hop carries the token id in its first 4 bytes
+        self.msg_in = torch.zeros((h,), dtype=torch.float16, device=dev)
+        self.msg_out = torch.zeros((h,), dtype=torch.float16, device=dev)
+        self.x = torch.zeros((1, 1, h), dtype=torch.float16, device=dev)
+        self.xn = torch.zeros((1, h), dtype=torch.float16, device=dev)
+        self.ids = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.logits = torch.zeros((1, self.model.vocab_padded), dtype=torch.float16, device=dev)
+        self.history = torch.zeros((n_seqs, max_seq_len + 2), dtype=torch.int32, device=dev)
+        self.use_graph = use_graph and self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=dev) if self.device.type == "cuda" else None
+        self.graphs = {}
+
+    # one stage step for sequence s: msg_in -> (layers) -> msg_out
+    def _step_eager(self, s: int):
+        m, ext, cfg = self.model, self.ext, self.cfg
+        if self.first:
+            self.ids.copy_(self.msg_in[:2].view(torch.int32))
+            ext.embed_rows(m.embed_tokens, self.ids, self.x.view(1, cfg.hidden_size))
+        else:
+            self.x.view(-1).copy_(self.msg_in)
+        sl, bt = self.seqlens[s:s + 1], self.block_table[s:s + 1]
+        for attn, mlp in m.layers:
+            # cache rows of sequence s through its own block-table row (pages of batch row s)
+            attn.forward(self.x, self.cache, 0, sl, bt)
+            mlp.forward(self.x)
+        ext.add_i32_(sl, 1)
+        if self.last:
+            ext.rms_norm(self.x.view(1, -1), m.norm.weight, self.xn, cfg.norm_eps)
+            ext.gemm_half_q_half(self.xn, m.lm_head.q_handle, self.logits)
+            ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history[s:s + 1], sl)
+            self.msg_out.zero_()
+            self.msg_out[:2].view(torch.int32).copy_(self.ids)
+        else:
+            self.msg_out.copy_(self.x.view(-1))
+
+    def capture(self):
+        if not self.use_graph:
+            return self
+        torch.cuda.synchronize()
+        with torch.cuda.stream(self.stream):
+            saved = self.seqlens.clone()
+            for s in range(self.n_seqs):
+                self.seqlens.fill_(self.cache.max_seq_len - 1)          # throw-away steps land in the last cache slot
+                self._step_eager(s)
+                self.seqlens.fill_(self.cache.max_seq_len - 1)
+                self.stream.synchronize()
+                self.ext.graph_begin_capture(self.stream.cuda_stream)
+                try:
+                    self._step_eager(s)
+                finally:
+                    self.graphs[s] = self.ext.graph_end_capture(self.stream.cuda_stream)
+            self.seqlens.copy_(saved)
+            self.stream.synchronize()
+        return self
+
+    def _on_stream(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def step(self, s: int):
+        with self._on_stream():
+            if self.use_graph:
+                self.ext.graph_launch(self.graphs[s], self.stream.cuda_stream)
+            else:
+                self._step_eager(s)
+
+    def exchange(self):
+        """msg_out -> next rank, msg_in <- previous rank (ring; last -> first carries the sampled token).  Issued on the
+        stage's own stream, so compute and hand-off are ordered without host synchronisation (RCCL: wait() is a stream
+        wait; gloo: it blocks the host)."""
+        nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+        with self._on_stream():
+            ops = [dist.P2POp(dist.isend, self.msg_out, nxt), dist.P2POp(dist.irecv, self.msg_in, prv)]
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+
+    def free(self):
+        for g in self.graphs.values():
+            self.ext.graph_free(g)
+        self.graphs = {}
+
+
+def run_pipeline(stage: PipelineStage, first_tokens, n_ticks: int):
+    """Drive `n_ticks` ticks.  At tick t rank r works on sequence (t - r) mod n_seqs (idle while the pipe fills).
+    Sequence s starts from token first_tokens[s].  Returns the number of tokens sampled by the last rank."""
+    n = stage.n_seqs
+    sampled = 0
+    for t in range(n_ticks):
+        s = (t - stage.rank) % n
+        active = t >= stage.rank
+        if stage.first and t < n:
+            # inject the prompt token of sequence t (instead of a token coming back from the last rank)
+            with stage._on_stream():
+                stage.msg_in.zero_()
+                stage.msg_in[:2].view(torch.int32).copy_(torch.tensor([int(first_tokens[t])], dtype=torch.int32).to(stage.device))
+        if active:
+            stage.step(s)
+            if stage.last:
+                sampled += 1
+        stage.exchange()
+    return sampled
+
+
+def run_layer_split_bench(cfg, args, rank: int, world: int, device):
+    """bench.py backend for --gpus N > 1: N sequences in flight over an N-stage layer split."""
+    n_seqs = world
+    max_seq = max(2048, ((args.ctx + (args.steps + args.warmup) // n_seqs + 2 + 255) // 256) * 256)
+    t_load = time.perf_counter()
+    stage = PipelineStage(cfg, rank, world, device, n_seqs, max_seq, recipe=args.recipe, use_graph=not args.no_graph)
+    stage.capture()
+    stage.seqlens.fill_(args.ctx)
+    torch.cuda.synchronize()
+    t_load = time.perf_counter() - t_load
+    first = list(range(1, n_seqs + 1))
+    # fill the pipe + warm-up (a "step" = one token sampled somewhere in the pipe = one tick once the pipe is full)
+    run_pipeline(stage, first, world + args.warmup)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    n = stage.n_seqs
+    base = world + args.warmup
+    for t in range(base, base + args.steps):
+        stage.step((t - rank) % n)
+        stage.exchange()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    stage.free()
+    return {"value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load}

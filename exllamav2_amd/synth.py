@@ -72,17 +72,25 @@ def synth_linear(k: int, n: int, recipe, device, gen: torch.Generator, sigma: fl
     return w
 
 
-def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_order: bool = True) -> dict:
-    """{'model.layers.0.self_attn.q_proj': {...}, ..., 'model.norm': tensor, 'model.embed_tokens': tensor}"""
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
+def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_order: bool = True,
+                     layers=None, with_embed: bool = True, with_head: bool = True) -> dict:
+    """{'model.layers.0.self_attn.q_proj': {...}, ..., 'model.norm': tensor, 'model.embed_tokens': tensor}.
+    Every layer draws from its own generator (seed, layer index), so a rank of a layer-split run can build exactly its
+    slice of the same checkpoint (`layers` = iterable of layer indices)."""
     rec = RECIPES[recipe]
     h, inter = cfg.hidden_size, cfg.intermediate_size
     qd = cfg.num_attention_heads * cfg.head_dim
     kvd = cfg.num_key_value_heads * cfg.head_dim
     ck = {}
     s_attn = 1.0 / math.sqrt(h)
-    for i in range(cfg.num_hidden_layers):
+
+    def gen_for(tag: int):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed * 100003 + tag)
+        return g
+
+    for i in (range(cfg.num_hidden_layers) if layers is None else layers):
+        gen = gen_for(i + 1)
         p = f"model.layers.{i}"
         ck[f"{p}.self_attn.q_proj"] = synth_linear(h, qd, rec["q_proj"], device, gen, s_attn, act_order)
         ck[f"{p}.self_attn.k_proj"] = synth_linear(h, kvd, rec["k_proj"], device, gen, s_attn, act_order)
@@ -94,8 +102,11 @@ def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_ord
         ck[f"{p}.mlp.down_proj"] = synth_linear(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
         ck[f"{p}.input_layernorm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
         ck[f"{p}.post_attention_layernorm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
-    ck["model.norm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
-    ck["model.embed_tokens"] = torch.randn(cfg.vocab_size, h, device=device, generator=gen).half()
-    vpad = (cfg.vocab_size + 31) // 32 * 32                                   # linear.py:82-88 pads out_features to x32
-    ck["lm_head"] = synth_linear(h, vpad, rec["lm_head"], device, gen, s_attn, act_order)
+    if with_embed:
+        ck["model.embed_tokens"] = torch.randn(cfg.vocab_size, h, device=device, generator=gen_for(0)).half()
+    if with_head:
+        gen = gen_for(99991)
+        ck["model.norm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
+        vpad = (cfg.vocab_size + 31) // 32 * 32                               # linear.py:82-88 pads out_features to x32
+        ck["lm_head"] = synth_linear(h, vpad, rec["lm_head"], device, gen, s_attn, act_order)
     return ck

@@ -1,0 +1,104 @@
+"""Layer-split pipeline across ranks (world_size 2, gloo, CPU emulation backend): tokens must equal the single-process
+model's greedy tokens exactly (same kernels, deterministic reductions)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.conftest import ROOT, build_emu_if_needed
+
+
+def _cfg():
+    from exllamav2_amd.config import ExLlamaV2Config
+    return ExLlamaV2Config(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                           num_key_value_heads=1, head_dim=64, vocab_size=96, max_seq_len=256, max_input_len=32)
+
+
+def _emu_ext():
+    from exllamav2_amd import _lib
+    from exllamav2_amd.ext import ExtC
+    return ExtC(_lib.Lib(build_emu_if_needed()), allow_cpu=True)
+
+
+def _worker(rank, world, port, n_ticks, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from exllamav2_amd.pipeline import PipelineStage, run_pipeline
+    stage = PipelineStage(_cfg(), rank, world, "cpu", n_seqs=world, max_seq_len=256, seed=5, ext=_emu_ext(), use_graph=False)
+    sampled = run_pipeline(stage, [3, 11], n_ticks)
+    if rank == world - 1:
+        np.save(out_path, stage.history.numpy())
+        assert sampled == n_ticks - (world - 1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_layer_split_pipeline_matches_single_process(tmp_path):
+    world, n_ticks = 2, 7                      # rank 1 samples at ticks 1..6: 3 tokens for each of the 2 sequences
+    out = str(tmp_path / "hist.npy")
+    build_emu_if_needed()
+    mp.spawn(_worker, args=(world, 29533, n_ticks, out), nprocs=world, join=True)
+    hist = np.load(out)
+    # single-process reference with the same checkpoint slices
+    from exllamav2_amd.cache import ExLlamaV2Cache
+    from exllamav2_amd.model import ExLlamaV2, GreedyGraphDecoder
+    from exllamav2_amd.synth import synth_checkpoint
+    cfg = _cfg()
+    model = ExLlamaV2(cfg, device="cpu", ext=_emu_ext()).load(synth_checkpoint(cfg, "cpu", seed=5))
+    for s, tok0 in enumerate([3, 11]):
+        cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=256)
+        dec = GreedyGraphDecoder(model, cache, batch_size=1)
+        dec.reset(torch.tensor([tok0]), 0)
+        dec.run(3, use_graph=False)
+        want = dec.tokens(0, 3).numpy()[0]
+        assert np.array_equal(hist[s, 1:4], want), (s, hist[s, :5], want)
+    model.unload()
+
+
+def test_split_layers_partition():
+    from exllamav2_amd.pipeline import split_layers
+    for L in (2, 22, 32, 80):
+        for w in (1, 2, 4, 8):
+            parts = [split_layers(L, w, r) for r in range(w)]
+            assert sum(parts, []) == list(range(L))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+@pytest.mark.gpu
+def test_pipeline_stage_graph_on_gpu():
+    """The per-sequence HIP graphs of a pipeline stage (world = 1: the stage is first and last), fed back by hand."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from exllamav2_amd.cache import ExLlamaV2Cache
+    from exllamav2_amd.model import ExLlamaV2, GreedyGraphDecoder
+    from exllamav2_amd.pipeline import PipelineStage
+    from exllamav2_amd.synth import synth_checkpoint
+    cfg = _cfg()
+    stage = PipelineStage(cfg, 0, 1, "cuda:0", n_seqs=2, max_seq_len=256, seed=5).capture()
+    toks = {0: [], 1: []}
+    cur = {0: 3, 1: 11}
+    for _ in range(3):
+        for s in (0, 1):
+            with stage._on_stream():
+                stage.msg_in.zero_()
+                stage.msg_in[:2].view(torch.int32).copy_(torch.tensor([cur[s]], dtype=torch.int32).cuda())
+            stage.step(s)
+            torch.cuda.synchronize()
+            cur[s] = int(stage.msg_out[:2].view(torch.int32).item())
+            toks[s].append(cur[s])
+    model = ExLlamaV2(cfg, device="cuda:0").load(synth_checkpoint(cfg, "cuda:0", seed=5))
+    for s, tok0 in enumerate([3, 11]):
+        cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=256)
+        dec = GreedyGraphDecoder(model, cache, batch_size=1).capture()
+        dec.reset(torch.tensor([tok0]), 0)
+        dec.run(3)
+        torch.cuda.synchronize()
+        assert dec.tokens(0, 3).cpu().numpy()[0].tolist() == toks[s]
+        dec.free()
+    stage.free()
