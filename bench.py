@@ -197,7 +197,11 @@ def main():
                       else f"decode tokens/s, {args.model} EXL2 {args.recipe}, bs=1 greedy",
             "value": round(result["value"], 2), "unit": "tokens/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(result["ms_per_step"], 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "weak",
+            # the reference's own published figure for THIS model/metric (README.md:71, RTX 4090)
+            "vs_baseline": round(result["value"] / 211.0, 3) if (args.model == "llama2-7b" and n_gpus == 1) else None,
+            "baseline_ref": "211 tokens/s, Llama2 7B EXL2 4.0bpw, RTX 4090 (reference README.md:71)",
+            "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{args.model} EXL2 {args.recipe} (synthetic weights, act-order), greedy decode, "
                                    f"bs=1 per sequence, ctx {args.ctx}+{args.warmup}..+{args.steps}, FP16 KV cache, "
                                    f"whole step in one HIP graph",
