@@ -92,6 +92,19 @@ def time_gemv_calls(model, dec, reps: int = 3):
     return total_ms / reps, launches // reps, nbytes // reps
 
 
+def pmc_traffic_gb(launches_per_step):
+    """HBM GB per decode step fetched by the q_gemm launches, from the committed PMC pass of this same command
+    (profiles/*_pmc_summary.json: separate `rocprofv3 --pmc FETCH_SIZE` run, KB per launch; x2 = the gfx950 correction for
+    wide coalesced reads, MI355X_MICROARCH.md section HBM).  None when no profile is committed."""
+    try:
+        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
+        d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+        kb = [v["avg"] for k, v in d.items() if k.startswith("FETCH_SIZE:") and "qgemv_stream_kernel<false, 4>" in k]
+        return round(kb[0] * 1024 * 2 * launches_per_step / 1e9, 3) if kb else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, recipe: str, seed: int = 0):
     """The oracle ("port": the reference has no CPU path) timed on the host cores: matmul(x,
     reconstruct) with pre-dequantized fp32 weights (compute-fair variant B), bounded sample = ONE transformer layer's 7
@@ -183,8 +196,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "qgemv_kernel<false> (all q_gemm launches of a decode step)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
-                "bytes_per_step": gemv_bytes, "launches_per_step": launches,
+                "traffic": pmc_traffic_gb(launches),
+                "traffic_unit": "GB per decode step (PMC FETCH_SIZE x2, profiles/)", "bytes_per_step": gemv_bytes, "launches_per_step": launches,
                 "avg_launch_us": round(gemv_ms * 1e3 / launches, 2),
                 "step_frac_of_weight_roofline": round((gemv_bytes + kv_bytes) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             },
