@@ -18,6 +18,7 @@ class ExLlamaV2Attention:
         self.o_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.o_proj", cfg.num_attention_heads * cfg.head_dim, h)
         self.pre_layernorm = None
         self.q_handle = None
+        self.fused_decode = True
 
     def load(self, ck: dict):
         cfg, m = self.model.config, self.model
@@ -56,22 +57,24 @@ class ExLlamaV2Attention:
                              apply_rope=False)
         if cache is None:
             raise RuntimeError("ExLlamaV2Attention.forward: a cache is required")
-        elif paged:
+        attn_out = m.temp_attn[:rows].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
+        if paged:
             cache.get_kv_state(self.layer_idx, b, 0, 0, 256, cache_seqlens, block_table)
             kc, vc = cache.paged_view(self.layer_idx)
-            ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, 0, cache_seqlens, block_table, cfg.rope_style)
+            sl, bt, past = cache_seqlens, block_table, 0
         else:
             kc, vc = cache.get_kv_state(self.layer_idx, b, 0, past_len)
-            ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, past_len, none_tensor, none_tensor, cfg.rope_style)
-        attn_out = m.temp_attn[:rows].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
-        if False:
-            pass
-        elif paged:
-            ext.paged_attn(q, kc, vc, attn_out, cache_seqlens, block_table, len_const=0, len_offset=q_len,
-                           scratch=m.attn_scratch)
+            sl, bt, past = None, None, past_len
+        # decode-shaped steps: one launch does RoPE + append + attention + split merge; otherwise three launches
+        fused = self.fused_decode and ext.attn_decode_fused(q, k, v, kc, vc, attn_out, m.sin, m.cos, sl, bt, past,
+                                                            cfg.rope_style, m.attn_scratch, m.attn_counters)
+        if not fused:
+            ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, past if not paged else 0,
+                               sl if paged else none_tensor, bt if paged else none_tensor, cfg.rope_style)
+            ext.paged_attn(q, kc, vc, attn_out, sl, bt, len_const=past, len_offset=q_len, scratch=m.attn_scratch)
+        if paged:
             cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
         else:
-            ext.paged_attn(q, kc, vc, attn_out, None, None, len_const=past_len, len_offset=q_len, scratch=m.attn_scratch)
             cache.store_kv_state(self.layer_idx, b, past_len, q_len)
         ext.q_attn_forward_2(self.q_handle, hidden_states, attn_out, b, q_len)
         return hidden_states

@@ -195,6 +195,248 @@ KERNEL void __launch_bounds__(256) attn_combine_kernel(const AttnArgs a, int hd)
     }
 }
 
+// ---- one-launch decode step: RoPE(q, new k) + append(new k, v) + split-KV attention + combine -----------------------------
+//
+// The three launches above (rope_append -> attn_decode -> attn_combine) cost ~4-5 us each on MI355X whatever their size
+// (launch-bound), i.e. more than the K/V stream itself at short contexts.  This kernel does the whole
+// flash_attn_with_kvcache(k=new_k, v=new_v, ...) contract (attn.py:602-613) in one launch:
+//   * q rows are rotated in registers (rope.cu NeoX numerics; the rotation partner d +- HDIM/2 lives in lane +- LPK/2);
+//   * keys at positions >= past come from k_new / v_new, are rotated, used, and written to the cache by the workgroup
+//     whose key slice owns them (row block 0 only, so every cache slot has exactly one writer);
+//   * the number of active splits is chosen ON THE DEVICE from the sequence length (the grid is fixed inside a HIP graph);
+//   * splits meet through a ticket counter per (batch, kv head, row block): the last arriver merges the partials
+//     (agent-scope release/acquire, cdna_hip_programming.md G16) and resets the counter for the next launch.
+struct FusedArgs
+{
+    const f16* q; const f16* k_new; const f16* v_new;   // [b, s, H|KVH, hd], un-rotated
+    f16* k_cache; f16* v_cache;
+    const f16* sin; const f16* cos;                     // [max_seq, HDIM]
+    const int* cache_seqlens; const int* block_table;
+    f16* out; float* part_o; float* part_ml; u32* counters;
+    int b, s, H, KVH;
+    int page_size, page_shift, pages_per_seq;
+    int past_const, nsplit, rope, keys_per_split_min;
+    float scale;
+};
+
+template <int LPK> DEV f16x8 rope_neox_frag(f16x8 x, const f16* sin, const f16* cos, int pos, int dl)
+{
+    // lane dl holds columns [8 dl, 8 dl + 8); its partner columns (+- HDIM/2) sit in lane dl ^ (LPK/2)
+    constexpr int HL = LPK / 2;
+    u32x4 u = __builtin_bit_cast(u32x4, x);
+    u32x4 pu;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) pu[i] = swz_xor_u32<HL>(u[i]);
+    const f16x8 partner = __builtin_bit_cast(f16x8, pu);
+    const size_t off = (size_t)pos * (LPK * 8) + (size_t)(dl % HL) * 8;
+    const f16x8 cs = *(const f16x8*)(cos + off);
+    f16x8 sn = *(const f16x8*)(sin + off);
+    if (dl < HL) sn = -sn;                               // left half: l' = l cos + r (-sin); right: r' = r cos + l sin
+    const f16x8 t = partner * sn;
+    return __builtin_elementwise_fma(x, cs, t);
+}
+
+template <int HDIM, int RB>
+KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs a)
+{
+    DYN_SMEM(smem);
+    constexpr int LPK = HDIM / 8;
+    constexpr int KPW = 64 / LPK;
+    constexpr int NSTREAM = ATT_WAVES * KPW;
+    constexpr int ROWF = HDIM + 2;
+
+    const int kh = bid_x();
+    const int split = bid_y();
+    const int G = a.H / a.KVH;
+    const int R = a.s * G;
+    const int rblocks = (R + RB - 1) / RB;
+    const int b = bid_z() / rblocks;
+    const int rblk = bid_z() % rblocks;
+    const int r0 = rblk * RB;
+    const int nrows = min(RB, R - r0);
+
+    const int lane = lane_id();
+    const int wv = wave_id();
+    const int group = lane / LPK;
+    const int dl = lane % LPK;
+
+    int past = a.past_const;
+    if (a.cache_seqlens) { const int p = a.cache_seqlens[b]; past += p > 0 ? p : 0; }
+    const int total = past + a.s;
+    int eff = (total + a.keys_per_split_min - 1) / a.keys_per_split_min;
+    eff = eff < 1 ? 1 : (eff > a.nsplit ? a.nsplit : eff);
+    if (split >= eff) return;
+    int kps = (total + eff - 1) / eff;
+    kps = (kps + 15) & ~15;
+    const int k_start = split * kps;
+    const int k_end = min(total, k_start + kps);
+
+    f16x8 qf[RB];
+    int limit[RB];
+    #pragma unroll
+    for (int r = 0; r < RB; r++)
+    {
+        const int rr = r0 + (r < nrows ? r : 0);
+        const int j = rr / G, g = rr - j * G;
+        f16x8 raw = *(const f16x8*)(a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM + dl * 8);
+        if (a.rope) raw = rope_neox_frag<LPK>(raw, a.sin, a.cos, past + j, dl);
+        qf[r] = raw;
+        limit[r] = past + j + 1;
+    }
+
+    float m[RB], l[RB], o[RB][8];
+    #pragma unroll
+    for (int r = 0; r < RB; r++)
+    {
+        m[r] = NEG_BIG; l[r] = 0.0f;
+        #pragma unroll
+        for (int e = 0; e < 8; e++) o[r][e] = 0.0f;
+    }
+
+    auto attend = [&](const f16x8 kf, const f16x8 vf, const int kpos, const bool in_range)
+    {
+        #pragma unroll
+        for (int r = 0; r < RB; r++)
+        {
+            if (r < nrows)
+            {
+                float d = 0.0f;
+                #pragma unroll
+                for (int e = 0; e < 4; e++)
+                    d = dot2_f32_f16((f16x2){qf[r][2 * e], qf[r][2 * e + 1]}, (f16x2){kf[2 * e], kf[2 * e + 1]}, d);
+                d = group_allreduce_add<LPK>(d);
+                const float sc = d * a.scale;
+                const bool valid = in_range && kpos < limit[r];
+                const float m_new = valid ? fmaxf(m[r], sc) : m[r];
+                const float alpha = fast_exp(m[r] - m_new);
+                const float p = valid ? fast_exp(sc - m_new) : 0.0f;
+                m[r] = m_new;
+                l[r] = l[r] * alpha + p;
+                #pragma unroll
+                for (int e = 0; e < 8; e++) o[r][e] = o[r][e] * alpha + p * (float)vf[e];
+            }
+        }
+    };
+    auto slot_of = [&](const int kp) -> size_t
+    {
+        if (a.block_table)
+            return (size_t)a.block_table[(size_t)b * a.pages_per_seq + (kp >> a.page_shift)] * a.page_size
+                   + (kp & (a.page_size - 1));
+        return (size_t)b * a.page_size + kp;
+    };
+
+    const size_t row_stride = (size_t)a.KVH * HDIM;
+    // keys already in the cache
+    const int k_old_end = min(k_end, past);
+    for (int base = k_start + wv * KPW; base < k_old_end; base += ATT_WAVES * KPW)
+    {
+        const int kpos = base + group;
+        const bool in_range = kpos < k_old_end;
+        const int kp = in_range ? kpos : k_start;
+        const size_t off = slot_of(kp) * row_stride + (size_t)kh * HDIM + dl * 8;
+        const f16x8 kf = ld_nt((const f16x8*)(a.k_cache + off));
+        const f16x8 vf = ld_nt((const f16x8*)(a.v_cache + off));
+        attend(kf, vf, kpos, in_range);
+    }
+    // keys of this step: rotate, use, append
+    for (int base = max(k_start, past) + wv * KPW; base < k_end; base += ATT_WAVES * KPW)
+    {
+        const int kpos = base + group;
+        const bool in_range = kpos < k_end;
+        const int kp = in_range ? kpos : k_end - 1;
+        const size_t src = (((size_t)b * a.s + (kp - past)) * a.KVH + kh) * HDIM + dl * 8;
+        f16x8 kf = *(const f16x8*)(a.k_new + src);
+        const f16x8 vf = *(const f16x8*)(a.v_new + src);
+        if (a.rope) kf = rope_neox_frag<LPK>(kf, a.sin, a.cos, kp, dl);
+        if (in_range && rblk == 0 && a.k_cache)
+        {
+            const size_t off = slot_of(kp) * row_stride + (size_t)kh * HDIM + dl * 8;
+            *(f16x8*)(a.k_cache + off) = kf;
+            *(f16x8*)(a.v_cache + off) = vf;
+        }
+        attend(kf, vf, kpos, in_range);
+    }
+
+    // merge the NSTREAM independent softmax streams of this workgroup
+    float* st = (float*)smem;
+    u32* ticket_lds = (u32*)(st + (size_t)NSTREAM * RB * ROWF);
+    const int stream = wv * KPW + group;
+    #pragma unroll
+    for (int r = 0; r < RB; r++)
+    {
+        if (r < nrows)
+        {
+            float* p = st + ((size_t)stream * RB + r) * ROWF;
+            #pragma unroll
+            for (int e = 0; e < 8; e++) p[dl * 8 + e] = o[r][e];
+            if (dl == 0) { p[HDIM] = m[r]; p[HDIM + 1] = l[r]; }
+        }
+    }
+    block_sync();
+    for (int idx = tid(); idx < nrows * HDIM; idx += nthreads())
+    {
+        const int r = idx / HDIM, d = idx - r * HDIM;
+        float M = NEG_BIG;
+        for (int s2 = 0; s2 < NSTREAM; s2++) M = fmaxf(M, st[((size_t)s2 * RB + r) * ROWF + HDIM]);
+        float L = 0.0f, O = 0.0f;
+        for (int s2 = 0; s2 < NSTREAM; s2++)
+        {
+            const float* p = st + ((size_t)s2 * RB + r) * ROWF;
+            const float w = fast_exp(p[HDIM] - M);
+            L += p[HDIM + 1] * w;
+            O += p[d] * w;
+        }
+        const int rr = r0 + r;
+        const int j = rr / G, g = rr - j * G;
+        const size_t qrow = ((size_t)b * a.s + j) * a.H + kh * G + g;
+        if (eff == 1)
+        {
+            a.out[qrow * HDIM + d] = (f16)(L > 0.0f ? O / L : 0.0f);
+        }
+        else
+        {
+            a.part_o[(qrow * a.nsplit + split) * HDIM + d] = O;
+            if (d == 0)
+            {
+                a.part_ml[(qrow * a.nsplit + split) * 2 + 0] = M;
+                a.part_ml[(qrow * a.nsplit + split) * 2 + 1] = L;
+            }
+        }
+    }
+    if (eff == 1) return;
+
+    // hand-off: the last split to arrive merges
+    wait_vmcnt0();
+    block_sync();
+    u32* counter = a.counters + ((size_t)b * a.KVH + kh) * rblocks + rblk;
+    if (tid() == 0)
+    {
+        fence_release_agent();
+        *ticket_lds = ticket_add_agent(counter, 1u);
+    }
+    block_sync();
+    if (*ticket_lds != (u32)(eff - 1)) return;
+    fence_acquire_agent();
+    for (int idx = tid(); idx < nrows * HDIM; idx += nthreads())
+    {
+        const int r = idx / HDIM, d = idx - r * HDIM;
+        const int rr = r0 + r;
+        const int j = rr / G, g = rr - j * G;
+        const size_t qrow = ((size_t)b * a.s + j) * a.H + kh * G + g;
+        float M = NEG_BIG;
+        for (int s2 = 0; s2 < eff; s2++) M = fmaxf(M, load_agent_f32(a.part_ml + (qrow * a.nsplit + s2) * 2));
+        float L = 0.0f, O = 0.0f;
+        for (int s2 = 0; s2 < eff; s2++)
+        {
+            const float w = fast_exp(load_agent_f32(a.part_ml + (qrow * a.nsplit + s2) * 2) - M);
+            L += load_agent_f32(a.part_ml + (qrow * a.nsplit + s2) * 2 + 1) * w;
+            O += load_agent_f32(a.part_o + (qrow * a.nsplit + s2) * HDIM + d) * w;
+        }
+        a.out[qrow * HDIM + d] = (f16)(L > 0.0f ? O / L : 0.0f);
+    }
+    if (tid() == 0) store_relaxed_agent(counter, 0u);
+}
+
 // ---- RoPE on q / new k + append of new k, v into the (paged) cache at device-side positions ---------------------------
 
 struct RopeAppendArgs
@@ -373,6 +615,73 @@ int exl2_paged_attn(const void* q, const void* k_cache, const void* v_cache, voi
     if (nsplit > 1)
         LAUNCH(attn_combine_kernel, dim3((unsigned)(batch * q_len * num_heads)), dim3(head_dim < 256 ? head_dim : 256), 0,
                stream, a, head_dim);
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
+}
+
+// One-launch decode-step attention (see attn_fused_kernel).  Returns 1 (nothing launched) when the shape is outside what
+// the fused kernel covers -- the caller then uses exl2_rope_kv_append + exl2_paged_attn.  q / k_new are NOT modified.
+// `counters`: >= batch * kv_heads * row_blocks zeroed u32, left zeroed.  Positions: past = past_const + cache_seqlens[b].
+int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, void* k_cache, void* v_cache, void* out,
+                           const void* sin, const void* cos, const int* cache_seqlens, const int* block_table,
+                           int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                           int page_size, int pages_per_seq, int past_const, float softmax_scale,
+                           int rope_style, int sincos_size, int nsplit, void* scratch, long long scratch_bytes,
+                           void* counters, int n_counters, void* stream)
+{
+    EXL2_REQUIRE(q && k_new && v_new && k_cache && v_cache && out, "attn_decode_fused: null argument");
+    EXL2_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "attn_decode_fused: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
+    EXL2_REQUIRE(rope_style == 0 || (sin && cos), "attn_decode_fused: sin/cos tables missing");
+    if (batch <= 0 || q_len <= 0) return EXL2_OK;
+    if (!(head_dim == 64 || head_dim == 128 || head_dim == 256)) return 1;
+    if (!(rope_style == 0 || (rope_style == 2 && (sincos_size <= 0 || sincos_size == head_dim)))) return 1;
+    const int G = num_heads / num_kv_heads;
+    const int R = q_len * G;
+    if (R > 32) return 1;
+    const int rb = R >= 8 ? 8 : (R >= 4 ? 4 : (R >= 2 ? 2 : 1));
+    const int rblocks = (R + rb - 1) / rb;
+    if (!counters || (long long)batch * num_kv_heads * rblocks > n_counters) return 1;
+    FusedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = (const f16*)q; a.k_new = (const f16*)k_new; a.v_new = (const f16*)v_new;
+    a.k_cache = (f16*)k_cache; a.v_cache = (f16*)v_cache; a.out = (f16*)out;
+    a.sin = (const f16*)sin; a.cos = (const f16*)cos;
+    a.cache_seqlens = cache_seqlens; a.block_table = block_table; a.counters = (u32*)counters;
+    a.b = batch; a.s = q_len; a.H = num_heads; a.KVH = num_kv_heads;
+    a.page_size = page_size; a.pages_per_seq = pages_per_seq; a.page_shift = ilog2_exact(page_size);
+    EXL2_REQUIRE(!block_table || a.page_shift >= 0, "attn_decode_fused: page_size %d must be a power of two", page_size);
+    a.past_const = past_const; a.rope = rope_style != 0; a.scale = softmax_scale;
+    a.keys_per_split_min = 128;
+    if (nsplit <= 0)
+    {
+        const long long base = (long long)num_kv_heads * batch * rblocks;
+        nsplit = (int)((512 + base - 1) / base);
+        if (nsplit > 16) nsplit = 16;
+        if (nsplit < 1) nsplit = 1;
+    }
+    const long long need = exl2_paged_attn_scratch_bytes(batch * q_len * num_heads, head_dim, nsplit);
+    if (need > scratch_bytes || (need > 0 && !scratch)) nsplit = 1;
+    a.nsplit = nsplit;
+    if (nsplit > 1)
+    {
+        a.part_o = (float*)scratch;
+        a.part_ml = a.part_o + (size_t)batch * q_len * num_heads * nsplit * head_dim;
+    }
+    dim3 grid((unsigned)num_kv_heads, (unsigned)nsplit, (unsigned)(batch * rblocks));
+    const int lpk = head_dim / 8, kpw = 64 / lpk;
+    const size_t lds = (size_t)ATT_WAVES * kpw * rb * (head_dim + 2) * 4 + 16;
+#define FUSED_CASE(HDIM_, RB_) LAUNCH((attn_fused_kernel<HDIM_, RB_>), grid, dim3(ATT_WAVES * 64), lds, stream, a)
+#define FUSED_HD(HDIM_) \
+    do { static bool attr_done = false; \
+         if (!attr_done) { (void)hipFuncSetAttribute((const void*)attn_fused_kernel<HDIM_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                           (void)hipFuncSetAttribute((const void*)attn_fused_kernel<HDIM_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+         switch (rb) { case 1: FUSED_CASE(HDIM_, 1); break; case 2: FUSED_CASE(HDIM_, 2); break; \
+                       case 4: FUSED_CASE(HDIM_, 4); break; default: FUSED_CASE(HDIM_, 8); break; } } while (0)
+    if (head_dim == 64) FUSED_HD(64);
+    else if (head_dim == 128) FUSED_HD(128);
+    else FUSED_HD(256);
+#undef FUSED_HD
+#undef FUSED_CASE
     HIP_TRY(hipGetLastError());
     return EXL2_OK;
 }

@@ -135,6 +135,14 @@ template <typename T> DEV void st_nt(T* p, T v) { __builtin_nontemporal_store(v,
 DEV float atomic_add_f32(float* p, float v) { return atomicAdd(p, v); }
 DEV u32 atomic_add_u32(u32* p, u32 v) { return atomicAdd(p, v); }
 
+// ---- inter-workgroup hand-off inside one launch (cdna_hip_programming.md G16: agent scope, placement independent) ------
+DEV void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+DEV void fence_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+DEV void fence_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+DEV u32 ticket_add_agent(u32* p, u32 v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV float load_agent_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void store_relaxed_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // dynamic LDS (16-byte aligned base, guide G17)
 #define DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define SHARED __shared__

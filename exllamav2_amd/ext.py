@@ -235,6 +235,26 @@ class ExtC:
             self._ptr(past_lens), self._ptr(block_table), page_size, pps, int(rope_style), int(sincos_size),
             self._stream(q)))
 
+    def attn_decode_fused(self, q, k_new, v_new, k_cache, v_cache, out, sin, cos, cache_seqlens, block_table,
+                          past_const: int, rope_style: int, scratch, counters, softmax_scale: float | None = None,
+                          sincos_size: int = 0, nsplit: int = 0) -> bool:
+        """One launch for RoPE + append + attention + merge; False when the shape needs the three-launch path."""
+        b, s, nh, hd = q.shape
+        kvh = k_new.shape[2]
+        page_size = k_cache.shape[1]
+        pps = 0 if _is_none(block_table) else block_table.shape[1]
+        scale = hd ** -0.5 if softmax_scale is None else softmax_scale
+        sb = 0 if scratch is None else scratch.numel() * scratch.element_size()
+        rc = self.lib.check(self.lib.exl2_attn_decode_fused(
+            self._ptr(q, torch.float16, "q"), self._ptr(k_new, torch.float16, "k_new"),
+            self._ptr(v_new, torch.float16, "v_new"), self._ptr(k_cache, torch.float16, "k_cache"),
+            self._ptr(v_cache, torch.float16, "v_cache"), self._ptr(out, torch.float16, "out"), self._ptr(sin),
+            self._ptr(cos), self._ptr(cache_seqlens, torch.int32, "cache_seqlens"),
+            self._ptr(block_table, torch.int32, "block_table"), b, s, nh, kvh, hd, page_size, pps, int(past_const),
+            float(scale), int(rope_style), int(sincos_size), int(nsplit), self._ptr(scratch), sb,
+            self._ptr(counters, torch.int32, "counters"), 0 if counters is None else counters.numel(), self._stream(q)))
+        return rc == 0
+
     def flash_attn_with_kvcache(self, q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, block_table=None,
                                 causal: bool = True, softmax_scale: float | None = None, scratch=None):
         """Drop-in for flash_attn.flash_attn_with_kvcache as the reference calls it (attn.py:602-613)."""

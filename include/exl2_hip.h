@@ -92,6 +92,17 @@ int exl2_rope_kv_append(void* q, void* k_new, const void* v_new, void* k_cache, 
                         int head_dim, int past_len, const int* past_lens, const int* block_table,
                         int page_size, int pages_per_seq, int rope_style, int sincos_size, void* stream);
 
+/* One-launch decode step: RoPE(q, k_new) + append(k_new, v_new) + split-KV attention + merge == the whole
+   flash_attn_with_kvcache(q, k_cache, v_cache, k = k_new, v = v_new, cache_seqlens, block_table, causal = True) call of
+   attn.py:602-613 preceded by rope_ (ext_bindings.cpp:123).  Returns 1 without launching when the shape is not covered
+   (then use exl2_rope_kv_append + exl2_paged_attn).  counters: zeroed u32[n_counters], left zeroed. */
+int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, void* k_cache, void* v_cache, void* out,
+                           const void* sin, const void* cos, const int* cache_seqlens, const int* block_table,
+                           int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                           int page_size, int pages_per_seq, int past_const, float softmax_scale,
+                           int rope_style, int sincos_size, int nsplit, void* scratch, long long scratch_bytes,
+                           void* counters, int n_counters, void* stream);
+
 /* ---- fused modules --------------------------------------------------------------------------------------------------- */
 
 /* make_q_attn (ext_qattn.cpp:24-104), q_attn_forward_1 (:115-159), q_attn_forward_2 (:161-191) */

@@ -191,6 +191,109 @@ def test_attention_paged_with_append(be):
     assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want))
 
 
+@pytest.mark.parametrize("hd,nh,kvh,s,rope", [(128, 4, 4, 1, True), (128, 8, 2, 1, True), (64, 4, 2, 2, True),
+                                               (128, 4, 2, 3, False), (256, 2, 1, 1, True)])
+def test_attention_fused_decode_step(be, hd, nh, kvh, s, rope):
+    """One launch == rope_(q, k) + flash_attn_with_kvcache(k=new_k, v=new_v) (attn.py:602-613): bit-exact cache append
+    (rope.cu numerics), attention within tolerance, for sequence lengths on both sides of the device-side split choice,
+    ticket counters left zeroed; repeated so a stale ticket or partial would show."""
+    rng = np.random.default_rng(16)
+    pages, ps = 7, 256
+    b = 2
+    table = np.array([[2, 0, 4], [1, 3, 5]], dtype=np.int32)
+    sin, cos = OM.rope_tables(1024, hd, neox=True)
+    scratch = torch.zeros((be.ext.paged_attn_scratch_bytes(b * s * nh, hd, 16) // 4 + 1,), dtype=torch.float32,
+                          device=be.device)
+    counters = torch.zeros((64,), dtype=torch.int32, device=be.device)
+    for seqlens in ([0, 5], [255, 300], [700, 127], [513, 640]):
+        seqlens = np.array(seqlens, dtype=np.int32)
+        kc = rng.standard_normal((pages, ps, kvh, hd)).astype(F16)
+        vc = rng.standard_normal((pages, ps, kvh, hd)).astype(F16)
+        q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+        kn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+        vn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+        q_r = OM.rope_(q, sin, cos, seqlens, neox=True) if rope else q
+        k_r = OM.rope_(kn, sin, cos, seqlens, neox=True) if rope else kn
+        kc_ref, vc_ref = kc.copy(), vc.copy()
+        want = OM.paged_attention(q_r, k_r, vn, kc_ref, vc_ref, seqlens, table)
+        kct, vct, qt, knt = be.t(kc), be.t(vc), be.t(q), be.t(kn)
+        out = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+        ok = be.ext.attn_decode_fused(qt, knt, be.t(vn), kct, vct, out, be.t(sin), be.t(cos), be.t(seqlens), be.t(table),
+                                      0, 2 if rope else 0, scratch, counters)
+        assert ok
+        assert np.array_equal(be.n(qt).view(np.uint16), q.view(np.uint16))          # inputs untouched
+        assert np.array_equal(be.n(kct).view(np.uint16), kc_ref.view(np.uint16))
+        assert np.array_equal(be.n(vct).view(np.uint16), vc_ref.view(np.uint16))
+        got = be.n(out)
+        assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want)), seqlens
+        assert int(be.n(counters).sum()) == 0
+
+
+def test_attention_fused_contiguous_and_fallback(be):
+    rng = np.random.default_rng(17)
+    b, T, past, hd, nh, kvh, s = 2, 512, 300, 128, 4, 2, 2
+    sin, cos = OM.rope_tables(1024, hd, neox=True)
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    k = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    v = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    kn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    vn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    pos = np.full((b,), past, dtype=np.int32)
+    q_r, k_r = OM.rope_(q, sin, cos, pos, neox=True), OM.rope_(kn, sin, cos, pos, neox=True)
+    k_full, v_full = k.copy(), v.copy()
+    k_full[:, past:past + s], v_full[:, past:past + s] = k_r, vn
+    want = OM.attention(q_r, k_full[:, :past + s], v_full[:, :past + s])
+    kt, vt = be.t(k), be.t(v)
+    out = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+    scratch = torch.zeros((be.ext.paged_attn_scratch_bytes(b * s * nh, hd, 16) // 4 + 1,), dtype=torch.float32,
+                          device=be.device)
+    counters = torch.zeros((64,), dtype=torch.int32, device=be.device)
+    assert be.ext.attn_decode_fused(be.t(q), be.t(kn), be.t(vn), kt, vt, out, be.t(sin), be.t(cos), None, None, past, 2,
+                                    scratch, counters)
+    assert np.array_equal(be.n(kt).view(np.uint16), k_full.view(np.uint16))
+    got = be.n(out)
+    assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want))
+    # shapes outside the fused kernel report "not handled" (the caller then uses the three-launch path)
+    assert not be.ext.attn_decode_fused(be.t(q), be.t(kn), be.t(vn), kt, vt, out, be.t(sin), be.t(cos), None, None, past,
+                                        1, scratch, counters)                      # GPT-J style rope
+    big_q = torch.zeros((1, 40, nh, hd), dtype=torch.float16, device=be.device)
+    big_k = torch.zeros((1, 40, kvh, hd), dtype=torch.float16, device=be.device)
+    assert not be.ext.attn_decode_fused(big_q, big_k, big_k, kt, vt, big_q.clone(), be.t(sin), be.t(cos), None, None, 0, 2,
+                                        scratch, counters)                         # prefill-sized
+
+
+@pytest.mark.gpu
+def test_attention_fused_handoff_stress():
+    """The split hand-off (ticket + agent-scope fences) under real concurrency: many back-to-back launches on the same
+    scratch must keep matching the three-launch path."""
+    from exllamav2_amd.ext import ext_c as ext
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    pages, ps, kvh, hd, nh, b, s = 40, 256, 32, 128, 32, 1, 1
+    table = torch.arange(pages, dtype=torch.int32, device=dev).view(1, pages)
+    sin, cos = (torch.from_numpy(x).to(dev) for x in OM.rope_tables(pages * ps, hd, neox=True))
+    kc = torch.randn((pages, ps, kvh, hd), generator=g).half().to(dev)
+    vc = torch.randn((pages, ps, kvh, hd), generator=g).half().to(dev)
+    scratch = torch.zeros((ext.paged_attn_scratch_bytes(b * s * nh, hd, 16) // 4 + 1,), dtype=torch.float32, device=dev)
+    scratch2 = torch.zeros_like(scratch)
+    counters = torch.zeros((64,), dtype=torch.int32, device=dev)
+    worst = 0.0
+    for it in range(200):
+        n = int(torch.randint(0, pages * ps - 2, (1,), generator=g))
+        sl = torch.tensor([n], dtype=torch.int32, device=dev)
+        q = torch.randn((b, s, nh, hd), generator=g).half().to(dev)
+        kn = torch.randn((b, s, kvh, hd), generator=g).half().to(dev)
+        vn = torch.randn((b, s, kvh, hd), generator=g).half().to(dev)
+        out = torch.zeros_like(q)
+        assert ext.attn_decode_fused(q, kn, vn, kc, vc, out, sin, cos, sl, table, 0, 2, scratch, counters)
+        q2, k2, out2 = q.clone(), kn.clone(), torch.zeros_like(q)
+        ext.rope_kv_append(q2, k2, vn, kc, vc, sin, cos, 0, sl, table, 2)
+        ext.paged_attn(q2, kc, vc, out2, sl, table, len_const=0, len_offset=s, scratch=scratch2)
+        worst = max(worst, float((out.float() - out2.float()).abs().max()))
+    assert worst <= 2e-3, worst
+    assert int(counters.sum()) == 0
+
+
 @pytest.mark.parametrize("neox", [True, False])
 def test_rope_kv_append(be, neox):
     rng = np.random.default_rng(7)
