@@ -1,6 +1,8 @@
 """ExLlamaV2Attention (reference attn.py:241-330 load/make_q_attn, :1017-1196 forward, :466-638 forward_paged)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .ext import none_tensor
@@ -18,7 +20,7 @@ class ExLlamaV2Attention:
         self.o_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.o_proj", cfg.num_attention_heads * cfg.head_dim, h)
         self.pre_layernorm = None
         self.q_handle = None
-        self.fused_decode = True
+        self.fused_decode = os.environ.get("EXL2_ATTN_FUSED", "1") != "0"       # A/B switch for measurements
 
     def load(self, ck: dict):
         cfg, m = self.model.config, self.model

@@ -129,6 +129,33 @@ DEV float dot2_f32_f16(f16x2 a, f16x2 b, float c) { return __builtin_amdgcn_fdot
 
 // ---- memory --------------------------------------------------------------------------------------------------------
 // streamed-once data (packed weights, KV pages): non-temporal so it does not displace the activation vector / tables
+// ---- asynchronous global -> LDS copies (no VGPR round trip; cdna_hip_programming.md "LDS DMA") --------------------------
+// Every active lane moves 16 (4) bytes from ITS global address to lds_wave_base + lane * 16 (4); lds_wave_base must be
+// wave-uniform.  Completion is counted by vmcnt like any vector load.
+DEV void dma_to_lds16(const void* g_lane_ptr, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane_ptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+DEV void dma_to_lds4(const void* g_lane_ptr, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane_ptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+// wait until at most N vector-memory operations of this wave are still in flight (they complete in issue order)
+template <int N> DEV void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for every
+// prefetched weight load of the wave before letting anybody pass
+DEV void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// (x & mask) | magic in ONE VALU op.  gfx950 VOP3 takes no 32-bit literal, so the compiler splits it into v_and + v_or
+// with literals; spelling it out keeps the mask in a scalar register and the magic in a vector register.
+DEV u32 and_or(u32 x, u32 mask, u32 magic)
+{
+    u32 r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(magic));
+    return r;
+}
 template <typename T> DEV T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
 template <typename T> DEV void st_nt(T* p, T v) { __builtin_nontemporal_store(v, p); }
 
@@ -154,6 +181,8 @@ DEV float fast_rcp(float x) { return __frcp_rn(x); }
 
 // shader-clock timestamp (s_memtime): used only by the EXL2_TRACE profiling build
 DEV u64 cycle_stamp() { return __builtin_amdgcn_s_memtime(); }
+// constant 100 MHz counter shared by all XCDs (10 ns ticks): timelines across workgroups in the EXL2_TRACE build
+DEV u64 realtime_stamp() { return __builtin_amdgcn_s_memrealtime(); }
 
 // scheduling fence: keeps the compiler from interleaving the decode of consecutive super-chunks (register pressure)
 DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

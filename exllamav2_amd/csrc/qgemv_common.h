@@ -14,22 +14,63 @@ struct PhaseCtx
     int M;
 };
 
+// One super-chunk (4 chunks of 32 K-rows x 16 columns) of one tile: decode to exact (code - zero) halves, multiply with
+// the staged activations on the matrix core, apply the group scale to the fp32 partial sum.
+//
+// Scale after the dot product, not per weight: a chunk lies inside one quantization group, and a lane's four
+// accumulators (rows 4j..4j+3 of column c) all belong to ITS column, so sum_k a_k (q_k - z) s == s * sum_k a_k (q_k - z).
+// The B operand is then an exact small integer in fp16 and the only rounding left is the fp32 accumulation -- closer to
+// the real-valued product than the reference's per-weight fp16 rounding (q_gemm_kernel.cuh:35-60), and 16 packed
+// multiplies per super-chunk cheaper.  When all four chunks share a group (group size >= 128, the common case) the four
+// MFMAs chain into one partial sum and the scale is applied once.
+// Rows >= M of the A operand are never zeroed: MFMA row i of A only feeds row i of D, and rows >= M are never stored.
 template <int BITS, bool GPTQ, bool FULL>
 DEV void gemv_super(const LaneWords<BITS>& lw, const PhaseCtx& ph, int chunk0, int nvalid, int lane, f32x4& acc)
 {
     const int c = lane & 15;
     const int j = lane >> 4;
 
-    // scale (and GPTQ zero point) of this lane's column for each chunk's group: LDS tables built in the prologue
-    f16 sc[4];
-    ZC zc[4];
+    int g[4];
     #pragma unroll
     for (int q = 0; q < 4; q++)
     {
         const int ci = (FULL || q < nvalid) ? chunk0 + q : chunk0;     // padded chunks are never multiplied in
-        const int g = ph.cg_lds[ci];
-        sc[q] = ph.sc_lds[g * 16 + c];
-        if constexpr (GPTQ) zc[q] = make_zc(ph.zp_lds[g * 16 + c]);
+        g[q] = uniform((int)ph.cg_lds[ci]);
+    }
+    const int mrow = c < ph.M ? c : ph.M - 1;
+    const f16* arow = ph.a_lds + mrow * ph.a_stride + (chunk0 * 32 - ph.phase_k0) + 8 * j;
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    if (FULL && g[0] == g[1] && g[0] == g[2] && g[0] == g[3])
+    {
+        const float s = (float)ph.sc_lds[g[0] * 16 + c];
+        ZC zc[4];
+        if constexpr (GPTQ) zc[0] = make_zc(ph.zp_lds[g[0] * 16 + c]);
+        else zc[0] = make_zc((f16)(float)(1 << (BITS - 1)));
+        zc[1] = zc[0]; zc[2] = zc[0]; zc[3] = zc[0];
+        f16x2 p[16];
+        dequant_super<BITS>(lw.w, zc, p);
+        f32x4 part = zero4;
+        #pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const f16x8 b = {p[4 * q].x, p[4 * q].y, p[4 * q + 1].x, p[4 * q + 1].y,
+                             p[4 * q + 2].x, p[4 * q + 2].y, p[4 * q + 3].x, p[4 * q + 3].y};
+            const f16x8 a = *(const f16x8*)(arow + q * 32);
+            part = mfma_16x16x32_f16(a, b, part);
+        }
+        #pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = fmaf(s, part[i], acc[i]);
+        return;
+    }
+
+    float s[4];
+    ZC zc[4];
+    #pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        s[q] = (float)ph.sc_lds[g[q] * 16 + c];
+        if constexpr (GPTQ) zc[q] = make_zc(ph.zp_lds[g[q] * 16 + c]);
     }
     if constexpr (!GPTQ)
     {
@@ -37,23 +78,19 @@ DEV void gemv_super(const LaneWords<BITS>& lw, const PhaseCtx& ph, int chunk0, i
         #pragma unroll
         for (int q = 0; q < 4; q++) zc[q] = z;
     }
-
     f16x2 p[16];
     dequant_super<BITS>(lw.w, zc, p);
-
-    const int mrow = c;     // A fragment: lane (i = l & 15, j) holds row i, k-slot j
-    const f16* arow = ph.a_lds + mrow * ph.a_stride + (chunk0 * 32 - ph.phase_k0) + 8 * j;
     #pragma unroll
     for (int q = 0; q < 4; q++)
     {
         if (FULL || q < nvalid)
         {
-            const f16x2 s2 = h2_dup(sc[q]);
-            const f16x2 b0 = p[4 * q + 0] * s2, b1 = p[4 * q + 1] * s2, b2 = p[4 * q + 2] * s2, b3 = p[4 * q + 3] * s2;
-            const f16x8 b = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
-            f16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (mrow < ph.M) a = *(const f16x8*)(arow + q * 32);
-            acc = mfma_16x16x32_f16(a, b, acc);
+            const f16x8 b = {p[4 * q].x, p[4 * q].y, p[4 * q + 1].x, p[4 * q + 1].y,
+                             p[4 * q + 2].x, p[4 * q + 2].y, p[4 * q + 3].x, p[4 * q + 3].y};
+            const f16x8 a = *(const f16x8*)(arow + q * 32);
+            const f32x4 part = mfma_16x16x32_f16(a, b, zero4);
+            #pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = fmaf(s[q], part[i], acc[i]);
         }
     }
 }
@@ -126,3 +163,73 @@ DEV void stage_rows(const GemvJob& job, const QMatDev& m, const f16* a, const f1
     }
 }
 
+// ---- staging through LDS: ONE global round trip -----------------------------------------------------------------------
+// stage_rows costs three dependent trips when the data is cold (row for the RMS sum -> q_perm -> gather of x / norm
+// weight), ~1-2 us each, all on the critical path of a ~10 us kernel.  The streaming kernel instead copies x, the second
+// operand and q_perm contiguously into LDS (asynchronous LDS-DMA, issued in the first cycles of the kernel) and permutes
+// LDS -> LDS.
+struct StageLds
+{
+    f16* rawx;          // [M][K]  x (or gate) in original order
+    f16* raw2;          // A_RMSNORM: norm weight [K]; A_*_MUL: up [M][K]
+    u16* perm;          // [K] (only when the matrix has a permutation)
+    float* rms;         // [16]
+};
+
+// 1 / rms of every row (rmsnorm.py / rms_norm.cu numerics: fp32 sum of squares of the clamped row)
+DEV void stage_rms_lds(const StageLds& L, int K, float eps, int M, int lane, int wv, int nw)
+{
+    const int oct = K >> 3;
+    for (int r = wv; r < M; r += nw)
+    {
+        float ss = 0.0f;
+        for (int i = lane; i < oct; i += 64)
+        {
+            const f16x8 v = ((const f16x8*)L.rawx)[r * oct + i];
+            #pragma unroll
+            for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)); ss = fmaf(f, f, ss); }
+        }
+        ss = wave_allreduce_add(ss);
+        L.rms[r] = fast_rsqrt(ss * (1.0f / (float)K) + eps);      // every lane stores the same value
+    }
+}
+
+template <int MODE>
+DEV void stage_shuffle_lds(const StageLds& L, bool has_perm, f16* a_lds, int a_stride, int K, int M, int t, int nt)
+{
+    const int oct = K >> 3;
+    for (int idx = t; idx < M * oct; idx += nt)
+    {
+        const int r = idx / oct, o = idx - r * oct;
+        u32 src[8];
+        if (has_perm)
+        {
+            const u32x4 pv = ((const u32x4*)L.perm)[o];
+            src[0] = pv.x & 0xFFFF; src[1] = pv.x >> 16; src[2] = pv.y & 0xFFFF; src[3] = pv.y >> 16;
+            src[4] = pv.z & 0xFFFF; src[5] = pv.z >> 16; src[6] = pv.w & 0xFFFF; src[7] = pv.w >> 16;
+        }
+        else
+        {
+            #pragma unroll
+            for (int e = 0; e < 8; e++) src[e] = (u32)(o * 8 + e);
+        }
+        const f16* xrow = L.rawx + (size_t)r * K;
+        f16x8 v;
+        #pragma unroll
+        for (int e = 0; e < 8; e++)
+        {
+            f16 xv = xrow[src[e]];
+            if constexpr (MODE == A_RMSNORM)
+            {
+                const float f = fmaxf(-65504.0f, fminf((float)xv, 65504.0f));
+                xv = (f16)((f * (float)L.raw2[src[e]]) * L.rms[r]);
+            }
+            else if constexpr (MODE == A_SILU_MUL) xv = clamp_h(act_h(xv, false) * L.raw2[(size_t)r * K + src[e]]);
+            else if constexpr (MODE == A_GELU_MUL) xv = clamp_h(act_h(xv, true) * L.raw2[(size_t)r * K + src[e]]);
+            else if constexpr (MODE == A_SILU) xv = act_h(xv, false);
+            else if constexpr (MODE == A_GELU) xv = act_h(xv, true);
+            v[e] = xv;
+        }
+        *(f16x8*)(a_lds + r * a_stride + o * 8) = v;
+    }
+}

@@ -3,75 +3,122 @@
 // Replaces gemm_half_q_half_kernel (exllamav2_ext/cuda/q_gemm_kernel.cuh:140-565) on the hot decode path; the generic
 // kernel in qgemv.hip stays for shapes that need phased activation staging.
 //
-// What bounds a 10-90 MB GEMV on MI355X is not ALU but (1) bytes in flight per CU and (2) the number of DEPENDENT memory
-// round trips between launch and the last store (~1 us each when the data is HBM-cold).  So:
-//   * a wavefront streams a CONTIGUOUS slice of one 16-column tile (the tile16 layout makes a tile's K range one linear
-//     stream) with a 4-deep register ring: loads are issued unconditionally in the steady state, so the compiler's
-//     counted vmcnt keeps three 1-KB loads per wave in flight while the fourth decodes;
-//   * the first ring fill of the largest bit-width section is issued BEFORE the prologue (run parameters travel in the
-//     kernel arguments = SGPRs, nothing has to be fetched to compute the addresses), so weights, q_perm, scales and
-//     descriptors are all in flight together: launch -> {everything} -> gather a[perm] -> decode -> reduce -> store;
-//   * a workgroup of W waves owns W/S tiles, S waves splitting each tile's K range; the activation vector is gathered
-//     through q_perm into LDS once per workgroup and shared by all its tiles; the S partial sums of a tile are combined
-//     through LDS in a fixed order (deterministic; no atomics, no cross-workgroup traffic);
-//   * decode = magic-number half2 unpack (qlayout.h) -> exact (q - zero) * scale in fp16 like reconstruct() -> B fragment
-//     of v_mfma_f32_16x16x32_f16, fp32 accumulate; RMSNorm / SiLU*up are folded into the activation staging, bias /
-//     residual / MoE weight into the epilogue (qgemv_common.h).
+// A 10-90 MB GEMV on MI355X lasts 5-20 us, so what bounds it is the number of DEPENDENT memory round trips between
+// launch and the last store (1-2 us each when the data is HBM-cold) and how early the weight stream starts:
+//   * everything the prologue needs lives in ONE by-value block of kernel arguments (JobHot): no pointer chasing through
+//     the argument segment before the first load can be issued;
+//   * the prologue's inputs (x rows, norm weight / up rows, q_perm, chunk->group map, scale codes, scale maxima) are
+//     copied global -> LDS by asynchronous LDS-DMA issued in the kernel's first cycles, and right behind them the wave's
+//     weight slice goes into a deep register ring (up to 8 KB per wave = the whole slice for the usual splits).  Vector
+//     memory completes in issue order, so `s_waitcnt vmcnt(ring loads)` releases the prologue as soon as ITS data is
+//     there while the weights keep streaming; barriers in the prologue order LDS only (block_sync_lds) -- a
+//     __syncthreads() would drain vmcnt, i.e. wait for the whole weight slice;
+//   * the activation permutation (act-order), RMSNorm and SiLU(gate)*up happen LDS -> LDS;
+//   * a wavefront streams a CONTIGUOUS slice of one 16-column tile (tile16 layout: a tile's K range is one linear
+//     stream); every ring load is unconditional (clamped), so the compiler's counted vmcnt lets item i decode while
+//     items i+1.. are in flight;
+//   * a workgroup of W waves owns W/S tiles, S waves splitting each tile's K range; the S partial sums of a tile are
+//     combined through LDS in a fixed order (deterministic; no atomics, no cross-workgroup traffic);
+//   * decode = magic-number half2 unpack (qlayout.h) -> exact (q - zero) in fp16 -> B fragment of
+//     v_mfma_f32_16x16x32_f16, group scale applied to the fp32 partial sums (qgemv_common.h); bias / residual / MoE
+//     routing weight in the epilogue.
 #include "qgemv_common.h"
 #include <stdlib.h>
 #include <string.h>
 
+// EXL2_TRACE build (tools/trace_gemv.py): per-wave timestamps at the phase boundaries of the kernel
+#ifdef EXL2_TRACE
+#define TRACE_POINT(i) do { if (args.trace && lane_id() == 0) args.trace[((size_t)(bid_y() * gdim_x() + bid_x()) * 16 + wave_id()) * 16 + (i)] = realtime_stamp(); } while (0)
+#else
+#define TRACE_POINT(i) do { } while (0)
+#endif
+
+// What the prologue and the main weight run need, flat and by value (selected with scalar selects, never indexed).
+struct JobHot
+{
+    const u32* main_ptr;          // (tile 0, super-chunk 0) of the main run
+    const u16* chunk_group;
+    const u32* q_scale;           // EXL2 scale codes / GPTQ qzeros [G, N/8]
+    const f16* scale_src;         // EXL2: padded q_scale_max copy [G] ; GPTQ: scales [G, N]
+    const u16* perm;
+    const f16* a; const f16* a2; const f16* norm_w;
+    u32 main_tile_stride; int main_F; int main_chunk0;
+    int tile0, n_tiles, K, G, N, lda, a_mode, a_stride;
+    float norm_eps;
+    u32 lds_scale_off, lds_zp_off, lds_cg_off, lds_rmf_off, lds_rawx_off, lds_raw2_off, lds_perm_off, lds_qsw_off, lds_smax_off;
+    u32 pad;
+};
+
 struct StreamArgs
 {
-    GemvJob job[MAX_FUSED_MATS];
+    JobHot hot[MAX_FUSED_MATS];
+    GemvJob job[MAX_FUSED_MATS];  // the rest (minor runs, epilogue): read while the weights stream
     int n_jobs;
     int M;          // rows (<= MAX_GEMV_ROWS)
     int S;          // waves per tile (power of two)
     int TPW;        // tiles per workgroup = waves / S
+    u64* trace;     // EXL2_TRACE build only: [block][wave][16] timestamps
 };
 
 // ---- streaming one wave's slice of one run ---------------------------------------------------------------------------
 
 template <int BITS> DEV void ring_load(LaneWords<BITS>& b, const u32* p, int lane) { load_lane_words<BITS>(p, lane, b); }
 
-// items [0, n) at ptr0 + i * 64 * BITS words, chunk index chunk0 + 4 i.  `b` may already hold items 0..min(n,4)-1.
-template <int BITS, bool GPTQ>
+// items [0, n) at ptr0 + i * 64 * BITS words, chunk index chunk0 + 4 i, streamed through a D-deep register ring.
+// `b` may already hold items 0..D-1 (clamped, see ring_fill).  EVERY load is unconditional (indices past the end are
+// clamped to the last item, a line that is in flight anyway): the compiler can then count -- s_waitcnt vmcnt(D-1) before
+// the first decode instead of vmcnt(0) -- and a wave with n <= D has its whole slice in flight from the first cycle.
+template <int BITS, int D>
+DEV void ring_fill(LaneWords<BITS> (&b)[D], const u32* ptr0, int n, int lane)
+{
+    constexpr size_t STEP = 64 * BITS;
+    const int last = n > 0 ? n - 1 : 0;
+    #pragma unroll
+    for (int u = 0; u < D; u++) ring_load<BITS>(b[u], ptr0 + (size_t)(u < last ? u : last) * STEP, lane);
+}
+
+template <int BITS, bool GPTQ, int D>
 DEV void stream_items(const u32* ptr0, int n, int chunk0, const PhaseCtx& ph, int lane, f32x4& acc,
-                      LaneWords<BITS> (&b)[4], bool preloaded)
+                      LaneWords<BITS> (&b)[D], bool preloaded)
 {
     constexpr size_t STEP = 64 * BITS;
     if (n <= 0) return;
-    if (!preloaded)
-    {
-        #pragma unroll
-        for (int u = 0; u < 4; u++) if (u < n) ring_load<BITS>(b[u], ptr0 + (size_t)u * STEP, lane);
-    }
+    if (!preloaded) ring_fill<BITS, D>(b, ptr0, n, lane);
+    const int last = n - 1;
     int i = 0;
-    // steady state: every load is unconditional -> exact vmcnt(3 * loads per item) before each decode
-    while (i + 8 <= n)
+    while (i + 2 * D <= n)
     {
         #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < D; u++)
         {
             gemv_super<BITS, GPTQ, true>(b[u], ph, chunk0 + 4 * (i + u), 4, lane, acc);
-            ring_load<BITS>(b[u], ptr0 + (size_t)(i + u + 4) * STEP, lane);
+            ring_load<BITS>(b[u], ptr0 + (size_t)(i + u + D) * STEP, lane);
         }
-        i += 4;
+        i += D;
     }
-    // drain: at most 7 items left, the ring holds items i .. min(i + 4, n) - 1
-    #pragma unroll
-    for (int u = 0; u < 4; u++)
+    // drain: fewer than 2 D items left, the ring holds items i .. i + D - 1 (clamped)
+    if (i + D < n)
     {
-        if (i + u < n) gemv_super<BITS, GPTQ, true>(b[u], ph, chunk0 + 4 * (i + u), 4, lane, acc);
-        if (i + u + 4 < n) ring_load<BITS>(b[u], ptr0 + (size_t)(i + u + 4) * STEP, lane);
+        #pragma unroll
+        for (int u = 0; u < D; u++)
+        {
+            gemv_super<BITS, GPTQ, true>(b[u], ph, chunk0 + 4 * (i + u), 4, lane, acc);
+            const int nx = i + u + D;
+            ring_load<BITS>(b[u], ptr0 + (size_t)(nx < last ? nx : last) * STEP, lane);
+        }
+        i += D;
     }
-    i += 4;
     #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < D; u++)
         if (i + u < n) gemv_super<BITS, GPTQ, true>(b[u], ph, chunk0 + 4 * (i + u), 4, lane, acc);
 }
 
 struct RunSlice { const u32* ptr0; int n; int chunk0; };
+
+// ring depth: the main run keeps up to 8 KB per wave in flight (the whole slice when the split gives <= MAIN_DEPTH items
+// per wave); the small leading sections of a mixed-width matrix use a shallow ring (register budget: 128 VGPRs)
+#define MINOR_DEPTH 4
+template <int MB> struct MainDepth { static constexpr int v = MB <= 4 ? 8 : (MB <= 6 ? 5 : 4); };
 
 // slice r of S of a full run, for one tile
 DEV RunSlice slice_of(const QRun& run, const QMatDev& m, int tile, int r, int S)
@@ -99,8 +146,8 @@ DEV void do_run(const QRun& run, const QMatDev& m, int tile, int r, int S, const
         return;
     }
     const RunSlice s = slice_of(run, m, tile, r, S);
-    LaneWords<BITS> b[4];
-    stream_items<BITS, GPTQ>(s.ptr0, s.n, s.chunk0, ph, lane, acc, b, false);
+    LaneWords<BITS> b[MINOR_DEPTH];
+    stream_items<BITS, GPTQ, MINOR_DEPTH>(s.ptr0, s.n, s.chunk0, ph, lane, acc, b, false);
 }
 
 template <bool GPTQ>
@@ -121,20 +168,48 @@ DEV void do_run_any(const QRun& run, const QMatDev& m, int tile, int r, int S, c
     }
 }
 
-// MB = bit width of the main (largest) run, whose first ring fill is issued ahead of the prologue; 0 = no early fill
+// number of vector loads one ring fill issues (what may stay in flight when the prologue data has landed)
+template <int MB> struct RingLoads
+{
+    static constexpr int per_item = (MB == 8 || MB == 6 || MB == 5) ? 2 : (MB == 3 ? 3 : 1);
+    static constexpr int v = MB ? MainDepth<(MB ? MB : 4)>::v * per_item : 0;
+};
+
+// contiguous global -> LDS copy of `units` 16-byte units, all waves of the workgroup; unit u of the copy comes from
+// src_of(u).  LDS destination dst + 16 u.
+template <typename F>
+DEV void dma_units16(F src_of, void* dst, int units, int wv, int nw, int lane)
+{
+    for (int base = wv * 64; base < units; base += nw * 64)
+    {
+        const int u = base + lane;
+        if (u < units) dma_to_lds16(src_of(u), (char*)dst + (size_t)base * 16);
+    }
+}
+template <typename F>
+DEV void dma_units4(F src_of, void* dst, int units, int wv, int nw, int lane)
+{
+    for (int base = wv * 64; base < units; base += nw * 64)
+    {
+        const int u = base + lane;
+        if (u < units) dma_to_lds4(src_of(u), (char*)dst + (size_t)base * 4);
+    }
+}
+
+// MB = bit width of the main (largest) run, whose ring fill is issued with the prologue; 0 = no early fill
 template <bool GPTQ, int MB>
 KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
 {
     DYN_SMEM(smem);
+    TRACE_POINT(0);
 
-    int ji = 0;
-    #pragma unroll
-    for (int i = 1; i < MAX_FUSED_MATS; i++)
-        if (i < args.n_jobs && bid_x() >= args.job[i].tile0) ji = i;
-    const GemvJob& job = args.job[ji];
-    const QMatDev& m = job.m;
+    // blockIdx.y = matrix of a fused launch: the whole parameter block arrives with ONE batch of scalar loads
+    const int ji = bid_y();
+    const JobHot& h = args.hot[ji];
+    if (bid_x() * args.TPW >= h.n_tiles) return;              // fused matrices of different widths share grid.x
     const int M = args.M;
     const int S = args.S;
+    const int TPW = args.TPW;
 
     const int t = tid();
     const int nt = nthreads();
@@ -143,87 +218,128 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     const int nw = nt >> 6;
     const int gidx = wv / S;                                  // tile slot inside the workgroup
     const int r = wv - gidx * S;                              // K-slice of that tile
-    const int n_tiles = m.N / TILE_N;
-    int tile = (bid_x() - job.tile0) * args.TPW + gidx;
+    const int n_tiles = h.n_tiles;
+    const int tile_base = bid_x() * TPW;
+    int tile = tile_base + gidx;
     const bool tile_ok = tile < n_tiles;
     if (!tile_ok) tile = n_tiles - 1;                         // idle slot: compute on a valid tile, never store
+    const int K = h.K, G = h.G, oct = K >> 3;
 
     f16* a_lds  = (f16*)smem;
-    f16* sc_lds = (f16*)(smem + job.lds_scale_off) + (size_t)gidx * m.G * 16;
-    f16* zp_lds = (f16*)(smem + job.lds_zp_off) + (size_t)gidx * m.G * 16;
-    u16* cg_lds = (u16*)(smem + job.lds_cg_off);
-    float* rmf_lds = (float*)(smem + job.lds_rmf_off) + wv * 16;
+    f16* sc_all = (f16*)(smem + h.lds_scale_off);
+    f16* zp_all = (f16*)(smem + h.lds_zp_off);
+    u16* cg_lds = (u16*)(smem + h.lds_cg_off);
+    u32* qsw    = (u32*)(smem + h.lds_qsw_off);
+    f16* smax   = (f16*)(smem + h.lds_smax_off);
+    StageLds L;
+    L.rawx = (f16*)(smem + h.lds_rawx_off); L.raw2 = (f16*)(smem + h.lds_raw2_off);
+    L.perm = (u16*)(smem + h.lds_perm_off); L.rms = (float*)(smem + h.lds_rmf_off);
     float* red  = (float*)smem;                               // aliases a_lds after the streaming
 
-    // ---- early ring fill of the main run (addresses come from kernel arguments only) ---------------------------------
-    LaneWords<(MB ? MB : 4)> pre[4];
+    // ---- issue: prologue inputs (LDS-DMA), then the weight ring ---------------------------------------------------------
+    {
+        const f16* a = h.a; const int lda = h.lda;
+        dma_units16([&](int u) { const int rr = u / oct, o = u - rr * oct; return (const void*)(a + (size_t)rr * lda + o * 8); },
+                    L.rawx, M * oct, wv, nw, lane);
+        if (h.a_mode == A_RMSNORM)
+        {
+            const f16* w = h.norm_w;
+            dma_units16([&](int u) { return (const void*)(w + (size_t)u * 8); }, L.raw2, oct, wv, nw, lane);
+        }
+        else if (h.a_mode == A_SILU_MUL || h.a_mode == A_GELU_MUL)
+        {
+            const f16* a2 = h.a2;
+            dma_units16([&](int u) { const int rr = u / oct, o = u - rr * oct; return (const void*)(a2 + (size_t)rr * lda + o * 8); },
+                        L.raw2, M * oct, wv, nw, lane);
+        }
+        if (h.perm)
+        {
+            const u16* pm = h.perm;
+            dma_units16([&](int u) { return (const void*)(pm + (size_t)u * 8); }, L.perm, oct, wv, nw, lane);
+        }
+        const u16* cgp = h.chunk_group;
+        dma_units4([&](int u) { return (const void*)(cgp + (size_t)u * 2); }, cg_lds, ((K >> 5) + 1) >> 1, wv, nw, lane);
+        const u32* qs = h.q_scale; const int n8 = h.N >> 3;
+        dma_units4([&](int u) { const int slot = u / (2 * G), rem = u - slot * 2 * G;
+                                const int tl = min(tile_base + slot, n_tiles - 1);
+                                return (const void*)(qs + (size_t)(rem >> 1) * n8 + tl * 2 + (rem & 1)); },
+                   qsw, TPW * G * 2, wv, nw, lane);
+        const f16* ss = h.scale_src;
+        if constexpr (GPTQ)
+        {
+            const int N = h.N;
+            dma_units4([&](int u) { const int slot = u / (8 * G), rem = u - slot * 8 * G;
+                                    const int tl = min(tile_base + slot, n_tiles - 1);
+                                    return (const void*)(ss + (size_t)(rem >> 3) * N + tl * 16 + 2 * (rem & 7)); },
+                       sc_all, TPW * G * 8, wv, nw, lane);
+        }
+        else
+        {
+            dma_units4([&](int u) { return (const void*)(ss + (size_t)u * 2); }, smax, (G + 1) >> 1, wv, nw, lane);
+        }
+    }
+    constexpr int DM = MainDepth<(MB ? MB : 4)>::v;
+    LaneWords<(MB ? MB : 4)> pre[DM];
     RunSlice ms; ms.n = 0; ms.ptr0 = nullptr; ms.chunk0 = 0;
     if constexpr (MB != 0)
     {
-        ms = slice_of(m.runs[m.main_run], m, tile, r, S);
-        #pragma unroll
-        for (int u = 0; u < 4; u++) if (u < ms.n) ring_load<MB>(pre[u], ms.ptr0 + (size_t)u * (64 * MB), lane);
+        const int F = h.main_F;
+        const int i0 = (int)(((long long)r * F) / S), i1 = (int)(((long long)(r + 1) * F) / S);
+        ms.n = i1 - i0;
+        ms.ptr0 = h.main_ptr + (size_t)tile * h.main_tile_stride + (size_t)i0 * (64u * MB);
+        ms.chunk0 = h.main_chunk0 + 4 * i0;
+        ring_fill<MB, DM>(pre, ms.ptr0, ms.n, lane);
     }
+    TRACE_POINT(1);
 
-    // ---- prologue: independent loads first (chunk map, this tile's group scales), then the activation gather ----------
-    for (int i = t; i < (m.K >> 5); i += nt) cg_lds[i] = m.chunk_group[i];
+    // ---- prologue: tables and activations, LDS -> LDS -------------------------------------------------------------------
+    wait_vmcnt_le<RingLoads<MB>::v>();
+    block_sync_lds();
+    TRACE_POINT(2);
+    for (int idx = t; idx < TPW * G * 16; idx += nt)
     {
-        const int n8 = m.N >> 3;
-        const int lt = r * 64 + lane;                         // thread index inside the tile's S-wave group
-        for (int idx = lt; idx < m.G * 16; idx += S * 64)
+        const int sg = idx >> 4, c = idx & 15;              // sg = slot * G + g
+        const u32 word = qsw[sg * 2 + (c >> 3)];
+        const int nib = (word >> (4 * (c & 7))) & 15;
+        if constexpr (GPTQ) zp_all[idx] = (f16)(float)(nib + 1);
+        else
         {
-            const int g = idx >> 4, c = idx & 15;
-            const int n = tile * 16 + c;
-            const u32 word = m.q_scale[(size_t)g * n8 + (n >> 3)];
-            const int nib = (word >> (4 * (n & 7))) & 15;
-            if constexpr (GPTQ)
-            {
-                sc_lds[idx] = m.scale_src[(size_t)g * m.N + n];
-                zp_lds[idx] = (f16)(float)(nib + 1);
-            }
-            else
-            {
-                sc_lds[idx] = (f16)(float)((nib + 1) * (nib + 1)) * m.scale_src[g];
-            }
+            const int slot = sg / G, g = sg - slot * G;
+            sc_all[idx] = (f16)(float)((nib + 1) * (nib + 1)) * smax[g];
         }
     }
-    if (job.a_mode == A_RMSNORM)
+    if (h.a_mode == A_RMSNORM)
     {
-        for (int rr = 0; rr < M; rr++)
-        {
-            const f16x8* xr = (const f16x8*)(job.a + (size_t)rr * job.lda);
-            float ss = 0.0f;
-            for (int i = lane; i < (m.K >> 3); i += 64)
-            {
-                const f16x8 v = xr[i];
-                #pragma unroll
-                for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)); ss = fmaf(f, f, ss); }
-            }
-            ss = wave_allreduce_add(ss);
-            rmf_lds[rr] = fast_rsqrt(ss * (1.0f / (float)m.K) + job.norm_eps);
-        }
+        stage_rms_lds(L, K, h.norm_eps, M, lane, wv, nw);
+        block_sync_lds();
     }
     {
-        const int oct = m.K >> 3;
-        switch (job.a_mode)
+        const bool hp = h.perm != nullptr;
+        switch (h.a_mode)
         {
-            case A_PLAIN:    stage_rows<A_PLAIN>(job, m, job.a, job.a2, a_lds, rmf_lds, 0, oct, M, t, nt); break;
-            case A_RMSNORM:  stage_rows<A_RMSNORM>(job, m, job.a, job.a2, a_lds, rmf_lds, 0, oct, M, t, nt); break;
-            case A_SILU_MUL: stage_rows<A_SILU_MUL>(job, m, job.a, job.a2, a_lds, rmf_lds, 0, oct, M, t, nt); break;
-            case A_GELU_MUL: stage_rows<A_GELU_MUL>(job, m, job.a, job.a2, a_lds, rmf_lds, 0, oct, M, t, nt); break;
-            case A_SILU:     stage_rows<A_SILU>(job, m, job.a, job.a2, a_lds, rmf_lds, 0, oct, M, t, nt); break;
-            default:         stage_rows<A_GELU>(job, m, job.a, job.a2, a_lds, rmf_lds, 0, oct, M, t, nt); break;
+            case A_PLAIN:    stage_shuffle_lds<A_PLAIN>(L, hp, a_lds, h.a_stride, K, M, t, nt); break;
+            case A_RMSNORM:  stage_shuffle_lds<A_RMSNORM>(L, hp, a_lds, h.a_stride, K, M, t, nt); break;
+            case A_SILU_MUL: stage_shuffle_lds<A_SILU_MUL>(L, hp, a_lds, h.a_stride, K, M, t, nt); break;
+            case A_GELU_MUL: stage_shuffle_lds<A_GELU_MUL>(L, hp, a_lds, h.a_stride, K, M, t, nt); break;
+            case A_SILU:     stage_shuffle_lds<A_SILU>(L, hp, a_lds, h.a_stride, K, M, t, nt); break;
+            default:         stage_shuffle_lds<A_GELU>(L, hp, a_lds, h.a_stride, K, M, t, nt); break;
         }
     }
-    block_sync();
+    TRACE_POINT(3);
+    block_sync_lds();
+    TRACE_POINT(4);
 
     // ---- stream -------------------------------------------------------------------------------------------------------
+    const GemvJob& job = args.job[ji];
+    const QMatDev& m = job.m;
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     PhaseCtx ph;
-    ph.a_lds = a_lds; ph.sc_lds = sc_lds; ph.zp_lds = zp_lds; ph.cg_lds = cg_lds; ph.a_stride = job.a_stride;
+    ph.a_lds = a_lds; ph.sc_lds = sc_all + (size_t)gidx * G * 16; ph.zp_lds = zp_all + (size_t)gidx * G * 16;
+    ph.cg_lds = cg_lds; ph.a_stride = h.a_stride;
     ph.M = M; ph.phase_k0 = 0;
 
-    if constexpr (MB != 0) stream_items<MB, GPTQ>(ms.ptr0, ms.n, ms.chunk0, ph, lane, acc, pre, true);
+    if constexpr (MB != 0) stream_items<MB, GPTQ, DM>(ms.ptr0, ms.n, ms.chunk0, ph, lane, acc, pre, true);
+    TRACE_POINT(5);
     for (int i = 0; i < m.n_runs; i++)
     {
         if (MB != 0 && i == m.main_run) continue;
@@ -231,7 +347,9 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     }
 
     // ---- combine the S slices of every tile (fixed order) + epilogue ----------------------------------------------------
+    TRACE_POINT(6);
     block_sync();
+    TRACE_POINT(7);
     {
         const int c = lane & 15, j = lane >> 4;
         #pragma unroll
@@ -242,12 +360,12 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
         }
     }
     block_sync();
-    for (int idx = t; idx < args.TPW * M * 16; idx += nt)
+    for (int idx = t; idx < TPW * M * 16; idx += nt)
     {
         const int slot = idx / (M * 16);
         const int rem = idx - slot * (M * 16);
         const int row = rem >> 4, c = rem & 15;
-        const int tl = (bid_x() - job.tile0) * args.TPW + slot;
+        const int tl = tile_base + slot;
         if (tl >= n_tiles) continue;
         float v = 0.0f;
         for (int w = 0; w < S; w++) v += red[((slot * S + w) * 16 + row) * 16 + c];
@@ -267,9 +385,15 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
             *cp = (f16)v;
         }
     }
+    TRACE_POINT(8);
 }
 
 // ---- host --------------------------------------------------------------------------------------------------------------
+
+#ifdef EXL2_TRACE
+static u64* g_trace_buf = nullptr;
+extern "C" void exl2_debug_set_trace(void* p) { g_trace_buf = (u64*)p; }
+#endif
 
 static inline u32 align16s(u32 x) { return (x + 15u) & ~15u; }
 
@@ -298,6 +422,8 @@ static void launch_variant(const StreamArgs& args, dim3 grid, dim3 block, u32 ld
     LAUNCH((qgemv_stream_kernel<GPTQ, MB>), grid, block, lds, stream, args);
 }
 
+static inline bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
+
 // returns 0 when launched, 1 when this kernel does not apply (caller falls back to the generic kernel), < 0 on error
 int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream)
 {
@@ -309,9 +435,14 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
     int min_items = 1 << 30, mb = -1;
     for (int i = 0; i < n_jobs; i++)
     {
-        const QMatDev& m = jobs[i].m;
+        const GemvJob& j = jobs[i];
+        const QMatDev& m = j.m;
         if (m.n_runs <= 0) return 1;
-        if ((long long)M * (m.K + 8) * 2 > 96 * 1024) return 1;                 // activations must fit in LDS in one piece
+        // LDS-DMA sources: 16-byte units
+        if (!aligned16(j.a) || (j.lda & 7) || (m.perm && !aligned16(m.perm))) return 1;
+        if ((j.a_mode == A_SILU_MUL || j.a_mode == A_GELU_MUL) && !aligned16(j.a2)) return 1;
+        if (j.a_mode == A_RMSNORM && !aligned16(j.norm_w)) return 1;
+        if (!gptq && !m.scale_pad) return 1;
         tiles += m.N / TILE_N;
         const QRun& mr = m.runs[m.main_run];
         const int items = mr.nvalid_last == 4 ? (int)mr.n_super : 0;
@@ -321,10 +452,11 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
     }
     if (mb < 0) mb = 0;
 
-    // S waves per tile: enough wavefronts to keep ~12 per CU streaming, but at least ~4 super-chunks per wave
-    const long long want = (long long)num_cus() * 12;
+    // S waves per tile: as many wavefronts as fit on the chip in ONE round (16 per CU at <= 128 VGPRs), at least two
+    // super-chunks per wave.  More waves = more of the weight stream in flight from the first cycle and more SIMDs decoding.
+    const long long cap = (long long)num_cus() * 16;
     int S = 1;
-    while (S < 16 && tiles * S < want && min_items / (S * 2) >= 4) S *= 2;
+    while (S < 16 && tiles * (S * 2) <= cap && min_items / (S * 2) >= 2) S *= 2;
     const char* fs = getenv("EXL2_GEMV_SPLIT");
     if (fs && atoi(fs) > 0) S = atoi(fs);
     int W = S > 8 ? S : 8;
@@ -335,29 +467,49 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
     StreamArgs args;
     memset(&args, 0, sizeof(args));
     args.n_jobs = n_jobs; args.M = M; args.S = S; args.TPW = TPW;
+#ifdef EXL2_TRACE
+    args.trace = g_trace_buf;
+#endif
     u32 lds = 0;
-    int blk0 = 0;
+    int blk_max = 0;
     for (int i = 0; i < n_jobs; i++)
     {
         GemvJob& j = args.job[i];
+        JobHot& h = args.hot[i];
         j = jobs[i];
-        j.tile0 = blk0;
-        blk0 += (j.m.N / TILE_N + TPW - 1) / TPW;
-        j.rows_per_phase = j.m.K;
-        j.a_stride = j.m.K + 8;
+        const QMatDev& m = j.m;
+        j.tile0 = 0;
+        const int blks = (m.N / TILE_N + TPW - 1) / TPW;
+        if (blks > blk_max) blk_max = blks;
+        j.rows_per_phase = m.K;
+        j.a_stride = m.K + 8;
         u32 a_bytes = align16s((u32)M * j.a_stride * 2);
         const u32 red_bytes = (u32)W * 16 * 16 * 4;
         if (a_bytes < red_bytes) a_bytes = red_bytes;
-        j.lds_scale_off = a_bytes;
-        j.lds_zp_off = j.lds_scale_off + align16s((u32)TPW * j.m.G * 32);
-        u32 total = j.lds_zp_off + (gptq ? align16s((u32)TPW * j.m.G * 32) : 0);
-        j.lds_cg_off = total;   total += align16s((u32)(j.m.K >> 5) * 2);
-        j.lds_rmf_off = total;  total += 16 * 16 * 4;
-        j.lds_desc_off = total;
+        const u32 row_bytes = align16s((u32)M * m.K * 2);
+        const bool two = j.a_mode == A_SILU_MUL || j.a_mode == A_GELU_MUL;
+        u32 total = a_bytes;
+        h.lds_scale_off = total;  total += align16s((u32)TPW * m.G * 32);
+        h.lds_zp_off = total;     total += gptq ? align16s((u32)TPW * m.G * 32) : 0;
+        h.lds_cg_off = total;     total += align16s((u32)(m.K >> 5) * 2 + 4);
+        h.lds_rmf_off = total;    total += 64;
+        h.lds_rawx_off = total;   total += row_bytes;
+        h.lds_raw2_off = total;   total += two ? row_bytes : (j.a_mode == A_RMSNORM ? align16s((u32)m.K * 2) : 0);
+        h.lds_perm_off = total;   total += m.perm ? align16s((u32)m.K * 2) : 0;
+        h.lds_qsw_off = total;    total += align16s((u32)TPW * m.G * 8);
+        h.lds_smax_off = total;   total += align16s((u32)m.G * 2 + 4);
         if (total > lds) lds = total;
+
+        const QRun& mr = m.runs[m.main_run];
+        h.main_ptr = (mr.in_tail ? m.tail : m.qw) + mr.base_word;
+        h.main_tile_stride = mr.tile_stride; h.main_F = (int)mr.n_super; h.main_chunk0 = (int)mr.k_base >> 5;
+        h.chunk_group = m.chunk_group; h.q_scale = m.q_scale; h.scale_src = gptq ? m.scale_src : m.scale_pad; h.perm = m.perm;
+        h.a = j.a; h.a2 = j.a2; h.norm_w = j.norm_w;
+        h.tile0 = j.tile0; h.n_tiles = m.N / TILE_N; h.K = m.K; h.G = m.G; h.N = m.N; h.lda = j.lda; h.a_mode = j.a_mode;
+        h.a_stride = j.a_stride; h.norm_eps = j.norm_eps;
     }
     if (lds > 160 * 1024) return 1;
-    dim3 grid((unsigned)blk0, 1, 1), block((unsigned)(W * 64), 1, 1);
+    dim3 grid((unsigned)blk_max, (unsigned)n_jobs, 1), block((unsigned)(W * 64), 1, 1);
     if (gptq)
     {
         if (mb == 4) launch_variant<true, 4>(args, grid, block, lds, stream);

@@ -128,8 +128,8 @@ struct QRun
 
 // ---- register-level decoders -----------------------------------------------------------------------------------------
 // raw(bits) -> exact (code - zero) as half2.  `zero` may differ per chunk (GPTQ); EXL2 passes 2^(b-1).
-DEV f16x2 dq_direct(u32 x, u32 mask, f16x2 sub)        { return as_h2((x & mask) | MAGIC_H2) - sub; }
-DEV f16x2 dq_scaled(u32 x, u32 mask, f16x2 mul, f16x2 add) { return h2_fma(as_h2((x & mask) | MAGIC_H2), mul, add); }
+DEV f16x2 dq_direct(u32 x, u32 mask, f16x2 sub)        { return as_h2(and_or(x, mask, MAGIC_H2)) - sub; }
+DEV f16x2 dq_scaled(u32 x, u32 mask, f16x2 mul, f16x2 add) { return h2_fma(as_h2(and_or(x, mask, MAGIC_H2)), mul, add); }
 
 // constants for one chunk: sub = 1024 + z ; addM = -(1024 / M + z)
 struct ZC { f16x2 sub, a4, a8, a16, a32, a64; };

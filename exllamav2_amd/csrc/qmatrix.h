@@ -17,6 +17,7 @@ struct QMatDev
     const u32*   q_scale;         // EXL2: 4-bit scale codes [G, N/8] ; GPTQ: qzeros [G, N/8]
     const f16*   scale_src;       // EXL2: q_scale_max [G] (already * prescale/256) ; GPTQ: scales [G, N]
     const f16*   bias;            // nullable
+    const f16*   scale_pad;       // EXL2: private copy of q_scale_max padded to a dword multiple (LDS-DMA source)
     int n_desc;
     int K, N, G;
     int is_gptq;
@@ -35,6 +36,7 @@ struct QMatrix
     u32*   tail_buf;
     QDesc* desc_buf;
     u16*   chunk_group_buf;
+    f16*   scale_pad_buf;
     // caller-owned (kept for reconstruct / TP splitting)
     u32* q_weight; u16* q_perm; u16* q_invperm;
     f16* temp_dq; int max_dq_rows;

@@ -294,7 +294,9 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
     hipError_t e = hipMalloc((void**)&temp, weight_words * sizeof(u32));
     if (e == hipSuccess && tail_words) e = hipMalloc((void**)&qm->tail_buf, tail_words * sizeof(u32));
     if (e == hipSuccess) e = hipMalloc((void**)&qm->desc_buf, descs.size() * sizeof(QDesc));
+    chunk_group.resize(chunk_group.size() + 2, (u16)0);            // readable as whole dwords (LDS-DMA source)
     if (e == hipSuccess) e = hipMalloc((void**)&qm->chunk_group_buf, chunk_group.size() * sizeof(u16));
+    if (e == hipSuccess && !is_gptq) e = hipMalloc((void**)&qm->scale_pad_buf, ((size_t)G + 2) * sizeof(f16));
     if (e != hipSuccess)
     {
         (void)hipGetLastError();
@@ -302,12 +304,18 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
         if (qm->tail_buf) (void)hipFree(qm->tail_buf);
         if (qm->desc_buf) (void)hipFree(qm->desc_buf);
         if (qm->chunk_group_buf) (void)hipFree(qm->chunk_group_buf);
+        if (qm->scale_pad_buf) (void)hipFree(qm->scale_pad_buf);
         free(qm);
         EXL2_FAIL(EXL2_E_OOM, "HIP out of memory (make_q_matrix: %zu bytes of re-layout scratch)", weight_words * 4);
     }
     HIP_TRY(hipMemcpyAsync(temp, q_weight, weight_words * sizeof(u32), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(qm->desc_buf, descs.data(), descs.size() * sizeof(QDesc), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(qm->chunk_group_buf, chunk_group.data(), chunk_group.size() * sizeof(u16), hipMemcpyHostToDevice, stream));
+    if (qm->scale_pad_buf)
+    {
+        HIP_TRY(hipMemsetAsync(qm->scale_pad_buf, 0, ((size_t)G + 2) * sizeof(f16), stream));
+        HIP_TRY(hipMemcpyAsync(qm->scale_pad_buf, q_scale_max, (size_t)G * sizeof(f16), hipMemcpyDeviceToDevice, stream));
+    }
     if (!x_map.empty())
     {
         HIP_TRY(hipMemcpyAsync(q_perm, x_map.data(), K * sizeof(u16), hipMemcpyHostToDevice, stream));
@@ -331,6 +339,7 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
     d.q_scale = is_gptq ? gptq_qzeros : q_scale;
     d.scale_src = is_gptq ? gptq_scales : q_scale_max;
     d.bias = bias;
+    d.scale_pad = qm->scale_pad_buf;
     d.n_desc = (int)descs.size(); d.K = K; d.N = N; d.G = G; d.is_gptq = is_gptq ? 1 : 0;
 
     // runs for the streaming kernel: one per section (+ one per partial super-chunk), in K order
@@ -388,6 +397,7 @@ void qmatrix_destroy(QMatrix* qm)
     if (qm->tail_buf) (void)hipFree(qm->tail_buf);
     if (qm->desc_buf) (void)hipFree(qm->desc_buf);
     if (qm->chunk_group_buf) (void)hipFree(qm->chunk_group_buf);
+    if (qm->scale_pad_buf) (void)hipFree(qm->scale_pad_buf);
     free(qm);
 }
 

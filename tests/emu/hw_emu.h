@@ -221,6 +221,12 @@ DEV u64 cycle_stamp() { return 0; }
 DEV void sched_fence() { }
 
 // ---- memory ----------------------------------------------------------------------------------------------------------
+DEV u64 realtime_stamp() { return 0; }
+DEV void dma_to_lds16(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
+DEV void dma_to_lds4(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 4, g_lane_ptr, 4); }
+template <int N> DEV void wait_vmcnt_le() { }
+DEV void block_sync_lds() { block_sync(); }
+DEV u32 and_or(u32 x, u32 mask, u32 magic) { return (x & mask) | magic; }
 template <typename T> DEV T ld_nt(const T* p) { return *p; }
 template <typename T> DEV void st_nt(T* p, T v) { *p = v; }
 DEV float atomic_add_f32(float* p, float v)
