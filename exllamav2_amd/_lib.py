@@ -12,7 +12,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "libexl2_hip.so")
+# EXL2_HIP_LIB: alternative build of the SAME library (kernel-tuning A/B runs, trace build); never a different backend
+HIP_LIB_PATH = os.environ.get("EXL2_HIP_LIB") or os.path.join(_HERE, "libexl2_hip.so")
 
 vp = C.c_void_p
 ci = C.c_int

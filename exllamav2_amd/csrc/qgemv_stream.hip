@@ -68,13 +68,13 @@ template <int BITS> DEV void ring_load(LaneWords<BITS>& b, const u32* p, int lan
 // `b` may already hold items 0..D-1 (clamped, see ring_fill).  EVERY load is unconditional (indices past the end are
 // clamped to the last item, a line that is in flight anyway): the compiler can then count -- s_waitcnt vmcnt(D-1) before
 // the first decode instead of vmcnt(0) -- and a wave with n <= D has its whole slice in flight from the first cycle.
-template <int BITS, int D>
+template <int BITS, int D, int LO = 0, int HI = D>
 DEV void ring_fill(LaneWords<BITS> (&b)[D], const u32* ptr0, int n, int lane)
 {
     constexpr size_t STEP = 64 * BITS;
     const int last = n > 0 ? n - 1 : 0;
     #pragma unroll
-    for (int u = 0; u < D; u++) ring_load<BITS>(b[u], ptr0 + (size_t)(u < last ? u : last) * STEP, lane);
+    for (int u = LO; u < HI; u++) ring_load<BITS>(b[u], ptr0 + (size_t)(u < last ? u : last) * STEP, lane);
 }
 
 template <int BITS, bool GPTQ, int D>
@@ -118,7 +118,10 @@ struct RunSlice { const u32* ptr0; int n; int chunk0; };
 // ring depth: the main run keeps up to 8 KB per wave in flight (the whole slice when the split gives <= MAIN_DEPTH items
 // per wave); the small leading sections of a mixed-width matrix use a shallow ring (register budget: 128 VGPRs)
 #define MINOR_DEPTH 4
-template <int MB> struct MainDepth { static constexpr int v = MB <= 4 ? 8 : (MB <= 6 ? 5 : 4); };
+#ifndef MAIN_DEPTH_NARROW
+#define MAIN_DEPTH_NARROW 4
+#endif
+template <int MB> struct MainDepth { static constexpr int v = MB <= 4 ? MAIN_DEPTH_NARROW : (MB <= 6 ? 5 : 4); };
 
 // slice r of S of a full run, for one tile
 DEV RunSlice slice_of(const QRun& run, const QMatDev& m, int tile, int r, int S)
@@ -278,7 +281,16 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
             dma_units4([&](int u) { return (const void*)(ss + (size_t)u * 2); }, smax, (G + 1) >> 1, wv, nw, lane);
         }
     }
+    TRACE_POINT(1);
+    // The prologue inputs travel alone: issued behind the weight flood they would queue behind ~all of it (the memory
+    // system serves the chip's requests roughly in arrival order) and the first barrier would open only when the whole
+    // matrix has been read.  One unloaded round trip (~1 us) later the ring fill goes out and the LDS work below overlaps
+    // with the weights' flight.
+    wait_vmcnt_le<0>();
+    block_sync_lds();
+    TRACE_POINT(2);
     constexpr int DM = MainDepth<(MB ? MB : 4)>::v;
+    constexpr int FIRST_SIP = DM < 2 ? DM : 2;
     LaneWords<(MB ? MB : 4)> pre[DM];
     RunSlice ms; ms.n = 0; ms.ptr0 = nullptr; ms.chunk0 = 0;
     if constexpr (MB != 0)
@@ -288,14 +300,13 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
         ms.n = i1 - i0;
         ms.ptr0 = h.main_ptr + (size_t)tile * h.main_tile_stride + (size_t)i0 * (64u * MB);
         ms.chunk0 = h.main_chunk0 + 4 * i0;
-        ring_fill<MB, DM>(pre, ms.ptr0, ms.n, lane);
+        // a first sip only: more than ~2 KB per wave overflows the CU's request queue and the wave would sit in the issue
+        // stage instead of doing the LDS work below; the rest of the ring goes out right after that work
+        ring_fill<MB, DM, 0, FIRST_SIP>(pre, ms.ptr0, ms.n, lane);
     }
-    TRACE_POINT(1);
+    TRACE_POINT(9);
 
     // ---- prologue: tables and activations, LDS -> LDS -------------------------------------------------------------------
-    wait_vmcnt_le<RingLoads<MB>::v>();
-    block_sync_lds();
-    TRACE_POINT(2);
     for (int idx = t; idx < TPW * G * 16; idx += nt)
     {
         const int sg = idx >> 4, c = idx & 15;              // sg = slot * G + g
@@ -308,11 +319,13 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
             sc_all[idx] = (f16)(float)((nib + 1) * (nib + 1)) * smax[g];
         }
     }
+    TRACE_POINT(10);
     if (h.a_mode == A_RMSNORM)
     {
         stage_rms_lds(L, K, h.norm_eps, M, lane, wv, nw);
         block_sync_lds();
     }
+    TRACE_POINT(11);
     {
         const bool hp = h.perm != nullptr;
         switch (h.a_mode)
@@ -325,6 +338,7 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
             default:         stage_shuffle_lds<A_GELU>(L, hp, a_lds, h.a_stride, K, M, t, nt); break;
         }
     }
+    if constexpr (MB != 0) ring_fill<MB, DM, FIRST_SIP, DM>(pre, ms.ptr0, ms.n, lane);
     TRACE_POINT(3);
     block_sync_lds();
     TRACE_POINT(4);
@@ -392,7 +406,9 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
 
 #ifdef EXL2_TRACE
 static u64* g_trace_buf = nullptr;
-extern "C" void exl2_debug_set_trace(void* p) { g_trace_buf = (u64*)p; }
+static int g_trace_which = 0, g_trace_count = 0;
+// trace the `which`-th streaming launch after this call (0 = the next one)
+extern "C" void exl2_debug_set_trace(void* p, int which) { g_trace_buf = (u64*)p; g_trace_which = which; g_trace_count = 0; }
 #endif
 
 static inline u32 align16s(u32 x) { return (x + 15u) & ~15u; }
@@ -468,7 +484,7 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
     memset(&args, 0, sizeof(args));
     args.n_jobs = n_jobs; args.M = M; args.S = S; args.TPW = TPW;
 #ifdef EXL2_TRACE
-    args.trace = g_trace_buf;
+    args.trace = (g_trace_buf && g_trace_count++ == g_trace_which) ? g_trace_buf : nullptr;
 #endif
     u32 lds = 0;
     int blk_max = 0;
