@@ -213,6 +213,10 @@ int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream)
     if (m->gate) { fill_job(jobs[n], m->gate, ns, m->temp_a, in_mode, C_STORE); n++; fill_job(jobs[n], m->up, ns, m->temp_b, in_mode, C_STORE); n++; }
     else         { fill_job(jobs[n], m->up, ns, m->temp_a, in_mode, C_STORE); n++; }
     for (int i = 0; i < n; i++) { jobs[i].norm_w = m->layernorm; jobs[i].norm_eps = m->norm_epsilon; }
+    // decode-shaped calls: gate / up write their columns straight into down's packed (act-order) row order, so down
+    // stages a contiguous row instead of gathering through q_perm (temp_a / temp_b have no other reader)
+    const bool scatter = skinny && m->down->dev.perm && m->down->q_invperm;
+    if (scatter) for (int i = 0; i < n; i++) jobs[i].c_invperm = m->down->q_invperm;
     LAUNCH_JOBS(jobs, n, rows, gptq, stream, "q_mlp_forward_");
 
     GemvJob d;
@@ -222,6 +226,7 @@ int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream)
         const int amode = m->gate ? (m->act_gelu ? A_GELU_MUL : A_SILU_MUL) : (m->act_gelu ? A_GELU : A_SILU);
         fill_job(d, m->down, m->temp_a, down_dst, amode, down_mode);
         d.a2 = m->temp_b;
+        if (scatter) d.m.perm = nullptr;
     }
     else
     {

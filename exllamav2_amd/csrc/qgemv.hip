@@ -284,7 +284,7 @@ KERNEL void __launch_bounds__(1024) qgemv_kernel(const GemvArgs args)
         if (!skip)
         {
             if (m.bias) v += (float)m.bias[n];
-            f16* cp = job.c + (size_t)grow * job.ldc + n;
+            f16* cp = job.c + (size_t)grow * job.ldc + (job.c_invperm ? (int)job.c_invperm[n] : n);
             if (job.c_mode == C_ACCUM) v += (float)*cp;
             *cp = (f16)v;
         }

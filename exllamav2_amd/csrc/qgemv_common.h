@@ -176,21 +176,31 @@ struct StageLds
     float* rms;         // [16]
 };
 
-// 1 / rms of every row (rmsnorm.py / rms_norm.cu numerics: fp32 sum of squares of the clamped row)
+// 1 / rms of every row (rmsnorm.py / rms_norm.cu numerics: fp32 sum of squares of the clamped row), all waves working:
+// wave w sums octets w, w + nw, ... of every row, the per-wave partial sums meet in LDS (fixed order).
+// L.rms must have room for 16 + 16 * nw floats.  Contains one block_sync_lds.
 DEV void stage_rms_lds(const StageLds& L, int K, float eps, int M, int lane, int wv, int nw)
 {
     const int oct = K >> 3;
-    for (int r = wv; r < M; r += nw)
+    float* part = L.rms + 16;
+    for (int r = 0; r < M; r++)
     {
         float ss = 0.0f;
-        for (int i = lane; i < oct; i += 64)
+        for (int i = wv * 64 + lane; i < oct; i += nw * 64)
         {
             const f16x8 v = ((const f16x8*)L.rawx)[r * oct + i];
             #pragma unroll
             for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)); ss = fmaf(f, f, ss); }
         }
         ss = wave_allreduce_add(ss);
-        L.rms[r] = fast_rsqrt(ss * (1.0f / (float)K) + eps);      // every lane stores the same value
+        part[r * nw + wv] = ss;                                  // every lane stores the same value
+    }
+    block_sync_lds();
+    if (wv == 0 && lane < M)
+    {
+        float ss = 0.0f;
+        for (int w = 0; w < nw; w++) ss += part[lane * nw + w];
+        L.rms[lane] = fast_rsqrt(ss * (1.0f / (float)K) + eps);
     }
 }
 
@@ -201,31 +211,46 @@ DEV void stage_shuffle_lds(const StageLds& L, bool has_perm, f16* a_lds, int a_s
     for (int idx = t; idx < M * oct; idx += nt)
     {
         const int r = idx / oct, o = idx - r * oct;
-        u32 src[8];
+        const f16* xrow = L.rawx + (size_t)r * K;
+        f16x8 x, y = {0, 0, 0, 0, 0, 0, 0, 0};
         if (has_perm)
         {
             const u32x4 pv = ((const u32x4*)L.perm)[o];
+            u32 src[8];
             src[0] = pv.x & 0xFFFF; src[1] = pv.x >> 16; src[2] = pv.y & 0xFFFF; src[3] = pv.y >> 16;
             src[4] = pv.z & 0xFFFF; src[5] = pv.z >> 16; src[6] = pv.w & 0xFFFF; src[7] = pv.w >> 16;
+            #pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = xrow[src[e]];
+            if constexpr (MODE == A_RMSNORM)
+            {
+                #pragma unroll
+                for (int e = 0; e < 8; e++) y[e] = L.raw2[src[e]];
+            }
+            else if constexpr (MODE == A_SILU_MUL || MODE == A_GELU_MUL)
+            {
+                #pragma unroll
+                for (int e = 0; e < 8; e++) y[e] = L.raw2[(size_t)r * K + src[e]];
+            }
         }
         else
         {
-            #pragma unroll
-            for (int e = 0; e < 8; e++) src[e] = (u32)(o * 8 + e);
+            // the producer already wrote the row in this matrix' packed order (GemvJob::c_invperm), or no act-order
+            x = ((const f16x8*)xrow)[o];
+            if constexpr (MODE == A_RMSNORM) y = ((const f16x8*)L.raw2)[o];
+            else if constexpr (MODE == A_SILU_MUL || MODE == A_GELU_MUL) y = ((const f16x8*)(L.raw2 + (size_t)r * K))[o];
         }
-        const f16* xrow = L.rawx + (size_t)r * K;
         f16x8 v;
         #pragma unroll
         for (int e = 0; e < 8; e++)
         {
-            f16 xv = xrow[src[e]];
+            f16 xv = x[e];
             if constexpr (MODE == A_RMSNORM)
             {
                 const float f = fmaxf(-65504.0f, fminf((float)xv, 65504.0f));
-                xv = (f16)((f * (float)L.raw2[src[e]]) * L.rms[r]);
+                xv = (f16)((f * (float)y[e]) * L.rms[r]);
             }
-            else if constexpr (MODE == A_SILU_MUL) xv = clamp_h(act_h(xv, false) * L.raw2[(size_t)r * K + src[e]]);
-            else if constexpr (MODE == A_GELU_MUL) xv = clamp_h(act_h(xv, true) * L.raw2[(size_t)r * K + src[e]]);
+            else if constexpr (MODE == A_SILU_MUL) xv = clamp_h(act_h(xv, false) * y[e]);
+            else if constexpr (MODE == A_GELU_MUL) xv = clamp_h(act_h(xv, true) * y[e]);
             else if constexpr (MODE == A_SILU) xv = act_h(xv, false);
             else if constexpr (MODE == A_GELU) xv = act_h(xv, true);
             v[e] = xv;

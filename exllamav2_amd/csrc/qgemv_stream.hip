@@ -46,7 +46,7 @@ struct JobHot
     int tile0, n_tiles, K, G, N, lda, a_mode, a_stride;
     float norm_eps;
     u32 lds_scale_off, lds_zp_off, lds_cg_off, lds_rmf_off, lds_rawx_off, lds_raw2_off, lds_perm_off, lds_qsw_off, lds_smax_off;
-    u32 pad;
+    int n_runs;
 };
 
 struct StreamArgs
@@ -226,6 +226,7 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     int tile = tile_base + gidx;
     const bool tile_ok = tile < n_tiles;
     if (!tile_ok) tile = n_tiles - 1;                         // idle slot: compute on a valid tile, never store
+    TRACE_POINT(12);
     const int K = h.K, G = h.G, oct = K >> 3;
 
     f16* a_lds  = (f16*)smem;
@@ -239,11 +240,11 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     L.perm = (u16*)(smem + h.lds_perm_off); L.rms = (float*)(smem + h.lds_rmf_off);
     float* red  = (float*)smem;                               // aliases a_lds after the streaming
 
-    // ---- issue: prologue inputs (LDS-DMA), then the weight ring ---------------------------------------------------------
+    // ---- issue: prologue inputs (LDS-DMA) --------------------------------------------------------------------------------
     {
         const f16* a = h.a; const int lda = h.lda;
-        dma_units16([&](int u) { const int rr = u / oct, o = u - rr * oct; return (const void*)(a + (size_t)rr * lda + o * 8); },
-                    L.rawx, M * oct, wv, nw, lane);
+        for (int rr = 0; rr < M; rr++)
+            dma_units16([&](int u) { return (const void*)(a + (size_t)rr * lda + (size_t)u * 8); }, L.rawx + (size_t)rr * K, oct, wv, nw, lane);
         if (h.a_mode == A_RMSNORM)
         {
             const f16* w = h.norm_w;
@@ -252,8 +253,8 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
         else if (h.a_mode == A_SILU_MUL || h.a_mode == A_GELU_MUL)
         {
             const f16* a2 = h.a2;
-            dma_units16([&](int u) { const int rr = u / oct, o = u - rr * oct; return (const void*)(a2 + (size_t)rr * lda + o * 8); },
-                        L.raw2, M * oct, wv, nw, lane);
+            for (int rr = 0; rr < M; rr++)
+                dma_units16([&](int u) { return (const void*)(a2 + (size_t)rr * lda + (size_t)u * 8); }, L.raw2 + (size_t)rr * K, oct, wv, nw, lane);
         }
         if (h.perm)
         {
@@ -263,23 +264,21 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
         const u16* cgp = h.chunk_group;
         dma_units4([&](int u) { return (const void*)(cgp + (size_t)u * 2); }, cg_lds, ((K >> 5) + 1) >> 1, wv, nw, lane);
         const u32* qs = h.q_scale; const int n8 = h.N >> 3;
-        dma_units4([&](int u) { const int slot = u / (2 * G), rem = u - slot * 2 * G;
-                                const int tl = min(tile_base + slot, n_tiles - 1);
-                                return (const void*)(qs + (size_t)(rem >> 1) * n8 + tl * 2 + (rem & 1)); },
-                   qsw, TPW * G * 2, wv, nw, lane);
         const f16* ss = h.scale_src;
-        if constexpr (GPTQ)
+        for (int slot = 0; slot < TPW; slot++)
         {
-            const int N = h.N;
-            dma_units4([&](int u) { const int slot = u / (8 * G), rem = u - slot * 8 * G;
-                                    const int tl = min(tile_base + slot, n_tiles - 1);
-                                    return (const void*)(ss + (size_t)(rem >> 3) * N + tl * 16 + 2 * (rem & 7)); },
-                       sc_all, TPW * G * 8, wv, nw, lane);
+            const int tl = min(tile_base + slot, n_tiles - 1);
+            dma_units4([&](int u) { return (const void*)(qs + (size_t)(u >> 1) * n8 + tl * 2 + (u & 1)); },
+                       qsw + (size_t)slot * 2 * G, 2 * G, wv, nw, lane);
+            if constexpr (GPTQ)
+            {
+                const int N = h.N;
+                dma_units4([&](int u) { return (const void*)(ss + (size_t)(u >> 3) * N + tl * 16 + 2 * (u & 7)); },
+                           sc_all + (size_t)slot * 16 * G, 8 * G, wv, nw, lane);
+            }
         }
-        else
-        {
+        if constexpr (!GPTQ)
             dma_units4([&](int u) { return (const void*)(ss + (size_t)u * 2); }, smax, (G + 1) >> 1, wv, nw, lane);
-        }
     }
     TRACE_POINT(1);
     // The prologue inputs travel alone: issued behind the weight flood they would queue behind ~all of it (the memory
@@ -290,7 +289,10 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     block_sync_lds();
     TRACE_POINT(2);
     constexpr int DM = MainDepth<(MB ? MB : 4)>::v;
-    constexpr int FIRST_SIP = DM < 2 ? DM : 2;
+#ifndef FIRST_SIP_ITEMS
+#define FIRST_SIP_ITEMS 2
+#endif
+    constexpr int FIRST_SIP = DM < FIRST_SIP_ITEMS ? DM : FIRST_SIP_ITEMS;
     LaneWords<(MB ? MB : 4)> pre[DM];
     RunSlice ms; ms.n = 0; ms.ptr0 = nullptr; ms.chunk0 = 0;
     if constexpr (MB != 0)
@@ -307,16 +309,25 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     TRACE_POINT(9);
 
     // ---- prologue: tables and activations, LDS -> LDS -------------------------------------------------------------------
-    for (int idx = t; idx < TPW * G * 16; idx += nt)
+    // scale / zero-point tables: one code word (8 columns) per thread
+    for (int i = t; i < TPW * G * 2; i += nt)
     {
-        const int sg = idx >> 4, c = idx & 15;              // sg = slot * G + g
-        const u32 word = qsw[sg * 2 + (c >> 3)];
-        const int nib = (word >> (4 * (c & 7))) & 15;
-        if constexpr (GPTQ) zp_all[idx] = (f16)(float)(nib + 1);
+        const u32 word = qsw[i];
+        f16x8 v;
+        if constexpr (GPTQ)
+        {
+            #pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = (f16)(float)(((word >> (4 * e)) & 15) + 1);
+            ((f16x8*)zp_all)[i] = v;
+        }
         else
         {
-            const int slot = sg / G, g = sg - slot * G;
-            sc_all[idx] = (f16)(float)((nib + 1) * (nib + 1)) * smax[g];
+            int g = i >> 1;
+            while (g >= G) g -= G;                                // i >> 1 = slot * G + g, TPW is small
+            const f16 mx = smax[g];
+            #pragma unroll
+            for (int e = 0; e < 8; e++) { const int nib = ((word >> (4 * e)) & 15) + 1; v[e] = (f16)(float)(nib * nib) * mx; }
+            ((f16x8*)sc_all)[i] = v;
         }
     }
     TRACE_POINT(10);
@@ -354,10 +365,13 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
 
     if constexpr (MB != 0) stream_items<MB, GPTQ, DM>(ms.ptr0, ms.n, ms.chunk0, ph, lane, acc, pre, true);
     TRACE_POINT(5);
-    for (int i = 0; i < m.n_runs; i++)
+    if (MB == 0 || h.n_runs > 1)
     {
-        if (MB != 0 && i == m.main_run) continue;
-        do_run_any<GPTQ>(m.runs[i], m, tile, r, S, ph, lane, acc);
+        for (int i = 0; i < m.n_runs; i++)
+        {
+            if (MB != 0 && i == m.main_run) continue;
+            do_run_any<GPTQ>(m.runs[i], m, tile, r, S, ph, lane, acc);
+        }
     }
 
     // ---- combine the S slices of every tile (fixed order) + epilogue ----------------------------------------------------
@@ -394,7 +408,7 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
         if (!skip)
         {
             if (m.bias) v += (float)m.bias[n];
-            f16* cp = job.c + (size_t)row * job.ldc + n;
+            f16* cp = job.c + (size_t)row * job.ldc + (job.c_invperm ? (int)job.c_invperm[n] : n);
             if (job.c_mode == C_ACCUM) v += (float)*cp;
             *cp = (f16)v;
         }
@@ -508,7 +522,7 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
         h.lds_scale_off = total;  total += align16s((u32)TPW * m.G * 32);
         h.lds_zp_off = total;     total += gptq ? align16s((u32)TPW * m.G * 32) : 0;
         h.lds_cg_off = total;     total += align16s((u32)(m.K >> 5) * 2 + 4);
-        h.lds_rmf_off = total;    total += 64;
+        h.lds_rmf_off = total;    total += 64 + 16 * 16 * 4;
         h.lds_rawx_off = total;   total += row_bytes;
         h.lds_raw2_off = total;   total += two ? row_bytes : (j.a_mode == A_RMSNORM ? align16s((u32)m.K * 2) : 0);
         h.lds_perm_off = total;   total += m.perm ? align16s((u32)m.K * 2) : 0;
@@ -522,7 +536,7 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
         h.chunk_group = m.chunk_group; h.q_scale = m.q_scale; h.scale_src = gptq ? m.scale_src : m.scale_pad; h.perm = m.perm;
         h.a = j.a; h.a2 = j.a2; h.norm_w = j.norm_w;
         h.tile0 = j.tile0; h.n_tiles = m.N / TILE_N; h.K = m.K; h.G = m.G; h.N = m.N; h.lda = j.lda; h.a_mode = j.a_mode;
-        h.a_stride = j.a_stride; h.norm_eps = j.norm_eps;
+        h.a_stride = j.a_stride; h.norm_eps = j.norm_eps; h.n_runs = m.n_runs;
     }
     if (lds > 160 * 1024) return 1;
     dim3 grid((unsigned)blk_max, (unsigned)n_jobs, 1), block((unsigned)(W * 64), 1, 1);

@@ -58,6 +58,7 @@ struct GemvJob
     const f16* norm_w;            // A_RMSNORM: weight [K]
     f16* c;                       // [M, ldc]
     const f16* r_weights;         // MoE routing weights [M, r_stride] (nullable)
+    const u16* c_invperm;         // nullable: column n is written to c[row, c_invperm[n]] (the consumer's packed order)
     int lda, ldc, r_stride;
     int a_mode, c_mode;
     int mul_r_weights;

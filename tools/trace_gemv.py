@@ -16,8 +16,8 @@ ext = ExtC(lib)
 set_trace = lib.dll.exl2_debug_set_trace
 set_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]; set_trace.restype = None
 NAMES = ["entry", "prologue DMA issued", "DMA landed + barrier", "shuffle done", "barrier1 passed", "main run done",
-         "minor runs done", "barrier2 passed", "end", "  (ring fill issued)", "  (scale table done)", "  (rms done)"]
-ORDER = [0, 1, 2, 9, 10, 11, 3, 4, 5, 6, 7, 8]
+         "minor runs done", "barrier2 passed", "end", "  (ring fill issued)", "  (scale table done)", "  (rms done)", "  (arguments loaded)"]
+ORDER = [0, 12, 1, 2, 9, 10, 11, 3, 4, 5, 6, 7, 8]
 TICK_US = 0.01
 
 
@@ -44,7 +44,7 @@ def report(buf, title):
     if True:
         t = buf.cpu().numpy().reshape(4096, 16, 16)
         used = t[:, :, 0] != 0
-        tt = t[used][:, :12].astype(np.float64) * TICK_US    # [waves, 12] in us
+        tt = t[used][:, :13].astype(np.float64) * TICK_US    # [waves, 13] in us
         t0 = tt[:, 0].min()
         print(f"{title}: waves {tt.shape[0]}  (us since the first wave's entry: median / p10 / p90 / max)")
         for i in ORDER:
@@ -80,6 +80,7 @@ def run_mlp(hidden=4096, inter=11008, recipe=([4], [1.0], 128)):
 
 if __name__ == "__main__":
     run_mlp()
+    sys.exit(0)
     r4 = ([4], [1.0], 128)
     run(4096, 4096, r4)
     run(4096, 11008, r4)
