@@ -180,19 +180,22 @@ template <int MB> struct RingLoads
 
 // contiguous global -> LDS copy of `units` 16-byte units, all waves of the workgroup; unit u of the copy comes from
 // src_of(u).  LDS destination dst + 16 u.
+// `first`: the wave that takes units [0, 64) -- small copies start on different waves so that no wave issues them all.
 template <typename F>
-DEV void dma_units16(F src_of, void* dst, int units, int wv, int nw, int lane)
+DEV void dma_units16(F src_of, void* dst, int units, int wv, int nw, int lane, int first = 0)
 {
-    for (int base = wv * 64; base < units; base += nw * 64)
+    int vw = wv - first; if (vw < 0) vw += nw;
+    for (int base = vw * 64; base < units; base += nw * 64)
     {
         const int u = base + lane;
         if (u < units) dma_to_lds16(src_of(u), (char*)dst + (size_t)base * 16);
     }
 }
 template <typename F>
-DEV void dma_units4(F src_of, void* dst, int units, int wv, int nw, int lane)
+DEV void dma_units4(F src_of, void* dst, int units, int wv, int nw, int lane, int first = 0)
 {
-    for (int base = wv * 64; base < units; base += nw * 64)
+    int vw = wv - first; if (vw < 0) vw += nw;
+    for (int base = vw * 64; base < units; base += nw * 64)
     {
         const int u = base + lane;
         if (u < units) dma_to_lds4(src_of(u), (char*)dst + (size_t)base * 4);
@@ -227,6 +230,11 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     const bool tile_ok = tile < n_tiles;
     if (!tile_ok) tile = n_tiles - 1;                         // idle slot: compute on a valid tile, never store
     TRACE_POINT(12);
+#ifdef EXL2_TRACE
+    if (args.trace && lane_id() == 0)      // where the wave runs: HW_ID (cu / sh / se) and XCC_ID
+        args.trace[((size_t)(bid_y() * gdim_x() + bid_x()) * 16 + wave_id()) * 16 + 13] =
+            ((u64)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (u64)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
     const int K = h.K, G = h.G, oct = K >> 3;
 
     f16* a_lds  = (f16*)smem;
@@ -262,23 +270,23 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
             dma_units16([&](int u) { return (const void*)(pm + (size_t)u * 8); }, L.perm, oct, wv, nw, lane);
         }
         const u16* cgp = h.chunk_group;
-        dma_units4([&](int u) { return (const void*)(cgp + (size_t)u * 2); }, cg_lds, ((K >> 5) + 1) >> 1, wv, nw, lane);
+        dma_units4([&](int u) { return (const void*)(cgp + (size_t)u * 2); }, cg_lds, ((K >> 5) + 1) >> 1, wv, nw, lane, 1 % nw);
         const u32* qs = h.q_scale; const int n8 = h.N >> 3;
         const f16* ss = h.scale_src;
         for (int slot = 0; slot < TPW; slot++)
         {
             const int tl = min(tile_base + slot, n_tiles - 1);
             dma_units4([&](int u) { return (const void*)(qs + (size_t)(u >> 1) * n8 + tl * 2 + (u & 1)); },
-                       qsw + (size_t)slot * 2 * G, 2 * G, wv, nw, lane);
+                       qsw + (size_t)slot * 2 * G, 2 * G, wv, nw, lane, (2 + slot) % nw);
             if constexpr (GPTQ)
             {
                 const int N = h.N;
                 dma_units4([&](int u) { return (const void*)(ss + (size_t)(u >> 3) * N + tl * 16 + 2 * (u & 7)); },
-                           sc_all + (size_t)slot * 16 * G, 8 * G, wv, nw, lane);
+                           sc_all + (size_t)slot * 16 * G, 8 * G, wv, nw, lane, (3 + slot) % nw);
             }
         }
         if constexpr (!GPTQ)
-            dma_units4([&](int u) { return (const void*)(ss + (size_t)u * 2); }, smax, (G + 1) >> 1, wv, nw, lane);
+            dma_units4([&](int u) { return (const void*)(ss + (size_t)u * 2); }, smax, (G + 1) >> 1, wv, nw, lane, nw - 1);
     }
     TRACE_POINT(1);
     // The prologue inputs travel alone: issued behind the weight flood they would queue behind ~all of it (the memory
@@ -482,17 +490,25 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
     }
     if (mb < 0) mb = 0;
 
-    // S waves per tile: as many wavefronts as fit on the chip in ONE round (16 per CU at <= 128 VGPRs), at least two
-    // super-chunks per wave.  More waves = more of the weight stream in flight from the first cycle and more SIMDs decoding.
-    const long long cap = (long long)num_cus() * 16;
-    int S = 1;
-    while (S < 16 && tiles * (S * 2) <= cap && min_items / (S * 2) >= 2) S *= 2;
+    // Shape of the launch.  Measured on MI355X (tools/trace_gemv.py): the dispatcher spreads workgroups breadth-first over
+    // the CUs, and a CU needs ~6.5 us + 29 ns per super-chunk it decodes -- the kernel lasts as long as its most loaded
+    // CU.  So: at most one workgroup per CU, every workgroup the same number of 16-column tiles (TPW), and the 16 wave
+    // slots of a CU split each tile's K range S ways (S need not be a power of two).
+    const int ncu = num_cus();
+    int t_max = 0;
+    for (int i = 0; i < n_jobs; i++) if (jobs[i].m.N / TILE_N > t_max) t_max = jobs[i].m.N / TILE_N;
+    const int wgs_per_job = ncu / n_jobs > 0 ? ncu / n_jobs : 1;
+    int TPW = (t_max + wgs_per_job - 1) / wgs_per_job;
+    if (TPW > 16) TPW = 16;
+    int S = 16 / TPW;
+    if (S > min_items / 2) S = min_items / 2;
+    if (S < 1) S = 1;
     const char* fs = getenv("EXL2_GEMV_SPLIT");
     if (fs && atoi(fs) > 0) S = atoi(fs);
-    int W = S > 8 ? S : 8;
-    const char* fw = getenv("EXL2_GEMV_WAVES");
-    if (fw && atoi(fw) >= S) W = atoi(fw);
-    const int TPW = W / S;
+    const char* ft = getenv("EXL2_GEMV_TPW");
+    if (ft && atoi(ft) > 0) TPW = atoi(ft);
+    if (TPW * S > 16) TPW = 16 / S > 0 ? 16 / S : 1;
+    const int W = TPW * S;
 
     StreamArgs args;
     memset(&args, 0, sizeof(args));

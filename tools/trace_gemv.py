@@ -50,6 +50,17 @@ def report(buf, title):
         for i in ORDER:
             col = tt[:, i] - t0
             print(f"  {NAMES[i]:20s} {np.median(col):7.2f} {np.percentile(col,10):7.2f} {np.percentile(col,90):7.2f} {col.max():7.2f}")
+        hw = t[used][:, 13]
+        xcc = (hw >> 32) & 0xF
+        cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7
+        cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+        ids, counts = np.unique(cuid, return_counts=True)
+        hist = np.bincount(counts)
+        print(f"  placement: {len(ids)} distinct CUs; waves per CU histogram " + ", ".join(f"{n}w:{c}" for n, c in enumerate(hist) if c))
+        endc = np.array([tt[cuid == i, 8].max() - t0 for i in ids])
+        for nwaves in np.unique(counts):
+            sel = endc[counts == nwaves]
+            print(f"    CUs with {nwaves:2d} waves: last end median {np.median(sel):6.2f} max {sel.max():6.2f}")
         life = tt[:, 8] - tt[:, 0]
         print(f"  wave lifetime        median {np.median(life):6.2f}  p90 {np.percentile(life,90):6.2f}  max {life.max():6.2f};"
               f" kernel span {tt[:, 8].max() - t0:6.2f} us")
