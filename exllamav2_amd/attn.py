@@ -14,10 +14,10 @@ class ExLlamaV2Attention:
         cfg = model.config
         self.model, self.ext, self.key, self.layer_idx = model, model.ext, key, layer_idx
         h = cfg.hidden_size
-        self.q_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.q_proj", h, cfg.num_attention_heads * cfg.head_dim)
-        self.k_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.k_proj", h, cfg.num_key_value_heads * cfg.head_dim)
-        self.v_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.v_proj", h, cfg.num_key_value_heads * cfg.head_dim)
-        self.o_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.o_proj", cfg.num_attention_heads * cfg.head_dim, h)
+        self.q_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.q_proj", h, cfg.num_attention_heads * cfg.head_dim, model)
+        self.k_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.k_proj", h, cfg.num_key_value_heads * cfg.head_dim, model)
+        self.v_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.v_proj", h, cfg.num_key_value_heads * cfg.head_dim, model)
+        self.o_proj = ExLlamaV2Linear(self.ext, key + ".self_attn.o_proj", cfg.num_attention_heads * cfg.head_dim, h, model)
         self.pre_layernorm = None
         self.q_handle = None
         self.fused_decode = os.environ.get("EXL2_ATTN_FUSED", "1") != "0"       # A/B switch for measurements
@@ -55,8 +55,17 @@ class ExLlamaV2Attention:
         k = m.temp_k[:rows].view(b, q_len, cfg.num_key_value_heads, cfg.head_dim)
         v = m.temp_v[:rows].view(b, q_len, cfg.num_key_value_heads, cfg.head_dim)
         paged = block_table is not None
-        ext.q_attn_forward_1(self.q_handle, hidden_states, b, q_len, 0, none_tensor, q, k, v, m.sin, m.cos,
-                             apply_rope=False)
+        big = rows > ExLlamaV2Linear.LIB_GEMM_MIN_ROWS and not m.native_prefill
+        if big:
+            # prefill-sized: unfused projections (reconstruct + library GEMM), reference forward_torch shape (attn.py:1198-)
+            xn = m.temp_state[:rows]
+            ext.rms_norm(hidden_states.view(rows, -1), self.pre_layernorm, xn, cfg.norm_eps)
+            q.view(rows, -1).copy_(self.q_proj.forward(xn))
+            k.view(rows, -1).copy_(self.k_proj.forward(xn))
+            v.view(rows, -1).copy_(self.v_proj.forward(xn))
+        else:
+            ext.q_attn_forward_1(self.q_handle, hidden_states, b, q_len, 0, none_tensor, q, k, v, m.sin, m.cos,
+                                 apply_rope=False)
         if cache is None:
             raise RuntimeError("ExLlamaV2Attention.forward: a cache is required")
         attn_out = m.temp_attn[:rows].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
@@ -68,15 +77,48 @@ class ExLlamaV2Attention:
             kc, vc = cache.get_kv_state(self.layer_idx, b, 0, past_len)
             sl, bt, past = None, None, past_len
         # decode-shaped steps: one launch does RoPE + append + attention + split merge; otherwise three launches
-        fused = self.fused_decode and ext.attn_decode_fused(q, k, v, kc, vc, attn_out, m.sin, m.cos, sl, bt, past,
+        fused = (not big) and self.fused_decode and ext.attn_decode_fused(q, k, v, kc, vc, attn_out, m.sin, m.cos, sl, bt, past,
                                                             cfg.rope_style, m.attn_scratch, m.attn_counters)
         if not fused:
             ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, past if not paged else 0,
                                sl if paged else none_tensor, bt if paged else none_tensor, cfg.rope_style)
-            ext.paged_attn(q, kc, vc, attn_out, sl, bt, len_const=past, len_offset=q_len, scratch=m.attn_scratch)
+            if big and not paged and q_len > 16:
+                self._attn_library(q, kc, vc, attn_out, past, q_len)
+            else:
+                ext.paged_attn(q, kc, vc, attn_out, sl, bt, len_const=past, len_offset=q_len, scratch=m.attn_scratch)
         if paged:
             cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
         else:
             cache.store_kv_state(self.layer_idx, b, past_len, q_len)
-        ext.q_attn_forward_2(self.q_handle, hidden_states, attn_out, b, q_len)
+        if big:
+            hidden_states.view(rows, -1).add_(self.o_proj.forward(attn_out.view(rows, -1)))
+        else:
+            ext.q_attn_forward_2(self.q_handle, hidden_states, attn_out, b, q_len)
         return hidden_states
+
+    def _attn_library(self, q, kc, vc, out, past: int, q_len: int):
+        """Long-query attention over a contiguous cache the way the reference does it without flash-attn (_attn_torch,
+        attn.py:869-937): torch SDPA / matmul with a lower-right causal mask, GQA by head repetition.  The decode-shaped
+        HIP kernel (attn.hip) streams the keys once per 8 query rows and is not the right tool for q_len in the
+        thousands; an MFMA flash-prefill kernel is listed in DESIGN.md as next."""
+        cfg = self.model.config
+        total = past + q_len
+        g = cfg.num_attention_heads // cfg.num_key_value_heads
+        qh = q.transpose(1, 2)                                                   # [b, H, s, hd]
+        kh = kc[:, :total].transpose(1, 2)
+        vh = vc[:, :total].transpose(1, 2)
+        if g > 1:
+            kh = kh.repeat_interleave(g, dim=1)
+            vh = vh.repeat_interleave(g, dim=1)
+        if q.device.type == "cuda":
+            if past == 0:
+                o = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, is_causal=True)
+            else:
+                mask = torch.ones((q_len, total), dtype=torch.bool, device=q.device).tril(diagonal=past)
+                o = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, attn_mask=mask)
+        else:
+            s = torch.matmul(qh.float(), kh.float().transpose(-1, -2)) * (cfg.head_dim ** -0.5)
+            mask = torch.ones((q_len, total), dtype=torch.bool).tril(diagonal=past)
+            s = s.masked_fill(~mask, float("-inf"))
+            o = torch.matmul(torch.softmax(s, dim=-1), vh.float()).half()
+        out.copy_(o.transpose(1, 2))

@@ -1,0 +1,427 @@
+// qgemm_prefill.hip -- prefill-shaped q_matrix x fp16 GEMM on the matrix cores, dequantizing INTO the GEMM.
+//
+// Replaces the reference's M > 32 path: reconstruct_kernel (cuda/q_matrix.cu:328-553) writes the whole fp16 [K, N] matrix
+// to HBM, then cuBLAS / hipBLAS Hgemm reads it back (cuda/q_gemm.cu:243-263) -- 2 x 2 K N bytes of traffic per call
+// and a library GEMM that knows nothing about the packing.  Here the packed weights are the B operand:
+//   * the tile16 layout (qlayout.h) stores, for every 128-row super-chunk of a 16-column tile, exactly the four
+//     v_mfma_f32_16x16x32_f16 B fragments of its four 32-row chunks, lane by lane.  A wave loads 64 x b dwords, decodes
+//     them in registers (same decoders and the same half(q - zero) * half(scale) rounding as reconstruct -> the weights
+//     that enter the MFMA are bit-identical to reconstruct()'s) and feeds the matrix core; B never touches LDS or HBM
+//     as fp16;
+//   * the activations are made "packed-K ordered" once per call by a row pre-pass (stage_rows_kernel: act-order gather
+//     through q_perm, fused with RMSNorm or act(gate) * up where the caller has them), so the GEMM reads A tiles as
+//     contiguous 16-byte units -- asynchronous LDS-DMA with an XOR swizzle applied on the GLOBAL side (lane addresses are
+//     free), conflict-free ds_read_b128 on the other side;
+//   * workgroup = 8 waves (4 x 2), block tile 256 x 256, wave tile 64 x 128 (32 accumulator tiles = 128 VGPRs of the 256
+//     a wave may use at 2 waves per SIMD), K step = one super-chunk (<= 128 rows); fp32 accumulation, bias / residual in
+//     the epilogue.
+// MFMA-bound by design: per K step a wave issues 128 MFMAs against ~500 VALU ops of decode.
+#include "qgemv_common.h"
+#include "errors.h"
+#include <stdlib.h>
+#include <string.h>
+
+#define PF_BM 256
+#define PF_BN 256
+#define PF_WAVES_M 4
+#define PF_WAVES_N 2
+#define PF_CT (PF_BN / PF_WAVES_N / 16)     // 16-column tiles per wave (8)
+#define PF_THREADS (PF_WAVES_M * PF_WAVES_N * 64)
+#define PF_A_BYTES (PF_BM * 256)                 // 256 rows x 128 halves
+#define PF_SC_BYTES (4 * PF_BN * 2)              // [chunk][column] scales of the current step
+#define PF_LDS_BYTES (PF_A_BYTES + 2 * PF_SC_BYTES)
+
+struct PrefillArgs
+{
+    QMatDev m;
+    const f16* a;           // [M, K] in packed K order, row stride K
+    f16* c; int ldc;
+    const u16* c_invperm;
+    int M, c_mode;
+};
+
+// scale (and GPTQ zero point) of column n for the (up to 4) chunks of one step, as the fp16 values reconstruct() uses
+template <bool GPTQ>
+DEV void step_scales(const QMatDev& m, int chunk0, int nvalid, int n, int q0, f16* sc, f16* zp)
+{
+    #pragma unroll
+    for (int i = 0; i < 2; i++)
+    {
+        const int q = q0 + i;
+        const int g = m.chunk_group[q < nvalid ? chunk0 + q : chunk0];
+        const u32 word = m.q_scale[(size_t)g * (m.N >> 3) + (n >> 3)];
+        const int nib = (word >> (4 * (n & 7))) & 15;
+        if constexpr (GPTQ) { sc[i] = m.scale_src[(size_t)g * m.N + n]; zp[i] = (f16)(float)(nib + 1); }
+        else                { sc[i] = (f16)(float)((nib + 1) * (nib + 1)) * m.scale_src[g]; zp[i] = (f16)0.0f; }
+    }
+}
+
+template <int BITS, bool GPTQ>
+DEV void decode_tile(const LaneWords<BITS>& lw, const f16* sc_lds, const f16* zp_lds, int col, f16x8 (&b)[4])
+{
+    ZC zc[4];
+    if constexpr (GPTQ)
+    {
+        #pragma unroll
+        for (int q = 0; q < 4; q++) zc[q] = make_zc(zp_lds[q * PF_BN + col]);
+    }
+    else
+    {
+        const ZC z = make_zc((f16)(float)(1 << (BITS - 1)));
+        #pragma unroll
+        for (int q = 0; q < 4; q++) zc[q] = z;
+    }
+    f16x2 p[16];
+    dequant_super<BITS>(lw.w, zc, p);
+    #pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        const f16x2 s2 = h2_dup(sc_lds[q * PF_BN + col]);
+        const f16x2 b0 = p[4 * q + 0] * s2, b1 = p[4 * q + 1] * s2, b2 = p[4 * q + 2] * s2, b3 = p[4 * q + 3] * s2;
+        b[q] = (f16x8){b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
+    }
+}
+
+// A wave's PF_CT column tiles are processed in batches of CB tiles through two alternating register sets: the packed
+// words of batch i + 1 are in flight while batch i decodes and multiplies (CB = 4 up to 4 bits, 2 above: 16 VGPRs a set).
+template <int BITS> struct Batch { static constexpr int CB = BITS <= 4 ? 4 : 2; static constexpr int NB = PF_CT / CB; };
+
+template <int BITS, int CB>
+DEV void load_tiles(LaneWords<BITS> (&w)[CB], const u32* base, u32 tile_stride, int tile0, int n_tiles, int s, int lane)
+{
+    #pragma unroll
+    for (int ct = 0; ct < CB; ct++)
+    {
+        int tile = tile0 + ct;
+        if (tile >= n_tiles) tile = n_tiles - 1;                    // partial last block column: computed, never stored
+        load_lane_words<BITS>(base + (size_t)tile * tile_stride + (size_t)s * (64 * BITS), lane, w[ct]);
+    }
+}
+
+template <int BITS, bool GPTQ, int CB, int CT0>
+DEV void multiply_tiles(const LaneWords<BITS> (&w)[CB], const u8* a_lds, const f16* sc_lds, const f16* zp_lds,
+                        int wm, int wn, int nvalid, int lane, f32x4 (&acc)[4][PF_CT])
+{
+    const int i16 = lane & 15, j4 = lane >> 4;
+    #pragma unroll
+    for (int c = 0; c < CB; c++)
+    {
+        const int ct = CT0 + c;
+        const int col_local = (wn * PF_CT + ct) * 16 + i16;         // this lane's column inside the block tile
+        f16x8 b[4];
+        decode_tile<BITS, GPTQ>(w[c], sc_lds, zp_lds, col_local, b);
+        #pragma unroll
+        for (int rt = 0; rt < 4; rt++)
+        {
+            const int row = wm * 64 + rt * 16 + i16;                // A fragment: lane (i, j) holds row i, k-slot j
+            #pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                if (q < nvalid)
+                {
+                    const int p = (4 * q + j4) ^ (row & 15);
+                    const f16x8 a = *(const f16x8*)(a_lds + (size_t)row * 256 + p * 16);
+                    acc[rt][ct] = mfma_16x16x32_f16(a, b[q], acc[rt][ct]);
+                }
+            }
+        }
+        sched_fence();          // keep the decode temporaries of different tiles from overlapping (register budget)
+    }
+}
+
+struct StepCtx
+{
+    const QMatDev* m; const f16* a; int M, K, m0, n0, n_tiles;
+    u8* a_lds; f16* sc_lds; f16* zp_lds;
+    int t, lane, wv, wm, wn, sc_col, sc_q0, sc_n;
+};
+
+// one K step (one super-chunk of `nvalid` 32-row chunks starting at packed row k0) for the whole block tile
+template <int BITS, bool GPTQ>
+DEV void k_step(const StepCtx& x, const u32* base, u32 tile_stride, int s, int k0, int nvalid, f32x4 (&acc)[4][PF_CT])
+{
+    constexpr int CB = Batch<BITS>::CB, NB = Batch<BITS>::NB;
+    const int tile0 = (x.n0 >> 4) + x.wn * PF_CT;
+    LaneWords<BITS> w0[CB], w1[CB];
+    load_tiles<BITS, CB>(w0, base, tile_stride, tile0, x.n_tiles, s, x.lane);
+
+    // stage A [256 rows x 32 nvalid K] (swizzled) and this step's scales
+    const int chunk0 = k0 >> 5;
+    const int units_row = nvalid * 4;                               // 16-byte units of A per row in this step
+    f16 sc2[2], zp2[2];
+    if (x.t < 2 * PF_BN) step_scales<GPTQ>(*x.m, chunk0, nvalid, x.sc_n, x.sc_q0, sc2, zp2);
+    for (int base_u = x.wv * 64; base_u < PF_BM * 16; base_u += (PF_THREADS / 64) * 64)
+    {
+        const int slot = base_u + x.lane;                           // LDS position: row = slot >> 4, p = slot & 15
+        const int row = slot >> 4, p = slot & 15;
+        const int u = p ^ (row & 15);                               // which 16-byte unit of the row lives there
+        const int grow = min(x.m0 + row, x.M - 1);
+        if (u < units_row)
+            dma_to_lds16(x.a + (size_t)grow * x.K + k0 + u * 8, x.a_lds + (size_t)base_u * 16);
+    }
+    if (x.t < 2 * PF_BN)
+    {
+        x.sc_lds[(x.sc_q0 + 0) * PF_BN + x.sc_col] = sc2[0]; x.sc_lds[(x.sc_q0 + 1) * PF_BN + x.sc_col] = sc2[1];
+        if constexpr (GPTQ) { x.zp_lds[(x.sc_q0 + 0) * PF_BN + x.sc_col] = zp2[0]; x.zp_lds[(x.sc_q0 + 1) * PF_BN + x.sc_col] = zp2[1]; }
+    }
+    wait_vmcnt_le<0>();
+    block_sync();
+
+    load_tiles<BITS, CB>(w1, base, tile_stride, tile0 + CB, x.n_tiles, s, x.lane);
+    multiply_tiles<BITS, GPTQ, CB, 0>(w0, x.a_lds, x.sc_lds, x.zp_lds, x.wm, x.wn, nvalid, x.lane, acc);
+    if constexpr (NB > 2) load_tiles<BITS, CB>(w0, base, tile_stride, tile0 + 2 * CB, x.n_tiles, s, x.lane);
+    multiply_tiles<BITS, GPTQ, CB, CB>(w1, x.a_lds, x.sc_lds, x.zp_lds, x.wm, x.wn, nvalid, x.lane, acc);
+    if constexpr (NB > 2)
+    {
+        load_tiles<BITS, CB>(w1, base, tile_stride, tile0 + 3 * CB, x.n_tiles, s, x.lane);
+        multiply_tiles<BITS, GPTQ, CB, 2 * CB>(w0, x.a_lds, x.sc_lds, x.zp_lds, x.wm, x.wn, nvalid, x.lane, acc);
+        multiply_tiles<BITS, GPTQ, CB, 3 * CB>(w1, x.a_lds, x.sc_lds, x.zp_lds, x.wm, x.wn, nvalid, x.lane, acc);
+    }
+    block_sync();
+}
+
+template <bool GPTQ>
+KERNEL void __launch_bounds__(PF_THREADS) qgemm_prefill_kernel(const PrefillArgs args)
+{
+    DYN_SMEM(smem);
+    const QMatDev& m = args.m;
+    const int t = tid();
+    const int lane = lane_id();
+    const int wv = uniform(wave_id());
+    const int wm = wv / PF_WAVES_N, wn = wv - wm * PF_WAVES_N;
+    const int n0 = bid_x() * PF_BN;
+    const int m0 = bid_y() * PF_BM;
+    const int K = m.K;
+    const int n_tiles = m.N / TILE_N;
+
+    u8* a_lds = (u8*)smem;
+    f16* sc_lds = (f16*)(smem + PF_A_BYTES);
+    f16* zp_lds = (f16*)(smem + PF_A_BYTES + PF_SC_BYTES);
+
+    f32x4 acc[4][PF_CT];
+    #pragma unroll
+    for (int rt = 0; rt < 4; rt++)
+        #pragma unroll
+        for (int ct = 0; ct < PF_CT; ct++) acc[rt][ct] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    // scale staging: thread t (of 512) owns column (t & 255) and chunks {2 (t >> 8), +1} of the step
+    const int sc_col = t & (PF_BN - 1);
+    const int sc_q0 = (t >> 8) * 2;
+    const int sc_n = min(n0 + sc_col, m.N - 1);
+
+    const int i16 = lane & 15, j4 = lane >> 4;
+    StepCtx x;
+    x.m = &m; x.a = args.a; x.M = args.M; x.K = K; x.m0 = m0; x.n0 = n0; x.n_tiles = n_tiles;
+    x.a_lds = a_lds; x.sc_lds = sc_lds; x.zp_lds = zp_lds;
+    x.t = t; x.lane = lane; x.wv = wv; x.wm = wm; x.wn = wn; x.sc_col = sc_col; x.sc_q0 = sc_q0; x.sc_n = sc_n;
+    for (int d = 0; d < m.n_desc; d++)
+    {
+        const QDesc* dp = m.desc + d;
+        const int n_super = uniform((int)dp->n_super);
+        const int bits = uniform((int)dp->bits);
+        const u32* base = (uniform((int)dp->in_tail) ? m.tail : m.qw) + uniform(dp->base_word);
+        const u32 tile_stride = uniform(dp->tile_stride);
+        const int k_base = uniform((int)dp->k_base);
+        const int nvalid_last = uniform((int)dp->nvalid_last);
+        for (int s = 0; s < n_super; s++)
+        {
+            const int nvalid = (s == n_super - 1) ? nvalid_last : 4;
+            const int k0 = k_base + s * SUPER_ROWS;
+            switch (GPTQ ? 4 : bits)
+            {
+                case 4: k_step<4, GPTQ>(x, base, tile_stride, s, k0, nvalid, acc); break;
+                case 8: k_step<8, GPTQ>(x, base, tile_stride, s, k0, nvalid, acc); break;
+                case 6: k_step<6, GPTQ>(x, base, tile_stride, s, k0, nvalid, acc); break;
+                case 5: k_step<5, GPTQ>(x, base, tile_stride, s, k0, nvalid, acc); break;
+                case 3: k_step<3, GPTQ>(x, base, tile_stride, s, k0, nvalid, acc); break;
+                default: k_step<2, GPTQ>(x, base, tile_stride, s, k0, nvalid, acc); break;
+            }
+        }
+    }
+
+    // ---- epilogue: D fragment lane (c = l & 15, j) holds rows 4 j .. 4 j + 3 of column c ---------------------------------
+    #pragma unroll
+    for (int ct = 0; ct < PF_CT; ct++)
+    {
+        const int n = n0 + (wn * PF_CT + ct) * 16 + i16;
+        if (n >= m.N) continue;
+        const float bias = m.bias ? (float)m.bias[n] : 0.0f;
+        const int nn = args.c_invperm ? (int)args.c_invperm[n] : n;
+        #pragma unroll
+        for (int rt = 0; rt < 4; rt++)
+        {
+            #pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                const int row = m0 + wm * 64 + rt * 16 + j4 * 4 + e;
+                if (row < args.M)
+                {
+                    f16* cp = args.c + (size_t)row * args.ldc + nn;
+                    float v = acc[rt][ct][e] + bias;
+                    if (args.c_mode == C_ACCUM) v += (float)*cp;
+                    *cp = (f16)v;
+                }
+            }
+        }
+    }
+}
+
+// ---- row pre-pass: out[r, k'] = f(a[r, perm[k']]) (f: identity | RMSNorm | act | act(gate) * up) -----------------------
+// One workgroup per row; the row is read once (contiguous), normalised / activated, and written in the matrix' packed
+// K order.  Numerics = stage_rows (qgemv_common.h) = rms_norm.cu / q_mlp_activation.cuh.
+
+struct RowStageArgs
+{
+    const f16* a; const f16* a2; const f16* norm_w; const u16* perm; f16* out;
+    int K, lda, mode; float eps;
+};
+
+KERNEL void __launch_bounds__(256) stage_rows_kernel(const RowStageArgs s)
+{
+    DYN_SMEM(smem);
+    const int r = bid_x();
+    const int t = tid(), nt = nthreads(), lane = lane_id(), wv = wave_id(), nw = nt >> 6;
+    f16* row = (f16*)smem;                                   // [K] transformed values in ORIGINAL order
+    float* part = (float*)(smem + (size_t)s.K * 2);
+    const f16* ar = s.a + (size_t)r * s.lda;
+    const f16* br = s.a2 ? s.a2 + (size_t)r * s.lda : nullptr;
+    const int oct = s.K >> 3;
+    float rms = 1.0f;
+    if (s.mode == A_RMSNORM)
+    {
+        float ss = 0.0f;
+        for (int i = t; i < oct; i += nt)
+        {
+            const f16x8 v = ((const f16x8*)ar)[i];
+            #pragma unroll
+            for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)); ss = fmaf(f, f, ss); }
+        }
+        ss = wave_allreduce_add(ss);
+        part[wv] = ss;
+        block_sync();
+        float tot = 0.0f;
+        for (int w = 0; w < nw; w++) tot += part[w];
+        rms = fast_rsqrt(tot * (1.0f / (float)s.K) + s.eps);
+    }
+    for (int i = t; i < oct; i += nt)
+    {
+        const f16x8 x = ((const f16x8*)ar)[i];
+        f16x8 y = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (s.mode == A_RMSNORM) y = ((const f16x8*)s.norm_w)[i];
+        else if (s.mode == A_SILU_MUL || s.mode == A_GELU_MUL) y = ((const f16x8*)br)[i];
+        f16x8 v;
+        #pragma unroll
+        for (int e = 0; e < 8; e++)
+        {
+            f16 xv = x[e];
+            if (s.mode == A_RMSNORM)
+            {
+                const float f = fmaxf(-65504.0f, fminf((float)xv, 65504.0f));
+                xv = (f16)((f * (float)y[e]) * rms);
+            }
+            else if (s.mode == A_SILU_MUL) xv = clamp_h(act_h(xv, false) * y[e]);
+            else if (s.mode == A_GELU_MUL) xv = clamp_h(act_h(xv, true) * y[e]);
+            else if (s.mode == A_SILU) xv = act_h(xv, false);
+            else if (s.mode == A_GELU) xv = act_h(xv, true);
+            v[e] = xv;
+        }
+        ((f16x8*)row)[i] = v;
+    }
+    block_sync();
+    f16* out = s.out + (size_t)r * s.K;
+    for (int i = t; i < oct; i += nt)
+    {
+        f16x8 v;
+        if (s.perm)
+        {
+            const u32x4 pv = ((const u32x4*)s.perm)[i];
+            v[0] = row[pv.x & 0xFFFF]; v[1] = row[pv.x >> 16]; v[2] = row[pv.y & 0xFFFF]; v[3] = row[pv.y >> 16];
+            v[4] = row[pv.z & 0xFFFF]; v[5] = row[pv.z >> 16]; v[6] = row[pv.w & 0xFFFF]; v[7] = row[pv.w >> 16];
+        }
+        else v = ((const f16x8*)row)[i];
+        ((f16x8*)out)[i] = v;
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------------
+
+// per-device scratch for the packed-order activations (grow-only; never grown while a stream is capturing)
+static f16* g_stage_buf[16] = {nullptr};
+static size_t g_stage_bytes[16] = {0};
+
+static int stage_scratch(size_t bytes, void* stream, f16** out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    EXL2_REQUIRE(dev >= 0 && dev < 16, "prefill: device index %d out of range", dev);
+    if (g_stage_bytes[dev] < bytes)
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing((hipStream_t)stream, &cs);
+        EXL2_REQUIRE(cs == hipStreamCaptureStatusNone, "prefill: staging scratch cannot grow inside a graph capture");
+        if (g_stage_buf[dev]) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(g_stage_buf[dev]); g_stage_buf[dev] = nullptr; g_stage_bytes[dev] = 0; }
+        if (hipMalloc((void**)&g_stage_buf[dev], bytes) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            EXL2_FAIL(EXL2_E_OOM, "HIP out of memory (prefill staging scratch: %zu bytes)", bytes);
+        }
+        g_stage_bytes[dev] = bytes;
+    }
+    *out = g_stage_buf[dev];
+    return EXL2_OK;
+}
+
+#define PF_ROW_CHUNK 4096
+
+// returns 0 when done, 1 when the prefill kernel does not apply (caller falls back), < 0 on error
+int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream)
+{
+    if (n_jobs < 1 || M < 1) return -1;
+    const char* off = getenv("EXL2_PREFILL_GENERIC");
+    if (off && atoi(off)) return 1;
+    for (int i = 0; i < n_jobs; i++)
+    {
+        const GemvJob& j = jobs[i];
+        if (j.r_weights) return 1;                                              // MoE routing: decode-shaped path only
+        if ((((size_t)j.a) & 15) || (j.lda & 7) || (j.m.perm && (((size_t)j.m.perm) & 15))) return 1;
+        if ((j.a_mode == A_SILU_MUL || j.a_mode == A_GELU_MUL) && (!j.a2 || (((size_t)j.a2) & 15))) return 1;
+        if (j.a_mode == A_RMSNORM && (!j.norm_w || (((size_t)j.norm_w) & 15))) return 1;
+        if ((size_t)j.m.K * 2 + 64 > 150 * 1024) return 1;
+    }
+    static bool attr = false;
+    if (!attr)
+    {
+        (void)hipFuncSetAttribute((const void*)qgemm_prefill_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qgemm_prefill_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)stage_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    int k_max = 0;
+    for (int i = 0; i < n_jobs; i++) if (jobs[i].m.K > k_max) k_max = jobs[i].m.K;
+    const int chunk = M < PF_ROW_CHUNK ? M : PF_ROW_CHUNK;
+    f16* stage = nullptr;
+    { const int rc = stage_scratch((size_t)chunk * k_max * 2, stream, &stage); if (rc) return rc; }
+
+    for (int r0 = 0; r0 < M; r0 += chunk)
+    {
+        const int rows = M - r0 < chunk ? M - r0 : chunk;
+        for (int i = 0; i < n_jobs; i++)
+        {
+            const GemvJob& j = jobs[i];
+            RowStageArgs s;
+            memset(&s, 0, sizeof(s));
+            s.a = j.a + (size_t)r0 * j.lda; s.a2 = j.a2 ? j.a2 + (size_t)r0 * j.lda : nullptr;
+            s.norm_w = j.norm_w; s.perm = j.m.perm; s.out = stage; s.K = j.m.K; s.lda = j.lda; s.mode = j.a_mode; s.eps = j.norm_eps;
+            LAUNCH(stage_rows_kernel, dim3((unsigned)rows), dim3(256), (size_t)j.m.K * 2 + 64, stream, s);
+
+            PrefillArgs p;
+            memset(&p, 0, sizeof(p));
+            p.m = j.m; p.a = stage; p.c = j.c + (size_t)r0 * j.ldc; p.ldc = j.ldc; p.c_invperm = j.c_invperm;
+            p.M = rows; p.c_mode = j.c_mode;
+            dim3 grid((unsigned)((j.m.N + PF_BN - 1) / PF_BN), (unsigned)((rows + PF_BM - 1) / PF_BM), 1);
+            if (gptq) LAUNCH((qgemm_prefill_kernel<true>), grid, dim3(PF_THREADS), PF_LDS_BYTES, stream, p);
+            else      LAUNCH((qgemm_prefill_kernel<false>), grid, dim3(PF_THREADS), PF_LDS_BYTES, stream, p);
+        }
+    }
+    return 0;
+}

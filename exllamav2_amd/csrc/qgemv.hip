@@ -346,6 +346,7 @@ static u32 plan_job_lds(GemvJob& j, int M, bool gptq, int nwaves)
 
 // Launch up to MAX_FUSED_MATS jobs (same M, same format family) as one grid.
 int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream);
+int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream);
 
 int qgemv_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream)
 {
@@ -353,6 +354,12 @@ int qgemv_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream)
     {
         // decode-shaped calls go to the streaming kernel (qgemv_stream.hip); this generic kernel handles the rest
         const int rc = qgemv_stream_launch(jobs, n_jobs, M, gptq, stream);
+        if (rc <= 0) return rc;
+    }
+    if (M > MAX_GEMV_ROWS)
+    {
+        // prefill-shaped calls: dequantize-into-MFMA GEMM (qgemm_prefill.hip)
+        const int rc = qgemm_prefill_launch(jobs, n_jobs, M, gptq, stream);
         if (rc <= 0) return rc;
     }
     GemvArgs args;

@@ -7,7 +7,14 @@ from .ext import none_tensor
 
 
 class ExLlamaV2Linear:
-    def __init__(self, ext, key: str, in_features: int, out_features: int):
+    # rows above which forward() uses reconstruct + library GEMM (the reference's own M > 32 method,
+    # cuda/q_gemm.cu:243-263 / linear.py:370-379).  Measured on MI355X (tools/prefill_bench.py): hipBLASLt on the
+    # reconstructed fp16 matrix reaches ~1.0 PFLOP/s at M = 16384, the round-1 dequantize-into-MFMA kernel
+    # (qgemm_prefill.hip) ~0.33; below this row count the decode kernel in 16-row passes is faster than either.
+    LIB_GEMM_MIN_ROWS = 64
+
+    def __init__(self, ext, key: str, in_features: int, out_features: int, model=None):
+        self.model = model
         self.ext = ext
         self.key = key
         self.in_features = in_features
@@ -32,8 +39,15 @@ class ExLlamaV2Linear:
     def forward(self, hidden_states: torch.Tensor, force_recons: bool = False, force_cuda: bool = False) -> torch.Tensor:
         """linear.py:361-379: gemm_half_q_half, or reconstruct + torch.matmul when force_recons."""
         n = self.out_features + self.padding
+        rows = hidden_states.numel() // self.in_features
+        if not force_recons and not force_cuda and self.model is not None and rows > self.LIB_GEMM_MIN_ROWS \
+                and not self.model.native_prefill:
+            force_recons = True
         if force_recons:
-            w = torch.empty((self.in_features, n), dtype=torch.float16, device=hidden_states.device)
+            if self.model is not None:
+                w = self.model.dq_scratch(self.in_features, n, hidden_states.device)
+            else:
+                w = torch.empty((self.in_features, n), dtype=torch.float16, device=hidden_states.device)
             self.ext.reconstruct(self.q_handle, w)
             out = torch.matmul(hidden_states, w)
             b = self.q_tensors.get("bias") if self.q_tensors else None

@@ -4,6 +4,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 
 from .attn import ExLlamaV2Attention
@@ -43,6 +45,8 @@ class ExLlamaV2:
         sb = self.ext.paged_attn_scratch_bytes(min(r, 64) * cfg.num_attention_heads, cfg.head_dim, 16)
         self.attn_scratch = torch.empty((sb // 4 + 16,), dtype=torch.float32, device=dev)
         self.attn_counters = torch.zeros((4096,), dtype=torch.int32, device=dev)     # split hand-off tickets (attn.hip)
+        self._dq = None                                   # reconstruct target of the library-GEMM prefill path (temp_dq)
+        self.native_prefill = os.environ.get("EXL2_NATIVE_PREFILL", "0") == "1"    # force qgemm_prefill.hip / attn.hip
         self.sin, self.cos = rope_tables(cfg, dev)
         self.modules = []
         self.layers = []
@@ -50,6 +54,12 @@ class ExLlamaV2:
         self.norm = None
         self.lm_head = None
         self.loaded = False
+
+    def dq_scratch(self, k: int, n: int, device) -> torch.Tensor:
+        """fp16 [k, n] view of the per-device dequantisation scratch (reference: temp_dq, device.py:102-115); grows on demand"""
+        if self._dq is None or self._dq.numel() < k * n:
+            self._dq = torch.empty((k * n,), dtype=torch.float16, device=device)
+        return self._dq[:k * n].view(k, n)
 
     def load(self, ck: dict, layers=None):
         """model.py:266-351: build the module handles from a checkpoint dict.  `layers` = the global layer indices this
@@ -68,7 +78,7 @@ class ExLlamaV2:
         self.vocab_padded = vpad
         if "lm_head" in ck:
             self.norm = ExLlamaV2RMSNorm(self.ext, "model.norm", ck["model.norm"], cfg.norm_eps)
-            self.lm_head = ExLlamaV2Linear(self.ext, "lm_head", cfg.hidden_size, vpad).load(ck["lm_head"])
+            self.lm_head = ExLlamaV2Linear(self.ext, "lm_head", cfg.hidden_size, vpad, self).load(ck["lm_head"])
         self.loaded = True
         return self
 
@@ -94,7 +104,7 @@ class ExLlamaV2:
         cfg = self.config
         b, q_len = input_ids.shape
         assert b * q_len <= self.max_rows, "chunk larger than the scratch arena"
-        x = self.embed_tokens[input_ids.to(self.device).view(-1)].view(b, q_len, cfg.hidden_size).contiguous()
+        x = self.embed_tokens[input_ids.to(self.device).reshape(-1)].view(b, q_len, cfg.hidden_size).contiguous()
         for attn, mlp in self.layers:
             attn.forward(x, cache, past_len, cache_seqlens, block_table)
             mlp.forward(x)

@@ -273,6 +273,8 @@ DEV hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 
 // graphs cannot be emulated: capture is refused, callers fall back to eager launches in the emu tests
 typedef void* hipGraph_t;
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
+DEV hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
 typedef void* hipGraphExec_t;
 enum { hipStreamCaptureModeRelaxed = 2 };
 DEV hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorInvalidValue; }

@@ -77,6 +77,26 @@ def test_chunked_prefill_equals_oracle(be):
     model.unload()
 
 
+@pytest.mark.parametrize("native", [False, True])
+def test_prefill_sized_forward_equals_oracle(be, native):
+    """rows > LIB_GEMM_MIN_ROWS: the unfused module route (reconstruct + library GEMM, library attention) and, with
+    native_prefill, the HIP route (qgemm_prefill.hip + attn.hip) must both match the oracle; then one decode step on the
+    cache they filled."""
+    cfg = tiny_cfg(max_input_len=128, max_seq_len=256)
+    model, oracle = build(be, cfg, seed=3)
+    model.native_prefill = native
+    cache = ExLlamaV2Cache(model, batch_size=1)
+    oracle.reset(1)
+    ids = np.random.default_rng(3).integers(0, cfg.vocab_size, size=(1, 80))
+    logits = model.forward(torch.from_numpy(ids), cache)
+    want = oracle.forward(ids)[:, -1:]
+    check_logits(be.n(logits), want)
+    nxt = np.array([[5]])
+    logits = model.forward(torch.from_numpy(nxt), cache)
+    check_logits(be.n(logits), oracle.forward(nxt)[:, -1:])
+    model.unload()
+
+
 def test_device_side_greedy_decode_paged(be):
     """The benchmark's decode loop (GreedyGraphDecoder, eager on the emulator / graph on the GPU)."""
     cfg = tiny_cfg()

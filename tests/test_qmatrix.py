@@ -81,6 +81,43 @@ def test_gemm_more_than_16_rows(be):
     be.ext.free_q_matrix(h)
 
 
+@pytest.mark.parametrize("name", ["b4_g128", "b4_tail", "b2", "b3", "b5", "b6", "b8", "mixed_all"])
+def test_prefill_identity_equals_reconstruct(be, name):
+    """M > 16 takes the dequantize-into-MFMA kernel (qgemm_prefill.hip): the B fragments must be reconstruct()'s weights
+    bit for bit, so gemm(I) == reconstruct() exactly (tests/test_gemv.py:155-159 relation), one call, M = K rows."""
+    k, n, spec = SPECS[name]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=14, act_order=True)
+    c = torch.zeros((k, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(np.eye(k, dtype=np.float16)), h, c)
+    assert np.array_equal(be.n(c).view(np.uint16), ref.view(np.uint16))
+    be.ext.free_q_matrix(h)
+
+
+@pytest.mark.parametrize("m", [17, 300])
+def test_prefill_vs_oracle(be, m):
+    k, n, spec = SPECS["mixed_5_4"]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=15, bias=True)
+    rng = np.random.default_rng(16)
+    a = rng.standard_normal((m, k)).astype(np.float16)
+    c = torch.zeros((m, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    want = OX.gemm_ref(a, ref, bias=t["bias"], exact=True)
+    assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= half_tol(want, k))
+    be.ext.free_q_matrix(h)
+
+
+def test_prefill_gptq_identity(be):
+    k, n, gs = 384, 48, 128
+    t = OX.synth_gptq(k, n, gs, seed=17, act_order=True)
+    ref = OX.gptq_reconstruct(t)
+    w = gptq_to_torch(be, t)                      # the handle keeps raw pointers: the tensors must outlive it
+    h = be.ext.make_q_matrix_from_dict(w, None)
+    c = torch.zeros((k, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(np.eye(k, dtype=np.float16)), h, c)
+    assert np.array_equal(be.n(c).view(np.uint16), ref.view(np.uint16))
+    be.ext.free_q_matrix(h)
+
+
 def test_gemm_bias(be):
     k, n, spec = SPECS["b4_g128"]
     t, ref, w, h = make_exl2(be, k, n, spec, seed=7, bias=True)

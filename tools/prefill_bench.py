@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Prefill-shaped q_gemm (dequantize-into-MFMA, qgemm_prefill.hip): TFLOP/s per Llama-2-7B linear at M = 8 x 2048 rows
+(BASELINE config 3) and smaller chunks; one JSON line per case.  --model adds the whole-model prefill rate."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from exllamav2_amd.ext import ext_c as ext, none_tensor
+from exllamav2_amd.synth import synth_linear
+
+MFMA_PEAK_F16 = 2500.0          # dense TFLOP/s, MI355X_MICROARCH.md
+
+
+def bench_linear(k, n, m, recipe, reps=5):
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+    w = synth_linear(k, n, recipe, "cuda", gen)
+    h = ext.make_q_matrix_from_dict(w, none_tensor)
+    a = torch.randn((m, k), device="cuda", dtype=torch.float16)
+    c = torch.empty((m, n), device="cuda", dtype=torch.float16)
+    ext.gemm_half_q_half(a, h, c); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): ext.gemm_half_q_half(a, h, c)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tf = 2.0 * m * k * n / ms / 1e9
+    # reference method for M > 32: reconstruct + fp16 GEMM (q_gemm.cu:243-263), here torch.matmul = hipBLASLt
+    wd = torch.empty((k, n), device="cuda", dtype=torch.float16)
+    ext.reconstruct(h, wd); torch.matmul(a, wd, out=c); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        ext.reconstruct(h, wd); torch.matmul(a, wd, out=c)
+    e1.record(); torch.cuda.synchronize()
+    ms_ref = e0.elapsed_time(e1) / reps
+    ext.free_q_matrix(h)
+    return {"k": k, "n": n, "m": m, "recipe": str(recipe), "ms": round(ms, 4), "TFLOPs": round(tf, 1),
+            "frac_mfma_peak": round(tf / MFMA_PEAK_F16, 4), "reconstruct_plus_hipblaslt_ms": round(ms_ref, 4),
+            "speedup_vs_reconstruct_gemm": round(ms_ref / ms, 3)}
+
+
+def bench_model(batch=8, seq=2048, layers=None, reps=2):
+    """test_inference.py -ps procedure (:533-579) at BASELINE config 3: forward(ids[batch, seq], preprocess_only=True)"""
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.synth import synth_checkpoint
+    from exllamav2_amd.model import ExLlamaV2
+    from exllamav2_amd.cache import ExLlamaV2Cache
+    cfg = ExLlamaV2Config.llama2_7b(max_seq_len=seq, max_input_len=2048, max_batch_size=batch)
+    if layers: cfg.num_hidden_layers = layers
+    ck = synth_checkpoint(cfg, "cuda", recipe="4.0bpw")
+    model = ExLlamaV2(cfg, device="cuda").load(ck)
+    cache = ExLlamaV2Cache(model, batch_size=batch, max_seq_len=seq)
+    ids = torch.randint(0, cfg.vocab_size - 1, (batch, seq), generator=torch.Generator().manual_seed(0)).to("cuda")
+    model.forward(ids, cache, preprocess_only=True); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cache.current_seq_len = 0
+        model.forward(ids, cache, preprocess_only=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"metric": "prefill tokens/s", "batch": batch, "seq": seq, "layers": cfg.num_hidden_layers,
+            "value": round(batch * seq / dt, 1), "ms": round(dt * 1e3, 2)}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--model", action="store_true")
+    ap.add_argument("--layers", type=int, default=0)
+    args = ap.parse_args()
+    if args.model:
+        print(json.dumps(bench_model(layers=args.layers or None)), flush=True)
+        sys.exit(0)
+    r4 = ([4], [1.0], 128)
+    cases = [(4096, 4096, 16384, ([5, 4], [0.1, 0.9], 128)), (4096, 11008, 16384, r4), (11008, 4096, 16384, ([8, 4], [0.05, 0.95], [32, 128])),
+             (4096, 11008, 2048, r4), (4096, 11008, 256, r4), (4096, 11008, 64, r4)]
+    if args.quick: cases = cases[1:2] + cases[3:4]
+    for k, n, m, rec in cases:
+        print(json.dumps(bench_linear(k, n, m, rec)), flush=True)
