@@ -50,8 +50,9 @@ for _n in ("make_q_matrix_split", "gemm_half_q_half_tp", "make_tp_context", "fre
            "tp_cross_device_barrier", "tp_all_reduce", "tp_attn_forward_", "tp_attn_forward_paged_", "tp_mlp_forward_",
            "rms_norm_tp"):
     globals()[_n] = _out_of_scope(_n, "tensor-parallel host-staged path: next row after the layer-split pipeline (SURVEY.md 8e)")
-for _n in ("make_q_moe_mlp", "free_q_moe_mlp", "q_moe_mlp_forward_"):
-    globals()[_n] = _out_of_scope(_n, "MoE expert path (config 5): next round (SURVEY.md 8a row a13); experts run through gemm_half_q_half")
+make_q_moe_mlp = _e.make_q_moe_mlp
+free_q_moe_mlp = _e.free_q_moe_mlp
+q_moe_mlp_forward_ = _e.q_moe_mlp_forward_
 for _n in ("fp16_to_fp8", "fp8_to_fp16", "cache_rotate", "count_match", "matrix_fp16_to_q4", "matrix_q4_to_fp16"):
     globals()[_n] = _out_of_scope(_n, "cache utilities outside the Q4 codec: 'next' rows (SURVEY.md 2.2, 8f N2)")
 for _n in ("layer_norm", "layer_norm_", "head_norm", "head_norm_", "softcap_", "gen_mrope_pos_ids", "gemm_half_half_half",

@@ -57,6 +57,11 @@ PROTOTYPES = {
     "exl2_make_q_mlp": (ci, [C.POINTER(vp), vp, vp, ci, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, ci, ci]),
     "exl2_free_q_mlp": (ci, [vp]),
     "exl2_q_mlp_forward": (ci, [vp, vp, ci, vp]),
+    "exl2_make_q_moe_mlp": (ci, [C.POINTER(vp), vp, vp, ci, cf, vp, ci, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                 vp, vp, vp, vp, vp, vp, ci, ci]),
+    "exl2_free_q_moe_mlp": (ci, [vp]),
+    "exl2_q_moe_mlp_forward": (ci, [vp, vp, ci, vp]),
+    "exl2_moe_route": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     # graphs
     "exl2_graph_begin_capture": (ci, [vp]),
     "exl2_graph_end_capture": (ci, [vp, C.POINTER(vp)]),

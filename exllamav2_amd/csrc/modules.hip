@@ -23,6 +23,7 @@ int exl2_rope_qk(void* x_q, void* x_k, const void* sin, const void* cos, int bat
                  int past_len, const int* past_lens, int neox_style, int sincos_size, void* stream);
 int exl2_act_mul(void* x, const void* y, int rows, int width, int act_gelu,
                  const void* r_weights, int r_weights_stride, void* stream);
+int exl2_moe_route(const void* x, const void* gate, void* logits, int rows, int hidden, int num_experts, int topk, void* stream);
 }
 
 static void fill_job(GemvJob& j, const QMatrix* qm, const f16* a, f16* c, int a_mode, int c_mode)
@@ -61,7 +62,91 @@ struct QMLP
     const f16* post_layernorm; const f16* post_layernorm_bias; bool residual_fp32; bool use_graphs;
 };
 
+#define MOE_MAX_EXPERTS 16
+struct QMoEMLP
+{
+    const f16* layernorm; float norm_epsilon;
+    const f16* gate; int num_experts, num_experts_per_token;
+    QMatrix* w1[MOE_MAX_EXPERTS]; QMatrix* w2[MOE_MAX_EXPERTS]; QMatrix* w3[MOE_MAX_EXPERTS];
+    f16* temp_state; f16* temp_a; f16* temp_b; f16* temp_logits;
+    int max_rows, hidden; bool act_gelu;
+};
+
 extern "C" {
+
+// make_q_moe_mlp (ext_qmlp.h; call site moe_mlp.py:114-133: w1 = gate proj, w3 = up proj, w2 = down proj)
+int exl2_make_q_moe_mlp(void** handle, const void* layernorm, const void* layernorm_bias, int layernorm_is_rms,
+                        float norm_epsilon, const void* gate, int num_experts, int num_experts_per_token,
+                        void* const* w1, void* const* w2, void* const* w3, void* temp_state, void* temp_gathered_state,
+                        void* temp_a, void* temp_b, void* temp_logits, void* temp_dq, int max_rows, int act_gelu)
+{
+    (void)temp_gathered_state; (void)temp_dq; (void)layernorm_bias;
+    EXL2_REQUIRE(handle && gate && w1 && w2 && w3, "make_q_moe_mlp: null argument");
+    EXL2_REQUIRE(layernorm && layernorm_is_rms, "make_q_moe_mlp: only RMSNorm pre-norm is built");
+    EXL2_REQUIRE(num_experts == 4 || num_experts == 8 || num_experts == 16,
+                 "make_q_moe_mlp: %d experts (the fused path covers 4, 8, 16 like q_mlp.cu:333)", num_experts);
+    EXL2_REQUIRE(num_experts_per_token >= 1 && num_experts_per_token <= num_experts, "make_q_moe_mlp: bad experts per token");
+    EXL2_REQUIRE(temp_state && temp_a && temp_b && temp_logits, "make_q_moe_mlp: temp buffers required");
+    QMoEMLP* m = (QMoEMLP*)calloc(1, sizeof(QMoEMLP));
+    if (!m) EXL2_FAIL(EXL2_E_OOM, "make_q_moe_mlp: host out of memory");
+    m->layernorm = (const f16*)layernorm; m->norm_epsilon = norm_epsilon; m->gate = (const f16*)gate;
+    m->num_experts = num_experts; m->num_experts_per_token = num_experts_per_token;
+    for (int i = 0; i < num_experts; i++)
+    {
+        m->w1[i] = (QMatrix*)w1[i]; m->w2[i] = (QMatrix*)w2[i]; m->w3[i] = (QMatrix*)w3[i];
+        if (!m->w1[i] || !m->w2[i] || !m->w3[i]) { free(m); EXL2_FAIL(EXL2_E_INVALID, "make_q_moe_mlp: expert %d has a null projection", i); }
+    }
+    m->temp_state = (f16*)temp_state; m->temp_a = (f16*)temp_a; m->temp_b = (f16*)temp_b; m->temp_logits = (f16*)temp_logits;
+    m->max_rows = max_rows; m->hidden = m->w1[0]->height; m->act_gelu = act_gelu;
+    *handle = m;
+    return EXL2_OK;
+}
+
+int exl2_free_q_moe_mlp(void* handle) { free(handle); return EXL2_OK; }
+
+// q_moe_mlp_forward_ (ext_qmlp.cpp:245-272 -> QMoEMLP::forward_, q_mlp.cu:318-402): in place on x [rows, hidden].
+// The reference takes rows <= 4; here any row count runs in passes of 16 rows (one MFMA row block): each expert's
+// weights stream once per pass for all the rows routed to it, launches whose rows all have zero weight exit at once.
+int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
+{
+    EXL2_REQUIRE(handle && x_, "q_moe_mlp_forward_: null argument");
+    QMoEMLP* m = (QMoEMLP*)handle;
+    if (rows <= 0) return EXL2_OK;
+    EXL2_REQUIRE(rows <= m->max_rows, "q_moe_mlp_forward_: %d rows exceed max_rows %d", rows, m->max_rows);
+    const int E = m->num_experts, hidden = m->hidden;
+    f16* x = (f16*)x_;
+    { const int rc = exl2_rms_norm(x, m->layernorm, m->temp_state, m->norm_epsilon, rows, hidden, 0, 0, 0, stream); if (rc) return rc; }
+    { const int rc = exl2_moe_route(m->temp_state, m->gate, m->temp_logits, rows, hidden, E, m->num_experts_per_token, stream); if (rc) return rc; }
+    const int inter = m->w1[0]->width;
+    for (int r0 = 0; r0 < rows; r0 += MAX_GEMV_ROWS)
+    {
+        const int nr = rows - r0 < MAX_GEMV_ROWS ? rows - r0 : MAX_GEMV_ROWS;
+        const f16* ts = m->temp_state + (size_t)r0 * hidden;
+        f16* ta = m->temp_a + (size_t)r0 * inter;
+        f16* tb = m->temp_b + (size_t)r0 * inter;
+        for (int e = 0; e < E; e++)
+        {
+            const f16* rw = m->temp_logits + (size_t)r0 * E + e;
+            GemvJob jobs[2];
+            fill_job(jobs[0], m->w1[e], ts, ta, A_PLAIN, C_STORE);
+            fill_job(jobs[1], m->w3[e], ts, tb, A_PLAIN, C_STORE);
+            const bool scatter = m->w2[e]->dev.perm && m->w2[e]->q_invperm;
+            for (int i = 0; i < 2; i++)
+            {
+                jobs[i].r_weights = rw; jobs[i].r_stride = E; jobs[i].mul_r_weights = 0;
+                if (scatter) jobs[i].c_invperm = m->w2[e]->q_invperm;
+            }
+            LAUNCH_JOBS(jobs, 2, nr, m->w1[e]->is_gptq, stream, "q_moe_mlp_forward_");
+            GemvJob d;
+            fill_job(d, m->w2[e], ta, x + (size_t)r0 * hidden, m->act_gelu ? A_GELU_MUL : A_SILU_MUL, C_ACCUM);
+            d.a2 = tb;
+            d.r_weights = rw; d.r_stride = E; d.mul_r_weights = 1;
+            if (scatter) d.m.perm = nullptr;
+            LAUNCH_JOBS(&d, 1, nr, m->w2[e]->is_gptq, stream, "q_moe_mlp_forward_");
+        }
+    }
+    return EXL2_OK;
+}
 
 // make_q_attn (ext_qattn.cpp:24-104); argument order = SURVEY.md A.5
 int exl2_make_q_attn(void** handle, const void* layernorm, const void* layernorm_bias, int layernorm_is_rms,

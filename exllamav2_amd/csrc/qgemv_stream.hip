@@ -47,6 +47,7 @@ struct JobHot
     float norm_eps;
     u32 lds_scale_off, lds_zp_off, lds_cg_off, lds_rmf_off, lds_rawx_off, lds_raw2_off, lds_perm_off, lds_qsw_off, lds_smax_off;
     int n_runs;
+    const f16* r_weights; int r_stride;  // MoE routing weights (nullable): a launch whose rows all weigh zero exits at once
 };
 
 struct StreamArgs
@@ -214,6 +215,13 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     const JobHot& h = args.hot[ji];
     if (bid_x() * args.TPW >= h.n_tiles) return;              // fused matrices of different widths share grid.x
     const int M = args.M;
+    if (h.r_weights)
+    {
+        // q_gemm_kernel.cuh:189-200: nothing to do for an expert no row is routed to (wave-uniform scalar loads)
+        u32 any = 0;
+        for (int rr = 0; rr < M; rr++) any |= (u32)as_u16(h.r_weights[(size_t)rr * h.r_stride]);
+        if (uniform(any) == 0) return;
+    }
     const int S = args.S;
     const int TPW = args.TPW;
 
@@ -553,6 +561,7 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
         h.a = j.a; h.a2 = j.a2; h.norm_w = j.norm_w;
         h.tile0 = j.tile0; h.n_tiles = m.N / TILE_N; h.K = m.K; h.G = m.G; h.N = m.N; h.lda = j.lda; h.a_mode = j.a_mode;
         h.a_stride = j.a_stride; h.norm_eps = j.norm_eps; h.n_runs = m.n_runs;
+        h.r_weights = j.r_weights; h.r_stride = j.r_stride;
     }
     if (lds > 160 * 1024) return 1;
     dim3 grid((unsigned)blk_max, (unsigned)n_jobs, 1), block((unsigned)(W * 64), 1, 1);

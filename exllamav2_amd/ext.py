@@ -320,6 +320,37 @@ class ExtC:
         self.lib.check(self.lib.exl2_q_mlp_forward(q_mlp, self._ptr(x, torch.float16, "x"), x.numel() // hidden,
                                                    self._stream(x)))
 
+    # ---- MoE (ext_qmlp.cpp:245-272) -------------------------------------------------------------------------------------
+
+    def make_q_moe_mlp(self, layernorm, layernorm_bias, layernorm_is_rms, norm_epsilon, gate, num_experts,
+                       num_experts_per_token, w1, w2, w3, temp_state, temp_gathered_state, temp_a, temp_b, temp_logits,
+                       temp_dq, max_rows, act_gelu) -> int:
+        if not (len(w1) == len(w2) == len(w3) == num_experts):
+            raise RuntimeError("make_q_moe_mlp: expert handle lists must have num_experts entries")
+        arr = lambda hs: (C.c_void_p * num_experts)(*[C.c_void_p(int(h)) for h in hs])
+        h = C.c_void_p()
+        self.lib.check(self.lib.exl2_make_q_moe_mlp(
+            C.byref(h), self._ptr(layernorm), self._ptr(layernorm_bias), int(layernorm_is_rms), float(norm_epsilon),
+            self._ptr(gate, torch.float16, "gate"), int(num_experts), int(num_experts_per_token), arr(w1), arr(w2), arr(w3),
+            self._ptr(temp_state), self._ptr(temp_gathered_state), self._ptr(temp_a), self._ptr(temp_b),
+            self._ptr(temp_logits), self._ptr(temp_dq), int(max_rows), int(act_gelu)))
+        return int(h.value)
+
+    def free_q_moe_mlp(self, handle: int) -> None:
+        self.lib.check(self.lib.exl2_free_q_moe_mlp(handle))
+
+    def q_moe_mlp_forward_(self, q_moe_mlp, x) -> None:
+        """In place on x [rows, hidden] (any row count up to max_rows; the reference's fused path stops at 4)."""
+        hidden = x.shape[-1]
+        self.lib.check(self.lib.exl2_q_moe_mlp_forward(q_moe_mlp, self._ptr(x, torch.float16, "x"), x.numel() // hidden,
+                                                       self._stream(x)))
+
+    def moe_route(self, x, gate, logits, topk: int) -> None:
+        rows, hidden = x.shape
+        self.lib.check(self.lib.exl2_moe_route(self._ptr(x, torch.float16, "x"), self._ptr(gate, torch.float16, "gate"),
+                                               self._ptr(logits, torch.float16, "logits"), rows, hidden, gate.shape[0],
+                                               int(topk), self._stream(x)))
+
     # ---- decode-loop utilities + graphs (ours; no reference counterpart at the ext_c level) ----------------------------
 
     def embed_rows(self, table, ids, out) -> None:

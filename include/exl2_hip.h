@@ -125,6 +125,18 @@ int exl2_make_q_mlp(void** handle, const void* layernorm, const void* layernorm_
 int exl2_free_q_mlp(void* handle);
 int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream);
 
+/* make_q_moe_mlp / q_moe_mlp_forward_ (ext_qmlp.h, ext_qmlp.cpp:245-272 -> QMoEMLP::forward_ cuda/q_mlp.cu:318-402).
+   w1 / w2 / w3: arrays of num_experts q_matrix handles (gate, down, up projections).  num_experts in {4, 8, 16}.
+   The reference accepts rows <= 4; this entry point takes any rows <= max_rows (16-row passes). */
+int exl2_make_q_moe_mlp(void** handle, const void* layernorm, const void* layernorm_bias, int layernorm_is_rms,
+                        float norm_epsilon, const void* gate, int num_experts, int num_experts_per_token,
+                        void* const* w1, void* const* w2, void* const* w3, void* temp_state, void* temp_gathered_state,
+                        void* temp_a, void* temp_b, void* temp_logits, void* temp_dq, int max_rows, int act_gelu);
+int exl2_free_q_moe_mlp(void* handle);
+int exl2_q_moe_mlp_forward(void* handle, void* x, int rows, void* stream);
+/* router: logits[rows, E] = x gate^T, then softmax -> top-k -> renormalise in place (cuda/q_mlp_softmax.cuh) */
+int exl2_moe_route(const void* x, const void* gate, void* logits, int rows, int hidden, int num_experts, int topk, void* stream);
+
 /* ---- decode-loop utilities and graphs (replace cuda/graph.cu and the host-side embedding / argmax round trips) ------- */
 
 int exl2_embed_rows(const void* table, const int* ids, void* out, int rows, int hidden, int vocab, void* stream);

@@ -1,0 +1,81 @@
+"""MoE expert path: router (softmax -> top-k -> renormalise) and the fused q_moe_mlp_forward_
+against a composition of oracle pieces (oracle.modules.moe_route / rms_norm / silu_mul + reconstructed experts).
+Reference semantics: QMoEMLP::forward_ (cuda/q_mlp.cu:318-402), routing arithmetic cuda/q_mlp_softmax.cuh."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import exl2 as OX
+from oracle import modules as OM
+from tests.util import make_exl2
+
+F16 = np.float16
+
+
+@pytest.mark.parametrize("experts,topk", [(8, 2), (4, 1), (16, 4)])
+def test_moe_route(be, experts, topk):
+    rng = np.random.default_rng(30)
+    rows, hidden = 5, 128
+    x = rng.standard_normal((rows, hidden)).astype(F16)
+    gate = (rng.standard_normal((experts, hidden)) * 0.2).astype(F16)
+    logits = torch.zeros((rows, experts), dtype=torch.float16, device=be.device)
+    be.ext.moe_route(be.t(x), be.t(gate), logits, topk)
+    raw = (x.astype(np.float32) @ gate.astype(np.float32).T).astype(F16)
+    want, mask = OM.moe_route(raw, topk)
+    got = be.n(logits)
+    assert np.array_equal(got != 0, mask)                                    # same experts selected
+    assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= 2e-3)
+    assert np.allclose(got.astype(np.float32).sum(-1), 1.0, atol=2e-3)
+
+
+@pytest.mark.parametrize("rows", [1, 3, 16, 21])
+def test_moe_mlp_forward(be, rows):
+    """Every expert's kernels see all rows; rows not routed to it are skipped, launches with no routed row exit.
+    rows = 16 is BASELINE config 5's decode batch (the reference falls back to a torch loop above 4 rows)."""
+    rng = np.random.default_rng(31)
+    E, topk, hidden, inter = 8, 2, 128, 256
+    spec_up = [(4, 32, hidden)]
+    spec_dn = [(5, 32, 64), (4, 64, inter - 64)]
+    keep, handles, refs = [], {"w1": [], "w2": [], "w3": []}, {"w1": [], "w2": [], "w3": []}
+    for e in range(E):
+        for name, (k, n, spec) in (("w1", (hidden, inter, spec_up)), ("w3", (hidden, inter, spec_up)), ("w2", (inter, hidden, spec_dn))):
+            t, ref, w, h = make_exl2(be, k, n, spec, seed=100 + 3 * e + len(name) + ord(name[1]), act_order=True)
+            keep.append(w); handles[name].append(h); refs[name].append(ref)
+    norm_w = (1.0 + 0.1 * rng.standard_normal(hidden)).astype(F16)
+    gate = (rng.standard_normal((E, hidden)) * 0.3).astype(F16)
+    x = rng.standard_normal((rows, hidden)).astype(F16)
+
+    max_rows = 32
+    dev = be.device
+    ts = torch.zeros((max_rows, hidden), dtype=torch.float16, device=dev)
+    ta = torch.zeros((max_rows, inter), dtype=torch.float16, device=dev)
+    tb = torch.zeros((max_rows, inter), dtype=torch.float16, device=dev)
+    tl = torch.zeros((max_rows, E), dtype=torch.float16, device=dev)
+    from exllamav2_amd.ext import none_tensor
+    nw, gt = be.t(norm_w), be.t(gate)
+    moe = be.ext.make_q_moe_mlp(nw, none_tensor, True, 1e-5, gt, E, topk, handles["w1"], handles["w2"], handles["w3"],
+                                ts, none_tensor, ta, tb, tl, none_tensor, max_rows, False)
+    xt = be.t(x)
+    be.ext.q_moe_mlp_forward_(moe, xt)
+    got = be.n(xt).astype(np.float64)
+
+    # oracle composition
+    xn = OM.rms_norm(x, norm_w, 1e-5)
+    raw = (xn.astype(np.float32) @ gate.astype(np.float32).T).astype(F16)
+    wts, mask = OM.moe_route(raw, topk)
+    assert np.array_equal(be.n(tl)[:rows] != 0, mask)
+    want = x.astype(np.float64).copy()
+    acc16 = x.copy()
+    for e in range(E):
+        sel = np.nonzero(mask[:, e])[0]
+        if len(sel) == 0: continue
+        g = OX.gemm_ref(xn[sel], refs["w1"][e], exact=True).astype(F16)
+        u = OX.gemm_ref(xn[sel], refs["w3"][e], exact=True).astype(F16)
+        a = OM.silu_mul(g, u)
+        d = OX.gemm_ref(a, refs["w2"][e], exact=True)
+        want[sel] += d * wts[sel, e].astype(np.float64)[:, None]
+    tol = np.abs(want) * 2.0 ** -8 + 6e-3                   # E sequential fp16 accumulations into the residual
+    assert np.all(np.abs(got - want) <= tol), float(np.abs(got - want).max())
+    be.ext.free_q_moe_mlp(moe)
+    for hs in handles.values():
+        for h in hs: be.ext.free_q_matrix(h)
