@@ -194,7 +194,7 @@ def main():
         result = {
             "value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load,
             "roofline": {
-                "bound": "hbm", "kernel": "qgemv_kernel<false> (all q_gemm launches of a decode step)",
+                "bound": "hbm", "kernel": "qgemv_stream_kernel<false, MB> (all q_gemm launches of a decode step: fused q|k|v, o, fused gate|up, down per layer + head)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic_gb(launches),
                 "traffic_unit": "GB per decode step (PMC FETCH_SIZE x2, profiles/)", "bytes_per_step": gemv_bytes, "launches_per_step": launches,

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #define ATT_WAVES 4
+#define ATT_UNROLL 4
 #define NEG_BIG (-1.0e30f)
 
 struct AttnArgs
@@ -326,17 +327,28 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     };
 
     const size_t row_stride = (size_t)a.KVH * HDIM;
-    // keys already in the cache
+    // keys already in the cache: the K/V rows of ATT_UNROLL steps are requested together (one round trip per batch instead
+    // of one per step -- a split covers ~128 keys = 8 steps, each step a dependent pair of loads otherwise)
     const int k_old_end = min(k_end, past);
-    for (int base = k_start + wv * KPW; base < k_old_end; base += ATT_WAVES * KPW)
+    constexpr int STEP = ATT_WAVES * KPW;
+    for (int base0 = k_start + wv * KPW; base0 < k_old_end; base0 += ATT_UNROLL * STEP)
     {
-        const int kpos = base + group;
-        const bool in_range = kpos < k_old_end;
-        const int kp = in_range ? kpos : k_start;
-        const size_t off = slot_of(kp) * row_stride + (size_t)kh * HDIM + dl * 8;
-        const f16x8 kf = ld_nt((const f16x8*)(a.k_cache + off));
-        const f16x8 vf = ld_nt((const f16x8*)(a.v_cache + off));
-        attend(kf, vf, kpos, in_range);
+        f16x8 kf[ATT_UNROLL], vf[ATT_UNROLL];
+        #pragma unroll
+        for (int u = 0; u < ATT_UNROLL; u++)
+        {
+            const int kpos = base0 + u * STEP + group;
+            const int kp = kpos < k_old_end ? kpos : k_start;       // keep the address valid, mask the score
+            const size_t off = slot_of(kp) * row_stride + (size_t)kh * HDIM + dl * 8;
+            kf[u] = ld_nt((const f16x8*)(a.k_cache + off));
+            vf[u] = ld_nt((const f16x8*)(a.v_cache + off));
+        }
+        #pragma unroll
+        for (int u = 0; u < ATT_UNROLL; u++)
+        {
+            const int kpos = base0 + u * STEP + group;
+            if (base0 + u * STEP < k_old_end) attend(kf[u], vf[u], kpos, kpos < k_old_end);
+        }
     }
     // keys of this step: rotate, use, append
     for (int base = max(k_start, past) + wv * KPW; base < k_end; base += ATT_WAVES * KPW)
