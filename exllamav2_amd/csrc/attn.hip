@@ -407,11 +407,13 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
         }
         else
         {
-            a.part_o[(qrow * a.nsplit + split) * HDIM + d] = O;
+            // partial results travel as agent-scope (write-through) stores and are read back with agent-scope loads: the
+            // hand-off then needs no L2 write-back / invalidate, only "my stores have completed" before the ticket
+            store_agent_f32(a.part_o + (qrow * a.nsplit + split) * HDIM + d, O);
             if (d == 0)
             {
-                a.part_ml[(qrow * a.nsplit + split) * 2 + 0] = M;
-                a.part_ml[(qrow * a.nsplit + split) * 2 + 1] = L;
+                store_agent_f32(a.part_ml + (qrow * a.nsplit + split) * 2 + 0, M);
+                store_agent_f32(a.part_ml + (qrow * a.nsplit + split) * 2 + 1, L);
             }
         }
     }
@@ -421,14 +423,9 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     wait_vmcnt0();
     block_sync();
     u32* counter = a.counters + ((size_t)b * a.KVH + kh) * rblocks + rblk;
-    if (tid() == 0)
-    {
-        fence_release_agent();
-        *ticket_lds = ticket_add_agent(counter, 1u);
-    }
+    if (tid() == 0) *ticket_lds = ticket_add_agent(counter, 1u);
     block_sync();
     if (*ticket_lds != (u32)(eff - 1)) return;
-    fence_acquire_agent();
     for (int idx = tid(); idx < nrows * HDIM; idx += nthreads())
     {
         const int r = idx / HDIM, d = idx - r * HDIM;

@@ -168,6 +168,8 @@ DEV void fence_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent
 DEV void fence_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 DEV u32 ticket_add_agent(u32* p, u32 v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV float load_agent_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// write-through store at agent scope (sc1): visible to the other XCDs without flushing the whole L2 (buffer_wbl2)
+DEV void store_agent_f32(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void store_relaxed_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // dynamic LDS (16-byte aligned base, guide G17)

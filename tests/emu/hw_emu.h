@@ -240,6 +240,7 @@ DEV void fence_release_agent() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 DEV void fence_acquire_agent() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 DEV u32 ticket_add_agent(u32* p, u32 v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 DEV float load_agent_f32(const float* p) { return *(const volatile float*)p; }
+DEV void store_agent_f32(float* p, float v) { *(volatile float*)p = v; }
 DEV void store_relaxed_agent(u32* p, u32 v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 
 #define DYN_SMEM(name) unsigned char* name = emu_ctx_->dyn_smem
