@@ -12,8 +12,9 @@
 //   * a lane's b dwords decode with the magic-number half2 trick into the B fragment of v_mfma_f32_16x16x32_f16; the
 //     activation rows (M <= 16, gathered through q_perm once per workgroup into LDS) are the A fragment.  The matrix
 //     core does the 2*M*16*32 flops of a chunk in 4 passes whatever M is, so M = 1..16 cost the same VALU work;
-//   * weights are dequantized to fp16 exactly like the reference's reconstruct (half(q - zero) * half(scale), one
-//     rounding) and accumulated in fp32: results equal matmul(x, reconstruct()) up to fp32 summation order;
+//   * the B operand is the exact (q - zero) in fp16; the group scale multiplies the fp32 partial sum (qgemv_common.h):
+//     gemm(I) still equals reconstruct() bit for bit, general results equal matmul(x, reconstruct()) within fp16
+//     rounding of the individual weights;
 //   * optional prologue fusions while the activations are staged: RMSNorm (rms_norm.cu numerics) or SiLU(gate)*up;
 //     optional epilogue: bias, accumulate into the residual (c += a*W), MoE routing weight.
 #include "qgemv_common.h"

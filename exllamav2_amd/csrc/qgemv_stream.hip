@@ -122,7 +122,7 @@ struct RunSlice { const u32* ptr0; int n; int chunk0; };
 #ifndef MAIN_DEPTH_NARROW
 #define MAIN_DEPTH_NARROW 4
 #endif
-template <int MB> struct MainDepth { static constexpr int v = MB <= 4 ? MAIN_DEPTH_NARROW : (MB <= 6 ? 5 : 4); };
+template <int MB> struct MainDepth { static constexpr int v = MB <= 4 ? MAIN_DEPTH_NARROW : (MB <= 6 ? 4 : 3); };
 
 // slice r of S of a full run, for one tile
 DEV RunSlice slice_of(const QRun& run, const QMatDev& m, int tile, int r, int S)
@@ -257,11 +257,14 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     float* red  = (float*)smem;                               // aliases a_lds after the streaming
 
     // ---- issue: prologue inputs (LDS-DMA) --------------------------------------------------------------------------------
+    const bool lds_stage = h.lds_rawx_off != 0;             // rows staged through LDS; else gathered from global memory
     {
         const f16* a = h.a; const int lda = h.lda;
+        if (lds_stage)
         for (int rr = 0; rr < M; rr++)
             dma_units16([&](int u) { return (const void*)(a + (size_t)rr * lda + (size_t)u * 8); }, L.rawx + (size_t)rr * K, oct, wv, nw, lane);
-        if (h.a_mode == A_RMSNORM)
+        if (!lds_stage) { }
+        else if (h.a_mode == A_RMSNORM)
         {
             const f16* w = h.norm_w;
             dma_units16([&](int u) { return (const void*)(w + (size_t)u * 8); }, L.raw2, oct, wv, nw, lane);
@@ -272,7 +275,7 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
             for (int rr = 0; rr < M; rr++)
                 dma_units16([&](int u) { return (const void*)(a2 + (size_t)rr * lda + (size_t)u * 8); }, L.raw2 + (size_t)rr * K, oct, wv, nw, lane);
         }
-        if (h.perm)
+        if (h.perm && lds_stage)
         {
             const u16* pm = h.perm;
             dma_units16([&](int u) { return (const void*)(pm + (size_t)u * 8); }, L.perm, oct, wv, nw, lane);
@@ -347,13 +350,14 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
         }
     }
     TRACE_POINT(10);
-    if (h.a_mode == A_RMSNORM)
+    if (lds_stage)
     {
-        stage_rms_lds(L, K, h.norm_eps, M, lane, wv, nw);
-        block_sync_lds();
-    }
-    TRACE_POINT(11);
-    {
+        if (h.a_mode == A_RMSNORM)
+        {
+            stage_rms_lds(L, K, h.norm_eps, M, lane, wv, nw);
+            block_sync_lds();
+        }
+        TRACE_POINT(11);
         const bool hp = h.perm != nullptr;
         switch (h.a_mode)
         {
@@ -363,6 +367,38 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
             case A_GELU_MUL: stage_shuffle_lds<A_GELU_MUL>(L, hp, a_lds, h.a_stride, K, M, t, nt); break;
             case A_SILU:     stage_shuffle_lds<A_SILU>(L, hp, a_lds, h.a_stride, K, M, t, nt); break;
             default:         stage_shuffle_lds<A_GELU>(L, hp, a_lds, h.a_stride, K, M, t, nt); break;
+        }
+    }
+    else
+    {
+        // many rows (M x K does not fit twice in LDS): gather straight from global memory -- three dependent round trips,
+        // amortised over M rows (stage_rows, qgemv_common.h)
+        const GemvJob& jc = args.job[ji];
+        float* rmf_w = L.rms + 16 + wv * 16;                 // per-wave copy: no block barrier needed
+        if (h.a_mode == A_RMSNORM)
+        {
+            for (int rr = 0; rr < M; rr++)
+            {
+                const f16x8* xr = (const f16x8*)(h.a + (size_t)rr * h.lda);
+                float ss = 0.0f;
+                for (int i = lane; i < oct; i += 64)
+                {
+                    const f16x8 v = xr[i];
+                    #pragma unroll
+                    for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)); ss = fmaf(f, f, ss); }
+                }
+                ss = wave_allreduce_add(ss);
+                rmf_w[rr] = fast_rsqrt(ss * (1.0f / (float)K) + h.norm_eps);
+            }
+        }
+        switch (h.a_mode)
+        {
+            case A_PLAIN:    stage_rows<A_PLAIN>(jc, jc.m, h.a, h.a2, a_lds, rmf_w, 0, oct, M, t, nt); break;
+            case A_RMSNORM:  stage_rows<A_RMSNORM>(jc, jc.m, h.a, h.a2, a_lds, rmf_w, 0, oct, M, t, nt); break;
+            case A_SILU_MUL: stage_rows<A_SILU_MUL>(jc, jc.m, h.a, h.a2, a_lds, rmf_w, 0, oct, M, t, nt); break;
+            case A_GELU_MUL: stage_rows<A_GELU_MUL>(jc, jc.m, h.a, h.a2, a_lds, rmf_w, 0, oct, M, t, nt); break;
+            case A_SILU:     stage_rows<A_SILU>(jc, jc.m, h.a, h.a2, a_lds, rmf_w, 0, oct, M, t, nt); break;
+            default:         stage_rows<A_GELU>(jc, jc.m, h.a, h.a2, a_lds, rmf_w, 0, oct, M, t, nt); break;
         }
     }
     if constexpr (MB != 0) ring_fill<MB, DM, FIRST_SIP, DM>(pre, ms.ptr0, ms.n, lane);
@@ -518,6 +554,8 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
     if (TPW * S > 16) TPW = 16 / S > 0 ? 16 / S : 1;
     const int W = TPW * S;
 
+    const char* nls = getenv("EXL2_GEMV_NO_LDS_STAGE");       // tests: force the many-rows staging route
+    const bool no_lds_stage = nls && atoi(nls);
     StreamArgs args;
     memset(&args, 0, sizeof(args));
     args.n_jobs = n_jobs; args.M = M; args.S = S; args.TPW = TPW;
@@ -547,11 +585,19 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
         h.lds_zp_off = total;     total += gptq ? align16s((u32)TPW * m.G * 32) : 0;
         h.lds_cg_off = total;     total += align16s((u32)(m.K >> 5) * 2 + 4);
         h.lds_rmf_off = total;    total += 64 + 16 * 16 * 4;
-        h.lds_rawx_off = total;   total += row_bytes;
-        h.lds_raw2_off = total;   total += two ? row_bytes : (j.a_mode == A_RMSNORM ? align16s((u32)m.K * 2) : 0);
-        h.lds_perm_off = total;   total += m.perm ? align16s((u32)m.K * 2) : 0;
         h.lds_qsw_off = total;    total += align16s((u32)TPW * m.G * 8);
         h.lds_smax_off = total;   total += align16s((u32)m.G * 2 + 4);
+        {
+            const u32 raw = row_bytes + (two ? row_bytes : (j.a_mode == A_RMSNORM ? align16s((u32)m.K * 2) : 0))
+                            + (m.perm ? align16s((u32)m.K * 2) : 0);
+            if (total + raw <= 160 * 1024 && !no_lds_stage)
+            {
+                h.lds_rawx_off = total;   total += row_bytes;
+                h.lds_raw2_off = total;   total += two ? row_bytes : (j.a_mode == A_RMSNORM ? align16s((u32)m.K * 2) : 0);
+                h.lds_perm_off = total;   total += m.perm ? align16s((u32)m.K * 2) : 0;
+            }
+            else { h.lds_rawx_off = 0; h.lds_raw2_off = 0; h.lds_perm_off = 0; }      // gather from global memory instead
+        }
         if (total > lds) lds = total;
 
         const QRun& mr = m.runs[m.main_run];

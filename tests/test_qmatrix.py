@@ -118,6 +118,21 @@ def test_prefill_gptq_identity(be):
     be.ext.free_q_matrix(h)
 
 
+@pytest.mark.parametrize("m", [3, 16])
+def test_gemm_many_rows_staging_route(be, m, monkeypatch):
+    """When M x K does not fit twice in LDS the streaming kernel gathers the rows from global memory instead of staging
+    them through LDS; forced here on a small shape."""
+    monkeypatch.setenv("EXL2_GEMV_NO_LDS_STAGE", "1")
+    k, n, spec = SPECS["mixed_5_4"]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=21, bias=True)
+    a = np.random.default_rng(22).standard_normal((m, k)).astype(np.float16)
+    c = torch.zeros((m, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    want = OX.gemm_ref(a, ref, bias=t["bias"], exact=True)
+    assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= half_tol(want, k))
+    be.ext.free_q_matrix(h)
+
+
 def test_gemm_bias(be):
     k, n, spec = SPECS["b4_g128"]
     t, ref, w, h = make_exl2(be, k, n, spec, seed=7, bias=True)
