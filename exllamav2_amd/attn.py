@@ -21,6 +21,7 @@ class ExLlamaV2Attention:
         self.pre_layernorm = None
         self.q_handle = None
         self.fused_decode = os.environ.get("EXL2_ATTN_FUSED", "1") != "0"       # A/B switch for measurements
+        self.q4_fused = os.environ.get("EXL2_Q4_FUSED", "1") != "0"
 
     def load(self, ck: dict):
         cfg, m = self.model.config, self.model
@@ -69,27 +70,52 @@ class ExLlamaV2Attention:
         if cache is None:
             raise RuntimeError("ExLlamaV2Attention.forward: a cache is required")
         attn_out = m.temp_attn[:rows].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
+        # Q4 cache, decode-sized step: attend straight from the codes (attn_q4.hip) -- the reference unpacks the whole live
+        # range to an fp16 temp for every layer of every step (cache.py:472-514)
+        # (the step's own K/V are attended in fp16 and quantised afterwards, the reference's order)
+        q4_direct = (getattr(cache, "wbits", 0) == 4 and hasattr(cache, "q4_views") and not big and self.q4_fused and q_len <= 8
+                     and q_len * (cfg.num_attention_heads // cfg.num_key_value_heads) <= 64
+                     and cfg.head_dim in (64, 128, 256)
+                     and (cfg.num_key_value_heads * cfg.head_dim) % 512 == 0)     # codec blocks (512 elements) must not span tokens
         if paged:
-            cache.get_kv_state(self.layer_idx, b, 0, 0, 256, cache_seqlens, block_table)
+            if not q4_direct:
+                cache.get_kv_state(self.layer_idx, b, 0, 0, 256, cache_seqlens, block_table)
             kc, vc = cache.paged_view(self.layer_idx)
             sl, bt, past = cache_seqlens, block_table, 0
         else:
-            kc, vc = cache.get_kv_state(self.layer_idx, b, 0, past_len)
+            if q4_direct:
+                kc, vc = cache.get_kv_state(self.layer_idx, b, 0, 0)           # width 0: the temp pair, nothing unpacked
+            else:
+                kc, vc = cache.get_kv_state(self.layer_idx, b, 0, past_len)
             sl, bt, past = None, None, past_len
-        # decode-shaped steps: one launch does RoPE + append + attention + split merge; otherwise three launches
-        fused = (not big) and self.fused_decode and ext.attn_decode_fused(q, k, v, kc, vc, attn_out, m.sin, m.cos, sl, bt, past,
-                                                            cfg.rope_style, m.attn_scratch, m.attn_counters)
-        if not fused:
+        if q4_direct:
+            # new K/V -> (rotated) into the fp16 staging rows -> quantised into the cache -> attention over codes
             ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, past if not paged else 0,
                                sl if paged else none_tensor, bt if paged else none_tensor, cfg.rope_style)
-            if big and not paged and q_len > 16:
-                self._attn_library(q, kc, vc, attn_out, past, q_len)
+            if paged:
+                cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
             else:
-                ext.paged_attn(q, kc, vc, attn_out, sl, bt, len_const=past, len_offset=q_len, scratch=m.attn_scratch)
-        if paged:
-            cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
+                cache.store_kv_state(self.layer_idx, b, past_len, q_len)
+            kq, ks, vq, vs = cache.q4_views(self.layer_idx, paged)
+            ok = ext.paged_attn_q4(q, kq, ks, vq, vs, attn_out, sl, bt, len_const=past, len_offset=q_len,
+                                   scratch=m.attn_scratch, k_new=k, v_new=v)
+            if not ok:
+                raise RuntimeError("ExLlamaV2Attention: fused Q4 attention rejected a shape it was selected for")
         else:
-            cache.store_kv_state(self.layer_idx, b, past_len, q_len)
+            # decode-shaped steps: one launch does RoPE + append + attention + split merge; otherwise three launches
+            fused = (not big) and self.fused_decode and ext.attn_decode_fused(
+                q, k, v, kc, vc, attn_out, m.sin, m.cos, sl, bt, past, cfg.rope_style, m.attn_scratch, m.attn_counters)
+            if not fused:
+                ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, past if not paged else 0,
+                                   sl if paged else none_tensor, bt if paged else none_tensor, cfg.rope_style)
+                if big and not paged and q_len > 16:
+                    self._attn_library(q, kc, vc, attn_out, past, q_len)
+                else:
+                    ext.paged_attn(q, kc, vc, attn_out, sl, bt, len_const=past, len_offset=q_len, scratch=m.attn_scratch)
+            if paged:
+                cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
+            else:
+                cache.store_kv_state(self.layer_idx, b, past_len, q_len)
         if big:
             hidden_states.view(rows, -1).add_(self.o_proj.forward(attn_out.view(rows, -1)))
         else:

@@ -90,6 +90,15 @@ class ExLlamaV2Cache_Q4(ExLlamaV2Cache):
         return (self.temp_k.view(-1, PAGE_SIZE, cfg.num_key_value_heads, cfg.head_dim),
                 self.temp_v.view(-1, PAGE_SIZE, cfg.num_key_value_heads, cfg.head_dim))
 
+    def q4_views(self, layer_idx, paged: bool):
+        """(k_codes, k_scales, v_codes, v_scales) of a layer for the fused Q4 attention kernel (attn_q4.hip): contiguous
+        [b, T, KVH, .] or, paged, [pages, 256, KVH, .]."""
+        ts = (self.key_states[layer_idx], self.key_scales[layer_idx], self.value_states[layer_idx], self.value_scales[layer_idx])
+        if not paged:
+            return ts
+        kvh = self.model.config.num_key_value_heads
+        return tuple(t.view(-1, PAGE_SIZE, kvh, t.shape[-1]) for t in ts)
+
     def footprint(self) -> int:
         ts = self.key_states + self.value_states + self.key_scales + self.value_scales
         return sum(t.numel() * t.element_size() for t in ts)

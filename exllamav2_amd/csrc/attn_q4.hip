@@ -1,0 +1,408 @@
+// attn_q4.hip -- decode attention straight from the Q4 KV cache.
+//
+// Reference behaviour: ExLlamaV2Cache_Q4.get_kv_state (cache.py:472-514) unpacks the WHOLE live range of K and V to an
+// fp16 temp for every layer of every decode step (q_to_fp16_kv, cache.cu:324-401), attention then reads that temp:
+// O(ctx) bytes written and read again per layer per token.  This kernel reads the 4-bit codes and scales directly:
+// 144 B per key per head (hd = 128) instead of 512 B, and nothing is unpacked to memory.
+//
+// The cache format (cache_q.cuh:4-185, restated in cache_q.hip): per 64 consecutive elements, even- and odd-indexed
+// elements are each rotated by a 32-point Walsh-Hadamard transform H, then every 32 contiguous elements share one fp16
+// scale s and store codes c in [0, 15]:   x = (1/32) H d,  d = (c - 8) s.   H is symmetric, so
+//     q . x = (1/32) (H q) . d            and            sum_keys p x = (1/32) H (sum_keys p d):
+// the QUERY is rotated once per workgroup, scores are dot products of the rotated query with raw codes, the weighted
+// values accumulate in the rotated domain and are rotated back once at the end.  (The reference rounds the unpacked
+// x to fp16 element by element; this path keeps fp32 sums -- same values within that rounding.)
+#include "hw.h"
+#include "errors.h"
+#include <string.h>
+
+#define AQ_WAVES 4
+#define AQ_NEG_BIG (-1.0e30f)
+
+struct AttnQ4Args
+{
+    const f16* q;                 // [b, s, H, hd]  (already rotated by RoPE)
+    const u8* k_codes; const f16* k_scales;     // [pages | b, page_size | T, KVH, hd/2] , [.., KVH, hd/32]
+    const u8* v_codes; const f16* v_scales;
+    const f16* k_new; const f16* v_new;          // nullable: [b, s, KVH, hd] fp16 (k rotated): keys >= total - s come from here
+    const int* cache_seqlens; const int* block_table;
+    f16* out; float* part_o; float* part_ml;
+    int b, s, H, KVH;
+    int page_size, page_shift, pages_per_seq;
+    int len_const, len_offset, nsplit, causal;
+    float scale;
+};
+
+// (c_lo - 8, c_hi - 8) as exact halves for byte `i` of the four code bytes in lo / hi (nibbles already split)
+DEV f16x2 code_pair(u32 lo, u32 hi, int i)
+{
+    const u32 l = (lo >> (8 * i)) & 0xFFu, h = (hi >> (8 * i)) & 0xFFu;
+    return as_h2(l | (h << 16) | 0x64006400u) - (f16x2){(f16)1032.0f, (f16)1032.0f};
+}
+
+template <int HDIM, int RB>
+KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4Args a)
+{
+    DYN_SMEM(smem);
+    constexpr int LPK = HDIM / 16;              // lanes per key: 16 elements (8 code bytes) each
+    constexpr int KPW = 64 / LPK;
+    constexpr int NSTREAM = AQ_WAVES * KPW;
+    constexpr int ROWF = HDIM + 2;
+
+    const int kh = bid_x();
+    const int split = bid_y();
+    const int G = a.H / a.KVH;
+    const int R = a.s * G;
+    const int rblocks = (R + RB - 1) / RB;
+    const int b = bid_z() / rblocks;
+    const int rblk = bid_z() % rblocks;
+    const int r0 = rblk * RB;
+    const int nrows = min(RB, R - r0);
+
+    const int lane = lane_id();
+    const int wv = wave_id();
+    const int group = lane / LPK;
+    const int u = lane % LPK;                   // elements [16 u, 16 u + 16) of the head
+
+    const int total = (a.cache_seqlens ? a.cache_seqlens[b] : a.len_const) + a.len_offset;
+    int kps = (total + a.nsplit - 1) / a.nsplit;
+    kps = (kps + 15) & ~15;
+    const int k_start = split * kps;
+    const int k_end = min(total, k_start + kps);
+
+    // ---- rotate the query rows: qh[64 g + 2 t + comp] = sum_t' H[t, t'] q[64 g + 2 t' + comp], H[t,t'] = (-1)^popc(t & t')
+    float* qh_lds = (float*)smem;                                       // [RB][HDIM]
+    for (int idx = tid(); idx < nrows * HDIM; idx += nthreads())
+    {
+        const int r = idx / HDIM, e = idx - r * HDIM;
+        const int rr = r0 + r, j = rr / G, g = rr - j * G;
+        const f16* qr = a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM;
+        const int span = e >> 6, t = (e & 63) >> 1, comp = e & 1;
+        float acc = 0.0f;
+        for (int t2 = 0; t2 < 32; t2++)
+        {
+            const float v = (float)qr[span * 64 + 2 * t2 + comp];
+            acc += (__builtin_popcount(t & t2) & 1) ? -v : v;
+        }
+        qh_lds[idx] = acc;
+    }
+    block_sync();
+    f16x2 qf[RB][8], qp[RB][8];                                         // rotated / plain query slices of this lane
+    int limit[RB];
+    #pragma unroll
+    for (int r = 0; r < RB; r++)
+    {
+        const int rs = r < nrows ? r : 0;
+        #pragma unroll
+        for (int i = 0; i < 8; i++)
+            qf[r][i] = (f16x2){(f16)qh_lds[rs * HDIM + 16 * u + 2 * i], (f16)qh_lds[rs * HDIM + 16 * u + 2 * i + 1]};
+        const int rr = r0 + rs, j = rr / G, g = rr - j * G;
+        const f16* qr = a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM + 16 * u;
+        #pragma unroll
+        for (int i = 0; i < 8; i++) qp[r][i] = (f16x2){qr[2 * i], qr[2 * i + 1]};
+        limit[r] = a.causal ? (total - a.s + j + 1) : total;
+    }
+    block_sync();
+
+    float m[RB], l[RB], o[RB][16];
+    #pragma unroll
+    for (int r = 0; r < RB; r++)
+    {
+        m[r] = AQ_NEG_BIG; l[r] = 0.0f;
+        #pragma unroll
+        for (int e = 0; e < 16; e++) o[r][e] = 0.0f;
+    }
+
+    const size_t tok_codes = (size_t)a.KVH * (HDIM / 2);                // bytes per token slot
+    const size_t tok_scales = (size_t)a.KVH * (HDIM / 32);
+    const int past = a.k_new ? total - a.s : total;                      // keys [past, total) come from k_new / v_new
+    const int k_old_end = min(k_end, past);
+    for (int base = k_start + wv * KPW; base < k_old_end; base += AQ_WAVES * KPW)
+    {
+        const int kpos = base + group;
+        const bool in_range = kpos < k_old_end;
+        const int kp = in_range ? kpos : k_start;
+        size_t tok;
+        if (a.block_table)
+            tok = (size_t)a.block_table[(size_t)b * a.pages_per_seq + (kp >> a.page_shift)] * a.page_size
+                  + (kp & (a.page_size - 1));
+        else
+            tok = (size_t)b * a.page_size + kp;
+        const size_t co = tok * tok_codes + (size_t)kh * (HDIM / 2) + u * 8;
+        const size_t so = tok * tok_scales + (size_t)kh * (HDIM / 32) + (u >> 1);
+        const u32x2 kc = ld_nt((const u32x2*)(a.k_codes + co));
+        const u32x2 vc = ld_nt((const u32x2*)(a.v_codes + co));
+        const float ks = (float)a.k_scales[so] * (1.0f / 32.0f);
+        const float vs = (float)a.v_scales[so];
+
+        f16x2 kd[8], vd[8];
+        {
+            const u32 l0 = kc.x & 0x0F0F0F0Fu, h0 = (kc.x >> 4) & 0x0F0F0F0Fu;
+            const u32 l1 = kc.y & 0x0F0F0F0Fu, h1 = (kc.y >> 4) & 0x0F0F0F0Fu;
+            #pragma unroll
+            for (int i = 0; i < 4; i++) { kd[i] = code_pair(l0, h0, i); kd[4 + i] = code_pair(l1, h1, i); }
+            const u32 m0 = vc.x & 0x0F0F0F0Fu, n0 = (vc.x >> 4) & 0x0F0F0F0Fu;
+            const u32 m1 = vc.y & 0x0F0F0F0Fu, n1 = (vc.y >> 4) & 0x0F0F0F0Fu;
+            #pragma unroll
+            for (int i = 0; i < 4; i++) { vd[i] = code_pair(m0, n0, i); vd[4 + i] = code_pair(m1, n1, i); }
+        }
+        #pragma unroll
+        for (int r = 0; r < RB; r++)
+        {
+            if (r < nrows)
+            {
+                float d = 0.0f;
+                #pragma unroll
+                for (int i = 0; i < 8; i++) d = dot2_f32_f16(qf[r][i], kd[i], d);
+                d *= ks;                                                // this lane's 16 elements: (1/32) s (H q).(c - 8)
+                if constexpr (LPK == 4) d = quad_allreduce_add(d);
+                else if constexpr (LPK == 8) d = row8_allreduce_add(d);
+                else d = row16_allreduce_add(d);
+                const float sc = d * a.scale;
+                const bool valid = in_range && kpos < limit[r];
+                const float m_new = valid ? fmaxf(m[r], sc) : m[r];
+                const float alpha = fast_exp(m[r] - m_new);
+                const float p = (valid ? fast_exp(sc - m_new) : 0.0f);
+                m[r] = m_new;
+                l[r] = l[r] * alpha + p;
+                const float pv = p * vs;
+                #pragma unroll
+                for (int i = 0; i < 8; i++)
+                {
+                    o[r][2 * i]     = o[r][2 * i]     * alpha + pv * (float)vd[i].x;
+                    o[r][2 * i + 1] = o[r][2 * i + 1] * alpha + pv * (float)vd[i].y;
+                }
+            }
+        }
+    }
+
+    // ---- the step's own keys / values, still fp16 (the reference attends over them before they are quantised) -------------
+    for (int base = max(k_start, past) + wv * KPW; base < k_end; base += AQ_WAVES * KPW)
+    {
+        const int kpos = base + group;
+        const bool in_range = kpos < k_end;
+        const int kp = in_range ? kpos : k_end - 1;
+        const size_t src = (((size_t)b * a.s + (kp - past)) * a.KVH + kh) * HDIM + 16 * u;
+        f16x2 kn[8];
+        float w[16];
+        #pragma unroll
+        for (int i = 0; i < 8; i++)
+        {
+            kn[i] = (f16x2){a.k_new[src + 2 * i], a.k_new[src + 2 * i + 1]};
+            w[2 * i] = (float)a.v_new[src + 2 * i]; w[2 * i + 1] = (float)a.v_new[src + 2 * i + 1];
+        }
+        // rotate v into the accumulation domain: H over the pair index t = 8 (u & 3) + i, per component
+        #pragma unroll
+        for (int mbit = 1; mbit < 8; mbit <<= 1)
+        {
+            #pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+                if (!(i & mbit))
+                {
+                    #pragma unroll
+                    for (int c = 0; c < 2; c++)
+                    {
+                        const float x0 = w[2 * i + c], x1 = w[2 * (i | mbit) + c];
+                        w[2 * i + c] = x0 + x1; w[2 * (i | mbit) + c] = x0 - x1;
+                    }
+                }
+            }
+        }
+        #pragma unroll
+        for (int lbit = 1; lbit < 4; lbit <<= 1)
+        {
+            #pragma unroll
+            for (int e = 0; e < 16; e++)
+            {
+                const float p = lbit == 1 ? shfl_xor_f32(w[e], 1) : shfl_xor_f32(w[e], 2);
+                w[e] = (u & lbit) ? p - w[e] : w[e] + p;
+            }
+        }
+        #pragma unroll
+        for (int r = 0; r < RB; r++)
+        {
+            if (r < nrows)
+            {
+                float d = 0.0f;
+                #pragma unroll
+                for (int i = 0; i < 8; i++) d = dot2_f32_f16(qp[r][i], kn[i], d);
+                if constexpr (LPK == 4) d = quad_allreduce_add(d);
+                else if constexpr (LPK == 8) d = row8_allreduce_add(d);
+                else d = row16_allreduce_add(d);
+                const float sc = d * a.scale;
+                const bool valid = in_range && kpos < limit[r];
+                const float m_new = valid ? fmaxf(m[r], sc) : m[r];
+                const float alpha = fast_exp(m[r] - m_new);
+                const float p = (valid ? fast_exp(sc - m_new) : 0.0f);
+                m[r] = m_new;
+                l[r] = l[r] * alpha + p;
+                #pragma unroll
+                for (int e = 0; e < 16; e++) o[r][e] = o[r][e] * alpha + p * w[e];
+            }
+        }
+    }
+
+    // ---- merge the streams of this workgroup (rotated domain), rotate back, store / emit partials --------------------------
+    float* st = (float*)smem;                                           // [NSTREAM][RB][ROWF]
+    const int stream = wv * KPW + group;
+    #pragma unroll
+    for (int r = 0; r < RB; r++)
+    {
+        if (r < nrows)
+        {
+            float* p = st + ((size_t)stream * RB + r) * ROWF;
+            #pragma unroll
+            for (int e = 0; e < 16; e++) p[u * 16 + e] = o[r][e];
+            if (u == 0) { p[HDIM] = m[r]; p[HDIM + 1] = l[r]; }
+        }
+    }
+    block_sync();
+    float* mg = st + (size_t)NSTREAM * RB * ROWF;                       // merged rotated rows [RB][HDIM + 2]
+    for (int idx = tid(); idx < nrows * HDIM; idx += nthreads())
+    {
+        const int r = idx / HDIM, d = idx - r * HDIM;
+        float M = AQ_NEG_BIG;
+        for (int s2 = 0; s2 < NSTREAM; s2++) M = fmaxf(M, st[((size_t)s2 * RB + r) * ROWF + HDIM]);
+        float L = 0.0f, O = 0.0f;
+        for (int s2 = 0; s2 < NSTREAM; s2++)
+        {
+            const float* p = st + ((size_t)s2 * RB + r) * ROWF;
+            const float w = fast_exp(p[HDIM] - M);
+            L += p[HDIM + 1] * w;
+            O += p[d] * w;
+        }
+        mg[r * ROWF + d] = O;
+        if (d == 0) { mg[r * ROWF + HDIM] = M; mg[r * ROWF + HDIM + 1] = L; }
+    }
+    block_sync();
+    for (int idx = tid(); idx < nrows * HDIM; idx += nthreads())
+    {
+        const int r = idx / HDIM, e = idx - r * HDIM;
+        const int span = e >> 6, t = (e & 63) >> 1, comp = e & 1;
+        float acc = 0.0f;
+        for (int t2 = 0; t2 < 32; t2++)
+        {
+            const float v = mg[r * ROWF + span * 64 + 2 * t2 + comp];
+            acc += (__builtin_popcount(t & t2) & 1) ? -v : v;
+        }
+        acc *= (1.0f / 32.0f);
+        const float M = mg[r * ROWF + HDIM], L = mg[r * ROWF + HDIM + 1];
+        const int rr = r0 + r, j = rr / G, g = rr - j * G;
+        const size_t qrow = ((size_t)b * a.s + j) * a.H + kh * G + g;
+        if (a.nsplit == 1)
+        {
+            a.out[qrow * HDIM + e] = (f16)(L > 0.0f ? acc / L : 0.0f);
+        }
+        else
+        {
+            a.part_o[(qrow * a.nsplit + split) * HDIM + e] = acc;
+            if (e == 0)
+            {
+                a.part_ml[(qrow * a.nsplit + split) * 2 + 0] = M;
+                a.part_ml[(qrow * a.nsplit + split) * 2 + 1] = L;
+            }
+        }
+    }
+}
+
+KERNEL void __launch_bounds__(256) attn_q4_combine_kernel(const AttnQ4Args a, int hd)
+{
+    const size_t qrow = bid_x();
+    for (int d = tid(); d < hd; d += nthreads())
+    {
+        float M = AQ_NEG_BIG;
+        for (int s2 = 0; s2 < a.nsplit; s2++) M = fmaxf(M, a.part_ml[(qrow * a.nsplit + s2) * 2]);
+        float L = 0.0f, O = 0.0f;
+        for (int s2 = 0; s2 < a.nsplit; s2++)
+        {
+            const float w = fast_exp(a.part_ml[(qrow * a.nsplit + s2) * 2] - M);
+            L += a.part_ml[(qrow * a.nsplit + s2) * 2 + 1] * w;
+            O += a.part_o[(qrow * a.nsplit + s2) * hd + d] * w;
+        }
+        a.out[qrow * hd + d] = (f16)(L > 0.0f ? O / L : 0.0f);
+    }
+}
+
+static int ilog2_exact_q4(int x) { int s = 0; while ((1 << s) < x) s++; return (1 << s) == x ? s : -1; }
+
+template <int HDIM>
+static void launch_q4(const AttnQ4Args& a, int rb, dim3 grid, void* stream)
+{
+    const int lpk = HDIM / 16, kpw = 64 / lpk;
+    const size_t lds = ((size_t)AQ_WAVES * kpw * rb + rb) * (HDIM + 2) * 4;
+    static bool attr_done = false;
+    if (!attr_done)
+    {
+        (void)hipFuncSetAttribute((const void*)attn_q4_decode_kernel<HDIM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_q4_decode_kernel<HDIM, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    switch (rb)
+    {
+        case 1: LAUNCH((attn_q4_decode_kernel<HDIM, 1>), grid, dim3(AQ_WAVES * 64), lds, stream, a); break;
+        case 2: LAUNCH((attn_q4_decode_kernel<HDIM, 2>), grid, dim3(AQ_WAVES * 64), lds, stream, a); break;
+        default: LAUNCH((attn_q4_decode_kernel<HDIM, 4>), grid, dim3(AQ_WAVES * 64), lds, stream, a); break;
+    }
+}
+
+extern "C" {
+
+// Attention over a Q4 KV cache.  k_new / v_new == NULL: the cache holds all `total` keys.  Otherwise the last q_len keys
+// (the step's own, k_new already rotated) are taken from these fp16 tensors -- the reference attends over the step's K/V
+// before quantising them (cache.py:517-556 runs after attention) -- and only keys < total - q_len come from the codes.
+// Same addressing / length conventions as exl2_paged_attn; codes [.., KVH, hd/2] uint8, scales [.., KVH, hd/32] fp16.
+// Returns 1 without launching for shapes it does not cover (caller unpacks with exl2_q_to_fp16_kv + exl2_paged_attn).
+int exl2_paged_attn_q4(const void* q, const void* k_codes, const void* k_scales, const void* v_codes, const void* v_scales,
+                       const void* k_new, const void* v_new, void* out, const int* cache_seqlens, const int* block_table,
+                       int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                       int page_size, int pages_per_seq, int len_const, int len_offset,
+                       float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes, void* stream)
+{
+    EXL2_REQUIRE(q && k_codes && k_scales && v_codes && v_scales && out, "paged_attn_q4: null argument");
+    EXL2_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged_attn_q4: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
+    if (batch <= 0 || q_len <= 0) return EXL2_OK;
+    if (!(head_dim == 64 || head_dim == 128 || head_dim == 256)) return 1;
+    const int G = num_heads / num_kv_heads;
+    const int R = q_len * G;
+    if (R > 64) return 1;
+    AttnQ4Args a;
+    memset(&a, 0, sizeof(a));
+    a.q = (const f16*)q; a.k_codes = (const u8*)k_codes; a.k_scales = (const f16*)k_scales;
+    a.v_codes = (const u8*)v_codes; a.v_scales = (const f16*)v_scales; a.out = (f16*)out;
+    EXL2_REQUIRE((k_new == nullptr) == (v_new == nullptr), "paged_attn_q4: k_new and v_new go together");
+    a.k_new = (const f16*)k_new; a.v_new = (const f16*)v_new;
+    a.cache_seqlens = cache_seqlens; a.block_table = block_table;
+    a.b = batch; a.s = q_len; a.H = num_heads; a.KVH = num_kv_heads;
+    a.page_size = page_size; a.pages_per_seq = pages_per_seq; a.page_shift = ilog2_exact_q4(page_size);
+    EXL2_REQUIRE(!block_table || a.page_shift >= 0, "paged_attn_q4: page_size %d must be a power of two", page_size);
+    a.len_const = len_const; a.len_offset = len_offset; a.causal = causal; a.scale = softmax_scale;
+    const int rb = R >= 4 ? 4 : (R >= 2 ? 2 : 1);
+    const int rblocks = (R + rb - 1) / rb;
+    if (nsplit <= 0)
+    {
+        const long long base = (long long)num_kv_heads * batch * rblocks;
+        nsplit = (int)((512 + base - 1) / base);
+        if (nsplit > 16) nsplit = 16;
+        if (nsplit < 1) nsplit = 1;
+    }
+    const long long need = nsplit <= 1 ? 0 : (long long)batch * q_len * num_heads * nsplit * (head_dim + 2) * 4;
+    if (need > scratch_bytes || (need > 0 && !scratch)) nsplit = 1;
+    a.nsplit = nsplit;
+    if (nsplit > 1)
+    {
+        a.part_o = (float*)scratch;
+        a.part_ml = a.part_o + (size_t)batch * q_len * num_heads * nsplit * head_dim;
+    }
+    dim3 grid((unsigned)num_kv_heads, (unsigned)nsplit, (unsigned)(batch * rblocks));
+    if (head_dim == 64) launch_q4<64>(a, rb, grid, stream);
+    else if (head_dim == 128) launch_q4<128>(a, rb, grid, stream);
+    else launch_q4<256>(a, rb, grid, stream);
+    if (nsplit > 1)
+        LAUNCH(attn_q4_combine_kernel, dim3((unsigned)(batch * q_len * num_heads)), dim3(head_dim < 256 ? head_dim : 256), 0,
+               stream, a, head_dim);
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
+}
+
+}  // extern "C"

@@ -103,6 +103,16 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
                            int rope_style, int sincos_size, int nsplit, void* scratch, long long scratch_bytes,
                            void* counters, int n_counters, void* stream);
 
+/* Decode attention straight from the Q4 KV cache (ExLlamaV2Cache_Q4, cache.py:409-606; format cache_q.cuh:4-185): replaces
+   q_to_fp16_kv of the whole live range (cache.py:472-514) + attention over the fp16 temp.  k_new / v_new (nullable, fp16
+   [b, q_len, KVH, hd], k_new rotated): the step's own keys, attended in fp16 like the reference does before it quantises them;
+   NULL = all keys come from the codes.  Returns 1 without launching for shapes it does not cover. */
+int exl2_paged_attn_q4(const void* q, const void* k_codes, const void* k_scales, const void* v_codes, const void* v_scales,
+                       const void* k_new, const void* v_new, void* out, const int* cache_seqlens, const int* block_table,
+                       int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                       int page_size, int pages_per_seq, int len_const, int len_offset,
+                       float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes, void* stream);
+
 /* ---- fused modules --------------------------------------------------------------------------------------------------- */
 
 /* make_q_attn (ext_qattn.cpp:24-104), q_attn_forward_1 (:115-159), q_attn_forward_2 (:161-191) */

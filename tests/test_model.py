@@ -121,6 +121,29 @@ def test_device_side_greedy_decode_paged(be):
     model.unload()
 
 
+def test_q4_cache_direct_attention_equals_unpack_route(be):
+    """Decode steps on a Q4 cache: attention straight from the codes (attn_q4.hip) gives the logits of the reference's
+    unpack-everything route (cache.py:472-514) up to the fp16 rounding that route applies to the unpacked values."""
+    cfg = tiny_cfg(hidden_size=256, num_attention_heads=4, num_key_value_heads=4, head_dim=128)   # 512 KV elements / token
+    ck = synth_checkpoint(cfg, be.device, seed=5)
+    ck2 = copy.deepcopy(ck)
+    ma = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    mb = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck2)
+    for attn, _ in mb.layers:
+        attn.q4_fused = False                                                   # reference route
+    ca, cb = ExLlamaV2Cache_Q4(ma, batch_size=1), ExLlamaV2Cache_Q4(mb, batch_size=1)
+    ids = torch.from_numpy(np.random.default_rng(5).integers(0, cfg.vocab_size, size=(1, 20)))
+    ma.forward(ids, ca); mb.forward(ids, cb)
+    for layer in range(cfg.num_hidden_layers):                                  # same codes in both caches so far?
+        assert torch.equal(ca.key_states[layer][:, :20], cb.key_states[layer][:, :20])
+    for tok in (5, 9, 3):
+        nxt = torch.tensor([[tok]])
+        a = be.n(ma.forward(nxt, ca)).astype(np.float64)
+        b = be.n(mb.forward(nxt, cb)).astype(np.float64)
+        assert np.abs(a - b).max() < 3e-2, float(np.abs(a - b).max())     # the unpack route rounds every K/V element to fp16
+    ma.unload(); mb.unload()
+
+
 def test_q4_cache_decode_close_to_fp16(be):
     """Q4 KV path end to end (cache.py:409-606): logits stay close to the FP16-cache logits (doc/qcache_eval.md)."""
     cfg = tiny_cfg()

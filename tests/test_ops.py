@@ -262,6 +262,73 @@ def test_attention_fused_contiguous_and_fallback(be):
                                         scratch, counters)                         # prefill-sized
 
 
+@pytest.mark.parametrize("hd,nh,kvh,s,paged", [(128, 4, 4, 1, False), (128, 8, 2, 1, True), (64, 8, 8, 2, False), (256, 2, 2, 1, True)])
+def test_attention_from_q4_cache(be, hd, nh, kvh, s, paged):
+    """attn_q4.hip: attention straight from Q4 codes + scales == attention over the unpacked cache (oracle q4_unpack of
+    the same codes), i.e. q_to_fp16_kv + attention of the reference (cache.py:472-514) without the unpack."""
+    rng = np.random.default_rng(40)
+    b, T = 2, 512
+    total = np.array([300, 511], dtype=np.int32)
+    kf = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    vf = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    kq, ks = OM.q4_pack(kf.reshape(-1))
+    vq, vs = OM.q4_pack(vf.reshape(-1))
+    k_un = OM.q4_unpack(kq, ks).reshape(b, T, kvh, hd)
+    v_un = OM.q4_unpack(vq, vs).reshape(b, T, kvh, hd)
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    want = np.stack([OM.attention(q[i:i + 1], k_un[i:i + 1, :total[i]], v_un[i:i + 1, :total[i]])[0] for i in range(b)])
+    kqt = be.t(kq.reshape(b, T, kvh, hd // 2)); kst = be.t(ks.reshape(b, T, kvh, hd // 32))
+    vqt = be.t(vq.reshape(b, T, kvh, hd // 2)); vst = be.t(vs.reshape(b, T, kvh, hd // 32))
+    scratch = torch.zeros((be.ext.paged_attn_scratch_bytes(b * s * nh, hd, 16) // 4 + 1,), dtype=torch.float32, device=be.device)
+    seq = be.t(total - s)
+    for nsplit in (1, 3):
+        out = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+        if paged:
+            ps = 256
+            table = np.array([[0, 1], [2, 3]], dtype=np.int32)                      # contiguous pages of each sequence
+            view = lambda x: x.view(-1, ps, kvh, x.shape[-1])
+            ok = be.ext.paged_attn_q4(be.t(q), view(kqt), view(kst), view(vqt), view(vst), out, seq, be.t(table),
+                                      len_const=0, len_offset=s, nsplit=nsplit, scratch=scratch)
+        else:
+            ok = be.ext.paged_attn_q4(be.t(q), kqt, kst, vqt, vst, out, seq, None, len_const=0, len_offset=s, nsplit=nsplit,
+                                      scratch=scratch)
+        assert ok
+        got = be.n(out)
+        assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want) + 2e-3), (nsplit, float(np.abs(got.astype(np.float32) - want.astype(np.float32)).max()))
+
+
+@pytest.mark.parametrize("hd,nh,kvh,s", [(128, 4, 4, 1), (128, 8, 2, 3), (64, 4, 4, 2), (256, 2, 1, 1)])
+def test_attention_from_q4_cache_with_fp16_new_tokens(be, hd, nh, kvh, s):
+    """The step's own K/V are attended in fp16 (the reference quantises them after attention, cache.py:517-556): keys
+    below total - s come from the Q4 codes, the last s from k_new / v_new."""
+    rng = np.random.default_rng(41)
+    b, T = 2, 256
+    total = np.array([77, 256], dtype=np.int32)
+    kf = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    vf = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    kq, ks = OM.q4_pack(kf.reshape(-1)); vq, vs = OM.q4_pack(vf.reshape(-1))
+    k_un = OM.q4_unpack(kq, ks).reshape(b, T, kvh, hd); v_un = OM.q4_unpack(vq, vs).reshape(b, T, kvh, hd)
+    kn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    vn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    want = []
+    for i in range(b):
+        kk = np.concatenate([k_un[i, :total[i] - s], kn[i]])[None]
+        vv = np.concatenate([v_un[i, :total[i] - s], vn[i]])[None]
+        want.append(OM.attention(q[i:i + 1], kk, vv)[0])
+    want = np.stack(want)
+    scratch = torch.zeros((be.ext.paged_attn_scratch_bytes(b * s * nh, hd, 16) // 4 + 1,), dtype=torch.float32, device=be.device)
+    for nsplit in (1, 2):
+        out = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+        assert be.ext.paged_attn_q4(be.t(q), be.t(kq.reshape(b, T, kvh, hd // 2)), be.t(ks.reshape(b, T, kvh, hd // 32)),
+                                    be.t(vq.reshape(b, T, kvh, hd // 2)), be.t(vs.reshape(b, T, kvh, hd // 32)), out,
+                                    be.t(total - s), None, len_const=0, len_offset=s, nsplit=nsplit, scratch=scratch,
+                                    k_new=be.t(kn), v_new=be.t(vn))
+        got = be.n(out)
+        err = np.abs(got.astype(np.float32) - want.astype(np.float32))
+        assert np.all(err <= _attn_tol(want) + 2e-3), (nsplit, float(err.max()))
+
+
 @pytest.mark.gpu
 def test_attention_fused_handoff_stress():
     """The split hand-off (ticket + agent-scope fences) under real concurrency: many back-to-back launches on the same
