@@ -17,6 +17,7 @@
 #include <string.h>
 
 #define AQ_WAVES 4
+#define AQ_UNROLL 4
 #define AQ_NEG_BIG (-1.0e30f)
 
 struct AttnQ4Args
@@ -117,24 +118,39 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
     const size_t tok_scales = (size_t)a.KVH * (HDIM / 32);
     const int past = a.k_new ? total - a.s : total;                      // keys [past, total) come from k_new / v_new
     const int k_old_end = min(k_end, past);
-    for (int base = k_start + wv * KPW; base < k_old_end; base += AQ_WAVES * KPW)
+    constexpr int STEP = AQ_WAVES * KPW;
+    for (int base0 = k_start + wv * KPW; base0 < k_old_end; base0 += AQ_UNROLL * STEP)
     {
-        const int kpos = base + group;
+        // codes and scales of AQ_UNROLL steps are requested together: one memory round trip per batch
+        u32x2 kcs[AQ_UNROLL], vcs[AQ_UNROLL];
+        f16 kss[AQ_UNROLL], vss[AQ_UNROLL];
+        #pragma unroll
+        for (int un = 0; un < AQ_UNROLL; un++)
+        {
+            const int kpos = base0 + un * STEP + group;
+            const int kp = kpos < k_old_end ? kpos : k_start;
+            size_t tok;
+            if (a.block_table)
+                tok = (size_t)a.block_table[(size_t)b * a.pages_per_seq + (kp >> a.page_shift)] * a.page_size
+                      + (kp & (a.page_size - 1));
+            else
+                tok = (size_t)b * a.page_size + kp;
+            const size_t co = tok * tok_codes + (size_t)kh * (HDIM / 2) + u * 8;
+            const size_t so = tok * tok_scales + (size_t)kh * (HDIM / 32) + (u >> 1);
+            kcs[un] = ld_nt((const u32x2*)(a.k_codes + co));
+            vcs[un] = ld_nt((const u32x2*)(a.v_codes + co));
+            kss[un] = a.k_scales[so];
+            vss[un] = a.v_scales[so];
+        }
+        #pragma unroll
+        for (int un = 0; un < AQ_UNROLL; un++)
+        {
+        if (base0 + un * STEP >= k_old_end) break;
+        const int kpos = base0 + un * STEP + group;
         const bool in_range = kpos < k_old_end;
-        const int kp = in_range ? kpos : k_start;
-        size_t tok;
-        if (a.block_table)
-            tok = (size_t)a.block_table[(size_t)b * a.pages_per_seq + (kp >> a.page_shift)] * a.page_size
-                  + (kp & (a.page_size - 1));
-        else
-            tok = (size_t)b * a.page_size + kp;
-        const size_t co = tok * tok_codes + (size_t)kh * (HDIM / 2) + u * 8;
-        const size_t so = tok * tok_scales + (size_t)kh * (HDIM / 32) + (u >> 1);
-        const u32x2 kc = ld_nt((const u32x2*)(a.k_codes + co));
-        const u32x2 vc = ld_nt((const u32x2*)(a.v_codes + co));
-        const float ks = (float)a.k_scales[so] * (1.0f / 32.0f);
-        const float vs = (float)a.v_scales[so];
-
+        const u32x2 kc = kcs[un], vc = vcs[un];
+        const float ks = (float)kss[un] * (1.0f / 32.0f);
+        const float vs = (float)vss[un];
         f16x2 kd[8], vd[8];
         {
             const u32 l0 = kc.x & 0x0F0F0F0Fu, h0 = (kc.x >> 4) & 0x0F0F0F0Fu;
@@ -173,6 +189,7 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
                     o[r][2 * i + 1] = o[r][2 * i + 1] * alpha + pv * (float)vd[i].y;
                 }
             }
+        }
         }
     }
 

@@ -152,7 +152,8 @@ def run_pipeline(stage: PipelineStage, first_tokens, n_ticks: int):
 def run_layer_split_bench(cfg, args, rank: int, world: int, device):
     """bench.py backend for --gpus N > 1: N sequences in flight over an N-stage layer split."""
     n_seqs = world
-    max_seq = max(2048, ((args.ctx + (args.steps + args.warmup) // n_seqs + 2 + 255) // 256) * 256)
+    ramp = 512                      # untimed ticks before the warm-up (clock ramp of a freshly started GPU), same on every rank
+    max_seq = max(2048, ((args.ctx + (args.steps + args.warmup + ramp) // n_seqs + 2 + 255) // 256) * 256)
     t_load = time.perf_counter()
     stage = PipelineStage(cfg, rank, world, device, n_seqs, max_seq, recipe=args.recipe, use_graph=not args.no_graph)
     stage.capture()
@@ -161,12 +162,12 @@ def run_layer_split_bench(cfg, args, rank: int, world: int, device):
     t_load = time.perf_counter() - t_load
     first = list(range(1, n_seqs + 1))
     # fill the pipe + warm-up (a "step" = one token sampled somewhere in the pipe = one tick once the pipe is full)
-    run_pipeline(stage, first, world + args.warmup)
+    run_pipeline(stage, first, world + ramp + args.warmup)
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     n = stage.n_seqs
-    base = world + args.warmup
+    base = world + ramp + args.warmup
     for t in range(base, base + args.steps):
         stage.step((t - rank) % n)
         stage.exchange()
