@@ -18,6 +18,7 @@
 
 #define AQ_WAVES 4
 #define AQ_UNROLL 4
+#define AQ_MAX_PAGES 256          // block-table entries of one split kept in LDS
 #define AQ_NEG_BIG (-1.0e30f)
 
 struct AttnQ4Args
@@ -39,6 +40,12 @@ DEV f16x2 code_pair(u32 lo, u32 hi, int i)
 {
     const u32 l = (lo >> (8 * i)) & 0xFFu, h = (hi >> (8 * i)) & 0xFFu;
     return as_h2(l | (h << 16) | 0x64006400u) - (f16x2){(f16)1032.0f, (f16)1032.0f};
+}
+
+DEV int q4_eff_splits(int total, int nsplit)
+{
+    const int e = (total + 255) >> 8;                       // ~256 keys per split at least
+    return e < 1 ? 1 : (e > nsplit ? nsplit : e);
 }
 
 template <int HDIM, int RB>
@@ -66,20 +73,40 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
     const int u = lane % LPK;                   // elements [16 u, 16 u + 16) of the head
 
     const int total = (a.cache_seqlens ? a.cache_seqlens[b] : a.len_const) + a.len_offset;
-    int kps = (total + a.nsplit - 1) / a.nsplit;
+    // the grid is fixed (HIP graph) but the sequence length is not: use as many splits as the length deserves
+    const int eff = q4_eff_splits(total, a.nsplit);
+    if (split >= eff) return;
+    int kps = (total + eff - 1) / eff;
     kps = (kps + 15) & ~15;
     const int k_start = split * kps;
     const int k_end = min(total, k_start + kps);
 
+    // ---- block-table entries of this split and the raw query rows into LDS ------------------------------------------------
+    float* qh_lds = (float*)smem;                                       // [RB][HDIM] rotated rows
+    f16* qraw_lds = (f16*)(qh_lds + RB * HDIM);                         // [RB][HDIM] raw rows
+    int* pg_lds = (int*)(qraw_lds + RB * HDIM);                         // [AQ_MAX_PAGES] page of key (k_start >> shift) + i
+    const int pg0 = a.block_table ? (k_start >> a.page_shift) : 0;
+    if (a.block_table)
+    {
+        const int npg = ((k_end > k_start ? k_end - 1 : k_start) >> a.page_shift) - pg0 + 1;
+        for (int i = tid(); i < npg && i < AQ_MAX_PAGES; i += nthreads())
+            pg_lds[i] = a.block_table[(size_t)b * a.pages_per_seq + pg0 + i];
+    }
+    for (int idx = tid(); idx < nrows * (HDIM / 8); idx += nthreads())
+    {
+        const int r = idx / (HDIM / 8), o8 = idx - r * (HDIM / 8);
+        const int rr = r0 + r, j = rr / G, g = rr - j * G;
+        ((f16x8*)qraw_lds)[idx] = *(const f16x8*)(a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM + o8 * 8);
+    }
+    block_sync();
     // ---- rotate the query rows: qh[64 g + 2 t + comp] = sum_t' H[t, t'] q[64 g + 2 t' + comp], H[t,t'] = (-1)^popc(t & t')
-    float* qh_lds = (float*)smem;                                       // [RB][HDIM]
     for (int idx = tid(); idx < nrows * HDIM; idx += nthreads())
     {
         const int r = idx / HDIM, e = idx - r * HDIM;
-        const int rr = r0 + r, j = rr / G, g = rr - j * G;
-        const f16* qr = a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM;
+        const f16* qr = qraw_lds + r * HDIM;
         const int span = e >> 6, t = (e & 63) >> 1, comp = e & 1;
         float acc = 0.0f;
+        #pragma unroll 8
         for (int t2 = 0; t2 < 32; t2++)
         {
             const float v = (float)qr[span * 64 + 2 * t2 + comp];
@@ -97,8 +124,8 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
         #pragma unroll
         for (int i = 0; i < 8; i++)
             qf[r][i] = (f16x2){(f16)qh_lds[rs * HDIM + 16 * u + 2 * i], (f16)qh_lds[rs * HDIM + 16 * u + 2 * i + 1]};
-        const int rr = r0 + rs, j = rr / G, g = rr - j * G;
-        const f16* qr = a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM + 16 * u;
+        const int rr = r0 + rs, j = rr / G;
+        const f16* qr = qraw_lds + rs * HDIM + 16 * u;
         #pragma unroll
         for (int i = 0; i < 8; i++) qp[r][i] = (f16x2){qr[2 * i], qr[2 * i + 1]};
         limit[r] = a.causal ? (total - a.s + j + 1) : total;
@@ -118,10 +145,23 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
     const size_t tok_scales = (size_t)a.KVH * (HDIM / 32);
     const int past = a.k_new ? total - a.s : total;                      // keys [past, total) come from k_new / v_new
     const int k_old_end = min(k_end, past);
+    // Codes stay biased: a pair is the half2 (1024 + c_even, 1024 + c_odd) straight from v_perm + or; the "- 8" is applied
+    // once per batch through sum(qh) on the K side and through sum(p s) on the V side (fp32, exact enough: the biased
+    // sums are ~130x the centred ones, 2^-24 relative each).  The running maximum is updated once per batch of AQ_UNROLL
+    // steps, so the 16 accumulators are rescaled once per batch, not per key.
     constexpr int STEP = AQ_WAVES * KPW;
+    float qsum[RB], osub[RB];
+    #pragma unroll
+    for (int r = 0; r < RB; r++)
+    {
+        float t = 0.0f;
+        #pragma unroll
+        for (int i = 0; i < 8; i++) t += (float)qf[r][i].x + (float)qf[r][i].y;
+        qsum[r] = t * 1032.0f;
+        osub[r] = 0.0f;
+    }
     for (int base0 = k_start + wv * KPW; base0 < k_old_end; base0 += AQ_UNROLL * STEP)
     {
-        // codes and scales of AQ_UNROLL steps are requested together: one memory round trip per batch
         u32x2 kcs[AQ_UNROLL], vcs[AQ_UNROLL];
         f16 kss[AQ_UNROLL], vss[AQ_UNROLL];
         #pragma unroll
@@ -131,8 +171,11 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
             const int kp = kpos < k_old_end ? kpos : k_start;
             size_t tok;
             if (a.block_table)
-                tok = (size_t)a.block_table[(size_t)b * a.pages_per_seq + (kp >> a.page_shift)] * a.page_size
-                      + (kp & (a.page_size - 1));
+            {
+                const int pi = (kp >> a.page_shift) - pg0;
+                const int pg = pi < AQ_MAX_PAGES ? pg_lds[pi] : a.block_table[(size_t)b * a.pages_per_seq + (kp >> a.page_shift)];
+                tok = (size_t)pg * a.page_size + (kp & (a.page_size - 1));
+            }
             else
                 tok = (size_t)b * a.page_size + kp;
             const size_t co = tok * tok_codes + (size_t)kh * (HDIM / 2) + u * 8;
@@ -142,55 +185,86 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
             kss[un] = a.k_scales[so];
             vss[un] = a.v_scales[so];
         }
+        // scores of the batch
+        float sc[RB][AQ_UNROLL];
         #pragma unroll
         for (int un = 0; un < AQ_UNROLL; un++)
         {
-        if (base0 + un * STEP >= k_old_end) break;
-        const int kpos = base0 + un * STEP + group;
-        const bool in_range = kpos < k_old_end;
-        const u32x2 kc = kcs[un], vc = vcs[un];
-        const float ks = (float)kss[un] * (1.0f / 32.0f);
-        const float vs = (float)vss[un];
-        f16x2 kd[8], vd[8];
-        {
-            const u32 l0 = kc.x & 0x0F0F0F0Fu, h0 = (kc.x >> 4) & 0x0F0F0F0Fu;
-            const u32 l1 = kc.y & 0x0F0F0F0Fu, h1 = (kc.y >> 4) & 0x0F0F0F0Fu;
+            const u32 l0 = kcs[un].x & 0x0F0F0F0Fu, h0 = (kcs[un].x >> 4) & 0x0F0F0F0Fu;
+            const u32 l1 = kcs[un].y & 0x0F0F0F0Fu, h1 = (kcs[un].y >> 4) & 0x0F0F0F0Fu;
+            f16x2 kd[8];
+            kd[0] = as_h2(byte_perm(h0, l0, 0x0C040C00u) | 0x64006400u); kd[1] = as_h2(byte_perm(h0, l0, 0x0C050C01u) | 0x64006400u);
+            kd[2] = as_h2(byte_perm(h0, l0, 0x0C060C02u) | 0x64006400u); kd[3] = as_h2(byte_perm(h0, l0, 0x0C070C03u) | 0x64006400u);
+            kd[4] = as_h2(byte_perm(h1, l1, 0x0C040C00u) | 0x64006400u); kd[5] = as_h2(byte_perm(h1, l1, 0x0C050C01u) | 0x64006400u);
+            kd[6] = as_h2(byte_perm(h1, l1, 0x0C060C02u) | 0x64006400u); kd[7] = as_h2(byte_perm(h1, l1, 0x0C070C03u) | 0x64006400u);
+            const float ks = (float)kss[un] * (1.0f / 32.0f);
+            const int kpos = base0 + un * STEP + group;
             #pragma unroll
-            for (int i = 0; i < 4; i++) { kd[i] = code_pair(l0, h0, i); kd[4 + i] = code_pair(l1, h1, i); }
-            const u32 m0 = vc.x & 0x0F0F0F0Fu, n0 = (vc.x >> 4) & 0x0F0F0F0Fu;
-            const u32 m1 = vc.y & 0x0F0F0F0Fu, n1 = (vc.y >> 4) & 0x0F0F0F0Fu;
-            #pragma unroll
-            for (int i = 0; i < 4; i++) { vd[i] = code_pair(m0, n0, i); vd[4 + i] = code_pair(m1, n1, i); }
-        }
-        #pragma unroll
-        for (int r = 0; r < RB; r++)
-        {
-            if (r < nrows)
+            for (int r = 0; r < RB; r++)
             {
                 float d = 0.0f;
                 #pragma unroll
                 for (int i = 0; i < 8; i++) d = dot2_f32_f16(qf[r][i], kd[i], d);
-                d *= ks;                                                // this lane's 16 elements: (1/32) s (H q).(c - 8)
+                d = (d - qsum[r]) * ks;
                 if constexpr (LPK == 4) d = quad_allreduce_add(d);
                 else if constexpr (LPK == 8) d = row8_allreduce_add(d);
                 else d = row16_allreduce_add(d);
-                const float sc = d * a.scale;
-                const bool valid = in_range && kpos < limit[r];
-                const float m_new = valid ? fmaxf(m[r], sc) : m[r];
-                const float alpha = fast_exp(m[r] - m_new);
-                const float p = (valid ? fast_exp(sc - m_new) : 0.0f);
-                m[r] = m_new;
-                l[r] = l[r] * alpha + p;
-                const float pv = p * vs;
-                #pragma unroll
-                for (int i = 0; i < 8; i++)
-                {
-                    o[r][2 * i]     = o[r][2 * i]     * alpha + pv * (float)vd[i].x;
-                    o[r][2 * i + 1] = o[r][2 * i + 1] * alpha + pv * (float)vd[i].y;
-                }
+                const bool valid = r < nrows && kpos < k_old_end && kpos < limit[r];
+                sc[r][un] = valid ? d * a.scale : AQ_NEG_BIG;
             }
         }
+        // one maximum / rescale per batch
+        float pw[RB][AQ_UNROLL];
+        #pragma unroll
+        for (int r = 0; r < RB; r++)
+        {
+            float m_new = m[r];
+            #pragma unroll
+            for (int un = 0; un < AQ_UNROLL; un++) m_new = fmaxf(m_new, sc[r][un]);
+            const float alpha = fast_exp(m[r] - m_new);
+            float ps = 0.0f;
+            #pragma unroll
+            for (int un = 0; un < AQ_UNROLL; un++)
+            {
+                const float p = sc[r][un] > 0.5f * AQ_NEG_BIG ? fast_exp(sc[r][un] - m_new) : 0.0f;
+                ps += p;
+                pw[r][un] = p * (float)vss[un];
+            }
+            m[r] = m_new;
+            l[r] = l[r] * alpha + ps;
+            osub[r] *= alpha;
+            #pragma unroll
+            for (int e = 0; e < 16; e++) o[r][e] *= alpha;
         }
+        // weighted biased codes
+        #pragma unroll
+        for (int un = 0; un < AQ_UNROLL; un++)
+        {
+            const u32 l0 = vcs[un].x & 0x0F0F0F0Fu, h0 = (vcs[un].x >> 4) & 0x0F0F0F0Fu;
+            const u32 l1 = vcs[un].y & 0x0F0F0F0Fu, h1 = (vcs[un].y >> 4) & 0x0F0F0F0Fu;
+            f16x2 vd[8];
+            vd[0] = as_h2(byte_perm(h0, l0, 0x0C040C00u) | 0x64006400u); vd[1] = as_h2(byte_perm(h0, l0, 0x0C050C01u) | 0x64006400u);
+            vd[2] = as_h2(byte_perm(h0, l0, 0x0C060C02u) | 0x64006400u); vd[3] = as_h2(byte_perm(h0, l0, 0x0C070C03u) | 0x64006400u);
+            vd[4] = as_h2(byte_perm(h1, l1, 0x0C040C00u) | 0x64006400u); vd[5] = as_h2(byte_perm(h1, l1, 0x0C050C01u) | 0x64006400u);
+            vd[6] = as_h2(byte_perm(h1, l1, 0x0C060C02u) | 0x64006400u); vd[7] = as_h2(byte_perm(h1, l1, 0x0C070C03u) | 0x64006400u);
+            float vfl[16];
+            #pragma unroll
+            for (int i = 0; i < 8; i++) { vfl[2 * i] = (float)vd[i].x; vfl[2 * i + 1] = (float)vd[i].y; }
+            #pragma unroll
+            for (int r = 0; r < RB; r++)
+            {
+                const float pv = pw[r][un];
+                osub[r] += pv;
+                #pragma unroll
+                for (int e = 0; e < 16; e++) o[r][e] = fmaf(pv, vfl[e], o[r][e]);
+            }
+        }
+    }
+    #pragma unroll
+    for (int r = 0; r < RB; r++)
+    {
+        #pragma unroll
+        for (int e = 0; e < 16; e++) o[r][e] -= 1032.0f * osub[r];
     }
 
     // ---- the step's own keys / values, still fp16 (the reference attends over them before they are quantised) -------------
@@ -261,6 +335,7 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
     }
 
     // ---- merge the streams of this workgroup (rotated domain), rotate back, store / emit partials --------------------------
+    block_sync();                                                       // every wave is done with the page ids in LDS
     float* st = (float*)smem;                                           // [NSTREAM][RB][ROWF]
     const int stream = wv * KPW + group;
     #pragma unroll
@@ -307,7 +382,7 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
         const float M = mg[r * ROWF + HDIM], L = mg[r * ROWF + HDIM + 1];
         const int rr = r0 + r, j = rr / G, g = rr - j * G;
         const size_t qrow = ((size_t)b * a.s + j) * a.H + kh * G + g;
-        if (a.nsplit == 1)
+        if (eff == 1)
         {
             a.out[qrow * HDIM + e] = (f16)(L > 0.0f ? acc / L : 0.0f);
         }
@@ -326,12 +401,16 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
 KERNEL void __launch_bounds__(256) attn_q4_combine_kernel(const AttnQ4Args a, int hd)
 {
     const size_t qrow = bid_x();
+    const int b = (int)(qrow / ((size_t)a.s * a.H));
+    const int total = (a.cache_seqlens ? a.cache_seqlens[b] : a.len_const) + a.len_offset;
+    const int eff = q4_eff_splits(total, a.nsplit);
+    if (eff == 1) return;                                   // the single split stored the result itself
     for (int d = tid(); d < hd; d += nthreads())
     {
         float M = AQ_NEG_BIG;
-        for (int s2 = 0; s2 < a.nsplit; s2++) M = fmaxf(M, a.part_ml[(qrow * a.nsplit + s2) * 2]);
+        for (int s2 = 0; s2 < eff; s2++) M = fmaxf(M, a.part_ml[(qrow * a.nsplit + s2) * 2]);
         float L = 0.0f, O = 0.0f;
-        for (int s2 = 0; s2 < a.nsplit; s2++)
+        for (int s2 = 0; s2 < eff; s2++)
         {
             const float w = fast_exp(a.part_ml[(qrow * a.nsplit + s2) * 2] - M);
             L += a.part_ml[(qrow * a.nsplit + s2) * 2 + 1] * w;
@@ -347,7 +426,9 @@ template <int HDIM>
 static void launch_q4(const AttnQ4Args& a, int rb, dim3 grid, void* stream)
 {
     const int lpk = HDIM / 16, kpw = 64 / lpk;
-    const size_t lds = ((size_t)AQ_WAVES * kpw * rb + rb) * (HDIM + 2) * 4;
+    size_t lds = ((size_t)AQ_WAVES * kpw * rb + rb) * (HDIM + 2) * 4;
+    const size_t pro = (size_t)rb * HDIM * 4 + (size_t)rb * HDIM * 2 + AQ_MAX_PAGES * 4;     // prologue: rotated + raw rows + pages
+    if (lds < pro) lds = pro;
     static bool attr_done = false;
     if (!attr_done)
     {
@@ -399,11 +480,13 @@ int exl2_paged_attn_q4(const void* q, const void* k_codes, const void* k_scales,
     if (nsplit <= 0)
     {
         const long long base = (long long)num_kv_heads * batch * rblocks;
-        nsplit = (int)((512 + base - 1) / base);
-        if (nsplit > 16) nsplit = 16;
+        // 144 B per key: the stream is latency-bound, not bandwidth-bound -- many short splits (4 waves each)
+        nsplit = (int)((1024 + base - 1) / base);
+        if (nsplit > 32) nsplit = 32;
         if (nsplit < 1) nsplit = 1;
     }
-    const long long need = nsplit <= 1 ? 0 : (long long)batch * q_len * num_heads * nsplit * (head_dim + 2) * 4;
+    long long need = nsplit <= 1 ? 0 : (long long)batch * q_len * num_heads * nsplit * (head_dim + 2) * 4;
+    while (nsplit > 1 && (need > scratch_bytes || !scratch)) { nsplit /= 2; need = nsplit <= 1 ? 0 : (long long)batch * q_len * num_heads * nsplit * (head_dim + 2) * 4; }
     if (need > scratch_bytes || (need > 0 && !scratch)) nsplit = 1;
     a.nsplit = nsplit;
     if (nsplit > 1)

@@ -140,9 +140,13 @@ KERNEL void __launch_bounds__(256) kv_codec_paged_kernel(const QKVArgs a)
 {
     const int kv = bid_z() & 1;
     const int y = bid_z() >> 1;
-    const int x = bid_x();
-    const int page = a.block_table[a.pages_per_seq * y + x];
     const int seqlen = a.cache_seqlens[y];
+    // pack: only the pages the appended tokens land in have work -- the grid covers those, counted from the page of
+    // `seqlen` (the reference launches one column of blocks per page of the sequence and lets them exit, cache.cu:143-195;
+    // at 16k tokens that is > 30 000 idle workgroups per layer per step)
+    const int x = DIR == 0 ? seqlen / a.page_size + bid_x() : bid_x();
+    if (x >= a.pages_per_seq) return;
+    const int page = a.block_table[a.pages_per_seq * y + x];
     const int vx_a = a.page_size * x;
     int px_a, px_b;
     if (DIR == 0) { px_a = seqlen - vx_a; px_b = px_a + a.q_len; }        // tokens being appended
@@ -184,8 +188,17 @@ static int kv_codec(const void* k_in, void* k_out, void* k_scales, const void* v
         a.cache_seqlens = cache_seqlens; a.block_table = block_table;
         a.pages_per_seq = pages_per_seq; a.page_size = page_size; a.q_len = width;
         long long per_page_blocks = ((long long)page_size * dim + QBLOCK - 1) / QBLOCK;
+        int pages_x = pages_per_seq;
+        if (DIR == 0)
+        {
+            // appended tokens: at most (width - 1) / page_size + 2 pages, width * dim / 512 (+ alignment) blocks each
+            const int touched = (width > 0 ? (width - 1) / page_size : 0) + 2;
+            if (touched < pages_x) pages_x = touched;
+            const long long need = ((long long)width * dim + QBLOCK - 1) / QBLOCK + 2;
+            if (need < per_page_blocks) per_page_blocks = need;
+        }
         if (per_page_blocks > 256) per_page_blocks = 256;
-        dim3 grid((unsigned)pages_per_seq, (unsigned)per_page_blocks, (unsigned)(2 * batch_size));
+        dim3 grid((unsigned)pages_x, (unsigned)per_page_blocks, (unsigned)(2 * batch_size));
         if (DIR == 0) LAUNCH(kv_codec_paged_kernel<0>, grid, dim3(256), 0, stream, a);
         else          LAUNCH(kv_codec_paged_kernel<1>, grid, dim3(256), 0, stream, a);
     }

@@ -148,6 +148,9 @@ template <int N> DEV void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" :
 // prefetched weight load of the wave before letting anybody pass
 DEV void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {hi:lo} (selector 0-3 -> lo, 4-7 -> hi, 0x0C -> 0x00)
+DEV u32 byte_perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
 // (x & mask) | magic in ONE VALU op.  gfx950 VOP3 takes no 32-bit literal, so the compiler splits it into v_and + v_or
 // with literals; spelling it out keeps the mask in a scalar register and the magic in a vector register.
 DEV u32 and_or(u32 x, u32 mask, u32 magic)

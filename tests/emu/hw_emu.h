@@ -226,6 +226,18 @@ DEV void dma_to_lds16(const void* g_lane_ptr, void* lds_wave_base) { memcpy((cha
 DEV void dma_to_lds4(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 4, g_lane_ptr, 4); }
 template <int N> DEV void wait_vmcnt_le() { }
 DEV void block_sync_lds() { block_sync(); }
+DEV u32 byte_perm(u32 hi, u32 lo, u32 sel)
+{
+    const unsigned long long pool = ((unsigned long long)hi << 32) | lo;
+    u32 r = 0;
+    for (int i = 0; i < 4; i++)
+    {
+        const u32 s = (sel >> (8 * i)) & 0xFF;
+        const u32 b = s < 8 ? (u32)((pool >> (8 * s)) & 0xFF) : (s == 0x0C ? 0u : 0xFFu);
+        r |= b << (8 * i);
+    }
+    return r;
+}
 DEV u32 and_or(u32 x, u32 mask, u32 magic) { return (x & mask) | magic; }
 template <typename T> DEV T ld_nt(const T* p) { return *p; }
 template <typename T> DEV void st_nt(T* p, T v) { *p = v; }
