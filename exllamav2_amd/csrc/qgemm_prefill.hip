@@ -21,15 +21,22 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define PF_BM 256
-#define PF_BN 256
-#define PF_WAVES_M 4
+#ifndef PF_BN
+#define PF_BN 128
+#endif
+#define PF_QPT (4 * PF_BN / (PF_WAVES_M * PF_WAVES_N * 64))   // scale chunks staged per thread
+#ifndef PF_WAVES_M
+#define PF_WAVES_M 2
+#endif
+#define PF_BM (PF_WAVES_M * 64)
 #define PF_WAVES_N 2
 #define PF_CT (PF_BN / PF_WAVES_N / 16)     // 16-column tiles per wave (8)
 #define PF_THREADS (PF_WAVES_M * PF_WAVES_N * 64)
-#define PF_A_BYTES (PF_BM * 256)                 // 256 rows x 128 halves
+#define PF_A_BYTES (PF_BM * 256)                 // PF_BM rows x 128 halves
 #define PF_SC_BYTES (4 * PF_BN * 2)              // [chunk][column] scales of the current step
-#define PF_LDS_BYTES (PF_A_BYTES + 2 * PF_SC_BYTES)
+#define PF_BUF_BYTES (PF_A_BYTES + 2 * PF_SC_BYTES)   // one stage: A tile + scales + zero points
+#define PF_TAB_OFF (2 * PF_BUF_BYTES)                 // chunk -> group map and (EXL2) per-group scale maxima, loaded once
+#define PF_LDS_BYTES(K, G) (PF_TAB_OFF + ((((K) >> 5) * 2 + 15) & ~15) + (((G) * 2 + 15) & ~15))
 
 struct PrefillArgs
 {
@@ -41,18 +48,20 @@ struct PrefillArgs
 };
 
 // scale (and GPTQ zero point) of column n for the (up to 4) chunks of one step, as the fp16 values reconstruct() uses
+// cg_lds / smax_lds: LDS copies of chunk_group and (EXL2) scale_src made at kernel start -- one global round trip per
+// step (the scale code word) instead of a chain of three
 template <bool GPTQ>
-DEV void step_scales(const QMatDev& m, int chunk0, int nvalid, int n, int q0, f16* sc, f16* zp)
+DEV void step_scales(const QMatDev& m, const u16* cg_lds, const f16* smax_lds, int chunk0, int nvalid, int n, int q0, f16* sc, f16* zp)
 {
     #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < PF_QPT; i++)
     {
         const int q = q0 + i;
-        const int g = m.chunk_group[q < nvalid ? chunk0 + q : chunk0];
+        const int g = cg_lds[q < nvalid ? chunk0 + q : chunk0];
         const u32 word = m.q_scale[(size_t)g * (m.N >> 3) + (n >> 3)];
         const int nib = (word >> (4 * (n & 7))) & 15;
         if constexpr (GPTQ) { sc[i] = m.scale_src[(size_t)g * m.N + n]; zp[i] = (f16)(float)(nib + 1); }
-        else                { sc[i] = (f16)(float)((nib + 1) * (nib + 1)) * m.scale_src[g]; zp[i] = (f16)0.0f; }
+        else                { sc[i] = (f16)(float)((nib + 1) * (nib + 1)) * smax_lds[g]; zp[i] = (f16)0.0f; }
     }
 }
 
@@ -84,7 +93,8 @@ DEV void decode_tile(const LaneWords<BITS>& lw, const f16* sc_lds, const f16* zp
 
 // A wave's PF_CT column tiles are processed in batches of CB tiles through two alternating register sets: the packed
 // words of batch i + 1 are in flight while batch i decodes and multiplies (CB = 4 up to 4 bits, 2 above: 16 VGPRs a set).
-template <int BITS> struct Batch { static constexpr int CB = BITS <= 4 ? 4 : 2; static constexpr int NB = PF_CT / CB; };
+template <int BITS> struct Batch { static constexpr int CB = 2; static constexpr int NB = PF_CT / CB; };
+static_assert(PF_CT == 4 || PF_CT == 8, "wave tile: 4 or 8 column tiles");
 
 template <int BITS, int CB>
 DEV void load_tiles(LaneWords<BITS> (&w)[CB], const u32* base, u32 tile_stride, int tile0, int n_tiles, int s, int lane)
@@ -134,6 +144,7 @@ struct StepCtx
     const QMatDev* m; const f16* a; int M, K, m0, n0, n_tiles;
     u8* a_lds; f16* sc_lds; f16* zp_lds;
     int t, lane, wv, wm, wn, sc_col, sc_q0, sc_n;
+    const u16* cg_lds; const f16* smax_lds;
 };
 
 // one K step (one super-chunk of `nvalid` 32-row chunks starting at packed row k0) for the whole block tile
@@ -148,8 +159,8 @@ DEV void k_step(const StepCtx& x, const u32* base, u32 tile_stride, int s, int k
     // stage A [256 rows x 32 nvalid K] (swizzled) and this step's scales
     const int chunk0 = k0 >> 5;
     const int units_row = nvalid * 4;                               // 16-byte units of A per row in this step
-    f16 sc2[2], zp2[2];
-    if (x.t < 2 * PF_BN) step_scales<GPTQ>(*x.m, chunk0, nvalid, x.sc_n, x.sc_q0, sc2, zp2);
+    f16 sc2[PF_QPT], zp2[PF_QPT];
+    step_scales<GPTQ>(*x.m, x.cg_lds, x.smax_lds, chunk0, nvalid, x.sc_n, x.sc_q0, sc2, zp2);
     for (int base_u = x.wv * 64; base_u < PF_BM * 16; base_u += (PF_THREADS / 64) * 64)
     {
         const int slot = base_u + x.lane;                           // LDS position: row = slot >> 4, p = slot & 15
@@ -159,10 +170,11 @@ DEV void k_step(const StepCtx& x, const u32* base, u32 tile_stride, int s, int k
         if (u < units_row)
             dma_to_lds16(x.a + (size_t)grow * x.K + k0 + u * 8, x.a_lds + (size_t)base_u * 16);
     }
-    if (x.t < 2 * PF_BN)
+    #pragma unroll
+    for (int i = 0; i < PF_QPT; i++)
     {
-        x.sc_lds[(x.sc_q0 + 0) * PF_BN + x.sc_col] = sc2[0]; x.sc_lds[(x.sc_q0 + 1) * PF_BN + x.sc_col] = sc2[1];
-        if constexpr (GPTQ) { x.zp_lds[(x.sc_q0 + 0) * PF_BN + x.sc_col] = zp2[0]; x.zp_lds[(x.sc_q0 + 1) * PF_BN + x.sc_col] = zp2[1]; }
+        x.sc_lds[(x.sc_q0 + i) * PF_BN + x.sc_col] = sc2[i];
+        if constexpr (GPTQ) x.zp_lds[(x.sc_q0 + i) * PF_BN + x.sc_col] = zp2[i];
     }
     wait_vmcnt_le<0>();
     block_sync();
@@ -180,8 +192,106 @@ DEV void k_step(const StepCtx& x, const u32* base, u32 tile_stride, int s, int k
     block_sync();
 }
 
+// CB column tiles decoded to B fragments in registers, then every A fragment of the wave's 64 rows is read ONCE from LDS
+// and used for all CB tiles (multiply_tiles re-reads it per tile: 4x the ds_read_b128 traffic, LDS-bound).
+template <int BITS, bool GPTQ, int CB, int CT0>
+DEV void multiply_batch(const LaneWords<BITS> (&w)[CB], const u8* a_lds, const f16* sc_lds, const f16* zp_lds,
+                        int wm, int wn, int lane, f32x4 (&acc)[4][PF_CT])
+{
+    const int i16 = lane & 15, j4 = lane >> 4;
+    f16x8 b[CB][4];
+    #pragma unroll
+    for (int c = 0; c < CB; c++)
+        decode_tile<BITS, GPTQ>(w[c], sc_lds, zp_lds, (wn * PF_CT + CT0 + c) * 16 + i16, b[c]);
+    #pragma unroll
+    for (int rt = 0; rt < 4; rt++)
+    {
+        const int row = wm * 64 + rt * 16 + i16;
+        f16x8 a[4];
+        #pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int p = (4 * q + j4) ^ (row & 15);
+            a[q] = *(const f16x8*)(a_lds + (size_t)row * 256 + p * 16);
+        }
+        #pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            #pragma unroll
+            for (int c = 0; c < CB; c++) acc[rt][CT0 + c] = mfma_16x16x32_f16(a[q], b[c][q], acc[rt][CT0 + c]);
+        }
+        sched_fence();          // one row tile's A fragments live at a time (register budget: 128 accumulators)
+    }
+}
+
+// All F full super-chunks of one run, software-pipelined: while step s multiplies, the A tile and the scales of step
+// s + 1 are in flight into the other LDS stage and the first batch of its packed weights into registers; one barrier
+// per step.
+template <int BITS, bool GPTQ>
+DEV void run_pipelined(const StepCtx& x, u8* smem, const u32* base, u32 tile_stride, int F, int k_base,
+                       f32x4 (&acc)[4][PF_CT])
+{
+    constexpr int CB = Batch<BITS>::CB, NB = Batch<BITS>::NB;
+    const int tile0 = (x.n0 >> 4) + x.wn * PF_CT;
+    u8* a_buf[2] = {smem, smem + PF_BUF_BYTES};
+    auto sc_of = [&](int b) { return (f16*)(a_buf[b] + PF_A_BYTES); };
+    auto zp_of = [&](int b) { return (f16*)(a_buf[b] + PF_A_BYTES + PF_SC_BYTES); };
+    auto issue_a = [&](int s, int b)
+    {
+        const int k0 = k_base + s * SUPER_ROWS;
+        for (int base_u = x.wv * 64; base_u < PF_BM * 16; base_u += (PF_THREADS / 64) * 64)
+        {
+            const int slot = base_u + x.lane;
+            const int row = slot >> 4, p = slot & 15;
+            const int u = p ^ (row & 15);
+            const int grow = min(x.m0 + row, x.M - 1);
+            dma_to_lds16(x.a + (size_t)grow * x.K + k0 + u * 8, a_buf[b] + (size_t)base_u * 16);
+        }
+    };
+    LaneWords<BITS> w0[CB], w1[CB];
+    f16 sc2[PF_QPT], zp2[PF_QPT];
+    issue_a(0, 0);
+    step_scales<GPTQ>(*x.m, x.cg_lds, x.smax_lds, k_base >> 5, 4, x.sc_n, x.sc_q0, sc2, zp2);
+    load_tiles<BITS, CB>(w0, base, tile_stride, tile0, x.n_tiles, 0, x.lane);
+    for (int s = 0; s < F; s++)
+    {
+        const int b = s & 1;
+        f16* scl = sc_of(b); f16* zpl = zp_of(b);
+        #pragma unroll
+        for (int i = 0; i < PF_QPT; i++)
+        {
+            scl[(x.sc_q0 + i) * PF_BN + x.sc_col] = sc2[i];
+            if constexpr (GPTQ) zpl[(x.sc_q0 + i) * PF_BN + x.sc_col] = zp2[i];
+        }
+        wait_vmcnt_le<0>();
+        block_sync();
+        if (s + 1 < F)
+        {
+            issue_a(s + 1, b ^ 1);
+            step_scales<GPTQ>(*x.m, x.cg_lds, x.smax_lds, (k_base >> 5) + 4 * (s + 1), 4, x.sc_n, x.sc_q0, sc2, zp2);
+        }
+        load_tiles<BITS, CB>(w1, base, tile_stride, tile0 + CB, x.n_tiles, s, x.lane);
+        multiply_batch<BITS, GPTQ, CB, 0>(w0, a_buf[b], scl, zpl, x.wm, x.wn, x.lane, acc);
+        if constexpr (NB == 2)
+        {
+            if (s + 1 < F) load_tiles<BITS, CB>(w0, base, tile_stride, tile0, x.n_tiles, s + 1, x.lane);
+            multiply_batch<BITS, GPTQ, CB, CB>(w1, a_buf[b], scl, zpl, x.wm, x.wn, x.lane, acc);
+        }
+        else
+        {
+            load_tiles<BITS, CB>(w0, base, tile_stride, tile0 + 2 * CB, x.n_tiles, s, x.lane);
+            multiply_batch<BITS, GPTQ, CB, CB>(w1, a_buf[b], scl, zpl, x.wm, x.wn, x.lane, acc);
+            load_tiles<BITS, CB>(w1, base, tile_stride, tile0 + 3 * CB, x.n_tiles, s, x.lane);
+            multiply_batch<BITS, GPTQ, CB, 2 * CB>(w0, a_buf[b], scl, zpl, x.wm, x.wn, x.lane, acc);
+            if (s + 1 < F) load_tiles<BITS, CB>(w0, base, tile_stride, tile0, x.n_tiles, s + 1, x.lane);
+            multiply_batch<BITS, GPTQ, CB, 3 * CB>(w1, a_buf[b], scl, zpl, x.wm, x.wn, x.lane, acc);
+        }
+    }
+    block_sync();                                            // stage buffers are free again for whoever comes next
+}
+
 template <bool GPTQ>
-KERNEL void __launch_bounds__(PF_THREADS) qgemm_prefill_kernel(const PrefillArgs args)
+KERNEL void __launch_bounds__(PF_THREADS, 2) qgemm_prefill_kernel(const PrefillArgs args)
 {
     DYN_SMEM(smem);
     const QMatDev& m = args.m;
@@ -205,8 +315,8 @@ KERNEL void __launch_bounds__(PF_THREADS) qgemm_prefill_kernel(const PrefillArgs
         for (int ct = 0; ct < PF_CT; ct++) acc[rt][ct] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
     // scale staging: thread t (of 512) owns column (t & 255) and chunks {2 (t >> 8), +1} of the step
-    const int sc_col = t & (PF_BN - 1);
-    const int sc_q0 = (t >> 8) * 2;
+    const int sc_col = t % PF_BN;
+    const int sc_q0 = (t / PF_BN) * PF_QPT;
     const int sc_n = min(n0 + sc_col, m.N - 1);
 
     const int i16 = lane & 15, j4 = lane >> 4;
@@ -214,6 +324,53 @@ KERNEL void __launch_bounds__(PF_THREADS) qgemm_prefill_kernel(const PrefillArgs
     x.m = &m; x.a = args.a; x.M = args.M; x.K = K; x.m0 = m0; x.n0 = n0; x.n_tiles = n_tiles;
     x.a_lds = a_lds; x.sc_lds = sc_lds; x.zp_lds = zp_lds;
     x.t = t; x.lane = lane; x.wv = wv; x.wm = wm; x.wn = wn; x.sc_col = sc_col; x.sc_q0 = sc_q0; x.sc_n = sc_n;
+    {
+        u16* cg = (u16*)(smem + PF_TAB_OFF);
+        f16* sm = (f16*)(smem + PF_TAB_OFF + (((K >> 5) * 2 + 15) & ~15));
+        for (int i = t; i < (K >> 5); i += PF_THREADS) cg[i] = m.chunk_group[i];
+        if constexpr (!GPTQ) for (int i = t; i < m.G; i += PF_THREADS) sm[i] = m.scale_src[i];
+        x.cg_lds = cg; x.smax_lds = sm;
+        block_sync();
+    }
+    if (m.n_runs > 0)
+    {
+        // one contiguous stream per bit-width section (QRun): full runs are software-pipelined, a partial last
+        // super-chunk (its own run, padded side buffer) takes the single-step path
+        for (int ri = 0; ri < m.n_runs; ri++)
+        {
+            const QRun& run = m.runs[ri];
+            const int bits = uniform((int)run.bits);
+            const u32* base = (uniform((int)run.in_tail) ? m.tail : m.qw) + uniform(run.base_word);
+            const u32 tile_stride = uniform(run.tile_stride);
+            const int F = uniform((int)run.n_super), k_base = uniform((int)run.k_base);
+            const int nvl = uniform((int)run.nvalid_last);
+            if (nvl == 4)
+            {
+                switch (GPTQ ? 4 : bits)
+                {
+                    case 4: run_pipelined<4, GPTQ>(x, smem, base, tile_stride, F, k_base, acc); break;
+                    case 8: run_pipelined<8, GPTQ>(x, smem, base, tile_stride, F, k_base, acc); break;
+                    case 6: run_pipelined<6, GPTQ>(x, smem, base, tile_stride, F, k_base, acc); break;
+                    case 5: run_pipelined<5, GPTQ>(x, smem, base, tile_stride, F, k_base, acc); break;
+                    case 3: run_pipelined<3, GPTQ>(x, smem, base, tile_stride, F, k_base, acc); break;
+                    default: run_pipelined<2, GPTQ>(x, smem, base, tile_stride, F, k_base, acc); break;
+                }
+            }
+            else
+            {
+                switch (GPTQ ? 4 : bits)
+                {
+                    case 4: k_step<4, GPTQ>(x, base, tile_stride, 0, k_base, nvl, acc); break;
+                    case 8: k_step<8, GPTQ>(x, base, tile_stride, 0, k_base, nvl, acc); break;
+                    case 6: k_step<6, GPTQ>(x, base, tile_stride, 0, k_base, nvl, acc); break;
+                    case 5: k_step<5, GPTQ>(x, base, tile_stride, 0, k_base, nvl, acc); break;
+                    case 3: k_step<3, GPTQ>(x, base, tile_stride, 0, k_base, nvl, acc); break;
+                    default: k_step<2, GPTQ>(x, base, tile_stride, 0, k_base, nvl, acc); break;
+                }
+            }
+        }
+    }
+    else
     for (int d = 0; d < m.n_desc; d++)
     {
         const QDesc* dp = m.desc + d;
@@ -419,8 +576,9 @@ int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stre
             p.m = j.m; p.a = stage; p.c = j.c + (size_t)r0 * j.ldc; p.ldc = j.ldc; p.c_invperm = j.c_invperm;
             p.M = rows; p.c_mode = j.c_mode;
             dim3 grid((unsigned)((j.m.N + PF_BN - 1) / PF_BN), (unsigned)((rows + PF_BM - 1) / PF_BM), 1);
-            if (gptq) LAUNCH((qgemm_prefill_kernel<true>), grid, dim3(PF_THREADS), PF_LDS_BYTES, stream, p);
-            else      LAUNCH((qgemm_prefill_kernel<false>), grid, dim3(PF_THREADS), PF_LDS_BYTES, stream, p);
+            const size_t lds = PF_LDS_BYTES(j.m.K, j.m.G);
+            if (gptq) LAUNCH((qgemm_prefill_kernel<true>), grid, dim3(PF_THREADS), lds, stream, p);
+            else      LAUNCH((qgemm_prefill_kernel<false>), grid, dim3(PF_THREADS), lds, stream, p);
         }
     }
     return 0;
