@@ -212,7 +212,7 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
 
     // blockIdx.y = matrix of a fused launch: the whole parameter block arrives with ONE batch of scalar loads
     const int ji = bid_y();
-    const JobHot& h = args.hot[ji];
+    const JobHot h = args.hot[ji];                           // by value: one batch of scalar loads, not one per use
     if (bid_x() * args.TPW >= h.n_tiles) return;              // fused matrices of different widths share grid.x
     const int M = args.M;
     if (h.r_weights)
