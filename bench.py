@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--cache", default="fp16", choices=["fp16", "q4"], help="KV cache type (q4: ExLlamaV2Cache_Q4)")
+    p.add_argument("--no-prefill", action="store_true", help="skip the extra prefill measurement (BASELINE configs[2])")
     return p.parse_args()
 
 
@@ -52,10 +53,12 @@ def make_cfg(name: str, max_seq_len: int):
     raise SystemExit(f"unknown model {name}")
 
 
-def time_gemv_calls(model, dec, reps: int = 3):
-    """Duration of the q_gemm launches of one decode step, each API call bracketed by events on the launch stream.
-    Returns (total_ms, launches, algorithmic_bytes) averaged over `reps` passes (all 32 layers: weights are HBM-cold,
-    3.4 GB >> 256 MB Infinity Cache, the rotation tests/test_gemv.py:84-128 relies on)."""
+def time_gemv_calls(model, dec, reps: int = 5):
+    """Average duration of the q_gemm launches of one decode step.  The 129 launches (fused q|k|v, o, fused gate|up, down
+    per layer + head) are captured alone into a HIP graph on the decoder's stream and replayed between two HIP events on
+    that stream -- no host launch gaps in the figure, only the kernels and their boundaries (what rocprofv3's
+    per-kernel average must agree with).  All 32 layers: weights are HBM-cold (3.4 GB >> 256 MB Infinity Cache), the
+    rotation tests/test_gemv.py:84-128 relies on.  Returns (ms per step, launches, algorithmic bytes)."""
     import torch
     from exllamav2_amd.ext import none_tensor
     ext, cfg = model.ext, model.config
@@ -65,32 +68,38 @@ def time_gemv_calls(model, dec, reps: int = 3):
     k = model.temp_k[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
     v = model.temp_v[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
     ao = model.temp_attn[:b].view(b, 1, -1)
-    events = []
 
-    def timed(fn):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record()
-        events.append((e0, e1))
-
-    launches = 0
-    nbytes = 0
-    for rep in range(reps + 1):
-        if rep == 1:
-            events.clear(); launches = 0; nbytes = 0            # pass 0 is a warm-up
+    def one_step():
+        launches, nbytes = 0, 0
         for attn, mlp in model.layers:
-            timed(lambda: ext.q_attn_forward_1(attn.q_handle, x, b, 1, 0, none_tensor, q, k, v, model.sin, model.cos,
-                                               apply_rope=False))
-            timed(lambda: ext.q_attn_forward_2(attn.q_handle, x, ao, b, 1))
-            timed(lambda: ext.q_mlp_forward_(mlp.q_handle, x))
+            ext.q_attn_forward_1(attn.q_handle, x, b, 1, 0, none_tensor, q, k, v, model.sin, model.cos, apply_rope=False)
+            ext.q_attn_forward_2(attn.q_handle, x, ao, b, 1)
+            ext.q_mlp_forward_(mlp.q_handle, x)
             launches += 4
             nbytes += sum(l.weight_bytes() for l in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj,
                                                      mlp.gate_proj, mlp.up_proj, mlp.down_proj))
-        timed(lambda: ext.gemm_half_q_half(dec.xn.view(b, -1), model.lm_head.q_handle, dec.logits))
-        launches += 1
-        nbytes += model.lm_head.weight_bytes()
-    torch.cuda.synchronize()
-    total_ms = sum(e0.elapsed_time(e1) for e0, e1 in events)
-    return total_ms / reps, launches // reps, nbytes // reps
+        ext.gemm_half_q_half(dec.xn.view(b, -1), model.lm_head.q_handle, dec.logits)
+        return launches + 1, nbytes + model.lm_head.weight_bytes()
+
+    stream = dec.stream
+    with torch.cuda.stream(stream):
+        launches, nbytes = one_step()                           # warm-up, eager
+        stream.synchronize()
+        ext.graph_begin_capture(stream.cuda_stream)
+        try:
+            one_step()
+        finally:
+            graph = ext.graph_end_capture(stream.cuda_stream)
+        ext.graph_launch(graph, stream.cuda_stream)
+        stream.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            ext.graph_launch(graph, stream.cuda_stream)
+        e1.record(stream)
+        stream.synchronize()
+        ext.graph_free(graph)
+    return e0.elapsed_time(e1) / reps, launches, nbytes
 
 
 def pmc_traffic_gb(launches_per_step):
@@ -140,6 +149,34 @@ def cpu_baseline(cfg, recipe: str, seed: int = 0):
     return {"value": round(1.0 / per_token, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": f"1 of {cfg.num_hidden_layers} layers (7 linears, pre-dequantized fp32, torch.matmul) x {tokens} tokens, "
                       f"extrapolated to {cfg.num_hidden_layers} layers + head"}
+
+
+def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq: int = 2048):
+    """BASELINE configs[2] beside the headline: test_inference.py -ps procedure (:533-579), forward(ids[8, 2048],
+    preprocess_only=True) on a fresh synthetic model; reported for the default host policy (reconstruct + library GEMM
+    above 64 rows) and, on 4 layers, for the all-native kernels."""
+    import torch
+    from exllamav2_amd import ExLlamaV2, ExLlamaV2Cache
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.synth import synth_checkpoint
+    out = {"workload": f"{model_name} EXL2 {recipe}, {batch} x {seq} tokens, forward(preprocess_only=True)", "unit": "tokens/s"}
+    for tag, layers, native in (("policy_route", None, False), ("native_kernels_4_layers", 4, True)):
+        cfg = ExLlamaV2Config.llama2_7b(max_seq_len=seq, max_input_len=2048, max_batch_size=batch)
+        if layers: cfg.num_hidden_layers = layers
+        model = ExLlamaV2(cfg, device=device).load(synth_checkpoint(cfg, device, recipe=recipe, seed=1))
+        model.native_prefill = native
+        cache = ExLlamaV2Cache(model, batch_size=batch, max_seq_len=seq)
+        ids = torch.randint(0, cfg.vocab_size - 1, (batch, seq), generator=torch.Generator().manual_seed(0)).to(device)
+        model.forward(ids, cache, preprocess_only=True); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cache.current_seq_len = 0
+        model.forward(ids, cache, preprocess_only=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[tag] = {"value": round(batch * seq / dt, 1), "ms": round(dt * 1e3, 2), "layers": cfg.num_hidden_layers}
+        model.unload(); del model, cache
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -235,6 +272,11 @@ def main():
         }
         for k in ("roofline", "load_s"):
             if k in result: out[k] = result[k]
+        if not args.no_prefill and n_gpus == 1 and args.model == "llama2-7b":
+            try:
+                out["prefill"] = prefill_rate(args.model, args.recipe, device)
+            except Exception as e:  # informational; never lose the headline number
+                out["prefill"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and n_gpus == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, args.recipe)

@@ -5,7 +5,7 @@ echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 
 for rep in 1 2; do
 for v in ${VARIANTS:-"A=1"}; do
   for ctx in ${CTXS:-0}; do
-    echo -n "$v ctx=$ctx: "; env $v timeout 600 python bench.py --ctx $ctx --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'])"
+    echo -n "$v ctx=$ctx: "; env $v timeout 600 python bench.py --ctx $ctx --no-cpu-baseline --no-prefill 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'])"
   done
 done
 done
