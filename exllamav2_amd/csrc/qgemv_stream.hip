@@ -37,15 +37,16 @@
 struct JobHot
 {
     const u32* main_ptr;          // (tile 0, super-chunk 0) of the main run
-    const u16* chunk_group;
-    const u32* q_scale;           // EXL2 scale codes / GPTQ qzeros [G, N/8]
-    const f16* scale_src;         // EXL2: padded q_scale_max copy [G] ; GPTQ: scales [G, N]
+    const u8*  pack;              // make-time prologue pack: [q_perm][chunk -> group map]
+    const f16* sc_tab;            // [tile][G][16] scales ; zp_tab: GPTQ zero points
+    const f16* zp_tab;
     const u16* perm;
     const f16* a; const f16* a2; const f16* norm_w;
     u32 main_tile_stride; int main_F; int main_chunk0;
     int tile0, n_tiles, K, G, N, lda, a_mode, a_stride;
     float norm_eps;
-    u32 lds_scale_off, lds_zp_off, lds_cg_off, lds_rmf_off, lds_rawx_off, lds_raw2_off, lds_perm_off, lds_qsw_off, lds_smax_off;
+    u32 lds_scale_off, lds_zp_off, lds_cg_off, lds_rmf_off, lds_rawx_off, lds_raw2_off, lds_perm_off;
+    u32 pack_units, pack_cg_off;
     int n_runs;
     const f16* r_weights; int r_stride;  // MoE routing weights (nullable): a launch whose rows all weigh zero exits at once
 };
@@ -249,8 +250,6 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     f16* sc_all = (f16*)(smem + h.lds_scale_off);
     f16* zp_all = (f16*)(smem + h.lds_zp_off);
     u16* cg_lds = (u16*)(smem + h.lds_cg_off);
-    u32* qsw    = (u32*)(smem + h.lds_qsw_off);
-    f16* smax   = (f16*)(smem + h.lds_smax_off);
     StageLds L;
     L.rawx = (f16*)(smem + h.lds_rawx_off); L.raw2 = (f16*)(smem + h.lds_raw2_off);
     L.perm = (u16*)(smem + h.lds_perm_off); L.rms = (float*)(smem + h.lds_rmf_off);
@@ -275,29 +274,24 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
             for (int rr = 0; rr < M; rr++)
                 dma_units16([&](int u) { return (const void*)(a2 + (size_t)rr * lda + (size_t)u * 8); }, L.raw2 + (size_t)rr * K, oct, wv, nw, lane);
         }
-        if (h.perm && lds_stage)
+        // make-time pack [q_perm][chunk -> group map]: one contiguous copy (the permutation only when rows go through LDS)
         {
-            const u16* pm = h.perm;
-            dma_units16([&](int u) { return (const void*)(pm + (size_t)u * 8); }, L.perm, oct, wv, nw, lane);
+            const u8* pk = h.pack;
+            const int skip = lds_stage ? 0 : (int)(h.pack_cg_off >> 4);
+            dma_units16([&](int u) { return (const void*)(pk + ((size_t)(skip + u) << 4)); }, smem + h.lds_perm_off + ((size_t)skip << 4),
+                        (int)h.pack_units - skip, wv, nw, lane, 1 % nw);
         }
-        const u16* cgp = h.chunk_group;
-        dma_units4([&](int u) { return (const void*)(cgp + (size_t)u * 2); }, cg_lds, ((K >> 5) + 1) >> 1, wv, nw, lane, 1 % nw);
-        const u32* qs = h.q_scale; const int n8 = h.N >> 3;
-        const f16* ss = h.scale_src;
-        for (int slot = 0; slot < TPW; slot++)
+        // scale (and GPTQ zero-point) tables of this workgroup's tiles: contiguous in the make-time [tile][G][16] layout
         {
-            const int tl = min(tile_base + slot, n_tiles - 1);
-            dma_units4([&](int u) { return (const void*)(qs + (size_t)(u >> 1) * n8 + tl * 2 + (u & 1)); },
-                       qsw + (size_t)slot * 2 * G, 2 * G, wv, nw, lane, (2 + slot) % nw);
+            const int nt_here = min(TPW, n_tiles - tile_base);
+            const f16* st = h.sc_tab + (size_t)tile_base * G * 16;
+            dma_units16([&](int u) { return (const void*)(st + (size_t)u * 8); }, sc_all, nt_here * G * 2, wv, nw, lane, 2 % nw);
             if constexpr (GPTQ)
             {
-                const int N = h.N;
-                dma_units4([&](int u) { return (const void*)(ss + (size_t)(u >> 3) * N + tl * 16 + 2 * (u & 7)); },
-                           sc_all + (size_t)slot * 16 * G, 8 * G, wv, nw, lane, (3 + slot) % nw);
+                const f16* zt = h.zp_tab + (size_t)tile_base * G * 16;
+                dma_units16([&](int u) { return (const void*)(zt + (size_t)u * 8); }, zp_all, nt_here * G * 2, wv, nw, lane, 3 % nw);
             }
         }
-        if constexpr (!GPTQ)
-            dma_units4([&](int u) { return (const void*)(ss + (size_t)u * 2); }, smax, (G + 1) >> 1, wv, nw, lane, nw - 1);
     }
     TRACE_POINT(1);
     // The prologue inputs travel alone: issued behind the weight flood they would queue behind ~all of it (the memory
@@ -328,27 +322,6 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     TRACE_POINT(9);
 
     // ---- prologue: tables and activations, LDS -> LDS -------------------------------------------------------------------
-    // scale / zero-point tables: one code word (8 columns) per thread
-    for (int i = t; i < TPW * G * 2; i += nt)
-    {
-        const u32 word = qsw[i];
-        f16x8 v;
-        if constexpr (GPTQ)
-        {
-            #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = (f16)(float)(((word >> (4 * e)) & 15) + 1);
-            ((f16x8*)zp_all)[i] = v;
-        }
-        else
-        {
-            int g = i >> 1;
-            while (g >= G) g -= G;                                // i >> 1 = slot * G + g, TPW is small
-            const f16 mx = smax[g];
-            #pragma unroll
-            for (int e = 0; e < 8; e++) { const int nib = ((word >> (4 * e)) & 15) + 1; v[e] = (f16)(float)(nib * nib) * mx; }
-            ((f16x8*)sc_all)[i] = v;
-        }
-    }
     TRACE_POINT(10);
     if (lds_stage)
     {
@@ -524,7 +497,7 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
         if (!aligned16(j.a) || (j.lda & 7) || (m.perm && !aligned16(m.perm))) return 1;
         if ((j.a_mode == A_SILU_MUL || j.a_mode == A_GELU_MUL) && !aligned16(j.a2)) return 1;
         if (j.a_mode == A_RMSNORM && !aligned16(j.norm_w)) return 1;
-        if (!gptq && !m.scale_pad) return 1;
+        if (!m.pack || !m.sc_tab || (gptq && !m.zp_tab)) return 1;
         tiles += m.N / TILE_N;
         const QRun& mr = m.runs[m.main_run];
         const int items = mr.nvalid_last == 4 ? (int)mr.n_super : 0;
@@ -583,27 +556,25 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
         u32 total = a_bytes;
         h.lds_scale_off = total;  total += align16s((u32)TPW * m.G * 32);
         h.lds_zp_off = total;     total += gptq ? align16s((u32)TPW * m.G * 32) : 0;
-        h.lds_cg_off = total;     total += align16s((u32)(m.K >> 5) * 2 + 4);
         h.lds_rmf_off = total;    total += 64 + 16 * 16 * 4;
-        h.lds_qsw_off = total;    total += align16s((u32)TPW * m.G * 8);
-        h.lds_smax_off = total;   total += align16s((u32)m.G * 2 + 4);
+        h.lds_perm_off = total;   total += m.pack_units * 16;               // pack image: [q_perm][chunk -> group map]
+        h.lds_cg_off = h.lds_perm_off + m.pack_cg_off;
         {
-            const u32 raw = row_bytes + (two ? row_bytes : (j.a_mode == A_RMSNORM ? align16s((u32)m.K * 2) : 0))
-                            + (m.perm ? align16s((u32)m.K * 2) : 0);
+            const u32 raw = row_bytes + (two ? row_bytes : (j.a_mode == A_RMSNORM ? align16s((u32)m.K * 2) : 0));
             if (total + raw <= 160 * 1024 && !no_lds_stage)
             {
                 h.lds_rawx_off = total;   total += row_bytes;
                 h.lds_raw2_off = total;   total += two ? row_bytes : (j.a_mode == A_RMSNORM ? align16s((u32)m.K * 2) : 0);
-                h.lds_perm_off = total;   total += m.perm ? align16s((u32)m.K * 2) : 0;
             }
-            else { h.lds_rawx_off = 0; h.lds_raw2_off = 0; h.lds_perm_off = 0; }      // gather from global memory instead
+            else { h.lds_rawx_off = 0; h.lds_raw2_off = 0; }                          // gather from global memory instead
         }
         if (total > lds) lds = total;
 
         const QRun& mr = m.runs[m.main_run];
         h.main_ptr = (mr.in_tail ? m.tail : m.qw) + mr.base_word;
         h.main_tile_stride = mr.tile_stride; h.main_F = (int)mr.n_super; h.main_chunk0 = (int)mr.k_base >> 5;
-        h.chunk_group = m.chunk_group; h.q_scale = m.q_scale; h.scale_src = gptq ? m.scale_src : m.scale_pad; h.perm = m.perm;
+        h.pack = m.pack; h.pack_units = m.pack_units; h.pack_cg_off = m.pack_cg_off; h.sc_tab = m.sc_tab; h.zp_tab = m.zp_tab;
+        h.perm = m.perm;
         h.a = j.a; h.a2 = j.a2; h.norm_w = j.norm_w;
         h.tile0 = j.tile0; h.n_tiles = m.N / TILE_N; h.K = m.K; h.G = m.G; h.N = m.N; h.lda = j.lda; h.a_mode = j.a_mode;
         h.a_stride = j.a_stride; h.norm_eps = j.norm_eps; h.n_runs = m.n_runs;

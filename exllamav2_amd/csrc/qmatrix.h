@@ -18,6 +18,12 @@ struct QMatDev
     const f16*   scale_src;       // EXL2: q_scale_max [G] (already * prescale/256) ; GPTQ: scales [G, N]
     const f16*   bias;            // nullable
     const f16*   scale_pad;       // EXL2: private copy of q_scale_max padded to a dword multiple (LDS-DMA source)
+    // decode-kernel prologue inputs prepared at make time (one contiguous LDS-DMA each instead of gathers + arithmetic):
+    const u8*    pack;            // [q_perm (K u16, if any)] [chunk -> group map (K/32 u16)], 16-byte aligned sections
+    u32          pack_units;      // size of pack in 16-byte units
+    u32          pack_cg_off;     // byte offset of the chunk -> group map inside pack
+    const f16*   sc_tab;          // [tile][G][16] fp16 scale of every (group, column), exactly reconstruct()'s values
+    const f16*   zp_tab;          // GPTQ: [tile][G][16] zero points (nibble + 1) as fp16
     int n_desc;
     int K, N, G;
     int is_gptq;
@@ -37,6 +43,9 @@ struct QMatrix
     QDesc* desc_buf;
     u16*   chunk_group_buf;
     f16*   scale_pad_buf;
+    u8*    pack_buf;
+    f16*   sc_tab_buf;
+    f16*   zp_tab_buf;
     // caller-owned (kept for reconstruct / TP splitting)
     u32* q_weight; u16* q_perm; u16* q_invperm;
     f16* temp_dq; int max_dq_rows;

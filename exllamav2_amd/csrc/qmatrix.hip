@@ -142,6 +142,21 @@ KERNEL void reconstruct_kernel(const QMatDev m, f16* out)
     }
 }
 
+// [tile][G][16] tables of the per-(group, column) scale (and GPTQ zero point) in the fp16 values reconstruct() uses
+KERNEL void __launch_bounds__(256) scale_table_kernel(const QMatDev m, f16* sc_tab, f16* zp_tab)
+{
+    const int tile = bid_x();
+    const int idx = bid_y() * 256 + tid();
+    if (idx >= m.G * 16) return;
+    const int g = idx >> 4, c = idx & 15;
+    const int n = tile * TILE_N + c;
+    const u32 word = m.q_scale[(size_t)g * (m.N >> 3) + (n >> 3)];
+    const int nib = (word >> (4 * (n & 7))) & 15;
+    const size_t o = ((size_t)tile * m.G + g) * 16 + c;
+    if (m.is_gptq) { sc_tab[o] = m.scale_src[(size_t)g * m.N + n]; zp_tab[o] = (f16)(float)(nib + 1); }
+    else           sc_tab[o] = (f16)(float)((nib + 1) * (nib + 1)) * m.scale_src[g];
+}
+
 // ---- host -----------------------------------------------------------------------------------------------------------
 
 struct Section { int bits; int k0; int chunks; int qrow0; };
@@ -297,6 +312,12 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
     chunk_group.resize(chunk_group.size() + 2, (u16)0);            // readable as whole dwords (LDS-DMA source)
     if (e == hipSuccess) e = hipMalloc((void**)&qm->chunk_group_buf, chunk_group.size() * sizeof(u16));
     if (e == hipSuccess && !is_gptq) e = hipMalloc((void**)&qm->scale_pad_buf, ((size_t)G + 2) * sizeof(f16));
+    const size_t perm_bytes = q_perm ? (((size_t)K * 2 + 15) & ~(size_t)15) : 0;
+    const size_t cg_bytes = ((size_t)n_chunks * 2 + 4 + 15) & ~(size_t)15;
+    const size_t tab_elems = (size_t)(N / TILE_N) * G * 16;
+    if (e == hipSuccess) e = hipMalloc((void**)&qm->pack_buf, perm_bytes + cg_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&qm->sc_tab_buf, tab_elems * sizeof(f16));
+    if (e == hipSuccess && is_gptq) e = hipMalloc((void**)&qm->zp_tab_buf, tab_elems * sizeof(f16));
     if (e != hipSuccess)
     {
         (void)hipGetLastError();
@@ -305,6 +326,9 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
         if (qm->desc_buf) (void)hipFree(qm->desc_buf);
         if (qm->chunk_group_buf) (void)hipFree(qm->chunk_group_buf);
         if (qm->scale_pad_buf) (void)hipFree(qm->scale_pad_buf);
+        if (qm->pack_buf) (void)hipFree(qm->pack_buf);
+        if (qm->sc_tab_buf) (void)hipFree(qm->sc_tab_buf);
+        if (qm->zp_tab_buf) (void)hipFree(qm->zp_tab_buf);
         free(qm);
         EXL2_FAIL(EXL2_E_OOM, "HIP out of memory (make_q_matrix: %zu bytes of re-layout scratch)", weight_words * 4);
     }
@@ -329,11 +353,25 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
         dim3 grid((unsigned)tiles, (unsigned)((r.n_super + 3) / 4), 1);
         LAUNCH(relayout_kernel, grid, dim3(256, 1, 1), 0, stream, r);
     }
+    // prologue pack (after q_perm has its final contents) and scale tables
+    HIP_TRY(hipMemsetAsync(qm->pack_buf, 0, perm_bytes + cg_bytes, stream));
+    if (q_perm) HIP_TRY(hipMemcpyAsync(qm->pack_buf, q_perm, (size_t)K * 2, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(qm->pack_buf + perm_bytes, chunk_group.data(), (size_t)n_chunks * 2, hipMemcpyHostToDevice, stream));
+    {
+        QMatDev t;
+        memset(&t, 0, sizeof(t));
+        t.q_scale = is_gptq ? gptq_qzeros : q_scale; t.scale_src = is_gptq ? gptq_scales : q_scale_max;
+        t.N = N; t.G = G; t.is_gptq = is_gptq ? 1 : 0;
+        LAUNCH(scale_table_kernel, dim3((unsigned)(N / TILE_N), (unsigned)((G * 16 + 255) / 256), 1), dim3(256, 1, 1), 0, stream,
+               t, qm->sc_tab_buf, qm->zp_tab_buf);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipFree(temp));
 
     QMatDev& d = qm->dev;
+    d.pack = qm->pack_buf; d.pack_units = (u32)((perm_bytes + cg_bytes) / 16); d.pack_cg_off = (u32)perm_bytes;
+    d.sc_tab = qm->sc_tab_buf; d.zp_tab = qm->zp_tab_buf;
     d.qw = q_weight; d.tail = qm->tail_buf; d.desc = qm->desc_buf; d.chunk_group = qm->chunk_group_buf;
     d.perm = q_perm;
     d.q_scale = is_gptq ? gptq_qzeros : q_scale;
@@ -398,6 +436,9 @@ void qmatrix_destroy(QMatrix* qm)
     if (qm->desc_buf) (void)hipFree(qm->desc_buf);
     if (qm->chunk_group_buf) (void)hipFree(qm->chunk_group_buf);
     if (qm->scale_pad_buf) (void)hipFree(qm->scale_pad_buf);
+    if (qm->pack_buf) (void)hipFree(qm->pack_buf);
+    if (qm->sc_tab_buf) (void)hipFree(qm->sc_tab_buf);
+    if (qm->zp_tab_buf) (void)hipFree(qm->zp_tab_buf);
     free(qm);
 }
 
