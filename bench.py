@@ -46,6 +46,8 @@ def make_cfg(name: str, max_seq_len: int):
     from exllamav2_amd.config import ExLlamaV2Config
     if name == "llama2-7b":
         return ExLlamaV2Config.llama2_7b(max_seq_len=max_seq_len, max_input_len=256)
+    if name == "llama2-70b":
+        return ExLlamaV2Config.llama2_70b(max_seq_len=max_seq_len, max_input_len=256)
     if name == "tinyllama":
         return ExLlamaV2Config.tinyllama_1b(max_input_len=256)
     if name == "tiny":

@@ -647,7 +647,10 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
     const int G = num_heads / num_kv_heads;
     const int R = q_len * G;
     if (R > 32) return 1;
-    const int rb = R >= 8 ? 8 : (R >= 4 ? 4 : (R >= 2 ? 2 : 1));
+    // few KV heads (GQA): prefer more, lighter workgroups -- 4 query rows each (the KV stream is small and re-read per
+    // row block) and up to 64 splits; with many KV heads 8 rows share one pass over the keys
+    const bool gqa_small = (long long)num_kv_heads * batch < 64;
+    const int rb = (R >= 8 && !gqa_small) ? 8 : (R >= 4 ? 4 : (R >= 2 ? 2 : 1));
     const int rblocks = (R + rb - 1) / rb;
     if (!counters || (long long)batch * num_kv_heads * rblocks > n_counters) return 1;
     FusedArgs a;
@@ -664,12 +667,12 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
     if (nsplit <= 0)
     {
         const long long base = (long long)num_kv_heads * batch * rblocks;
-        nsplit = (int)((512 + base - 1) / base);
-        if (nsplit > 16) nsplit = 16;
+        nsplit = (int)((1024 + base - 1) / base);
+        if (nsplit > 64) nsplit = 64;
         if (nsplit < 1) nsplit = 1;
     }
-    const long long need = exl2_paged_attn_scratch_bytes(batch * q_len * num_heads, head_dim, nsplit);
-    if (need > scratch_bytes || (need > 0 && !scratch)) nsplit = 1;
+    long long need = exl2_paged_attn_scratch_bytes(batch * q_len * num_heads, head_dim, nsplit);
+    while (nsplit > 1 && (need > scratch_bytes || !scratch)) { nsplit /= 2; need = exl2_paged_attn_scratch_bytes(batch * q_len * num_heads, head_dim, nsplit); }
     a.nsplit = nsplit;
     if (nsplit > 1)
     {

@@ -35,13 +35,6 @@ struct AttnQ4Args
     float scale;
 };
 
-// (c_lo - 8, c_hi - 8) as exact halves for byte `i` of the four code bytes in lo / hi (nibbles already split)
-DEV f16x2 code_pair(u32 lo, u32 hi, int i)
-{
-    const u32 l = (lo >> (8 * i)) & 0xFFu, h = (hi >> (8 * i)) & 0xFFu;
-    return as_h2(l | (h << 16) | 0x64006400u) - (f16x2){(f16)1032.0f, (f16)1032.0f};
-}
-
 DEV int q4_eff_splits(int total, int nsplit)
 {
     const int e = (total + 255) >> 8;                       // ~256 keys per split at least

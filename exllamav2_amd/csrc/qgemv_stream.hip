@@ -525,6 +525,26 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
     const char* ft = getenv("EXL2_GEMV_TPW");
     if (ft && atoi(ft) > 0) TPW = atoi(ft);
     if (TPW * S > 16) TPW = 16 / S > 0 ? 16 / S : 1;
+    // many quantisation groups (small group size x large K): the per-tile scale tables may not fit for TPW tiles --
+    // fewer tiles per workgroup (more workgroups, possibly a second round) still beats the generic kernel by far
+    for (;;)
+    {
+        u32 worst = 0;
+        for (int i = 0; i < n_jobs; i++)
+        {
+            const QMatDev& m = jobs[i].m;
+            u32 a_bytes = align16s((u32)M * (m.K + 8) * 2);
+            const u32 red_bytes = (u32)(TPW * S) * 16 * 16 * 4;
+            if (a_bytes < red_bytes) a_bytes = red_bytes;
+            const u32 t = a_bytes + align16s((u32)TPW * m.G * 32) * (gptq ? 2 : 1) + 64 + 16 * 16 * 4 + m.pack_units * 16;
+            if (t > worst) worst = t;
+        }
+        if (worst <= 160 * 1024 || TPW == 1) break;
+        TPW = (TPW + 1) / 2;
+        S = 16 / TPW;
+        if (S > min_items / 2) S = min_items / 2;
+        if (S < 1) S = 1;
+    }
     const int W = TPW * S;
 
     const char* nls = getenv("EXL2_GEMV_NO_LDS_STAGE");       // tests: force the many-rows staging route

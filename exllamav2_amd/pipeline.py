@@ -16,7 +16,7 @@ import time
 import torch
 import torch.distributed as dist
 
-from .cache import ExLlamaV2Cache, PAGE_SIZE
+from .cache import ExLlamaV2Cache, ExLlamaV2Cache_Q4, PAGE_SIZE
 from .model import ExLlamaV2
 from .synth import synth_checkpoint
 
@@ -31,7 +31,7 @@ class PipelineStage:
     """One rank's slice of the model + per-sequence decode state (device-side positions, like GreedyGraphDecoder)."""
 
     def __init__(self, cfg, rank: int, world: int, device, n_seqs: int, max_seq_len: int, recipe: str = "4.0bpw",
-                 seed: int = 0, ext=None, use_graph: bool = True):
+                 seed: int = 0, ext=None, use_graph: bool = True, cache_type: str = "fp16"):
         self.cfg, self.rank, self.world, self.n_seqs = cfg, rank, world, n_seqs
         self.first, self.last = rank == 0, rank == world - 1
         self.device = torch.device(device)
@@ -40,7 +40,8 @@ class PipelineStage:
                               with_head=self.last)
         self.model = ExLlamaV2(cfg, device=device, ext=ext).load(ck, layers=layers)
         self.ext = self.model.ext
-        self.cache = ExLlamaV2Cache(self.model, batch_size=n_seqs, max_seq_len=max_seq_len)
+        cache_cls = ExLlamaV2Cache_Q4 if cache_type == "q4" else ExLlamaV2Cache
+        self.cache = cache_cls(self.model, batch_size=n_seqs, max_seq_len=max_seq_len)
         pages = max_seq_len // PAGE_SIZE
         dev = self.device
         self.block_table = torch.arange(n_seqs * pages, dtype=torch.int32, device=dev).view(n_seqs, pages).contiguous()
@@ -155,7 +156,8 @@ def run_layer_split_bench(cfg, args, rank: int, world: int, device):
     ramp = 512                      # untimed ticks before the warm-up (clock ramp of a freshly started GPU), same on every rank
     max_seq = max(2048, ((args.ctx + (args.steps + args.warmup + ramp) // n_seqs + 2 + 255) // 256) * 256)
     t_load = time.perf_counter()
-    stage = PipelineStage(cfg, rank, world, device, n_seqs, max_seq, recipe=args.recipe, use_graph=not args.no_graph)
+    stage = PipelineStage(cfg, rank, world, device, n_seqs, max_seq, recipe=args.recipe, use_graph=not args.no_graph,
+                          cache_type=getattr(args, "cache", "fp16"))
     stage.capture()
     stage.seqlens.fill_(args.ctx)
     torch.cuda.synchronize()
