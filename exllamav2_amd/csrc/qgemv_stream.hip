@@ -47,6 +47,7 @@ struct JobHot
     float norm_eps;
     u32 lds_scale_off, lds_zp_off, lds_cg_off, lds_rmf_off, lds_rawx_off, lds_raw2_off, lds_perm_off;
     u32 pack_units, pack_cg_off;
+    int main_bits;                // bit width of this matrix' main run (the early ring fill applies when it equals MB)
     int n_runs;
     const f16* r_weights; int r_stride;  // MoE routing weights (nullable): a launch whose rows all weigh zero exits at once
 };
@@ -308,7 +309,10 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     constexpr int FIRST_SIP = DM < FIRST_SIP_ITEMS ? DM : FIRST_SIP_ITEMS;
     LaneWords<(MB ? MB : 4)> pre[DM];
     RunSlice ms; ms.n = 0; ms.ptr0 = nullptr; ms.chunk0 = 0;
-    if constexpr (MB != 0)
+    // fused matrices may have different main widths (q / k vs v in low-bpw models): the early fill serves the ones that
+    // match this instantiation, the others stream all their runs through the run loop below
+    const bool fast_main = MB != 0 && h.main_bits == MB;
+    if (fast_main)
     {
         const int F = h.main_F;
         const int i0 = (int)(((long long)r * F) / S), i1 = (int)(((long long)(r + 1) * F) / S);
@@ -317,7 +321,7 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
         ms.chunk0 = h.main_chunk0 + 4 * i0;
         // a first sip only: more than ~2 KB per wave overflows the CU's request queue and the wave would sit in the issue
         // stage instead of doing the LDS work below; the rest of the ring goes out right after that work
-        ring_fill<MB, DM, 0, FIRST_SIP>(pre, ms.ptr0, ms.n, lane);
+        ring_fill<(MB ? MB : 4), DM, 0, FIRST_SIP>(pre, ms.ptr0, ms.n, lane);
     }
     TRACE_POINT(9);
 
@@ -374,7 +378,7 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
             default:         stage_rows<A_GELU>(jc, jc.m, h.a, h.a2, a_lds, rmf_w, 0, oct, M, t, nt); break;
         }
     }
-    if constexpr (MB != 0) ring_fill<MB, DM, FIRST_SIP, DM>(pre, ms.ptr0, ms.n, lane);
+    if (fast_main) ring_fill<(MB ? MB : 4), DM, FIRST_SIP, DM>(pre, ms.ptr0, ms.n, lane);
     TRACE_POINT(3);
     block_sync_lds();
     TRACE_POINT(4);
@@ -388,13 +392,13 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     ph.cg_lds = cg_lds; ph.a_stride = h.a_stride;
     ph.M = M; ph.phase_k0 = 0;
 
-    if constexpr (MB != 0) stream_items<MB, GPTQ, DM>(ms.ptr0, ms.n, ms.chunk0, ph, lane, acc, pre, true);
+    if (fast_main) stream_items<(MB ? MB : 4), GPTQ, DM>(ms.ptr0, ms.n, ms.chunk0, ph, lane, acc, pre, true);
     TRACE_POINT(5);
-    if (MB == 0 || h.n_runs > 1)
+    if (!fast_main || h.n_runs > 1)
     {
         for (int i = 0; i < m.n_runs; i++)
         {
-            if (MB != 0 && i == m.main_run) continue;
+            if (fast_main && i == m.main_run) continue;
             do_run_any<GPTQ>(m.runs[i], m, tile, r, S, ph, lane, acc);
         }
     }
@@ -488,6 +492,7 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
     if (off && atoi(off)) return 1;
     long long tiles = 0;
     int min_items = 1 << 30, mb = -1;
+    long long bits_weight[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < n_jobs; i++)
     {
         const GemvJob& j = jobs[i];
@@ -503,8 +508,9 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
         const int items = mr.nvalid_last == 4 ? (int)mr.n_super : 0;
         if (items < min_items) min_items = items;
         const int b = items > 0 ? (int)mr.bits : 0;
-        if (mb < 0) mb = b; else if (mb != b) mb = 0;
+        if (b >= 2 && b <= 8) bits_weight[b] += (long long)items * b * (m.N / TILE_N);
     }
+    for (int b = 2; b <= 8; b++) if (bits_weight[b] > 0 && (mb < 0 || bits_weight[b] > bits_weight[mb])) mb = b;
     if (mb < 0) mb = 0;
 
     // Shape of the launch.  Measured on MI355X (tools/trace_gemv.py): the dispatcher spreads workgroups breadth-first over
@@ -593,6 +599,7 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
         const QRun& mr = m.runs[m.main_run];
         h.main_ptr = (mr.in_tail ? m.tail : m.qw) + mr.base_word;
         h.main_tile_stride = mr.tile_stride; h.main_F = (int)mr.n_super; h.main_chunk0 = (int)mr.k_base >> 5;
+        h.main_bits = mr.nvalid_last == 4 ? (int)mr.bits : 0;
         h.pack = m.pack; h.pack_units = m.pack_units; h.pack_cg_off = m.pack_cg_off; h.sc_tab = m.sc_tab; h.zp_tab = m.zp_tab;
         h.perm = m.perm;
         h.a = j.a; h.a2 = j.a2; h.norm_w = j.norm_w;
