@@ -667,8 +667,8 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
     if (nsplit <= 0)
     {
         const long long base = (long long)num_kv_heads * batch * rblocks;
-        nsplit = (int)((1024 + base - 1) / base);
-        if (nsplit > 64) nsplit = 64;
+        nsplit = (int)(((gqa_small ? 1024 : 512) + base - 1) / base);
+        if (nsplit > (gqa_small ? 64 : 16)) nsplit = gqa_small ? 64 : 16;
         if (nsplit < 1) nsplit = 1;
     }
     long long need = exl2_paged_attn_scratch_bytes(batch * q_len * num_heads, head_dim, nsplit);

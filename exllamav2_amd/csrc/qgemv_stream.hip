@@ -34,7 +34,7 @@
 #endif
 
 // What the prologue and the main weight run need, flat and by value (selected with scalar selects, never indexed).
-struct JobHot
+struct alignas(64) JobHot          // 64-byte aligned entries: whole-line scalar loads at a dynamic index
 {
     const u32* main_ptr;          // (tile 0, super-chunk 0) of the main run
     const u8*  pack;              // make-time prologue pack: [q_perm][chunk -> group map]
@@ -206,7 +206,8 @@ DEV void dma_units4(F src_of, void* dst, int units, int wv, int nw, int lane, in
 }
 
 // MB = bit width of the main (largest) run, whose ring fill is issued with the prologue; 0 = no early fill
-template <bool GPTQ, int MB>
+// MIXED: the fused matrices do not all have MB as their main width (then the early fill is decided per workgroup)
+template <bool GPTQ, int MB, bool MIXED = false>
 KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
 {
     DYN_SMEM(smem);
@@ -311,7 +312,7 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     RunSlice ms; ms.n = 0; ms.ptr0 = nullptr; ms.chunk0 = 0;
     // fused matrices may have different main widths (q / k vs v in low-bpw models): the early fill serves the ones that
     // match this instantiation, the others stream all their runs through the run loop below
-    const bool fast_main = MB != 0 && h.main_bits == MB;
+    const bool fast_main = MB != 0 && (!MIXED || h.main_bits == MB);
     if (fast_main)
     {
         const int F = h.main_F;
@@ -470,15 +471,17 @@ static int num_cus()
 }
 
 template <bool GPTQ, int MB>
-static void launch_variant(const StreamArgs& args, dim3 grid, dim3 block, u32 lds, void* stream)
+static void launch_variant(const StreamArgs& args, dim3 grid, dim3 block, u32 lds, void* stream, bool mixed = false)
 {
     static bool attr = false;
     if (!attr)
     {
-        (void)hipFuncSetAttribute((const void*)qgemv_stream_kernel<GPTQ, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qgemv_stream_kernel<GPTQ, MB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qgemv_stream_kernel<GPTQ, MB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    LAUNCH((qgemv_stream_kernel<GPTQ, MB>), grid, block, lds, stream, args);
+    if (mixed) LAUNCH((qgemv_stream_kernel<GPTQ, MB, true>), grid, block, lds, stream, args);
+    else       LAUNCH((qgemv_stream_kernel<GPTQ, MB, false>), grid, block, lds, stream, args);
 }
 
 static inline bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
@@ -608,6 +611,8 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
         h.r_weights = j.r_weights; h.r_stride = j.r_stride;
     }
     if (lds > 160 * 1024) return 1;
+    bool mixed = false;
+    for (int i = 0; i < n_jobs; i++) if (args.hot[i].main_bits != mb) mixed = true;
     dim3 grid((unsigned)blk_max, (unsigned)n_jobs, 1), block((unsigned)(W * 64), 1, 1);
     if (gptq)
     {
@@ -618,12 +623,12 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
     {
         switch (mb)
         {
-            case 4: launch_variant<false, 4>(args, grid, block, lds, stream); break;
-            case 8: launch_variant<false, 8>(args, grid, block, lds, stream); break;
-            case 6: launch_variant<false, 6>(args, grid, block, lds, stream); break;
-            case 5: launch_variant<false, 5>(args, grid, block, lds, stream); break;
-            case 3: launch_variant<false, 3>(args, grid, block, lds, stream); break;
-            case 2: launch_variant<false, 2>(args, grid, block, lds, stream); break;
+            case 4: launch_variant<false, 4>(args, grid, block, lds, stream, mixed); break;
+            case 8: launch_variant<false, 8>(args, grid, block, lds, stream, mixed); break;
+            case 6: launch_variant<false, 6>(args, grid, block, lds, stream, mixed); break;
+            case 5: launch_variant<false, 5>(args, grid, block, lds, stream, mixed); break;
+            case 3: launch_variant<false, 3>(args, grid, block, lds, stream, mixed); break;
+            case 2: launch_variant<false, 2>(args, grid, block, lds, stream, mixed); break;
             default: launch_variant<false, 0>(args, grid, block, lds, stream); break;
         }
     }
