@@ -153,7 +153,7 @@ def run_pipeline(stage: PipelineStage, first_tokens, n_ticks: int):
 def run_layer_split_bench(cfg, args, rank: int, world: int, device):
     """bench.py backend for --gpus N > 1: N sequences in flight over an N-stage layer split."""
     n_seqs = world
-    ramp = 512                      # untimed ticks before the warm-up (clock ramp of a freshly started GPU), same on every rank
+    ramp = 2048                     # untimed ticks before the warm-up (clock ramp of a freshly started GPU), same on every rank
     max_seq = max(2048, ((args.ctx + (args.steps + args.warmup + ramp) // n_seqs + 2 + 255) // 256) * 256)
     t_load = time.perf_counter()
     stage = PipelineStage(cfg, rank, world, device, n_seqs, max_seq, recipe=args.recipe, use_graph=not args.no_graph,
