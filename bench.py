@@ -111,7 +111,7 @@ def pmc_traffic_gb(launches_per_step):
     try:
         files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
         d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
-        kb = [v["avg"] for k, v in d.items() if k.startswith("FETCH_SIZE:") and "qgemv_stream_kernel<false, 4>" in k]
+        kb = [v["avg"] for k, v in d.items() if k.startswith("FETCH_SIZE:") and "qgemv_stream_kernel<false, 4" in k]
         return round(kb[0] * 1024 * 2 * launches_per_step / 1e9, 3) if kb else None
     except Exception:
         return None
