@@ -7,12 +7,13 @@
 // launch and the last store (1-2 us each when the data is HBM-cold) and how early the weight stream starts:
 //   * everything the prologue needs lives in ONE by-value block of kernel arguments (JobHot): no pointer chasing through
 //     the argument segment before the first load can be issued;
-//   * the prologue's inputs (x rows, norm weight / up rows, q_perm, chunk->group map, scale codes, scale maxima) are
-//     copied global -> LDS by asynchronous LDS-DMA issued in the kernel's first cycles, and right behind them the wave's
-//     weight slice goes into a deep register ring (up to 8 KB per wave = the whole slice for the usual splits).  Vector
-//     memory completes in issue order, so `s_waitcnt vmcnt(ring loads)` releases the prologue as soon as ITS data is
-//     there while the weights keep streaming; barriers in the prologue order LDS only (block_sync_lds) -- a
-//     __syncthreads() would drain vmcnt, i.e. wait for the whole weight slice;
+//   * the prologue's inputs (x rows, norm weight / up rows, the make-time pack = q_perm + chunk->group map, this
+//     workgroup's slice of the make-time [tile][G][16] scale table) are copied global -> LDS by asynchronous LDS-DMA
+//     issued in the kernel's first cycles; they travel alone (behind the weight flood they would queue behind ~all of
+//     it), then a first sip of the weight slice goes into the register ring, the rest after the LDS work; barriers in
+//     the prologue order LDS only (block_sync_lds) -- a __syncthreads() would drain vmcnt, i.e. wait for every
+//     prefetched weight load.  The prologue runs at 3 waves per SIMD and is bound by its instruction count, so anything
+//     computable at load time (scale tables) is;
 //   * the activation permutation (act-order), RMSNorm and SiLU(gate)*up happen LDS -> LDS;
 //   * a wavefront streams a CONTIGUOUS slice of one 16-column tile (tile16 layout: a tile's K range is one linear
 //     stream); every ring load is unconditional (clamped), so the compiler's counted vmcnt lets item i decode while
