@@ -50,3 +50,17 @@ def test_missing_library_is_loud(tmp_path):
     from exllamav2_amd import _lib
     with pytest.raises(_lib.Exl2Error, match="no CPU fallback"):
         _lib.Lib(str(tmp_path / "libexl2_hip.so"))
+
+
+def test_flash_attn_shim_signature():
+    """dropin/flash_attn exposes what the reference probes and calls (attn.py:35-59, 602-613)."""
+    import importlib.util, inspect, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropin", "flash_attn", "__init__.py")
+    spec = importlib.util.spec_from_file_location("flash_attn_shim", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert tuple(int(x) for x in mod.__version__.split(".")) >= (2, 5, 7)
+    params = inspect.signature(mod.flash_attn_with_kvcache).parameters
+    for name in ("q", "k_cache", "v_cache", "k", "v", "cache_seqlens", "block_table", "causal", "softmax_scale"):
+        assert name in params
+
