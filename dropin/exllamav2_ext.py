@@ -46,7 +46,8 @@ def _out_of_scope(name, why):
     return f
 
 
-for _n in ("make_q_matrix_split", "gemm_half_q_half_tp", "make_tp_context", "free_tp_context", "tp_broadcast", "tp_gather",
+make_q_matrix_split = _e.make_q_matrix_split
+for _n in ("gemm_half_q_half_tp", "make_tp_context", "free_tp_context", "tp_broadcast", "tp_gather",
            "tp_cross_device_barrier", "tp_all_reduce", "tp_attn_forward_", "tp_attn_forward_paged_", "tp_mlp_forward_",
            "rms_norm_tp"):
     globals()[_n] = _out_of_scope(_n, "tensor-parallel host-staged path: next row after the layer-split pipeline (SURVEY.md 8e)")

@@ -100,6 +100,18 @@ class ExtC:
             self._stream(q_weight)))
         return int(handle.value)
 
+    def make_q_matrix_split(self, q_weight, q_perm, q_invperm, q_scale, q_scale_max, q_groups, q_group_map,
+                            gptq_qzeros, gptq_scales, gptq_g_idx, bias, temp_dq, max_dq_rows) -> int:
+        """ext_qmatrix.cpp:113-187: handle over tensors that were already sliced along the output features for one
+        device of a tensor-parallel split (the slicing itself is host code: contiguous `q_weight[:, a:b]`,
+        `q_scale[:, a/8:b/8]`, `bias[a:b]`, shared q_perm / q_groups).  EXL2 only, like the reference.  The reference's
+        variant merely skips building the group map; here the map is derived from q_groups either way, so this is
+        make_q_matrix with the reference's restriction."""
+        if _is_none(q_scale) or not _is_none(gptq_qzeros) or not _is_none(gptq_scales) or not _is_none(gptq_g_idx):
+            raise RuntimeError("Tensor split not implemented for GPTQ matrices")
+        return self.make_q_matrix(q_weight, q_perm, q_invperm, q_scale, q_scale_max, q_groups, q_group_map, gptq_qzeros,
+                                  gptq_scales, gptq_g_idx, bias, temp_dq, max_dq_rows)
+
     def free_q_matrix(self, handle: int) -> None:
         self.lib.check(self.lib.exl2_free_q_matrix(handle))
 
@@ -408,7 +420,7 @@ class ExtC:
     # ---- python-level adapter (exllamav2/ext.py:325-410) --------------------------------------------------------------
 
     def make_q_matrix_from_dict(self, w: dict, temp_dq, key: str | None = None, prescale: float = 1,
-                                max_dq_rows: int = 0, offset_qzeros: bool = False) -> int:
+                                max_dq_rows: int = 0, offset_qzeros: bool = False, split: bool = False) -> int:
         """The reference's `ext.make_q_matrix(w, temp_dq, ...)` adapter: EXL2 (:334-357) or GPTQ (:361-410) tensors."""
         if "q_weight" in w:
             w["q_scale_max"] *= prescale / 256
@@ -416,10 +428,10 @@ class ExtC:
             if "q_invperm" in w: w["q_invperm"] = w["q_invperm"].short()
             if "q_group_map" not in w:
                 w["q_group_map"] = self.make_group_map(w["q_groups"], w["q_weight"].shape[0]).to(w["q_groups"].device)
-            return self.make_q_matrix(w["q_weight"], w.get("q_perm", none_tensor), w.get("q_invperm", none_tensor),
-                                      w["q_scale"], w["q_scale_max"], w["q_groups"], w["q_group_map"],
-                                      none_tensor, none_tensor, none_tensor, w.get("bias", none_tensor),
-                                      temp_dq, max_dq_rows)
+            mk = self.make_q_matrix_split if split else self.make_q_matrix
+            return mk(w["q_weight"], w.get("q_perm", none_tensor), w.get("q_invperm", none_tensor),
+                      w["q_scale"], w["q_scale_max"], w["q_groups"], w["q_group_map"],
+                      none_tensor, none_tensor, none_tensor, w.get("bias", none_tensor), temp_dq, max_dq_rows)
         elif "qweight" in w:
             if prescale != 1: w["scales"] *= prescale
             if w["scales"].dtype == torch.float: w["scales"] = w["scales"].half()

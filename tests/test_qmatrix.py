@@ -133,6 +133,33 @@ def test_gemm_many_rows_staging_route(be, m, monkeypatch):
     be.ext.free_q_matrix(h)
 
 
+def test_make_q_matrix_split_column_shards(be):
+    """Tensor-parallel sharding along the output features (tensor_p.py -> make_q_matrix_split, ext_qmatrix.cpp:113-187):
+    handles over column slices reproduce the matching columns of the full product, and reconstruct() of a shard is the
+    slice of the full reconstruct() bit for bit."""
+    k, n, spec = SPECS["mixed_5_4"]
+    t = OX.synth_exl2(k, n, spec, seed=31, act_order=True, bias=True)
+    ref = OX.exl2_reconstruct(t)
+    a = np.random.default_rng(32).standard_normal((3, k)).astype(np.float16)
+    want = OX.gemm_ref(a, ref, bias=t["bias"], exact=True)
+    from tests.util import exl2_to_torch
+    keep = []
+    for (c0, c1) in ((0, 32), (32, 64)):
+        ts = dict(t)
+        ts["q_weight"] = np.ascontiguousarray(t["q_weight"][:, c0:c1])
+        ts["q_scale"] = np.ascontiguousarray(t["q_scale"][:, c0 // 8:c1 // 8])
+        ts["bias"] = np.ascontiguousarray(t["bias"][c0:c1])
+        w = exl2_to_torch(be, ts); keep.append(w)
+        h = be.ext.make_q_matrix_from_dict(w, None, split=True)
+        out = torch.zeros((k, c1 - c0), dtype=torch.float16, device=be.device)
+        be.ext.reconstruct(h, out)
+        assert np.array_equal(be.n(out).view(np.uint16), ref[:, c0:c1].view(np.uint16))
+        c = torch.zeros((3, c1 - c0), dtype=torch.float16, device=be.device)
+        be.ext.gemm_half_q_half(be.t(a), h, c)
+        assert np.all(np.abs(be.n(c).astype(np.float64) - want[:, c0:c1]) <= half_tol(want[:, c0:c1], k))
+        be.ext.free_q_matrix(h)
+
+
 def test_gemm_bias(be):
     k, n, spec = SPECS["b4_g128"]
     t, ref, w, h = make_exl2(be, k, n, spec, seed=7, bias=True)
