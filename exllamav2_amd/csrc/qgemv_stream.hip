@@ -281,7 +281,7 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
         {
             const u8* pk = h.pack;
             const int skip = lds_stage ? 0 : (int)(h.pack_cg_off >> 4);
-            dma_units16([&](int u) { return (const void*)(pk + ((size_t)(skip + u) << 4)); }, smem + h.lds_perm_off + ((size_t)skip << 4),
+            dma_units16([&](int u) { return (const void*)(pk + ((size_t)(skip + u) << 4)); }, lds_stage ? smem + h.lds_perm_off : smem + h.lds_cg_off,
                         (int)h.pack_units - skip, wv, nw, lane, 1 % nw);
         }
         // scale (and GPTQ zero-point) tables of this workgroup's tiles: contiguous in the make-time [tile][G][16] layout
@@ -546,7 +546,7 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
             u32 a_bytes = align16s((u32)M * (m.K + 8) * 2);
             const u32 red_bytes = (u32)(TPW * S) * 16 * 16 * 4;
             if (a_bytes < red_bytes) a_bytes = red_bytes;
-            const u32 t = a_bytes + align16s((u32)TPW * m.G * 32) * (gptq ? 2 : 1) + 64 + 16 * 16 * 4 + m.pack_units * 16;
+            const u32 t = a_bytes + align16s((u32)TPW * m.G * 32) * (gptq ? 2 : 1) + 64 + 16 * 16 * 4 + (m.pack_units * 16 - m.pack_cg_off);
             if (t > worst) worst = t;
         }
         if (worst <= 160 * 1024 || TPW == 1) break;
@@ -587,16 +587,23 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
         h.lds_scale_off = total;  total += align16s((u32)TPW * m.G * 32);
         h.lds_zp_off = total;     total += gptq ? align16s((u32)TPW * m.G * 32) : 0;
         h.lds_rmf_off = total;    total += 64 + 16 * 16 * 4;
-        h.lds_perm_off = total;   total += m.pack_units * 16;               // pack image: [q_perm][chunk -> group map]
-        h.lds_cg_off = h.lds_perm_off + m.pack_cg_off;
         {
+            // rows staged through LDS: the whole pack image [q_perm][chunk -> group map] + raw rows; many-rows route (gather
+            // from global memory): only the chunk -> group map part of the pack lives in LDS
             const u32 raw = row_bytes + (two ? row_bytes : (j.a_mode == A_RMSNORM ? align16s((u32)m.K * 2) : 0));
-            if (total + raw <= 160 * 1024 && !no_lds_stage)
+            if (total + m.pack_units * 16 + raw <= 160 * 1024 && !no_lds_stage)
             {
+                h.lds_perm_off = total;   total += m.pack_units * 16;
+                h.lds_cg_off = h.lds_perm_off + m.pack_cg_off;
                 h.lds_rawx_off = total;   total += row_bytes;
                 h.lds_raw2_off = total;   total += two ? row_bytes : (j.a_mode == A_RMSNORM ? align16s((u32)m.K * 2) : 0);
             }
-            else { h.lds_rawx_off = 0; h.lds_raw2_off = 0; }                          // gather from global memory instead
+            else
+            {
+                h.lds_perm_off = 0;
+                h.lds_cg_off = total;     total += m.pack_units * 16 - m.pack_cg_off;
+                h.lds_rawx_off = 0; h.lds_raw2_off = 0;
+            }
         }
         if (total > lds) lds = total;
 
