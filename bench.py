@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--cache", default="fp16", choices=["fp16", "q4"], help="KV cache type (q4: ExLlamaV2Cache_Q4)")
     p.add_argument("--no-prefill", action="store_true", help="skip the extra prefill measurement (BASELINE configs[2])")
+    p.add_argument("--batch", type=int, default=1, help="sequences decoded together (BASELINE configs[4]: 16)")
     return p.parse_args()
 
 
@@ -48,6 +49,8 @@ def make_cfg(name: str, max_seq_len: int):
         return ExLlamaV2Config.llama2_7b(max_seq_len=max_seq_len, max_input_len=256)
     if name == "llama2-70b":
         return ExLlamaV2Config.llama2_70b(max_seq_len=max_seq_len, max_input_len=256)
+    if name == "mixtral-8x7b":
+        return ExLlamaV2Config.mixtral_8x7b(max_seq_len=max_seq_len, max_input_len=256, max_batch_size=16)
     if name == "tinyllama":
         return ExLlamaV2Config.tinyllama_1b(max_input_len=256)
     if name == "tiny":
@@ -215,21 +218,21 @@ def main():
         t_load = time.perf_counter() - t_load
         if args.cache == "q4":
             from exllamav2_amd.cache import ExLlamaV2Cache_Q4
-            cache = ExLlamaV2Cache_Q4(model, batch_size=1, max_seq_len=max_seq)
+            cache = ExLlamaV2Cache_Q4(model, batch_size=args.batch, max_seq_len=max_seq)
         else:
-            cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=max_seq)
-        dec = GreedyGraphDecoder(model, cache, batch_size=1)
+            cache = ExLlamaV2Cache(model, batch_size=args.batch, max_seq_len=max_seq)
+        dec = GreedyGraphDecoder(model, cache, batch_size=args.batch)
         if not args.no_graph:
             dec.capture()
         # clock ramp: a GPU that has been idle (fresh box) runs its first few hundred milliseconds ~15 % slow; this untimed
         # stretch is part of set-up, the W warm-up steps below are still run and not timed
-        dec.reset(torch.tensor([1]), 0)
+        dec.reset(torch.tensor([1] * args.batch), 0)
         t_ramp = time.perf_counter()
         while time.perf_counter() - t_ramp < 4.0:
-            dec.reset(torch.tensor([1]), 0)
+            dec.reset(torch.tensor([1] * args.batch), 0)
             dec.run(64, use_graph=not args.no_graph)
             torch.cuda.synchronize()
-        dec.reset(torch.tensor([1]), args.ctx)                 # KV of the first `ctx` positions = resident (zeros)
+        dec.reset(torch.tensor([1] * args.batch), args.ctx)     # KV of the first `ctx` positions = resident (zeros)
         dec.run(args.warmup, use_graph=not args.no_graph)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -240,6 +243,11 @@ def main():
         assert int(dec.cache_seqlens[0]) == args.ctx + args.warmup + args.steps
         assert int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab_size
 
+        if getattr(cfg, "num_experts", 0) or args.batch != 1:
+            # MoE / batched runs: headline rate only (the q_gemm roofline figure is defined on configs[1])
+            result = {"value": args.batch * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load}
+            dec.free()
+            return finish(args, cfg, result, rank, world, n_gpus, device, dist)
         gemv_ms, launches, gemv_bytes = time_gemv_calls(model, dec)
         kv_bytes = 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2 * (args.ctx + args.warmup + args.steps // 2)
         achieved = gemv_bytes / (gemv_ms * 1e-3) / 1e9
@@ -256,25 +264,29 @@ def main():
         }
         dec.free()
 
+    return finish(args, cfg, result, rank, world, n_gpus, device, dist)
+
+
+def finish(args, cfg, result, rank, world, n_gpus, device, dist):
     if rank == 0:
         out = {
-            "metric": "decode tokens/s, Llama-2-7B EXL2 4.0bpw, bs=1 greedy" if args.model == "llama2-7b"
-                      else f"decode tokens/s, {args.model} EXL2 {args.recipe}, bs=1 greedy",
+            "metric": "decode tokens/s, Llama-2-7B EXL2 4.0bpw, bs=1 greedy" if (args.model == "llama2-7b" and args.batch == 1)
+                      else f"decode tokens/s, {args.model} EXL2 {args.recipe}, bs={args.batch} greedy",
             "value": round(result["value"], 2), "unit": "tokens/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(result["ms_per_step"], 4), "higher_is_better": True,
             "scaling": "weak",
             # the reference's own published figure for THIS model/metric (README.md:71, RTX 4090)
-            "vs_baseline": round(result["value"] / 211.0, 3) if (args.model == "llama2-7b" and n_gpus == 1) else None,
+            "vs_baseline": round(result["value"] / 211.0, 3) if (args.model == "llama2-7b" and n_gpus == 1 and args.batch == 1) else None,
             "baseline_ref": "211 tokens/s, Llama2 7B EXL2 4.0bpw, RTX 4090 (reference README.md:71)",
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{args.model} EXL2 {args.recipe} (synthetic weights, act-order), greedy decode, "
-                                   f"bs=1 per sequence, ctx {args.ctx}+{args.warmup}..+{args.steps}, {args.cache.upper()} KV cache, "
+                                   f"bs={args.batch}, ctx {args.ctx}+{args.warmup}..+{args.steps}, {args.cache.upper()} KV cache, "
                                    f"whole step in one HIP graph",
                        "parallelism": "single GPU" if n_gpus == 1 else f"layer-split pipeline x{n_gpus}, {n_gpus} sequences in flight"},
         }
         for k in ("roofline", "load_s"):
             if k in result: out[k] = result[k]
-        if not args.no_prefill and n_gpus == 1 and args.model == "llama2-7b":
+        if not args.no_prefill and n_gpus == 1 and args.model == "llama2-7b" and args.batch == 1:
             try:
                 out["prefill"] = prefill_rate(args.model, args.recipe, device)
             except Exception as e:  # informational; never lose the headline number
@@ -288,6 +300,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
 
 
 if __name__ == "__main__":

@@ -20,6 +20,8 @@ class ExLlamaV2Config:
     max_batch_size: int = 1
     max_input_len: int = 2048               # chunk size of forward (config.py:196, model.py:833)
     arch: str = "llama"
+    num_experts: int = 0                    # > 0: Mixtral-style sparse MLP (moe_mlp.py), experts per token below
+    num_experts_per_token: int = 2
 
     @staticmethod
     def llama2_7b(**kw):
@@ -34,6 +36,12 @@ class ExLlamaV2Config:
     def llama2_70b(**kw):
         return ExLlamaV2Config(hidden_size=8192, intermediate_size=28672, num_hidden_layers=80, num_attention_heads=64,
                                num_key_value_heads=8, head_dim=128, **kw)
+
+    @staticmethod
+    def mixtral_8x7b(**kw):
+        return ExLlamaV2Config(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+                               num_key_value_heads=8, head_dim=128, vocab_size=32000, num_experts=8,
+                               num_experts_per_token=2, arch="mixtral", **kw)
 
     @staticmethod
     def tiny_test(**kw):

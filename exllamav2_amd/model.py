@@ -14,6 +14,7 @@ from .config import ExLlamaV2Config
 from .ext import ext_c, none_tensor
 from .linear import ExLlamaV2Linear
 from .mlp import ExLlamaV2MLP
+from .moe_mlp import ExLlamaV2MoEMLP
 from .rmsnorm import ExLlamaV2RMSNorm
 
 
@@ -71,7 +72,10 @@ class ExLlamaV2:
         for local_idx, i in enumerate(self.layer_ids):
             key = f"model.layers.{i}"
             attn = ExLlamaV2Attention(self, key, local_idx).load(ck)
-            mlp = ExLlamaV2MLP(self, key, local_idx).load(ck)
+            if getattr(cfg, "num_experts", 0):
+                mlp = ExLlamaV2MoEMLP(self, key, local_idx, cfg.num_experts, cfg.num_experts_per_token).load(ck)
+            else:
+                mlp = ExLlamaV2MLP(self, key, local_idx).load(ck)
             self.layers.append((attn, mlp))
             self.modules += [attn, mlp]
         vpad = (cfg.vocab_size + 31) // 32 * 32

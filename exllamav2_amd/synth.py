@@ -20,6 +20,11 @@ RECIPES = {
     },
     "4.0bpw_plain": {k: ([4], [1.0], 128) for k in
                      ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")} | {"lm_head": ([6], [1.0], 128)},
+    "3.5bpw": {
+        "q_proj": ([4, 3], [0.5, 0.5], 128), "k_proj": ([4, 3], [0.5, 0.5], 128), "v_proj": ([4, 3], [0.6, 0.4], 64),
+        "o_proj": ([4, 3], [0.5, 0.5], 128), "gate_proj": ([4, 3], [0.5, 0.5], 128), "up_proj": ([4, 3], [0.5, 0.5], 64),
+        "down_proj": ([4, 3], [0.6, 0.4], 128), "lm_head": ([6], [1.0], 128),
+    },
     "2.5bpw": {
         "q_proj": ([3, 2], [0.1, 0.9], 64), "k_proj": ([3, 2], [0.1, 0.9], 64), "v_proj": ([4, 3], [0.1, 0.9], 128),
         "o_proj": ([3, 2], [0.1, 0.9], 64), "gate_proj": ([3, 2], [0.1, 0.9], 64), "up_proj": ([3, 2], [0.3, 0.7], 64),
@@ -96,10 +101,19 @@ def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_ord
         ck[f"{p}.self_attn.k_proj"] = synth_linear(h, kvd, rec["k_proj"], device, gen, s_attn, act_order)
         ck[f"{p}.self_attn.v_proj"] = synth_linear(h, kvd, rec["v_proj"], device, gen, s_attn, act_order)
         ck[f"{p}.self_attn.o_proj"] = synth_linear(qd, h, rec["o_proj"], device, gen, 0.5 / math.sqrt(qd), act_order)
-        ck[f"{p}.mlp.gate_proj"] = synth_linear(h, inter, rec["gate_proj"], device, gen, s_attn, act_order)
-        ck[f"{p}.mlp.up_proj"] = synth_linear(h, inter, rec["up_proj"], device, gen, s_attn, act_order)
-        # the reference folds down_proj's act-order into gate/up at load -> identity perm here
-        ck[f"{p}.mlp.down_proj"] = synth_linear(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
+        if getattr(cfg, "num_experts", 0):
+            # Mixtral-style sparse MLP (moe_mlp.py:25-133): experts w1 (gate), w3 (up), w2 (down) + fp16 router
+            for e in range(cfg.num_experts):
+                q = f"{p}.block_sparse_moe.experts.{e}"
+                ck[f"{q}.w1"] = synth_linear(h, inter, rec["gate_proj"], device, gen, s_attn, act_order)
+                ck[f"{q}.w3"] = synth_linear(h, inter, rec["up_proj"], device, gen, s_attn, act_order)
+                ck[f"{q}.w2"] = synth_linear(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
+            ck[f"{p}.block_sparse_moe.gate"] = (torch.randn(cfg.num_experts, h, device=device, generator=gen) * s_attn).half()
+        else:
+            ck[f"{p}.mlp.gate_proj"] = synth_linear(h, inter, rec["gate_proj"], device, gen, s_attn, act_order)
+            ck[f"{p}.mlp.up_proj"] = synth_linear(h, inter, rec["up_proj"], device, gen, s_attn, act_order)
+            # the reference folds down_proj's act-order into gate/up at load -> identity perm here
+            ck[f"{p}.mlp.down_proj"] = synth_linear(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
         ck[f"{p}.input_layernorm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
         ck[f"{p}.post_attention_layernorm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
     if with_embed:

@@ -79,3 +79,32 @@ def test_moe_mlp_forward(be, rows):
     be.ext.free_q_moe_mlp(moe)
     for hs in handles.values():
         for h in hs: be.ext.free_q_matrix(h)
+
+
+def test_moe_model_forward(be):
+    """Mixtral-style model through the ordinary ExLlamaV2 loop (config.num_experts > 0): prefill + decode run, logits are
+    finite, two identical sequences in a batch produce identical rows, and the sparse MLP of layer 0 applied by hand to
+    the same input equals what the model computed (the model adds nothing around the module)."""
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.synth import synth_checkpoint
+    from exllamav2_amd.model import ExLlamaV2
+    from exllamav2_amd.cache import ExLlamaV2Cache
+    cfg = ExLlamaV2Config(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+                          num_key_value_heads=1, head_dim=64, vocab_size=96, max_seq_len=256, max_input_len=32,
+                          max_batch_size=2, num_experts=4, num_experts_per_token=2, arch="mixtral")
+    ck = synth_checkpoint(cfg, be.device, recipe="3.5bpw", seed=7)
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    cache = ExLlamaV2Cache(model, batch_size=2)
+    ids = torch.from_numpy(np.random.default_rng(7).integers(0, cfg.vocab_size, size=(1, 6))).repeat(2, 1)
+    logits = be.n(model.forward(ids, cache))
+    assert np.all(np.isfinite(logits)) and np.array_equal(logits[0], logits[1])
+    nxt = torch.tensor([[5], [5]])
+    step = be.n(model.forward(nxt, cache))
+    assert np.all(np.isfinite(step)) and np.array_equal(step[0], step[1])
+    attn, moe = model.layers[0]
+    x = torch.from_numpy(np.random.default_rng(8).standard_normal((2, 1, cfg.hidden_size)).astype(np.float16)).to(be.device)
+    y1 = x.clone(); moe.forward(y1)
+    y2 = x.clone(); be.ext.q_moe_mlp_forward_(moe.q_handle, y2.view(2, -1))
+    assert torch.equal(y1, y2)
+    model.unload()
+
