@@ -433,9 +433,8 @@ struct RowStageArgs
     int K, lda, mode; float eps;
 };
 
-KERNEL void __launch_bounds__(256) stage_rows_kernel(const RowStageArgs s)
+DEV void stage_rows_body(const RowStageArgs& s, char* smem)
 {
-    DYN_SMEM(smem);
     const int r = bid_x();
     const int t = tid(), nt = nthreads(), lane = lane_id(), wv = wave_id(), nw = nt >> 6;
     f16* row = (f16*)smem;                                   // [K] transformed values in ORIGINAL order
@@ -500,6 +499,20 @@ KERNEL void __launch_bounds__(256) stage_rows_kernel(const RowStageArgs s)
     }
 }
 
+KERNEL void __launch_bounds__(256) stage_rows_kernel(const RowStageArgs s)
+{
+    DYN_SMEM(smem);
+    stage_rows_body(s, (char*)smem);
+}
+
+// the same for the matrices of a fused launch (blockIdx.y = matrix): one launch ahead of the phased decode kernel
+struct RowStageMulti { RowStageArgs s[MAX_FUSED_MATS]; };
+KERNEL void __launch_bounds__(256) stage_rows_multi_kernel(const RowStageMulti a)
+{
+    DYN_SMEM(smem);
+    stage_rows_body(a.s[bid_y()], (char*)smem);
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------------------
 
 // per-device scratch for the packed-order activations (grow-only; never grown while a stream is capturing)
@@ -525,6 +538,47 @@ static int stage_scratch(size_t bytes, void* stream, f16** out)
         g_stage_bytes[dev] = bytes;
     }
     *out = g_stage_buf[dev];
+    return EXL2_OK;
+}
+
+// Pre-pass for the phased decode kernel (qgemv_stream.hip): rows of every job in its packed K order, into the per-device
+// scratch; out[i] = where job i's [M, K_i] rows went.  A plain, unpermuted input is used in place (out[i] = a, ld = lda).
+int stage_rows_for_decode(const GemvJob* jobs, int n_jobs, int M, void* stream, const f16** out, int* out_ld)
+{
+    static bool attr = false;
+    if (!attr)
+    {
+        (void)hipFuncSetAttribute((const void*)stage_rows_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    size_t total = 0;
+    int k_max = 0, n_staged = 0;
+    for (int i = 0; i < n_jobs; i++)
+    {
+        const GemvJob& j = jobs[i];
+        if (j.a_mode == A_PLAIN && !j.m.perm) continue;
+        EXL2_REQUIRE((size_t)j.m.K * 2 + 64 <= 150 * 1024, "q_gemm: K = %d too large for the row pre-pass", j.m.K);
+        total += (size_t)M * j.m.K * 2;
+        if (j.m.K > k_max) k_max = j.m.K;
+        n_staged++;
+    }
+    f16* stage = nullptr;
+    if (n_staged) { const int rc = stage_scratch(total, stream, &stage); if (rc) return rc; }
+    RowStageMulti ra;
+    memset(&ra, 0, sizeof(ra));
+    int n = 0;
+    size_t off = 0;
+    for (int i = 0; i < n_jobs; i++)
+    {
+        const GemvJob& j = jobs[i];
+        if (j.a_mode == A_PLAIN && !j.m.perm) { out[i] = j.a; out_ld[i] = j.lda; continue; }
+        RowStageArgs& s = ra.s[n++];
+        s.a = j.a; s.a2 = j.a2; s.norm_w = j.norm_w; s.perm = j.m.perm; s.out = stage + off; s.K = j.m.K; s.lda = j.lda;
+        s.mode = j.a_mode; s.eps = j.norm_eps;
+        out[i] = stage + off; out_ld[i] = j.m.K;
+        off += (size_t)M * j.m.K;
+    }
+    if (n) LAUNCH(stage_rows_multi_kernel, dim3((unsigned)M, (unsigned)n, 1), dim3(256), (size_t)k_max * 2 + 64, stream, ra);
     return EXL2_OK;
 }
 

@@ -24,6 +24,7 @@
 //     v_mfma_f32_16x16x32_f16, group scale applied to the fp32 partial sums (qgemv_common.h); bias / residual / MoE
 //     routing weight in the epilogue.
 #include "qgemv_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -447,6 +448,183 @@ KERNEL void __launch_bounds__(1024) qgemv_stream_kernel(const StreamArgs args)
     TRACE_POINT(8);
 }
 
+// ---- many rows x large K: phased kernel ---------------------------------------------------------------------------------
+//
+// When M rows of K activations do not fit in LDS next to their raw copy (M = 5..16 at K >= 4096, e.g. a batch of 16
+// sequences decoding), the activations are brought into each matrix' packed K order ONCE by a row pre-pass
+// (stage_rows_for_decode, qgemm_prefill.hip: norm / activation / act-order permutation, M small workgroups) instead of
+// once per workgroup, and this kernel walks K in phases: LDS-DMA the [M, rows] slab of the packed rows (contiguous
+// row segments, one round trip out of L2), stream the matching super-chunks of every tile, next slab.  The partial sums
+// stay in registers across phases; everything else (tile16 stream, S-way K split, fixed-order combine, epilogue) is the
+// streaming kernel's.
+struct PhasedArgs
+{
+    GemvJob job[MAX_FUSED_MATS];
+    const f16* ap[MAX_FUSED_MATS];      // packed-order rows [M, ap_ld]
+    int ap_ld[MAX_FUSED_MATS];
+    u32 lds_scale_off[MAX_FUSED_MATS], lds_zp_off[MAX_FUSED_MATS], lds_cg_off[MAX_FUSED_MATS];
+    int n_jobs, M, S, TPW;
+    int items_max;                      // super-chunks of K per phase that fit the slab
+};
+
+template <int BITS, bool GPTQ>
+DEV void phase_items(const QRun& run, const QMatDev& m, int tile, int it0, int n, int r, int S, const PhaseCtx& ph, int lane, f32x4& acc)
+{
+    const int i0 = it0 + (int)(((long long)r * n) / S), i1 = it0 + (int)(((long long)(r + 1) * n) / S);
+    const u32* ptr0 = (run.in_tail ? m.tail : m.qw) + run.base_word + (size_t)tile * run.tile_stride + (size_t)i0 * (64u * BITS);
+    LaneWords<BITS> b[MINOR_DEPTH];
+    stream_items<BITS, GPTQ, MINOR_DEPTH>(ptr0, i1 - i0, ((int)run.k_base >> 5) + 4 * i0, ph, lane, acc, b, false);
+}
+
+template <int BITS, bool GPTQ>
+DEV void phase_tail(const QRun& run, const QMatDev& m, int tile, const PhaseCtx& ph, int lane, f32x4& acc)
+{
+    LaneWords<BITS> w;
+    load_lane_words<BITS>(m.tail + run.base_word + (size_t)tile * run.tile_stride, lane, w);
+    gemv_super<BITS, GPTQ, false>(w, ph, (int)run.k_base >> 5, (int)run.nvalid_last, lane, acc);
+}
+
+template <bool GPTQ>
+KERNEL void __launch_bounds__(1024) qgemv_phased_kernel(const PhasedArgs args)
+{
+    DYN_SMEM(smem);
+    const int ji = bid_y();
+    const GemvJob& job = args.job[ji];
+    const QMatDev& m = job.m;
+    const int TPW = args.TPW, S = args.S, M = args.M;
+    const int n_tiles = m.N / TILE_N;
+    if (bid_x() * TPW >= n_tiles) return;
+    if (job.r_weights)
+    {
+        u32 any = 0;
+        for (int rr = 0; rr < M; rr++) any |= (u32)as_u16(job.r_weights[(size_t)rr * job.r_stride]);
+        if (uniform(any) == 0) return;                      // q_gemm_kernel.cuh:189-200
+    }
+    const int t = tid(), nt = nthreads(), lane = lane_id();
+    const int wv = uniform(wave_id()), nw = nt >> 6;
+    const int gidx = wv / S, r = wv - gidx * S;
+    const int tile_base = bid_x() * TPW;
+    int tile = tile_base + gidx;
+    if (tile >= n_tiles) tile = n_tiles - 1;                  // idle slot: compute on a valid tile, never store
+    const int G = m.G;
+
+    f16* a_lds  = (f16*)smem;
+    f16* sc_all = (f16*)(smem + args.lds_scale_off[ji]);
+    f16* zp_all = (f16*)(smem + args.lds_zp_off[ji]);
+    u16* cg_lds = (u16*)(smem + args.lds_cg_off[ji]);
+    float* red  = (float*)smem;
+
+    // tables: chunk -> group map (tail of the make-time pack) and this workgroup's [tile][G][16] scale slices
+    {
+        const u8* pk = m.pack;
+        const int skip = (int)(m.pack_cg_off >> 4);
+        dma_units16([&](int u) { return (const void*)(pk + ((size_t)(skip + u) << 4)); }, cg_lds, (int)m.pack_units - skip, wv, nw, lane);
+        const int nt_here = min(TPW, n_tiles - tile_base);
+        const f16* st = m.sc_tab + (size_t)tile_base * G * 16;
+        dma_units16([&](int u) { return (const void*)(st + (size_t)u * 8); }, sc_all, nt_here * G * 2, wv, nw, lane, 1 % nw);
+        if constexpr (GPTQ)
+        {
+            const f16* zt = m.zp_tab + (size_t)tile_base * G * 16;
+            dma_units16([&](int u) { return (const void*)(zt + (size_t)u * 8); }, zp_all, nt_here * G * 2, wv, nw, lane, 2 % nw);
+        }
+    }
+
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    PhaseCtx ph;
+    ph.sc_lds = sc_all + (size_t)gidx * G * 16; ph.zp_lds = zp_all + (size_t)gidx * G * 16;
+    ph.cg_lds = cg_lds; ph.a_lds = a_lds; ph.M = M;
+    const f16* ap = args.ap[ji];
+    const int ap_ld = args.ap_ld[ji];
+    bool first = true;
+    for (int i = 0; i < m.n_runs; i++)
+    {
+        const QRun& run = m.runs[i];
+        const bool full = run.nvalid_last == 4;
+        const int F = full ? (int)run.n_super : 1;
+        const int n_ph = (F + args.items_max - 1) / args.items_max;
+        const int ipp = (F + n_ph - 1) / n_ph;
+        for (int it0 = 0; it0 < F; it0 += ipp)
+        {
+            const int n = min(ipp, F - it0);
+            const int k0 = (int)run.k_base + it0 * SUPER_ROWS;
+            const int rows = full ? n * SUPER_ROWS : (int)run.nvalid_last * 32;
+            const int a_stride = rows + 8;
+            if (!first) block_sync_lds();                    // the previous slab's readers are done
+            first = false;
+            const int upr = rows >> 3;
+            for (int rr = 0; rr < M; rr++)
+                dma_units16([&](int u) { return (const void*)(ap + (size_t)rr * ap_ld + k0 + (size_t)u * 8); },
+                            a_lds + (size_t)rr * a_stride, upr, wv, nw, lane, rr % nw);
+            wait_vmcnt_le<0>();
+            block_sync_lds();
+            ph.a_stride = a_stride; ph.phase_k0 = k0;
+            if (!full)
+            {
+                if (r != 0) continue;                         // partial super-chunk: the split's first wave takes it
+                if constexpr (GPTQ) phase_tail<4, true>(run, m, tile, ph, lane, acc);
+                else switch (run.bits)
+                {
+                    case 4: phase_tail<4, false>(run, m, tile, ph, lane, acc); break;
+                    case 8: phase_tail<8, false>(run, m, tile, ph, lane, acc); break;
+                    case 6: phase_tail<6, false>(run, m, tile, ph, lane, acc); break;
+                    case 5: phase_tail<5, false>(run, m, tile, ph, lane, acc); break;
+                    case 3: phase_tail<3, false>(run, m, tile, ph, lane, acc); break;
+                    default: phase_tail<2, false>(run, m, tile, ph, lane, acc); break;
+                }
+                continue;
+            }
+            if constexpr (GPTQ) phase_items<4, true>(run, m, tile, it0, n, r, S, ph, lane, acc);
+            else switch (run.bits)
+            {
+                case 4: phase_items<4, false>(run, m, tile, it0, n, r, S, ph, lane, acc); break;
+                case 8: phase_items<8, false>(run, m, tile, it0, n, r, S, ph, lane, acc); break;
+                case 6: phase_items<6, false>(run, m, tile, it0, n, r, S, ph, lane, acc); break;
+                case 5: phase_items<5, false>(run, m, tile, it0, n, r, S, ph, lane, acc); break;
+                case 3: phase_items<3, false>(run, m, tile, it0, n, r, S, ph, lane, acc); break;
+                default: phase_items<2, false>(run, m, tile, it0, n, r, S, ph, lane, acc); break;
+            }
+        }
+    }
+
+    // combine the S slices of every tile (fixed order) + epilogue: as in qgemv_stream_kernel
+    block_sync();
+    {
+        const int c = lane & 15, j = lane >> 4;
+        #pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int row = j * 4 + q;
+            if (row < M) red[(wv * 16 + row) * 16 + c] = acc[q];
+        }
+    }
+    block_sync();
+    for (int idx = t; idx < TPW * M * 16; idx += nt)
+    {
+        const int slot = idx / (M * 16);
+        const int rem = idx - slot * (M * 16);
+        const int row = rem >> 4, c = rem & 15;
+        const int tl = tile_base + slot;
+        if (tl >= n_tiles) continue;
+        float v = 0.0f;
+        for (int w = 0; w < S; w++) v += red[((slot * S + w) * 16 + row) * 16 + c];
+        const int n = tl * 16 + c;
+        bool skip = false;
+        if (job.r_weights)
+        {
+            const f16 rw = job.r_weights[(size_t)row * job.r_stride];
+            if (as_u16(rw) == 0) skip = true;
+            if (job.mul_r_weights) v *= (float)rw;
+        }
+        if (!skip)
+        {
+            if (m.bias) v += (float)m.bias[n];
+            f16* cp = job.c + (size_t)row * job.ldc + (job.c_invperm ? (int)job.c_invperm[n] : n);
+            if (job.c_mode == C_ACCUM) v += (float)*cp;
+            *cp = (f16)v;
+        }
+    }
+}
+
 // ---- host --------------------------------------------------------------------------------------------------------------
 
 #ifdef EXL2_TRACE
@@ -486,6 +664,72 @@ static void launch_variant(const StreamArgs& args, dim3 grid, dim3 block, u32 ld
 }
 
 static inline bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
+
+int stage_rows_for_decode(const GemvJob* jobs, int n_jobs, int M, void* stream, const f16** out, int* out_ld);   // qgemm_prefill.hip
+
+// slab budget of the phased kernel (bytes of LDS for the [M, rows] activations of one phase)
+#define PHASED_SLAB_BYTES (136u * 1024u)
+
+static int qgemv_phased_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, int TPW, int S, void* stream)
+{
+    PhasedArgs args;
+    memset(&args, 0, sizeof(args));
+    int items_max = (int)(PHASED_SLAB_BYTES / ((u32)M * 2) - 8) / SUPER_ROWS;
+    const char* fi = getenv("EXL2_GEMV_PHASE_ITEMS");       // tests: small slabs = many phases at small K
+    if (fi && atoi(fi) > 0 && atoi(fi) < items_max) items_max = atoi(fi);
+    if (items_max < 1) return 1;
+    for (int i = 0; i < n_jobs; i++)
+        if ((jobs[i].m.K & 7) || (jobs[i].a_mode == A_PLAIN && !jobs[i].m.perm && (jobs[i].lda & 7))) return 1;
+    // tables must fit beside the slab: fewer tiles per workgroup for matrices with many groups
+    u32 lds = 0;
+    for (;;)
+    {
+        lds = 0;
+        for (int i = 0; i < n_jobs; i++)
+        {
+            const QMatDev& m = jobs[i].m;
+            int f_max = 1;
+            for (int q = 0; q < m.n_runs; q++) if (m.runs[q].nvalid_last == 4 && (int)m.runs[q].n_super > f_max) f_max = (int)m.runs[q].n_super;
+            const int n_ph = (f_max + items_max - 1) / items_max;
+            const int ipp = (f_max + n_ph - 1) / n_ph;
+            u32 total = align16s((u32)M * (u32)(ipp * SUPER_ROWS + 8) * 2);
+            const u32 red_bytes = (u32)(TPW * S) * 16 * 16 * 4;
+            if (total < red_bytes) total = red_bytes;
+            args.lds_scale_off[i] = total; total += align16s((u32)TPW * m.G * 32);
+            args.lds_zp_off[i] = total;    total += gptq ? align16s((u32)TPW * m.G * 32) : 0;
+            args.lds_cg_off[i] = total;    total += m.pack_units * 16 - m.pack_cg_off;
+            if (total > lds) lds = total;
+        }
+        if (lds <= 160 * 1024) break;
+        if (TPW > 1) { TPW = (TPW + 1) / 2; S = 16 / TPW; continue; }
+        if (items_max > 1) { items_max = (items_max * 3) / 4 > 0 ? (items_max * 3) / 4 : 1; continue; }
+        return 1;
+    }
+    {
+        const int rc = stage_rows_for_decode(jobs, n_jobs, M, stream, args.ap, args.ap_ld);
+        if (rc) return rc;
+    }
+    int blk_max = 0;
+    for (int i = 0; i < n_jobs; i++)
+    {
+        args.job[i] = jobs[i];
+        const int blks = (jobs[i].m.N / TILE_N + TPW - 1) / TPW;
+        if (blks > blk_max) blk_max = blks;
+    }
+    args.n_jobs = n_jobs; args.M = M; args.S = S; args.TPW = TPW; args.items_max = items_max;
+    static bool attr = false;
+    if (!attr)
+    {
+        (void)hipFuncSetAttribute((const void*)qgemv_phased_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)qgemv_phased_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    dim3 grid((unsigned)blk_max, (unsigned)n_jobs, 1), block((unsigned)(TPW * S * 64), 1, 1);
+    if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_gemm route: phased M=%d jobs=%d TPW=%d S=%d items=%d lds=%u\n", M, n_jobs, TPW, S, items_max, lds);
+    if (gptq) LAUNCH((qgemv_phased_kernel<true>), grid, block, lds, stream, args);
+    else      LAUNCH((qgemv_phased_kernel<false>), grid, block, lds, stream, args);
+    return 0;
+}
 
 // returns 0 when launched, 1 when this kernel does not apply (caller falls back to the generic kernel), < 0 on error
 int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream)
@@ -535,6 +779,28 @@ int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* strea
     const char* ft = getenv("EXL2_GEMV_TPW");
     if (ft && atoi(ft) > 0) TPW = atoi(ft);
     if (TPW * S > 16) TPW = 16 / S > 0 ? 16 / S : 1;
+    {
+        // more than a few rows whose raw + staged copies do not fit in LDS: pre-pass + phased kernel
+        bool fits = true;
+        for (int i = 0; i < n_jobs; i++)
+        {
+            const GemvJob& j = jobs[i];
+            const QMatDev& m = j.m;
+            const u32 row_bytes = align16s((u32)M * m.K * 2);
+            const bool two = j.a_mode == A_SILU_MUL || j.a_mode == A_GELU_MUL;
+            const unsigned long long need = (unsigned long long)align16s((u32)M * (m.K + 8) * 2) + row_bytes
+                + (two ? row_bytes : (j.a_mode == A_RMSNORM ? align16s((u32)m.K * 2) : 0)) + (unsigned long long)m.pack_units * 16
+                + (unsigned long long)align16s((u32)m.G * 32) * (gptq ? 2 : 1) + 64 + 16 * 16 * 4;
+            if (need > 160 * 1024) fits = false;
+        }
+        const char* fp = getenv("EXL2_GEMV_PHASED");        // 0: never, 1: whenever M > 1 (tests), default: M > 4 and no fit
+        const int force = fp ? atoi(fp) : -1;
+        if (force != 0 && ((force == 1 && M > 1) || (M > 4 && !fits)))
+        {
+            const int rc = qgemv_phased_launch(jobs, n_jobs, M, gptq, TPW, S, stream);
+            if (rc <= 0) return rc;
+        }
+    }
     // many quantisation groups (small group size x large K): the per-tile scale tables may not fit for TPW tiles --
     // fewer tiles per workgroup (more workgroups, possibly a second round) still beats the generic kernel by far
     for (;;)

@@ -97,6 +97,25 @@ def test_prefill_sized_forward_equals_oracle(be, native):
     model.unload()
 
 
+def test_batch_decode_phased_route_equals_oracle(be, monkeypatch):
+    """A batch of 16 sequences decoding: every fused module GEMV (RMSNorm -> q/k/v, o, RMSNorm -> gate/up, act*up -> down
+    with the scatter epilogue) through the row pre-pass + phased kernel."""
+    monkeypatch.setenv("EXL2_GEMV_PHASED", "1")
+    monkeypatch.setenv("EXL2_GEMV_PHASE_ITEMS", "1")
+    cfg = tiny_cfg(num_hidden_layers=2)
+    model, oracle = build(be, cfg, seed=5)
+    cache = ExLlamaV2Cache(model, batch_size=16)
+    oracle.reset(16)
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, cfg.vocab_size, size=(16, 1))
+    for _ in range(3):
+        logits = model.forward(torch.from_numpy(ids), cache)
+        want = oracle.forward(ids)
+        check_logits(be.n(logits), want)
+        ids = np.argmax(want[:, -1], axis=-1)[:, None]
+    model.unload()
+
+
 def test_device_side_greedy_decode_paged(be):
     """The benchmark's decode loop (GreedyGraphDecoder, eager on the emulator / graph on the GPU)."""
     cfg = tiny_cfg()

@@ -133,6 +133,49 @@ def test_gemm_many_rows_staging_route(be, m, monkeypatch):
     be.ext.free_q_matrix(h)
 
 
+@pytest.mark.parametrize("name,m,items", [("mixed_all", 5, 1), ("mixed_all", 16, 2), ("mixed_5_4", 16, 2), ("long_runs", 9, 5),
+                                          ("b4_tail", 16, 1), ("long_runs", 16, 64)])
+def test_gemm_phased_route(be, name, m, items, monkeypatch):
+    """Batch-of-sequences decode (M = 5..16 rows at large K): row pre-pass into the packed K order + the phased kernel
+    (qgemv_stream.hip), forced here on small shapes with slabs of `items` super-chunks (several phases per section,
+    partial super-chunks as phases of their own)."""
+    monkeypatch.setenv("EXL2_GEMV_PHASED", "1")
+    monkeypatch.setenv("EXL2_GEMV_PHASE_ITEMS", str(items))
+    k, n, spec = SPECS[name]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=41, bias=True)
+    a = np.random.default_rng(42).standard_normal((m, k)).astype(np.float16)
+    c = torch.zeros((m, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    want = OX.gemm_ref(a, ref, bias=t["bias"], exact=True)
+    assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= half_tol(want, k))
+    # identity rows through the phased route reproduce reconstruct() bit for bit
+    if k <= 1024:
+        eye = np.eye(k, dtype=np.float16)
+        t2, ref2, w2, h2 = make_exl2(be, k, n, spec, seed=41, bias=False)
+        for r0 in range(0, k, 16):
+            c2 = torch.zeros((16, n), dtype=torch.float16, device=be.device)
+            be.ext.gemm_half_q_half(be.t(eye[r0:r0 + 16]), h2, c2)
+            assert np.array_equal(be.n(c2).view(np.uint16), ref2[r0:r0 + 16].view(np.uint16))
+        be.ext.free_q_matrix(h2)
+    be.ext.free_q_matrix(h)
+
+
+def test_gemm_phased_route_gptq(be, monkeypatch):
+    monkeypatch.setenv("EXL2_GEMV_PHASED", "1")
+    monkeypatch.setenv("EXL2_GEMV_PHASE_ITEMS", "1")
+    k, n, gs = 384, 48, 128
+    t = OX.synth_gptq(k, n, gs, seed=43, act_order=True)
+    ref = OX.gptq_reconstruct(t)
+    w = gptq_to_torch(be, t)
+    h = be.ext.make_q_matrix_from_dict(w, None)
+    a = np.random.default_rng(44).standard_normal((16, k)).astype(np.float16)
+    c = torch.zeros((16, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    want = OX.gemm_ref(a, ref, exact=True)
+    assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= half_tol(want, k))
+    be.ext.free_q_matrix(h)
+
+
 def test_make_q_matrix_split_column_shards(be):
     """Tensor-parallel sharding along the output features (tensor_p.py -> make_q_matrix_split, ext_qmatrix.cpp:113-187):
     handles over column slices reproduce the matching columns of the full product, and reconstruct() of a shard is the
