@@ -49,14 +49,21 @@ class ExLlamaV2Attention:
         Contiguous mode (attn.py:1017-1196): scalar `past_len`, cache viewed [b, max_seq_len, kvh, hd].
         Paged mode (attn.py:466-638): `cache_seqlens` int32 [b] + `block_table` int32 [b, pages] on the device,
         cache viewed [pages, 256, kvh, hd]; positions are read on the device (graph-capturable)."""
-        cfg, m, ext = self.model.config, self.model, self.ext
         b, q_len, _ = hidden_states.shape
+        rows = b * q_len
+        big = rows > ExLlamaV2Linear.LIB_GEMM_MIN_ROWS and not self.model.native_prefill
+        q, k, v = self._project_qkv(hidden_states, b, q_len, big)
+        attn_out = self._attend(q, k, v, cache, past_len, cache_seqlens, block_table, big)
+        return self._project_out(hidden_states, attn_out, b, q_len, big)
+
+    def _project_qkv(self, hidden_states, b: int, q_len: int, big: bool):
+        """Front half (q_attn_forward_1, q_attn.cu:153-317): RMSNorm + q/k/v projections into the scratch rows; RoPE is
+        applied later, inside the attention launch."""
+        cfg, m, ext = self.model.config, self.model, self.ext
         rows = b * q_len
         q = m.temp_q[:rows].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
         k = m.temp_k[:rows].view(b, q_len, cfg.num_key_value_heads, cfg.head_dim)
         v = m.temp_v[:rows].view(b, q_len, cfg.num_key_value_heads, cfg.head_dim)
-        paged = block_table is not None
-        big = rows > ExLlamaV2Linear.LIB_GEMM_MIN_ROWS and not m.native_prefill
         if big:
             # prefill-sized: unfused projections (reconstruct + library GEMM), reference forward_torch shape (attn.py:1198-)
             xn = m.temp_state[:rows]
@@ -67,6 +74,14 @@ class ExLlamaV2Attention:
         else:
             ext.q_attn_forward_1(self.q_handle, hidden_states, b, q_len, 0, none_tensor, q, k, v, m.sin, m.cos,
                                  apply_rope=False)
+        return q, k, v
+
+    def _attend(self, q, k, v, cache, past_len, cache_seqlens, block_table, big: bool):
+        """RoPE(q, new k) + KV append + attention over the (paged or contiguous, FP16 or Q4) cache -> attn_out rows."""
+        cfg, m, ext = self.model.config, self.model, self.ext
+        b, q_len = q.shape[0], q.shape[1]
+        rows = b * q_len
+        paged = block_table is not None
         if cache is None:
             raise RuntimeError("ExLlamaV2Attention.forward: a cache is required")
         attn_out = m.temp_attn[:rows].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
@@ -116,6 +131,12 @@ class ExLlamaV2Attention:
                 cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
             else:
                 cache.store_kv_state(self.layer_idx, b, past_len, q_len)
+        return attn_out
+
+    def _project_out(self, hidden_states, attn_out, b: int, q_len: int, big: bool):
+        """Back half (q_attn_forward_2, q_attn.cu:319-345): x += attn_out . Wo"""
+        ext = self.ext
+        rows = b * q_len
         if big:
             hidden_states.view(rows, -1).add_(self.o_proj.forward(attn_out.view(rows, -1)))
         else:
