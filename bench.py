@@ -40,6 +40,8 @@ def parse():
     p.add_argument("--cache", default="fp16", choices=["fp16", "q4"], help="KV cache type (q4: ExLlamaV2Cache_Q4)")
     p.add_argument("--no-prefill", action="store_true", help="skip the extra prefill measurement (BASELINE configs[2])")
     p.add_argument("--batch", type=int, default=1, help="sequences decoded together (BASELINE configs[4]: 16)")
+    p.add_argument("--parallel", default="pipeline", choices=["pipeline", "tp"],
+                   help="N > 1: layer-split pipeline (default, weak scaling) or tensor parallel (column shards + all-gather, strong scaling)")
     return p.parse_args()
 
 
@@ -207,7 +209,10 @@ def main():
     max_seq = max(2048, ((args.ctx + args.steps + args.warmup + 1 + 255) // 256) * 256)
     cfg = make_cfg(args.model, max_seq)
 
-    if n_gpus > 1:
+    if n_gpus > 1 and args.parallel == "tp":
+        from exllamav2_amd.tensor_p import run_tp_bench
+        result = run_tp_bench(cfg, args, rank, world, device)
+    elif n_gpus > 1:
         from exllamav2_amd.pipeline import run_layer_split_bench
         result = run_layer_split_bench(cfg, args, rank, world, device)
     else:
@@ -251,13 +256,16 @@ def main():
         gemv_ms, launches, gemv_bytes = time_gemv_calls(model, dec)
         kv_bytes = 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2 * (args.ctx + args.warmup + args.steps // 2)
         achieved = gemv_bytes / (gemv_ms * 1e-3) / 1e9
+        traffic_gb = pmc_traffic_gb(launches)
         result = {
             "value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load,
             "roofline": {
                 "bound": "hbm", "kernel": "qgemv_stream_kernel<false, MB> (all q_gemm launches of a decode step: fused q|k|v, o, fused gate|up, down per layer + head)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic_gb(launches),
-                "traffic_unit": "GB per decode step (PMC FETCH_SIZE x2, profiles/)", "bytes_per_step": gemv_bytes, "launches_per_step": launches,
+                "traffic": None if traffic_gb is None else round(traffic_gb * 1e9 / launches),
+                "traffic_unit": "HBM bytes per q_gemm launch (PMC FETCH_SIZE x2, profiles/*_pmc_summary.json; 4-bit layer launches)",
+                "algorithmic_bytes_per_launch": round(gemv_bytes / launches),
+                "traffic_per_step_GB": traffic_gb, "bytes_per_step": gemv_bytes, "launches_per_step": launches,
                 "avg_launch_us": round(gemv_ms * 1e3 / launches, 2),
                 "step_frac_of_weight_roofline": round((gemv_bytes + kv_bytes) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             },
@@ -274,7 +282,7 @@ def finish(args, cfg, result, rank, world, n_gpus, device, dist):
                       else f"decode tokens/s, {args.model} EXL2 {args.recipe}, bs={args.batch} greedy",
             "value": round(result["value"], 2), "unit": "tokens/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(result["ms_per_step"], 4), "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": result.get("scaling", "weak"),
             # the reference's own published figure for THIS model/metric (README.md:71, RTX 4090)
             "vs_baseline": round(result["value"] / 211.0, 3) if (args.model == "llama2-7b" and n_gpus == 1 and args.batch == 1) else None,
             "baseline_ref": "211 tokens/s, Llama2 7B EXL2 4.0bpw, RTX 4090 (reference README.md:71)",
@@ -282,9 +290,10 @@ def finish(args, cfg, result, rank, world, n_gpus, device, dist):
             "config": {"workload": f"{args.model} EXL2 {args.recipe} (synthetic weights, act-order), greedy decode, "
                                    f"bs={args.batch}, ctx {args.ctx}+{args.warmup}..+{args.steps}, {args.cache.upper()} KV cache, "
                                    f"whole step in one HIP graph",
-                       "parallelism": "single GPU" if n_gpus == 1 else f"layer-split pipeline x{n_gpus}, {n_gpus} sequences in flight"},
+                       "parallelism": "single GPU" if n_gpus == 1 else
+                                      result.get("parallelism", f"layer-split pipeline x{n_gpus}, {n_gpus} sequences in flight")},
         }
-        for k in ("roofline", "load_s"):
+        for k in ("roofline", "load_s", "weight_bytes_per_rank"):
             if k in result: out[k] = result[k]
         if not args.no_prefill and n_gpus == 1 and args.model == "llama2-7b" and args.batch == 1:
             try:

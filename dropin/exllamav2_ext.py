@@ -50,7 +50,7 @@ make_q_matrix_split = _e.make_q_matrix_split
 for _n in ("gemm_half_q_half_tp", "make_tp_context", "free_tp_context", "tp_broadcast", "tp_gather",
            "tp_cross_device_barrier", "tp_all_reduce", "tp_attn_forward_", "tp_attn_forward_paged_", "tp_mlp_forward_",
            "rms_norm_tp"):
-    globals()[_n] = _out_of_scope(_n, "tensor-parallel host-staged path: next row after the layer-split pipeline (SURVEY.md 8e)")
+    globals()[_n] = _out_of_scope(_n, "the reference's single-process, host-staged tensor-parallel bindings are not mirrored; tensor parallel here is one process per GPU over RCCL: exllamav2_amd/tensor_p.py (SURVEY.md 8e)")
 make_q_moe_mlp = _e.make_q_moe_mlp
 free_q_moe_mlp = _e.free_q_moe_mlp
 q_moe_mlp_forward_ = _e.q_moe_mlp_forward_

@@ -250,7 +250,6 @@ class ExLlamaV2TP(ExLlamaV2):
         """`ck` holds FULL tensors (every rank reads the same checkpoint, like the reference's loader); each module
         keeps only its column shards."""
         cfg = self.full_config
-        self.embed_tokens = ck.get("model.embed_tokens")
         self.layer_ids = list(range(cfg.num_hidden_layers) if layers is None else layers)
         for local_idx, i in enumerate(self.layer_ids):
             key = f"model.layers.{i}"
@@ -258,12 +257,32 @@ class ExLlamaV2TP(ExLlamaV2):
             mlp = TPMLP(self, key, local_idx).load(ck)
             self.layers.append((attn, mlp))
             self.modules += [attn, mlp]
+        self._load_ends(ck)
+        return self
+
+    def load_more(self, ck: dict, layer: int):
+        """Incremental load: one layer's full tensors at a time, so a rank never holds more than one unsharded layer
+        (70B at 2.5 bpw: 0.27 GB per layer instead of 22 GB)."""
+        key = f"model.layers.{layer}"
+        if not hasattr(self, "layer_ids"): self.layer_ids = []
+        local_idx = len(self.layers)
+        attn = TPAttention(self, key, local_idx).load(ck)
+        mlp = TPMLP(self, key, local_idx).load(ck)
+        self.layers.append((attn, mlp))
+        self.modules += [attn, mlp]
+        self.layer_ids.append(layer)
+        self._load_ends(ck)
+        return self
+
+    def _load_ends(self, ck: dict):
+        cfg = self.full_config
+        if "model.embed_tokens" in ck:
+            self.embed_tokens = ck["model.embed_tokens"]
         self.vocab_padded = self.tp.vocab_padded
         if "lm_head" in ck:
             self.norm = ExLlamaV2RMSNorm(self.ext, "model.norm", ck["model.norm"], cfg.norm_eps)
             self.lm_head = TPHead(self, ck["lm_head"])
         self.loaded = True
-        return self
 
 
 class TPGreedyDecoder:
@@ -305,3 +324,56 @@ class TPGreedyDecoder:
 
     def tokens(self, start: int, n: int) -> torch.Tensor:
         return self.history[:, start + 1:start + 1 + n]
+
+
+def run_tp_bench(cfg, args, rank: int, world: int, device):
+    """bench.py backend for `--gpus N --parallel tp`: ONE sequence (per batch row) decoded by all ranks together --
+    strong scaling (total work per token fixed, 1/N of the weight bytes per rank).  Eager launches: the step contains
+    collectives, so it is not captured into a HIP graph here."""
+    import time
+
+    from .cache import ExLlamaV2Cache, ExLlamaV2Cache_Q4
+    from .synth import synth_checkpoint
+    max_seq = max(2048, ((args.ctx + args.steps + args.warmup + 1 + 255) // 256) * 256)
+    cfg = dataclasses.replace(cfg, max_seq_len=max_seq)
+    t_load = time.perf_counter()
+    model = ExLlamaV2TP(cfg, rank, world, device=device)
+    # every rank draws the same full tensors (same seed) layer by layer and keeps only its shards
+    for i in range(cfg.num_hidden_layers):
+        ck = synth_checkpoint(cfg, device, recipe=args.recipe, seed=0, layers=[i], with_embed=(i == 0),
+                              with_head=(i == cfg.num_hidden_layers - 1))
+        _pad_head(ck, model.tp.vocab_padded)
+        model.load_more(ck, i)
+        del ck
+    torch.cuda.synchronize()
+    t_load = time.perf_counter() - t_load
+    cache_cls = ExLlamaV2Cache_Q4 if getattr(args, "cache", "fp16") == "q4" else ExLlamaV2Cache
+    cache = cache_cls(model, batch_size=args.batch, max_seq_len=max_seq)
+    dec = TPGreedyDecoder(model, cache, batch_size=args.batch)
+    dec.reset(torch.tensor([1] * args.batch), args.ctx)
+    dec.run(args.warmup)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    dec.run(args.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    toks = dec.tokens(args.ctx + args.warmup, args.steps)
+    assert int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab_size
+    return {"value": args.batch * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load,
+            "scaling": "strong", "parallelism": f"tensor parallel x{world} (column shards + all-gather over RCCL), eager launches",
+            "weight_bytes_per_rank": model.weight_bytes()}
+
+
+def _pad_head(ck: dict, vocab_padded: int):
+    """Zero-extend lm_head's columns to the evenly splitting width (padded logits columns are never sampled: argmax
+    looks at vocab_size columns)."""
+    w = ck.get("lm_head")
+    if w is None or w["q_weight"].shape[1] == vocab_padded:
+        return
+    extra = vocab_padded - w["q_weight"].shape[1]
+    w["q_weight"] = torch.nn.functional.pad(w["q_weight"], (0, extra)).contiguous()
+    w["q_scale"] = torch.nn.functional.pad(w["q_scale"], (0, extra // 8)).contiguous()

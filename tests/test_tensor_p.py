@@ -42,7 +42,15 @@ def _worker(rank, world, port, out_dir):
     from exllamav2_amd.cache import ExLlamaV2Cache
     from exllamav2_amd.tensor_p import ExLlamaV2TP, TPGreedyDecoder
     cfg = _cfg()
-    model = ExLlamaV2TP(cfg, rank, world, device="cpu", ext=_emu_ext()).load(_checkpoint(cfg))
+    model = ExLlamaV2TP(cfg, rank, world, device="cpu", ext=_emu_ext())
+    if rank == 0:
+        model.load(_checkpoint(cfg))
+    else:
+        # the incremental loader of the bench (one unsharded layer resident at a time) must build the same model
+        from exllamav2_amd.synth import synth_checkpoint
+        for i in range(cfg.num_hidden_layers):
+            model.load_more(synth_checkpoint(cfg, "cpu", seed=9, layers=[i], with_embed=(i == 0),
+                                             with_head=(i == cfg.num_hidden_layers - 1)), i)
     assert model.config.num_key_value_heads == cfg.num_key_value_heads // world
     cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=256)
     assert cache.key_states[0].shape[2] == cfg.num_key_value_heads // world          # 1/N of the KV cache per rank
@@ -115,3 +123,42 @@ def test_all_gather_columns_single_rank_is_identity():
     ctx = TPContext(_cfg(), 0, 1, "cpu", max_rows=4)
     x = torch.randn(3, 64).half()
     assert ctx.all_gather_columns(x) is x
+
+
+@pytest.mark.gpu
+def test_tp_shard_path_on_gpu():
+    """World size 1 on the real library: the tensor-parallel modules (make_q_matrix_split handles, unfused norm /
+    projections / act*mul, gathered logits) against the fused single-device model and the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from exllamav2_amd.cache import ExLlamaV2Cache
+    from exllamav2_amd.model import ExLlamaV2
+    from exllamav2_amd.synth import synth_checkpoint
+    from exllamav2_amd.tensor_p import ExLlamaV2TP, TPGreedyDecoder
+    from oracle.model import OracleModel
+    cfg = _cfg()
+    ck = synth_checkpoint(cfg, "cuda:0", seed=9)
+    oracle = OracleModel(cfg, ck)
+    oracle.reset(1)
+    want = oracle.forward(np.array([PROMPT]))
+    tp = ExLlamaV2TP(cfg, 0, 1, device="cuda:0").load(synth_checkpoint(cfg, "cuda:0", seed=9))
+    cache = ExLlamaV2Cache(tp, batch_size=1, max_seq_len=256)
+    got = tp.forward(torch.tensor([PROMPT]), cache, last_id_only=False)
+    torch.cuda.synchronize()
+    assert np.abs(got.float().cpu().numpy().astype(np.float64) - want).max() < LOGIT_TOL
+    model = ExLlamaV2(cfg, device="cuda:0").load(ck)
+    single = model.forward(torch.tensor([PROMPT]), ExLlamaV2Cache(model, batch_size=1, max_seq_len=256), last_id_only=False)
+    assert (got.float() - single.float()).abs().max().item() < LOGIT_TOL
+    dec = TPGreedyDecoder(tp, cache, batch_size=1)
+    dec.reset(torch.tensor([int(np.argmax(want[0, -1]))]), len(PROMPT))
+    dec.run(N_DECODE)
+    torch.cuda.synchronize()
+    toks = dec.tokens(len(PROMPT), N_DECODE).cpu().numpy()[0]
+    tok = int(np.argmax(want[0, -1]))
+    for i in range(N_DECODE):
+        w = oracle.forward(np.array([[tok]]))[0, -1]
+        top = np.sort(w)[-2:]
+        if top[1] - top[0] > 4 * LOGIT_TOL:
+            assert int(toks[i]) == int(np.argmax(w))
+        tok = int(toks[i])
+    tp.unload(); model.unload()
