@@ -54,7 +54,11 @@ for _n in ("gemm_half_q_half_tp", "make_tp_context", "free_tp_context", "tp_broa
 make_q_moe_mlp = _e.make_q_moe_mlp
 free_q_moe_mlp = _e.free_q_moe_mlp
 q_moe_mlp_forward_ = _e.q_moe_mlp_forward_
-for _n in ("fp16_to_fp8", "fp8_to_fp16", "cache_rotate", "count_match", "matrix_fp16_to_q4", "matrix_q4_to_fp16"):
+fp16_to_fp8 = _e.fp16_to_fp8
+fp8_to_fp16 = _e.fp8_to_fp16
+cache_rotate = _e.cache_rotate
+count_match = _e.count_match
+for _n in ("matrix_fp16_to_q4", "matrix_q4_to_fp16"):
     globals()[_n] = _out_of_scope(_n, "cache utilities outside the Q4 codec: 'next' rows (SURVEY.md 2.2, 8f N2)")
 for _n in ("layer_norm", "layer_norm_", "head_norm", "head_norm_", "softcap_", "gen_mrope_pos_ids", "gemm_half_half_half",
            "had_paley", "had_paley2", "pack_rows_4", "pack_columns", "quantize", "quantize_err", "quantize_range",

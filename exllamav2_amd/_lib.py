@@ -42,6 +42,10 @@ PROTOTYPES = {
     # quantized KV cache
     "exl2_fp16_to_q_kv": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, ci, vp]),
     "exl2_q_to_fp16_kv": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, ci, vp]),
+    "exl2_fp16_to_fp8": (ci, [vp, vp, ci, cll, ci, ci, ci, vp]),
+    "exl2_fp8_to_fp16": (ci, [vp, vp, ci, cll, ci, ci, ci, vp]),
+    "exl2_cache_rotate": (ci, [vp, vp, cll, ci, vp]),
+    "exl2_count_match": (ci, [vp, vp, ci, ci, vp]),
     # attention
     "exl2_paged_attn_scratch_bytes": (cll, [ci, ci, ci]),
     "exl2_paged_attn": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, vp, cll, vp]),

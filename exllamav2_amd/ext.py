@@ -214,6 +214,48 @@ class ExtC:
         self._kv_codec(self.lib.exl2_q_to_fp16_kv, k_in, k_out, k_scales, v_in, v_out, v_scales, batch_size, offset,
                        width, page_size, cache_seqlens, block_table, wbits, k_out)
 
+    def _fp8(self, fn, name, in_tensor, out_tensor, batch_size, offset, width, in_dtype, out_dtype) -> None:
+        if in_tensor.dtype != in_dtype or out_tensor.dtype != out_dtype: raise RuntimeError(f"{name}: bad dtypes")
+        if in_tensor.dim() != 4 or tuple(in_tensor.shape) != tuple(out_tensor.shape):
+            raise RuntimeError(f"{name}: tensors must be [batch, seq, kv_heads, head_dim] of the same shape")
+        if batch_size > in_tensor.shape[0]: raise RuntimeError(f"{name}: batch_size exceeds the cache")
+        tsize = in_tensor.shape[2] * in_tensor.shape[3]
+        self.lib.check(fn(self._ptr(in_tensor), self._ptr(out_tensor), int(batch_size), in_tensor.shape[1] * tsize, tsize,
+                          int(offset), int(width), self._stream(in_tensor)))
+
+    def fp16_to_fp8(self, in_tensor, out_tensor, batch_size: int, offset: int, width: int) -> None:
+        """ext_cache.cpp:14-45: FP8 cache store (upper byte of each fp16) of tokens [offset, offset + width)."""
+        self._fp8(self.lib.exl2_fp16_to_fp8, "fp16_to_fp8", in_tensor, out_tensor, batch_size, offset, width,
+                  torch.float16, torch.uint8)
+
+    def fp8_to_fp16(self, in_tensor, out_tensor, batch_size: int, offset: int, width: int) -> None:
+        """ext_cache.cpp:47-78"""
+        self._fp8(self.lib.exl2_fp8_to_fp16, "fp8_to_fp16", in_tensor, out_tensor, batch_size, offset, width,
+                  torch.uint8, torch.float16)
+
+    def cache_rotate(self, cache, order, temp) -> None:
+        """cuda/cache.cu:548-576: cyclic move of cache pages (defragmenter).  cache [num_pages, ...] contiguous, order
+        int32 [n] on the cache's device, temp sized as one page (checked like the reference; not used by the kernel)."""
+        if cache.dim() < 2: raise RuntimeError("cache argument must have dim >= 2")
+        if order.dim() != 1: raise RuntimeError("order argument must have dim == 1")
+        if order.dtype != torch.int32: raise RuntimeError("cache_rotate: order must be int32")
+        page_bytes = cache.numel() * cache.element_size() // cache.shape[0]
+        if temp.numel() * temp.element_size() != page_bytes: raise RuntimeError("temp tensor incorrect size")
+        if not cache.is_contiguous(): raise RuntimeError("cache_rotate: cache must be contiguous")
+        self.lib.check(self.lib.exl2_cache_rotate(self._ptr(cache), self._ptr(order, torch.int32, "order"), page_bytes,
+                                                  order.shape[0], self._stream(cache)))
+
+    def count_match(self, a, b, max_a: int) -> int:
+        """ext_cache.cpp:285-302: common-prefix length of two (1, n) int64 CPU tensors, at most min(max_a, b.shape[1])."""
+        import ctypes
+        if a.dtype != torch.int64 or b.dtype != torch.int64 or a.device.type != "cpu" or b.device.type != "cpu":
+            raise RuntimeError("count_match: int64 CPU tensors expected")
+        a, b = a.contiguous(), b.contiguous()
+        out = ctypes.c_int(0)
+        self.lib.check(self.lib.exl2_count_match(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                                                 min(int(max_a), a.shape[-1]), b.shape[-1], ctypes.byref(out)))
+        return int(out.value)
+
     # ---- attention (replaces flash_attn_with_kvcache / _attn_torch; SURVEY.md A.7) -------------------------------------
 
     def paged_attn_scratch_bytes(self, rows: int, head_dim: int, nsplit: int) -> int:

@@ -78,6 +78,22 @@ int exl2_q_to_fp16_kv(const void* k_in, void* k_out, const void* k_scales, const
                       int page_size, const int* cache_seqlens, const int* block_table, int pages_per_seq, int wbits,
                       void* stream);
 
+/* FP8 cache codec: fp16_to_fp8 / fp8_to_fp16 (ext_cache.cpp:14-78 -> cuda/cache.cu:20-142).  FP8 = upper byte of the fp16
+ * (E5M2 by truncation).  in/out [batch, seq, kv_heads, head_dim]; row_stride = seq * kv_heads * head_dim elements,
+ * token_size = kv_heads * head_dim; tokens [offset, offset + width) of the first batch_size rows. */
+int exl2_fp16_to_fp8(const void* in, void* out, int batch_size, long long row_stride, int token_size, int offset, int width,
+                     void* stream);
+int exl2_fp8_to_fp16(const void* in, void* out, int batch_size, long long row_stride, int token_size, int offset, int width,
+                     void* stream);
+
+/* cache_rotate (ext_cache.h / cuda/cache.cu:499-576; defragmenter generator/dynamic.py:1350-1471): cyclic move of whole
+ * pages of a paged cache: temp <- page[order[0]]; page[order[i]] <- page[order[i+1]]; page[order[n-1]] <- temp.
+ * order: int32[n] on the device.  No temp page is needed here (kept in registers). */
+int exl2_cache_rotate(void* cache, const int* order, long long page_bytes, int n, void* stream);
+
+/* count_match (ext_cache.cpp:285-302): host; leading positions at which two int64 token rows agree, <= min(max_a, len_b) */
+int exl2_count_match(const long long* a, const long long* b, int max_a, int len_b, int* match);
+
 /* ---- attention (replaces flash_attn_with_kvcache, attn.py:602-613, and _attn_torch, attn.py:869-937) ---------------- */
 
 long long exl2_paged_attn_scratch_bytes(int rows, int head_dim, int nsplit);

@@ -218,3 +218,44 @@ def moe_route(logits: np.ndarray, top_k: int):
     pk = np.where(mask, p, 0.0)
     pk = pk / pk.sum(axis=-1, keepdims=True)
     return pk.astype(F16), mask
+
+
+# ---- cache utilities of the dynamic generator's data path -------------------------------------------------------------
+
+def fp16_to_fp8(x: np.ndarray) -> np.ndarray:
+    """FP8 cache store (cuda/cache.cu:20-37 `compress`): the upper byte of each fp16, i.e. E5M2 by truncation."""
+    return (np.ascontiguousarray(x, dtype=np.float16).view(np.uint16) >> 8).astype(np.uint8)
+
+
+def fp8_to_fp16(c: np.ndarray) -> np.ndarray:
+    """cuda/cache.cu:39-44 `decompress`: the byte becomes the upper byte of an fp16, low byte zero."""
+    return (c.astype(np.uint16) << 8).view(np.float16)
+
+
+def fp8_range(token_size: int, offset: int, width: int):
+    """Element range [lo, hi) of a cache row that array_fp16_to_fp8_cuda touches (cache.cu:86-100): the token range in
+    elements, start rounded down and length rounded up to 8."""
+    lo = offset * token_size // 8 * 8
+    hi = lo + ((offset + width) * token_size - lo + 7) // 8 * 8
+    return lo, hi
+
+
+def cache_rotate(pages: np.ndarray, order) -> np.ndarray:
+    """cuda/cache.cu:534-546: temp <- page[order[0]]; for a, b in pairwise(order): page[a] <- page[b];
+    page[order[-1]] <- temp.  Returns a new array."""
+    out = pages.copy()
+    order = [int(o) for o in order]
+    temp = pages[order[0]].copy()
+    for a, b in zip(order[:-1], order[1:]):
+        out[a] = pages[b]
+    out[order[-1]] = temp
+    return out
+
+
+def count_match(a: np.ndarray, b: np.ndarray, max_a: int) -> int:
+    """ext_cache.cpp:285-302 / generator/dynamic.py:1504-1509: matching elements from the left between two (1, n) rows."""
+    m = min(max_a, b.shape[-1])
+    i = 0
+    while i < m and a[0, i] == b[0, i]:
+        i += 1
+    return i

@@ -404,3 +404,76 @@ def test_decode_utilities(be):
     lens = be.t(np.array([5, 9], dtype=np.int32))
     be.ext.add_i32_(lens, 3)
     assert np.array_equal(be.n(lens), [8, 12])
+
+
+# ---- FP8 cache codec, page rotation, prefix match (cache_util.hip) -------------------------------------------------------
+
+@pytest.mark.parametrize("offset,width,bsz", [(0, 7, 2), (3, 5, 1), (5, 0, 2), (0, 16, 2)])
+def test_fp8_cache_codec(be, offset, width, bsz):
+    """fp16_to_fp8 / fp8_to_fp16 over a token range: bit-exact bytes inside the (8-element rounded) range, nothing
+    outside it is touched; special values (inf, nan, subnormals, -0) travel as bytes."""
+    rng = np.random.default_rng(40 + offset)
+    b, s, kvh, hd = 2, 16, 3, 4                         # token size 12: ranges that are not multiples of 8 get rounded
+    x = (rng.standard_normal((b, s, kvh, hd)) * 4).astype(F16)
+    x.reshape(-1)[:6] = np.array([np.inf, -np.inf, np.nan, -0.0, 6e-8, 65504.0], dtype=F16)
+    lo, hi = OM.fp8_range(kvh * hd, offset, width)
+    out = torch.full((b, s, kvh, hd), 0xA5, dtype=torch.uint8, device=be.device)
+    be.ext.fp16_to_fp8(be.t(x), out, bsz, offset, width)
+    got = be.n(out).reshape(b, -1)
+    want = np.full((b, s * kvh * hd), 0xA5, dtype=np.uint8)
+    want[:bsz, lo:hi] = OM.fp16_to_fp8(x).reshape(b, -1)[:bsz, lo:hi]
+    assert np.array_equal(got, want)
+    back = torch.full((b, s, kvh, hd), 7.0, dtype=torch.float16, device=be.device)
+    be.ext.fp8_to_fp16(out, back, bsz, offset, width)
+    wantb = np.full((b, s * kvh * hd), 7.0, dtype=F16)
+    wantb[:bsz, lo:hi] = OM.fp8_to_fp16(want[:bsz, lo:hi])
+    assert np.array_equal(be.n(back).reshape(b, -1).view(np.uint16), wantb.view(np.uint16))
+    # truncation error bound of E5M2: |x - fp8(x)| < 2^-2 |x| for normal values
+    xs = x.reshape(b, -1)[:bsz, lo:hi].astype(np.float32)
+    ys = wantb[:bsz, lo:hi].astype(np.float32)
+    ok = np.isfinite(xs) & (np.abs(xs) > 1e-4)
+    with np.errstate(invalid="ignore"):
+        err = np.abs(xs - ys)
+    assert np.all(err[ok] <= np.abs(xs)[ok] * 0.25)
+
+
+def test_fp8_cache_codec_errors(be):
+    x = torch.zeros((1, 4, 2, 8), dtype=torch.float16, device=be.device)
+    o = torch.zeros((1, 4, 2, 8), dtype=torch.uint8, device=be.device)
+    with pytest.raises(RuntimeError):
+        be.ext.fp16_to_fp8(o, x, 1, 0, 1)                # dtypes swapped
+    with pytest.raises(RuntimeError):
+        be.ext.fp16_to_fp8(x, o, 1, 3, 2)                # range past the row
+    with pytest.raises(RuntimeError):
+        be.ext.fp8_to_fp16(o, x[:, :2], 1, 0, 1)         # shape mismatch
+
+
+@pytest.mark.parametrize("n_pages,page_elems,order", [
+    (6, 256 * 2 * 8, [4, 1, 3]), (5, 40, [0, 4]), (9, 5000, [8, 2, 7, 0, 5, 3, 1]), (3, 64, [2]),
+    (12, 8 * 1024, [11, 0, 10, 1, 9, 2, 8, 3, 7, 4])])
+def test_cache_rotate(be, n_pages, page_elems, order):
+    """Cyclic page move of the defragmenter: bit-exact against the sequential restatement, untouched pages unchanged,
+    n rotations of an n-cycle are the identity."""
+    rng = np.random.default_rng(len(order))
+    pages = rng.integers(0, 65536, size=(n_pages, page_elems), dtype=np.uint16)
+    cache = be.t(pages.view(np.float16))
+    temp = torch.zeros((page_elems,), dtype=torch.float16, device=be.device)
+    o = be.t(np.array(order, dtype=np.int32))
+    be.ext.cache_rotate(cache, o, temp)
+    want = OM.cache_rotate(pages, order)
+    assert np.array_equal(be.n(cache).view(np.uint16), want)
+    for _ in range(len(order) - 1):
+        be.ext.cache_rotate(cache, o, temp)
+    assert np.array_equal(be.n(cache).view(np.uint16), pages)
+    with pytest.raises(RuntimeError):
+        be.ext.cache_rotate(cache, o, temp[:-8])         # "temp tensor incorrect size"
+
+
+def test_count_match(be):
+    a = torch.tensor([[5, 6, 7, 8, 9, 10]], dtype=torch.int64)
+    for b_list, max_a, want in (([5, 6, 7, 1, 9], 6, 3), ([5, 6, 7, 8, 9, 10, 11], 6, 6), ([5, 6, 7, 8], 6, 4),
+                                ([5, 6, 7, 8, 9, 10], 2, 2), ([1], 6, 0), ([5, 6], 0, 0)):
+        b = torch.tensor([b_list], dtype=torch.int64)
+        assert be.ext.count_match(a, b, max_a) == want == OM.count_match(a.numpy(), b.numpy(), max_a)
+    with pytest.raises(RuntimeError):
+        be.ext.count_match(a.int(), a, 3)
