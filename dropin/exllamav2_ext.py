@@ -58,8 +58,8 @@ fp16_to_fp8 = _e.fp16_to_fp8
 fp8_to_fp16 = _e.fp8_to_fp16
 cache_rotate = _e.cache_rotate
 count_match = _e.count_match
-for _n in ("matrix_fp16_to_q4", "matrix_q4_to_fp16"):
-    globals()[_n] = _out_of_scope(_n, "cache utilities outside the Q4 codec: 'next' rows (SURVEY.md 2.2, 8f N2)")
+matrix_fp16_to_q4 = _e.matrix_fp16_to_q4
+matrix_q4_to_fp16 = _e.matrix_q4_to_fp16
 for _n in ("layer_norm", "layer_norm_", "head_norm", "head_norm_", "softcap_", "gen_mrope_pos_ids", "gemm_half_half_half",
            "had_paley", "had_paley2", "pack_rows_4", "pack_columns", "quantize", "quantize_err", "quantize_range",
            "quantize_range_inplace", "sim_anneal", "apply_rep_penalty", "sample_basic", "logit_filter_exclusive",

@@ -214,6 +214,24 @@ class ExtC:
         self._kv_codec(self.lib.exl2_q_to_fp16_kv, k_in, k_out, k_scales, v_in, v_out, v_scales, batch_size, offset,
                        width, page_size, cache_seqlens, block_table, wbits, k_out)
 
+    def _matrix_q4(self, fn, name, half, codes, scales) -> None:
+        """ext_qmatrix.cpp:293-335: the Q4 cache codec over a flat array (matrix_*_cuda call array_*_q_kv_cuda with K only,
+        one row, width = numel, 4 bits; used for Q4-compressed fp16 head / embedding weights, linear.py:191-212,500)."""
+        if half.dtype != torch.float16 or codes.dtype != torch.uint8: raise RuntimeError(f"{name}: bad dtypes")
+        if half.numel() != codes.numel() * 2: raise RuntimeError(f"{name}: tensor size mismatch")
+        numel = half.numel()
+        if numel % 512: raise RuntimeError(f"{name}: numel must be a multiple of 512 (one codec block)")
+        if scales.numel() * 32 < numel: raise RuntimeError(f"{name}: scales tensor too small")
+        k_in, k_out = (half, codes) if fn is self.lib.exl2_fp16_to_q_kv else (codes, half)
+        self.lib.check(fn(self._ptr(k_in), self._ptr(k_out), self._ptr(scales, torch.float16, "scales"), None, None, None,
+                          1, 512, numel // 512, 0, numel // 512, 0, None, None, 0, 4, self._stream(half)))
+
+    def matrix_fp16_to_q4(self, in_tensor, out_tensor, scales) -> None:
+        self._matrix_q4(self.lib.exl2_fp16_to_q_kv, "matrix_fp16_to_q4", in_tensor, out_tensor, scales)
+
+    def matrix_q4_to_fp16(self, in_tensor, scales, out_tensor) -> None:
+        self._matrix_q4(self.lib.exl2_q_to_fp16_kv, "matrix_q4_to_fp16", out_tensor, in_tensor, scales)
+
     def _fp8(self, fn, name, in_tensor, out_tensor, batch_size, offset, width, in_dtype, out_dtype) -> None:
         if in_tensor.dtype != in_dtype or out_tensor.dtype != out_dtype: raise RuntimeError(f"{name}: bad dtypes")
         if in_tensor.dim() != 4 or tuple(in_tensor.shape) != tuple(out_tensor.shape):

@@ -477,3 +477,22 @@ def test_count_match(be):
         assert be.ext.count_match(a, b, max_a) == want == OM.count_match(a.numpy(), b.numpy(), max_a)
     with pytest.raises(RuntimeError):
         be.ext.count_match(a.int(), a, 3)
+
+
+def test_matrix_q4_roundtrip(be):
+    """matrix_fp16_to_q4 / matrix_q4_to_fp16 (ext_qmatrix.cpp:293-335): the Q4 cache codec over a flat matrix."""
+    rng = np.random.default_rng(77)
+    w = (rng.standard_normal((48, 64)) * 0.05).astype(F16)          # 3072 elements = 6 codec blocks
+    codes = torch.zeros((48, 32), dtype=torch.uint8, device=be.device)
+    scales = torch.zeros((48 * 64 // 32,), dtype=torch.float16, device=be.device)
+    be.ext.matrix_fp16_to_q4(be.t(w), codes, scales)
+    want_codes, want_scales = OM.q4_pack(w.reshape(-1))
+    assert np.array_equal(be.n(scales).view(np.uint16), want_scales.view(np.uint16))
+    assert (be.n(codes).reshape(-1) == want_codes).mean() >= 0.999
+    back = torch.zeros((48, 64), dtype=torch.float16, device=be.device)
+    be.ext.matrix_q4_to_fp16(codes, scales, back)
+    want = OM.q4_unpack(be.n(codes).reshape(-1), be.n(scales))
+    assert np.array_equal(be.n(back).reshape(-1).view(np.uint16), want.view(np.uint16))
+    assert np.abs(be.n(back).astype(np.float32) - w.astype(np.float32)).max() < 0.03
+    with pytest.raises(RuntimeError):
+        be.ext.matrix_fp16_to_q4(be.t(w)[:, :60].contiguous(), codes, scales)      # size mismatch
