@@ -138,24 +138,9 @@ class TPAttention(ExLlamaV2Attention):
         self.q_handle = None
         self.fused_decode, self.q4_fused = True, True
 
-    def load(self, ck: dict):
-        for lin in (self.q_proj, self.k_proj, self.v_proj, self.o_proj):
-            lin.load(ck[lin.key])
-        self.pre_layernorm = ck[self.key + ".input_layernorm"]
-        return self
-
-    def _project_qkv(self, hidden_states, b, q_len, big):
-        cfg, m, ext = self.model.config, self.model, self.ext                  # config = the LOCAL head counts
-        rows = b * q_len
-        xn = m.temp_state[:rows]
-        ext.rms_norm(hidden_states.view(rows, -1), self.pre_layernorm, xn, cfg.norm_eps)
-        q = m.temp_q[:rows].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
-        k = m.temp_k[:rows].view(b, q_len, cfg.num_key_value_heads, cfg.head_dim)
-        v = m.temp_v[:rows].view(b, q_len, cfg.num_key_value_heads, cfg.head_dim)
-        q.view(rows, -1).copy_(self.q_proj.forward(xn))
-        k.view(rows, -1).copy_(self.k_proj.forward(xn))
-        v.view(rows, -1).copy_(self.v_proj.forward(xn))
-        return q, k, v
+    # load() and _project_qkv() are the single-device ones: the fused front half (one launch: RMSNorm + q | k | v)
+    # runs on the shards with the LOCAL head counts of model.config; the handle's o_proj slot (the o shard) is only
+    # used by q_attn_forward_2, which this class replaces:
 
     def _project_out(self, hidden_states, attn_out, b, q_len, big):
         rows = b * q_len
