@@ -4,8 +4,9 @@
 // layout / host-logic bugs surface before any GPU time is spent.  It is never built into, nor loadable by, the product
 // package (exllamav2_amd/_lib.py loads only the gfx950 library and raises if it is missing).
 //
-// Model: one workgroup runs at a time; its blockDim.x threads are OS threads; __syncthreads is a barrier over the live
-// threads of the block; wave64 cross-lane operations go through a per-wave exchange buffer with a per-wave barrier.
+// Model: one workgroup runs at a time; its blockDim.x threads are fibers (user-level contexts) scheduled round-robin on
+// the launching OS thread; __syncthreads is a barrier over the live threads of the block; wave64 cross-lane operations
+// go through a per-wave exchange buffer with a per-wave barrier.
 #ifndef EXL2_HW_H
 #define EXL2_HW_H
 #define EXL2_EMU 1
@@ -16,8 +17,6 @@
 #include <string.h>
 #include <math.h>
 #include <mutex>
-#include <condition_variable>
-#include <thread>
 #include <vector>
 #include <functional>
 #include <algorithm>
@@ -48,25 +47,26 @@ using std::min;
 using std::max;
 
 // ---- runtime model ---------------------------------------------------------------------------------------------------
+// Cooperative barrier: every thread of a workgroup is a FIBER on the launching OS thread (emu_runtime.cpp), so there is
+// nothing to lock.  A fiber that has to wait records (barrier, generation) and yields; the scheduler does not resume it
+// until the generation has moved -- one context switch per waiting thread per barrier, no kernel involvement.
+struct EmuBarrier;
+void emu_block_on(EmuBarrier* bar, unsigned gen);
 struct EmuBarrier
 {
-    std::mutex m;
-    std::condition_variable cv;
     int live = 0, arrived = 0;
     unsigned gen = 0;
     void reset(int n) { live = n; arrived = 0; }
     void wait()
     {
-        std::unique_lock<std::mutex> lk(m);
         const unsigned g = gen;
-        if (++arrived >= live) { arrived = 0; gen++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
+        if (++arrived >= live) { arrived = 0; gen++; }
+        else emu_block_on(this, g);
     }
     void leave()
     {
-        std::unique_lock<std::mutex> lk(m);
         live--;
-        if (live > 0 && arrived >= live) { arrived = 0; gen++; cv.notify_all(); }
+        if (live > 0 && arrived >= live) { arrived = 0; gen++; }
     }
 };
 
@@ -81,7 +81,6 @@ struct EmuDim { unsigned x, y, z; };
 struct EmuCtx
 {
     EmuBarrier block_bar;
-    EmuBarrier done_bar;
     EmuWave wave[16];
     unsigned char* dyn_smem;
     EmuDim grid, block;
@@ -93,8 +92,8 @@ struct dim3
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 
-extern thread_local int emu_tid_;
-extern thread_local EmuDim emu_bid_;
+extern int emu_tid_;
+extern EmuDim emu_bid_;
 extern EmuCtx* emu_ctx_;
 void emu_launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
 
