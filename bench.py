@@ -6,7 +6,8 @@ append -- one "step" is one generated token; the whole step (embedding, 32 layer
 bookkeeping) runs on the device as one HIP graph.  Inputs (weights, cache, first token) are resident in HBM when the
 timed region starts.  Rank 0 prints ONE JSON line.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--model llama2-7b|tinyllama|tiny] [--ctx C] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--model llama2-7b|llama2-70b|mixtral-8x7b|tinyllama|tiny]
+                  [--recipe 4.0bpw|3.5bpw|2.5bpw|gptq-4bit-128g] [--ctx C] [--batch B] [--cache fp16|q4] [--no-cpu-baseline]
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): layer-split ("gpu_split", model.py:176-263) as a pipeline:
 rank r owns layers [r L/N, (r+1) L/N); N independent sequences are in flight, one per stage, hidden states hop
@@ -128,9 +129,10 @@ def cpu_baseline(cfg, recipe: str, seed: int = 0):
     linears x 8 tokens, extrapolated to layers + head."""
     import numpy as np
     import torch
-    from exllamav2_amd.synth import synth_linear, RECIPES
+    from exllamav2_amd.synth import synth_linear, synth_linear_gptq, RECIPES, GPTQ_RECIPES
     from oracle import exl2 as OX
-    rec = RECIPES[recipe]
+    gptq = recipe in GPTQ_RECIPES
+    rec = RECIPES["4.0bpw"] if gptq else RECIPES[recipe]
     gen = torch.Generator(device="cpu"); gen.manual_seed(seed)
     h, inter = cfg.hidden_size, cfg.intermediate_size
     qd, kvd = cfg.num_attention_heads * cfg.head_dim, cfg.num_key_value_heads * cfg.head_dim
@@ -140,6 +142,10 @@ def cpu_baseline(cfg, recipe: str, seed: int = 0):
     torch.set_num_threads(threads)
     ws = []
     for name, k, n in shapes:
+        if gptq:
+            w = synth_linear_gptq(k, n, GPTQ_RECIPES[recipe], "cpu", gen)
+            ws.append(torch.from_numpy(OX.gptq_reconstruct({kk: vv.numpy() for kk, vv in w.items()}).astype(np.float32)))
+            continue
         w = synth_linear(k, n, rec[name], "cpu", gen)
         t = {kk: vv.numpy() for kk, vv in w.items() if kk != "q_perm"}
         ws.append(torch.from_numpy(OX.exl2_reconstruct(t).astype(np.float32)))

@@ -77,12 +77,42 @@ def synth_linear(k: int, n: int, recipe, device, gen: torch.Generator, sigma: fl
     return w
 
 
+GPTQ_RECIPES = {"gptq-4bit-128g": 128, "gptq-4bit-32g": 32}     # BASELINE configs[0]: TinyLlama GPTQ 4-bit g128
+
+
+def synth_linear_gptq(k: int, n: int, group_size: int, device, gen: torch.Generator, sigma: float = 0.02,
+                      act_order: bool = False) -> dict:
+    """GPTQ tensor set (module.py:125-130): qweight int32 [K/8, N] (8 nibbles along K per word), qzeros
+    int32 [G, N/8] (stored nibble = zero - 1), scales fp16 [G, N], g_idx int32 [K] (shuffled = act-order)."""
+    assert k % group_size == 0 and k % 8 == 0 and n % 8 == 0
+    g = k // group_size
+    dev = torch.device(device)
+    # uniform 4-bit codes around zero 8 with std sqrt(21.25): scale so that dequantized weights have std ~ sigma
+    sc = sigma / math.sqrt(21.25)
+    w = {
+        "qweight": torch.randint(-2 ** 31, 2 ** 31 - 1, (k // 8, n), dtype=torch.int32, device=dev, generator=gen),
+        "qzeros": torch.full((g, n // 8), 0x77777777, dtype=torch.int32, device=dev),                 # zero = 8 everywhere
+        "scales": (sc * (0.5 + torch.rand(g, n, device=dev, generator=gen))).half(),
+    }
+    gi = torch.arange(k, device=dev, dtype=torch.int32) // group_size
+    if act_order:
+        gi = gi[torch.randperm(k, device=dev, generator=gen)]
+    w["g_idx"] = gi.contiguous()
+    return w
+
+
 def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_order: bool = True,
                      layers=None, with_embed: bool = True, with_head: bool = True) -> dict:
     """{'model.layers.0.self_attn.q_proj': {...}, ..., 'model.norm': tensor, 'model.embed_tokens': tensor}.
     Every layer draws from its own generator (seed, layer index), so a rank of a layer-split run can build exactly its
     slice of the same checkpoint (`layers` = iterable of layer indices)."""
-    rec = RECIPES[recipe]
+    if recipe in GPTQ_RECIPES:
+        gs = GPTQ_RECIPES[recipe]
+        rec = {k: gs for k in RECIPES["4.0bpw"]}
+        make = lambda k, n, r, dev, gen, sigma, act: synth_linear_gptq(k, n, r, dev, gen, sigma, act)
+    else:
+        rec = RECIPES[recipe]
+        make = synth_linear
     h, inter = cfg.hidden_size, cfg.intermediate_size
     qd = cfg.num_attention_heads * cfg.head_dim
     kvd = cfg.num_key_value_heads * cfg.head_dim
@@ -97,23 +127,23 @@ def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_ord
     for i in (range(cfg.num_hidden_layers) if layers is None else layers):
         gen = gen_for(i + 1)
         p = f"model.layers.{i}"
-        ck[f"{p}.self_attn.q_proj"] = synth_linear(h, qd, rec["q_proj"], device, gen, s_attn, act_order)
-        ck[f"{p}.self_attn.k_proj"] = synth_linear(h, kvd, rec["k_proj"], device, gen, s_attn, act_order)
-        ck[f"{p}.self_attn.v_proj"] = synth_linear(h, kvd, rec["v_proj"], device, gen, s_attn, act_order)
-        ck[f"{p}.self_attn.o_proj"] = synth_linear(qd, h, rec["o_proj"], device, gen, 0.5 / math.sqrt(qd), act_order)
+        ck[f"{p}.self_attn.q_proj"] = make(h, qd, rec["q_proj"], device, gen, s_attn, act_order)
+        ck[f"{p}.self_attn.k_proj"] = make(h, kvd, rec["k_proj"], device, gen, s_attn, act_order)
+        ck[f"{p}.self_attn.v_proj"] = make(h, kvd, rec["v_proj"], device, gen, s_attn, act_order)
+        ck[f"{p}.self_attn.o_proj"] = make(qd, h, rec["o_proj"], device, gen, 0.5 / math.sqrt(qd), act_order)
         if getattr(cfg, "num_experts", 0):
             # Mixtral-style sparse MLP (moe_mlp.py:25-133): experts w1 (gate), w3 (up), w2 (down) + fp16 router
             for e in range(cfg.num_experts):
                 q = f"{p}.block_sparse_moe.experts.{e}"
-                ck[f"{q}.w1"] = synth_linear(h, inter, rec["gate_proj"], device, gen, s_attn, act_order)
-                ck[f"{q}.w3"] = synth_linear(h, inter, rec["up_proj"], device, gen, s_attn, act_order)
-                ck[f"{q}.w2"] = synth_linear(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
+                ck[f"{q}.w1"] = make(h, inter, rec["gate_proj"], device, gen, s_attn, act_order)
+                ck[f"{q}.w3"] = make(h, inter, rec["up_proj"], device, gen, s_attn, act_order)
+                ck[f"{q}.w2"] = make(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
             ck[f"{p}.block_sparse_moe.gate"] = (torch.randn(cfg.num_experts, h, device=device, generator=gen) * s_attn).half()
         else:
-            ck[f"{p}.mlp.gate_proj"] = synth_linear(h, inter, rec["gate_proj"], device, gen, s_attn, act_order)
-            ck[f"{p}.mlp.up_proj"] = synth_linear(h, inter, rec["up_proj"], device, gen, s_attn, act_order)
+            ck[f"{p}.mlp.gate_proj"] = make(h, inter, rec["gate_proj"], device, gen, s_attn, act_order)
+            ck[f"{p}.mlp.up_proj"] = make(h, inter, rec["up_proj"], device, gen, s_attn, act_order)
             # the reference folds down_proj's act-order into gate/up at load -> identity perm here
-            ck[f"{p}.mlp.down_proj"] = synth_linear(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
+            ck[f"{p}.mlp.down_proj"] = make(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
         ck[f"{p}.input_layernorm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
         ck[f"{p}.post_attention_layernorm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
     if with_embed:
@@ -122,5 +152,5 @@ def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_ord
         gen = gen_for(99991)
         ck["model.norm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
         vpad = (cfg.vocab_size + 31) // 32 * 32                               # linear.py:82-88 pads out_features to x32
-        ck["lm_head"] = synth_linear(h, vpad, rec["lm_head"], device, gen, s_attn, act_order)
+        ck["lm_head"] = make(h, vpad, rec["lm_head"], device, gen, s_attn, act_order)
     return ck

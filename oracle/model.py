@@ -33,7 +33,11 @@ class OracleModel:
         self.cfg = cfg
         self.w = {}
         for k, v in ck.items():
-            if isinstance(v, dict):
+            if isinstance(v, dict) and "qweight" in v:
+                t = {kk: _np(vv).copy() for kk, vv in v.items() if kk in ("qweight", "qzeros", "scales", "g_idx")}
+                self.w[k] = OX.gptq_reconstruct(t).astype(np.float32)
+                self.w[k + ".bias"] = _np(v["bias"]).astype(np.float32) if "bias" in v else None
+            elif isinstance(v, dict):
                 self.w[k] = OX.exl2_reconstruct(_lin_tensors(v)).astype(np.float32)
                 self.w[k + ".bias"] = _np(v["bias"]).astype(np.float32) if "bias" in v else None
             else:

@@ -184,3 +184,29 @@ def test_q4_cache_decode_close_to_fp16(be):
     assert d.max() < 0.5 and d.mean() < 0.1             # 4-bit keys/values: small but non-zero drift
     assert np.any(d > 0)
     m16.unload(); m4.unload()
+
+
+@pytest.mark.parametrize("recipe,act_order", [("gptq-4bit-128g", False), ("gptq-4bit-32g", True)])
+def test_gptq_model_equals_oracle(be, recipe, act_order):
+    """BASELINE configs[0] shape in miniature: a GQA Llama whose linears are GPTQ 4-bit (sequential and act-order
+    g_idx) through the same module path -- fused attention front half, fused MLP, head -- prefill then greedy decode."""
+    cfg = tiny_cfg(num_attention_heads=4, num_key_value_heads=2, intermediate_size=384)
+    ck = synth_checkpoint(cfg, be.device, recipe=recipe, seed=3, act_order=act_order)
+    oracle = OracleModel(cfg, ck)
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    assert be.ext.q_matrix_info(model.layers[0][0].q_proj.q_handle)["is_gptq"]
+    cache = ExLlamaV2Cache(model, batch_size=1)
+    oracle.reset(1)
+    ids = np.array([[5, 9, 77, 31]])
+    logits = model.forward(torch.from_numpy(ids), cache, last_id_only=False)
+    want = oracle.forward(ids)
+    check_logits(be.n(logits), want)
+    nxt = np.argmax(want[:, -1], axis=-1)[:, None]
+    for _ in range(2):
+        logits = model.forward(torch.from_numpy(nxt), cache)
+        want = oracle.forward(nxt)
+        check_logits(be.n(logits), want)
+        conf = confident(want[:, -1])
+        assert np.array_equal(be.n(logits)[:, -1].argmax(-1)[conf], np.argmax(want[:, -1], -1)[conf])
+        nxt = np.argmax(want[:, -1], axis=-1)[:, None]
+    model.unload()
