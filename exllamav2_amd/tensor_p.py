@@ -311,7 +311,7 @@ class TPGreedyDecoder:
         return self.history[:, start + 1:start + 1 + n]
 
 
-def run_tp_bench(cfg, args, rank: int, world: int, device):
+def run_tp_bench(cfg, args, rank: int, world: int, device, ext=None):
     """bench.py backend for `--gpus N --parallel tp`: ONE sequence (per batch row) decoded by all ranks together --
     strong scaling (total work per token fixed, 1/N of the weight bytes per rank).  Eager launches: the step contains
     collectives, so it is not captured into a HIP graph here."""
@@ -322,7 +322,8 @@ def run_tp_bench(cfg, args, rank: int, world: int, device):
     max_seq = max(2048, ((args.ctx + args.steps + args.warmup + 1 + 255) // 256) * 256)
     cfg = dataclasses.replace(cfg, max_seq_len=max_seq)
     t_load = time.perf_counter()
-    model = ExLlamaV2TP(cfg, rank, world, device=device)
+    sync = torch.cuda.synchronize if torch.device(device).type == "cuda" else (lambda: None)
+    model = ExLlamaV2TP(cfg, rank, world, device=device, ext=ext)
     # every rank draws the same full tensors (same seed) layer by layer and keeps only its shards
     for i in range(cfg.num_hidden_layers):
         ck = synth_checkpoint(cfg, device, recipe=args.recipe, seed=0, layers=[i], with_embed=(i == 0),
@@ -330,18 +331,18 @@ def run_tp_bench(cfg, args, rank: int, world: int, device):
         _pad_head(ck, model.tp.vocab_padded)
         model.load_more(ck, i)
         del ck
-    torch.cuda.synchronize()
+    sync()
     t_load = time.perf_counter() - t_load
     cache_cls = ExLlamaV2Cache_Q4 if getattr(args, "cache", "fp16") == "q4" else ExLlamaV2Cache
     cache = cache_cls(model, batch_size=args.batch, max_seq_len=max_seq)
     dec = TPGreedyDecoder(model, cache, batch_size=args.batch)
     dec.reset(torch.tensor([1] * args.batch), args.ctx)
     dec.run(args.warmup)
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
     t0 = time.perf_counter()
     dec.run(args.steps)
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)

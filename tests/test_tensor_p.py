@@ -103,6 +103,27 @@ def test_tensor_parallel_matches_single_process(tmp_path):
     model.unload()
 
 
+def _bench_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    from exllamav2_amd.tensor_p import run_tp_bench
+    cfg = _cfg()
+    cfg.vocab_size = 90                                    # lm_head has 96 columns -> zero-extended to 128 = 2 x 64 (_pad_head)
+    args = argparse.Namespace(ctx=2, steps=2, warmup=1, recipe="4.0bpw", batch=2, cache="fp16")
+    r = run_tp_bench(cfg, args, rank, world, "cpu", ext=_emu_ext())
+    assert r["scaling"] == "strong" and r["value"] > 0 and r["weight_bytes_per_rank"] > 0
+    dist.destroy_process_group()
+
+
+def test_tp_bench_backend_runs_on_gloo(tmp_path):
+    """bench.py --parallel tp backend end to end (incremental shard loading, padded head, batch of 2, timing collectives)."""
+    build_emu_if_needed()
+    mp.spawn(_bench_worker, args=(2, 29549, str(tmp_path)), nprocs=2, join=True)
+
+
 def test_tp_split_plan():
     from exllamav2_amd.config import ExLlamaV2Config
     from exllamav2_amd.tensor_p import TPContext, tp_ranges
