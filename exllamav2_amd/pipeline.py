@@ -150,22 +150,24 @@ def run_pipeline(stage: PipelineStage, first_tokens, n_ticks: int):
     return sampled
 
 
-def run_layer_split_bench(cfg, args, rank: int, world: int, device):
+def run_layer_split_bench(cfg, args, rank: int, world: int, device, ext=None):
     """bench.py backend for --gpus N > 1: N sequences in flight over an N-stage layer split."""
     n_seqs = world
-    ramp = 2048                     # untimed ticks before the warm-up (clock ramp of a freshly started GPU), same on every rank
+    on_gpu = torch.device(device).type == "cuda"
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    ramp = getattr(args, "ramp", 2048)   # untimed ticks before the warm-up (clock ramp of a freshly started GPU), same on every rank
     max_seq = max(2048, ((args.ctx + (args.steps + args.warmup + ramp) // n_seqs + 2 + 255) // 256) * 256)
     t_load = time.perf_counter()
     stage = PipelineStage(cfg, rank, world, device, n_seqs, max_seq, recipe=args.recipe, use_graph=not args.no_graph,
-                          cache_type=getattr(args, "cache", "fp16"))
+                          cache_type=getattr(args, "cache", "fp16"), ext=ext)
     stage.capture()
     stage.seqlens.fill_(args.ctx)
-    torch.cuda.synchronize()
+    sync()
     t_load = time.perf_counter() - t_load
     first = list(range(1, n_seqs + 1))
     # fill the pipe + warm-up (a "step" = one token sampled somewhere in the pipe = one tick once the pipe is full)
     run_pipeline(stage, first, world + ramp + args.warmup)
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
     t0 = time.perf_counter()
     n = stage.n_seqs
@@ -173,7 +175,7 @@ def run_layer_split_bench(cfg, args, rank: int, world: int, device):
     for t in range(base, base + args.steps):
         stage.step((t - rank) % n)
         stage.exchange()
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)

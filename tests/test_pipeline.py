@@ -61,6 +61,25 @@ def test_layer_split_pipeline_matches_single_process(tmp_path):
     model.unload()
 
 
+def _bench_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    from exllamav2_amd.pipeline import run_layer_split_bench
+    args = argparse.Namespace(ctx=3, steps=4, warmup=2, ramp=2, recipe="4.0bpw", no_graph=True, cache="fp16")
+    r = run_layer_split_bench(_cfg(), args, rank, world, "cpu", ext=_emu_ext())
+    assert r["value"] > 0 and r["ms_per_step"] > 0
+    dist.destroy_process_group()
+
+
+def test_layer_split_bench_backend_runs_on_gloo():
+    """The function `bench.py --gpus N` calls for N > 1 (pipe fill, warm-up, timed ticks, max-over-ranks timing), end to end."""
+    build_emu_if_needed()
+    mp.spawn(_bench_worker, args=(2, 29535), nprocs=2, join=True)
+
+
 def test_split_layers_partition():
     from exllamav2_amd.pipeline import split_layers
     for L in (2, 22, 32, 80):
