@@ -262,7 +262,8 @@ def main():
         gemv_ms, launches, gemv_bytes = time_gemv_calls(model, dec)
         kv_bytes = 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2 * (args.ctx + args.warmup + args.steps // 2)
         achieved = gemv_bytes / (gemv_ms * 1e-3) / 1e9
-        traffic_gb = pmc_traffic_gb(launches)
+        # the committed PMC pass is of the headline configuration only
+        traffic_gb = pmc_traffic_gb(launches) if (args.model == "llama2-7b" and args.recipe == "4.0bpw") else None
         result = {
             "value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load,
             "roofline": {
@@ -281,11 +282,15 @@ def main():
     return finish(args, cfg, result, rank, world, n_gpus, device, dist)
 
 
+def fmt_name(recipe: str) -> str:
+    return ("GPTQ " + recipe[5:]) if recipe.startswith("gptq-") else ("EXL2 " + recipe)
+
+
 def finish(args, cfg, result, rank, world, n_gpus, device, dist):
     if rank == 0:
         out = {
             "metric": "decode tokens/s, Llama-2-7B EXL2 4.0bpw, bs=1 greedy" if (args.model == "llama2-7b" and args.batch == 1)
-                      else f"decode tokens/s, {args.model} EXL2 {args.recipe}, bs={args.batch} greedy",
+                      else f"decode tokens/s, {args.model} {fmt_name(args.recipe)}, bs={args.batch} greedy",
             "value": round(result["value"], 2), "unit": "tokens/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(result["ms_per_step"], 4), "higher_is_better": True,
             "scaling": result.get("scaling", "weak"),
@@ -293,7 +298,7 @@ def finish(args, cfg, result, rank, world, n_gpus, device, dist):
             "vs_baseline": round(result["value"] / 211.0, 3) if (args.model == "llama2-7b" and n_gpus == 1 and args.batch == 1) else None,
             "baseline_ref": "211 tokens/s, Llama2 7B EXL2 4.0bpw, RTX 4090 (reference README.md:71)",
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{args.model} EXL2 {args.recipe} (synthetic weights, act-order), greedy decode, "
+            "config": {"workload": f"{args.model} {fmt_name(args.recipe)} (synthetic weights, act-order), greedy decode, "
                                    f"bs={args.batch}, ctx {args.ctx}+{args.warmup}..+{args.steps}, {args.cache.upper()} KV cache, "
                                    f"whole step in one HIP graph",
                        "parallelism": "single GPU" if n_gpus == 1 else
