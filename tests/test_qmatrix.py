@@ -260,3 +260,48 @@ def test_errors_are_loud(be):
     bad["q_groups"][0] = 7      # unsupported bit width
     with pytest.raises(RuntimeError):
         be.ext.make_q_matrix_from_dict(bad, None)
+
+
+# ---- BASELINE.json full sizes: the Llama-2-7B linears with the reference's 4.0 bpw bit mixes ---------------------------
+
+FULL_SIZE = {   # role -> (K, N, emulation too?)   (the emulation runs the 4096 x 4096 and 11008 x 4096 shapes in seconds)
+    "q_proj": (4096, 4096, True), "down_proj": (11008, 4096, True), "gate_proj": (4096, 11008, False),
+    "lm_head": (4096, 32000, False),
+}
+
+
+@pytest.mark.parametrize("role", list(FULL_SIZE))
+def test_full_size_linear(be, role):
+    """Size-independent properties at the real shapes: (i) one-hot rows through q_gemm return rows of the matrix, bit
+    for bit the oracle's reconstruct() (a product by 1.0 and a single fp16 rounding: the gemm(I) == reconstruct()
+    relation on a handful of rows); (ii) the device's reconstruct() of those rows' columns agrees; (iii) a random
+    activation row lands within the fp16 tolerance of the float64 product, where the tolerance carries the K-dependent
+    term of the reference's fp16-rounded weights (2^-11 relative per weight, random walk over K)."""
+    from exllamav2_amd.synth import RECIPES, synth_linear
+    k, n, on_emu = FULL_SIZE[role]
+    if be.is_emu and not on_emu:
+        pytest.skip("full-size shape runs on the hip backend only")
+    gen = torch.Generator(); gen.manual_seed(123)
+    w = synth_linear(k, n, RECIPES["4.0bpw"][role], "cpu", gen, sigma=0.02, act_order=True)
+    t = {kk: vv.numpy().copy() for kk, vv in w.items() if kk != "q_perm"}
+    ref = OX.exl2_reconstruct(t)                                         # fp16 [K, N], original row order
+    wd = {kk: vv.to(be.device) for kk, vv in w.items()}
+    h = be.ext.make_q_matrix_from_dict(wd, None)
+    rows = [0, 1, k // 2 + 3, k - 1]
+    a = np.zeros((len(rows), k), dtype=np.float16)
+    for i, r in enumerate(rows): a[i, r] = 1.0
+    c = torch.zeros((len(rows), n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    assert np.array_equal(be.n(c).view(np.uint16), ref[rows].view(np.uint16))
+    if not be.is_emu:
+        out = torch.zeros((k, n), dtype=torch.float16, device=be.device)
+        be.ext.reconstruct(h, out)
+        assert np.array_equal(be.n(out).view(np.uint16), ref.view(np.uint16))
+    x = np.random.default_rng(5).standard_normal((1, k)).astype(np.float16)
+    y = torch.zeros((1, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(x), h, y)
+    want = x.astype(np.float64) @ ref.astype(np.float64)
+    w_rms = float(np.sqrt(np.mean(ref.astype(np.float32) ** 2)))
+    tol = np.abs(want) * 2.0 ** -10 + 1.5e-3 + 6.0 * 2.0 ** -11 * np.sqrt(k) * w_rms
+    assert np.all(np.abs(be.n(y).astype(np.float64) - want) <= tol), float(np.abs(be.n(y) - want).max())
+    be.ext.free_q_matrix(h)
