@@ -5,10 +5,19 @@ package; only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline
 only as the checker.
 
 Every function is a restatement (numpy, plain loops for tiny cases) of the reference's semantics and
-cites the reference file:line it follows.  Parity status: **unpinned by execution** -- the reference
-has no CPU implementation of this path and ships no golden vectors, so the
-oracle is pinned by *relation* (pack -> unpack round trips that restate both `pack_tensor.cu` and the
-plain `qdq_*.cuh` decoders, identity-matrix GEMM == reconstruct, WHT involution) and by the pure
-torch functions of the reference that do run on CPU (`tests/golden/make_golden.py` imports those and
-commits their outputs as fixtures).
+cites the reference file:line it follows.  Parity status:
+
+* **pinned by execution of the reference's own code**: the packed K-stream bit order of every width
+  (2, 3, 4, 5, 6, 8 bits), the 4-bit scale decode (`dq_scale`) and the GPTQ `(q - zero)` decode --
+  `oracle/ref_build/` compiles the reference's `exllamav2_ext/cuda/quant/qdq_*.cuh` for the host from
+  where they lie under /root/reference (a shim supplies the CUDA fp16 vocabulary; outputs in
+  `oracle/_ref/`, git-ignored), `tests/golden/make_golden_qdq.py` records what the reference's
+  load-time shuffle + kernel-side dequant return for seeded inputs, and `tests/test_oracle_ref.py`
+  checks `oracle/exl2.py` against that fixture everywhere and against the live library here;
+  likewise the pure torch functions of the reference that run on CPU (group map, RMSNorm, attention,
+  RoPE tables, MLP activation: `tests/golden/make_golden.py`);
+* **unpinned by execution, pinned by relation**: the multiply itself (the reference has no CPU q_gemm
+  and ships no golden vectors, SURVEY.md section 8c: `gemm(I) == reconstruct()`, one-hot rows at full
+  size, `gemm(x) ~ x @ reconstruct()`), the act-order row scatter of `reconstruct`, and the Q4 cache
+  codec (pack -> unpack round trips, WHT involution).
 """

@@ -1,6 +1,7 @@
 """Oracle: EXL2 / GPTQ weight formats, reconstruct and q_gemm semantics (numpy).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Parity unpinned by execution; pinned by relation.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Weight / scale / GPTQ decode: pinned by execution of the reference's
+qdq_*.cuh (tests/test_oracle_ref.py); the multiply and the row scatter: parity unpinned by execution, pinned by relation.
 
 Reference files restated here (all under /root/reference/exllamav2/):
   * on-disk packing ............ exllamav2_ext/cuda/pack_tensor.cu:10-35 (pack_rows_4), :118-248 (pack_columns)
