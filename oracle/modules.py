@@ -202,6 +202,31 @@ def q4_unpack(packed: np.ndarray, scales: np.ndarray) -> np.ndarray:
     return hmul(w, F16(1.0 / 32.0)).reshape(-1)
 
 
+def q8_pack(x: np.ndarray):
+    """x fp16 flat [n], n % 512 == 0 -> (uint8 [n], fp16 scales [n/32])   (cache_q.cuh:78-107, wbits = 8: the K side of
+    the Q6 cache and both sides of the Q8 cache, cache.cu:259-276)."""
+    n = x.shape[0]
+    assert n % 512 == 0
+    w = _wht32_pairs(x.astype(F16).reshape(n // 64, 32, 2))
+    a = np.abs(w).max(axis=-1)
+    absmax = a.reshape(-1, 2, 16).max(axis=-1)
+    am = np.repeat(absmax, 16, axis=-1).reshape(-1, 32, 1).astype(F16)
+    wn = hfma(hdiv(w, am), F16(128.0), F16(128.0))
+    with np.errstate(invalid="ignore"):
+        q = np.where(np.isnan(wn), 0, np.rint(wn.astype(F32)))
+    q = np.clip(q, 0, 255).astype(np.uint8)
+    return q.reshape(-1), hmul(absmax.reshape(-1), F16(1.0 / 128.0))
+
+
+def q8_unpack(codes: np.ndarray, scales: np.ndarray) -> np.ndarray:
+    """(cache_q.cuh:147-185, wbits = 8): (code - 128) * scale, butterfly, * 1/32."""
+    n = codes.shape[0]
+    w = (codes.astype(np.int32) - 128).astype(F16).reshape(n // 64, 32, 2)
+    sc = np.repeat(scales.astype(F16).reshape(-1, 2), 16, axis=-1).reshape(-1, 32, 1)
+    w = _wht32_pairs(hmul(w, sc))
+    return hmul(w, F16(1.0 / 32.0)).reshape(-1)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # MoE routing (moe_mlp.py:276-314 ; q_mlp_softmax.cuh:156-189): softmax fp32, keep top-k, renormalise
 # ----------------------------------------------------------------------------------------------------------------------

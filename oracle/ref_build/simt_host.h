@@ -1,0 +1,36 @@
+// simt_host.h -- the few SIMT builtins the reference's cache_q.cuh uses (warp shuffles over 32 lanes, __syncthreads,
+// __shared__), executed on the host: the logical threads of ONE block are fibers run round-robin (simt_host.cpp).
+// TEST INFRASTRUCTURE ONLY (see cuda_shim.h).
+#pragma once
+#include <string.h>
+#include <functional>
+
+namespace simt
+{
+void run_block(int nthreads, const std::function<void(int)>& body);    // body(t), t = 0 .. nthreads-1
+int tid();
+void barrier(int group);                                               // group = 0: whole block; 32: the caller's warp
+extern unsigned char xchg[1024][16];
+}
+
+template <typename T> static inline T simt_exchange(T v, int src_lane)
+{
+    static_assert(sizeof(T) <= 16, "exchange slot too small");
+    const int t = simt::tid();
+    memcpy(simt::xchg[t], &v, sizeof(T));
+    simt::barrier(32);
+    T r;
+    memcpy(&r, simt::xchg[(t & ~31) | (src_lane & 31)], sizeof(T));
+    simt::barrier(32);
+    return r;
+}
+// every lane executes the instruction in the reference code; the mask only names the lanes whose result is used
+template <typename T> static inline T __shfl_xor_sync(unsigned, T v, int lane_mask) { return simt_exchange(v, (simt::tid() & 31) ^ lane_mask); }
+template <typename T> static inline T __shfl_down_sync(unsigned, T v, int delta)
+{
+    const int lane = simt::tid() & 31;
+    return simt_exchange(v, lane + delta < 32 ? lane + delta : lane);
+}
+static inline void __syncthreads() { simt::barrier(0); }
+#define __shared__ static
+#define __restrict__

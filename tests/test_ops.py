@@ -496,3 +496,39 @@ def test_matrix_q4_roundtrip(be):
     assert np.abs(be.n(back).astype(np.float32) - w.astype(np.float32)).max() < 0.03
     with pytest.raises(RuntimeError):
         be.ext.matrix_fp16_to_q4(be.t(w)[:, :60].contiguous(), codes, scales)      # size mismatch
+
+
+@pytest.mark.parametrize("wbits", [8, 6])
+def test_q8_q6_cache_contiguous_roundtrip(be, wbits):
+    """Q8 cache (8-bit keys and values) and Q6 cache (8-bit keys, 4-bit values: cache.cu:259-276) against the oracle's
+    codec, which is pinned to the reference's cache_q.cuh by execution (tests/test_oracle_ref.py)."""
+    from exllamav2_amd.ext import none_tensor
+    rng = np.random.default_rng(60 + wbits)
+    b, T, kvh, hd = 2, 8, 2, 128
+    k = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    v = (rng.standard_normal((b, T, kvh, hd)) * 0.5).astype(F16)
+    vbits = 8 if wbits == 8 else 4
+    kq = torch.zeros((b, T, kvh, hd), dtype=torch.uint8, device=be.device)
+    vq = torch.zeros((b, T, kvh, hd // (8 // vbits)), dtype=torch.uint8, device=be.device)
+    ks = torch.zeros((b, T, kvh, hd // 32), dtype=torch.float16, device=be.device)
+    vs = torch.zeros_like(ks)
+    be.ext.fp16_to_q_kv(be.t(k), kq, ks, be.t(v), vq, vs, b, 2, 4, 0, none_tensor, none_tensor, wbits)
+    vpack, vunpack = (OM.q8_pack, OM.q8_unpack) if vbits == 8 else (OM.q4_pack, OM.q4_unpack)
+    for i in range(b):
+        kc, ksc = OM.q8_pack(k[i, 2:6].reshape(-1))
+        vc, vsc = vpack(v[i, 2:6].reshape(-1))
+        got_k, got_v = be.n(kq)[i, 2:6].reshape(-1), be.n(vq)[i, 2:6].reshape(-1)
+        assert (got_k == kc).mean() >= 0.999 and (got_v == vc).mean() >= 0.999      # fp16 division ties, as for Q4
+        assert np.array_equal(be.n(ks)[i, 2:6].reshape(-1).view(np.uint16), ksc.view(np.uint16))
+        assert np.array_equal(be.n(vs)[i, 2:6].reshape(-1).view(np.uint16), vsc.view(np.uint16))
+    assert np.all(be.n(kq)[:, :2] == 0) and np.all(be.n(kq)[:, 6:] == 0)          # outside the token range: untouched
+    ko = torch.zeros((b, T, kvh, hd), dtype=torch.float16, device=be.device)
+    vo = torch.zeros_like(ko)
+    be.ext.q_to_fp16_kv(kq, ko, ks, vq, vo, vs, b, 2, 4, 0, none_tensor, none_tensor, wbits)
+    for i in range(b):
+        want_k = OM.q8_unpack(be.n(kq)[i, 2:6].reshape(-1), be.n(ks)[i, 2:6].reshape(-1))
+        want_v = vunpack(be.n(vq)[i, 2:6].reshape(-1), be.n(vs)[i, 2:6].reshape(-1))
+        assert np.array_equal(be.n(ko)[i, 2:6].reshape(-1).view(np.uint16), want_k.view(np.uint16))
+        assert np.array_equal(be.n(vo)[i, 2:6].reshape(-1).view(np.uint16), want_v.view(np.uint16))
+    errk = np.abs(be.n(ko)[:, 2:6].astype(np.float32) - k[:, 2:6].astype(np.float32))
+    assert errk.max() < 0.05                                                      # 8-bit keys: step = absmax / 128

@@ -75,3 +75,53 @@ def test_generator_is_reproducible(tmp_path):
     fx = np.load(FIXTURE)
     for bits in BITS:
         assert np.array_equal(G.decode_columns(lib, bits, fx[f"words_{bits}"]), fx[f"decoded_{bits}"])
+
+
+# ---- quantized KV-cache codec: the reference's cache_q.cuh executed on the host (256 logical threads per block) ----------
+
+CACHE_FIXTURE = os.path.join(ROOT, "tests", "golden", "reference_cache_q.npz")
+
+
+def _codec(wbits):
+    from oracle import modules as OM
+    return (OM.q4_pack, OM.q4_unpack) if wbits == 4 else (OM.q8_pack, OM.q8_unpack)
+
+
+def _same_f16(a, b):
+    return np.array_equal(np.asarray(a, dtype=np.float16).view(np.uint16), np.asarray(b, dtype=np.float16).view(np.uint16))
+
+
+@pytest.mark.parametrize("wbits", [4, 8])
+def test_fixture_cache_codec_equals_oracle(wbits):
+    """codes, scales and dequantized values bit for bit -- including the all-zero block (0/0 -> code 0), a zero group,
+    overflow of the butterfly to inf, subnormals and exact rounding ties"""
+    fx = np.load(CACHE_FIXTURE)
+    pack, unpack = _codec(wbits)
+    for b in range(fx["x"].shape[0]):
+        with np.errstate(all="ignore"):
+            codes, scales = pack(fx["x"][b])
+            back = unpack(fx[f"codes_{wbits}"][b], fx[f"scales_{wbits}"][b])
+        assert np.array_equal(codes, fx[f"codes_{wbits}"][b]), b
+        assert _same_f16(scales, fx[f"scales_{wbits}"][b]), b
+        assert _same_f16(back, fx[f"unpacked_{wbits}"][b]), b
+
+
+@pytest.mark.parametrize("wbits", [4, 8])
+def test_live_reference_cache_codec_equals_oracle(wbits):
+    if not os.path.isdir("/root/reference/exllamav2/exllamav2_ext/cuda"):
+        pytest.skip("reference sources not present on this machine (the committed fixture still pins the oracle)")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_cacheq as G
+    lib = G.load()
+    x = G.blocks(77 + wbits, 24)[5:]                           # fresh random blocks
+    codes, scales = G.pack_blocks(lib, wbits, x)
+    back = G.unpack_blocks(lib, wbits, codes, scales)
+    pack, unpack = _codec(wbits)
+    for b in range(x.shape[0]):
+        c, s = pack(x[b])
+        assert np.array_equal(c, codes[b]) and _same_f16(s, scales[b])
+        assert _same_f16(unpack(codes[b], scales[b]), back[b])
+    # the fixture is what the script produces today
+    fx = np.load(CACHE_FIXTURE)
+    c0, s0 = G.pack_blocks(lib, wbits, fx["x"])
+    assert np.array_equal(c0, fx[f"codes_{wbits}"]) and _same_f16(s0, fx[f"scales_{wbits}"])
