@@ -14,10 +14,13 @@ cites the reference file:line it follows.  Parity status:
   `oracle/_ref/`, git-ignored), `tests/golden/make_golden_qdq.py` records what the reference's
   load-time shuffle + kernel-side dequant return for seeded inputs, and `tests/test_oracle_ref.py`
   checks `oracle/exl2.py` against that fixture everywhere and against the live library here;
+  the quantized-KV-cache codec (`cuda/cache_q.cuh` run with 256 logical threads per block on a host
+  fiber scheduler, `oracle/ref_build/simt_host.*`; fixture `tests/golden/reference_cache_q.npz`,
+  generator `tests/golden/make_golden_cacheq.py`): codes, scales, dequantized values bit for bit;
   likewise the pure torch functions of the reference that run on CPU (group map, RMSNorm, attention,
   RoPE tables, MLP activation: `tests/golden/make_golden.py`);
 * **unpinned by execution, pinned by relation**: the multiply itself (the reference has no CPU q_gemm
   and ships no golden vectors, SURVEY.md section 8c: `gemm(I) == reconstruct()`, one-hot rows at full
-  size, `gemm(x) ~ x @ reconstruct()`), the act-order row scatter of `reconstruct`, and the Q4 cache
-  codec (pack -> unpack round trips, WHT involution).
+  size, `gemm(x) ~ x @ reconstruct()`), the act-order row scatter of `reconstruct`, and the cache
+  addressing around the codec (token ranges, paging).
 """
