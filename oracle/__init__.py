@@ -17,10 +17,14 @@ cites the reference file:line it follows.  Parity status:
   the quantized-KV-cache codec (`cuda/cache_q.cuh` run with 256 logical threads per block on a host
   fiber scheduler, `oracle/ref_build/simt_host.*`; fixture `tests/golden/reference_cache_q.npz`,
   generator `tests/golden/make_golden_cacheq.py`): codes, scales, dequantized values bit for bit;
+  `reconstruct()` itself (the text of `shuffle_kernel` + `reconstruct_kernel` extracted from
+  `cuda/q_matrix.cu` at build time into the git-ignored `oracle/_ref/`, run block by block with threads
+  as fibers; fixture `tests/golden/reference_reconstruct.npz`): `exl2_reconstruct` bit for bit on every
+  width / mix / act-order case;
   likewise the pure torch functions of the reference that run on CPU (group map, RMSNorm, attention,
   RoPE tables, MLP activation: `tests/golden/make_golden.py`);
 * **unpinned by execution, pinned by relation**: the multiply itself (the reference has no CPU q_gemm
-  and ships no golden vectors, SURVEY.md section 8c: `gemm(I) == reconstruct()`, one-hot rows at full
-  size, `gemm(x) ~ x @ reconstruct()`), the act-order row scatter of `reconstruct`, and the cache
-  addressing around the codec (token ranges, paging).
+  and ships no golden vectors; its semantics are `matmul(x, reconstruct())`:
+  `gemm(I) == reconstruct()`, one-hot rows at full size, `gemm(x) ~ x @ reconstruct()`), the GPTQ
+  reconstruct kernel beyond its decode step, and the cache addressing around the codec.
 """

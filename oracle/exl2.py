@@ -1,7 +1,8 @@
 """Oracle: EXL2 / GPTQ weight formats, reconstruct and q_gemm semantics (numpy).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Weight / scale / GPTQ decode: pinned by execution of the reference's
-qdq_*.cuh (tests/test_oracle_ref.py); the multiply and the row scatter: parity unpinned by execution, pinned by relation.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Weight / scale / GPTQ decode and exl2_reconstruct: pinned by
+execution of the reference's qdq_*.cuh and q_matrix.cu kernels (tests/test_oracle_ref.py); the multiply: parity unpinned
+by execution, pinned by relation to reconstruct.
 
 Reference files restated here (all under /root/reference/exllamav2/):
   * on-disk packing ............ exllamav2_ext/cuda/pack_tensor.cu:10-35 (pack_rows_4), :118-248 (pack_columns)

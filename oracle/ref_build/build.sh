@@ -8,6 +8,13 @@ REF=${EXL2_REFERENCE:-/root/reference}/exllamav2/exllamav2_ext
 OUT="$HERE/../_ref"
 [ -d "$REF/cuda/quant" ] || { echo "reference sources not found under $REF" >&2; exit 3; }
 mkdir -p "$OUT"
+# up to date?  (every output newer than the recipe's files and than the reference sources it compiles)
+if [ -z "$EXL2_REF_FORCE" ] && [ -f "$OUT/libqdq_ref.so" ] && [ -f "$OUT/libcacheq_ref.so" ] && [ -f "$OUT/libqmatrix_ref.so" ]; then
+    OLDEST=$(ls -t "$OUT"/libqdq_ref.so "$OUT"/libcacheq_ref.so "$OUT"/libqmatrix_ref.so | tail -1)
+    if [ -z "$(find "$HERE" "$REF/cuda/quant" "$REF/cuda/cache_q.cuh" "$REF/cuda/q_matrix.cu" "$REF/cuda/matrix_view.cuh" "$REF/config.h" -type f -newer "$OLDEST" 2>/dev/null | head -1)" ]; then
+        echo "oracle/_ref is up to date"; exit 0
+    fi
+fi
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
 $CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -I"$HERE" -I"$REF" -include "$HERE/cuda_shim.h" \
     "$HERE/qdq_driver.cpp" -o "$OUT/libqdq_ref.so"
@@ -16,3 +23,15 @@ echo "built $OUT/libqdq_ref.so"
 $CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -I"$HERE" -I"$REF" \
     "$HERE/cache_q_driver.cpp" "$HERE/simt_host.cpp" -o "$OUT/libcacheq_ref.so"
 echo "built $OUT/libcacheq_ref.so"
+# q_matrix.cu: the text of shuffle_kernel and reconstruct_kernel, extracted at build time into the git-ignored output
+# directory (the file as a whole needs nvcc / hipcc: kernel launch syntax, CUDA host API), then compiled with the headers
+# it uses straight from the reference tree
+QM="$REF/cuda/q_matrix.cu"
+{
+  awk '/^__global__ void shuffle_kernel/,/^}/' "$QM"
+  awk '/^__global__ void reconstruct_kernel/,/^}/' "$QM"
+} > "$OUT/q_matrix_kernels.inc"
+grep -q "shuffle_8bit_4" "$OUT/q_matrix_kernels.inc" && grep -q "b_q_group_map" "$OUT/q_matrix_kernels.inc" || { echo "kernel extraction failed" >&2; exit 4; }
+$CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -I"$HERE" -I"$HERE/stubs" -I"$REF" -I"$OUT" \
+    "$HERE/q_matrix_driver.cpp" "$HERE/simt_host.cpp" -o "$OUT/libqmatrix_ref.so"
+echo "built $OUT/libqmatrix_ref.so"

@@ -11,8 +11,6 @@
 struct int4 { int x, y, z, w; };
 static inline half2 __habs2(half2 a) { half2 r = {mk_half(fabs((double)a.x.v)), mk_half(fabs((double)a.y.v))}; return r; }
 static inline half __hmax(half a, half b) { return (double)a.v >= (double)b.v ? a : b; }
-static inline half __low2half(half2 a) { return a.x; }
-static inline half __high2half(half2 a) { return a.y; }
 static inline half2 __h2div(half2 a, half2 b) { half2 r = {mk_half((double)a.x.v / (double)b.x.v), mk_half((double)a.y.v / (double)b.y.v)}; return r; }
 static inline int __half2int_rn(half a) { return (int)nearbyint((double)a.v); }          // default mode: ties to even
 static inline half2 __float2half2_rn(float f) { half2 r = {mk_half(f), mk_half(f)}; return r; }

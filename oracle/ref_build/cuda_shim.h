@@ -37,6 +37,9 @@ static inline half2 __hadd2(half2 a, half2 b) { half2 r = {__hadd(a.x, b.x), __h
 static inline half2 __hsub2(half2 a, half2 b) { half2 r = {__hsub(a.x, b.x), __hsub(a.y, b.y)}; return r; }
 static inline half2 __hmul2(half2 a, half2 b) { half2 r = {__hmul(a.x, b.x), __hmul(a.y, b.y)}; return r; }
 static inline half2 __hfma2(half2 a, half2 b, half2 c) { half2 r = {__hfma(a.x, b.x, c.x), __hfma(a.y, b.y, c.y)}; return r; }
+static inline half __low2half(half2 a) { return a.x; }
+static inline half __high2half(half2 a) { return a.y; }
+static inline float __half2float(half a) { return (float)a.v; }
 // funnel shift right, clamped: the low 32 bits of (hi:lo) >> min(shift, 32)
 static inline uint32_t __funnelshift_rc(uint32_t lo, uint32_t hi, uint32_t shift)
 {

@@ -79,6 +79,20 @@ void fiber_main()
 }
 }  // namespace
 
+Dim block_idx = {0, 0, 0}, grid_dim = {1, 1, 1}, block_dim = {1, 1, 1};
+
+void run_grid(unsigned gx, unsigned gy, int nthreads, const std::function<void()>& kernel_call)
+{
+    grid_dim = {gx, gy, 1}; block_dim = {(unsigned)nthreads, 1, 1};
+    const int padded = (nthreads + 31) / 32 * 32;          // whole warps; the extra lanes do not call the kernel
+    for (unsigned by = 0; by < gy; by++)
+        for (unsigned bx = 0; bx < gx; bx++)
+        {
+            block_idx = {bx, by, 0};
+            run_block(padded, [&](int t) { if (t < nthreads) kernel_call(); });
+        }
+}
+
 int tid() { return cur; }
 
 void barrier(int group)

@@ -32,5 +32,20 @@ template <typename T> static inline T __shfl_down_sync(unsigned, T v, int delta)
     return simt_exchange(v, lane + delta < 32 ? lane + delta : lane);
 }
 static inline void __syncthreads() { simt::barrier(0); }
+
+// kernel coordinates for __global__ functions run through simt::run_grid
+namespace simt
+{
+struct Dim { unsigned x, y, z; };
+extern Dim block_idx, grid_dim, block_dim;
+static inline Dim thread_idx() { Dim d = {(unsigned)tid(), 0u, 0u}; return d; }
+// every block of the grid, one after the other, `nthreads` logical threads each
+void run_grid(unsigned gx, unsigned gy, int nthreads, const std::function<void()>& kernel_call);
+}
+#define threadIdx (simt::thread_idx())
+#define blockIdx  (simt::block_idx)
+#define gridDim   (simt::grid_dim)
+#define blockDim  (simt::block_dim)
+#define __global__ static
 #define __shared__ static
 #define __restrict__

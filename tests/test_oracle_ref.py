@@ -125,3 +125,49 @@ def test_live_reference_cache_codec_equals_oracle(wbits):
     fx = np.load(CACHE_FIXTURE)
     c0, s0 = G.pack_blocks(lib, wbits, fx["x"])
     assert np.array_equal(c0, fx[f"codes_{wbits}"]) and _same_f16(s0, fx[f"scales_{wbits}"])
+
+
+# ---- reconstruct(): the reference's shuffle_kernel + reconstruct_kernel executed on the host ----------------------------
+
+RECON_FIXTURE = os.path.join(ROOT, "tests", "golden", "reference_reconstruct.npz")
+
+
+def _recon_mod():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_reconstruct as G
+    return G
+
+
+@pytest.mark.parametrize("act_order", [False, True])
+def test_fixture_reconstruct_equals_oracle(act_order):
+    """oracle.exl2.exl2_reconstruct == the reference's own kernels, bit for bit: every bit width and mix, partial last
+    groups, with and without the act-order scatter (SHA-256 per case; two matrices stored in full)"""
+    import hashlib
+    G = _recon_mod()
+    fx = np.load(RECON_FIXTURE)
+    for name in G.CASES:
+        tag = f"{name}_{'act' if act_order else 'seq'}"
+        got = OX.exl2_reconstruct(G.case_tensors(name, act_order))
+        digest = np.frombuffer(hashlib.sha256(np.ascontiguousarray(got).tobytes()).digest(), dtype=np.uint8)
+        assert np.array_equal(digest, fx["sha256_" + tag]), tag
+        if "full_" + tag in fx.files:
+            assert np.array_equal(got.view(np.uint16), fx["full_" + tag].view(np.uint16)), tag
+
+
+def test_live_reference_reconstruct_equals_oracle():
+    if not os.path.isdir("/root/reference/exllamav2/exllamav2_ext/cuda"):
+        pytest.skip("reference sources not present on this machine (the committed fixture still pins the oracle)")
+    G = _recon_mod()
+    lib = G.load()
+    # fresh seeds, the shapes of tests/test_qmatrix.py (incl. the 2304-row matrix) and a wider one
+    from tests.test_qmatrix import SPECS
+    cases = [(k, n, spec, 900 + i, bool(i & 1)) for i, (k, n, spec) in enumerate(SPECS.values())]
+    cases.append((512, 384, [(6, 32, 64), (4, 64, 192), (3, 128, 256)], 77, True))
+    for k, n, spec, seed, act in cases:
+        t = OX.synth_exl2(k, n, spec, seed=seed, act_order=act)
+        want = G.reference_reconstruct(lib, t)
+        assert np.array_equal(OX.exl2_reconstruct(t).view(np.uint16), want.view(np.uint16)), (k, n, spec)
+    # and the fixture is what the script produces today
+    fx = np.load(RECON_FIXTURE)
+    out = G.reference_reconstruct(lib, G.case_tensors("mixed_all", True))
+    assert np.array_equal(out.view(np.uint16), fx["full_mixed_all_act"].view(np.uint16))
