@@ -8,7 +8,6 @@
 #include "simt_host.h"
 
 // the rest of the vocabulary cache_q.cuh needs
-struct int4 { int x, y, z, w; };
 static inline half2 __habs2(half2 a) { half2 r = {mk_half(fabs((double)a.x.v)), mk_half(fabs((double)a.y.v))}; return r; }
 static inline half __hmax(half a, half b) { return (double)a.v >= (double)b.v ? a : b; }
 static inline half2 __h2div(half2 a, half2 b) { half2 r = {mk_half((double)a.x.v / (double)b.x.v), mk_half((double)a.y.v / (double)b.y.v)}; return r; }

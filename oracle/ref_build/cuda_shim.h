@@ -40,6 +40,13 @@ static inline half2 __hfma2(half2 a, half2 b, half2 c) { half2 r = {__hfma(a.x, 
 static inline half __low2half(half2 a) { return a.x; }
 static inline half __high2half(half2 a) { return a.y; }
 static inline float __half2float(half a) { return (float)a.v; }
+static inline float __low2float(half2 a) { return (float)a.x.v; }
+static inline float __high2float(half2 a) { return (float)a.y.v; }
+struct int4 { int x, y, z, w; };
+// the reference's compat.cuh builds atomicAdd(half2*) from a CAS loop around __hadd2; blocks run one after the other on
+// the host, so the read-modify-write is simply sequential (one of the orders the GPU may produce)
+static inline void atomicAdd(half2* address, half2 val) { *address = __hadd2(*address, val); }
+static inline void atomicAdd(half* address, half val) { *address = __hadd(*address, val); }
 // funnel shift right, clamped: the low 32 bits of (hi:lo) >> min(shift, 32)
 static inline uint32_t __funnelshift_rc(uint32_t lo, uint32_t hi, uint32_t shift)
 {

@@ -81,16 +81,17 @@ void fiber_main()
 
 Dim block_idx = {0, 0, 0}, grid_dim = {1, 1, 1}, block_dim = {1, 1, 1};
 
-void run_grid(unsigned gx, unsigned gy, int nthreads, const std::function<void()>& kernel_call)
+void run_grid(unsigned gx, unsigned gy, int nthreads, const std::function<void()>& kernel_call, unsigned gz)
 {
-    grid_dim = {gx, gy, 1}; block_dim = {(unsigned)nthreads, 1, 1};
+    grid_dim = {gx, gy, gz}; block_dim = {(unsigned)nthreads, 1, 1};
     const int padded = (nthreads + 31) / 32 * 32;          // whole warps; the extra lanes do not call the kernel
-    for (unsigned by = 0; by < gy; by++)
-        for (unsigned bx = 0; bx < gx; bx++)
-        {
-            block_idx = {bx, by, 0};
-            run_block(padded, [&](int t) { if (t < nthreads) kernel_call(); });
-        }
+    for (unsigned bz = 0; bz < gz; bz++)                    // z outermost: slice z = 0 (which clears c) runs first
+        for (unsigned by = 0; by < gy; by++)
+            for (unsigned bx = 0; bx < gx; bx++)
+            {
+                block_idx = {bx, by, bz};
+                run_block(padded, [&](int t) { if (t < nthreads) kernel_call(); });
+            }
 }
 
 int tid() { return cur; }

@@ -40,7 +40,7 @@ struct Dim { unsigned x, y, z; };
 extern Dim block_idx, grid_dim, block_dim;
 static inline Dim thread_idx() { Dim d = {(unsigned)tid(), 0u, 0u}; return d; }
 // every block of the grid, one after the other, `nthreads` logical threads each
-void run_grid(unsigned gx, unsigned gy, int nthreads, const std::function<void()>& kernel_call);
+void run_grid(unsigned gx, unsigned gy, int nthreads, const std::function<void()>& kernel_call, unsigned gz = 1);
 }
 #define threadIdx (simt::thread_idx())
 #define blockIdx  (simt::block_idx)

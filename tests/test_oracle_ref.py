@@ -171,3 +171,59 @@ def test_live_reference_reconstruct_equals_oracle():
     fx = np.load(RECON_FIXTURE)
     out = G.reference_reconstruct(lib, G.case_tensors("mixed_all", True))
     assert np.array_equal(out.view(np.uint16), fx["full_mixed_all_act"].view(np.uint16))
+
+
+# ---- q_gemm: the reference's decode GEMV kernel executed on the host -----------------------------------------------------
+
+GEMM_FIXTURE = os.path.join(ROOT, "tests", "golden", "reference_q_gemm.npz")
+
+
+def _gemm_mod():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_qgemm as G
+    return G
+
+
+def test_reference_kernel_within_stated_tolerance_and_ours_at_least_as_close(be):
+    """The yardstick for q_gemm is measured, not chosen: the reference's own kernel (fp16 partial sums, split-K) lands
+    1e-3 .. 5e-3 away from matmul(a, reconstruct()) on these shapes.  (i) that distance is inside the tolerance the
+    parity tests state; (ii) this repository's q_gemm, on the same tensors and activations, is at least as close to
+    matmul(a, reconstruct()) as the reference's kernel is (fp32 partial sums: in fact several times closer)."""
+    import torch
+    from tests.util import exl2_to_torch, half_tol
+    G = _gemm_mod()
+    fx = np.load(GEMM_FIXTURE)
+    for name, m in G.GEMM_CASES:
+        t = G.R.case_tensors(name, True)
+        a = G.activations(name, m)
+        k = a.shape[1]
+        want = a.astype(np.float64) @ OX.exl2_reconstruct(t).astype(np.float64)
+        e_ref = max(np.abs(fx[f"c_{name}_{m}_{bk}"].astype(np.float64) - want).max() for bk in (32, 64))
+        assert e_ref <= 4 * float(half_tol(want, k).max()), (name, m, e_ref)             # (i): same order as the stated bar
+        w = exl2_to_torch(be, t)                                   # stays alive: the handle keeps raw pointers into it
+        h = be.ext.make_q_matrix_from_dict(w, None)
+        c = torch.zeros((m, want.shape[1]), dtype=torch.float16, device=be.device)
+        be.ext.gemm_half_q_half(be.t(a), h, c)
+        e_ours = np.abs(be.n(c).astype(np.float64) - want).max()
+        be.ext.free_q_matrix(h)
+        assert e_ours <= e_ref, (name, m, e_ours, e_ref)                                 # (ii)
+
+
+def test_live_reference_gemm_reproduces_fixture():
+    if not os.path.isdir("/root/reference/exllamav2/exllamav2_ext/cuda"):
+        pytest.skip("reference sources not present on this machine (the committed fixture is still used)")
+    G = _gemm_mod()
+    lib = G.load()
+    fx = np.load(GEMM_FIXTURE)
+    for name, m in G.GEMM_CASES[:3]:
+        got = G.reference_gemm(lib, G.R.case_tensors(name, True), G.activations(name, m), 64)
+        assert np.array_equal(got.view(np.uint16), fx[f"c_{name}_{m}_64"].view(np.uint16))
+    # one-hot rows through the reference kernel return rows of the reference reconstruct(): the gemm(I) == reconstruct()
+    # relation of its own tests/test_gemv.py, executed
+    t = G.R.case_tensors("mixed_all", True)
+    k = G.R.CASES["mixed_all"][0]
+    a = np.zeros((4, k), dtype=np.float16)
+    rows = [0, 37, 401, k - 1]
+    for i, r in enumerate(rows): a[i, r] = 1.0
+    got = G.reference_gemm(lib, t, a, 32)
+    assert np.array_equal(got.view(np.uint16), OX.exl2_reconstruct(t)[rows].view(np.uint16))
