@@ -21,6 +21,8 @@ cites the reference file:line it follows.  Parity status:
   `cuda/q_matrix.cu` at build time into the git-ignored `oracle/_ref/`, run block by block with threads
   as fibers; fixture `tests/golden/reference_reconstruct.npz`): `exl2_reconstruct` bit for bit on every
   width / mix / act-order case;
+  the decode GEMV kernel `gemm_half_q_half_kernel` (header template, included as it lies) as the
+  measured yardstick for the q_gemm tolerance (`tests/golden/reference_q_gemm.npz`);
   likewise the pure torch functions of the reference that run on CPU (group map, RMSNorm, attention,
   RoPE tables, MLP activation: `tests/golden/make_golden.py`);
 * **unpinned by execution, pinned by relation**: the multiply itself (the reference has no CPU q_gemm
