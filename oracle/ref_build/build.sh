@@ -23,13 +23,15 @@ echo "built $OUT/libqdq_ref.so"
 $CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -I"$HERE" -I"$REF" \
     "$HERE/cache_q_driver.cpp" "$HERE/simt_host.cpp" -o "$OUT/libcacheq_ref.so"
 echo "built $OUT/libcacheq_ref.so"
-# q_matrix.cu: the text of shuffle_kernel and reconstruct_kernel, extracted at build time into the git-ignored output
+# q_matrix.cu: the text of shuffle_kernel, reconstruct_kernel, reconstruct_gptq_kernel and make_sequential_kernel, extracted at build time into the git-ignored output
 # directory (the file as a whole needs nvcc / hipcc: kernel launch syntax, CUDA host API), then compiled with the headers
 # it uses straight from the reference tree
 QM="$REF/cuda/q_matrix.cu"
 {
   awk '/^__global__ void shuffle_kernel/,/^}/' "$QM"
   awk '/^__global__ void reconstruct_kernel/,/^}/' "$QM"
+  awk '/^__global__ void reconstruct_gptq_kernel/,/^}/' "$QM"
+  awk '/^__global__ void make_sequential_kernel/,/^}/' "$QM"
 } > "$OUT/q_matrix_kernels.inc"
 grep -q "shuffle_8bit_4" "$OUT/q_matrix_kernels.inc" && grep -q "b_q_group_map" "$OUT/q_matrix_kernels.inc" || { echo "kernel extraction failed" >&2; exit 4; }
 $CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -Wno-pass-failed -I"$HERE" -I"$HERE/stubs" -I"$REF" -I"$OUT" \

@@ -5,7 +5,7 @@ oracle/ref_build/build.sh extracts the text of shuffle_kernel and reconstruct_ke
 exllamav2_ext/cuda/q_matrix.cu (where it lies under /root/reference; into the git-ignored oracle/_ref/) and compiles it,
 with matrix_view.cuh and quant/qdq_*.cuh straight from the reference tree, for the host: blocks run one after the other,
 their threads as fibers (oracle/ref_build/simt_host.*).  For seeded EXL2 tensor sets of every bit width and mix, with and
-without act-order, this script records the reference's reconstruct() output: SHA-256 of the fp16 matrix for every case,
+without act-order, this script records the reference's reconstruct() output (EXL2, and GPTQ 4-bit incl. act-order g_idx): SHA-256 of the fp16 matrix for every case,
 the full matrix for two small ones.  tests/test_oracle_ref.py checks oracle.exl2.exl2_reconstruct against it.
 
 Run from the repo root:  python tests/golden/make_golden_reconstruct.py
@@ -32,6 +32,8 @@ CASES = {
     "mixed_5_4": (1024, 64, [(5, 128, 128), (4, 128, 896)]),
 }
 FULL = ("b4_tail", "mixed_all")
+# GPTQ 4-bit: (K, N, group size, act-order)
+GPTQ_CASES = [(256, 32, 128, False), (256, 32, 64, True), (384, 48, 128, True), (160, 16, 32, False), (1024, 128, 128, True)]
 
 
 def load():
@@ -40,7 +42,34 @@ def load():
     lib = ctypes.CDLL(LIB)
     lib.ref_exl2_reconstruct.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
     lib.ref_exl2_reconstruct.restype = ctypes.c_int
+    lib.ref_gptq_reconstruct.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    lib.ref_gptq_reconstruct.restype = ctypes.c_int
     return lib
+
+
+def reference_gptq_reconstruct(lib, t: dict) -> np.ndarray:
+    """GPTQ tensors -> fp16 [K, N] by the reference's make_sequential_kernel (act-order), shuffle_kernel and
+    reconstruct_gptq_kernel.  The row order handed to them is the stable counting sort of g_idx that make_sequential's
+    host loop computes (q_matrix.cu:606-642), restated in oracle.exl2.gptq_sequential_perm."""
+    from oracle import exl2 as OX
+    qw = np.ascontiguousarray(t["qweight"]).view(np.uint32).copy()
+    k, n = qw.shape[0] * 8, qw.shape[1]
+    groups = t["qzeros"].shape[0]
+    g_idx = np.asarray(t["g_idx"])
+    sequential = np.array_equal(g_idx, np.arange(k) // (k // groups))
+    perm = None if sequential else OX.gptq_sequential_perm(g_idx, groups)[0].astype(np.uint16)
+    qz = np.ascontiguousarray(t["qzeros"]).view(np.uint32).copy()
+    sc = np.ascontiguousarray(t["scales"]).view(np.uint16).copy()
+    out = np.zeros((k, n), dtype=np.uint16)
+    assert lib.ref_gptq_reconstruct(qw.ctypes.data, None if perm is None else perm.ctypes.data, qz.ctypes.data,
+                                    sc.ctypes.data, k, n, groups, out.ctypes.data) == 0
+    return out.view(np.float16)
+
+
+def gptq_tensors(case) -> dict:
+    from oracle import exl2 as OX
+    k, n, gs, act = case
+    return OX.synth_gptq(k, n, gs, seed=43, act_order=act)
 
 
 def reference_reconstruct(lib, t: dict) -> np.ndarray:
@@ -81,6 +110,10 @@ def main():
             fx["sha256_" + tag] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest(), dtype=np.uint8)
             if name in FULL and act:
                 fx["full_" + tag] = out
+    for case in GPTQ_CASES:
+        out = reference_gptq_reconstruct(lib, gptq_tensors(case))
+        tag = "gptq_%d_%d_%d_%s" % (case[0], case[1], case[2], "act" if case[3] else "seq")
+        fx["sha256_" + tag] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest(), dtype=np.uint8)
     path = os.path.join(ROOT, "tests", "golden", "reference_reconstruct.npz")
     np.savez_compressed(path, **fx)
     print(f"wrote {path} ({os.path.getsize(path)} bytes)")

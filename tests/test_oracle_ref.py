@@ -154,6 +154,27 @@ def test_fixture_reconstruct_equals_oracle(act_order):
             assert np.array_equal(got.view(np.uint16), fx["full_" + tag].view(np.uint16)), tag
 
 
+def test_fixture_gptq_reconstruct_equals_oracle():
+    import hashlib
+    G = _recon_mod()
+    fx = np.load(RECON_FIXTURE)
+    for case in G.GPTQ_CASES:
+        tag = "gptq_%d_%d_%d_%s" % (case[0], case[1], case[2], "act" if case[3] else "seq")
+        got = OX.gptq_reconstruct(G.gptq_tensors(case))
+        digest = np.frombuffer(hashlib.sha256(np.ascontiguousarray(got).tobytes()).digest(), dtype=np.uint8)
+        assert np.array_equal(digest, fx["sha256_" + tag]), tag
+
+
+def test_live_reference_gptq_reconstruct_equals_oracle():
+    if not os.path.isdir("/root/reference/exllamav2/exllamav2_ext/cuda"):
+        pytest.skip("reference sources not present on this machine (the committed fixture still pins the oracle)")
+    G = _recon_mod()
+    lib = G.load()
+    for i, (k, n, gs, act) in enumerate([(512, 64, 128, True), (256, 32, 32, True), (640, 96, 128, False)]):
+        t = OX.synth_gptq(k, n, gs, seed=500 + i, act_order=act)
+        assert np.array_equal(OX.gptq_reconstruct(t).view(np.uint16), G.reference_gptq_reconstruct(lib, t).view(np.uint16))
+
+
 def test_live_reference_reconstruct_equals_oracle():
     if not os.path.isdir("/root/reference/exllamav2/exllamav2_ext/cuda"):
         pytest.skip("reference sources not present on this machine (the committed fixture still pins the oracle)")
