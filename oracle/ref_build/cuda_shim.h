@@ -47,6 +47,8 @@ struct int4 { int x, y, z, w; };
 // the host, so the read-modify-write is simply sequential (one of the orders the GPU may produce)
 static inline void atomicAdd(half2* address, half2 val) { *address = __hadd2(*address, val); }
 static inline void atomicAdd(half* address, half val) { *address = __hadd(*address, val); }
+static inline half2 __hneg2(half2 a) { half2 r = {mk_half(-(double)a.x.v), mk_half(-(double)a.y.v)}; return r; }
+static inline half2 __lowhigh2highlow(half2 a) { half2 r = {a.y, a.x}; return r; }
 // funnel shift right, clamped: the low 32 bits of (hi:lo) >> min(shift, 32)
 static inline uint32_t __funnelshift_rc(uint32_t lo, uint32_t hi, uint32_t shift)
 {

@@ -81,9 +81,11 @@ void fiber_main()
 
 Dim block_idx = {0, 0, 0}, grid_dim = {1, 1, 1}, block_dim = {1, 1, 1};
 
-void run_grid(unsigned gx, unsigned gy, int nthreads, const std::function<void()>& kernel_call, unsigned gz)
+void run_grid(unsigned gx, unsigned gy, int nthreads, const std::function<void()>& kernel_call, unsigned gz, unsigned block_dim_x)
 {
-    grid_dim = {gx, gy, gz}; block_dim = {(unsigned)nthreads, 1, 1};
+    grid_dim = {gx, gy, gz};
+    if (block_dim_x) block_dim = {block_dim_x, (unsigned)nthreads / block_dim_x, 1};
+    else block_dim = {(unsigned)nthreads, 1, 1};
     const int padded = (nthreads + 31) / 32 * 32;          // whole warps; the extra lanes do not call the kernel
     for (unsigned bz = 0; bz < gz; bz++)                    // z outermost: slice z = 0 (which clears c) runs first
         for (unsigned by = 0; by < gy; by++)

@@ -38,9 +38,12 @@ namespace simt
 {
 struct Dim { unsigned x, y, z; };
 extern Dim block_idx, grid_dim, block_dim;
-static inline Dim thread_idx() { Dim d = {(unsigned)tid(), 0u, 0u}; return d; }
+// blocks are launched with a linear thread count; block_dim.x (set by run_grid: the whole count unless block_dim_x is
+// given) folds it into (x, y) for kernels written for 2-D blocks
+static inline Dim thread_idx() { Dim d = {(unsigned)tid() % block_dim.x, (unsigned)tid() / block_dim.x, 0u}; return d; }
 // every block of the grid, one after the other, `nthreads` logical threads each
-void run_grid(unsigned gx, unsigned gy, int nthreads, const std::function<void()>& kernel_call, unsigned gz = 1);
+void run_grid(unsigned gx, unsigned gy, int nthreads, const std::function<void()>& kernel_call, unsigned gz = 1,
+              unsigned block_dim_x = 0);
 }
 #define threadIdx (simt::thread_idx())
 #define blockIdx  (simt::block_idx)

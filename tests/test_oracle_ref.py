@@ -248,3 +248,37 @@ def test_live_reference_gemm_reproduces_fixture():
     for i, r in enumerate(rows): a[i, r] = 1.0
     got = G.reference_gemm(lib, t, a, 32)
     assert np.array_equal(got.view(np.uint16), OX.exl2_reconstruct(t)[rows].view(np.uint16))
+
+
+# ---- RoPE: the reference's rope_cuda_arr_neox / rope_cuda_arr_gptj executed on the host --------------------------------
+
+ROPE_FIXTURE = os.path.join(ROOT, "tests", "golden", "reference_rope.npz")
+
+
+def _rope_mod():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_rope as G
+    return G
+
+
+def test_fixture_rope_equals_oracle():
+    """oracle.modules.rope_ == the reference's rotation, bit for bit: NeoX and GPT-J style, scalar past_len and
+    per-sequence past_lens, head_dim 64 / 128 / 256"""
+    from oracle import modules as OM
+    G = _rope_mod()
+    fx = np.load(ROPE_FIXTURE)
+    for i, (b, s, nh, hd, past, lens, neox) in enumerate(G.CASES):
+        x, sin, cos = G.inputs(i)
+        pos = np.full((b,), past) + (0 if lens is None else np.array(lens))
+        got = OM.rope_(x, sin, cos, pos, neox)
+        assert np.array_equal(got.view(np.uint16), fx[f"out_{i}"].view(np.uint16)), i
+
+
+def test_live_reference_rope_reproduces_fixture():
+    if not os.path.isdir("/root/reference/exllamav2/exllamav2_ext/cuda"):
+        pytest.skip("reference sources not present on this machine (the committed fixture still pins the oracle)")
+    G = _rope_mod()
+    lib = G.load()
+    fx = np.load(ROPE_FIXTURE)
+    for i in range(len(G.CASES)):
+        assert np.array_equal(G.reference_rope(lib, i).view(np.uint16), fx[f"out_{i}"].view(np.uint16))
