@@ -16,7 +16,9 @@ cites the reference file:line it follows.  Parity status:
   checks `oracle/exl2.py` against that fixture everywhere and against the live library here;
   the quantized-KV-cache codec (`cuda/cache_q.cuh` run with 256 logical threads per block on a host
   fiber scheduler, `oracle/ref_build/simt_host.*`; fixture `tests/golden/reference_cache_q.npz`,
-  generator `tests/golden/make_golden_cacheq.py`): codes, scales, dequantized values bit for bit;
+  generator `tests/golden/make_golden_cacheq.py`): codes, scales, dequantized values bit for bit; the
+  paged / contiguous addressing kernels of `cuda/cache.cu` around it
+  (`tests/golden/reference_cache_addressing.npz`);
   `reconstruct()` itself (the text of `shuffle_kernel` + `reconstruct_kernel` extracted from
   `cuda/q_matrix.cu` at build time into the git-ignored `oracle/_ref/`, run block by block with threads
   as fibers; fixture `tests/golden/reference_reconstruct.npz`): `exl2_reconstruct` bit for bit on every
@@ -28,6 +30,6 @@ cites the reference file:line it follows.  Parity status:
   RoPE tables, MLP activation: `tests/golden/make_golden.py`);
 * **unpinned by execution, pinned by relation**: the multiply itself (the reference has no CPU q_gemm
   and ships no golden vectors; its semantics are `matmul(x, reconstruct())`:
-  `gemm(I) == reconstruct()`, one-hot rows at full size, `gemm(x) ~ x @ reconstruct()`), the GPTQ
-  reconstruct kernel beyond its decode step, and the cache addressing around the codec.
+  `gemm(I) == reconstruct()`, one-hot rows at full size, `gemm(x) ~ x @ reconstruct()`, with the
+  reference kernel's own error as the yardstick) and the fused module kernels (compositions).
 """

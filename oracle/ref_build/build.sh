@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 # up to date?  (every output newer than the recipe's files and than the reference sources it compiles)
 if [ -z "$EXL2_REF_FORCE" ] && [ -f "$OUT/libqdq_ref.so" ] && [ -f "$OUT/libcacheq_ref.so" ] && [ -f "$OUT/libqmatrix_ref.so" ] && [ -f "$OUT/librope_ref.so" ]; then
     OLDEST=$(ls -t "$OUT"/libqdq_ref.so "$OUT"/libcacheq_ref.so "$OUT"/libqmatrix_ref.so "$OUT"/librope_ref.so | tail -1)
-    if [ -z "$(find "$HERE" "$REF/cuda/quant" "$REF/cuda/cache_q.cuh" "$REF/cuda/q_matrix.cu" "$REF/cuda/rope.cu" "$REF/cuda/q_gemm_kernel.cuh" "$REF/cuda/matrix_view.cuh" "$REF/config.h" -type f -newer "$OLDEST" 2>/dev/null | head -1)" ]; then
+    if [ -z "$(find "$HERE" "$REF/cuda/quant" "$REF/cuda/cache_q.cuh" "$REF/cuda/cache.cu" "$REF/cuda/q_matrix.cu" "$REF/cuda/rope.cu" "$REF/cuda/q_gemm_kernel.cuh" "$REF/cuda/matrix_view.cuh" "$REF/config.h" -type f -newer "$OLDEST" 2>/dev/null | head -1)" ]; then
         echo "oracle/_ref is up to date"; exit 0
     fi
 fi
@@ -20,7 +20,14 @@ $CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -I"$HERE" -I"$REF" -include 
     "$HERE/qdq_driver.cpp" -o "$OUT/libqdq_ref.so"
 echo "built $OUT/libqdq_ref.so"
 # the quantized-KV-cache codec (cuda/cache_q.cuh): 256 logical threads per 512-element block, run as fibers
-$CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -I"$HERE" -I"$REF" \
+CC_="$REF/cuda/cache.cu"
+: > "$OUT/cache_kernels.inc"
+for KN in fp16_to_q_kv_paged_kernel fp16_to_q_kv_kernel q_to_fp16_kv_paged_kernel q_to_fp16_kv_kernel; do
+  echo "template <int wbits_k, int wbits_v>" >> "$OUT/cache_kernels.inc"
+  awk "/^__global__ void $KN\$/,/^}/" "$CC_" >> "$OUT/cache_kernels.inc"
+done
+grep -q "cache_seqlens\[y\]" "$OUT/cache_kernels.inc" || { echo "cache kernel extraction failed" >&2; exit 4; }
+$CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -I"$HERE" -I"$REF" -I"$OUT" \
     "$HERE/cache_q_driver.cpp" "$HERE/simt_host.cpp" -o "$OUT/libcacheq_ref.so"
 echo "built $OUT/libcacheq_ref.so"
 # q_matrix.cu: the text of shuffle_kernel, reconstruct_kernel, reconstruct_gptq_kernel and make_sequential_kernel, extracted at build time into the git-ignored output

@@ -18,8 +18,18 @@ template <typename T> static inline T __ldg(const T* p) { return *p; }
 template <typename T> static inline void __stcg(T* p, T v) { *p = v; }
 template <typename T> static inline void __stwb(T* p, T v) { *p = v; }
 
-#define BLOCKSIZE_Q 512
+#include "config.h"
+#include <algorithm>
+using std::min;
+using std::max;
+#define BLOCKSIZE_Q Q_CACHE_BLOCKSIZE_Q
+#define SUPER_BLOCKSIZE_Q Q_CACHE_SUPER_BLOCKSIZE_Q
+#define THREADS_Q (BLOCKSIZE_Q / 2)
 #include "cuda/cache_q.cuh"
+
+// the four addressing kernels of cuda/cache.cu (:143-223 pack, :324-400 unpack; paged and contiguous): text extracted by
+// build.sh at build time into the git-ignored oracle/_ref/cache_kernels.inc (cache.cu itself has launch syntax)
+#include "cache_kernels.inc"
 
 extern "C" {
 
@@ -49,6 +59,67 @@ int ref_cache_q_to_fp16(int wbits, const uint8_t* in, const uint16_t* scales, ui
         else            q_to_fp16<8>(t, a_in, (const half*)a_s, (half*)a_out, 0, 512);
     });
     memcpy(out, a_out, sizeof(a_out));
+    return 0;
+}
+
+// array_fp16_to_q_kv_paged_cuda / array_q_to_fp16_kv_paged_cuda (cache.cu:225-260, 402-440): grid (pages_per_seq,
+// SUPER_BLOCKSIZE_Q / BLOCKSIZE_Q, 2 * batch), THREADS_Q threads.  dir 0 = fp16 -> q (append q_len tokens at
+// cache_seqlens), 1 = q -> fp16 (everything valid).  wbits 4 | 6 | 8 as in the reference (6 = 8-bit keys, 4-bit values).
+int ref_cache_paged(int dir, int wbits, void* k_a, void* k_b, void* k_scales, void* v_a, void* v_b, void* v_scales,
+                    int batch, int dim, int pages_per_seq, const int* cache_seqlens, const int* block_table, int page_size, int q_len)
+{
+    if (wbits != 4 && wbits != 6 && wbits != 8) return -1;
+    auto launch = [&](auto kernel_call) { simt::run_grid(pages_per_seq, SUPER_BLOCKSIZE_Q / BLOCKSIZE_Q, THREADS_Q, kernel_call, batch * 2); };
+    if (dir == 0)
+    {
+        const half* ki = (const half*)k_a; unsigned char* ko = (unsigned char*)k_b; half* ks = (half*)k_scales;
+        const half* vi = (const half*)v_a; unsigned char* vo = (unsigned char*)v_b; half* vs = (half*)v_scales;
+        if (wbits == 4) launch([&]() { fp16_to_q_kv_paged_kernel<4, 4>(ki, ko, ks, vi, vo, vs, cache_seqlens, block_table, pages_per_seq, page_size, dim, q_len); });
+        else if (wbits == 6) launch([&]() { fp16_to_q_kv_paged_kernel<8, 4>(ki, ko, ks, vi, vo, vs, cache_seqlens, block_table, pages_per_seq, page_size, dim, q_len); });
+        else launch([&]() { fp16_to_q_kv_paged_kernel<8, 8>(ki, ko, ks, vi, vo, vs, cache_seqlens, block_table, pages_per_seq, page_size, dim, q_len); });
+    }
+    else
+    {
+        const unsigned char* ki = (const unsigned char*)k_a; half* ko = (half*)k_b; const half* ks = (const half*)k_scales;
+        const unsigned char* vi = (const unsigned char*)v_a; half* vo = (half*)v_b; const half* vs = (const half*)v_scales;
+        if (wbits == 4) launch([&]() { q_to_fp16_kv_paged_kernel<4, 4>(ki, ks, ko, vi, vs, vo, cache_seqlens, block_table, pages_per_seq, page_size, dim); });
+        else if (wbits == 6) launch([&]() { q_to_fp16_kv_paged_kernel<8, 4>(ki, ks, ko, vi, vs, vo, cache_seqlens, block_table, pages_per_seq, page_size, dim); });
+        else launch([&]() { q_to_fp16_kv_paged_kernel<8, 8>(ki, ks, ko, vi, vs, vo, cache_seqlens, block_table, pages_per_seq, page_size, dim); });
+    }
+    return 0;
+}
+
+// contiguous: fp16_to_q_kv / q_to_fp16_kv's non-paged branch (ext_cache.cpp:139-171: token range widened to whole
+// 512-element blocks, then elements) + array_*_cuda (cache.cu:262-322, 442-497): grid (width / 512, batch, 2)
+int ref_cache_contiguous(int dir, int wbits, void* k_a, void* k_b, void* k_scales, void* v_a, void* v_b, void* v_scales,
+                         int batch, int dim, int seq_tokens, int offset_tokens, int width_tokens)
+{
+    if (wbits != 4 && wbits != 6 && wbits != 8) return -1;
+    int offset = offset_tokens, width = width_tokens;
+    if (dim % Q_CACHE_BLOCKSIZE_Q)
+    {
+        while ((offset * dim) % Q_CACHE_BLOCKSIZE_Q) offset--;
+        while ((width * dim) % Q_CACHE_BLOCKSIZE_Q) width++;
+    }
+    offset *= dim; width *= dim;
+    const int stride = seq_tokens * dim;
+    auto launch = [&](auto kernel_call) { simt::run_grid(width / BLOCKSIZE_Q, batch, THREADS_Q, kernel_call, 2); };
+    if (dir == 0)
+    {
+        const half* ki = (const half*)k_a; unsigned char* ko = (unsigned char*)k_b; half* ks = (half*)k_scales;
+        const half* vi = (const half*)v_a; unsigned char* vo = (unsigned char*)v_b; half* vs = (half*)v_scales;
+        if (wbits == 4) launch([&]() { fp16_to_q_kv_kernel<4, 4>(ki, ko, ks, vi, vo, vs, dim, offset, stride); });
+        else if (wbits == 6) launch([&]() { fp16_to_q_kv_kernel<8, 4>(ki, ko, ks, vi, vo, vs, dim, offset, stride); });
+        else launch([&]() { fp16_to_q_kv_kernel<8, 8>(ki, ko, ks, vi, vo, vs, dim, offset, stride); });
+    }
+    else
+    {
+        const unsigned char* ki = (const unsigned char*)k_a; half* ko = (half*)k_b; const half* ks = (const half*)k_scales;
+        const unsigned char* vi = (const unsigned char*)v_a; half* vo = (half*)v_b; const half* vs = (const half*)v_scales;
+        if (wbits == 4) launch([&]() { q_to_fp16_kv_kernel<4, 4>(ki, ks, ko, vi, vs, vo, dim, offset, stride); });
+        else if (wbits == 6) launch([&]() { q_to_fp16_kv_kernel<8, 4>(ki, ks, ko, vi, vs, vo, dim, offset, stride); });
+        else launch([&]() { q_to_fp16_kv_kernel<8, 8>(ki, ks, ko, vi, vs, vo, dim, offset, stride); });
+    }
     return 0;
 }
 

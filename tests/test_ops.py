@@ -532,3 +532,75 @@ def test_q8_q6_cache_contiguous_roundtrip(be, wbits):
         assert np.array_equal(be.n(vo)[i, 2:6].reshape(-1).view(np.uint16), want_v.view(np.uint16))
     errk = np.abs(be.n(ko)[:, 2:6].astype(np.float32) - k[:, 2:6].astype(np.float32))
     assert errk.max() < 0.05                                                      # 8-bit keys: step = absmax / 128
+
+
+# ---- cache addressing against the EXECUTED reference kernels (tests/golden/make_golden_cache_paged.py) -------------------
+
+def _cache_golden():
+    import os, sys
+    from tests.conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_cache_paged as G
+    return G, np.load(os.path.join(ROOT, "tests", "golden", "reference_cache_addressing.npz"))
+
+
+def _check_pack(be, got, fx, tag):
+    """scales (hence the set of written 512-element blocks) bit for bit; codes identical outside fp16 division ties;
+    nothing written where the reference writes nothing"""
+    kq, ks, vq, vs = (be.n(t) for t in got)
+    for name, g in (("kq", kq), ("ks", ks), ("vq", vq), ("vs", vs)):
+        want = fx[f"{tag}_{name}"]
+        if name in ("ks", "vs"):
+            assert np.array_equal(g.view(np.uint16), want.view(np.uint16)), (tag, name)
+        else:
+            written = np.repeat((fx[f"{tag}_{name[0]}s"].view(np.uint16) != 0), g.shape[-1] // fx[f"{tag}_{name[0]}s"].shape[-1], axis=-1)
+            assert np.all(g[~written] == 0), (tag, name)
+            assert (g[written] == want[written]).mean() >= 0.999, (tag, name)
+
+
+def _sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+@pytest.mark.hip_unverified
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_paged_cache_addressing_equals_reference_kernels(be, i):
+    G, fx = _cache_golden()
+    wbits, pages, kvh, hd, q_len, seqlens, table = G.PAGED[i]
+    k, v = G.kv_inputs(f"paged{i}", (pages, G.PS, kvh, hd))
+    kb, vb = G.code_bytes(wbits, hd)
+    kq = torch.zeros((pages, G.PS, kvh, kb), dtype=torch.uint8, device=be.device)
+    vq = torch.zeros((pages, G.PS, kvh, vb), dtype=torch.uint8, device=be.device)
+    ks = torch.zeros((pages, G.PS, kvh, hd // 32), dtype=torch.float16, device=be.device)
+    vs = torch.zeros_like(ks)
+    sl, bt = np.array(seqlens, np.int32), np.array(table, np.int32)
+    be.ext.fp16_to_q_kv(be.t(k), kq, ks, be.t(v), vq, vs, len(seqlens), 0, q_len, G.PS, be.t(sl), be.t(bt), wbits)
+    _check_pack(be, (kq, ks, vq, vs), fx, f"paged{i}")
+    qk, qks, qv, qvs = G.q_inputs(f"paged{i}", wbits, (pages, G.PS), kvh, hd)
+    ko = torch.zeros((pages, G.PS, kvh, hd), dtype=torch.float16, device=be.device)
+    vo = torch.zeros_like(ko)
+    be.ext.q_to_fp16_kv(be.t(qk), ko, be.t(qks), be.t(qv), vo, be.t(qvs), len(seqlens), 0, 0, G.PS,
+                        be.t((sl + q_len).astype(np.int32)), be.t(bt), wbits)
+    assert np.array_equal(_sha(be.n(ko)), fx[f"paged{i}_ko_sha"]) and np.array_equal(_sha(be.n(vo)), fx[f"paged{i}_vo_sha"])
+
+
+@pytest.mark.hip_unverified
+@pytest.mark.parametrize("i", [0, 1, 2, 3])
+def test_contiguous_cache_addressing_equals_reference_kernels(be, i):
+    from exllamav2_amd.ext import none_tensor
+    G, fx = _cache_golden()
+    wbits, b, T, kvh, hd, offset, width = G.CONTIG[i]
+    k, v = G.kv_inputs(f"contig{i}", (b, T, kvh, hd))
+    kb, vb = G.code_bytes(wbits, hd)
+    kq = torch.zeros((b, T, kvh, kb), dtype=torch.uint8, device=be.device)
+    vq = torch.zeros((b, T, kvh, vb), dtype=torch.uint8, device=be.device)
+    ks = torch.zeros((b, T, kvh, hd // 32), dtype=torch.float16, device=be.device)
+    vs = torch.zeros_like(ks)
+    be.ext.fp16_to_q_kv(be.t(k), kq, ks, be.t(v), vq, vs, b, offset, width, 0, none_tensor, none_tensor, wbits)
+    _check_pack(be, (kq, ks, vq, vs), fx, f"contig{i}")
+    qk, qks, qv, qvs = G.q_inputs(f"contig{i}", wbits, (b, T), kvh, hd)
+    ko = torch.zeros((b, T, kvh, hd), dtype=torch.float16, device=be.device)
+    vo = torch.zeros_like(ko)
+    be.ext.q_to_fp16_kv(be.t(qk), ko, be.t(qks), be.t(qv), vo, be.t(qvs), b, offset, width, 0, none_tensor, none_tensor, wbits)
+    assert np.array_equal(_sha(be.n(ko)), fx[f"contig{i}_ko_sha"]) and np.array_equal(_sha(be.n(vo)), fx[f"contig{i}_vo_sha"])
