@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 # up to date?  (every output newer than the recipe's files and than the reference sources it compiles)
 if [ -z "$EXL2_REF_FORCE" ] && [ -f "$OUT/libqdq_ref.so" ] && [ -f "$OUT/libcacheq_ref.so" ] && [ -f "$OUT/libqmatrix_ref.so" ] && [ -f "$OUT/librope_ref.so" ] && [ -f "$OUT/librmsnorm_ref.so" ]; then
     OLDEST=$(ls -t "$OUT"/libqdq_ref.so "$OUT"/libcacheq_ref.so "$OUT"/libqmatrix_ref.so "$OUT"/librope_ref.so "$OUT"/librmsnorm_ref.so | tail -1)
-    if [ -z "$(find "$HERE" "$REF/cuda/quant" "$REF/cuda/cache_q.cuh" "$REF/cuda/cache.cu" "$REF/cuda/q_matrix.cu" "$REF/cuda/rope.cu" "$REF/cuda/rms_norm.cu" "$REF/cuda/q_gemm_kernel.cuh" "$REF/cuda/matrix_view.cuh" "$REF/config.h" -type f -newer "$OLDEST" 2>/dev/null | head -1)" ]; then
+    if [ -z "$(find "$HERE" "$REF/cuda/quant" "$REF/cuda/cache_q.cuh" "$REF/cuda/cache.cu" "$REF/cuda/q_matrix.cu" "$REF/cuda/rope.cu" "$REF/cuda/rms_norm.cu" "$REF/cuda/q_gemm_kernel.cuh" "$REF/cuda/q_gemm_kernel_gptq.cuh" "$REF/cuda/matrix_view.cuh" "$REF/config.h" -type f -newer "$OLDEST" 2>/dev/null | head -1)" ]; then
         echo "oracle/_ref is up to date"; exit 0
     fi
 fi
@@ -42,7 +42,7 @@ QM="$REF/cuda/q_matrix.cu"
 } > "$OUT/q_matrix_kernels.inc"
 grep -q "shuffle_8bit_4" "$OUT/q_matrix_kernels.inc" && grep -q "b_q_group_map" "$OUT/q_matrix_kernels.inc" || { echo "kernel extraction failed" >&2; exit 4; }
 $CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -Wno-pass-failed -I"$HERE" -I"$HERE/stubs" -I"$REF" -I"$OUT" \
-    "$HERE/q_matrix_driver.cpp" "$HERE/simt_host.cpp" -o "$OUT/libqmatrix_ref.so"
+    "$HERE/q_matrix_driver.cpp" "$HERE/gptq_gemm_driver.cpp" "$HERE/simt_host.cpp" -o "$OUT/libqmatrix_ref.so"
 echo "built $OUT/libqmatrix_ref.so"
 # rope.cu: the two __device__ rotation functions (same reason, same treatment)
 RP="$REF/cuda/rope.cu"

@@ -25,6 +25,8 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
 import make_golden_reconstruct as R                                   # CASES, case_tensors, build + load
 
 GEMM_CASES = [("b4_g128", 1), ("b3", 2), ("b6", 3), ("mixed_all", 4), ("mixed_5_4", 1), ("mixed_5_4", 3)]
+# GPTQ 4-bit (gemm_half_q_half_gptq_kernel, q_gemm_kernel_gptq.cuh:61-246): index into R.GPTQ_CASES, rows
+GPTQ_GEMM_CASES = [(0, 1), (1, 2), (2, 4), (4, 3)]
 
 
 def load():
@@ -33,7 +35,31 @@ def load():
     lib.ref_exl2_shuffle.restype = ctypes.c_int
     lib.ref_exl2_gemm.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
     lib.ref_exl2_gemm.restype = ctypes.c_int
+    lib.ref_gptq_gemm.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    lib.ref_gptq_gemm.restype = ctypes.c_int
     return lib
+
+
+def gptq_activations(ci: int, m: int) -> np.ndarray:
+    return np.random.default_rng(2000 + 11 * ci + m).standard_normal((m, R.GPTQ_CASES[ci][0])).astype(np.float16)
+
+
+def reference_gptq_gemm(lib, t: dict, a: np.ndarray) -> np.ndarray:
+    """the reference's load-time steps (make_sequential_kernel for a shuffled g_idx, shuffle_kernel) + its GPTQ GEMV"""
+    from oracle import exl2 as OX
+    qw = np.ascontiguousarray(t["qweight"]).view(np.uint32).copy()
+    k, n = qw.shape[0] * 8, qw.shape[1]
+    groups = t["qzeros"].shape[0]
+    g_idx = np.asarray(t["g_idx"])
+    sequential = np.array_equal(g_idx, np.arange(k) // (k // groups))
+    perm = None if sequential else OX.gptq_sequential_perm(g_idx, groups)[0].astype(np.uint16)
+    qz = np.ascontiguousarray(t["qzeros"]).view(np.uint32).copy()
+    sc = np.ascontiguousarray(t["scales"]).view(np.uint16).copy()
+    a = np.ascontiguousarray(a.astype(np.float16))
+    c = np.full((a.shape[0], n), 0x7e00, dtype=np.uint16)
+    assert lib.ref_gptq_gemm(a.ctypes.data, a.shape[0], qw.ctypes.data, None if perm is None else perm.ctypes.data,
+                             qz.ctypes.data, sc.ctypes.data, k, n, groups, c.ctypes.data) == 0
+    return c.view(np.float16)
 
 
 def activations(name: str, m: int) -> np.ndarray:
@@ -68,6 +94,8 @@ def main():
         a = activations(name, m)
         for bk in (32, 64):
             fx[f"c_{name}_{m}_{bk}"] = reference_gemm(lib, t, a, bk)
+    for ci, m in GPTQ_GEMM_CASES:
+        fx[f"c_gptq_{ci}_{m}"] = reference_gptq_gemm(lib, R.gptq_tensors(R.GPTQ_CASES[ci]), gptq_activations(ci, m))
     path = os.path.join(ROOT, "tests", "golden", "reference_q_gemm.npz")
     np.savez_compressed(path, **fx)
     print(f"wrote {path} ({os.path.getsize(path)} bytes)")

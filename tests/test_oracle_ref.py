@@ -230,6 +230,29 @@ def test_reference_kernel_within_stated_tolerance_and_ours_at_least_as_close(be)
         assert e_ours <= e_ref, (name, m, e_ours, e_ref)                                 # (ii)
 
 
+@pytest.mark.hip_unverified
+def test_gptq_q_gemm_at_least_as_close_as_reference_kernel(be):
+    """Same yardstick for GPTQ: the reference's gemm_half_q_half_gptq_kernel (scale folded into an fp16 fma on biased
+    codes, fp16 partial sums) is 3e-3 .. 9e-3 away from matmul(a, reconstruct()) on these shapes; ours must not be farther."""
+    import torch
+    from tests.util import gptq_to_torch
+    G = _gemm_mod()
+    fx = np.load(GEMM_FIXTURE)
+    for ci, m in G.GPTQ_GEMM_CASES:
+        t = G.R.gptq_tensors(G.R.GPTQ_CASES[ci])
+        a = G.gptq_activations(ci, m)
+        want = a.astype(np.float64) @ OX.gptq_reconstruct(t).astype(np.float64)
+        e_ref = np.abs(fx[f"c_gptq_{ci}_{m}"].astype(np.float64) - want).max()
+        assert e_ref <= 2e-2, (ci, m, e_ref)
+        w = gptq_to_torch(be, t)                                   # stays alive: the handle keeps raw pointers into it
+        h = be.ext.make_q_matrix_from_dict(w, None)
+        c = torch.zeros((m, want.shape[1]), dtype=torch.float16, device=be.device)
+        be.ext.gemm_half_q_half(be.t(a), h, c)
+        e_ours = np.abs(be.n(c).astype(np.float64) - want).max()
+        be.ext.free_q_matrix(h)
+        assert e_ours <= e_ref, (ci, m, e_ours, e_ref)
+
+
 def test_live_reference_gemm_reproduces_fixture():
     if not os.path.isdir("/root/reference/exllamav2/exllamav2_ext/cuda"):
         pytest.skip("reference sources not present on this machine (the committed fixture is still used)")
