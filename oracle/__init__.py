@@ -26,7 +26,8 @@ cites the reference file:line it follows.  Parity status:
   the decode GEMV kernel `gemm_half_q_half_kernel` (header template, included as it lies) as the
   measured yardstick for the q_gemm tolerance (`tests/golden/reference_q_gemm.npz`);
   the RoPE rotation (`rope_cuda_arr_neox` / `_gptj` of `cuda/rope.cu`, `tests/golden/reference_rope.npz`) and
-  `rms_norm_kernel` (`cuda/rms_norm.cu`; the float64-sum oracle is within one fp16 ulp of it);
+  `rms_norm_kernel` (`cuda/rms_norm.cu`; the float64-sum oracle is within one fp16 ulp of it); the MoE
+  routing kernels of `cuda/q_mlp_softmax.cuh` (`tests/golden/reference_moe_routing.npz`);
   likewise the pure torch functions of the reference that run on CPU (group map, RMSNorm, attention,
   RoPE tables, MLP activation: `tests/golden/make_golden.py`);
 * **unpinned by execution, pinned by relation**: the multiply itself (the reference has no CPU q_gemm

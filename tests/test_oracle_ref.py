@@ -356,3 +356,35 @@ def test_live_reference_rms_norm_reproduces_fixture():
     fx = np.load(RMS_FIXTURE)
     for i in range(len(G.CASES)):
         assert np.array_equal(G.reference_rms_norm(lib, i).view(np.uint16), fx[f"y_{i}"].view(np.uint16))
+
+
+# ---- MoE routing: the reference's softmax{4,8,16}_topk_norm_kernel executed on the host --------------------------------
+
+MOE_FIXTURE = os.path.join(ROOT, "tests", "golden", "reference_moe_routing.npz")
+
+
+def _moe_mod():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_moe as G
+    return G
+
+
+def test_fixture_moe_routing_equals_oracle():
+    """oracle.modules.moe_route == the reference's routing kernels: same experts selected, weights bit for bit"""
+    from oracle import modules as OM
+    G = _moe_mod()
+    fx = np.load(MOE_FIXTURE)
+    for i, (e, k, rows) in enumerate(G.CASES):
+        w, mask = OM.moe_route(G.logits(i), k)
+        assert np.array_equal(fx[f"w_{i}"] != 0, mask), i
+        assert np.array_equal(w.view(np.uint16), fx[f"w_{i}"].view(np.uint16)), i
+
+
+def test_live_reference_moe_routing_reproduces_fixture():
+    if not os.path.isdir("/root/reference/exllamav2/exllamav2_ext/cuda"):
+        pytest.skip("reference sources not present on this machine (the committed fixture still pins the oracle)")
+    G = _moe_mod()
+    lib = G.load()
+    fx = np.load(MOE_FIXTURE)
+    for i in range(len(G.CASES)):
+        assert np.array_equal(G.reference_route(lib, i).view(np.uint16), fx[f"w_{i}"].view(np.uint16))
