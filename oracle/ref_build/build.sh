@@ -9,9 +9,9 @@ OUT="$HERE/../_ref"
 [ -d "$REF/cuda/quant" ] || { echo "reference sources not found under $REF" >&2; exit 3; }
 mkdir -p "$OUT"
 # up to date?  (every output newer than the recipe's files and than the reference sources it compiles)
-if [ -z "$EXL2_REF_FORCE" ] && [ -f "$OUT/libqdq_ref.so" ] && [ -f "$OUT/libcacheq_ref.so" ] && [ -f "$OUT/libqmatrix_ref.so" ] && [ -f "$OUT/librope_ref.so" ] && [ -f "$OUT/librmsnorm_ref.so" ] && [ -f "$OUT/libmoe_ref.so" ]; then
-    OLDEST=$(ls -t "$OUT"/libqdq_ref.so "$OUT"/libcacheq_ref.so "$OUT"/libqmatrix_ref.so "$OUT"/librope_ref.so "$OUT"/librmsnorm_ref.so "$OUT"/libmoe_ref.so | tail -1)
-    if [ -z "$(find "$HERE" "$REF/cuda/quant" "$REF/cuda/cache_q.cuh" "$REF/cuda/cache.cu" "$REF/cuda/q_matrix.cu" "$REF/cuda/rope.cu" "$REF/cuda/rms_norm.cu" "$REF/cuda/q_mlp_softmax.cuh" "$REF/cuda/q_gemm_kernel.cuh" "$REF/cuda/q_gemm_kernel_gptq.cuh" "$REF/cuda/matrix_view.cuh" "$REF/config.h" -type f -newer "$OLDEST" 2>/dev/null | head -1)" ]; then
+if [ -z "$EXL2_REF_FORCE" ] && [ -f "$OUT/libqdq_ref.so" ] && [ -f "$OUT/libcacheq_ref.so" ] && [ -f "$OUT/libqmatrix_ref.so" ] && [ -f "$OUT/librope_ref.so" ] && [ -f "$OUT/librmsnorm_ref.so" ] && [ -f "$OUT/libmoe_ref.so" ] && [ -f "$OUT/libactmul_ref.so" ]; then
+    OLDEST=$(ls -t "$OUT"/libqdq_ref.so "$OUT"/libcacheq_ref.so "$OUT"/libqmatrix_ref.so "$OUT"/librope_ref.so "$OUT"/librmsnorm_ref.so "$OUT"/libmoe_ref.so "$OUT"/libactmul_ref.so | tail -1)
+    if [ -z "$(find "$HERE" "$REF/cuda/quant" "$REF/cuda/cache_q.cuh" "$REF/cuda/cache.cu" "$REF/cuda/q_matrix.cu" "$REF/cuda/rope.cu" "$REF/cuda/rms_norm.cu" "$REF/cuda/q_mlp_softmax.cuh" "$REF/cuda/q_mlp_activation.cuh" "$REF/cuda/q_gemm_kernel.cuh" "$REF/cuda/q_gemm_kernel_gptq.cuh" "$REF/cuda/matrix_view.cuh" "$REF/config.h" -type f -newer "$OLDEST" 2>/dev/null | head -1)" ]; then
         echo "oracle/_ref is up to date"; exit 0
     fi
 fi
@@ -55,7 +55,7 @@ $CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -I"$HERE" 
     "$HERE/rope_driver.cpp" "$HERE/simt_host.cpp" -o "$OUT/librope_ref.so"
 echo "built $OUT/librope_ref.so"
 # rms_norm.cu: the rms_norm_kernel template (the driver supplies the `template <int blocks_per_warp>` line)
-awk '/^__global__ void rms_norm_kernel$/,/^}/' "$REF/cuda/rms_norm.cu" "$REF/cuda/q_mlp_softmax.cuh" > "$OUT/rms_norm_kernel.inc"
+awk '/^__global__ void rms_norm_kernel$/,/^}/' "$REF/cuda/rms_norm.cu" "$REF/cuda/q_mlp_softmax.cuh" "$REF/cuda/q_mlp_activation.cuh" > "$OUT/rms_norm_kernel.inc"
 grep -q "rsqrtf" "$OUT/rms_norm_kernel.inc" || { echo "rms_norm extraction failed" >&2; exit 4; }
 $CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -Wno-pass-failed -I"$HERE" -I"$HERE/stubs" -I"$REF" -I"$OUT" \
     "$HERE/rms_norm_driver.cpp" "$HERE/simt_host.cpp" -o "$OUT/librmsnorm_ref.so"
@@ -64,3 +64,7 @@ echo "built $OUT/librmsnorm_ref.so"
 $CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -I"$HERE" -I"$HERE/stubs" -I"$REF" \
     "$HERE/moe_softmax_driver.cpp" "$HERE/simt_host.cpp" -o "$OUT/libmoe_ref.so"
 echo "built $OUT/libmoe_ref.so"
+# q_mlp_activation.cuh: act_mul_kernel (a header: included directly)
+$CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -I"$HERE" -I"$HERE/stubs" -I"$REF" \
+    "$HERE/act_mul_driver.cpp" "$HERE/simt_host.cpp" -o "$OUT/libactmul_ref.so"
+echo "built $OUT/libactmul_ref.so"

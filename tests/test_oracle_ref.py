@@ -388,3 +388,20 @@ def test_live_reference_moe_routing_reproduces_fixture():
     fx = np.load(MOE_FIXTURE)
     for i in range(len(G.CASES)):
         assert np.array_equal(G.reference_route(lib, i).view(np.uint16), fx[f"w_{i}"].view(np.uint16))
+
+
+# ---- SiLU(gate) * up: the reference's act_mul_kernel executed on the host (yardstick) -----------------------------------
+
+def test_fixture_act_mul_within_two_ulps_of_oracle():
+    """The reference has two forms of the activation: the kernel (six fp16 steps) and torch (fp32 silu rounded once,
+    mlp.py:486-494; the oracle's).  Executed, they are at most 2 fp16 ulps apart (~ 95 % within 1) -- the measured basis of
+    the 2-ulp bar of tests/test_ops.py::test_act_mul."""
+    from oracle import modules as OM
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_actmul as G
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "reference_act_mul.npz"))
+    g, u = G.inputs()
+    d = _ulp_diff(OM.silu_mul(g, u), fx["silu_mul"])
+    assert d.max() <= 2 and (d <= 1).mean() > 0.9, (d.max(), (d <= 1).mean())
+    if os.path.isdir("/root/reference/exllamav2/exllamav2_ext/cuda"):
+        assert np.array_equal(G.reference_act_mul(G.load()).view(np.uint16), fx["silu_mul"].view(np.uint16))
