@@ -392,16 +392,16 @@ def test_live_reference_moe_routing_reproduces_fixture():
 
 # ---- SiLU(gate) * up: the reference's act_mul_kernel executed on the host (yardstick) -----------------------------------
 
-def test_fixture_act_mul_within_two_ulps_of_oracle():
+def test_fixture_act_mul_kernel_form_close_to_oracle_torch_form():
     """The reference has two forms of the activation: the kernel (six fp16 steps) and torch (fp32 silu rounded once,
-    mlp.py:486-494; the oracle's).  Executed, they are at most 2 fp16 ulps apart (~ 95 % within 1) -- the measured basis of
-    the 2-ulp bar of tests/test_ops.py::test_act_mul."""
+    mlp.py:486-494; the oracle's).  Executed, they are ~ 95 % within 1 fp16 ulp, > 99.9 % within 2 and never more than 3
+    apart -- the measured basis of the 2-ulp bar of tests/test_ops.py::test_act_mul (our kernel evaluates the torch form)."""
     from oracle import modules as OM
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import make_golden_actmul as G
     fx = np.load(os.path.join(ROOT, "tests", "golden", "reference_act_mul.npz"))
     g, u = G.inputs()
     d = _ulp_diff(OM.silu_mul(g, u), fx["silu_mul"])
-    assert d.max() <= 2 and (d <= 1).mean() > 0.9, (d.max(), (d <= 1).mean())
+    assert d.max() <= 3 and (d <= 2).mean() > 0.999 and (d <= 1).mean() > 0.9, (d.max(), (d <= 1).mean())
     if os.path.isdir("/root/reference/exllamav2/exllamav2_ext/cuda"):
         assert np.array_equal(G.reference_act_mul(G.load()).view(np.uint16), fx["silu_mul"].view(np.uint16))
