@@ -103,6 +103,43 @@ def test_tensor_parallel_matches_single_process(tmp_path):
     model.unload()
 
 
+def _q4_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from exllamav2_amd.cache import ExLlamaV2Cache_Q4
+    from exllamav2_amd.tensor_p import ExLlamaV2TP, TPGreedyDecoder
+    cfg = _cfg()
+    model = ExLlamaV2TP(cfg, rank, world, device="cpu", ext=_emu_ext()).load(_checkpoint(cfg))
+    cache = ExLlamaV2Cache_Q4(model, batch_size=1, max_seq_len=256)
+    logits = model.forward(torch.tensor([PROMPT]), cache, last_id_only=False)
+    nxt = model.forward(torch.tensor([[int(torch.argmax(logits[0, -1]))]]), cache)      # one decode step over the Q4 cache
+    np.save(os.path.join(out_dir, f"q4logits{rank}.npy"), torch.cat([logits, nxt], dim=1).float().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tensor_parallel_with_q4_cache(tmp_path):
+    """BASELINE configs[3] in miniature (tensor parallel + Q4 KV cache): each rank quantises ITS KV heads (the 512-element
+    codec blocks then span different tokens than on one device, so the 4-bit noise differs); ranks agree bit for bit and
+    the logits stay within the Q4 tolerance of the FP16-cache oracle."""
+    world = 2
+    build_emu_if_needed()
+    mp.spawn(_q4_worker, args=(world, 29551, str(tmp_path)), nprocs=world, join=True)
+    l0, l1 = (np.load(tmp_path / f"q4logits{r}.npy") for r in range(world))
+    assert np.array_equal(l0, l1)
+    from oracle.model import OracleModel
+    cfg = _cfg()
+    oracle = OracleModel(cfg, _checkpoint(cfg))
+    oracle.reset(1)
+    want = oracle.forward(np.array([PROMPT]))
+    assert np.abs(l0[:, :len(PROMPT)].astype(np.float64) - want).max() < LOGIT_TOL      # prefill attends over fp16 new tokens
+    nxt = oracle.forward(np.array([[int(np.argmax(want[0, -1]))]]))
+    d = np.abs(l0[:, len(PROMPT):].astype(np.float64) - nxt)
+    assert d.max() < 0.6 and d.mean() < 0.12            # decode over 4-bit K/V: the drift bar of test_q4_cache_decode_close_to_fp16
+
+
 def _bench_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
