@@ -80,6 +80,50 @@ def test_layer_split_bench_backend_runs_on_gloo():
     mp.spawn(_bench_worker, args=(2, 29535), nprocs=2, join=True)
 
 
+def _moe_cfg():
+    from exllamav2_amd.config import ExLlamaV2Config
+    return ExLlamaV2Config(hidden_size=128, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                           num_key_value_heads=1, head_dim=64, vocab_size=96, max_seq_len=256, max_input_len=32,
+                           num_experts=4, num_experts_per_token=2, arch="mixtral")
+
+
+def _moe_worker(rank, world, port, n_ticks, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from exllamav2_amd.pipeline import PipelineStage, run_pipeline
+    stage = PipelineStage(_moe_cfg(), rank, world, "cpu", n_seqs=world, max_seq_len=256, recipe="3.5bpw", seed=6,
+                          ext=_emu_ext(), use_graph=False)
+    run_pipeline(stage, [4, 9], n_ticks)
+    if rank == world - 1:
+        np.save(out_path, stage.history.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_layer_split_pipeline_with_moe_blocks(tmp_path):
+    """BASELINE configs[4] in miniature: a Mixtral-style model (sparse MoE MLP, 3.5 bpw mix) over the layer split --
+    the reference's own multi-GPU mode for MoE (no tensor parallel for Mixtral)."""
+    world, n_ticks = 2, 5
+    out = str(tmp_path / "hist.npy")
+    build_emu_if_needed()
+    mp.spawn(_moe_worker, args=(world, 29537, n_ticks, out), nprocs=world, join=True)
+    hist = np.load(out)
+    from exllamav2_amd.cache import ExLlamaV2Cache
+    from exllamav2_amd.model import ExLlamaV2, GreedyGraphDecoder
+    from exllamav2_amd.synth import synth_checkpoint
+    cfg = _moe_cfg()
+    model = ExLlamaV2(cfg, device="cpu", ext=_emu_ext()).load(synth_checkpoint(cfg, "cpu", recipe="3.5bpw", seed=6))
+    for s, tok0 in enumerate([4, 9]):
+        cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=256)
+        dec = GreedyGraphDecoder(model, cache, batch_size=1)
+        dec.reset(torch.tensor([tok0]), 0)
+        dec.run(2, use_graph=False)
+        assert np.array_equal(hist[s, 1:3], dec.tokens(0, 2).numpy()[0]), (s, hist[s, :4])
+    model.unload()
+
+
 def test_split_layers_partition():
     from exllamav2_amd.pipeline import split_layers
     for L in (2, 22, 32, 80):
