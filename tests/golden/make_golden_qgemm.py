@@ -29,6 +29,22 @@ GEMM_CASES = [("b4_g128", 1), ("b3", 2), ("b6", 3), ("mixed_all", 4), ("mixed_5_
 GPTQ_GEMM_CASES = [(0, 1), (1, 2), (2, 4), (4, 3)]
 
 
+# full Llama-2-7B shapes with the reference's 4.0 bpw bit mixes (the tensors of tests/test_qmatrix.py::test_full_size_linear)
+FULL_CASES = [("q_proj", 4096, 4096), ("down_proj", 11008, 4096)]
+
+
+def full_tensors(role: str, k: int, n: int) -> dict:
+    import torch
+    from exllamav2_amd.synth import RECIPES, synth_linear
+    gen = torch.Generator(); gen.manual_seed(123)
+    w = synth_linear(k, n, RECIPES["4.0bpw"][role], "cpu", gen, sigma=0.02, act_order=True)
+    return {kk: vv.numpy().copy() for kk, vv in w.items() if kk != "q_perm"}
+
+
+def full_activation(k: int) -> np.ndarray:
+    return np.random.default_rng(5).standard_normal((1, k)).astype(np.float16)
+
+
 def load():
     lib = R.load()
     lib.ref_exl2_shuffle.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -94,6 +110,10 @@ def main():
         a = activations(name, m)
         for bk in (32, 64):
             fx[f"c_{name}_{m}_{bk}"] = reference_gemm(lib, t, a, bk)
+    for role, k, n in FULL_CASES:
+        t = full_tensors(role, k, n)
+        for bk in (32, 64):
+            fx[f"c_full_{role}_{bk}"] = reference_gemm(lib, t, full_activation(k), bk)
     for ci, m in GPTQ_GEMM_CASES:
         fx[f"c_gptq_{ci}_{m}"] = reference_gptq_gemm(lib, R.gptq_tensors(R.GPTQ_CASES[ci]), gptq_activations(ci, m))
     path = os.path.join(ROOT, "tests", "golden", "reference_q_gemm.npz")
