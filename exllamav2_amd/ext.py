@@ -139,6 +139,8 @@ class ExtC:
         m = a.numel() // info["height"]
         if c.numel() != m * info["width"]:
             raise RuntimeError("gemm_half_q_half: a and c have incompatible shapes")
+        if m == 0:
+            return                                # zero rows (an expert nobody was routed to): nothing to launch
         self.lib.check(self.lib.exl2_gemm_half_q_half(
             self._ptr(a, torch.float16, "a"), b, self._ptr(c, torch.float16, "c"), m, 1, None, 0, 0, self._stream(a)))
 

@@ -313,3 +313,26 @@ def test_full_size_linear(be, role):
         e_ref = min(np.abs(fx[f"c_full_{role}_{bk}"].astype(np.float64) - want).max() for bk in (32, 64))
         assert err.max() <= e_ref, (role, float(err.max()), float(e_ref))
     be.ext.free_q_matrix(h)
+
+
+@pytest.mark.hip_unverified
+def test_empty_and_ragged_inputs(be):
+    """Edge cases of the boundary: zero rows is a no-op (the reference's grid of height 0 launches nothing), every row
+    count 1..17 through the skinny / phased / staged routes agrees with the oracle row by row (a ragged batch is just a
+    different M), and shapes that do not match the handle are refused loudly."""
+    k, n, spec = SPECS["mixed_5_4"]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=21)
+    c0 = torch.full((0, n), 7.0, dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(torch.zeros((0, k), dtype=torch.float16, device=be.device), h, c0)      # no-op, no error
+    rng = np.random.default_rng(22)
+    a = rng.standard_normal((17, k)).astype(np.float16)
+    want = OX.gemm_ref(a, ref, exact=True)
+    for m in (1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17):
+        c = torch.zeros((m, n), dtype=torch.float16, device=be.device)
+        be.ext.gemm_half_q_half(be.t(a[:m]), h, c)
+        assert np.all(np.abs(be.n(c).astype(np.float64) - want[:m]) <= half_tol(want[:m], k)), m
+    with pytest.raises(RuntimeError):
+        be.ext.gemm_half_q_half(be.t(a[:2, :k - 32]), h, torch.zeros((2, n), dtype=torch.float16, device=be.device))
+    with pytest.raises(RuntimeError):
+        be.ext.gemm_half_q_half(be.t(a[:2]), h, torch.zeros((3, n), dtype=torch.float16, device=be.device))
+    be.ext.free_q_matrix(h)
