@@ -26,7 +26,15 @@ for KN in fp16_to_q_kv_paged_kernel fp16_to_q_kv_kernel q_to_fp16_kv_paged_kerne
   echo "template <int wbits_k, int wbits_v>" >> "$OUT/cache_kernels.inc"
   awk "/^__global__ void $KN\$/,/^}/" "$CC_" >> "$OUT/cache_kernels.inc"
 done
-grep -q "cache_seqlens\[y\]" "$OUT/cache_kernels.inc" || { echo "cache kernel extraction failed" >&2; exit 4; }
+# + the FP8 codec (compress / decompress + their kernels) and the defragmenter's page rotation
+awk '/^__device__ inline uint32_t compress/,/^}/' "$CC_" >> "$OUT/cache_kernels.inc"
+awk '/^__device__ inline uint32_t decompress/,/^}/' "$CC_" >> "$OUT/cache_kernels.inc"
+awk '/^__global__ void fp16_to_fp8_kernel$/,/^}/' "$CC_" >> "$OUT/cache_kernels.inc"
+awk '/^__global__ void fp8_to_fp16_kernel$/,/^}/' "$CC_" >> "$OUT/cache_kernels.inc"
+echo "#define NUM_THREADS 512" >> "$OUT/cache_kernels.inc"
+echo "#define CEIL_DIVIDE(x, size) (((x) + (size) - 1) / (size))" >> "$OUT/cache_kernels.inc"
+awk '/^void cache_rotate_kernel$/,/^}/' "$CC_" | sed '1s/^/__global__ /' >> "$OUT/cache_kernels.inc"
+grep -q "cache_seqlens\[y\]" "$OUT/cache_kernels.inc" && grep -q "rotate_len" "$OUT/cache_kernels.inc" && grep -q "0xff000000" "$OUT/cache_kernels.inc" || { echo "cache kernel extraction failed" >&2; exit 4; }
 $CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -I"$HERE" -I"$REF" -I"$OUT" \
     "$HERE/cache_q_driver.cpp" "$HERE/simt_host.cpp" -o "$OUT/libcacheq_ref.so"
 echo "built $OUT/libcacheq_ref.so"

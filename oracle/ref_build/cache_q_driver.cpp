@@ -20,6 +20,11 @@ template <typename T> static inline void __stwb(T* p, T v) { *p = v; }
 
 #include "config.h"
 #include <algorithm>
+struct int2 { int x, y; };
+static inline int2 make_int2(int x, int y) { int2 r = {x, y}; return r; }
+static inline int4 make_int4(int x, int y, int z, int w) { int4 r = {x, y, z, w}; return r; }
+struct uint4 { unsigned x, y, z, w; };
+#define __launch_bounds__(...)
 using std::min;
 using std::max;
 #define BLOCKSIZE_Q Q_CACHE_BLOCKSIZE_Q
@@ -120,6 +125,28 @@ int ref_cache_contiguous(int dir, int wbits, void* k_a, void* k_b, void* k_scale
         else if (wbits == 6) launch([&]() { q_to_fp16_kv_kernel<8, 4>(ki, ks, ko, vi, vs, vo, dim, offset, stride); });
         else launch([&]() { q_to_fp16_kv_kernel<8, 8>(ki, ks, ko, vi, vs, vo, dim, offset, stride); });
     }
+    return 0;
+}
+
+// FP8 cache codec: array_fp16_to_fp8_cuda / array_fp8_to_fp16_cuda (cache.cu:78-141): range rounded to 8 elements, block 32,
+// grid (ceil(range / 8 / 32), height).  dir 0 = fp16 -> fp8.  offset / width in ELEMENTS (the binding multiplies tokens by
+// kv_heads * head_dim, ext_cache.cpp:27-31).
+int ref_cache_fp8(int dir, const void* in, void* out, int stride, int height, int offset, int width)
+{
+    int mn = offset, mx = offset + width;
+    mn = mn / 8 * 8;
+    mx = mn + (mx - mn + 7) / 8 * 8;
+    if (mx <= mn) return 0;
+    const unsigned gx = ((mx - mn) / 8 + 31) / 32;
+    if (dir == 0) simt::run_grid(gx, height, 32, [&]() { fp16_to_fp8_kernel((const half*)in, (unsigned char*)out, stride, height, mn, mx); });
+    else          simt::run_grid(gx, height, 32, [&]() { fp8_to_fp16_kernel((const unsigned char*)in, (half*)out, stride, height, mn, mx); });
+    return 0;
+}
+
+// cache_rotate (cache.cu:548-576): 128 blocks x 512 threads; order = int32 page ids; temp = one page
+int ref_cache_rotate(void* cache, const uint32_t* order, void* temp, long long page_bytes, int rotate_len)
+{
+    simt::run_grid(128, 1, 512, [&]() { cache_rotate_kernel((uint8_t*)cache, order, (uint8_t*)temp, (size_t)page_bytes, (size_t)rotate_len); });
     return 0;
 }
 

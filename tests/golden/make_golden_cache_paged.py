@@ -5,7 +5,7 @@ The four addressing kernels of exllamav2_ext/cuda/cache.cu (fp16_to_q_kv[_paged]
 text extracted at build time into the git-ignored oracle/_ref/, see oracle/ref_build/build.sh) run on the host with the
 grids of array_*_cuda, 256 logical threads per block.  Scenarios: paged append across a page boundary, token ranges that
 must be widened to whole 512-element blocks (dim 128, 256) and ones that need not (dim 1024), 4 / 6 / 8-bit caches,
-contiguous ranges.  Recorded: for the pack direction the full (mostly zero) code and scale tensors -- i.e. exactly WHICH
+contiguous ranges; plus the FP8 codec kernels (cache.cu:20-141) and cache_rotate_kernel (:499-546).  Recorded: for the pack direction the full (mostly zero) code and scale tensors -- i.e. exactly WHICH
 blocks the reference writes and what it writes; for the unpack direction SHA-256 of the fp16 outputs.
 
 Run from the repo root:  python tests/golden/make_golden_cache_paged.py
@@ -40,6 +40,10 @@ def load():
     lib.ref_cache_paged.restype = ctypes.c_int
     lib.ref_cache_contiguous.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_int] * 5
     lib.ref_cache_contiguous.restype = ctypes.c_int
+    lib.ref_cache_fp8.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4
+    lib.ref_cache_fp8.restype = ctypes.c_int
+    lib.ref_cache_rotate.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int]
+    lib.ref_cache_rotate.restype = ctypes.c_int
     return lib
 
 
@@ -108,6 +112,43 @@ def contig_unpack(lib, i: int):
     return ko, vo
 
 
+# FP8 codec: (offset tokens, width tokens) on a [2, 16, 3, 4] cache (token size 12: ranges get rounded to 8 elements);
+# page rotation: (pages, page elements (uint16; the reference kernel needs page bytes % 2048 == 0), order)
+FP8_CASES = [(0, 7), (3, 5), (0, 16), (5, 0)]
+ROTATE_CASES = [(6, 4096, [4, 1, 3]), (9, 5120, [8, 2, 7, 0, 5, 3, 1]), (3, 1024, [2]), (12, 8192, [11, 0, 10, 1, 9, 2, 8, 3, 7, 4])]
+
+
+def fp8_input():
+    x = (np.random.default_rng(11).standard_normal((2, 16, 3, 4)) * 4).astype(np.float16)
+    x.reshape(-1)[:6] = np.array([np.inf, -np.inf, np.nan, -0.0, 6e-8, 65504.0], dtype=np.float16)
+    return x
+
+
+def reference_fp8(lib, i: int):
+    off, wd = FP8_CASES[i]
+    x = fp8_input()
+    b, s, kvh, hd = x.shape
+    out = np.full((b, s * kvh * hd), 0xA5, np.uint8)
+    lib.ref_cache_fp8(0, x.ctypes.data, out.ctypes.data, s * kvh * hd, b, off * kvh * hd, wd * kvh * hd)
+    back = np.full((b, s * kvh * hd), 7.0, np.float16)
+    lib.ref_cache_fp8(1, out.ctypes.data, back.ctypes.data, s * kvh * hd, b, off * kvh * hd, wd * kvh * hd)
+    return out, back
+
+
+def rotate_input(i: int):
+    n_pages, pe, order = ROTATE_CASES[i]
+    return np.random.default_rng(50 + i).integers(0, 65536, size=(n_pages, pe), dtype=np.uint16)
+
+
+def reference_rotate(lib, i: int):
+    n_pages, pe, order = ROTATE_CASES[i]
+    c = rotate_input(i).copy()
+    temp = np.zeros(pe, np.uint16)
+    o = np.array(order, np.uint32)
+    lib.ref_cache_rotate(c.ctypes.data, o.ctypes.data, temp.ctypes.data, pe * 2, len(order))
+    return c
+
+
 def digest(a: np.ndarray) -> np.ndarray:
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
 
@@ -122,6 +163,11 @@ def main():
             ko, vo = unpack(lib, i)
             fx[f"{kind}{i}_ko_sha"] = digest(ko); fx[f"{kind}{i}_vo_sha"] = digest(vo)
             fx[f"{kind}{i}_ko_written"] = np.array([int((ko.view(np.uint16) != 0).sum()), int((vo.view(np.uint16) != 0).sum())])
+    for i in range(len(FP8_CASES)):
+        out, back = reference_fp8(lib, i)
+        fx[f"fp8_{i}_codes"] = out; fx[f"fp8_{i}_back"] = back
+    for i in range(len(ROTATE_CASES)):
+        fx[f"rotate_{i}_sha"] = digest(reference_rotate(lib, i))
     path = os.path.join(ROOT, "tests", "golden", "reference_cache_addressing.npz")
     np.savez_compressed(path, **fx)
     print(f"wrote {path} ({os.path.getsize(path)} bytes)")

@@ -405,3 +405,33 @@ def test_fixture_act_mul_kernel_form_close_to_oracle_torch_form():
     assert d.max() <= 3 and (d <= 2).mean() > 0.999 and (d <= 1).mean() > 0.9, (d.max(), (d <= 1).mean())
     if os.path.isdir("/root/reference/exllamav2/exllamav2_ext/cuda"):
         assert np.array_equal(G.reference_act_mul(G.load()).view(np.uint16), fx["silu_mul"].view(np.uint16))
+
+
+# ---- FP8 cache codec and page rotation: the reference's kernels executed on the host ------------------------------------
+
+def test_fixture_fp8_codec_and_cache_rotate_equal_oracle():
+    """fp16_to_fp8_kernel / fp8_to_fp16_kernel (incl. the 8-element rounding of the token range and what stays untouched,
+    inf / nan / subnormal bytes) and cache_rotate_kernel of cuda/cache.cu == oracle.modules restatements, bit for bit"""
+    import hashlib
+    from oracle import modules as OM
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_cache_paged as G
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "reference_cache_addressing.npz"))
+    x = G.fp8_input()
+    b, s, kvh, hd = x.shape
+    for i, (off, wd) in enumerate(G.FP8_CASES):
+        lo, hi = OM.fp8_range(kvh * hd, off, wd)
+        want = np.full((b, s * kvh * hd), 0xA5, np.uint8)
+        want[:, lo:hi] = OM.fp16_to_fp8(x).reshape(b, -1)[:, lo:hi]
+        assert np.array_equal(want, fx[f"fp8_{i}_codes"]), i
+        back = np.full((b, s * kvh * hd), 7.0, np.float16)
+        back[:, lo:hi] = OM.fp8_to_fp16(want[:, lo:hi])
+        assert np.array_equal(back.view(np.uint16), fx[f"fp8_{i}_back"].view(np.uint16)), i
+    for i, (n_pages, pe, order) in enumerate(G.ROTATE_CASES):
+        got = OM.cache_rotate(G.rotate_input(i), order)
+        assert np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(got).tobytes()).digest(), dtype=np.uint8),
+                              fx[f"rotate_{i}_sha"]), i
+    if os.path.isdir("/root/reference/exllamav2/exllamav2_ext/cuda"):
+        lib = G.load()
+        assert np.array_equal(G.reference_fp8(lib, 1)[0], fx["fp8_1_codes"])
+        assert np.array_equal(G.digest(G.reference_rotate(lib, 1)), fx["rotate_1_sha"])
