@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--ctx", type=int, default=0, help="tokens already in the KV cache when timing starts")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-parity-check", action="store_true", help="skip the pre-timing oracle check of the device logits")
     p.add_argument("--cache", default="fp16", choices=["fp16", "q4"], help="KV cache type (q4: ExLlamaV2Cache_Q4)")
     p.add_argument("--no-prefill", action="store_true", help="skip the extra prefill measurement (BASELINE configs[2])")
     p.add_argument("--batch", type=int, default=1, help="sequences decoded together (BASELINE configs[4]: 16)")
@@ -108,6 +109,57 @@ def time_gemv_calls(model, dec, reps: int = 5):
         stream.synchronize()
         ext.graph_free(graph)
     return e0.elapsed_time(e1) / reps, launches, nbytes
+
+
+def oracle_for_parity(cfg, ck, layers: int = 2):
+    """CHECKER, not product: the numpy oracle (oracle/model.py) over the first `layers` layers + final norm + head of the
+    very checkpoint the bench decodes with.  Must be built BEFORE model.load() re-lays q_weight out in place."""
+    import copy
+    from oracle.model import OracleModel
+    ocfg = copy.copy(cfg)
+    ocfg.num_hidden_layers = layers
+    keep = {k: v for k, v in ck.items()
+            if not k.startswith("model.layers.") or int(k.split(".")[2]) < layers}
+    return OracleModel(ocfg, keep)
+
+
+def parity_check(model, oracle, device, n_decode: int = 3):
+    """Before anything is timed: the device (eager product path, same kernels the graph replays) runs a 4-token prompt and
+    `n_decode` greedy steps through the first layers + head; logits must match the oracle within the model-level fp16
+    tolerance of tests/test_model.py (0.03 + |x| 2^-8), token ids wherever the oracle's top-1/top-2 margin is confident."""
+    import numpy as np
+    import torch
+    from exllamav2_amd import ExLlamaV2Cache
+    layers = oracle.cfg.num_hidden_layers
+    full = model.layers
+    model.layers = full[:layers]
+    try:
+        cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=256)
+        cache.key_states, cache.value_states = cache.key_states[:layers], cache.value_states[:layers]
+        ids = np.array([[1, 15043, 3186, 29892]]) % model.config.vocab_size
+        oracle.reset(1)
+        worst, checked, tok_checked = 0.0, 0, 0
+        cur = ids
+        for step in range(1 + n_decode):
+            want = oracle.forward(cur)[:, -1]
+            got = model.forward(torch.from_numpy(cur), cache).float().cpu().numpy()[:, -1].astype(np.float64)
+            err = np.abs(got - want)
+            tol = 0.03 + np.abs(want) * 2.0 ** -8
+            worst = max(worst, float((err / tol).max()))
+            if not np.all(err <= tol):
+                raise SystemExit(f"[bench] parity check FAILED at step {step}: max |logit - oracle| = {err.max():.4f}")
+            top2 = np.sort(want[0])[-2:]
+            if top2[1] - top2[0] > 0.12:
+                tok_checked += 1
+                if int(got[0].argmax()) != int(want[0].argmax()):
+                    raise SystemExit(f"[bench] parity check FAILED at step {step}: greedy token differs from the oracle")
+            checked += want.size
+            cur = np.array([[int(want[0].argmax())]])
+        del cache
+    finally:
+        model.layers = full
+    return {"layers": layers, "steps": 1 + n_decode, "logits_checked": checked, "worst_err_over_tol": round(worst, 3),
+            "confident_tokens_equal": tok_checked, "tolerance": "0.03 + |x| * 2^-8 (fp16, tests/test_model.py)"}
 
 
 def pmc_traffic_gb(launches_per_step):
@@ -224,9 +276,14 @@ def main():
     else:
         t_load = time.perf_counter()
         ck = synth_checkpoint(cfg, device, recipe=args.recipe, seed=0)
+        do_parity = not args.no_parity_check and not getattr(cfg, "num_experts", 0)
+        oracle = oracle_for_parity(cfg, ck) if do_parity else None        # checker; before load() re-lays q_weight out
+        t_load = time.perf_counter()
         model = ExLlamaV2(cfg, device=device).load(ck)
         torch.cuda.synchronize()
         t_load = time.perf_counter() - t_load
+        parity = parity_check(model, oracle, device) if do_parity else None
+        del oracle
         if args.cache == "q4":
             from exllamav2_amd.cache import ExLlamaV2Cache_Q4
             cache = ExLlamaV2Cache_Q4(model, batch_size=args.batch, max_seq_len=max_seq)
@@ -257,6 +314,7 @@ def main():
         if getattr(cfg, "num_experts", 0) or args.batch != 1:
             # MoE / batched runs: headline rate only (the q_gemm roofline figure is defined on configs[1])
             result = {"value": args.batch * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load}
+            if parity is not None: result["parity_check"] = parity
             dec.free()
             return finish(args, cfg, result, rank, world, n_gpus, device, dist)
         gemv_ms, launches, gemv_bytes = time_gemv_calls(model, dec)
@@ -278,6 +336,8 @@ def main():
             },
         }
         dec.free()
+        if parity is not None:
+            result["parity_check"] = parity
 
     return finish(args, cfg, result, rank, world, n_gpus, device, dist)
 
@@ -304,7 +364,7 @@ def finish(args, cfg, result, rank, world, n_gpus, device, dist):
                        "parallelism": "single GPU" if n_gpus == 1 else
                                       result.get("parallelism", f"layer-split pipeline x{n_gpus}, {n_gpus} sequences in flight")},
         }
-        for k in ("roofline", "load_s", "weight_bytes_per_rank"):
+        for k in ("roofline", "load_s", "weight_bytes_per_rank", "parity_check"):
             if k in result: out[k] = result[k]
         if not args.no_prefill and n_gpus == 1 and args.model == "llama2-7b" and args.batch == 1:
             try:

@@ -48,7 +48,7 @@ DEV void fp16_to_q_block(int t, const f16* in, u8* out, f16* scales, size_t bloc
 
     if constexpr (WBITS == 4)
     {
-        f16x2 n = w / am2;
+        f16x2 n = h2_div_rn(w, am2);
         n = h2_fma(n, h2_dup((f16)8.0f), h2_dup((f16)8.0f));
         u32 q = (u32)rint_clamp(n.x, 15) | ((u32)rint_clamp(n.y, 15) << 4);
         q |= shfl_idx_u32(q, lane_id() + 1) << 8;          // lanes t % 2 == 0 now hold 2 bytes
@@ -58,7 +58,7 @@ DEV void fp16_to_q_block(int t, const f16* in, u8* out, f16* scales, size_t bloc
     }
     else
     {
-        f16x2 n = w / am2;
+        f16x2 n = h2_div_rn(w, am2);
         n = h2_fma(n, h2_dup((f16)128.0f), h2_dup((f16)128.0f));
         u32 q = (u32)rint_clamp(n.x, 255) | ((u32)rint_clamp(n.y, 255) << 8);
         q |= shfl_idx_u32(q, lane_id() + 1) << 16;

@@ -43,6 +43,12 @@ DEV u32   f32_bits(float x) { return __builtin_bit_cast(u32, x); }
 DEV f16x2 h2_fma(f16x2 a, f16x2 b, f16x2 c) { return __builtin_elementwise_fma(a, b, c); }
 DEV f16x2 h2_dup(f16 x) { return (f16x2){x, x}; }
 DEV f16   h_fma(f16 a, f16 b, f16 c) { return __builtin_fmaf16(a, b, c); }
+// correctly rounded fp16 quotient (== __hdiv / __h2div of the reference): the fp32 quotient of two halves is correctly
+// rounded (IEEE divide, -fhip-fp32-correctly-rounded-divide-sqrt is the compiler default) and rounding it once more to
+// 11 bits is innocuous (24 >= 2*11 + 2), so the result is the exactly rounded a / b.  A plain `a / b` on _Float16 lowers
+// to v_rcp_f32 * a, which lands one code away on ties.
+DEV f16   h_div_rn(f16 a, f16 b) { return (f16)__fdiv_rn((float)a, (float)b); }
+DEV f16x2 h2_div_rn(f16x2 a, f16x2 b) { return (f16x2){h_div_rn(a.x, b.x), h_div_rn(a.y, b.y)}; }
 
 // ---- thread / wave identity (all kernels use 1-D blocks whose size is a multiple of 64) -----------------------------
 DEV int lane_id() { return threadIdx.x & 63; }

@@ -121,6 +121,8 @@ DEV u32   f32_bits(float x) { return __builtin_bit_cast(u32, x); }
 
 DEV f16 h_fma(f16 a, f16 b, f16 c) { return (f16)((double)a * (double)b + (double)c); }
 DEV f16x2 h2_fma(f16x2 a, f16x2 b, f16x2 c) { return (f16x2){h_fma(a.x, b.x, c.x), h_fma(a.y, b.y, c.y)}; }
+DEV f16 h_div_rn(f16 a, f16 b) { return (f16)((float)a / (float)b); }
+DEV f16x2 h2_div_rn(f16x2 a, f16x2 b) { return (f16x2){h_div_rn(a.x, b.x), h_div_rn(a.y, b.y)}; }
 DEV f16x2 h2_dup(f16 x) { return (f16x2){x, x}; }
 
 DEV float fast_exp(float x) { return expf(x); }

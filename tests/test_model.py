@@ -210,3 +210,43 @@ def test_gptq_model_equals_oracle(be, recipe, act_order):
         assert np.array_equal(be.n(logits)[:, -1].argmax(-1)[conf], np.argmax(want[:, -1], -1)[conf])
         nxt = np.argmax(want[:, -1], axis=-1)[:, None]
     model.unload()
+
+
+@pytest.mark.gpu
+def test_llama2_7b_width_two_layers_equals_oracle():
+    """BASELINE configs[1]'s widths (hidden 4096, intermediate 11008, 32 heads, vocab 32000) on two layers: prefill logits,
+    then graph-decoded greedy tokens through the exact decoder bench.py times, against the oracle.  Product path only
+    (libexl2_hip.so on cuda:0); too large for the CPU emulation backend."""
+    from tests.conftest import Backend
+    be = Backend("hip")
+    cfg = ExLlamaV2Config.llama2_7b(max_seq_len=256, max_input_len=32)
+    cfg.num_hidden_layers = 2
+    ck = synth_checkpoint(cfg, be.device, recipe="4.0bpw", seed=0)
+    oracle = OracleModel(cfg, ck)
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    cache = ExLlamaV2Cache(model, batch_size=1)
+    ids = np.array([[1, 15043, 3186, 29892, 445]])
+    oracle.reset(1)
+    want = oracle.forward(ids)
+    logits = model.forward(torch.from_numpy(ids), cache, last_id_only=False)
+    check_logits(be.n(logits), want)
+    # decode 6 tokens with the device-side greedy loop; teacher-force the oracle with the device's tokens and compare
+    # logits every step, token ids wherever the oracle's margin is confident
+    dec = GreedyGraphDecoder(model, cache, batch_size=1).capture()
+    first = int(np.argmax(want[0, -1]))
+    dec.reset(torch.tensor([first]), ids.shape[1])
+    dec.run(6)
+    torch.cuda.synchronize()
+    toks = dec.tokens(ids.shape[1], 6).cpu().numpy()[0]
+    tok = first
+    n_conf = 0
+    for i in range(6):
+        w = oracle.forward(np.array([[tok]]))[0, -1]
+        if confident(w[None])[0]:
+            assert toks[i] == int(np.argmax(w)), (i, toks[i], int(np.argmax(w)))
+            n_conf += 1
+        tok = int(toks[i])
+    # the last step's logits are still in the decoder's buffer
+    check_logits(be.n(dec.logits)[:, :cfg.vocab_size].reshape(1, 1, -1), w[None, None])
+    dec.free()
+    model.unload()

@@ -230,7 +230,6 @@ def test_reference_kernel_within_stated_tolerance_and_ours_at_least_as_close(be)
         assert e_ours <= e_ref, (name, m, e_ours, e_ref)                                 # (ii)
 
 
-@pytest.mark.hip_unverified
 def test_gptq_q_gemm_at_least_as_close_as_reference_kernel(be):
     """Same yardstick for GPTQ: the reference's gemm_half_q_half_gptq_kernel (scale folded into an fp16 fma on biased
     codes, fp16 partial sums) is 3e-3 .. 9e-3 away from matmul(a, reconstruct()) on these shapes; ours must not be farther."""
@@ -335,7 +334,6 @@ def test_fixture_rms_norm_within_one_ulp_of_oracle():
         assert d.max() <= 1 and (d == 0).mean() > 0.999, (i, d.max())
 
 
-@pytest.mark.hip_unverified
 def test_rms_norm_kernel_against_reference_kernel(be):
     import torch
     G = _rms_mod()
