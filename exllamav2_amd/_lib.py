@@ -51,7 +51,7 @@ PROTOTYPES = {
     "exl2_paged_attn": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, vp, cll, vp]),
     "exl2_rope_kv_append": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, vp]),
     "exl2_attn_decode_fused": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, ci,
-                                    vp, cll, vp, ci, vp]),
+                                    vp, cll, vp, ci, vp, vp]),
     "exl2_paged_attn_q4": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, vp, cll, vp]),
     # fused modules
     "exl2_make_q_attn": (ci, [C.POINTER(vp), vp, vp, ci, ci, cf, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci,
@@ -67,6 +67,16 @@ PROTOTYPES = {
     "exl2_free_q_moe_mlp": (ci, [vp]),
     "exl2_q_moe_mlp_forward": (ci, [vp, vp, ci, vp]),
     "exl2_moe_route": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
+    # chained decode (csrc/qgemv_flat.hip)
+    "exl2_q_attn_chain_info": (ci, [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp)]),
+    "exl2_q_mlp_chain_info": (ci, [vp, C.POINTER(ci), C.POINTER(vp)]),
+    "exl2_q_matrix_perm_info": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+    "exl2_q_attn_forward_1_chain": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, vp]),
+    "exl2_q_attn_forward_2_chain": (ci, [vp, vp, vp, ci, vp, vp, vp, C.POINTER(ci), vp]),
+    "exl2_q_mlp_forward_chain": (ci, [vp, vp, vp, vp, ci, ci, vp, vp, vp, C.POINTER(ci), vp]),
+    "exl2_gemm_half_q_half_chain": (ci, [vp, vp, ci, vp, cf, vp, vp, ci, vp]),
+    "exl2_embed_rows_chain": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp]),
+    "exl2_gather_f16": (ci, [vp, vp, vp, ci, vp]),
     # graphs
     "exl2_graph_begin_capture": (ci, [vp]),
     "exl2_graph_end_capture": (ci, [vp, C.POINTER(vp)]),

@@ -133,6 +133,18 @@ class ExLlamaV2Attention:
                 cache.store_kv_state(self.layer_idx, b, past_len, q_len)
         return attn_out
 
+    def attend_chain(self, q, k, v, cache, cache_seqlens, block_table, out_invperm):
+        """Decode attention of the chained step (model.GreedyGraphDecoder): the one-launch kernel, output written in o_proj's
+        packed order.  Paged FP16 cache only; raises when the shape needs another path (the decoder then un-chains)."""
+        cfg, m, ext = self.model.config, self.model, self.ext
+        b, q_len = q.shape[0], q.shape[1]
+        kc, vc = cache.paged_view(self.layer_idx)
+        attn_out = m.temp_attn[:b * q_len].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
+        if not ext.attn_decode_fused(q, k, v, kc, vc, attn_out, m.sin, m.cos, cache_seqlens, block_table, 0, cfg.rope_style,
+                                     m.attn_scratch, m.attn_counters, out_invperm=out_invperm):
+            raise RuntimeError("attend_chain: shape not covered by the one-launch attention kernel")
+        return attn_out
+
     def _project_out(self, hidden_states, attn_out, b: int, q_len: int, big: bool):
         """Back half (q_attn_forward_2, q_attn.cu:319-345): x += attn_out . Wo"""
         ext = self.ext

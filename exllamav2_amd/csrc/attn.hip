@@ -214,11 +214,21 @@ struct FusedArgs
     const f16* sin; const f16* cos;                     // [max_seq, HDIM]
     const int* cache_seqlens; const int* block_table;
     f16* out; float* part_o; float* part_ml; u32* counters;
-    int b, s, H, KVH;
+    const u16* out_invperm;                             // nullable: feature n of a token row is stored at out[row, out_invperm[n]]
+    int b, s, H, KVH;                                   // (the consumer's packed order, i.e. o_proj's act-order: qgemv_flat.hip)
     int page_size, page_shift, pages_per_seq;
     int past_const, nsplit, rope, keys_per_split_min;
     float scale;
 };
+
+// where feature d of query row qrow = (token row) * H + head goes
+template <int HDIM> DEV size_t fused_out_index(const FusedArgs& a, size_t qrow, int d)
+{
+    if (!a.out_invperm) return qrow * HDIM + d;
+    const size_t tok = qrow / a.H;
+    const int head = (int)(qrow - tok * a.H);
+    return tok * ((size_t)a.H * HDIM) + a.out_invperm[head * HDIM + d];
+}
 
 template <int LPK> DEV f16x8 rope_neox_frag(f16x8 x, const f16* sin, const f16* cos, int pos, int dl)
 {
@@ -403,7 +413,7 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
         const size_t qrow = ((size_t)b * a.s + j) * a.H + kh * G + g;
         if (eff == 1)
         {
-            a.out[qrow * HDIM + d] = (f16)(L > 0.0f ? O / L : 0.0f);
+            a.out[fused_out_index<HDIM>(a, qrow, d)] = (f16)(L > 0.0f ? O / L : 0.0f);
         }
         else
         {
@@ -441,7 +451,7 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
             L += load_agent_f32(a.part_ml + (qrow * a.nsplit + s2) * 2 + 1) * w;
             O += load_agent_f32(a.part_o + (qrow * a.nsplit + s2) * HDIM + d) * w;
         }
-        a.out[qrow * HDIM + d] = (f16)(L > 0.0f ? O / L : 0.0f);
+        a.out[fused_out_index<HDIM>(a, qrow, d)] = (f16)(L > 0.0f ? O / L : 0.0f);
     }
     if (tid() == 0) store_relaxed_agent(counter, 0u);
 }
@@ -636,7 +646,7 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
                            int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
                            int page_size, int pages_per_seq, int past_const, float softmax_scale,
                            int rope_style, int sincos_size, int nsplit, void* scratch, long long scratch_bytes,
-                           void* counters, int n_counters, void* stream)
+                           void* counters, int n_counters, const void* out_invperm, void* stream)
 {
     EXL2_REQUIRE(q && k_new && v_new && k_cache && v_cache && out, "attn_decode_fused: null argument");
     EXL2_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "attn_decode_fused: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
@@ -659,6 +669,7 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
     a.k_cache = (f16*)k_cache; a.v_cache = (f16*)v_cache; a.out = (f16*)out;
     a.sin = (const f16*)sin; a.cos = (const f16*)cos;
     a.cache_seqlens = cache_seqlens; a.block_table = block_table; a.counters = (u32*)counters;
+    a.out_invperm = (const u16*)out_invperm;
     a.b = batch; a.s = q_len; a.H = num_heads; a.KVH = num_kv_heads;
     a.page_size = page_size; a.pages_per_seq = pages_per_seq; a.page_shift = ilog2_exact(page_size);
     EXL2_REQUIRE(!block_table || a.page_shift >= 0, "attn_decode_fused: page_size %d must be a power of two", page_size);

@@ -265,6 +265,45 @@ KERNEL void __launch_bounds__(256) embed_rows_kernel(const f16* table, const int
     for (int i = tid(); i < (hidden >> 3); i += 256) dst[i] = src[i];
 }
 
+// embedding row -> x, x in the first consumer's packed order, and the row's sum of squares (npart = 1): what the chained
+// decode (qgemv_flat.hip) expects from the producer of a residual stream
+KERNEL void __launch_bounds__(256) embed_rows_chain_kernel(const f16* table, const int* ids, f16* out, int hidden, int vocab,
+                                                           const u16* invperm, f16* xp, float* ss)
+{
+    SHARED float part[4];
+    const int row = bid_x();
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const f16x8* src = (const f16x8*)(table + (size_t)id * hidden);
+    f16x8* dst = (f16x8*)(out + (size_t)row * hidden);
+    f16* xr = xp + (size_t)row * hidden;
+    float sq = 0.0f;
+    for (int i = tid(); i < (hidden >> 3); i += 256)
+    {
+        const f16x8 v = src[i];
+        dst[i] = v;
+        if (invperm)
+        {
+            const u32x4 pv = ((const u32x4*)invperm)[i];
+            xr[pv.x & 0xFFFF] = v[0]; xr[pv.x >> 16] = v[1]; xr[pv.y & 0xFFFF] = v[2]; xr[pv.y >> 16] = v[3];
+            xr[pv.z & 0xFFFF] = v[4]; xr[pv.z >> 16] = v[5]; xr[pv.w & 0xFFFF] = v[6]; xr[pv.w >> 16] = v[7];
+        }
+        else ((f16x8*)xr)[i] = v;
+        #pragma unroll
+        for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)); sq = fmaf(f, f, sq); }
+    }
+    sq = wave_allreduce_add(sq);
+    if (lane_id() == 0) part[wave_id()] = sq;
+    block_sync();
+    if (tid() == 0) ss[row] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+KERNEL void __launch_bounds__(256) gather_f16_kernel(const f16* src, const u16* perm, f16* dst, int n)
+{
+    const int i = bid_x() * 256 + tid();
+    if (i < n) dst[i] = src[perm ? (int)perm[i] : i];
+}
+
 KERNEL void __launch_bounds__(1024) argmax_rows_kernel(const f16* logits, int* out_ids, int vocab, int ld,
                                                        int* history, const int* hist_pos, int hist_stride)
 {
@@ -311,6 +350,28 @@ int exl2_embed_rows(const void* table, const int* ids, void* out, int rows, int 
     EXL2_REQUIRE(hidden % 8 == 0, "embed_rows: hidden %d must be a multiple of 8", hidden);
     if (rows <= 0) return EXL2_OK;
     LAUNCH(embed_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const f16*)table, ids, (f16*)out, hidden, vocab);
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
+}
+
+int exl2_embed_rows_chain(const void* table, const int* ids, void* x, int rows, int hidden, int vocab,
+                          const void* next_invperm, void* xp_out, float* ss_out, void* stream)
+{
+    EXL2_REQUIRE(table && ids && x && xp_out && ss_out, "embed_rows_chain: null argument");
+    EXL2_REQUIRE(hidden % 8 == 0, "embed_rows_chain: hidden %d must be a multiple of 8", hidden);
+    EXL2_REQUIRE(!next_invperm || (((size_t)next_invperm) & 15) == 0, "embed_rows_chain: invperm must be 16-byte aligned");
+    if (rows <= 0) return EXL2_OK;
+    LAUNCH(embed_rows_chain_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const f16*)table, ids, (f16*)x, hidden, vocab,
+           (const u16*)next_invperm, (f16*)xp_out, ss_out);
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
+}
+
+int exl2_gather_f16(const void* src, const void* perm, void* dst, int n, void* stream)
+{
+    EXL2_REQUIRE(src && dst, "gather_f16: null argument");
+    if (n <= 0) return EXL2_OK;
+    LAUNCH(gather_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const f16*)src, (const u16*)perm, (f16*)dst, n);
     HIP_TRY(hipGetLastError());
     return EXL2_OK;
 }

@@ -67,6 +67,10 @@ DEV void block_sync() { __syncthreads(); }
 DEV u32 uniform(u32 x) { return __builtin_amdgcn_readfirstlane(x); }
 DEV int uniform(int x) { return (int)__builtin_amdgcn_readfirstlane((u32)x); }
 
+// Pin a wave-uniform value into a scalar register HERE: kernel-argument loads feeding it cannot be sunk past this point, so
+// a run of pins at the top of a kernel turns scattered single-dword argument loads into one batch of wide scalar loads.
+template <typename T> DEV void pin_scalar(T& x) { asm volatile("" : "+s"(x)); }
+
 // ---- cross-lane ----------------------------------------------------------------------------------------------------
 // butterfly exchange within a wave: value held by lane (lane ^ mask).  Masks 1,2 map to DPP quad_perm, 4/8 to
 // row_half_mirror / row_mirror AFTER the lower steps of an all-reduce made the halves uniform; the generic form
@@ -143,6 +147,12 @@ DEV void dma_to_lds16(const void* g_lane_ptr, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane_ptr,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// the same for data streamed once (packed weights): non-temporal policy (aux = 2: MI355X_MICROARCH.md "nt-weights")
+DEV void dma_to_lds16_nt(const void* g_lane_ptr, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane_ptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
 DEV void dma_to_lds4(const void* g_lane_ptr, void* lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane_ptr,
@@ -153,6 +163,9 @@ template <int N> DEV void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" :
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for every
 // prefetched weight load of the wave before letting anybody pass
 DEV void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// all LDS reads of this wave have returned (before an LDS-DMA may overwrite what they read: the compiler does not order
+// a global_load_lds behind a pending ds_read)
+DEV void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {hi:lo} (selector 0-3 -> lo, 4-7 -> hi, 0x0C -> 0x00)
 DEV u32 byte_perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }

@@ -9,9 +9,11 @@
 // Whole-token graphs are captured by the host with exl2_graph_* around these calls (all positions are read on the
 // device), instead of the reference's per-module graphs with patched kernel arguments (graph.cu:141-164).
 #include "qmatrix.h"
+#include "qgemv_flat.h"
 #include "errors.h"
 #include <string.h>
 #include <stdlib.h>
+#include <vector>
 
 int qgemv_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream);
 
@@ -51,6 +53,7 @@ struct QAttn
     bool has_residual; int rope_style; int sincos_size;
     const f16* q_norm; const f16* k_norm; const f16* post_layernorm; const f16* post_layernorm_bias;
     bool residual_fp32; bool use_graphs;
+    bool chain_ok; f16* norm_w_perm;            // chained decode: layernorm gathered through q/k/v's shared q_perm (owned)
 };
 
 struct QMLP
@@ -60,7 +63,45 @@ struct QMLP
     f16* temp_state; f16* temp_a; f16* temp_b; f16* temp_dq;
     int max_rows; bool act_gelu; bool has_residual;
     const f16* post_layernorm; const f16* post_layernorm_bias; bool residual_fp32; bool use_graphs;
+    bool chain_ok; f16* norm_w_perm;            // chained decode: layernorm gathered through gate/up's shared q_perm (owned)
 };
+
+// true when every matrix carries the same act-order permutation (or none does)
+static bool same_perm(QMatrix* const* ms, int n)
+{
+    const int K = ms[0]->height;
+    bool any = false, all = true;
+    for (int i = 0; i < n; i++) { if (ms[i]->q_perm) any = true; else all = false; if (ms[i]->height != K) return false; }
+    if (!any) return true;
+    if (!all) return false;
+    std::vector<u16> a(K), b(K);
+    if (hipMemcpy(a.data(), ms[0]->q_perm, (size_t)K * 2, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    for (int i = 1; i < n; i++)
+    {
+        if (ms[i]->q_perm == ms[0]->q_perm) continue;
+        if (hipMemcpy(b.data(), ms[i]->q_perm, (size_t)K * 2, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (memcmp(a.data(), b.data(), (size_t)K * 2) != 0) return false;
+    }
+    return true;
+}
+
+// norm weight in the packed order of `qm` (make time; small): dst[i] = w[perm[i]]
+static f16* permuted_norm(const f16* w, const QMatrix* qm)
+{
+    const int K = qm->height;
+    std::vector<u16> wh(K), ph(K), out(K);
+    if (hipMemcpy(wh.data(), w, (size_t)K * 2, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+    if (qm->q_perm)
+    {
+        if (hipMemcpy(ph.data(), qm->q_perm, (size_t)K * 2, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+        for (int i = 0; i < K; i++) out[i] = wh[ph[i] < K ? ph[i] : 0];
+    }
+    else out = wh;
+    f16* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)K * 2) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, out.data(), (size_t)K * 2, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    return d;
+}
 
 #define MOE_MAX_EXPERTS 16
 struct QMoEMLP
@@ -172,13 +213,31 @@ int exl2_make_q_attn(void** handle, const void* layernorm, const void* layernorm
     a->sincos_size = sincos_size;
     a->post_layernorm = (const f16*)post_layernorm; a->post_layernorm_bias = (const f16*)post_layernorm_bias;
     a->residual_fp32 = residual_fp32; a->use_graphs = use_graphs;
-    EXL2_REQUIRE(a->q_proj->height == hidden_size && a->k_proj->height == hidden_size && a->v_proj->height == hidden_size,
-                 "make_q_attn: projection heights do not match hidden_size %d", hidden_size);
+    if (!(a->q_proj->height == hidden_size && a->k_proj->height == hidden_size && a->v_proj->height == hidden_size))
+    {
+        free(a);
+        EXL2_FAIL(EXL2_E_INVALID, "make_q_attn: projection heights do not match hidden_size %d", hidden_size);
+    }
+    {
+        // chained decode (qgemv_flat.hip): plain pre-RMSNorm residual block whose q/k/v share one act-order permutation
+        QMatrix* qkv[3] = {a->q_proj, a->k_proj, a->v_proj};
+        const bool gq = a->q_proj->is_gptq;
+        a->chain_ok = a->layernorm && a->layernorm_is_rms && !a->post_layernorm && a->has_residual && !a->layernorm_bias
+                      && a->k_proj->is_gptq == gq && a->v_proj->is_gptq == gq && a->o_proj->is_gptq == gq
+                      && a->o_proj->height == num_heads * head_dim && a->o_proj->width == hidden_size && same_perm(qkv, 3);
+        if (a->chain_ok) { a->norm_w_perm = permuted_norm(a->layernorm, a->q_proj); if (!a->norm_w_perm) a->chain_ok = false; }
+    }
     *handle = a;
     return EXL2_OK;
 }
 
-int exl2_free_q_attn(void* handle) { free(handle); return EXL2_OK; }
+int exl2_free_q_attn(void* handle)
+{
+    QAttn* a = (QAttn*)handle;
+    if (a && a->norm_w_perm) (void)hipFree(a->norm_w_perm);
+    free(handle);
+    return EXL2_OK;
+}
 
 // q_attn_forward_1 (ext_qattn.cpp:115-159 -> q_attn.cu:247-317): q,k,v = proj(rmsnorm(x)); RoPE(q, k) in place.
 // apply_rope = 0 skips the rotation (the caller fuses it with the KV append, exl2_rope_kv_append).
@@ -263,11 +322,26 @@ int exl2_make_q_mlp(void** handle, const void* layernorm, const void* layernorm_
     m->max_rows = max_rows; m->act_gelu = act_gelu; m->has_residual = has_residual;
     m->post_layernorm = (const f16*)post_layernorm; m->post_layernorm_bias = (const f16*)post_layernorm_bias;
     m->residual_fp32 = residual_fp32; m->use_graphs = use_graphs;
+    if (m->gate)
+    {
+        QMatrix* gu[2] = {m->gate, m->up};
+        const bool gq = m->up->is_gptq;
+        m->chain_ok = m->layernorm && m->layernorm_is_rms && !m->layernorm_bias && !m->post_layernorm && m->has_residual
+                      && m->gate->is_gptq == gq && m->down->is_gptq == gq && m->gate->width == m->up->width
+                      && m->down->height == m->up->width && m->down->width == m->up->height && same_perm(gu, 2);
+        if (m->chain_ok) { m->norm_w_perm = permuted_norm(m->layernorm, m->up); if (!m->norm_w_perm) m->chain_ok = false; }
+    }
     *handle = m;
     return EXL2_OK;
 }
 
-int exl2_free_q_mlp(void* handle) { free(handle); return EXL2_OK; }
+int exl2_free_q_mlp(void* handle)
+{
+    QMLP* m = (QMLP*)handle;
+    if (m && m->norm_w_perm) (void)hipFree(m->norm_w_perm);
+    free(handle);
+    return EXL2_OK;
+}
 
 // q_mlp_forward_ (ext_qmlp.cpp:87-118 -> q_mlp.cu:153-236): x (+)= act(n Wg) * (n Wu) Wd, n = rmsnorm(x); in place on x
 int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream)
@@ -329,6 +403,126 @@ int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream)
     LAUNCH_JOBS(&d, 1, rows, m->down->is_gptq, stream, "q_mlp_forward_");
     if (m->post_layernorm)
         return exl2_rms_norm(m->temp_state, m->post_layernorm, x, m->norm_epsilon, rows, hidden, 1, 0, 0, stream);
+    return EXL2_OK;
+}
+
+
+// ---- chained decode (qgemv_flat.hip) -----------------------------------------------------------------------------------------
+
+#define FLAT_TRY(in, stream, wgs, what) do { \
+    const int _rc = qgemv_flat_launch(in, stream, wgs); \
+    if (_rc > 0) EXL2_FAIL(EXL2_E_INVALID, "%s: shape not covered by the chained decode kernel", what); \
+    if (_rc < 0) EXL2_FAIL(EXL2_E_INVALID, "%s: launch configuration rejected (%d)", what, _rc); \
+    HIP_TRY(hipGetLastError()); } while (0)
+
+int exl2_q_attn_chain_info(void* handle, int* capable, const void** in_invperm, const void** o_invperm)
+{
+    EXL2_REQUIRE(handle, "q_attn_chain_info: null handle");
+    QAttn* a = (QAttn*)handle;
+    if (capable) *capable = a->chain_ok ? 1 : 0;
+    if (in_invperm) *in_invperm = a->q_proj->q_perm ? a->q_proj->q_invperm : nullptr;
+    if (o_invperm) *o_invperm = a->o_proj->q_perm ? a->o_proj->q_invperm : nullptr;
+    return EXL2_OK;
+}
+
+int exl2_q_mlp_chain_info(void* handle, int* capable, const void** in_invperm)
+{
+    EXL2_REQUIRE(handle, "q_mlp_chain_info: null handle");
+    QMLP* m = (QMLP*)handle;
+    if (capable) *capable = m->chain_ok ? 1 : 0;
+    if (in_invperm) *in_invperm = m->up->q_perm ? m->up->q_invperm : nullptr;
+    return EXL2_OK;
+}
+
+int exl2_q_matrix_perm_info(void* q_matrix, const void** perm, const void** invperm)
+{
+    EXL2_REQUIRE(q_matrix, "q_matrix_perm_info: null handle");
+    QMatrix* q = (QMatrix*)q_matrix;
+    if (perm) *perm = q->q_perm;
+    if (invperm) *invperm = q->q_perm ? q->q_invperm : nullptr;
+    return EXL2_OK;
+}
+
+int exl2_q_attn_forward_1_chain(void* handle, const void* xp, const float* ss, int npart, int rows,
+                                void* temp_q, void* temp_k, void* temp_v, void* stream)
+{
+    EXL2_REQUIRE(handle && xp && ss && temp_q && temp_k && temp_v, "q_attn_forward_1_chain: null argument");
+    QAttn* a = (QAttn*)handle;
+    EXL2_REQUIRE(a->chain_ok, "q_attn_forward_1_chain: module is not chain-capable");
+    if (rows <= 0) return EXL2_OK;
+    EXL2_REQUIRE(rows <= a->max_rows && rows <= MAX_GEMV_ROWS, "q_attn_forward_1_chain: %d rows", rows);
+    FlatIn in; memset(&in, 0, sizeof(in));
+    QMatrix* ms[3] = {a->q_proj, a->k_proj, a->v_proj};
+    void* cs[3] = {temp_q, temp_k, temp_v};
+    for (int i = 0; i < 3; i++) { in.qm[i] = ms[i]; in.c[i] = (f16*)cs[i]; in.ldc[i] = ms[i]->width; }
+    in.n_mats = 3; in.M = rows; in.a_mode = A_NORM_PRE; in.a = (const f16*)xp; in.lda = a->hidden_size;
+    in.norm_w = a->norm_w_perm; in.ss = ss; in.npart = npart; in.eps = a->norm_epsilon; in.c_mode = C_STORE;
+    FLAT_TRY(in, stream, nullptr, "q_attn_forward_1_chain");
+    return EXL2_OK;
+}
+
+int exl2_q_attn_forward_2_chain(void* handle, void* x, const void* attn_out_packed, int rows, const void* next_invperm,
+                                void* xp_out, float* ss_out, int* npart_out, void* stream)
+{
+    EXL2_REQUIRE(handle && x && attn_out_packed, "q_attn_forward_2_chain: null argument");
+    QAttn* a = (QAttn*)handle;
+    EXL2_REQUIRE(a->chain_ok, "q_attn_forward_2_chain: module is not chain-capable");
+    if (rows <= 0) return EXL2_OK;
+    EXL2_REQUIRE(rows <= a->max_rows && rows <= MAX_GEMV_ROWS, "q_attn_forward_2_chain: %d rows", rows);
+    FlatIn in; memset(&in, 0, sizeof(in));
+    in.qm[0] = a->o_proj; in.c[0] = (f16*)x; in.ldc[0] = a->o_proj->width;
+    in.n_mats = 1; in.M = rows; in.a_mode = A_DIRECT; in.a = (const f16*)attn_out_packed; in.lda = a->o_proj->height;
+    in.c_mode = C_ACCUM;
+    in.xp_out = (f16*)xp_out; in.xp_invperm = (const u16*)next_invperm; in.ss_out = xp_out ? ss_out : nullptr; in.ldxp = a->hidden_size;
+    int wgs = 0;
+    FLAT_TRY(in, stream, &wgs, "q_attn_forward_2_chain");
+    if (npart_out) *npart_out = wgs;
+    return EXL2_OK;
+}
+
+int exl2_q_mlp_forward_chain(void* handle, void* x, const void* xp, const float* ss, int npart, int rows,
+                             const void* next_invperm, void* xp_out, float* ss_out, int* npart_out, void* stream)
+{
+    EXL2_REQUIRE(handle && x && xp && ss, "q_mlp_forward_chain: null argument");
+    QMLP* m = (QMLP*)handle;
+    EXL2_REQUIRE(m->chain_ok, "q_mlp_forward_chain: module is not chain-capable");
+    if (rows <= 0) return EXL2_OK;
+    EXL2_REQUIRE(rows <= m->max_rows && rows <= MAX_GEMV_ROWS, "q_mlp_forward_chain: %d rows", rows);
+    const int hidden = m->up->height, inter = m->up->width;
+    {
+        // gate | up from (xp, ss); SiLU(gate) * up in the epilogue, written in down's packed order
+        FlatIn in; memset(&in, 0, sizeof(in));
+        in.qm[0] = m->gate; in.qm[1] = m->up; in.c[0] = m->temp_a; in.c[1] = m->temp_a; in.ldc[0] = inter; in.ldc[1] = inter;
+        in.c_invperm[0] = m->down->q_perm ? m->down->q_invperm : nullptr;
+        in.n_mats = 2; in.pair = 1; in.M = rows; in.a_mode = A_NORM_PRE; in.a = (const f16*)xp; in.lda = hidden;
+        in.norm_w = m->norm_w_perm; in.ss = ss; in.npart = npart; in.eps = m->norm_epsilon; in.c_mode = C_STORE;
+        in.act_gelu = m->act_gelu ? 1 : 0;
+        FLAT_TRY(in, stream, nullptr, "q_mlp_forward_chain");
+    }
+    {
+        FlatIn in; memset(&in, 0, sizeof(in));
+        in.qm[0] = m->down; in.c[0] = (f16*)x; in.ldc[0] = hidden;
+        in.n_mats = 1; in.M = rows; in.a_mode = A_DIRECT; in.a = m->temp_a; in.lda = inter; in.c_mode = C_ACCUM;
+        in.xp_out = (f16*)xp_out; in.xp_invperm = (const u16*)next_invperm; in.ss_out = xp_out ? ss_out : nullptr; in.ldxp = hidden;
+        int wgs = 0;
+        FLAT_TRY(in, stream, &wgs, "q_mlp_forward_chain");
+        if (npart_out) *npart_out = wgs;
+    }
+    return EXL2_OK;
+}
+
+int exl2_gemm_half_q_half_chain(const void* xp, const float* ss, int npart, const void* norm_w_perm, float eps,
+                                void* q_matrix, void* c, int rows, void* stream)
+{
+    EXL2_REQUIRE(xp && ss && norm_w_perm && q_matrix && c, "gemm_half_q_half_chain: null argument");
+    QMatrix* q = (QMatrix*)q_matrix;
+    if (rows <= 0) return EXL2_OK;
+    EXL2_REQUIRE(rows <= MAX_GEMV_ROWS, "gemm_half_q_half_chain: %d rows", rows);
+    FlatIn in; memset(&in, 0, sizeof(in));
+    in.qm[0] = q; in.c[0] = (f16*)c; in.ldc[0] = q->width;
+    in.n_mats = 1; in.M = rows; in.a_mode = A_NORM_PRE; in.a = (const f16*)xp; in.lda = q->height;
+    in.norm_w = (const f16*)norm_w_perm; in.ss = ss; in.npart = npart; in.eps = eps; in.c_mode = C_STORE;
+    FLAT_TRY(in, stream, nullptr, "gemm_half_q_half_chain");
     return EXL2_OK;
 }
 

@@ -258,3 +258,99 @@ DEV void stage_shuffle_lds(const StageLds& L, bool has_perm, f16* a_lds, int a_s
         *(f16x8*)(a_lds + r * a_stride + o * 8) = v;
     }
 }
+
+// ---- streaming one wave's slice of one run ---------------------------------------------------------------------------
+
+template <int BITS> DEV void ring_load(LaneWords<BITS>& b, const u32* p, int lane) { load_lane_words<BITS>(p, lane, b); }
+
+// items [0, n) at ptr0 + i * 64 * BITS words, chunk index chunk0 + 4 i, streamed through a D-deep register ring.
+// `b` may already hold items 0..D-1 (clamped, see ring_fill).  EVERY load is unconditional (indices past the end are
+// clamped to the last item, a line that is in flight anyway): the compiler can then count -- s_waitcnt vmcnt(D-1) before
+// the first decode instead of vmcnt(0) -- and a wave with n <= D has its whole slice in flight from the first cycle.
+template <int BITS, int D, int LO = 0, int HI = D>
+DEV void ring_fill(LaneWords<BITS> (&b)[D], const u32* ptr0, int n, int lane)
+{
+    constexpr size_t STEP = 64 * BITS;
+    const int last = n > 0 ? n - 1 : 0;
+    #pragma unroll
+    for (int u = LO; u < HI; u++) ring_load<BITS>(b[u], ptr0 + (size_t)(u < last ? u : last) * STEP, lane);
+}
+
+template <int BITS, bool GPTQ, int D>
+DEV void stream_items(const u32* ptr0, int n, int chunk0, const PhaseCtx& ph, int lane, f32x4& acc,
+                      LaneWords<BITS> (&b)[D], bool preloaded)
+{
+    constexpr size_t STEP = 64 * BITS;
+    if (n <= 0) return;
+    if (!preloaded) ring_fill<BITS, D>(b, ptr0, n, lane);
+    const int last = n - 1;
+    int i = 0;
+    while (i + 2 * D <= n)
+    {
+        #pragma unroll
+        for (int u = 0; u < D; u++)
+        {
+            gemv_super<BITS, GPTQ, true>(b[u], ph, chunk0 + 4 * (i + u), 4, lane, acc);
+            ring_load<BITS>(b[u], ptr0 + (size_t)(i + u + D) * STEP, lane);
+        }
+        i += D;
+    }
+    // drain: fewer than 2 D items left, the ring holds items i .. i + D - 1 (clamped)
+    if (i + D < n)
+    {
+        #pragma unroll
+        for (int u = 0; u < D; u++)
+        {
+            gemv_super<BITS, GPTQ, true>(b[u], ph, chunk0 + 4 * (i + u), 4, lane, acc);
+            const int nx = i + u + D;
+            ring_load<BITS>(b[u], ptr0 + (size_t)(nx < last ? nx : last) * STEP, lane);
+        }
+        i += D;
+    }
+    #pragma unroll
+    for (int u = 0; u < D; u++)
+        if (i + u < n) gemv_super<BITS, GPTQ, true>(b[u], ph, chunk0 + 4 * (i + u), 4, lane, acc);
+}
+
+
+// ring depth: the main run keeps up to 8 KB per wave in flight (the whole slice when the split gives <= MAIN_DEPTH items
+// per wave); the small leading sections of a mixed-width matrix use a shallow ring (register budget: 128 VGPRs)
+#define MINOR_DEPTH 4
+#ifndef MAIN_DEPTH_NARROW
+#define MAIN_DEPTH_NARROW 4
+#endif
+template <int MB> struct MainDepth { static constexpr int v = MB <= 4 ? MAIN_DEPTH_NARROW : (MB <= 6 ? 4 : 3); };
+
+
+// number of vector loads one ring fill issues (what may stay in flight when the prologue data has landed)
+template <int MB> struct RingLoads
+{
+    static constexpr int per_item = (MB == 8 || MB == 6 || MB == 5) ? 2 : (MB == 3 ? 3 : 1);
+    static constexpr int v = MB ? MainDepth<(MB ? MB : 4)>::v * per_item : 0;
+};
+
+
+// contiguous global -> LDS copy of `units` 16-byte units, all waves of the workgroup; unit u of the copy comes from
+// src_of(u).  LDS destination dst + 16 u.
+// `first`: the wave that takes units [0, 64) -- small copies start on different waves so that no wave issues them all.
+template <typename F>
+DEV void dma_units16(F src_of, void* dst, int units, int wv, int nw, int lane, int first = 0)
+{
+    int vw = wv - first; if (vw < 0) vw += nw;
+    for (int base = vw * 64; base < units; base += nw * 64)
+    {
+        const int u = base + lane;
+        if (u < units) dma_to_lds16(src_of(u), (char*)dst + (size_t)base * 16);
+    }
+}
+template <typename F>
+DEV void dma_units4(F src_of, void* dst, int units, int wv, int nw, int lane, int first = 0)
+{
+    int vw = wv - first; if (vw < 0) vw += nw;
+    for (int base = vw * 64; base < units; base += nw * 64)
+    {
+        const int u = base + lane;
+        if (u < units) dma_to_lds4(src_of(u), (char*)dst + (size_t)base * 4);
+    }
+}
+

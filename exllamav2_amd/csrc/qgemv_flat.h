@@ -1,0 +1,23 @@
+// qgemv_flat.h -- host interface of the chained decode q_gemm (qgemv_flat.hip), used by modules.hip
+#pragma once
+#include "qmatrix.h"
+
+#define FLAT_MAX_MATS 4
+enum { A_DIRECT = 0, A_NORM_PRE = 1 };
+
+struct FlatIn
+{
+    const QMatrix* qm[FLAT_MAX_MATS]; f16* c[FLAT_MAX_MATS]; const u16* c_invperm[FLAT_MAX_MATS]; int ldc[FLAT_MAX_MATS];
+    int n_mats, M;
+    int a_mode;                   // A_DIRECT: `a` rows are in the matrices' packed K order; A_NORM_PRE: xp + ss + norm_w
+    const f16* a; int lda;
+    const f16* norm_w;            // A_NORM_PRE: RMSNorm weight in packed order [K]
+    const float* ss; int npart;   // A_NORM_PRE: partial sums of squares [M, npart]
+    float eps;
+    int pair;                     // 2 matrices (gate, up): output = act(gate) * up, written through mat 0's c / c_invperm
+    int act_gelu, c_mode;         // C_STORE / C_ACCUM (residual)
+    f16* xp_out; const u16* xp_invperm; float* ss_out; int ldxp;     // chain-out (nullable)
+};
+
+// 0: launched; 1: shape not covered; < 0: error.  *wgs_out = grid size = partial sums a chain-out launch writes per row
+int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out);

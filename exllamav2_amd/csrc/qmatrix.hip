@@ -316,7 +316,8 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
     const size_t cg_bytes = ((size_t)n_chunks * 2 + 4 + 15) & ~(size_t)15;
     const size_t tab_elems = (size_t)(N / TILE_N) * G * 16;
     if (e == hipSuccess) e = hipMalloc((void**)&qm->pack_buf, perm_bytes + cg_bytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&qm->sc_tab_buf, tab_elems * sizeof(f16));
+    // the chunk -> group map rides behind the scale table: the chained decode kernel derives its address from sc_tab
+    if (e == hipSuccess) e = hipMalloc((void**)&qm->sc_tab_buf, tab_elems * sizeof(f16) + cg_bytes);
     if (e == hipSuccess && is_gptq) e = hipMalloc((void**)&qm->zp_tab_buf, tab_elems * sizeof(f16));
     if (e != hipSuccess)
     {
@@ -357,6 +358,8 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
     HIP_TRY(hipMemsetAsync(qm->pack_buf, 0, perm_bytes + cg_bytes, stream));
     if (q_perm) HIP_TRY(hipMemcpyAsync(qm->pack_buf, q_perm, (size_t)K * 2, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(qm->pack_buf + perm_bytes, chunk_group.data(), (size_t)n_chunks * 2, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync((u8*)qm->sc_tab_buf + tab_elems * sizeof(f16), 0, cg_bytes, stream));
+    HIP_TRY(hipMemcpyAsync((u8*)qm->sc_tab_buf + tab_elems * sizeof(f16), chunk_group.data(), (size_t)n_chunks * 2, hipMemcpyHostToDevice, stream));
     {
         QMatDev t;
         memset(&t, 0, sizeof(t));

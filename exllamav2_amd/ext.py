@@ -332,8 +332,9 @@ class ExtC:
 
     def attn_decode_fused(self, q, k_new, v_new, k_cache, v_cache, out, sin, cos, cache_seqlens, block_table,
                           past_const: int, rope_style: int, scratch, counters, softmax_scale: float | None = None,
-                          sincos_size: int = 0, nsplit: int = 0) -> bool:
-        """One launch for RoPE + append + attention + merge; False when the shape needs the three-launch path."""
+                          sincos_size: int = 0, nsplit: int = 0, out_invperm: int | None = None) -> bool:
+        """One launch for RoPE + append + attention + merge; False when the shape needs the three-launch path.
+        out_invperm (device pointer, u16 [H * hd]): write the output in o_proj's packed order (chained decode)."""
         b, s, nh, hd = q.shape
         kvh = k_new.shape[2]
         page_size = k_cache.shape[1]
@@ -347,7 +348,8 @@ class ExtC:
             self._ptr(cos), self._ptr(cache_seqlens, torch.int32, "cache_seqlens"),
             self._ptr(block_table, torch.int32, "block_table"), b, s, nh, kvh, hd, page_size, pps, int(past_const),
             float(scale), int(rope_style), int(sincos_size), int(nsplit), self._ptr(scratch), sb,
-            self._ptr(counters, torch.int32, "counters"), 0 if counters is None else counters.numel(), self._stream(q)))
+            self._ptr(counters, torch.int32, "counters"), 0 if counters is None else counters.numel(),
+            out_invperm or None, self._stream(q)))
         return rc == 0
 
     def flash_attn_with_kvcache(self, q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, block_table=None,
@@ -445,6 +447,64 @@ class ExtC:
         self.lib.check(self.lib.exl2_moe_route(self._ptr(x, torch.float16, "x"), self._ptr(gate, torch.float16, "gate"),
                                                self._ptr(logits, torch.float16, "logits"), rows, hidden, gate.shape[0],
                                                int(topk), self._stream(x)))
+
+    # ---- chained decode (csrc/qgemv_flat.hip; ours) -----------------------------------------------------------------------
+
+    def q_attn_chain_info(self, q_attn: int):
+        """(capable, in_invperm pointer or None, o_invperm pointer or None)"""
+        cap, a, b = C.c_int(0), C.c_void_p(), C.c_void_p()
+        self.lib.check(self.lib.exl2_q_attn_chain_info(q_attn, C.byref(cap), C.byref(a), C.byref(b)))
+        return bool(cap.value), a.value, b.value
+
+    def q_mlp_chain_info(self, q_mlp: int):
+        cap, a = C.c_int(0), C.c_void_p()
+        self.lib.check(self.lib.exl2_q_mlp_chain_info(q_mlp, C.byref(cap), C.byref(a)))
+        return bool(cap.value), a.value
+
+    def q_matrix_perm_info(self, q_handle: int):
+        """(q_perm pointer or None, q_invperm pointer or None) of a q_matrix (u16 device arrays)"""
+        a, b = C.c_void_p(), C.c_void_p()
+        self.lib.check(self.lib.exl2_q_matrix_perm_info(q_handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def q_attn_forward_1_chain(self, q_attn, xp, ss, npart: int, rows: int, q_temp, k_temp, v_temp) -> None:
+        self.lib.check(self.lib.exl2_q_attn_forward_1_chain(
+            q_attn, self._ptr(xp, torch.float16, "xp"), self._ptr(ss, torch.float32, "ss"), int(npart), int(rows),
+            self._ptr(q_temp, torch.float16, "q_temp"), self._ptr(k_temp, torch.float16, "k_temp"),
+            self._ptr(v_temp, torch.float16, "v_temp"), self._stream(xp)))
+
+    def q_attn_forward_2_chain(self, q_attn, x, attn_out_packed, rows: int, next_invperm, xp_out, ss_out) -> int:
+        """Returns the number of partial sums per row written to ss_out."""
+        n = C.c_int(0)
+        self.lib.check(self.lib.exl2_q_attn_forward_2_chain(
+            q_attn, self._ptr(x, torch.float16, "x"), self._ptr(attn_out_packed, torch.float16, "attn_out"), int(rows),
+            next_invperm or None, self._ptr(xp_out, torch.float16, "xp_out"), self._ptr(ss_out, torch.float32, "ss_out"),
+            C.byref(n), self._stream(x)))
+        return n.value
+
+    def q_mlp_forward_chain(self, q_mlp, x, xp, ss, npart: int, rows: int, next_invperm, xp_out, ss_out) -> int:
+        n = C.c_int(0)
+        self.lib.check(self.lib.exl2_q_mlp_forward_chain(
+            q_mlp, self._ptr(x, torch.float16, "x"), self._ptr(xp, torch.float16, "xp"), self._ptr(ss, torch.float32, "ss"),
+            int(npart), int(rows), next_invperm or None, self._ptr(xp_out, torch.float16, "xp_out"),
+            self._ptr(ss_out, torch.float32, "ss_out"), C.byref(n), self._stream(x)))
+        return n.value
+
+    def gemm_half_q_half_chain(self, xp, ss, npart: int, norm_w_perm, eps: float, q_handle: int, c, rows: int) -> None:
+        self.lib.check(self.lib.exl2_gemm_half_q_half_chain(
+            self._ptr(xp, torch.float16, "xp"), self._ptr(ss, torch.float32, "ss"), int(npart),
+            self._ptr(norm_w_perm, torch.float16, "norm_w_perm"), float(eps), q_handle, self._ptr(c, torch.float16, "c"),
+            int(rows), self._stream(xp)))
+
+    def embed_rows_chain(self, table, ids, x, next_invperm, xp_out, ss_out) -> None:
+        self.lib.check(self.lib.exl2_embed_rows_chain(
+            self._ptr(table, torch.float16, "table"), self._ptr(ids, torch.int32, "ids"), self._ptr(x, torch.float16, "x"),
+            ids.numel(), table.shape[1], table.shape[0], next_invperm or None, self._ptr(xp_out, torch.float16, "xp_out"),
+            self._ptr(ss_out, torch.float32, "ss_out"), self._stream(x)))
+
+    def gather_f16(self, src, perm_ptr, dst) -> None:
+        self.lib.check(self.lib.exl2_gather_f16(self._ptr(src, torch.float16, "src"), perm_ptr or None,
+                                                self._ptr(dst, torch.float16, "dst"), src.numel(), self._stream(src)))
 
     # ---- decode-loop utilities + graphs (ours; no reference counterpart at the ext_c level) ----------------------------
 

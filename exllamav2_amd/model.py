@@ -163,8 +163,67 @@ class GreedyGraphDecoder:
         self.graph = None
         # capture is not permitted on the legacy default stream: the decoder owns a stream (device.py:67-72 does too)
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.chain = None
+        if os.environ.get("EXL2_CHAIN", "1") != "0":
+            self._setup_chain()
+
+    def _setup_chain(self):
+        """Chained decode (csrc/qgemv_flat.hip): every producer of the residual stream leaves it in its consumer's packed
+        (act-order) order + partial sums of squares.  Needs: dense layers whose q/k/v and gate/up share a permutation (every
+        quantizer-written checkpoint), an FP16 paged-view cache, a head on this device, <= 16 rows."""
+        m, ext, cfg = self.model, self.model.ext, self.model.config
+        if self.b > 16 or m.lm_head is None or m.embed_tokens is None or getattr(self.cache, "wbits", 0):
+            return
+        plan = []
+        for attn, mlp in m.layers:
+            if not hasattr(mlp, "gate_proj") or mlp.q_handle is None or attn.q_handle is None:
+                return
+            cap_a, in_a, o_inv = ext.q_attn_chain_info(attn.q_handle)
+            cap_m, in_m = ext.q_mlp_chain_info(mlp.q_handle)
+            if not (cap_a and cap_m):
+                return
+            plan.append((in_a, o_inv, in_m))
+        dev = m.device
+        head_perm, head_inv = ext.q_matrix_perm_info(m.lm_head.q_handle)
+        norm_head = torch.empty_like(m.norm.weight)
+        ext.gather_f16(m.norm.weight, head_perm, norm_head)
+        self.chain = {
+            "plan": plan, "head_inv": head_inv, "norm_head": norm_head,
+            "xp_a": torch.zeros((self.b, cfg.hidden_size), dtype=torch.float16, device=dev),
+            "xp_b": torch.zeros((self.b, cfg.hidden_size), dtype=torch.float16, device=dev),
+            "ss_a": torch.zeros((self.b, 256), dtype=torch.float32, device=dev),
+            "ss_b": torch.zeros((self.b, 256), dtype=torch.float32, device=dev),
+        }
+
+    def step_chain(self):
+        m, ext, cfg, ch = self.model, self.model.ext, self.model.config, self.chain
+        b, plan = self.b, ch["plan"]
+        x2 = self.x.view(b, cfg.hidden_size)
+        q = m.temp_q[:b].view(b, 1, cfg.num_attention_heads, cfg.head_dim)
+        k = m.temp_k[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
+        v = m.temp_v[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
+        xp_a, xp_b, ss_a, ss_b = ch["xp_a"], ch["xp_b"], ch["ss_a"], ch["ss_b"]
+        ext.embed_rows_chain(m.embed_tokens, self.ids, x2, plan[0][0], xp_a, ss_a)
+        npart = 1
+        for i, (attn, mlp) in enumerate(m.layers):
+            in_a, o_inv, in_m = plan[i]
+            ext.q_attn_forward_1_chain(attn.q_handle, xp_a, ss_a, npart, b, q, k, v)
+            ao = attn.attend_chain(q, k, v, self.cache, self.cache_seqlens, self.block_table, o_inv)
+            npart = ext.q_attn_forward_2_chain(attn.q_handle, x2, ao, b, in_m, xp_b, ss_b)
+            nxt = plan[i + 1][0] if i + 1 < len(plan) else ch["head_inv"]
+            npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, xp_b, ss_b, npart, b, nxt, xp_a, ss_a)
+        ext.gemm_half_q_half_chain(xp_a, ss_a, npart, ch["norm_head"], cfg.norm_eps, m.lm_head.q_handle, self.logits, b)
+        ext.add_i32_(self.cache_seqlens, 1)
+        ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens)
 
     def step_eager(self):
+        if self.chain is not None:
+            try:
+                return self.step_chain()
+            except RuntimeError as e:
+                if "not covered" not in str(e):
+                    raise
+                self.chain = None               # a shape outside the chained kernels: the module-by-module route below
         m, ext, cfg = self.model, self.model.ext, self.model.config
         ext.embed_rows(m.embed_tokens, self.ids, self.x.view(self.b, cfg.hidden_size))
         for attn, mlp in m.layers:

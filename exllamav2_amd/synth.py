@@ -49,7 +49,9 @@ def group_plan(rows: int, bits: list, props: list, group_size) -> list:
     return plan
 
 
-def synth_linear(k: int, n: int, recipe, device, gen: torch.Generator, sigma: float = 0.02, act_order: bool = True) -> dict:
+def synth_linear(k: int, n: int, recipe, device, gen: torch.Generator, sigma: float = 0.02, act_order: bool = True,
+                 invperm: torch.Tensor | None = None) -> dict:
+    """`invperm`: use this act-order permutation instead of drawing one (projections that share their input share it)."""
     bits, props, gs = recipe
     plan = group_plan(k, bits, props, gs)
     q_groups, smax = [], []
@@ -69,7 +71,9 @@ def synth_linear(k: int, n: int, recipe, device, gen: torch.Generator, sigma: fl
                         * (0.5 + torch.rand(g, device=dev, generator=gen))).half(),
         "q_groups": torch.tensor(q_groups, dtype=torch.int16, device=dev),
     }
-    if act_order:
+    if invperm is not None:
+        w["q_invperm"] = invperm.clone()
+    elif act_order:
         w["q_invperm"] = torch.randperm(k, device=dev, generator=gen).to(torch.int32)
     else:
         w["q_invperm"] = torch.arange(k, device=dev, dtype=torch.int32)
@@ -102,17 +106,22 @@ def synth_linear_gptq(k: int, n: int, group_size: int, device, gen: torch.Genera
 
 
 def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_order: bool = True,
-                     layers=None, with_embed: bool = True, with_head: bool = True) -> dict:
+                     layers=None, with_embed: bool = True, with_head: bool = True, shared_perm: bool = True) -> dict:
     """{'model.layers.0.self_attn.q_proj': {...}, ..., 'model.norm': tensor, 'model.embed_tokens': tensor}.
     Every layer draws from its own generator (seed, layer index), so a rank of a layer-split run can build exactly its
-    slice of the same checkpoint (`layers` = iterable of layer indices)."""
+    slice of the same checkpoint (`layers` = iterable of layer indices).
+    shared_perm (EXL2): q/k/v share one act-order permutation, gate/up (and every expert's w1/w3) another -- as in every
+    checkpoint the reference's quantizer writes: the permutation is argsort(diag(H)) (adaptivegptq.py:236-251) and k/v
+    reuse q's Hessian, gate reuses up's, the experts reuse w1.0's (conversion/quantize.py:138-139,165,190-192).
+    shared_perm=False draws one permutation per linear (format-legal, never produced by the quantizer)."""
     if recipe in GPTQ_RECIPES:
         gs = GPTQ_RECIPES[recipe]
         rec = {k: gs for k in RECIPES["4.0bpw"]}
-        make = lambda k, n, r, dev, gen, sigma, act: synth_linear_gptq(k, n, r, dev, gen, sigma, act)
+        make_ = lambda k, n, r, dev, gen, sigma, act, ip=None: synth_linear_gptq(k, n, r, dev, gen, sigma, act)
     else:
         rec = RECIPES[recipe]
-        make = synth_linear
+        make_ = lambda k, n, r, dev, gen, sigma, act, ip=None: synth_linear(k, n, r, dev, gen, sigma, act, invperm=ip)
+    make = make_
     h, inter = cfg.hidden_size, cfg.intermediate_size
     qd = cfg.num_attention_heads * cfg.head_dim
     kvd = cfg.num_key_value_heads * cfg.head_dim
@@ -128,20 +137,24 @@ def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_ord
         gen = gen_for(i + 1)
         p = f"model.layers.{i}"
         ck[f"{p}.self_attn.q_proj"] = make(h, qd, rec["q_proj"], device, gen, s_attn, act_order)
-        ck[f"{p}.self_attn.k_proj"] = make(h, kvd, rec["k_proj"], device, gen, s_attn, act_order)
-        ck[f"{p}.self_attn.v_proj"] = make(h, kvd, rec["v_proj"], device, gen, s_attn, act_order)
+        ip = ck[f"{p}.self_attn.q_proj"].get("q_invperm") if (shared_perm and act_order) else None
+        ck[f"{p}.self_attn.k_proj"] = make(h, kvd, rec["k_proj"], device, gen, s_attn, act_order, ip)
+        ck[f"{p}.self_attn.v_proj"] = make(h, kvd, rec["v_proj"], device, gen, s_attn, act_order, ip)
         ck[f"{p}.self_attn.o_proj"] = make(qd, h, rec["o_proj"], device, gen, 0.5 / math.sqrt(qd), act_order)
         if getattr(cfg, "num_experts", 0):
             # Mixtral-style sparse MLP (moe_mlp.py:25-133): experts w1 (gate), w3 (up), w2 (down) + fp16 router
+            ip = None
             for e in range(cfg.num_experts):
                 q = f"{p}.block_sparse_moe.experts.{e}"
-                ck[f"{q}.w1"] = make(h, inter, rec["gate_proj"], device, gen, s_attn, act_order)
-                ck[f"{q}.w3"] = make(h, inter, rec["up_proj"], device, gen, s_attn, act_order)
+                ck[f"{q}.w1"] = make(h, inter, rec["gate_proj"], device, gen, s_attn, act_order, ip)
+                if shared_perm and act_order and ip is None: ip = ck[f"{q}.w1"].get("q_invperm")
+                ck[f"{q}.w3"] = make(h, inter, rec["up_proj"], device, gen, s_attn, act_order, ip)
                 ck[f"{q}.w2"] = make(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
             ck[f"{p}.block_sparse_moe.gate"] = (torch.randn(cfg.num_experts, h, device=device, generator=gen) * s_attn).half()
         else:
-            ck[f"{p}.mlp.gate_proj"] = make(h, inter, rec["gate_proj"], device, gen, s_attn, act_order)
             ck[f"{p}.mlp.up_proj"] = make(h, inter, rec["up_proj"], device, gen, s_attn, act_order)
+            ip = ck[f"{p}.mlp.up_proj"].get("q_invperm") if (shared_perm and act_order) else None
+            ck[f"{p}.mlp.gate_proj"] = make(h, inter, rec["gate_proj"], device, gen, s_attn, act_order, ip)
             # the reference folds down_proj's act-order into gate/up at load -> identity perm here
             ck[f"{p}.mlp.down_proj"] = make(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
         ck[f"{p}.input_layernorm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()

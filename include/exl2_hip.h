@@ -117,7 +117,9 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
                            int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
                            int page_size, int pages_per_seq, int past_const, float softmax_scale,
                            int rope_style, int sincos_size, int nsplit, void* scratch, long long scratch_bytes,
-                           void* counters, int n_counters, void* stream);
+                           void* counters, int n_counters, const void* out_invperm, void* stream);
+/* out_invperm (nullable, u16 [num_heads * head_dim]): feature n of a token's output row is stored at column out_invperm[n]
+   -- o_proj's packed (act-order) K order, so that exl2_q_attn_forward_2_chain copies its input without a gather. */
 
 /* Decode attention straight from the Q4 KV cache (ExLlamaV2Cache_Q4, cache.py:409-606; format cache_q.cuh:4-185): replaces
    q_to_fp16_kv of the whole live range (cache.py:472-514) + attention over the fp16 temp.  k_new / v_new (nullable, fp16
@@ -162,6 +164,35 @@ int exl2_free_q_moe_mlp(void* handle);
 int exl2_q_moe_mlp_forward(void* handle, void* x, int rows, void* stream);
 /* router: logits[rows, E] = x gate^T, then softmax -> top-k -> renormalise in place (cuda/q_mlp_softmax.cuh) */
 int exl2_moe_route(const void* x, const void* gate, void* logits, int rows, int hidden, int num_experts, int topk, void* stream);
+
+/* ---- chained decode (ours; replaces the COMPOSITION q_attn.cu:153-345 / q_mlp.cu:153-236 make of rms_norm + q_gemm +
+   act_mul launches on the decode path; csrc/qgemv_flat.hip).  A producer leaves the residual stream in the form its consumer's
+   prologue wants: `xp` = x in the consumer's packed (act-order) K order [rows, hidden], `ss` = one partial sum of squares
+   per producer workgroup [rows, npart] (RMSNorm needs only their sum).  A module is chain-capable when its fused input
+   projections share one act-order permutation (they do in every EXL2 checkpoint: the quantizer reuses one Hessian for
+   q/k/v and for gate/up, conversion/quantize.py:138-139,165) and it is a plain pre-RMSNorm residual block.
+   rows <= 16.  All of these return EXL2_E_INVALID "not covered" for shapes outside the kernel's reach (nothing launched). */
+int exl2_q_attn_chain_info(void* handle, int* capable, const void** in_invperm, const void** o_invperm);
+int exl2_q_mlp_chain_info(void* handle, int* capable, const void** in_invperm);
+int exl2_q_matrix_perm_info(void* q_matrix, const void** perm, const void** invperm);
+/* q, k, v = proj(rmsnorm(x)) from (xp, ss); no RoPE (the attention launch rotates) */
+int exl2_q_attn_forward_1_chain(void* handle, const void* xp, const float* ss, int npart, int rows,
+                                void* temp_q, void* temp_k, void* temp_v, void* stream);
+/* x += attn_out . Wo with attn_out already in o_proj's packed order (exl2_attn_decode_fused out_invperm); publishes
+   (xp_out, ss_out) for the next consumer through next_invperm (nullable = identity); *npart_out = partials per row */
+int exl2_q_attn_forward_2_chain(void* handle, void* x, const void* attn_out_packed, int rows, const void* next_invperm,
+                                void* xp_out, float* ss_out, int* npart_out, void* stream);
+/* x += (act(n Wg) * (n Wu)) Wd, n from (xp, ss); publishes (xp_out, ss_out) for the next consumer */
+int exl2_q_mlp_forward_chain(void* handle, void* x, const void* xp, const float* ss, int npart, int rows,
+                             const void* next_invperm, void* xp_out, float* ss_out, int* npart_out, void* stream);
+/* c = rmsnorm(x) . W from (xp, ss); norm_w_perm = the norm weight gathered through W's q_perm (exl2_gather_f16) */
+int exl2_gemm_half_q_half_chain(const void* xp, const float* ss, int npart, const void* norm_w_perm, float eps,
+                                void* q_matrix, void* c, int rows, void* stream);
+/* embedding rows -> x, and published as (xp_out, ss_out with npart = 1) for the first consumer */
+int exl2_embed_rows_chain(const void* table, const int* ids, void* x, int rows, int hidden, int vocab,
+                          const void* next_invperm, void* xp_out, float* ss_out, void* stream);
+/* dst[i] = src[perm[i]] (u16 perm, nullable = copy), n elements */
+int exl2_gather_f16(const void* src, const void* perm, void* dst, int n, void* stream);
 
 /* ---- decode-loop utilities and graphs (replace cuda/graph.cu and the host-side embedding / argmax round trips) ------- */
 

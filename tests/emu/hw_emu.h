@@ -129,6 +129,8 @@ DEV float fast_exp(float x) { return expf(x); }
 DEV float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
 DEV float fast_rcp(float x) { return 1.0f / x; }
 
+template <typename T> DEV void pin_scalar(T&) { }
+
 // ---- cross-lane ------------------------------------------------------------------------------------------------------
 template <typename T> DEV T emu_wave_read(T mine, int src_lane)
 {
@@ -224,6 +226,8 @@ DEV void sched_fence() { }
 // ---- memory ----------------------------------------------------------------------------------------------------------
 DEV u64 realtime_stamp() { return 0; }
 DEV void dma_to_lds16(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
+DEV void dma_to_lds16_nt(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
+DEV void wait_lds_reads() { }
 DEV void dma_to_lds4(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 4, g_lane_ptr, 4); }
 template <int N> DEV void wait_vmcnt_le() { }
 DEV void block_sync_lds() { block_sync(); }

@@ -1,0 +1,173 @@
+"""Chained decode (csrc/qgemv_flat.hip + the chain entry points of modules.hip) against the oracle and against the
+module-by-module route.
+
+What the chain replaces is a COMPOSITION of reference kernels (q_attn.cu:153-345, q_mlp.cu:153-236: rms_norm -> q_gemm ->
+rope / act_mul -> q_gemm -> residual): its results must equal the oracle's within the same fp16 tolerance as the
+unchained route (tests/test_model.py), step by step, for every bit-width mix, for GPTQ, for several rows.
+"""
+import numpy as np
+import pytest
+import torch
+
+from exllamav2_amd.cache import ExLlamaV2Cache, ExLlamaV2Cache_Q4
+from exllamav2_amd.config import ExLlamaV2Config
+from exllamav2_amd.model import ExLlamaV2, GreedyGraphDecoder
+from exllamav2_amd.synth import synth_checkpoint
+from oracle.model import OracleModel
+from oracle import exl2 as OX
+from oracle import modules as OM
+from tests.test_model import tiny_cfg, check_logits, confident
+from tests.util import exl2_to_torch, half_tol
+
+
+def _decode_and_check(be, cfg, recipe, batch, steps=3, seed=0, act_order=True, expect_chain=True, **ck_kw):
+    ck = synth_checkpoint(cfg, be.device, recipe=recipe, seed=seed, act_order=act_order, **ck_kw)
+    oracle = OracleModel(cfg, ck)
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    cache = ExLlamaV2Cache(model, batch_size=batch)
+    dec = GreedyGraphDecoder(model, cache, batch_size=batch)
+    assert (dec.chain is not None) == expect_chain
+    if not be.is_emu:
+        dec.capture()
+    rng = np.random.default_rng(seed)
+    first = rng.integers(0, cfg.vocab_size, size=(batch,))
+    dec.reset(torch.from_numpy(first), 0)
+    oracle.reset(batch)
+    tok = first.copy()
+    for i in range(steps):
+        dec.run(1, use_graph=not be.is_emu)
+        want = oracle.forward(tok[:, None])[:, -1]
+        got = be.n(dec.logits)[:, :cfg.vocab_size]
+        check_logits(got[:, None], want[:, None])
+        g = be.n(dec.tokens(i, 1))[:, 0]
+        assert np.array_equal(g, got.argmax(-1))                      # the device samples its own logits greedily
+        conf = confident(want)
+        assert np.array_equal(g[conf], want.argmax(-1)[conf])
+        tok = g.copy()                                                  # follow the device: each step is checked alone
+    assert (dec.chain is not None) == expect_chain
+    dec.free()
+    model.unload()
+
+
+@pytest.mark.parametrize("recipe", ["4.0bpw", "3.5bpw", "2.5bpw"])
+@pytest.mark.parametrize("batch", [1, 3])
+def test_chain_decode_equals_oracle(be, recipe, batch):
+    cfg = tiny_cfg(num_attention_heads=4, num_key_value_heads=2, intermediate_size=384)
+    _decode_and_check(be, cfg, recipe, batch, seed=11)
+
+
+def test_chain_decode_many_rows(be):
+    """16 sequences: the row loop of the A_NORM_PRE prologue, 16 finalising waves"""
+    cfg = tiny_cfg(max_batch_size=16)
+    _decode_and_check(be, cfg, "4.0bpw", 16, steps=2, seed=12)
+
+
+@pytest.mark.parametrize("recipe,act_order", [("gptq-4bit-128g", False), ("gptq-4bit-32g", True)])
+def test_chain_decode_gptq(be, recipe, act_order):
+    cfg = tiny_cfg(num_attention_heads=4, num_key_value_heads=2, intermediate_size=384)
+    # GPTQ act-order permutations are derived per matrix from g_idx: synthetic ones differ between q/k/v -> unchained
+    _decode_and_check(be, cfg, recipe, 2, seed=13, act_order=act_order, expect_chain=not act_order)
+
+
+def test_distinct_permutations_fall_back(be):
+    """q/k/v with three different act-order permutations (format-legal, never written by the quantizer): the modules report
+    not chain-capable and the decoder takes the module-by-module route with the same results."""
+    cfg = tiny_cfg()
+    _decode_and_check(be, cfg, "4.0bpw", 1, seed=14, expect_chain=False, shared_perm=False)
+
+
+def test_chain_tokens_equal_unchained_route(be, monkeypatch):
+    cfg = tiny_cfg(num_hidden_layers=3)
+    outs = []
+    for chain in ("1", "0"):
+        monkeypatch.setenv("EXL2_CHAIN", chain)
+        ck = synth_checkpoint(cfg, be.device, recipe="4.0bpw", seed=15)
+        model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+        cache = ExLlamaV2Cache(model, batch_size=2)
+        dec = GreedyGraphDecoder(model, cache, batch_size=2)
+        assert (dec.chain is not None) == (chain == "1")
+        dec.reset(torch.tensor([3, 50]), 0)
+        dec.run(5, use_graph=False)
+        outs.append((be.n(dec.tokens(0, 5)).copy(), be.n(dec.logits).astype(np.float64).copy()))
+        dec.free(); model.unload()
+    # same arithmetic per element up to fp32 summation order: logits within a few fp16 ulps, tokens equal where it matters
+    assert np.abs(outs[0][1] - outs[1][1]).max() < 0.02
+    assert (outs[0][0] == outs[1][0]).mean() >= 0.8
+
+
+def test_q4_cache_stays_unchained(be):
+    cfg = tiny_cfg()
+    ck = synth_checkpoint(cfg, be.device, seed=16)
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    dec = GreedyGraphDecoder(model, ExLlamaV2Cache_Q4(model, batch_size=1), batch_size=1)
+    assert dec.chain is None
+    dec.free(); model.unload()
+
+
+# ---- op level: the chain entry points one by one ------------------------------------------------------------------------
+
+def _mk(be, k, n, spec, seed, invperm=None):
+    t = OX.synth_exl2(k, n, spec, seed=seed, act_order=True, sigma=0.05)
+    if invperm is not None:
+        t["q_invperm"] = invperm.copy()
+    ref = OX.exl2_reconstruct(t)
+    w = exl2_to_torch(be, t)
+    return t, ref, w, be.ext.make_q_matrix_from_dict(w, None)
+
+
+CHAIN_SPECS = {   # <= 4 runs per matrix (main + FLAT_MINORS): full runs and partial super-chunks of every bit width
+    "8_5_3": (416, [(8, 32, 128), (5, 64, 160), (3, 64, 128)]),
+    "6_4_2": (544, [(6, 32, 128), (4, 128, 256), (2, 64, 160)]),
+    "tails_only": (96, [(5, 32, 32), (4, 32, 64)]),
+}
+
+
+@pytest.mark.parametrize("spec_name", list(CHAIN_SPECS))
+@pytest.mark.parametrize("rows", [1, 2, 7])
+def test_gemm_chain_norm_pre(be, rows, spec_name):
+    """exl2_gemm_half_q_half_chain: c = rmsnorm(x) . W from (xp, ss partials, permuted norm weight); every bit width in K"""
+    k, spec = CHAIN_SPECS[spec_name]
+    n = 96
+    t, ref, w, h = _mk(be, k, n, spec, 21)
+    rng = np.random.default_rng(rows)
+    x = (rng.standard_normal((rows, k)) * 2).astype(np.float16)
+    nw = (1 + 0.1 * rng.standard_normal(k)).astype(np.float16)
+    perm = np.argsort(t["q_invperm"]).astype(np.int64)                 # packed row -> input feature
+    xp = x[:, perm]
+    npart = 5                                                          # any split of the sum of squares into partials
+    sq = x.astype(np.float32) ** 2
+    ss = np.stack([sq[:, i::npart].sum(-1) for i in range(npart)], axis=-1).astype(np.float32)
+    c = torch.zeros((rows, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half_chain(be.t(xp), be.t(ss), npart, be.t(nw[perm]), 1e-5, h, c, rows)
+    want = OX.gemm_ref(OM.rms_norm(x, nw, 1e-5), ref, exact=True)
+    assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= 2 * half_tol(want, k))
+    be.ext.free_q_matrix(h)
+
+
+def test_gemm_chain_too_many_runs_is_refused(be):
+    """more bit-width runs than the chained kernel carries: a clean "not covered" error, nothing launched"""
+    t, ref, w, h = _mk(be, 800, 96, [(8, 32, 32), (6, 32, 96), (5, 64, 128), (4, 128, 256), (3, 64, 160), (2, 64, 128)], 22)
+    x = torch.zeros((1, 800), dtype=torch.float16, device=be.device)
+    ss = torch.ones((1, 1), dtype=torch.float32, device=be.device)
+    c = torch.zeros((1, 96), dtype=torch.float16, device=be.device)
+    with pytest.raises(RuntimeError, match="not covered"):
+        be.ext.gemm_half_q_half_chain(x, ss, 1, x[0].clone(), 1e-5, h, c, 1)
+    be.ext.free_q_matrix(h)
+
+
+def test_embed_rows_chain(be):
+    rng = np.random.default_rng(5)
+    vocab, hidden = 50, 256
+    table = rng.standard_normal((vocab, hidden)).astype(np.float16)
+    ids = np.array([3, 49, 0], dtype=np.int32)
+    invperm = rng.permutation(hidden).astype(np.uint16)
+    x = torch.zeros((3, hidden), dtype=torch.float16, device=be.device)
+    xp = torch.zeros_like(x)
+    ss = torch.zeros((3, 256), dtype=torch.float32, device=be.device)
+    inv_t = be.t(invperm.view(np.int16))
+    be.ext.embed_rows_chain(be.t(table), be.t(ids), x, inv_t.data_ptr(), xp, ss)
+    assert np.array_equal(be.n(x), table[ids])
+    want_xp = np.zeros_like(table[ids]); want_xp[:, invperm] = table[ids]
+    assert np.array_equal(be.n(xp), want_xp)
+    want_ss = (table[ids].astype(np.float32) ** 2).sum(-1)
+    assert np.allclose(be.n(ss).reshape(-1)[:3], want_ss, rtol=1e-5)      # [rows, npart = 1]
