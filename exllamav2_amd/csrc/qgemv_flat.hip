@@ -35,7 +35,7 @@
 
 #define FLAT_MAX_SLOTS 16
 #define FLAT_WAVES 16
-#define FLAT_MINORS 3             // bit-width runs besides the main one that a matrix may have on this path
+#define FLAT_MINORS 8             // bit-width runs (full runs and partial super-chunks) besides the main one
 
 #ifdef EXL2_TRACE
 #define FTRACE(i) do { if (args.trace && lane_id() == 0) args.trace[((size_t)bid_x() * 16 + wave_id()) * 16 + (i)] = realtime_stamp(); } while (0)
@@ -59,12 +59,14 @@ struct FpMatHot
     int main_meta;                // bits | chunk0 << 8
     int pad;
 };
-struct FpMinor { const u32* base; u32 tile_stride; u32 n_chunk; u32 meta; u32 pad; };     // 24 bytes: n_super | chunk0 << 16; bits | nvalid << 8
-struct FpMatCold
+struct FpMinor { u32 base_off; u32 tile_stride; u32 n_chunk; u32 meta; };     // 16 bytes: word offset of (tile 0, item 0) in qw / tail;
+                                                                                // n_super | chunk0 << 16; bits | nvalid << 8 | in_tail << 16
+struct alignas(64) FpMatCold
 {
+    const u32* qw; const u32* tail;           // with minor[0..2]: one 64-byte block = one scalar load for the usual matrix
+    FpMinor minor[FLAT_MINORS];
     f16* c; const u16* c_invperm; const f16* bias;
     int ldc, n_minor;
-    FpMinor minor[FLAT_MINORS];
 };
 
 struct FlatArgs
@@ -77,7 +79,8 @@ struct FlatArgs
     int npart, lda, K, M, a_mode, n_mats, pair, a_stride;
     int c_mode, act_gelu, ldxp, any_bias, wgs;
     int units_lo, units_rem;      // a workgroup owns lo units (pairs in pair mode), the first `rem` workgroups one more
-    int S[2], slot_mul[2], slice_mul[2];      // per class (lo / lo + 1 units): waves per slot, floor(w / S) and floor(x / S) multipliers
+    int S[2], slot_mul[2], slice_mul[2];      // per class (lo / lo + 1 units): waves per slot, floor(w / S) and floor(x / Sm) multipliers
+    u32 lds_minor_off, minor_wave_bytes;      // wave-private staging of the minor items
     float eps;
     u32 lds_sc_off, sc_piece, lds_zp_off, lds_cg_off, cg_stride, lds_red_off;
     FpMatHot hot[FLAT_MAX_MATS];
@@ -220,7 +223,7 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
     const int S = cls ? args.S[1] : args.S[0];
     const int slot = (wv * (cls ? args.slot_mul[1] : args.slot_mul[0])) >> 8;  // floor(wv / S)
     const int r = wv - slot * S;
-    const int smul = cls ? args.slice_mul[1] : args.slice_mul[0];               // floor(x / S) = (x * smul) >> 16
+    const int smul = cls ? args.slice_mul[1] : args.slice_mul[0];               // floor(x / Sm) = (x * smul) >> 16
     const bool active = slot < nslots;
     // slot (relative) -> matrix, tile
     auto slot_mat = [&](int s) -> int {
@@ -248,6 +251,10 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
     // the wave's slice of its slot's main run
     const int mj = active ? slot_mat(slot) : 0;
     const int mtile = active ? slot_tile(slot, mj) : 0;
+    // the matrix' minor-run records: requested now (one 64-byte scalar load), used after the ring fill has been issued
+    const u32x4* cold_blk = (const u32x4*)&args.cold[mj];
+    const u32x4 cb0 = cold_blk[0], cb1 = cold_blk[1], cb2 = cold_blk[2], cb3 = cold_blk[3];
+    const int n_minor = active ? (mj == 0 ? args.hot[0].pad : mj == 1 ? args.hot[1].pad : mj == 2 ? args.hot[2].pad : args.hot[3].pad) : 0;
     Seg first; first.n = 0; first.ptr = nullptr; first.bits = 4; first.nvalid = 4; first.chunk0 = 0;
     if (active)
     {
@@ -377,6 +384,44 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
         ph.cg_lds = (const u16*)(smem + args.lds_cg_off + (size_t)mj * args.cg_stride);
     };
 
+    // ---- the minor runs (the matrix' other bit widths, partial super-chunks): a few percent of a tile.  Streamed after the
+    // main slice through registers they would start cold -- a memory round trip on every wave.  Instead every wave copies
+    // ITS share of the slot's minor items (item i of run q belongs to wave (i + 3 q) mod S) into a wave-private LDS area by
+    // LDS-DMA right behind its ring fill, and decodes them from there after the main slice: no round trip, no registers,
+    // no synchronisation (a wave only reads what it copied itself).
+    u8* my_minor = smem + args.lds_minor_off + (size_t)wv * args.minor_wave_bytes;
+    auto for_my_minor_items = [&](auto&& fn) {
+        // fn(src, bits, nvalid, chunk): the same walk at issue and at decode time
+        const u32* qw = (const u32*)(((u64)cb0.y << 32) | cb0.x);
+        const u32* tl = (const u32*)(((u64)cb0.w << 32) | cb0.z);
+        auto one_run = [&](int q, u32 base_off, u32 tile_stride, u32 n_chunk, u32 meta) {
+            const int bits = (int)(meta & 0xFFu), nvalid = (int)((meta >> 8) & 0xFFu);
+            const int F = (int)(n_chunk & 0xFFFFu), chunk0 = (int)(n_chunk >> 16);
+            const u32* base = (((meta >> 16) & 1u) ? tl : qw) + base_off + (size_t)mtile * tile_stride;
+            int i = r - 3 * q; while (i < 0) i += S;                  // first item of run q that is mine
+            #pragma nounroll
+            for (; i < F; i += S) fn(base + (size_t)i * (64u * bits), bits, nvalid, chunk0 + 4 * i);
+        };
+        if (n_minor > 0) one_run(0, cb1.x, cb1.y, cb1.z, cb1.w);
+        if (n_minor > 1) one_run(1, cb2.x, cb2.y, cb2.z, cb2.w);
+        if (n_minor > 2) one_run(2, cb3.x, cb3.y, cb3.z, cb3.w);
+        #pragma nounroll
+        for (int q = 3; q < n_minor; q++)                               // rare: more than three minor runs
+        {
+            const FpMinor& mn = args.cold[mj].minor[q];
+            one_run(q, mn.base_off, mn.tile_stride, mn.n_chunk, mn.meta);
+        }
+    };
+    auto issue_minors = [&]() -> int {
+        int n_dma = 0; u32 off = 0;
+        for_my_minor_items([&](const u32* src, int bits, int nvalid, int chunk) {
+            (void)nvalid; (void)chunk;
+            ring_issue(src, my_minor + off, bits, lane);
+            n_dma += item_dma_instrs(bits); off += 256u * bits;
+        });
+        return n_dma;
+    };
+
     // ---- head: ring fill of the main slice (the weight addresses depend on nothing) around the prologue, then the main
     // slice itself.  One copy per bit width so that the ring lives in typed registers from fill to decode.
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -387,10 +432,11 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
         LaneWords<BITS> b[DD];
         ring_fill<BITS, DD, 0, DD>(b, first.ptr, first.n, lane);
         FTRACE(9);
+        const int mdma = issue_minors();
         prologue();
         FTRACE(3);
         // the LDS-DMA copies (rows in A_DIRECT mode, tables) were issued before the ring loads: wait for them only
-        wait_vmcnt_le<DD * LPI>();
+        wait_vmcnt_dyn(DD * LPI + mdma);
         block_sync_lds();
         FTRACE(4);
         set_tables();
@@ -398,6 +444,7 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
     };
     if (!early)
     {
+        (void)issue_minors();
         prologue();
         FTRACE(3);
         wait_vmcnt_le<0>();
@@ -416,32 +463,33 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
         default: head(std::integral_constant<int, 2>()); break;
     }
 
-    // ---- the other runs of the slot's matrix: slice r of S of every full run, the partial super-chunks to slice 0 ----------
+    // ---- the minor items of this wave, from LDS --------------------------------------------------------------------------------
     if (active)
     {
-        const FpMatCold& cm = args.cold[mj];
-        const int nm = cm.n_minor;
-        #pragma nounroll
-        for (int q = 0; q < nm; q++)
-        {
-            const FpMinor& mn = cm.minor[q];
-            Seg sg;
-            sg.bits = (int)(mn.meta & 0xFFu); sg.nvalid = (int)((mn.meta >> 8) & 0xFFu);
-            const int F = (int)(mn.n_chunk & 0xFFFFu), chunk0 = (int)(mn.n_chunk >> 16);
-            const u32* base = mn.base + (size_t)mtile * mn.tile_stride;
-            if (sg.nvalid != 4)
+        wait_vmcnt_le<0>();                                               // (landed long ago: issued before the main slice streamed)
+        u32 off = 0;
+        for_my_minor_items([&](const u32* src, int bits, int nvalid, int chunk) {
+            (void)src;
+            const u32* slot_ptr = (const u32*)(my_minor + off);
+            off += 256u * bits;
+            auto consume = [&](auto bits_tag) {
+                constexpr int BITS = decltype(bits_tag)::value;
+                LaneWords<BITS> w;
+                lds_lane_words<BITS>(slot_ptr, lane, w);
+                if (nvalid == 4) gemv_super<BITS, GPTQ, true>(w, ph, chunk, 4, lane, acc);
+                else             gemv_super<BITS, GPTQ, false>(w, ph, chunk, nvalid, lane, acc);
+            };
+            if constexpr (GPTQ) consume(std::integral_constant<int, 4>());
+            else switch (bits)
             {
-                if (r != 0) continue;
-                sg.ptr = base; sg.n = 1; sg.chunk0 = chunk0;
+                case 4: consume(std::integral_constant<int, 4>()); break;
+                case 8: consume(std::integral_constant<int, 8>()); break;
+                case 6: consume(std::integral_constant<int, 6>()); break;
+                case 5: consume(std::integral_constant<int, 5>()); break;
+                case 3: consume(std::integral_constant<int, 3>()); break;
+                default: consume(std::integral_constant<int, 2>()); break;
             }
-            else
-            {
-                const int i0 = (r * F * smul) >> 16, i1 = ((r + 1) * F * smul) >> 16;
-                if (i1 <= i0) continue;
-                sg.ptr = base + (size_t)i0 * (64u * sg.bits); sg.n = i1 - i0; sg.chunk0 = chunk0 + 4 * i0;
-            }
-            flat_stream_any<GPTQ>(sg, ph, lane, acc);
-        }
+        });
         // this wave's partial sum of its slot
         const int c = lane & 15, j4 = lane >> 4;
         #pragma unroll
@@ -580,7 +628,7 @@ int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out)
         h.n_tiles = d.N / TILE_N; h.G = d.G; h.cg_units = (int)(d.pack_units - (d.pack_cg_off >> 4));
         h.unit0 = in.pair ? 0 : units;
         FpMatCold& e = args.cold[j];
-        e.c = in.c[j]; e.c_invperm = in.c_invperm[j]; e.bias = d.bias; e.ldc = in.ldc[j];
+        e.qw = d.qw; e.tail = d.tail; e.c = in.c[j]; e.c_invperm = in.c_invperm[j]; e.bias = d.bias; e.ldc = in.ldc[j];
         e.n_minor = 0;
         for (int i = 0; i < d.n_runs; i++)
         {
@@ -590,9 +638,11 @@ int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out)
             if (has_main && i == d.main_run) continue;
             if (e.n_minor >= FLAT_MINORS) return 1;                  // more bit-width runs than this path carries
             FpMinor& mn = e.minor[e.n_minor++];
-            mn.base = (run.in_tail ? d.tail : d.qw) + run.base_word; mn.tile_stride = run.tile_stride;
-            mn.n_chunk = (u32)run.n_super | ((u32)((int)run.k_base >> 5) << 16); mn.meta = (u32)run.bits | ((u32)run.nvalid_last << 8);
+            mn.base_off = run.base_word; mn.tile_stride = run.tile_stride;
+            mn.n_chunk = (u32)run.n_super | ((u32)((int)run.k_base >> 5) << 16);
+            mn.meta = (u32)run.bits | ((u32)run.nvalid_last << 8) | (run.in_tail ? (1u << 16) : 0u);
         }
+        h.pad = e.n_minor;                                          // (hot word: the minor-run count)
         if (d.bias) args.any_bias = 1;
         units += h.n_tiles;
         if (d.G > g_max) g_max = d.G;
@@ -610,6 +660,7 @@ int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out)
     if (in.ss_out && wgs > 256) return 1;
     const int lo = items / wgs, rem = items % wgs;
     const int spu = in.pair ? 2 : 1;
+    u32 minor_wave_bytes = 0;
     for (int c = 0; c < 2; c++)
     {
         const int ns = (lo + c) * spu;                                     // slots of a workgroup of this class
@@ -621,6 +672,21 @@ int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out)
         args.slot_mul[c] = 256 / S + 1;
         args.slice_mul[c] = 65536 / S + 1;
         if (!mul_ok(S, args.slot_mul[c], 8, FLAT_WAVES - 1) || !mul_ok(S, args.slice_mul[c], 16, (S + 1) * (f_max > 0 ? f_max : 1))) return 1;
+        if (ns <= 0) continue;
+        // bytes of minor items the busiest wave of a slot stages (the kernel's assignment: item i of run q -> wave (i + 3 q) mod S)
+        for (int j = 0; j < in.n_mats; j++)
+            for (int r = 0; r < S; r++)
+            {
+                u32 bytes = 0;
+                for (int q = 0; q < args.cold[j].n_minor; q++)
+                {
+                    const FpMinor& mn = args.cold[j].minor[q];
+                    const int F = (int)(mn.n_chunk & 0xFFFFu), bits = (int)(mn.meta & 0xFFu);
+                    int i = r - 3 * q; while (i < 0) i += S;
+                    for (; i < F; i += S) bytes += 256u * bits;
+                }
+                if (bytes > minor_wave_bytes) minor_wave_bytes = bytes;
+            }
     }
     args.a = in.a; args.norm_w = in.norm_w; args.ss = in.ss; args.npart = in.npart; args.lda = in.lda; args.K = K; args.M = M;
     args.a_mode = in.a_mode; args.n_mats = in.n_mats; args.pair = in.pair; args.eps = in.eps;
@@ -634,6 +700,7 @@ int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out)
     args.cg_stride = cg_max * 16;
     args.lds_cg_off = total; total += args.cg_stride * in.n_mats;
     args.lds_red_off = total; total += (u32)FLAT_WAVES * M * 16 * 4;
+    args.lds_minor_off = total; args.minor_wave_bytes = al16(minor_wave_bytes); total += FLAT_WAVES * args.minor_wave_bytes;
     if (total > 160 * 1024) return 1;
 #ifdef EXL2_TRACE
     args.trace = (g_ftrace_buf && g_ftrace_count++ == g_ftrace_which) ? g_ftrace_buf : nullptr;

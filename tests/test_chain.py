@@ -115,7 +115,8 @@ def _mk(be, k, n, spec, seed, invperm=None):
     return t, ref, w, be.ext.make_q_matrix_from_dict(w, None)
 
 
-CHAIN_SPECS = {   # <= 4 runs per matrix (main + FLAT_MINORS): full runs and partial super-chunks of every bit width
+CHAIN_SPECS = {   # full runs and partial super-chunks of every bit width
+    "all_widths": (800, [(8, 32, 32), (6, 32, 96), (5, 64, 128), (4, 128, 256), (3, 64, 160), (2, 64, 128)]),
     "8_5_3": (416, [(8, 32, 128), (5, 64, 160), (3, 64, 128)]),
     "6_4_2": (544, [(6, 32, 128), (4, 128, 256), (2, 64, 160)]),
     "tails_only": (96, [(5, 32, 32), (4, 32, 64)]),
@@ -141,17 +142,6 @@ def test_gemm_chain_norm_pre(be, rows, spec_name):
     be.ext.gemm_half_q_half_chain(be.t(xp), be.t(ss), npart, be.t(nw[perm]), 1e-5, h, c, rows)
     want = OX.gemm_ref(OM.rms_norm(x, nw, 1e-5), ref, exact=True)
     assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= 2 * half_tol(want, k))
-    be.ext.free_q_matrix(h)
-
-
-def test_gemm_chain_too_many_runs_is_refused(be):
-    """more bit-width runs than the chained kernel carries: a clean "not covered" error, nothing launched"""
-    t, ref, w, h = _mk(be, 800, 96, [(8, 32, 32), (6, 32, 96), (5, 64, 128), (4, 128, 256), (3, 64, 160), (2, 64, 128)], 22)
-    x = torch.zeros((1, 800), dtype=torch.float16, device=be.device)
-    ss = torch.ones((1, 1), dtype=torch.float32, device=be.device)
-    c = torch.zeros((1, 96), dtype=torch.float16, device=be.device)
-    with pytest.raises(RuntimeError, match="not covered"):
-        be.ext.gemm_half_q_half_chain(x, ss, 1, x[0].clone(), 1e-5, h, c, 1)
     be.ext.free_q_matrix(h)
 
 
