@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-parity-check", action="store_true", help="skip the pre-timing oracle check of the device logits")
+    p.add_argument("--no-ctx-window", action="store_true", help="skip the extra ctx-1920 decode window")
     p.add_argument("--cache", default="fp16", choices=["fp16", "q4"], help="KV cache type (q4: ExLlamaV2Cache_Q4)")
     p.add_argument("--no-prefill", action="store_true", help="skip the extra prefill measurement (BASELINE configs[2])")
     p.add_argument("--batch", type=int, default=1, help="sequences decoded together (BASELINE configs[4]: 16)")
@@ -78,7 +79,26 @@ def time_gemv_calls(model, dec, reps: int = 5):
     v = model.temp_v[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
     ao = model.temp_attn[:b].view(b, 1, -1)
 
-    def one_step():
+    ch = getattr(dec, "chain", None)
+
+    def one_step_chain():
+        # the q_gemm launches of the chained decode step (csrc/qgemv_flat.hip), with the decoder's own buffers
+        launches, nbytes, npart = 0, 0, 1
+        plan = ch["plan"]
+        x2 = x.view(b, cfg.hidden_size)
+        for i, (attn, mlp) in enumerate(model.layers):
+            in_a, o_inv, in_m = plan[i]
+            ext.q_attn_forward_1_chain(attn.q_handle, ch["xp_a"], ch["ss_a"], npart, b, q, k, v)
+            npart = ext.q_attn_forward_2_chain(attn.q_handle, x2, ao, b, in_m, ch["xp_b"], ch["ss_b"])
+            nxt = plan[i + 1][0] if i + 1 < len(plan) else ch["head_inv"]
+            npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, ch["xp_b"], ch["ss_b"], npart, b, nxt, ch["xp_a"], ch["ss_a"])
+            launches += 4
+            nbytes += sum(l.weight_bytes() for l in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj,
+                                                     mlp.gate_proj, mlp.up_proj, mlp.down_proj))
+        ext.gemm_half_q_half_chain(ch["xp_a"], ch["ss_a"], npart, ch["norm_head"], cfg.norm_eps, model.lm_head.q_handle, dec.logits, b)
+        return launches + 1, nbytes + model.lm_head.weight_bytes()
+
+    def one_step_modules():
         launches, nbytes = 0, 0
         for attn, mlp in model.layers:
             ext.q_attn_forward_1(attn.q_handle, x, b, 1, 0, none_tensor, q, k, v, model.sin, model.cos, apply_rope=False)
@@ -90,6 +110,7 @@ def time_gemv_calls(model, dec, reps: int = 5):
         ext.gemm_half_q_half(dec.xn.view(b, -1), model.lm_head.q_handle, dec.logits)
         return launches + 1, nbytes + model.lm_head.weight_bytes()
 
+    one_step = one_step_chain if ch is not None else one_step_modules
     stream = dec.stream
     with torch.cuda.stream(stream):
         launches, nbytes = one_step()                           # warm-up, eager
@@ -162,17 +183,21 @@ def parity_check(model, oracle, device, n_decode: int = 3):
             "confident_tokens_equal": tok_checked, "tolerance": "0.03 + |x| * 2^-8 (fp16, tests/test_model.py)"}
 
 
-def pmc_traffic_gb(launches_per_step):
-    """HBM GB per decode step fetched by the q_gemm launches, from the committed PMC pass of this same command
+def pmc_traffic_gb(launches_per_step, kernel_prefix: str):
+    """HBM GB per decode step fetched by the q_gemm launches, from the COMMITTED PMC pass of this same command
     (profiles/*_pmc_summary.json: separate `rocprofv3 --pmc FETCH_SIZE` run, KB per launch; x2 = the gfx950 correction for
-    wide coalesced reads, MI355X_MICROARCH.md section HBM).  None when no profile is committed."""
+    wide coalesced reads, MI355X_MICROARCH.md section HBM).  Counters cannot be read from inside this process, so the
+    figure is labelled with the file it comes from.  (None, None) when no profile of this kernel is committed."""
     try:
         files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
-        d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
-        kb = [v["avg"] for k, v in d.items() if k.startswith("FETCH_SIZE:") and "qgemv_stream_kernel<false, 4" in k]
-        return round(kb[0] * 1024 * 2 * launches_per_step / 1e9, 3) if kb else None
+        for f in reversed(files):
+            d = json.load(open(os.path.join(ROOT, "profiles", f)))
+            kb = [v["avg"] for k, v in d.items() if k.startswith("FETCH_SIZE:") and kernel_prefix in k]
+            if kb:
+                return round(kb[0] * 1024 * 2 * launches_per_step / 1e9, 3), "committed profile profiles/" + f
     except Exception:
-        return None
+        pass
+    return None, None
 
 
 def cpu_baseline(cfg, recipe: str, seed: int = 0):
@@ -192,7 +217,7 @@ def cpu_baseline(cfg, recipe: str, seed: int = 0):
               ("gate_proj", h, inter), ("up_proj", h, inter), ("down_proj", inter, h)]
     threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
-    ws = []
+    ws, ts = [], []
     for name, k, n in shapes:
         if gptq:
             w = synth_linear_gptq(k, n, GPTQ_RECIPES[recipe], "cpu", gen)
@@ -200,6 +225,7 @@ def cpu_baseline(cfg, recipe: str, seed: int = 0):
             continue
         w = synth_linear(k, n, rec[name], "cpu", gen)
         t = {kk: vv.numpy() for kk, vv in w.items() if kk != "q_perm"}
+        ts.append(t)
         ws.append(torch.from_numpy(OX.exl2_reconstruct(t).astype(np.float32)))
     tokens = 8
     x = torch.randn(1, h)
@@ -211,9 +237,21 @@ def cpu_baseline(cfg, recipe: str, seed: int = 0):
     dt = (time.perf_counter() - t0) / tokens
     head_scale = (h * cfg.vocab_size) / sum(k * n for _, k, n in shapes)
     per_token = dt * (cfg.num_hidden_layers + head_scale)
-    return {"value": round(1.0 / per_token, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"1 of {cfg.num_hidden_layers} layers (7 linears, pre-dequantized fp32, torch.matmul) x {tokens} tokens, "
-                      f"extrapolated to {cfg.num_hidden_layers} layers + head"}
+    out = {"value": round(1.0 / per_token, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
+           "sample": f"variant B (BASELINE.md 3): 1 of {cfg.num_hidden_layers} layers (7 linears, pre-dequantized fp32, "
+                     f"torch.matmul) x {tokens} tokens, extrapolated to {cfg.num_hidden_layers} layers + head"}
+    # variant A (dequantize on the fly, what a CPU port of the q_gemm path itself does): the oracle's reconstruct + matmul
+    # per token, one layer x one token, extrapolated the same way
+    if not gptq:
+        t0 = time.perf_counter()
+        xa = np.random.default_rng(0).standard_normal((1, h)).astype(np.float32)
+        for t in ts:
+            w = OX.exl2_reconstruct(t).astype(np.float32)
+            _ = (xa if w.shape[0] == h else np.zeros((1, w.shape[0]), np.float32)) @ w
+        dta = time.perf_counter() - t0
+        out["variant_a"] = {"value": round(1.0 / (dta * (cfg.num_hidden_layers + head_scale)), 5), "unit": "tokens/s", "cores": 1,
+                            "sample": "dequantize-on-the-fly (numpy oracle: reconstruct + matmul per token), 1 layer x 1 token, extrapolated"}
+    return out
 
 
 def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq: int = 2048):
@@ -321,20 +359,31 @@ def main():
         kv_bytes = 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2 * (args.ctx + args.warmup + args.steps // 2)
         achieved = gemv_bytes / (gemv_ms * 1e-3) / 1e9
         # the committed PMC pass is of the headline configuration only
-        traffic_gb = pmc_traffic_gb(launches) if (args.model == "llama2-7b" and args.recipe == "4.0bpw") else None
+        chained = getattr(dec, "chain", None) is not None
+        kname = "qgemv_flat_kernel<false>" if chained else "qgemv_stream_kernel<false, 4"
+        traffic_gb, traffic_src = pmc_traffic_gb(launches, kname) if (args.model == "llama2-7b" and args.recipe == "4.0bpw") else (None, None)
+        extra = {}
+        if args.model == "llama2-7b" and args.ctx == 0 and not args.no_ctx_window:
+            # SURVEY.md 8d's second window: the same decode with 1920 tokens already in the cache (steps 1921..1984)
+            dec.reset(torch.tensor([1] * args.batch), 1920)
+            dec.run(8, use_graph=not args.no_graph); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dec.run(64, use_graph=not args.no_graph); torch.cuda.synchronize()
+            extra["ctx1920_tokens_per_s"] = round(64 / (time.perf_counter() - t1), 2)
         result = {
             "value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load,
             "roofline": {
-                "bound": "hbm", "kernel": "qgemv_stream_kernel<false, MB> (all q_gemm launches of a decode step: fused q|k|v, o, fused gate|up, down per layer + head)",
+                "bound": "hbm", "kernel": ("qgemv_flat_kernel" if chained else "qgemv_stream_kernel<false, MB>") + " (all q_gemm launches of a decode step: fused q|k|v, o, fused gate|up, down per layer + head)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None if traffic_gb is None else round(traffic_gb * 1e9 / launches),
-                "traffic_unit": "HBM bytes per q_gemm launch (PMC FETCH_SIZE x2, profiles/*_pmc_summary.json; 4-bit layer launches)",
+                "traffic_unit": "HBM bytes per q_gemm launch (PMC FETCH_SIZE x2)", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(gemv_bytes / launches),
                 "traffic_per_step_GB": traffic_gb, "bytes_per_step": gemv_bytes, "launches_per_step": launches,
                 "avg_launch_us": round(gemv_ms * 1e3 / launches, 2),
                 "step_frac_of_weight_roofline": round((gemv_bytes + kv_bytes) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             },
         }
+        if extra: result["extra"] = extra
         dec.free()
         if parity is not None:
             result["parity_check"] = parity
@@ -364,7 +413,7 @@ def finish(args, cfg, result, rank, world, n_gpus, device, dist):
                        "parallelism": "single GPU" if n_gpus == 1 else
                                       result.get("parallelism", f"layer-split pipeline x{n_gpus}, {n_gpus} sequences in flight")},
         }
-        for k in ("roofline", "load_s", "weight_bytes_per_rank", "parity_check"):
+        for k in ("roofline", "load_s", "weight_bytes_per_rank", "parity_check", "extra"):
             if k in result: out[k] = result[k]
         if not args.no_prefill and n_gpus == 1 and args.model == "llama2-7b" and args.batch == 1:
             try:

@@ -6,6 +6,9 @@ forwarded, with the reference's argument order, to the MI355X library through `e
 C ABI of include/exl2_hip.h).  Names outside the hot path (sampler, safetensors loader, quantizer, LoRA, vision, TP
 host-staging) raise NotImplementedError with the SURVEY.md section that scopes them out -- loudly, never silently.
 """
+import numpy as _np
+import torch as _torch
+
 from exllamav2_amd.ext import ext_c as _e
 
 make_q_matrix = _e.make_q_matrix
@@ -63,6 +66,79 @@ matrix_q4_to_fp16 = _e.matrix_q4_to_fp16
 for _n in ("layer_norm", "layer_norm_", "head_norm", "head_norm_", "softcap_", "gen_mrope_pos_ids", "gemm_half_half_half",
            "had_paley", "had_paley2", "pack_rows_4", "pack_columns", "quantize", "quantize_err", "quantize_range",
            "quantize_range_inplace", "sim_anneal", "apply_rep_penalty", "sample_basic", "logit_filter_exclusive",
-           "fast_fill_cpu_ones_bool", "fast_fadd_cpu", "fast_copy_cpu", "partial_strings_match", "dump_profile_results",
-           "stloader_read", "stloader_open_file", "stloader_close_file", "tensor_remap", "tensor_remap_4bit"):
+           "dump_profile_results", "stloader_open_file", "stloader_close_file"):
     globals()[_n] = _out_of_scope(_n, "outside the quantized forward path (SURVEY.md 2.2: OUT OF SCOPE)")
+
+
+# ---- load path: thin host code, as SURVEY.md 8b asks (the reference's are CPU loops too) ---------------------------------
+
+def stloader_read(filename: str, offset: int, size: int, target) -> None:
+    """ext_stloader.cpp:11-157: `size` bytes at `offset` of `filename` -> the contiguous tensor `target` (CPU or device).
+    The reference reads 1 MiB blocks on 8 threads into a bounce buffer; here one read + one copy (the bytes end up the
+    same; what the loader is FOR -- time to first token -- is SURVEY.md 8f row N3, not this path)."""
+    if size == 0:
+        return
+    nbytes = target.numel() * target.element_size()
+    if size != nbytes:
+        raise RuntimeError(f"stloader_read: {size} bytes requested for a tensor of {nbytes} bytes")
+    if not target.is_contiguous():
+        raise RuntimeError("stloader_read: target must be contiguous")
+    buf = _np.fromfile(filename, dtype=_np.uint8, count=size, offset=offset)
+    if buf.size != size:
+        raise RuntimeError(f"stloader_read: short read from {filename} ({buf.size} of {size} bytes)")
+    target.view(-1).view(_torch.uint8).copy_(_torch.from_numpy(buf))
+
+
+def tensor_remap(tensor, index) -> None:
+    """ext_stloader.cpp:160-184: in place, new[:, c] = old[:, index[c]] (int32 CPU tensors): the MLP act-order folding of
+    linear.py:156-158."""
+    if tensor.dtype != _torch.int32 or index.dtype != _torch.int32 or tensor.dim() != 2 or index.shape[0] != tensor.shape[1]:
+        raise RuntimeError("tensor_remap: expects int32 [rows, cols] and int32 [cols]")
+    tensor.copy_(tensor[:, index.long()])
+
+
+def tensor_remap_4bit(tensor, index) -> None:
+    """ext_stloader.cpp:186-219: the same on 4-bit values packed 8 per int32 along the columns (q_scale)."""
+    if tensor.dtype != _torch.int32 or index.dtype != _torch.int32 or tensor.dim() != 2 or index.shape[0] != tensor.shape[1] * 8:
+        raise RuntimeError("tensor_remap_4bit: expects int32 [rows, cols / 8] and int32 [cols]")
+    w = tensor.numpy().view(_np.uint32)
+    shifts = _np.arange(8, dtype=_np.uint32) * 4
+    nib = ((w[:, :, None] >> shifts) & 0xF).reshape(w.shape[0], -1)            # [rows, cols]
+    nib = nib[:, index.numpy().astype(_np.int64)].reshape(w.shape[0], -1, 8)
+    packed = (nib.astype(_np.uint32) << shifts).sum(axis=-1, dtype=_np.uint32)
+    w[...] = packed
+
+
+def fast_fill_cpu_ones_bool(tensor) -> None:                          # ext_sampling.cpp: logit-filter helper of the sampler
+    tensor.fill_(True)
+
+
+def fast_fadd_cpu(a, b) -> None:
+    a.add_(b)
+
+
+def fast_copy_cpu(a, b) -> None:
+    a.copy_(b)
+
+
+def partial_strings_match(match, offsets, strings) -> int:
+    """cpp/generator.cpp:12-55 (stop-string scan of the generators): `match` and `strings` are UTF-32 buffers, `offsets`
+    the byte offsets of the strings.  Returns the position in `match` of the first full occurrence of a string (strings
+    in order), -2 when a string matches up to the end of `match` (could still complete), -1 otherwise."""
+    q = _np.frombuffer(match, dtype=_np.uint32)
+    off = _np.frombuffer(offsets, dtype=_np.uint32)
+    st = _np.frombuffer(strings, dtype=_np.uint32)
+    q_len = q.size
+    for i in range(off.size - 1):
+        beg = int(off[i]) // 4
+        s = st[beg:int(off[i + 1]) // 4]
+        s_len = s.size
+        for a0 in range(q_len):
+            a, b = a0, 0
+            while a < q_len and b < s_len and q[a] == s[b]:
+                a += 1; b += 1
+                if b == s_len:
+                    return a0
+                if a == q_len:
+                    return -2
+    return -1

@@ -169,8 +169,11 @@ DEV void wait_vmcnt_dyn(int n)
 }
 
 // ---- streaming a segment through a register ring (qgemv_common.h: stream_items) ----------------------------------------------
+#ifndef RING_DEPTH4
+#define RING_DEPTH4 4
+#endif
 #define RING_DEPTH 4
-template <int BITS> struct FlatDepth { static constexpr int v = BITS == 8 ? 3 : RING_DEPTH; };
+template <int BITS> struct FlatDepth { static constexpr int v = BITS == 8 ? 3 : (BITS <= 4 ? RING_DEPTH4 : RING_DEPTH); };
 struct Seg { const u32* ptr; int n; int chunk0; int bits; int nvalid; };
 
 template <int BITS, bool GPTQ>

@@ -106,7 +106,8 @@ def synth_linear_gptq(k: int, n: int, group_size: int, device, gen: torch.Genera
 
 
 def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_order: bool = True,
-                     layers=None, with_embed: bool = True, with_head: bool = True, shared_perm: bool = True) -> dict:
+                     layers=None, with_embed: bool = True, with_head: bool = True, shared_perm: bool = True,
+                     down_act_order: bool = False) -> dict:
     """{'model.layers.0.self_attn.q_proj': {...}, ..., 'model.norm': tensor, 'model.embed_tokens': tensor}.
     Every layer draws from its own generator (seed, layer index), so a rank of a layer-split run can build exactly its
     slice of the same checkpoint (`layers` = iterable of layer indices).
@@ -156,7 +157,8 @@ def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_ord
             ip = ck[f"{p}.mlp.up_proj"].get("q_invperm") if (shared_perm and act_order) else None
             ck[f"{p}.mlp.gate_proj"] = make(h, inter, rec["gate_proj"], device, gen, s_attn, act_order, ip)
             # the reference folds down_proj's act-order into gate/up at load -> identity perm here
-            ck[f"{p}.mlp.down_proj"] = make(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
+            # (down_act_order=True keeps down_proj's own permutation, as on disk: the reference's loader does the folding)
+            ck[f"{p}.mlp.down_proj"] = make(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), down_act_order and act_order)
         ck[f"{p}.input_layernorm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
         ck[f"{p}.post_attention_layernorm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
     if with_embed:

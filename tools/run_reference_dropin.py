@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Runs the UNMODIFIED reference host code (ExLlamaV2Config / ExLlamaV2 / ExLlamaV2Cache, the greedy loop of
+test_inference.py:604-609) on top of the drop-in (dropin/exllamav2_ext.py -> libexl2_hip.so) and prints logits / tokens
+as JSON for the caller to compare with the oracle.
+
+  PYTHONPATH=dropin:<repo>:<dir holding the reference's exllamav2 package> python tools/run_reference_dropin.py <model_dir> <out.npz>
+
+The reference package comes from /root/reference where that exists, or from the build-time mirror of its *.py files under
+the git-ignored oracle/_ref/reference_py (oracle/ref_build/build.sh) on a machine without the reference tree."""
+import sys
+import numpy as np
+import torch
+
+
+def main(model_dir: str, out: str, steps: int = 4):
+    import exllamav2
+    from exllamav2 import ExLlamaV2, ExLlamaV2Config, ExLlamaV2Cache
+    from exllamav2.ext import ext_c
+    assert ext_c.__name__ == "exllamav2_ext" and "dropin" in ext_c.__file__, ext_c.__file__
+    config = ExLlamaV2Config(model_dir)
+    config.max_seq_len = 256
+    config.max_input_len = 32
+    config.no_flash_attn = True                 # contiguous cache + the reference's own _attn_torch for this run ...
+    config.no_sdpa = True                       # ... in its matmul form: the SDPA branch of v0.3.2 passes get_block_diag_mask()
+                                                # == None as the mask when cu_seqlens is unset (attn.py:890-891), i.e. it is
+                                                # NOT causal for q_len > 1 -- a reference bug off the flash-attn path
+    model = ExLlamaV2(config)
+    model.load()
+    cache = ExLlamaV2Cache(model, max_seq_len=256)
+    ids = torch.tensor([[3, 17, 42, 7]])
+    # test_inference.py:604-609: logits = model.forward(ids[:, -1:], cache); sample = argmax; ids = cat
+    logits = model.forward(ids, cache, last_id_only=False)
+    all_logits = [logits.float().cpu().numpy()]
+    toks = []
+    for _ in range(steps):
+        sample = torch.argmax(logits[0, -1]).cpu().unsqueeze(0).unsqueeze(0)
+        toks.append(int(sample))
+        ids = torch.cat((ids, sample), dim=-1)
+        logits = model.forward(ids[:, -1:], cache)
+        all_logits.append(logits.float().cpu().numpy())
+    np.savez(out, prefill=all_logits[0], steps=np.concatenate(all_logits[1:], axis=1), tokens=np.array(toks))
+    print("reference-on-dropin ok:", toks)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
