@@ -65,7 +65,7 @@ matrix_fp16_to_q4 = _e.matrix_fp16_to_q4
 matrix_q4_to_fp16 = _e.matrix_q4_to_fp16
 for _n in ("layer_norm", "layer_norm_", "head_norm", "head_norm_", "softcap_", "gen_mrope_pos_ids", "gemm_half_half_half",
            "had_paley", "had_paley2", "pack_rows_4", "pack_columns", "quantize", "quantize_err", "quantize_range",
-           "quantize_range_inplace", "sim_anneal", "apply_rep_penalty", "sample_basic", "logit_filter_exclusive",
+           "quantize_range_inplace", "sim_anneal", "apply_rep_penalty", "logit_filter_exclusive",
            "dump_profile_results", "stloader_open_file", "stloader_close_file"):
     globals()[_n] = _out_of_scope(_n, "outside the quantized forward path (SURVEY.md 2.2: OUT OF SCOPE)")
 
@@ -142,3 +142,28 @@ def partial_strings_match(match, offsets, strings) -> int:
                 if a == q_len:
                     return -2
     return -1
+
+
+def sample_basic(logits, temperature, top_k, top_p, top_a, min_p, tfs, typical, random, output_tokens, output_probs,
+                 output_kprobs, output_ktokens, logit_filter, mirostat, mirostat_mu, mirostat_tau, mirostat_eta,
+                 post_temperature, xtc_mask, xtc_probability, xtc_threshold, min_temp, max_temp, temp_exponent,
+                 smoothing_factor, skew):
+    """ext_sampling.cpp sample_basic, the GREEDY case only (top_k == 1 or temperature == 0): what
+    ExLlamaV2Sampler.Settings.greedy() asks for and what the reference's test_inference.py measures.  The AVX2 sampler
+    chain (top-p / min-p / typical / mirostat / XTC ...) is outside the quantized forward path and raises."""
+    greedy = top_k == 1 or temperature == 0.0
+    if not greedy or mirostat or (xtc_probability and xtc_probability > 0.0):
+        raise NotImplementedError("exllamav2_ext.sample_basic: only greedy sampling (top_k = 1) is built in this drop-in; "
+                                  "the CPU sampler is outside the quantized forward path (SURVEY.md 2.2)")
+    x = logits.reshape(-1, logits.shape[-1]).float()
+    if logit_filter is not None and logit_filter.device.type != "meta":
+        x = x.masked_fill(~logit_filter.reshape(x.shape).bool(), float("-inf"))
+    tok = _torch.argmax(x, dim=-1)
+    output_tokens.copy_(tok.view(output_tokens.shape))
+    output_probs.fill_(1.0)
+    if output_ktokens is not None and output_ktokens.device.type != "meta":
+        k = output_ktokens.shape[-1]
+        p = _torch.softmax(x, dim=-1)
+        kp, kt = _torch.topk(p, k, dim=-1)
+        output_ktokens.copy_(kt.view(output_ktokens.shape)); output_kprobs.copy_(kp.view(output_kprobs.shape))
+    return []

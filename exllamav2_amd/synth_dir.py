@@ -37,3 +37,26 @@ def write_model_dir(path: str, cfg, ck: dict) -> str:
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump(config, f)
     return path
+
+
+def write_tokenizer(path: str, vocab_size: int) -> None:
+    """A tiny HF tokenizer.json (byte-level BPE without merges: ids 0 / 1 / 2 = <pad> / <s> / </s>, 3..258 = the 256 byte
+    symbols, the rest filler tokens) so that the reference's ExLlamaV2Tokenizer (tokenizer/tokenizer.py:122-) and with it
+    ExLlamaV2DynamicGenerator can be constructed on a synthetic model directory.  Needs the `tokenizers` package (host
+    side, load time only)."""
+    from tokenizers import Tokenizer, models, pre_tokenizers, decoders
+    assert vocab_size >= 259
+    vocab = {"<pad>": 0, "<s>": 1, "</s>": 2}
+    for ch in pre_tokenizers.ByteLevel.alphabet():
+        pass
+    alphabet = sorted(pre_tokenizers.ByteLevel.alphabet())
+    for i, ch in enumerate(alphabet):
+        vocab[ch] = 3 + i
+    for i in range(3 + len(alphabet), vocab_size):
+        vocab[f"<filler{i}>"] = i
+    tok = Tokenizer(models.BPE(vocab=vocab, merges=[], unk_token=None))
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tok.decoder = decoders.ByteLevel()
+    tok.save(os.path.join(path, "tokenizer.json"))
+    with open(os.path.join(path, "tokenizer_config.json"), "w") as f:
+        json.dump({"bos_token": "<s>", "eos_token": "</s>", "pad_token": "<pad>"}, f)

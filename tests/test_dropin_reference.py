@@ -115,6 +115,11 @@ def test_unmodified_reference_runs_on_the_dropin(tmp_path):
     ck = synth_checkpoint(cfg, "cpu", seed=0, down_act_order=True)
     oracle = OracleModel(cfg, ck)
     model_dir = write_model_dir(str(tmp_path / "model"), cfg, ck)
+    try:
+        from exllamav2_amd.synth_dir import write_tokenizer
+        write_tokenizer(model_dir, cfg.vocab_size)                 # enables the dynamic-generator leg of the runner
+    except ImportError:
+        pass
     out = str(tmp_path / "out.npz")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "dropin"), ROOT, ref]))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_dropin.py"), model_dir, out],
@@ -130,3 +135,17 @@ def test_unmodified_reference_runs_on_the_dropin(tmp_path):
         w = oracle.forward(np.array([[int(tok)]]))
         g = got["steps"][:, i:i + 1, :cfg.vocab_size].astype(np.float64)
         assert np.all(np.abs(g - w) <= tol(w)), i
+    # the dynamic generator (paged attention through dropin/flash_attn): per job, logits of every generated position
+    if "dyn_tokens_0" in got:
+        for j in range(2):
+            prompt, toks, lg = got[f"dyn_prompt_{j}"], got[f"dyn_tokens_{j}"], got[f"dyn_logits_{j}"]
+            assert len(toks) == 4 and lg.shape[1] == len(toks)
+            oracle.reset(1)
+            w = oracle.forward(prompt[None, :])[:, -1:]
+            for i, tok in enumerate(toks):
+                g = lg[:, i:i + 1, :cfg.vocab_size].astype(np.float64)
+                assert np.all(np.abs(g - w) <= tol(w)), (j, i)
+                top2 = np.sort(w[0, 0])[-2:]
+                if top2[1] - top2[0] > 0.12:
+                    assert int(tok) == int(np.argmax(w[0, 0])), (j, i)
+                w = oracle.forward(np.array([[int(tok)]]))

@@ -38,8 +38,43 @@ def main(model_dir: str, out: str, steps: int = 4):
         ids = torch.cat((ids, sample), dim=-1)
         logits = model.forward(ids[:, -1:], cache)
         all_logits.append(logits.float().cpu().numpy())
-    np.savez(out, prefill=all_logits[0], steps=np.concatenate(all_logits[1:], axis=1), tokens=np.array(toks))
-    print("reference-on-dropin ok:", toks)
+    res = dict(prefill=all_logits[0], steps=np.concatenate(all_logits[1:], axis=1), tokens=np.array(toks))
+    print("reference-on-dropin ok (contiguous cache, greedy loop):", toks)
+
+    # ---- ExLlamaV2DynamicGenerator, paged mode: attn.py:466-638 forward_paged -> flash_attn_with_kvcache (dropin/flash_attn ->
+    # exl2_rope_kv_append + exl2_paged_attn), page table / defragmenter / prefix matching of dynamic.py untouched
+    import os
+    if os.path.exists(os.path.join(model_dir, "tokenizer.json")):
+        from exllamav2 import ExLlamaV2Tokenizer
+        from exllamav2.generator import ExLlamaV2DynamicGenerator, ExLlamaV2DynamicJob, ExLlamaV2Sampler
+        config2 = ExLlamaV2Config(model_dir)
+        config2.max_seq_len = 1024
+        config2.max_input_len = 256
+        model2 = ExLlamaV2(config2)
+        model2.load()
+        cache2 = ExLlamaV2Cache(model2, max_seq_len=1024)
+        tokenizer = ExLlamaV2Tokenizer(config2)
+        gen = ExLlamaV2DynamicGenerator(model=model2, cache=cache2, tokenizer=tokenizer, max_batch_size=4, max_chunk_size=256, paged=True)
+        assert gen.paged
+        prompts = [[3, 17, 42, 7], [5, 9, 77, 31, 100, 250]]
+        jobs = []
+        for pr in prompts:
+            job = ExLlamaV2DynamicJob(input_ids=torch.tensor([pr]), max_new_tokens=steps, gen_settings=ExLlamaV2Sampler.Settings.greedy(),
+                                      return_logits=True, stop_conditions=[], identifier=len(jobs))
+            gen.enqueue(job); jobs.append(job)
+        toks2 = {i: [] for i in range(len(prompts))}
+        logits2 = {i: [] for i in range(len(prompts))}
+        while gen.num_remaining_jobs():
+            for r in gen.iterate():
+                if r["stage"] == "streaming" and "token_ids" in r:
+                    toks2[r["identifier"]] += r["token_ids"][0].tolist()
+                    if "logits" in r: logits2[r["identifier"]].append(r["logits"].float().cpu().numpy())
+        for i in range(len(prompts)):
+            res[f"dyn_tokens_{i}"] = np.array(toks2[i])
+            res[f"dyn_logits_{i}"] = np.concatenate(logits2[i], axis=1)
+            res[f"dyn_prompt_{i}"] = np.array(prompts[i])
+        print("reference-on-dropin ok (dynamic generator, paged):", toks2)
+    np.savez(out, **res)
 
 
 if __name__ == "__main__":
