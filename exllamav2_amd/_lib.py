@@ -37,7 +37,7 @@ PROTOTYPES = {
     "exl2_act_mul": (ci, [vp, vp, ci, ci, ci, vp, ci, vp]),
     # decode-loop utilities
     "exl2_embed_rows": (ci, [vp, vp, vp, ci, ci, ci, vp]),
-    "exl2_argmax_rows": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, vp]),
+    "exl2_argmax_rows": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp]),
     "exl2_add_i32": (ci, [vp, ci, ci, vp]),
     # quantized KV cache
     "exl2_fp16_to_q_kv": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, ci, vp]),

@@ -305,17 +305,27 @@ KERNEL void __launch_bounds__(256) gather_f16_kernel(const f16* src, const u16* 
 }
 
 KERNEL void __launch_bounds__(1024) argmax_rows_kernel(const f16* logits, int* out_ids, int vocab, int ld,
-                                                       int* history, const int* hist_pos, int hist_stride)
+                                                       int* history, int* hist_pos, int hist_stride, int pos_inc)
 {
     SHARED float best_v[16];
     SHARED int best_i[16];
     const int row = bid_x();
     const f16* lr = logits + (size_t)row * ld;
     float bv = -3.0e38f; int bi = 0;
-    for (int i = tid(); i < vocab; i += nthreads())
+    // 16-byte loads when the row allows it; a thread visits its octets in ascending order and inside an octet the
+    // elements in ascending order, so `>` keeps the lowest index among equal values
+    const bool vec = ((ld & 7) == 0) && ((((size_t)logits) & 15) == 0);
+    const int n8 = vec ? (vocab >> 3) : 0;
+    for (int o = tid(); o < n8; o += nthreads())
+    {
+        const f16x8 v8 = ((const f16x8*)lr)[o];
+        #pragma unroll
+        for (int e = 0; e < 8; e++) { const float v = (float)v8[e]; if (v > bv) { bv = v; bi = o * 8 + e; } }
+    }
+    for (int i = n8 * 8 + tid(); i < vocab; i += nthreads())
     {
         const float v = (float)lr[i];
-        if (v > bv) { bv = v; bi = i; }             // strided scan keeps the lowest index among equal values per thread
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
     }
     // wave reduction: larger value wins, ties -> lower index (torch.argmax returns the first maximum)
     for (int mask = 1; mask < 64; mask <<= 1)
@@ -332,7 +342,14 @@ KERNEL void __launch_bounds__(1024) argmax_rows_kernel(const f16* logits, int* o
         for (int w = 1; w < nw; w++)
             if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) { bv = best_v[w]; bi = best_i[w]; }
         out_ids[row] = bi;
-        if (history) history[(size_t)row * hist_stride + hist_pos[row]] = bi;      // token log, position read on device
+        // token log at the position read on the device; pos_inc != 0: this launch also advances the position (the decode
+        // loop's `cache_seqlens += 1`, one launch less per step)
+        if (hist_pos)
+        {
+            const int pos = hist_pos[row] + pos_inc;
+            if (pos_inc) hist_pos[row] = pos;
+            if (history) history[(size_t)row * hist_stride + pos] = bi;
+        }
     }
 }
 
@@ -377,12 +394,13 @@ int exl2_gather_f16(const void* src, const void* perm, void* dst, int n, void* s
 }
 
 int exl2_argmax_rows(const void* logits, int* out_ids, int rows, int vocab, int ld,
-                     int* history, const int* hist_pos, int hist_stride, void* stream)
+                     int* history, int* hist_pos, int hist_stride, int pos_inc, void* stream)
 {
     EXL2_REQUIRE(logits && out_ids, "argmax_rows: null argument");
+    EXL2_REQUIRE(!history || hist_pos, "argmax_rows: history needs hist_pos");
     if (rows <= 0) return EXL2_OK;
     LAUNCH(argmax_rows_kernel, dim3((unsigned)rows), dim3(1024), 0, stream, (const f16*)logits, out_ids, vocab, ld,
-           history, hist_pos, hist_stride);
+           history, hist_pos, hist_stride, pos_inc);
     HIP_TRY(hipGetLastError());
     return EXL2_OK;
 }

@@ -513,14 +513,15 @@ class ExtC:
                                                 self._ptr(ids, torch.int32, "ids"), self._ptr(out, torch.float16, "out"),
                                                 ids.numel(), table.shape[1], table.shape[0], self._stream(out)))
 
-    def argmax_rows(self, logits, out_ids, vocab: int | None = None, history=None, hist_pos=None) -> None:
-        """Greedy sampling on the device; optionally logs the token at history[row, hist_pos[row]]."""
+    def argmax_rows(self, logits, out_ids, vocab: int | None = None, history=None, hist_pos=None, pos_inc: int = 0) -> None:
+        """Greedy sampling on the device; optionally logs the token at history[row, hist_pos[row] + pos_inc] and, when
+        pos_inc != 0, advances hist_pos by it (the decode loop's position increment, in the same launch)."""
         ld = logits.shape[-1]
         self.lib.check(self.lib.exl2_argmax_rows(self._ptr(logits, torch.float16, "logits"),
                                                  self._ptr(out_ids, torch.int32, "out_ids"), logits.numel() // ld,
                                                  int(vocab or ld), ld, self._ptr(history, torch.int32, "history"),
                                                  self._ptr(hist_pos, torch.int32, "hist_pos"),
-                                                 0 if history is None else history.shape[-1], self._stream(logits)))
+                                                 0 if history is None else history.shape[-1], int(pos_inc), self._stream(logits)))
 
     def add_i32_(self, t, value: int) -> None:
         self.lib.check(self.lib.exl2_add_i32(self._ptr(t, torch.int32, "t"), t.numel(), int(value), self._stream(t)))

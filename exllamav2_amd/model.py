@@ -213,8 +213,7 @@ class GreedyGraphDecoder:
             nxt = plan[i + 1][0] if i + 1 < len(plan) else ch["head_inv"]
             npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, xp_b, ss_b, npart, b, nxt, xp_a, ss_a)
         ext.gemm_half_q_half_chain(xp_a, ss_a, npart, ch["norm_head"], cfg.norm_eps, m.lm_head.q_handle, self.logits, b)
-        ext.add_i32_(self.cache_seqlens, 1)
-        ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens)
+        ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens, pos_inc=1)
 
     def step_eager(self):
         if self.chain is not None:
@@ -231,8 +230,7 @@ class GreedyGraphDecoder:
             mlp.forward(self.x)
         ext.rms_norm(self.x.view(self.b, -1), m.norm.weight, self.xn.view(self.b, -1), cfg.norm_eps)
         ext.gemm_half_q_half(self.xn.view(self.b, -1), m.lm_head.q_handle, self.logits)
-        ext.add_i32_(self.cache_seqlens, 1)
-        ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens)
+        ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens, pos_inc=1)
 
     def _on_stream(self):
         import contextlib

@@ -197,8 +197,11 @@ int exl2_gather_f16(const void* src, const void* perm, void* dst, int n, void* s
 /* ---- decode-loop utilities and graphs (replace cuda/graph.cu and the host-side embedding / argmax round trips) ------- */
 
 int exl2_embed_rows(const void* table, const int* ids, void* out, int rows, int hidden, int vocab, void* stream);
+/* greedy sampling on the device (test_inference.py:607 argmax; first maximum wins like torch.argmax).  history (nullable):
+   token log [rows, hist_stride], written at hist_pos[row] + pos_inc; pos_inc != 0 also stores that sum back to hist_pos (the
+   decode loop's position increment folded into this launch). */
 int exl2_argmax_rows(const void* logits, int* out_ids, int rows, int vocab, int ld,
-                     int* history, const int* hist_pos, int hist_stride, void* stream);
+                     int* history, int* hist_pos, int hist_stride, int pos_inc, void* stream);
 int exl2_add_i32(int* p, int n, int value, void* stream);
 int exl2_graph_begin_capture(void* stream);
 int exl2_graph_end_capture(void* stream, void** graph_exec);
