@@ -13,6 +13,7 @@
 #include "errors.h"
 #include <string.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <vector>
 
 int qgemv_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream);
@@ -104,6 +105,8 @@ static f16* permuted_norm(const f16* w, const QMatrix* qm)
 }
 
 #define MOE_MAX_EXPERTS 16
+struct QMoEMLP;
+static bool hidden_ok(const QMoEMLP* m);
 struct QMoEMLP
 {
     const f16* layernorm; float norm_epsilon;
@@ -111,7 +114,40 @@ struct QMoEMLP
     QMatrix* w1[MOE_MAX_EXPERTS]; QMatrix* w2[MOE_MAX_EXPERTS]; QMatrix* w3[MOE_MAX_EXPERTS];
     f16* temp_state; f16* temp_a; f16* temp_b; f16* temp_logits;
     int max_rows, hidden; bool act_gelu;
+    bool group_ok;                              // every expert's w1 / w3 share one act-order permutation: grouped launches
 };
+
+// ---- small kernels of the grouped MoE path -----------------------------------------------------------------------------------
+// rows of src gathered through a u16 permutation: dst[r, i] = src[r, perm[i]] (activations into the experts' packed K order)
+KERNEL void __launch_bounds__(256) gather_rows_f16_kernel(const f16* src, const u16* perm, f16* dst, int K)
+{
+    const int row = bid_y();
+    const int i = bid_x() * 256 + tid();
+    if (i < K) dst[(size_t)row * K + i] = src[(size_t)row * K + (perm ? (int)perm[i] : i)];
+}
+// x[r, :] += sum over the experts e row r is routed to of part[e, r, :] (already weighted), fp32 sum in expert order, one rounding
+KERNEL void __launch_bounds__(256) moe_combine_kernel(f16* x, const f16* part, const f16* weights, int rows, int hidden, int E)
+{
+    const int row = bid_y();
+    const int o = bid_x() * 256 + tid();
+    if (o * 8 >= hidden) return;
+    f16x8 xv = ((const f16x8*)(x + (size_t)row * hidden))[o];
+    float acc[8];
+    #pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = (float)xv[k];
+    for (int e = 0; e < E; e++)
+    {
+        if (as_u16(weights[(size_t)row * E + e]) == 0) continue;
+        const f16x8 pv = ((const f16x8*)(part + ((size_t)e * rows + row) * hidden))[o];
+        #pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] += (float)pv[k];
+    }
+    #pragma unroll
+    for (int k = 0; k < 8; k++) xv[k] = (f16)acc[k];
+    ((f16x8*)(x + (size_t)row * hidden))[o] = xv;
+}
+
+static bool hidden_ok(const QMoEMLP* m) { return (m->hidden & 7) == 0; }
 
 extern "C" {
 
@@ -139,6 +175,13 @@ int exl2_make_q_moe_mlp(void** handle, const void* layernorm, const void* layern
     }
     m->temp_state = (f16*)temp_state; m->temp_a = (f16*)temp_a; m->temp_b = (f16*)temp_b; m->temp_logits = (f16*)temp_logits;
     m->max_rows = max_rows; m->hidden = m->w1[0]->height; m->act_gelu = act_gelu;
+    {
+        // grouped launches (qgemv_flat.hip) need one packed input order for every expert's gate / up projection -- the
+        // quantizer gives them one (conversion/quantize.py:190-192: w1.i and w3.i reuse w1.0's Hessian)
+        QMatrix* all[2 * MOE_MAX_EXPERTS];
+        for (int i = 0; i < num_experts; i++) { all[2 * i] = m->w1[i]; all[2 * i + 1] = m->w3[i]; }
+        m->group_ok = num_experts <= 16 && same_perm(all, 2 * num_experts) && hidden_ok(m);
+    }
     *handle = m;
     return EXL2_OK;
 }
@@ -159,6 +202,49 @@ int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
     { const int rc = exl2_rms_norm(x, m->layernorm, m->temp_state, m->norm_epsilon, rows, hidden, 0, 0, 0, stream); if (rc) return rc; }
     { const int rc = exl2_moe_route(m->temp_state, m->gate, m->temp_logits, rows, hidden, E, m->num_experts_per_token, stream); if (rc) return rc; }
     const int inter = m->w1[0]->width;
+    // ---- grouped route (rows <= 16): all experts' gate|up in ONE launch (SiLU * up in the epilogue, written in each down
+    // projection's packed order), all experts' down in ONE launch (weighted partial outputs), one combine.  Replaces the
+    // per-expert launch loop below (3 launches per expert: q_mlp.cu:318-402 has the same shape, moe_mlp.py:255-323 a
+    // Python loop above 4 rows).
+    if (m->group_ok && rows <= MAX_GEMV_ROWS && 2 * MAX_GEMV_ROWS <= m->max_rows && (long long)E * rows <= m->max_rows &&
+        (long long)E * rows * hidden <= (long long)m->max_rows * inter && !getenv("EXL2_MOE_SERIAL"))
+    {
+        if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: grouped rows=%d experts=%d\n", rows, E);
+        f16* xg = m->temp_state + (size_t)MAX_GEMV_ROWS * hidden;           // normalised rows in the experts' packed order
+        LAUNCH(gather_rows_f16_kernel, dim3((unsigned)((hidden + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
+               (const f16*)m->temp_state, (const u16*)m->w1[0]->q_perm, xg, hidden);
+        FlatIn ins[MOE_MAX_EXPERTS];
+        for (int e = 0; e < E; e++)
+        {
+            FlatIn& in = ins[e]; memset(&in, 0, sizeof(in));
+            in.qm[0] = m->w1[e]; in.qm[1] = m->w3[e];
+            in.c[0] = m->temp_a + (size_t)e * rows * inter; in.c[1] = in.c[0]; in.ldc[0] = inter; in.ldc[1] = inter;
+            in.c_invperm[0] = m->w2[e]->q_perm ? m->w2[e]->q_invperm : nullptr;
+            in.n_mats = 2; in.pair = 1; in.M = rows; in.a_mode = A_DIRECT; in.a = xg; in.lda = hidden; in.c_mode = C_STORE;
+            in.act_gelu = m->act_gelu ? 1 : 0;
+        }
+        int rc = qgemv_flat_group_launch(ins, E, m->temp_logits, E, 0, 0, stream);
+        if (rc == 0)
+        {
+            for (int e = 0; e < E; e++)
+            {
+                FlatIn& in = ins[e]; memset(&in, 0, sizeof(in));
+                in.qm[0] = m->w2[e]; in.c[0] = m->temp_b + (size_t)e * rows * hidden; in.ldc[0] = hidden;
+                in.n_mats = 1; in.M = rows; in.a_mode = A_DIRECT; in.a = m->temp_a; in.lda = inter; in.c_mode = C_STORE;
+            }
+            rc = qgemv_flat_group_launch(ins, E, m->temp_logits, E, 1, (long long)rows * inter, stream);
+            if (rc < 0) EXL2_FAIL(EXL2_E_INVALID, "q_moe_mlp_forward_: grouped down launch rejected (%d)", rc);
+            if (rc == 0)
+            {
+                LAUNCH(moe_combine_kernel, dim3((unsigned)((hidden / 8 + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
+                       x, (const f16*)m->temp_b, (const f16*)m->temp_logits, rows, hidden, E);
+                HIP_TRY(hipGetLastError());
+                return EXL2_OK;
+            }
+            // (the gate|up launch wrote only temp_a: the serial route below recomputes everything)
+        }
+        else if (rc < 0) EXL2_FAIL(EXL2_E_INVALID, "q_moe_mlp_forward_: grouped gate|up launch rejected (%d)", rc);
+    }
     for (int r0 = 0; r0 < rows; r0 += MAX_GEMV_ROWS)
     {
         const int nr = rows - r0 < MAX_GEMV_ROWS ? rows - r0 : MAX_GEMV_ROWS;

@@ -21,3 +21,9 @@ struct FlatIn
 
 // 0: launched; 1: shape not covered; < 0: error.  *wgs_out = grid size = partial sums a chain-out launch writes per row
 int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out);
+
+// `n_groups` sets of identically shaped matrices (MoE experts) on blockIdx.y of one launch: group g reads its rows at
+// a + g * a_gstride (A_DIRECT only), writes through its own c pointers, is skipped when no row carries a weight in column g
+// of r_weights [M, r_stride]; rows with zero weight are not written; mul_r: result *= weight.  0: launched, 1: not covered.
+int qgemv_flat_group_launch(const FlatIn* ins, int n_groups, const f16* r_weights, int r_stride, int mul_r, long long a_gstride,
+                            void* stream);

@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <mutex>
 
 #define FLAT_MAX_SLOTS 16
 #define FLAT_WAVES 16
@@ -69,22 +70,49 @@ struct alignas(64) FpMatCold
     int ldc, n_minor;
 };
 
-struct FlatArgs
+struct FlatHdr
 {
     const f16* a;                 // A_DIRECT: rows in packed order [M, lda]; A_NORM_PRE: xp [M, lda]
     const f16* norm_w;            // A_NORM_PRE: norm weight in packed order [K]
     const float* ss;              // A_NORM_PRE: partial sums of squares [M, npart]
     f16* xp_out; const u16* xp_invperm; float* ss_out;      // chain-out (nullable): x in the next consumer's order + partials
+    const f16* r_weights;         // grouped (MoE) launches: routing weights [M, r_stride], column = group; nullable
     u64* trace;
     int npart, lda, K, M, a_mode, n_mats, pair, a_stride;
     int c_mode, act_gelu, ldxp, any_bias, wgs;
     int units_lo, units_rem;      // a workgroup owns lo units (pairs in pair mode), the first `rem` workgroups one more
-    int S[2], slot_mul[2], slice_mul[2];      // per class (lo / lo + 1 units): waves per slot, floor(w / S) and floor(x / Sm) multipliers
+    int S[2], slot_mul[2], slice_mul[2];      // per class (lo / lo + 1 units): waves per slot, floor(w / S) and floor(x / S) multipliers
     u32 lds_minor_off, minor_wave_bytes;      // wave-private staging of the minor items
     float eps;
     u32 lds_sc_off, sc_piece, lds_zp_off, lds_cg_off, cg_stride, lds_red_off;
-    FpMatHot hot[FLAT_MAX_MATS];
-    FpMatCold cold[FLAT_MAX_MATS];
+    int r_stride, mul_r;          // grouped launches: row stride of r_weights; multiply the result by the weight (down projection)
+    long long a_gstride;          // grouped launches: elements between the inputs of consecutive groups
+};
+
+// one launch = one set of <= 4 fused matrices ...
+struct FlatArgs : FlatHdr
+{
+    FpMatHot hot_[FLAT_MAX_MATS];
+    FpMatCold cold_[FLAT_MAX_MATS];
+    DEV const FpMatHot& hot(int j) const { return hot_[j]; }
+    DEV const FpMatCold& cold(int j) const { return cold_[j]; }
+    DEV int group() const { return 0; }
+    static constexpr bool grouped = false;
+};
+
+// ... or blockIdx.y = group: every group its own set of matrices, all with the same shapes (the experts of a MoE layer:
+// replaces the per-expert launch loop of QMoEMLP::forward_, q_mlp.cu:318-402 / moe_mlp.py:255-323).  The group index is
+// arithmetic on the block id, so `hot(j)` stays one batch of scalar loads.
+#define FLAT_MAX_GROUPS 16
+#define FLAT_GROUP_MATS 2
+struct FlatGroupArgs : FlatHdr
+{
+    FpMatHot hot_[FLAT_MAX_GROUPS * FLAT_GROUP_MATS];
+    FpMatCold cold_[FLAT_MAX_GROUPS * FLAT_GROUP_MATS];
+    DEV const FpMatHot& hot(int j) const { return hot_[bid_y() * FLAT_GROUP_MATS + (j < FLAT_GROUP_MATS ? j : 0)]; }
+    DEV const FpMatCold& cold(int j) const { return cold_[bid_y() * FLAT_GROUP_MATS + (j < FLAT_GROUP_MATS ? j : 0)]; }
+    DEV int group() const { return bid_y(); }
+    static constexpr bool grouped = true;
 };
 
 // ---- the weight stream: a wave-private ring of items in LDS, filled by LDS-DMA -------------------------------------------
@@ -205,8 +233,11 @@ DEV void flat_stream_any(const Seg& s, const PhaseCtx& ph, int lane, f32x4& acc)
     }
 }
 
-template <bool GPTQ>
-KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
+// BIG: some matrix of the launch has a second run of >= 2 items per wave (e.g. 4 / 3-bit halves): those runs stream through
+// the register ring after the main slice.  A separate instantiation: the extra streaming code costs the common case
+// (one dominant width + a few percent of others) ~10 % through its sheer size (measured).
+template <bool GPTQ, typename ARGS, bool BIG>
+KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
 {
     DYN_SMEM(smem);
     FTRACE(0);
@@ -217,6 +248,17 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
     const int M = args.M, K = args.K;
     const int oct = K >> 3;
     const int b = bid_x();
+
+    // grouped launch: the group's routing weights; a group no row is routed to has nothing to do (wave-uniform scalar loads)
+    const f16* rw = nullptr;
+    if constexpr (ARGS::grouped) rw = args.r_weights ? args.r_weights + args.group() : nullptr;
+    if (ARGS::grouped && rw)
+    {
+        u32 any = 0;
+        for (int rr = 0; rr < M; rr++) any |= (u32)as_u16(rw[(size_t)rr * args.r_stride]);
+        if (uniform(any) == 0) return;
+    }
+    const f16* a_in = ARGS::grouped ? args.a + (size_t)args.group() * (size_t)args.a_gstride : args.a;
 
     // ---- this workgroup's units, this wave's slot and K slice: a handful of scalar ops -----------------------------------
     const int cls = b < args.units_rem ? 1 : 0;
@@ -231,17 +273,18 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
     // slot (relative) -> matrix, tile
     auto slot_mat = [&](int s) -> int {
         if (args.pair) return s & 1;
+        if (args.n_mats == 1) return 0;
         const int u = start + s;
-        return (u >= args.hot[1].unit0 ? 1 : 0) + (u >= args.hot[2].unit0 ? 1 : 0) + (u >= args.hot[3].unit0 ? 1 : 0);
+        return (u >= args.hot(1).unit0 ? 1 : 0) + (u >= args.hot(2).unit0 ? 1 : 0) + (u >= args.hot(3).unit0 ? 1 : 0);
     };
     auto slot_tile = [&](int s, int j) -> int {
         if (args.pair) return start + (s >> 1);
-        const int u0j = j == 0 ? args.hot[0].unit0 : j == 1 ? args.hot[1].unit0 : j == 2 ? args.hot[2].unit0 : args.hot[3].unit0;
+        const int u0j = j == 0 ? args.hot(0).unit0 : j == 1 ? args.hot(1).unit0 : j == 2 ? args.hot(2).unit0 : args.hot(3).unit0;
         return start + s - u0j;
     };
     // first tile of matrix j in this workgroup and how many (its table piece)
     auto mat_piece = [&](int j, int& tile0, int& ntile) {
-        const FpMatHot& h = args.hot[j];
+        const FpMatHot& h = args.hot(j);
         if (args.pair) { tile0 = start; ntile = cnt; return; }
         const int lo = start > h.unit0 ? start : h.unit0;
         const int e = h.unit0 + h.n_tiles, hi = start + cnt < e ? start + cnt : e;
@@ -255,16 +298,16 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
     const int mj = active ? slot_mat(slot) : 0;
     const int mtile = active ? slot_tile(slot, mj) : 0;
     // the matrix' minor-run records: requested now (one 64-byte scalar load), used after the ring fill has been issued
-    const u32x4* cold_blk = (const u32x4*)&args.cold[mj];
+    const u32x4* cold_blk = (const u32x4*)&args.cold(mj);
     const u32x4 cb0 = cold_blk[0], cb1 = cold_blk[1], cb2 = cold_blk[2], cb3 = cold_blk[3];
-    const int n_minor = active ? (mj == 0 ? args.hot[0].pad : mj == 1 ? args.hot[1].pad : mj == 2 ? args.hot[2].pad : args.hot[3].pad) : 0;
+    const int n_minor = active ? (mj == 0 ? args.hot(0).pad : mj == 1 ? args.hot(1).pad : mj == 2 ? args.hot(2).pad : args.hot(3).pad) : 0;
     Seg first; first.n = 0; first.ptr = nullptr; first.bits = 4; first.nvalid = 4; first.chunk0 = 0;
     if (active)
     {
-        const u32* mb = mj == 0 ? args.hot[0].main_base : mj == 1 ? args.hot[1].main_base : mj == 2 ? args.hot[2].main_base : args.hot[3].main_base;
-        const u32 ms = mj == 0 ? args.hot[0].main_stride : mj == 1 ? args.hot[1].main_stride : mj == 2 ? args.hot[2].main_stride : args.hot[3].main_stride;
-        const int mF = mj == 0 ? args.hot[0].main_F : mj == 1 ? args.hot[1].main_F : mj == 2 ? args.hot[2].main_F : args.hot[3].main_F;
-        const int mm = mj == 0 ? args.hot[0].main_meta : mj == 1 ? args.hot[1].main_meta : mj == 2 ? args.hot[2].main_meta : args.hot[3].main_meta;
+        const u32* mb = mj == 0 ? args.hot(0).main_base : mj == 1 ? args.hot(1).main_base : mj == 2 ? args.hot(2).main_base : args.hot(3).main_base;
+        const u32 ms = mj == 0 ? args.hot(0).main_stride : mj == 1 ? args.hot(1).main_stride : mj == 2 ? args.hot(2).main_stride : args.hot(3).main_stride;
+        const int mF = mj == 0 ? args.hot(0).main_F : mj == 1 ? args.hot(1).main_F : mj == 2 ? args.hot(2).main_F : args.hot(3).main_F;
+        const int mm = mj == 0 ? args.hot(0).main_meta : mj == 1 ? args.hot(1).main_meta : mj == 2 ? args.hot(2).main_meta : args.hot(3).main_meta;
         const int i0 = (r * mF * smul) >> 16, i1 = ((r + 1) * mF * smul) >> 16;
         first.bits = mm & 0xFF;
         first.n = i1 - i0;
@@ -282,7 +325,7 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
     float ssp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (args.a_mode == A_DIRECT)
     {
-        const f16* a = args.a; const int lda = args.lda;
+        const f16* a = a_in; const int lda = args.lda;
         for (int rr = 0; rr < M; rr++)
             dma_units16([&](int u) { return (const void*)(a + (size_t)rr * lda + (size_t)u * 8); }, a_lds + (size_t)rr * args.a_stride, oct, wv, nw, lane, rr % nw);
     }
@@ -301,7 +344,7 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
         const int j = wv & 3, sub = wv >> 2;
         if (j < args.n_mats)
         {
-            const FpMatHot& h = args.hot[j];
+            const FpMatHot& h = args.hot(j);
             int tile0, ntile;
             mat_piece(j, tile0, ntile);
             if (ntile > 0)
@@ -380,7 +423,7 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
     auto set_tables = [&]() {
         int tile0, ntile;
         mat_piece(mj, tile0, ntile);
-        const int G = mj == 0 ? args.hot[0].G : mj == 1 ? args.hot[1].G : mj == 2 ? args.hot[2].G : args.hot[3].G;
+        const int G = mj == 0 ? args.hot(0).G : mj == 1 ? args.hot(1).G : mj == 2 ? args.hot(2).G : args.hot(3).G;
         const size_t off = (size_t)mj * args.sc_piece + (size_t)(mtile - tile0) * G * 32;
         ph.sc_lds = (const f16*)(smem + args.lds_sc_off + off);
         ph.zp_lds = (const f16*)(smem + args.lds_zp_off + off);
@@ -393,14 +436,35 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
     // LDS-DMA right behind its ring fill, and decodes them from there after the main slice: no round trip, no registers,
     // no synchronisation (a wave only reads what it copied itself).
     u8* my_minor = smem + args.lds_minor_off + (size_t)wv * args.minor_wave_bytes;
+    // a run's record -> fields.  meta bit 17: a BIG run (>= 2 items per wave): it streams through the register ring after the
+    // main slice (its cold start is paid once per many items); small runs and partial super-chunks are staged in LDS.
+    const u32* cold_qw = (const u32*)(((u64)cb0.y << 32) | cb0.x);
+    const u32* cold_tl = (const u32*)(((u64)cb0.w << 32) | cb0.z);
+    struct MinorRec { const u32* base; int F, bits, nvalid, chunk0; bool big; };
+    auto minor_rec = [&](int q) -> MinorRec {
+        u32 base_off, tile_stride, n_chunk, meta;
+        if (q < 3)
+        {
+            base_off = q == 0 ? cb1.x : q == 1 ? cb2.x : cb3.x; tile_stride = q == 0 ? cb1.y : q == 1 ? cb2.y : cb3.y;
+            n_chunk = q == 0 ? cb1.z : q == 1 ? cb2.z : cb3.z; meta = q == 0 ? cb1.w : q == 1 ? cb2.w : cb3.w;
+        }
+        else
+        {
+            const FpMinor& mn = args.cold(mj).minor[q];                 // rare: more than three minor runs
+            base_off = mn.base_off; tile_stride = mn.tile_stride; n_chunk = mn.n_chunk; meta = mn.meta;
+        }
+        MinorRec m;
+        m.base = (((meta >> 16) & 1u) ? cold_tl : cold_qw) + base_off + (size_t)mtile * tile_stride;
+        m.F = (int)(n_chunk & 0xFFFFu); m.bits = (int)(meta & 0xFFu); m.nvalid = (int)((meta >> 8) & 0xFFu);
+        m.chunk0 = (int)(n_chunk >> 16); m.big = ((meta >> 17) & 1u) != 0;
+        return m;
+    };
+    // (common case, !BIG: the first three records unrolled from registers -- fewest scalar instructions before barrier 1)
     auto for_my_minor_items = [&](auto&& fn) {
-        // fn(src, bits, nvalid, chunk): the same walk at issue and at decode time
-        const u32* qw = (const u32*)(((u64)cb0.y << 32) | cb0.x);
-        const u32* tl = (const u32*)(((u64)cb0.w << 32) | cb0.z);
         auto one_run = [&](int q, u32 base_off, u32 tile_stride, u32 n_chunk, u32 meta) {
             const int bits = (int)(meta & 0xFFu), nvalid = (int)((meta >> 8) & 0xFFu);
             const int F = (int)(n_chunk & 0xFFFFu), chunk0 = (int)(n_chunk >> 16);
-            const u32* base = (((meta >> 16) & 1u) ? tl : qw) + base_off + (size_t)mtile * tile_stride;
+            const u32* base = (((meta >> 16) & 1u) ? cold_tl : cold_qw) + base_off + (size_t)mtile * tile_stride;
             int i = r - 3 * q; while (i < 0) i += S;                  // first item of run q that is mine
             #pragma nounroll
             for (; i < F; i += S) fn(base + (size_t)i * (64u * bits), bits, nvalid, chunk0 + 4 * i);
@@ -411,17 +475,36 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
         #pragma nounroll
         for (int q = 3; q < n_minor; q++)                               // rare: more than three minor runs
         {
-            const FpMinor& mn = args.cold[mj].minor[q];
+            const FpMinor& mn = args.cold(mj).minor[q];
             one_run(q, mn.base_off, mn.tile_stride, mn.n_chunk, mn.meta);
         }
     };
     auto issue_minors = [&]() -> int {
+        // LDS-DMA of this wave's share of the small runs: item i of run q belongs to wave (i + 3 q) mod S
         int n_dma = 0; u32 off = 0;
-        for_my_minor_items([&](const u32* src, int bits, int nvalid, int chunk) {
-            (void)nvalid; (void)chunk;
-            ring_issue(src, my_minor + off, bits, lane);
-            n_dma += item_dma_instrs(bits); off += 256u * bits;
-        });
+        if (!active) return 0;
+        if constexpr (!BIG)
+        {
+            for_my_minor_items([&](const u32* src, int bits, int nvalid, int chunk) {
+                (void)nvalid; (void)chunk;
+                ring_issue(src, my_minor + off, bits, lane);
+                n_dma += item_dma_instrs(bits); off += 256u * bits;
+            });
+            return n_dma;
+        }
+        #pragma nounroll
+        for (int q = 0; q < n_minor; q++)
+        {
+            const MinorRec m = minor_rec(q);
+            if (m.big) continue;
+            int i = r - 3 * q; while (i < 0) i += S;
+            #pragma nounroll
+            for (; i < m.F; i += S)
+            {
+                ring_issue(m.base + (size_t)i * (64u * m.bits), my_minor + off, m.bits, lane);
+                n_dma += item_dma_instrs(m.bits); off += 256u * m.bits;
+            }
+        }
         return n_dma;
     };
 
@@ -466,15 +549,28 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
         default: head(std::integral_constant<int, 2>()); break;
     }
 
-    // ---- the minor items of this wave, from LDS --------------------------------------------------------------------------------
+    // ---- the matrix' other BIG runs: slice r of S of each, through the register ring ---------------------------------------------
+    if constexpr (BIG) if (active)
+    {
+        #pragma nounroll
+        for (int q = 0; q < n_minor; q++)
+        {
+            const MinorRec m = minor_rec(q);
+            if (!m.big) continue;
+            const int i0 = (r * m.F * smul) >> 16, i1 = ((r + 1) * m.F * smul) >> 16;
+            if (i1 <= i0) continue;
+            Seg sg;
+            sg.bits = m.bits; sg.nvalid = m.nvalid; sg.ptr = m.base + (size_t)i0 * (64u * m.bits); sg.n = i1 - i0; sg.chunk0 = m.chunk0 + 4 * i0;
+            flat_stream_any<GPTQ>(sg, ph, lane, acc);
+        }
+    }
+
+    // ---- the small runs' items of this wave, from LDS ---------------------------------------------------------------------------
     if (active)
     {
         wait_vmcnt_le<0>();                                               // (landed long ago: issued before the main slice streamed)
         u32 off = 0;
-        for_my_minor_items([&](const u32* src, int bits, int nvalid, int chunk) {
-            (void)src;
-            const u32* slot_ptr = (const u32*)(my_minor + off);
-            off += 256u * bits;
+        auto decode_item = [&](const u32* slot_ptr, int bits, int nvalid, int chunk) {
             auto consume = [&](auto bits_tag) {
                 constexpr int BITS = decltype(bits_tag)::value;
                 LaneWords<BITS> w;
@@ -492,7 +588,33 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
                 case 3: consume(std::integral_constant<int, 3>()); break;
                 default: consume(std::integral_constant<int, 2>()); break;
             }
-        });
+        };
+        if constexpr (!BIG)
+        {
+            for_my_minor_items([&](const u32* src, int bits, int nvalid, int chunk) {
+                (void)src;
+                const u32* slot_ptr = (const u32*)(my_minor + off);
+                off += 256u * bits;
+                decode_item(slot_ptr, bits, nvalid, chunk);
+            });
+        }
+        else
+        {
+            #pragma nounroll
+            for (int q = 0; q < n_minor; q++)
+            {
+                const MinorRec m = minor_rec(q);
+                if (m.big) continue;
+                int i = r - 3 * q; while (i < 0) i += S;
+                #pragma nounroll
+                for (; i < m.F; i += S)
+                {
+                    const u32* slot_ptr = (const u32*)(my_minor + off);
+                    off += 256u * m.bits;
+                    decode_item(slot_ptr, m.bits, m.nvalid, m.chunk0 + 4 * i);
+                }
+            }
+        }
         // this wave's partial sum of its slot
         const int c = lane & 15, j4 = lane >> 4;
         #pragma unroll
@@ -518,18 +640,20 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
         return v;
     };
     float sq = 0.0f;
+    const f16 rwt = (ARGS::grouped && rw) ? rw[(size_t)row * args.r_stride] : (f16)1.0f;
+    const bool row_on = !(ARGS::grouped && rw) || as_u16(rwt) != 0;      // rows the group is not routed to are left alone
     #pragma unroll
     for (int i = 0; i < 4; i++)
     {
         const int o = (lane >> 4) + 4 * i;
-        if (o < n_out)
+        if (o < n_out && row_on)
         {
             const int s = args.pair ? 2 * o : o;
             const int j = slot_mat(s);
             const int n = slot_tile(s, j) * 16 + ep_c;
-            f16* cbase = j == 0 ? args.cold[0].c : j == 1 ? args.cold[1].c : j == 2 ? args.cold[2].c : args.cold[3].c;
-            const u16* cip = j == 0 ? args.cold[0].c_invperm : j == 1 ? args.cold[1].c_invperm : j == 2 ? args.cold[2].c_invperm : args.cold[3].c_invperm;
-            const int cld = j == 0 ? args.cold[0].ldc : j == 1 ? args.cold[1].ldc : j == 2 ? args.cold[2].ldc : args.cold[3].ldc;
+            f16* cbase = j == 0 ? args.cold(0).c : j == 1 ? args.cold(1).c : j == 2 ? args.cold(2).c : args.cold(3).c;
+            const u16* cip = j == 0 ? args.cold(0).c_invperm : j == 1 ? args.cold(1).c_invperm : j == 2 ? args.cold(2).c_invperm : args.cold(3).c_invperm;
+            const int cld = j == 0 ? args.cold(0).ldc : j == 1 ? args.cold(1).ldc : j == 2 ? args.cold(2).ldc : args.cold(3).ldc;
             f16* cp = cbase + (size_t)row * cld + (cip ? (int)cip[n] : n);
             f16 y;
             if (args.pair)
@@ -537,8 +661,8 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
                 float gv = slot_sum(2 * o), uv = slot_sum(2 * o + 1);
                 if (args.any_bias)
                 {
-                    if (args.cold[0].bias) gv += (float)args.cold[0].bias[n];
-                    if (args.cold[1].bias) uv += (float)args.cold[1].bias[n];
+                    if (args.cold(0).bias) gv += (float)args.cold(0).bias[n];
+                    if (args.cold(1).bias) uv += (float)args.cold(1).bias[n];
                 }
                 y = clamp_h(act_h((f16)gv, args.act_gelu != 0) * (f16)uv);
             }
@@ -547,9 +671,10 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const FlatArgs args)
                 float v = slot_sum(o);
                 if (args.any_bias)
                 {
-                    const f16* bp = j == 0 ? args.cold[0].bias : j == 1 ? args.cold[1].bias : j == 2 ? args.cold[2].bias : args.cold[3].bias;
+                    const f16* bp = j == 0 ? args.cold(0).bias : j == 1 ? args.cold(1).bias : j == 2 ? args.cold(2).bias : args.cold(3).bias;
                     if (bp) v += (float)bp[n];
                 }
+                if (ARGS::grouped && args.mul_r) v *= (float)rwt;
                 if (args.c_mode == C_ACCUM) v += (float)*cp;
                 y = (f16)v;
             }
@@ -600,23 +725,17 @@ static bool mul_ok(int S, int m, int sh, int xmax)
     return true;
 }
 
-// returns 0 when launched, 1 when the shape is not covered (caller falls back), < 0 on error.  *wgs_out = grid size
-// (= the number of partial sums a chain-out launch publishes per row).
-int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out)
+// Fills the header and the per-matrix records of ONE set of fused matrices; `hot` / `cold` point at the set's records.
+// f_max / g_max / cg_max / max_minor accumulate over sets (a grouped launch plans every group into one header).
+struct FlatPlanAcc { int units, g_max, f_max; u32 cg_max; bool any_bias; };
+
+static int flat_fill_mats(const FlatIn& in, FpMatHot* hot, FpMatCold* cold, int n_slots_hot, FlatPlanAcc& acc)
 {
-    if (in.n_mats < 1 || in.n_mats > FLAT_MAX_MATS || in.M < 1 || in.M > MAX_GEMV_ROWS) return 1;
     const QMatrix* q0 = in.qm[0];
     const bool gptq = q0->is_gptq;
-    const int K = q0->height, M = in.M;
-    if (K & 7) return 1;
-    if (!ptr16(in.a) || (in.lda & 7)) return 1;
-    if (in.a_mode == A_NORM_PRE && (!ptr16(in.norm_w) || !in.ss || in.npart < 1 || in.npart > 256)) return 1;
-    if (in.pair && (in.n_mats != 2 || in.qm[0]->width != in.qm[1]->width)) return 1;
-    FlatArgs args;
-    memset(&args, 0, sizeof(args));
-    int units = 0, g_max = 0, f_max = 0, max_bits = 2;
-    u32 cg_max = 0;
-    for (int j = 0; j < FLAT_MAX_MATS; j++) args.hot[j].unit0 = 0x7fffffff;
+    const int K = q0->height;
+    int units = 0;
+    for (int j = 0; j < n_slots_hot; j++) hot[j].unit0 = 0x7fffffff;
     for (int j = 0; j < in.n_mats; j++)
     {
         const QMatrix* qm = in.qm[j];
@@ -624,43 +743,75 @@ int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out)
         if (qm->height != K || qm->is_gptq != gptq || d.n_runs <= 0 || !d.sc_tab || (gptq && !d.zp_tab)) return 1;
         const QRun& mr = d.runs[d.main_run];
         const bool has_main = mr.nvalid_last == 4;                // else: no full super-chunk at all (sections < 128 rows)
-        FpMatHot& h = args.hot[j];
+        FpMatHot& h = hot[j];
         h.main_base = (mr.in_tail ? d.tail : d.qw) + mr.base_word; h.main_stride = mr.tile_stride; h.main_F = has_main ? mr.n_super : 0;
         h.main_meta = (int)mr.bits | (((int)mr.k_base >> 5) << 8);
         h.sc_tab = d.sc_tab; h.zp_tab = d.zp_tab;
         h.n_tiles = d.N / TILE_N; h.G = d.G; h.cg_units = (int)(d.pack_units - (d.pack_cg_off >> 4));
         h.unit0 = in.pair ? 0 : units;
-        FpMatCold& e = args.cold[j];
+        FpMatCold& e = cold[j];
         e.qw = d.qw; e.tail = d.tail; e.c = in.c[j]; e.c_invperm = in.c_invperm[j]; e.bias = d.bias; e.ldc = in.ldc[j];
         e.n_minor = 0;
         for (int i = 0; i < d.n_runs; i++)
         {
             const QRun& run = d.runs[i];
-            if ((int)run.bits > max_bits) max_bits = run.bits;
-            if (run.nvalid_last == 4 && (int)run.n_super > f_max) f_max = run.n_super;
+            if (run.nvalid_last == 4 && (int)run.n_super > acc.f_max) acc.f_max = run.n_super;
             if (has_main && i == d.main_run) continue;
             if (e.n_minor >= FLAT_MINORS) return 1;                  // more bit-width runs than this path carries
             FpMinor& mn = e.minor[e.n_minor++];
             mn.base_off = run.base_word; mn.tile_stride = run.tile_stride;
             mn.n_chunk = (u32)run.n_super | ((u32)((int)run.k_base >> 5) << 16);
             mn.meta = (u32)run.bits | ((u32)run.nvalid_last << 8) | (run.in_tail ? (1u << 16) : 0u);
+            // a full run with >= 2 items for every wave even at the finest split (16 waves per slot): register ring, not LDS staging
+            if (run.nvalid_last == 4 && (int)run.n_super >= 2 * FLAT_WAVES) mn.meta |= 1u << 17;
         }
         h.pad = e.n_minor;                                          // (hot word: the minor-run count)
-        if (d.bias) args.any_bias = 1;
+        if (d.bias) acc.any_bias = true;
         units += h.n_tiles;
-        if (d.G > g_max) g_max = d.G;
-        if ((u32)h.cg_units > cg_max) cg_max = (u32)h.cg_units;
+        if (d.G > acc.g_max) acc.g_max = d.G;
+        if ((u32)h.cg_units > acc.cg_max) acc.cg_max = (u32)h.cg_units;
     }
+    acc.units = units;
+    return 0;
+}
+
+// bytes of minor items the busiest wave of a slot stages (the kernel's assignment: item i of run q -> wave (i + 3 q) mod S)
+static u32 flat_minor_bytes(const FpMatCold* cold, int n_mats, int S)
+{
+    u32 worst = 0;
+    for (int j = 0; j < n_mats; j++)
+        for (int r = 0; r < S; r++)
+        {
+            u32 bytes = 0;
+            for (int q = 0; q < cold[j].n_minor; q++)
+            {
+                const FpMinor& mn = cold[j].minor[q];
+                if ((mn.meta >> 17) & 1u) continue;                       // big run: register ring, not staged
+                const int F = (int)(mn.n_chunk & 0xFFFFu), bits = (int)(mn.meta & 0xFFu);
+                int i = r - 3 * q; while (i < 0) i += S;
+                for (; i < F; i += S) bytes += 256u * bits;
+            }
+            if (bytes > worst) worst = bytes;
+        }
+    return worst;
+}
+
+// the work split + LDS layout shared by all sets of a launch; returns the dynamic LDS size (0: not covered)
+static u32 flat_plan(FlatHdr& hdr, const FlatIn& in, const FlatPlanAcc& acc, u32 minor_bytes_of_S(int, void*), void* ctx,
+                     bool chain_out, int* wgs_out)
+{
+    const int K = in.qm[0]->height, M = in.M;
+    const bool gptq = in.qm[0]->is_gptq;
     const int ncu = flat_num_cus();
     // workgroups: one per CU; more when a workgroup would own more than 16 slots (pairs: 8)
     const int per_wg_max = in.pair ? FLAT_MAX_SLOTS / 2 : FLAT_MAX_SLOTS;
-    const int items = in.pair ? units / 2 : units;
+    const int items = in.pair ? acc.units / 2 : acc.units;
     int wgs = ncu;
     if (items < wgs) wgs = items;
     if ((items + wgs - 1) / wgs > per_wg_max) wgs = (items + per_wg_max - 1) / per_wg_max;
     const char* fw = getenv("EXL2_FLAT_WGS");
     if (fw && atoi(fw) > 0 && (items + atoi(fw) - 1) / atoi(fw) <= per_wg_max && atoi(fw) <= items) wgs = atoi(fw);
-    if (in.ss_out && wgs > 256) return 1;
+    if (chain_out && wgs > 256) return 0;
     const int lo = items / wgs, rem = items % wgs;
     const int spu = in.pair ? 2 : 1;
     u32 minor_wave_bytes = 0;
@@ -668,56 +819,121 @@ int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out)
     {
         const int ns = (lo + c) * spu;                                     // slots of a workgroup of this class
         int S = ns > 0 ? FLAT_WAVES / ns : 1;
-        if (S < 1) return 1;
+        if (S < 1) return 0;
         const char* fsp = getenv("EXL2_FLAT_SPLIT");
         if (fsp && atoi(fsp) > 0 && atoi(fsp) * ns <= FLAT_WAVES) S = atoi(fsp);
-        args.S[c] = S;
-        args.slot_mul[c] = 256 / S + 1;
-        args.slice_mul[c] = 65536 / S + 1;
-        if (!mul_ok(S, args.slot_mul[c], 8, FLAT_WAVES - 1) || !mul_ok(S, args.slice_mul[c], 16, (S + 1) * (f_max > 0 ? f_max : 1))) return 1;
+        hdr.S[c] = S;
+        hdr.slot_mul[c] = 256 / S + 1;
+        hdr.slice_mul[c] = 65536 / S + 1;
+        if (!mul_ok(S, hdr.slot_mul[c], 8, FLAT_WAVES - 1) || !mul_ok(S, hdr.slice_mul[c], 16, (S + 1) * (acc.f_max > 0 ? acc.f_max : 1))) return 0;
         if (ns <= 0) continue;
-        // bytes of minor items the busiest wave of a slot stages (the kernel's assignment: item i of run q -> wave (i + 3 q) mod S)
-        for (int j = 0; j < in.n_mats; j++)
-            for (int r = 0; r < S; r++)
-            {
-                u32 bytes = 0;
-                for (int q = 0; q < args.cold[j].n_minor; q++)
-                {
-                    const FpMinor& mn = args.cold[j].minor[q];
-                    const int F = (int)(mn.n_chunk & 0xFFFFu), bits = (int)(mn.meta & 0xFFu);
-                    int i = r - 3 * q; while (i < 0) i += S;
-                    for (; i < F; i += S) bytes += 256u * bits;
-                }
-                if (bytes > minor_wave_bytes) minor_wave_bytes = bytes;
-            }
+        const u32 b = minor_bytes_of_S(S, ctx);
+        if (b > minor_wave_bytes) minor_wave_bytes = b;
     }
-    args.a = in.a; args.norm_w = in.norm_w; args.ss = in.ss; args.npart = in.npart; args.lda = in.lda; args.K = K; args.M = M;
-    args.a_mode = in.a_mode; args.n_mats = in.n_mats; args.pair = in.pair; args.eps = in.eps;
-    args.a_stride = K + 8; args.c_mode = in.c_mode; args.act_gelu = in.act_gelu;
-    args.xp_out = in.xp_out; args.xp_invperm = in.xp_invperm; args.ss_out = in.ss_out; args.ldxp = in.ldxp; args.wgs = wgs;
-    args.units_lo = lo; args.units_rem = rem;
-    u32 total = al16((u32)M * (u32)args.a_stride * 2);
-    args.sc_piece = al16((u32)(lo + 1) * (u32)g_max * 32);
-    args.lds_sc_off = total; total += args.sc_piece * in.n_mats;
-    args.lds_zp_off = total; total += gptq ? args.sc_piece * in.n_mats : 0;
-    args.cg_stride = cg_max * 16;
-    args.lds_cg_off = total; total += args.cg_stride * in.n_mats;
-    args.lds_red_off = total; total += (u32)FLAT_WAVES * M * 16 * 4;
-    args.lds_minor_off = total; args.minor_wave_bytes = al16(minor_wave_bytes); total += FLAT_WAVES * args.minor_wave_bytes;
-    if (total > 160 * 1024) return 1;
+    hdr.a = in.a; hdr.norm_w = in.norm_w; hdr.ss = in.ss; hdr.npart = in.npart; hdr.lda = in.lda; hdr.K = K; hdr.M = M;
+    hdr.a_mode = in.a_mode; hdr.n_mats = in.n_mats; hdr.pair = in.pair; hdr.eps = in.eps;
+    hdr.a_stride = K + 8; hdr.c_mode = in.c_mode; hdr.act_gelu = in.act_gelu; hdr.any_bias = acc.any_bias ? 1 : 0;
+    hdr.xp_out = in.xp_out; hdr.xp_invperm = in.xp_invperm; hdr.ss_out = in.ss_out; hdr.ldxp = in.ldxp; hdr.wgs = wgs;
+    hdr.units_lo = lo; hdr.units_rem = rem;
+    u32 total = al16((u32)M * (u32)hdr.a_stride * 2);
+    hdr.sc_piece = al16((u32)(lo + 1) * (u32)acc.g_max * 32);
+    hdr.lds_sc_off = total; total += hdr.sc_piece * in.n_mats;
+    hdr.lds_zp_off = total; total += gptq ? hdr.sc_piece * in.n_mats : 0;
+    hdr.cg_stride = acc.cg_max * 16;
+    hdr.lds_cg_off = total; total += hdr.cg_stride * in.n_mats;
+    hdr.lds_red_off = total; total += (u32)FLAT_WAVES * M * 16 * 4;
+    hdr.lds_minor_off = total; hdr.minor_wave_bytes = al16(minor_wave_bytes); total += FLAT_WAVES * hdr.minor_wave_bytes;
+    if (total > 160 * 1024) return 0;
 #ifdef EXL2_TRACE
-    args.trace = (g_ftrace_buf && g_ftrace_count++ == g_ftrace_which) ? g_ftrace_buf : nullptr;
+    hdr.trace = (g_ftrace_buf && g_ftrace_count++ == g_ftrace_which) ? g_ftrace_buf : nullptr;
 #endif
-    static bool attr = false;
-    if (!attr)
-    {
-        (void)hipFuncSetAttribute((const void*)qgemv_flat_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)qgemv_flat_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    dim3 grid((unsigned)wgs, 1, 1), block(FLAT_WAVES * 64, 1, 1);
-    if (gptq) LAUNCH((qgemv_flat_kernel<true>), grid, block, total, stream, args);
-    else      LAUNCH((qgemv_flat_kernel<false>), grid, block, total, stream, args);
     if (wgs_out) *wgs_out = wgs;
+    return total;
+}
+
+static bool flat_in_ok(const FlatIn& in)
+{
+    if (in.n_mats < 1 || in.n_mats > FLAT_MAX_MATS || in.M < 1 || in.M > MAX_GEMV_ROWS) return false;
+    if (in.qm[0]->height & 7) return false;
+    if (!ptr16(in.a) || (in.lda & 7)) return false;
+    if (in.a_mode == A_NORM_PRE && (!ptr16(in.norm_w) || !in.ss || in.npart < 1 || in.npart > 256)) return false;
+    if (in.pair && (in.n_mats != 2 || in.qm[0]->width != in.qm[1]->width)) return false;
+    return true;
+}
+
+static void flat_attrs()
+{
+    static bool attr = false;
+    if (attr) return;
+#define FLAT_ATTR(...) (void)hipFuncSetAttribute((const void*)qgemv_flat_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    FLAT_ATTR(false, FlatArgs, false); FLAT_ATTR(false, FlatArgs, true); FLAT_ATTR(true, FlatArgs, false);
+    FLAT_ATTR(false, FlatGroupArgs, false); FLAT_ATTR(false, FlatGroupArgs, true); FLAT_ATTR(true, FlatGroupArgs, false);
+#undef FLAT_ATTR
+    attr = true;
+}
+
+static bool flat_any_big(const FpMatCold* cold, int n)
+{
+    for (int j = 0; j < n; j++) for (int q = 0; q < cold[j].n_minor; q++) if ((cold[j].minor[q].meta >> 17) & 1u) return true;
+    return false;
+}
+
+// returns 0 when launched, 1 when the shape is not covered (caller falls back), < 0 on error.  *wgs_out = grid size
+// (= the number of partial sums a chain-out launch publishes per row).
+int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out)
+{
+    if (!flat_in_ok(in)) return 1;
+    FlatArgs args;
+    memset(&args, 0, sizeof(args));
+    FlatPlanAcc acc; memset(&acc, 0, sizeof(acc));
+    if (flat_fill_mats(in, args.hot_, args.cold_, FLAT_MAX_MATS, acc)) return 1;
+    struct Ctx { const FpMatCold* cold; int n; } ctx = {args.cold_, in.n_mats};
+    int wgs = 0;
+    const u32 lds = flat_plan(args, in, acc, [](int S, void* c) { return flat_minor_bytes(((Ctx*)c)->cold, ((Ctx*)c)->n, S); }, &ctx,
+                              in.ss_out != nullptr, &wgs);
+    if (!lds) return 1;
+    flat_attrs();
+    dim3 grid((unsigned)wgs, 1, 1), block(FLAT_WAVES * 64, 1, 1);
+    if (in.qm[0]->is_gptq) LAUNCH((qgemv_flat_kernel<true, FlatArgs, false>), grid, block, lds, stream, args);      // (GPTQ: one run)
+    else if (flat_any_big(args.cold_, in.n_mats)) LAUNCH((qgemv_flat_kernel<false, FlatArgs, true>), grid, block, lds, stream, args);
+    else                   LAUNCH((qgemv_flat_kernel<false, FlatArgs, false>), grid, block, lds, stream, args);
+    if (wgs_out) *wgs_out = wgs;
+    return 0;
+}
+
+// Grouped launch: `n_groups` sets of matrices of identical shapes (the experts of a MoE layer) as blockIdx.y of ONE launch.
+// Group g reads its input rows at a + g * a_gstride, writes through its own c pointers, and is weighted by column g of
+// r_weights [M, r_stride]: a group none of whose rows carries a weight exits at entry (q_gemm_kernel.cuh:189-200), rows
+// with a zero weight are not written; mul_r multiplies the result by the weight.
+int qgemv_flat_group_launch(const FlatIn* ins, int n_groups, const f16* r_weights, int r_stride, int mul_r, long long a_gstride,
+                            void* stream)
+{
+    if (n_groups < 1 || n_groups > FLAT_MAX_GROUPS || !r_weights) return 1;
+    const FlatIn& in0 = ins[0];
+    if (in0.n_mats > FLAT_GROUP_MATS || in0.xp_out || in0.ss_out || in0.c_mode != C_STORE) return 1;
+    static FlatGroupArgs args;                                        // (large: keep it off the stack; launches copy it)
+    static std::mutex mtx;
+    std::lock_guard<std::mutex> lock(mtx);
+    memset(&args, 0, sizeof(args));
+    FlatPlanAcc acc; memset(&acc, 0, sizeof(acc));
+    int units0 = -1;
+    for (int g = 0; g < n_groups; g++)
+    {
+        const FlatIn& in = ins[g];
+        if (!flat_in_ok(in) || in.n_mats != in0.n_mats || in.pair != in0.pair || in.M != in0.M || in.a_mode != A_DIRECT ||
+            in.qm[0]->height != in0.qm[0]->height || in.qm[0]->is_gptq != in0.qm[0]->is_gptq) return 1;
+        if (flat_fill_mats(in, args.hot_ + g * FLAT_GROUP_MATS, args.cold_ + g * FLAT_GROUP_MATS, FLAT_GROUP_MATS, acc)) return 1;
+        if (units0 < 0) units0 = acc.units; else if (acc.units != units0) return 1;       // same shapes in every group
+    }
+    struct Ctx { const FpMatCold* cold; int n; } ctx = {args.cold_, n_groups * FLAT_GROUP_MATS};
+    int wgs = 0;
+    const u32 lds = flat_plan(args, in0, acc, [](int S, void* c) { return flat_minor_bytes(((Ctx*)c)->cold, ((Ctx*)c)->n, S); }, &ctx, false, &wgs);
+    if (!lds) return 1;
+    args.r_weights = r_weights; args.r_stride = r_stride; args.mul_r = mul_r; args.a_gstride = a_gstride;
+    flat_attrs();
+    dim3 grid((unsigned)wgs, (unsigned)n_groups, 1), block(FLAT_WAVES * 64, 1, 1);
+    if (in0.qm[0]->is_gptq) LAUNCH((qgemv_flat_kernel<true, FlatGroupArgs, false>), grid, block, lds, stream, args);
+    else if (flat_any_big(args.cold_, n_groups * FLAT_GROUP_MATS)) LAUNCH((qgemv_flat_kernel<false, FlatGroupArgs, true>), grid, block, lds, stream, args);
+    else                    LAUNCH((qgemv_flat_kernel<false, FlatGroupArgs, false>), grid, block, lds, stream, args);
     return 0;
 }

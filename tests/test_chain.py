@@ -120,6 +120,7 @@ CHAIN_SPECS = {   # full runs and partial super-chunks of every bit width
     "8_5_3": (416, [(8, 32, 128), (5, 64, 160), (3, 64, 128)]),
     "6_4_2": (544, [(6, 32, 128), (4, 128, 256), (2, 64, 160)]),
     "tails_only": (96, [(5, 32, 32), (4, 32, 64)]),
+    "two_big_runs": (8448, [(4, 128, 4224), (3, 64, 4096), (2, 64, 128)]),    # a second run of >= 32 super-chunks: register ring
 }
 
 
@@ -141,7 +142,10 @@ def test_gemm_chain_norm_pre(be, rows, spec_name):
     c = torch.zeros((rows, n), dtype=torch.float16, device=be.device)
     be.ext.gemm_half_q_half_chain(be.t(xp), be.t(ss), npart, be.t(nw[perm]), 1e-5, h, c, rows)
     want = OX.gemm_ref(OM.rms_norm(x, nw, 1e-5), ref, exact=True)
-    assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= 2 * half_tol(want, k))
+    # the normalised activations may sit one fp16 ulp from the oracle's (fp32 partial sums vs float64): K independent
+    # 2^-11 relative perturbations add ~ sqrt(K) * 2^-11 * |x| |w| on top of the output rounding
+    slack = 2 * max(1.0, (k / 1024.0) ** 0.5)
+    assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= slack * half_tol(want, k))
     be.ext.free_q_matrix(h)
 
 

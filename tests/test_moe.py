@@ -28,24 +28,35 @@ def test_moe_route(be, experts, topk):
     assert np.allclose(got.astype(np.float32).sum(-1), 1.0, atol=2e-3)
 
 
+@pytest.mark.parametrize("shared_perm", [True, False])
 @pytest.mark.parametrize("rows", [1, 3, 16, 21])
-def test_moe_mlp_forward(be, rows):
+def test_moe_mlp_forward(be, rows, shared_perm):
     """Every expert's kernels see all rows; rows not routed to it are skipped, launches with no routed row exit.
-    rows = 16 is BASELINE config 5's decode batch (the reference falls back to a torch loop above 4 rows)."""
+    rows = 16 is BASELINE config 5's decode batch (the reference falls back to a torch loop above 4 rows).
+    shared_perm: every expert's w1 / w3 carry ONE act-order permutation, as the quantizer writes them
+    (conversion/quantize.py:190-192) -> the grouped route (all experts in one launch per projection stage) for rows <= 16;
+    per-matrix permutations (format-legal, never produced) -> the per-expert launch loop."""
+    from tests.util import exl2_to_torch
     rng = np.random.default_rng(31)
     E, topk, hidden, inter = 8, 2, 128, 256
-    spec_up = [(4, 32, hidden)]
+    spec_up = [(5, 32, 32), (4, 32, hidden - 32)]
     spec_dn = [(5, 32, 64), (4, 64, inter - 64)]
     keep, handles, refs = [], {"w1": [], "w2": [], "w3": []}, {"w1": [], "w2": [], "w3": []}
+    shared = rng.permutation(hidden).astype(np.int32)
     for e in range(E):
         for name, (k, n, spec) in (("w1", (hidden, inter, spec_up)), ("w3", (hidden, inter, spec_up)), ("w2", (inter, hidden, spec_dn))):
-            t, ref, w, h = make_exl2(be, k, n, spec, seed=100 + 3 * e + len(name) + ord(name[1]), act_order=True)
+            t = OX.synth_exl2(k, n, spec, seed=100 + 3 * e + len(name) + ord(name[1]), act_order=True)
+            if shared_perm and name != "w2":
+                t["q_invperm"] = shared.copy()
+            ref = OX.exl2_reconstruct(t)
+            w = exl2_to_torch(be, t)
+            h = be.ext.make_q_matrix_from_dict(w, None)
             keep.append(w); handles[name].append(h); refs[name].append(ref)
     norm_w = (1.0 + 0.1 * rng.standard_normal(hidden)).astype(F16)
     gate = (rng.standard_normal((E, hidden)) * 0.3).astype(F16)
     x = rng.standard_normal((rows, hidden)).astype(F16)
 
-    max_rows = 32
+    max_rows = 128                                        # room for the grouped route's per-expert scratch (E * rows rows)
     dev = be.device
     ts = torch.zeros((max_rows, hidden), dtype=torch.float16, device=dev)
     ta = torch.zeros((max_rows, inter), dtype=torch.float16, device=dev)

@@ -13,16 +13,18 @@ def main():
     gen = torch.Generator(device="cuda"); gen.manual_seed(0)
     rec_up = ([4, 3], [0.5, 0.5], 128); rec_dn = ([4, 3], [0.6, 0.4], 128)
     mods, keep = [], []
-    max_rows = 16
+    max_rows = 128
     ts = torch.empty((max_rows, hidden), device="cuda", dtype=torch.float16)
     ta = torch.empty((max_rows, inter), device="cuda", dtype=torch.float16)
     tb = torch.empty((max_rows, inter), device="cuda", dtype=torch.float16)
     bytes_expert = 0
     for l in range(layers):
         hs = {"w1": [], "w2": [], "w3": []}
+        ip = None                                         # one act-order permutation for every expert's w1 / w3 (quantize.py:190-192)
         for e in range(E):
             for name, (k, n, rec) in (("w1", (hidden, inter, rec_up)), ("w3", (hidden, inter, rec_up)), ("w2", (inter, hidden, rec_dn))):
-                w = synth_linear(k, n, rec, "cuda", gen); keep.append(w)
+                w = synth_linear(k, n, rec, "cuda", gen, invperm=(ip if name != "w2" else None)); keep.append(w)
+                if name == "w1" and ip is None: ip = w["q_invperm"]
                 h = ext.make_q_matrix_from_dict(w, none_tensor); hs[name].append(h)
                 if l == 0 and e == 0: bytes_expert += ext.q_matrix_info(h)["bytes"]
         norm = torch.ones((hidden,), device="cuda", dtype=torch.float16)
