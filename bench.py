@@ -360,7 +360,7 @@ def main():
         achieved = gemv_bytes / (gemv_ms * 1e-3) / 1e9
         # the committed PMC pass is of the headline configuration only
         chained = getattr(dec, "chain", None) is not None
-        kname = "qgemv_flat_kernel<false>" if chained else "qgemv_stream_kernel<false, 4"
+        kname = "qgemv_flat_kernel<false" if chained else "qgemv_stream_kernel<false, 4"
         traffic_gb, traffic_src = pmc_traffic_gb(launches, kname) if (args.model == "llama2-7b" and args.recipe == "4.0bpw") else (None, None)
         extra = {}
         if args.model == "llama2-7b" and args.ctx == 0 and not args.no_ctx_window:
