@@ -559,12 +559,11 @@ static void launch_decode(const AttnArgs& a, int rb, dim3 grid, void* stream)
 {
     const int lpk = HDIM / 8, kpw = 64 / lpk;
     const size_t lds = (size_t)ATT_WAVES * kpw * rb * (HDIM + 2) * 4;
-    static bool attr_done = false;
-    if (!attr_done)
+    static bool attr_done[EXL2_MAX_DEVICES] = {false};
+    if (exl2_first_on_device(attr_done))
     {
         (void)hipFuncSetAttribute((const void*)attn_decode_kernel<HDIM, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)attn_decode_kernel<HDIM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     switch (rb)
     {
@@ -695,9 +694,9 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
     const size_t lds = (size_t)ATT_WAVES * kpw * rb * (head_dim + 2) * 4 + 16;
 #define FUSED_CASE(HDIM_, RB_) LAUNCH((attn_fused_kernel<HDIM_, RB_>), grid, dim3(ATT_WAVES * 64), lds, stream, a)
 #define FUSED_HD(HDIM_) \
-    do { static bool attr_done = false; \
-         if (!attr_done) { (void)hipFuncSetAttribute((const void*)attn_fused_kernel<HDIM_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                           (void)hipFuncSetAttribute((const void*)attn_fused_kernel<HDIM_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+    do { static bool attr_done[EXL2_MAX_DEVICES] = {false}; \
+         if (exl2_first_on_device(attr_done)) { (void)hipFuncSetAttribute((const void*)attn_fused_kernel<HDIM_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                           (void)hipFuncSetAttribute((const void*)attn_fused_kernel<HDIM_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
          switch (rb) { case 1: FUSED_CASE(HDIM_, 1); break; case 2: FUSED_CASE(HDIM_, 2); break; \
                        case 4: FUSED_CASE(HDIM_, 4); break; default: FUSED_CASE(HDIM_, 8); break; } } while (0)
     if (head_dim == 64) FUSED_HD(64);

@@ -422,12 +422,11 @@ static void launch_q4(const AttnQ4Args& a, int rb, dim3 grid, void* stream)
     size_t lds = ((size_t)AQ_WAVES * kpw * rb + rb) * (HDIM + 2) * 4;
     const size_t pro = (size_t)rb * HDIM * 4 + (size_t)rb * HDIM * 2 + AQ_MAX_PAGES * 4;     // prologue: rotated + raw rows + pages
     if (lds < pro) lds = pro;
-    static bool attr_done = false;
-    if (!attr_done)
+    static bool attr_done[EXL2_MAX_DEVICES] = {false};
+    if (exl2_first_on_device(attr_done))
     {
         (void)hipFuncSetAttribute((const void*)attn_q4_decode_kernel<HDIM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)attn_q4_decode_kernel<HDIM, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     switch (rb)
     {

@@ -18,3 +18,23 @@ void exl2_set_error(const char* fmt, ...);
 #define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
     exl2_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     return _e == hipErrorOutOfMemory ? EXL2_E_OOM : EXL2_E_HIP; } } while (0)
+
+// Host-side device scoping (the reference wraps every binding in an at::cuda::OptionalCUDAGuard, e.g. ext_qmatrix.cpp:41):
+// entry points that own a device index switch to it and put the caller's device back on the way out; one-time per-device
+// set-up (function attributes, CU count, scratch) is keyed on the device that is current at the call.
+struct DeviceGuard
+{
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (dev < 0 || hipGetDevice(&prev) != hipSuccess || prev == dev) return;
+        switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define EXL2_MAX_DEVICES 32
+static inline int exl2_current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= EXL2_MAX_DEVICES) d = 0; return d; }
+// true exactly once per device for the given flag array
+static inline bool exl2_first_on_device(bool* flags) { const int d = exl2_current_device(); if (flags[d]) return false; flags[d] = true; return true; }

@@ -40,7 +40,8 @@ static void fill_job(GemvJob& j, const QMatrix* qm, const f16* a, f16* c, int a_
 
 #define LAUNCH_JOBS(jobs, n, M, gptq, stream, what) do { \
     const int _rc = qgemv_launch(jobs, n, M, gptq, stream); \
-    if (_rc != 0) EXL2_FAIL(EXL2_E_INVALID, "%s: launch configuration rejected (%d)", what, _rc); \
+    if (_rc < 0) return _rc;            /* the launcher has left its own message (staging OOM, capture, ...) */ \
+    if (_rc > 0) EXL2_FAIL(EXL2_E_INVALID, "%s: launch configuration rejected (%d)", what, _rc); \
     HIP_TRY(hipGetLastError()); } while (0)
 
 // ---- QAttn ----------------------------------------------------------------------------------------------------------
@@ -335,6 +336,8 @@ int exl2_q_attn_forward_1(void* handle, const void* x, int batch_size, int q_len
     QAttn* a = (QAttn*)handle;
     const int rows = batch_size * q_len;
     if (rows <= 0) return EXL2_OK;
+    // temp_state (and the caller's temp_q/k/v) are sized for max_rows (attn.py:377-379 keeps chunks inside it)
+    EXL2_REQUIRE(rows <= a->max_rows, "q_attn_forward_1: %d rows exceed max_rows %d", rows, a->max_rows);
     const bool gptq = a->q_proj->is_gptq;
     EXL2_REQUIRE(a->k_proj->is_gptq == gptq && a->v_proj->is_gptq == gptq, "q_attn_forward_1: mixed EXL2/GPTQ projections");
     GemvJob jobs[3];
@@ -378,6 +381,7 @@ int exl2_q_attn_forward_2(void* handle, void* x, const void* attn_output, int ba
     QAttn* a = (QAttn*)handle;
     const int rows = batch_size * q_len;
     if (rows <= 0) return EXL2_OK;
+    EXL2_REQUIRE(rows <= a->max_rows, "q_attn_forward_2: %d rows exceed max_rows %d", rows, a->max_rows);
     GemvJob j;
     if (!a->post_layernorm)
     {
@@ -387,6 +391,7 @@ int exl2_q_attn_forward_2(void* handle, void* x, const void* attn_output, int ba
     }
     fill_job(j, a->o_proj, (const f16*)attn_output, a->temp_state, A_PLAIN, C_STORE);
     LAUNCH_JOBS(&j, 1, rows, a->o_proj->is_gptq, stream, "q_attn_forward_2");
+    // add_residual is unconditional in the post-norm branch, as in the reference (q_attn.cu:339, q_mlp.cu:230)
     return exl2_rms_norm(a->temp_state, a->post_layernorm, x, a->norm_epsilon, rows, a->hidden_size, 1, 0, 0, stream);
 }
 
@@ -435,6 +440,7 @@ int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream)
     EXL2_REQUIRE(handle && x, "q_mlp_forward_: null argument");
     QMLP* m = (QMLP*)handle;
     if (rows <= 0) return EXL2_OK;
+    EXL2_REQUIRE(rows <= m->max_rows, "q_mlp_forward_: %d rows exceed max_rows %d", rows, m->max_rows);
     const int hidden = m->up->height;
     const bool gptq = m->up->is_gptq;
     const bool skinny = rows <= MAX_GEMV_ROWS;

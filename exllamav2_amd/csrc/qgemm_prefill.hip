@@ -20,6 +20,8 @@
 #include "errors.h"
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
+#include <mutex>
 
 #ifndef PF_BN
 #define PF_BN 128
@@ -515,29 +517,44 @@ KERNEL void __launch_bounds__(256) stage_rows_multi_kernel(const RowStageMulti a
 
 // ---- host ---------------------------------------------------------------------------------------------------------------
 
-// per-device scratch for the packed-order activations (grow-only; never grown while a stream is capturing)
-static f16* g_stage_buf[16] = {nullptr};
-static size_t g_stage_bytes[16] = {0};
+// Scratch for the packed-order activations, one per (device, stream): launches on one stream are ordered, two streams
+// never share a buffer.  A buffer that has been handed out is NEVER freed -- a captured graph (GreedyGraphDecoder,
+// PipelineStage) may have its address baked into kernel arguments -- so a larger request allocates a new one (at least
+// twice the old size, which bounds the retired total by the live size) and the old one stays allocated.  Growing inside
+// a capture is refused.
+struct StageSlot { int dev; void* stream; f16* buf; size_t bytes; };
+static std::vector<StageSlot> g_stage_slots;
+static std::mutex g_stage_mutex;
 
 static int stage_scratch(size_t bytes, void* stream, f16** out)
 {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    EXL2_REQUIRE(dev >= 0 && dev < 16, "prefill: device index %d out of range", dev);
-    if (g_stage_bytes[dev] < bytes)
+    const int dev = exl2_current_device();
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
+    StageSlot* slot = nullptr;
+    for (StageSlot& s : g_stage_slots) if (s.dev == dev && s.stream == stream) { slot = &s; break; }
+    if (!slot) { g_stage_slots.push_back(StageSlot{dev, stream, nullptr, 0}); slot = &g_stage_slots.back(); }
+    if (slot->bytes < bytes)
     {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing((hipStream_t)stream, &cs);
         EXL2_REQUIRE(cs == hipStreamCaptureStatusNone, "prefill: staging scratch cannot grow inside a graph capture");
-        if (g_stage_buf[dev]) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(g_stage_buf[dev]); g_stage_buf[dev] = nullptr; g_stage_bytes[dev] = 0; }
-        if (hipMalloc((void**)&g_stage_buf[dev], bytes) != hipSuccess)
+        size_t want = bytes < (size_t)(1 << 20) ? (size_t)(1 << 20) : bytes;
+        if (want < slot->bytes * 2) want = slot->bytes * 2;
+        f16* fresh = nullptr;
+        if (hipMalloc((void**)&fresh, want) != hipSuccess)
         {
             (void)hipGetLastError();
-            EXL2_FAIL(EXL2_E_OOM, "HIP out of memory (prefill staging scratch: %zu bytes)", bytes);
+            want = bytes;
+            if (hipMalloc((void**)&fresh, want) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                EXL2_FAIL(EXL2_E_OOM, "HIP out of memory (prefill staging scratch: %zu bytes)", bytes);
+            }
         }
-        g_stage_bytes[dev] = bytes;
+        slot->buf = fresh;                    // the previous buffer stays allocated (see above)
+        slot->bytes = want;
     }
-    *out = g_stage_buf[dev];
+    *out = slot->buf;
     return EXL2_OK;
 }
 
@@ -545,11 +562,10 @@ static int stage_scratch(size_t bytes, void* stream, f16** out)
 // scratch; out[i] = where job i's [M, K_i] rows went.  A plain, unpermuted input is used in place (out[i] = a, ld = lda).
 int stage_rows_for_decode(const GemvJob* jobs, int n_jobs, int M, void* stream, const f16** out, int* out_ld)
 {
-    static bool attr = false;
-    if (!attr)
+    static bool attr[EXL2_MAX_DEVICES] = {false};
+    if (exl2_first_on_device(attr))
     {
         (void)hipFuncSetAttribute((const void*)stage_rows_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
     }
     size_t total = 0;
     int k_max = 0, n_staged = 0;
@@ -599,13 +615,12 @@ int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stre
         if (j.a_mode == A_RMSNORM && (!j.norm_w || (((size_t)j.norm_w) & 15))) return 1;
         if ((size_t)j.m.K * 2 + 64 > 150 * 1024) return 1;
     }
-    static bool attr = false;
-    if (!attr)
+    static bool attr[EXL2_MAX_DEVICES] = {false};
+    if (exl2_first_on_device(attr))
     {
         (void)hipFuncSetAttribute((const void*)qgemm_prefill_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qgemm_prefill_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)stage_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
     }
     int k_max = 0;
     for (int i = 0; i < n_jobs; i++) if (jobs[i].m.K > k_max) k_max = jobs[i].m.K;

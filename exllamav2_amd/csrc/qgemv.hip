@@ -18,6 +18,7 @@
 //   * optional prologue fusions while the activations are staged: RMSNorm (rms_norm.cu numerics) or SiLU(gate)*up;
 //     optional epilogue: bias, accumulate into the residual (c += a*W), MoE routing weight.
 #include "qgemv_common.h"
+#include "errors.h"
 #include <stdlib.h>
 
 // ---- a wave's work list: the super-chunks g = g0 + wv, g0 + wv + nw, ... of the descriptors [d, de) ------------------
@@ -294,19 +295,23 @@ KERNEL void __launch_bounds__(1024) qgemv_kernel(const GemvArgs args)
 
 // ---- host launcher ---------------------------------------------------------------------------------------------------
 
-static int g_num_cus = 0;
+static int device_cus()
+{
+    static int n[EXL2_MAX_DEVICES] = {0};
+    const int dev = exl2_current_device();
+    if (n[dev] <= 0)
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
+        if (n[dev] <= 0) n[dev] = 256;
+    }
+    return n[dev];
+}
 
 static int pick_waves(long long tiles, int max_super_per_tile)
 {
     // enough wavefronts in flight to cover HBM latency (~16+ waves/CU over 256 CUs) without starving each wave of work
-    if (g_num_cus <= 0)
-    {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            g_num_cus = prop.multiProcessorCount;
-        if (g_num_cus <= 0) g_num_cus = 256;
-    }
+    const int g_num_cus = device_cus();
     const char* force = getenv("EXL2_GEMV_WAVES");
     if (force && atoi(force) > 0) return atoi(force);
     // keep >= ~16 wavefronts per CU streaming; prefer several small workgroups per CU (their prologues overlap each
@@ -351,7 +356,7 @@ int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stre
 
 int qgemv_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream)
 {
-    if (n_jobs < 1 || n_jobs > MAX_FUSED_MATS || M < 1) return -1;
+    if (n_jobs < 1 || n_jobs > MAX_FUSED_MATS || M < 1) EXL2_FAIL(EXL2_E_INVALID, "q_gemm: %d fused matrices / %d rows not launchable", n_jobs, M);
     {
         // decode-shaped calls go to the streaming kernel (qgemv_stream.hip); this generic kernel handles the rest
         const int rc = qgemv_stream_launch(jobs, n_jobs, M, gptq, stream);
@@ -386,15 +391,14 @@ int qgemv_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream)
         const u32 l = plan_job_lds(args.job[i], Mb, gptq, nwaves);
         if (l > lds) lds = l;
     }
-    if (lds > 160 * 1024) return -2;
+    if (lds > 160 * 1024) EXL2_FAIL(EXL2_E_UNSUPPORTED, "q_gemm: %u bytes of LDS needed, 160 KB available", lds);
     dim3 grid((unsigned)tiles, (unsigned)((M + MAX_GEMV_ROWS - 1) / MAX_GEMV_ROWS), 1);
     dim3 block(nwaves * 64, 1, 1);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[gptq ? 1 : 0])
+    static bool attr_set[2][EXL2_MAX_DEVICES] = {{false}};
+    if (exl2_first_on_device(attr_set[gptq ? 1 : 0]))
     {
         if (gptq) hipFuncSetAttribute((const void*)qgemv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         else      hipFuncSetAttribute((const void*)qgemv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[gptq ? 1 : 0] = true;
     }
     if (gptq) LAUNCH(qgemv_kernel<true>, grid, block, lds, stream, args);
     else      LAUNCH(qgemv_kernel<false>, grid, block, lds, stream, args);

@@ -708,14 +708,15 @@ static inline bool ptr16(const void* p) { return (((size_t)p) & 15) == 0; }
 
 static int flat_num_cus()
 {
-    static int n = 0;
-    if (n <= 0)
+    static int n[EXL2_MAX_DEVICES] = {0};
+    const int dev = exl2_current_device();
+    if (n[dev] <= 0)
     {
-        hipDeviceProp_t prop; int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
+        if (n[dev] <= 0) n[dev] = 256;
     }
-    return n;
+    return n[dev];
 }
 
 // floor(x / S) == (x * m) >> sh for every x in [0, xmax]?
@@ -863,13 +864,12 @@ static bool flat_in_ok(const FlatIn& in)
 
 static void flat_attrs()
 {
-    static bool attr = false;
-    if (attr) return;
+    static bool attr[EXL2_MAX_DEVICES] = {false};
+    if (!exl2_first_on_device(attr)) return;
 #define FLAT_ATTR(...) (void)hipFuncSetAttribute((const void*)qgemv_flat_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
     FLAT_ATTR(false, FlatArgs, false); FLAT_ATTR(false, FlatArgs, true); FLAT_ATTR(true, FlatArgs, false);
     FLAT_ATTR(false, FlatGroupArgs, false); FLAT_ATTR(false, FlatGroupArgs, true); FLAT_ATTR(true, FlatGroupArgs, false);
 #undef FLAT_ATTR
-    attr = true;
 }
 
 static bool flat_any_big(const FpMatCold* cold, int n)

@@ -24,6 +24,7 @@
 //     v_mfma_f32_16x16x32_f16, group scale applied to the fp32 partial sums (qgemv_common.h); bias / residual / MoE
 //     routing weight in the epilogue.
 #include "qgemv_common.h"
+#include "errors.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -546,26 +547,25 @@ static inline u32 align16s(u32 x) { return (x + 15u) & ~15u; }
 
 static int num_cus()
 {
-    static int n = 0;
-    if (n <= 0)
+    static int n[EXL2_MAX_DEVICES] = {0};
+    const int dev = exl2_current_device();
+    if (n[dev] <= 0)
     {
         hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
+        if (n[dev] <= 0) n[dev] = 256;
     }
-    return n;
+    return n[dev];
 }
 
 template <bool GPTQ, int MB>
 static void launch_variant(const StreamArgs& args, dim3 grid, dim3 block, u32 lds, void* stream, bool mixed = false)
 {
-    static bool attr = false;
-    if (!attr)
+    static bool attr[EXL2_MAX_DEVICES] = {false};
+    if (exl2_first_on_device(attr))
     {
         (void)hipFuncSetAttribute((const void*)qgemv_stream_kernel<GPTQ, MB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qgemv_stream_kernel<GPTQ, MB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
     }
     if (mixed) LAUNCH((qgemv_stream_kernel<GPTQ, MB, true>), grid, block, lds, stream, args);
     else       LAUNCH((qgemv_stream_kernel<GPTQ, MB, false>), grid, block, lds, stream, args);
@@ -625,12 +625,11 @@ static int qgemv_phased_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, int 
         if (blks > blk_max) blk_max = blks;
     }
     args.n_jobs = n_jobs; args.M = M; args.S = S; args.TPW = TPW; args.items_max = items_max;
-    static bool attr = false;
-    if (!attr)
+    static bool attr[EXL2_MAX_DEVICES] = {false};
+    if (exl2_first_on_device(attr))
     {
         (void)hipFuncSetAttribute((const void*)qgemv_phased_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)qgemv_phased_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
     }
     dim3 grid((unsigned)blk_max, (unsigned)n_jobs, 1), block((unsigned)(TPW * S * 64), 1, 1);
     if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_gemm route: phased M=%d jobs=%d TPW=%d S=%d items=%d lds=%u\n", M, n_jobs, TPW, S, items_max, lds);
@@ -642,7 +641,7 @@ static int qgemv_phased_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, int 
 // returns 0 when launched, 1 when this kernel does not apply (caller falls back to the generic kernel), < 0 on error
 int qgemv_stream_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream)
 {
-    if (n_jobs < 1 || n_jobs > MAX_FUSED_MATS || M < 1) return -1;
+    if (n_jobs < 1 || n_jobs > MAX_FUSED_MATS || M < 1) EXL2_FAIL(EXL2_E_INVALID, "q_gemm: %d fused matrices / %d rows not launchable", n_jobs, M);
     if (M > MAX_GEMV_ROWS) return 1;
     const char* off = getenv("EXL2_GEMV_GENERIC");
     if (off && atoi(off)) return 1;

@@ -163,6 +163,8 @@ struct Section { int bits; int k0; int chunks; int qrow0; };
 
 static bool bits_ok(int b) { return b == 2 || b == 3 || b == 4 || b == 5 || b == 6 || b == 8; }
 
+void qmatrix_destroy(QMatrix* qm);
+
 int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
                    u32* q_weight, u16* q_perm, u16* q_invperm, u32* q_scale, f16* q_scale_max, u16* q_groups,
                    u32* gptq_qzeros, f16* gptq_scales, const u32* gptq_g_idx_host,
@@ -177,7 +179,7 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
     EXL2_REQUIRE(G > 0, "make_q_matrix: no groups");
     if (!is_gptq) EXL2_REQUIRE(q_scale && q_scale_max && q_groups, "make_q_matrix: EXL2 tensors missing");
     else          EXL2_REQUIRE(gptq_scales, "make_q_matrix: GPTQ scales missing");
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard on_device(device);
 
     const int n_chunks = K / 32;
     std::vector<u16> chunk_group(n_chunks);
@@ -298,14 +300,21 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
 
     { u32 pre = 0; for (QDesc& d : descs) { d.sc_prefix = pre; pre += d.n_super; } }
 
+    // everything allocated below is released on any early return (error paths included) unless `keep` is set at the end
+    struct Hold
+    {
+        QMatrix* qm = nullptr; u32* temp = nullptr; bool keep = false;
+        ~Hold() { if (temp) (void)hipFree(temp); if (qm && !keep) qmatrix_destroy(qm); }
+    } hold;
     QMatrix* qm = (QMatrix*)calloc(1, sizeof(QMatrix));
     if (!qm) EXL2_FAIL(EXL2_E_OOM, "make_q_matrix: host out of memory");
+    hold.qm = qm;
     qm->device = device; qm->height = K; qm->width = N; qm->groups = G; qm->is_gptq = is_gptq;
     qm->q_weight = q_weight; qm->q_perm = q_perm; qm->q_invperm = q_invperm;
     qm->temp_dq = temp_dq; qm->max_dq_rows = max_dq_rows; qm->max_bits = max_bits;
 
     const size_t weight_words = (size_t)total_qrows * N;
-    u32* temp = nullptr;
+    u32*& temp = hold.temp;
     hipError_t e = hipMalloc((void**)&temp, weight_words * sizeof(u32));
     if (e == hipSuccess && tail_words) e = hipMalloc((void**)&qm->tail_buf, tail_words * sizeof(u32));
     if (e == hipSuccess) e = hipMalloc((void**)&qm->desc_buf, descs.size() * sizeof(QDesc));
@@ -322,15 +331,6 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
     if (e != hipSuccess)
     {
         (void)hipGetLastError();
-        if (temp) (void)hipFree(temp);
-        if (qm->tail_buf) (void)hipFree(qm->tail_buf);
-        if (qm->desc_buf) (void)hipFree(qm->desc_buf);
-        if (qm->chunk_group_buf) (void)hipFree(qm->chunk_group_buf);
-        if (qm->scale_pad_buf) (void)hipFree(qm->scale_pad_buf);
-        if (qm->pack_buf) (void)hipFree(qm->pack_buf);
-        if (qm->sc_tab_buf) (void)hipFree(qm->sc_tab_buf);
-        if (qm->zp_tab_buf) (void)hipFree(qm->zp_tab_buf);
-        free(qm);
         EXL2_FAIL(EXL2_E_OOM, "HIP out of memory (make_q_matrix: %zu bytes of re-layout scratch)", weight_words * 4);
     }
     HIP_TRY(hipMemcpyAsync(temp, q_weight, weight_words * sizeof(u32), hipMemcpyDeviceToDevice, stream));
@@ -370,7 +370,7 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipFree(temp));
+    { u32* t = temp; temp = nullptr; HIP_TRY(hipFree(t)); }
 
     QMatDev& d = qm->dev;
     d.pack = qm->pack_buf; d.pack_units = (u32)((perm_bytes + cg_bytes) / 16); d.pack_cg_off = (u32)perm_bytes;
@@ -427,6 +427,7 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
     if (q_perm) b += (long long)K * 2;
     qm->weight_bytes = b;
 
+    hold.keep = true;
     *out = qm;
     return EXL2_OK;
 }
@@ -434,7 +435,7 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
 void qmatrix_destroy(QMatrix* qm)
 {
     if (!qm) return;
-    (void)hipSetDevice(qm->device);
+    DeviceGuard on_device(qm->device);
     if (qm->tail_buf) (void)hipFree(qm->tail_buf);
     if (qm->desc_buf) (void)hipFree(qm->desc_buf);
     if (qm->chunk_group_buf) (void)hipFree(qm->chunk_group_buf);

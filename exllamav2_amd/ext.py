@@ -9,6 +9,7 @@ in the hand-written gfx950 kernels.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 
 import torch
 
@@ -570,6 +571,30 @@ class ExtC:
                                       none_tensor, w["qzeros"], w["scales"], none_tensor,
                                       w.get("bias", none_tensor), temp_dq, max_dq_rows)
         raise RuntimeError("make_q_matrix: neither EXL2 nor GPTQ tensors in dict")
+
+
+def _device_scoped(fn):
+    """The reference opens `const at::cuda::OptionalCUDAGuard device_guard(device_of(x))` at the top of every binding
+    (e.g. ext_qmatrix.cpp:41, ext_qattn.cpp:131): the op runs on the device of its tensors, whatever the caller's current
+    device is, and the caller's device is put back afterwards.  Same here: the first HIP tensor among the arguments
+    names the device; the switch only happens when it differs from the current one (gpu_split / one process, many GPUs).
+    Handle-only calls (free_*, *_info) are scoped inside the library by the device stored in the handle."""
+    @functools.wraps(fn)
+    def scoped(self, *args, **kwargs):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.device.type == "cuda":
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(self, *args, **kwargs)
+                break
+        return fn(self, *args, **kwargs)
+    return scoped
+
+
+for _name, _fn in list(vars(ExtC).items()):
+    if not _name.startswith("_") and callable(_fn) and not isinstance(_fn, (property, staticmethod, classmethod)):
+        setattr(ExtC, _name, _device_scoped(_fn))
+del _name, _fn
 
 
 ext_c = ExtC()

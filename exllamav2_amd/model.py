@@ -93,11 +93,17 @@ class ExLlamaV2:
         self.layers, self.modules, self.loaded = [], [], False
 
     def weight_bytes(self) -> int:
-        """Algorithmic bytes one token streams through the linears."""
+        """Algorithmic bytes one token streams through the linears.  A sparse-MoE layer streams
+        its router plus `num_experts_per_token` of its experts per token (moe_mlp.py:238-253)."""
         n = self.lm_head.weight_bytes() if self.lm_head else 0
         for attn, mlp in self.layers:
-            for lin in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj):
+            for lin in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj):
                 n += lin.weight_bytes()
+            if hasattr(mlp, "gate_proj"):
+                n += sum(lin.weight_bytes() for lin in (mlp.gate_proj, mlp.up_proj, mlp.down_proj))
+            else:
+                per_expert = sum(l.weight_bytes() for l in mlp.w1 + mlp.w2 + mlp.w3) // mlp.num_experts
+                n += per_expert * mlp.num_experts_per_token + mlp.gate.numel() * 2
         return n
 
     # ---- forward ------------------------------------------------------------------------------------------------------
@@ -164,6 +170,8 @@ class GreedyGraphDecoder:
         # capture is not permitted on the legacy default stream: the decoder owns a stream (device.py:67-72 does too)
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.chain = None
+        self.pos = 0                  # host mirror of cache_seqlens (all rows advance together): bounds are checked here,
+        self.limit = min(cache.max_seq_len, cfg.max_seq_len)      # the kernels index pages / sin-cos rows unchecked
         if os.environ.get("EXL2_CHAIN", "1") != "0":
             self._setup_chain()
 
@@ -241,11 +249,13 @@ class GreedyGraphDecoder:
         saved and restored, so capturing never disturbs a cache that already holds a prompt."""
         ext = self.model.ext
         torch.cuda.synchronize()
-        scratch_pos = self.cache.max_seq_len - 1
+        scratch_pos = self.limit - 1
         with self._on_stream():
             saved_state = (self.cache_seqlens.clone(), self.ids.clone())
-            saved_kv = [(k[:, scratch_pos].clone(), v[:, scratch_pos].clone())
-                        for k, v in zip(self.cache.key_states, self.cache.value_states)]
+            slot_tensors = list(self.cache.key_states) + list(self.cache.value_states)
+            # quantized caches: the scales of the scratch slot too (they sit at the same [batch, position] index)
+            slot_tensors += list(getattr(self.cache, "key_scales", [])) + list(getattr(self.cache, "value_scales", []))
+            saved_kv = [t[:, scratch_pos].clone() for t in slot_tensors]
             self.cache_seqlens.fill_(scratch_pos)
             self.step_eager()                               # warm-up: lazy one-time setup must not happen under capture
             self.cache_seqlens.fill_(scratch_pos)
@@ -256,8 +266,8 @@ class GreedyGraphDecoder:
             finally:
                 self.graph = ext.graph_end_capture(self.stream.cuda_stream)
             self.cache_seqlens.copy_(saved_state[0]); self.ids.copy_(saved_state[1])
-            for (k, v), (sk, sv) in zip(zip(self.cache.key_states, self.cache.value_states), saved_kv):
-                k[:, scratch_pos].copy_(sk); v[:, scratch_pos].copy_(sv)
+            for t, s in zip(slot_tensors, saved_kv):
+                t[:, scratch_pos].copy_(s)
             self.stream.synchronize()
         return self
 
@@ -265,9 +275,13 @@ class GreedyGraphDecoder:
         with self._on_stream():
             self.ids.copy_(first_ids.to(torch.int32).view(-1))
             self.cache_seqlens.fill_(seq_len)
+        self.pos = int(seq_len)
 
     def run(self, n_tokens: int, use_graph: bool = True):
         ext = self.model.ext
+        if self.pos + n_tokens > self.limit:
+            raise RuntimeError(f"decode: {self.pos} cached + {n_tokens} new tokens exceed the cache / max_seq_len ({self.limit})")
+        self.pos += n_tokens
         with self._on_stream():
             sptr = self.stream.cuda_stream if self.stream is not None else None
             for _ in range(n_tokens):

@@ -58,6 +58,8 @@ class PipelineStage:
         self.use_graph = use_graph and self.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=dev) if self.device.type == "cuda" else None
         self.graphs = {}
+        self.pos = [0] * n_seqs                                   # host mirror of seqlens: the kernels do not bound-check
+        self.limit = min(max_seq_len, cfg.max_seq_len)
 
     # one stage step for sequence s: msg_in -> (layers) -> msg_out
     def _step_eager(self, s: int):
@@ -89,9 +91,9 @@ class PipelineStage:
         with torch.cuda.stream(self.stream):
             saved = self.seqlens.clone()
             for s in range(self.n_seqs):
-                self.seqlens.fill_(self.cache.max_seq_len - 1)          # throw-away steps land in the last cache slot
+                self.seqlens.fill_(self.limit - 1)          # throw-away steps land in the last cache slot
                 self._step_eager(s)
-                self.seqlens.fill_(self.cache.max_seq_len - 1)
+                self.seqlens.fill_(self.limit - 1)
                 self.stream.synchronize()
                 self.ext.graph_begin_capture(self.stream.cuda_stream)
                 try:
@@ -107,6 +109,9 @@ class PipelineStage:
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def step(self, s: int):
+        if self.pos[s] + 1 > self.limit:
+            raise RuntimeError(f"pipeline stage: sequence {s} is at the cache / max_seq_len limit ({self.limit})")
+        self.pos[s] += 1
         with self._on_stream():
             if self.use_graph:
                 self.ext.graph_launch(self.graphs[s], self.stream.cuda_stream)

@@ -287,10 +287,12 @@ class TPGreedyDecoder:
         self.history = torch.zeros((batch_size, cache.max_seq_len + 2), dtype=torch.int32, device=dev)
         self.x = torch.zeros((batch_size, 1, cfg.hidden_size), dtype=torch.float16, device=dev)
         self.xn = torch.zeros_like(self.x)
+        self.pos, self.limit = 0, min(cache.max_seq_len, cfg.max_seq_len)
 
     def reset(self, first_ids: torch.Tensor, seq_len: int = 0):
         self.ids.copy_(first_ids.to(torch.int32).view(-1))
         self.cache_seqlens.fill_(seq_len)
+        self.pos = int(seq_len)
 
     def step(self):
         m, ext, cfg = self.model, self.model.ext, self.model.full_config
@@ -304,6 +306,9 @@ class TPGreedyDecoder:
         ext.argmax_rows(logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens)
 
     def run(self, n_tokens: int):
+        if self.pos + n_tokens > self.limit:
+            raise RuntimeError(f"decode: {self.pos} cached + {n_tokens} new tokens exceed the cache / max_seq_len ({self.limit})")
+        self.pos += n_tokens
         for _ in range(n_tokens):
             self.step()
 

@@ -136,6 +136,11 @@ def test_device_side_greedy_decode_paged(be):
             assert got[i] == int(np.argmax(want)), (i, got, np.argmax(want))
         tok = int(got[i])                                 # follow the device's own choice: each step is checked alone
     assert be.n(dec.cache_seqlens)[0] == n
+    # the kernels index cache pages and sin/cos rows unchecked: running past the cache is refused on the host
+    dec.reset(torch.tensor([7]), cache.max_seq_len - 2)
+    dec.run(2, use_graph=False)
+    with pytest.raises(RuntimeError, match="exceed the cache"):
+        dec.run(1, use_graph=False)
     dec.free()
     model.unload()
 

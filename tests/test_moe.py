@@ -117,5 +117,9 @@ def test_moe_model_forward(be):
     y1 = x.clone(); moe.forward(y1)
     y2 = x.clone(); be.ext.q_moe_mlp_forward_(moe.q_handle, y2.view(2, -1))
     assert torch.equal(y1, y2)
+    # bytes one token streams: attention + head + router + num_experts_per_token of the experts
+    dense = model.lm_head.weight_bytes() + sum(l.weight_bytes() for l in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj))
+    experts = sum(l.weight_bytes() for l in moe.w1 + moe.w2 + moe.w3)
+    assert model.weight_bytes() == dense + experts // 4 * 2 + moe.gate.numel() * 2
     model.unload()
 

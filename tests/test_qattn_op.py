@@ -128,3 +128,16 @@ def test_forward_2_residual(be, attn, rows):
     be.ext.q_attn_forward_2(attn["h"], xt, be.t(a), 1, rows, [], none_tensor)
     want = OX.gemm_ref(a.reshape(rows, -1), attn["refs"]["o"], c_in=x.reshape(rows, -1), exact=True)
     assert np.all(np.abs(be.n(xt).reshape(rows, -1).astype(np.float64) - want) <= half_tol(want, NH * HD))
+
+
+def test_rows_beyond_max_rows_are_refused(be, attn):
+    """temp_state is sized for max_rows (64 here): a larger chunk must be an error, not a write past the scratch."""
+    rows = 65
+    x = torch.zeros((1, rows, HID), dtype=torch.float16, device=be.device)
+    q = torch.zeros((1, rows, NH, HD), dtype=torch.float16, device=be.device)
+    k = torch.zeros((1, rows, NKV, HD), dtype=torch.float16, device=be.device)
+    v = torch.zeros_like(k)
+    with pytest.raises(RuntimeError, match="exceed max_rows"):
+        be.ext.q_attn_forward_1(attn["h"], x, 1, rows, 0, none_tensor, q, k, v, be.t(attn["sin"]), be.t(attn["cos"]))
+    with pytest.raises(RuntimeError, match="exceed max_rows"):
+        be.ext.q_attn_forward_2(attn["h"], x, q.view(1, rows, NH * HD), 1, rows)
