@@ -86,6 +86,18 @@ def time_gemv_calls(model, dec, reps: int = 5):
         launches, nbytes, npart = 0, 0, 1
         plan = ch["plan"]
         x2 = x.view(b, cfg.hidden_size)
+        overlap = "flags" in ch                                  # EXL2_CHAIN_OVERLAP=1: the same two-stream hand-off as the step
+        if overlap:
+            ext.chain_overlap_begin(ch["flags"], dec.stream.cuda_stream, ch["stream_b"].cuda_stream)
+        try:
+            launches, nbytes = chain_launches(plan, x2, npart)
+        finally:
+            if overlap:
+                ext.chain_overlap_end()
+        return launches, nbytes
+
+    def chain_launches(plan, x2, npart):
+        launches, nbytes = 0, 0
         for i, (attn, mlp) in enumerate(model.layers):
             in_a, o_inv, in_m = plan[i]
             ext.q_attn_forward_1_chain(attn.q_handle, ch["xp_a"], ch["ss_a"], npart, b, q, k, v)
@@ -363,6 +375,10 @@ def main():
         kname = "qgemv_flat_kernel<false" if chained else "qgemv_stream_kernel<false, 4"
         traffic_gb, traffic_src = pmc_traffic_gb(launches, kname) if (args.model == "llama2-7b" and args.recipe == "4.0bpw") else (None, None)
         extra = {}
+        if dec.chain is not None and "flags" in dec.chain:
+            # overlapped chain (EXL2_CHAIN_OVERLAP=1): waits that gave up would make the timing meaningless -- must be 0
+            extra["chain_overlap"] = {"launches": int((dec.chain["flags"][:-1, 0] > 0).sum()),
+                                      "wait_timeouts": int(dec.chain["flags"][:, 1].sum())}
         if args.model == "llama2-7b" and args.ctx == 0 and not args.no_ctx_window:
             # SURVEY.md 8d's second window: the same decode with 1920 tokens already in the cache (steps 1921..1984)
             dec.reset(torch.tensor([1] * args.batch), 1920)

@@ -3,16 +3,43 @@ it up instead of JIT-building its CUDA sources (`import exllamav2_ext` succeeds 
 
 Every name of the reference's pybind module (ext_bindings.cpp:27-138) that lies on the quantized forward path is
 forwarded, with the reference's argument order, to the MI355X library through `exllamav2_amd.ext_c` (ctypes over the
-C ABI of include/exl2_hip.h).  Names outside the hot path (sampler, safetensors loader, quantizer, LoRA, vision, TP
-host-staging) raise NotImplementedError with the SURVEY.md section that scopes them out -- loudly, never silently.
+C ABI of include/exl2_hip.h).  Names outside the hot path (sampler chain, quantizer, LoRA, vision) raise
+NotImplementedError with the SURVEY.md section that scopes them out -- loudly, never silently.
 """
+import os as _os
+
 import numpy as _np
 import torch as _torch
 
 from exllamav2_amd.ext import ext_c as _e
+from exllamav2_amd import ext_tp as _tp
 
-make_q_matrix = _e.make_q_matrix
-free_q_matrix = _e.free_q_matrix
+# make_q_matrix (ext_qmatrix.cpp:21-111) may re-lay q_weight out in place -- the reference shuffles it in place too
+# (q_matrix.cu:123-196).  But the reference's tensor-parallel loader later slices that tensor by output columns
+# (linear.py:572-576) and hands the slices to make_q_matrix_split: its own shuffle is column-local, so the slices stay valid;
+# the tile-major layout of libexl2_hip.so is not.  The drop-in therefore re-lays out a PRIVATE copy and leaves the caller's
+# tensor as loaded (one extra copy of the packed weights while the handle lives; EXL2_DROPIN_INPLACE=1 restores the in-place
+# behaviour and gives up `model.load_tp`).
+_private_weights = {}
+
+
+def make_q_matrix(q_weight, q_perm, q_invperm, q_scale, q_scale_max, q_groups, q_group_map, gptq_qzeros, gptq_scales,
+                  gptq_g_idx, bias, temp_dq, max_dq_rows):
+    if _os.environ.get("EXL2_DROPIN_INPLACE", "0") != "0":
+        return _e.make_q_matrix(q_weight, q_perm, q_invperm, q_scale, q_scale_max, q_groups, q_group_map, gptq_qzeros,
+                                gptq_scales, gptq_g_idx, bias, temp_dq, max_dq_rows)
+    own = q_weight.clone()
+    h = _e.make_q_matrix(own, q_perm, q_invperm, q_scale, q_scale_max, q_groups, q_group_map, gptq_qzeros, gptq_scales,
+                         gptq_g_idx, bias, temp_dq, max_dq_rows)
+    _private_weights[h] = own
+    return h
+
+
+def free_q_matrix(handle):
+    _e.free_q_matrix(handle)
+    _private_weights.pop(handle, None)
+
+
 reconstruct = _e.reconstruct
 gemm_half_q_half = _e.gemm_half_q_half
 make_group_map = _e.make_group_map
@@ -49,11 +76,20 @@ def _out_of_scope(name, why):
     return f
 
 
-make_q_matrix_split = _e.make_q_matrix_split
-for _n in ("gemm_half_q_half_tp", "make_tp_context", "free_tp_context", "tp_broadcast", "tp_gather",
-           "tp_cross_device_barrier", "tp_all_reduce", "tp_attn_forward_", "tp_attn_forward_paged_", "tp_mlp_forward_",
-           "rms_norm_tp"):
-    globals()[_n] = _out_of_scope(_n, "the reference's single-process, host-staged tensor-parallel bindings are not mirrored; tensor parallel here is one process per GPU over RCCL: exllamav2_amd/tensor_p.py (SURVEY.md 8e)")
+make_q_matrix_split = _e.make_q_matrix_split          # (its inputs are fresh contiguous slices: re-laid out in place)
+# the reference's single-process tensor parallel (ext_tp.cpp, tp_* of ext_qattn.cpp / ext_qmlp.cpp): host staging through
+# pinned buffers + per-device kernels, mirrored in exllamav2_amd/ext_tp.py
+make_tp_context = _tp.make_tp_context
+free_tp_context = _tp.free_tp_context
+tp_broadcast = _tp.tp_broadcast
+tp_gather = _tp.tp_gather
+tp_cross_device_barrier = _tp.tp_cross_device_barrier
+tp_all_reduce = _tp.tp_all_reduce
+gemm_half_q_half_tp = _tp.gemm_half_q_half_tp
+rms_norm_tp = _tp.rms_norm_tp
+tp_mlp_forward_ = _tp.tp_mlp_forward_
+tp_attn_forward_ = _tp.tp_attn_forward_
+tp_attn_forward_paged_ = _tp.tp_attn_forward_paged_
 make_q_moe_mlp = _e.make_q_moe_mlp
 free_q_moe_mlp = _e.free_q_moe_mlp
 q_moe_mlp_forward_ = _e.q_moe_mlp_forward_

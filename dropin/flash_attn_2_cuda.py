@@ -1,8 +1,20 @@
 """`flash_attn_2_cuda` stand-in: the reference imports it next to `flash_attn` when it detects paged-attention support
-(attn.py:56) and only calls into it from its single-process tensor-parallel bindings (ext_qattn.cpp:291, 416-438), which
-this drop-in serves through dropin/exllamav2_ext.py's own TP entry points -- so nothing here is ever called."""
+(attn.py:56) and calls `fwd_kvcache` from its single-process tensor-parallel bindings (ext_qattn.cpp:291, 416-438, 653-675).
+The drop-in's own TP entry points (exllamav2_amd/ext_tp.py) go straight to libexl2_hip.so; this function serves the same
+positional call for anybody else."""
+from flash_attn import flash_attn_with_kvcache as _fa
 
 
-def fwd_kvcache(*a, **k):
-    raise NotImplementedError("flash_attn_2_cuda.fwd_kvcache: not used by the drop-in (paged attention goes through "
-                              "flash_attn.flash_attn_with_kvcache -> libexl2_hip.so)")
+def fwd_kvcache(q, k_cache, v_cache, k, v, cache_seqlens, rotary_cos, rotary_sin, cache_batch_idx, cache_leftpad,
+                block_table, alibi_slopes, out, softmax_scale, causal, window_left, window_right, softcap,
+                rotary_interleaved, num_splits):
+    """Argument order of flash-attn 2.5.7+'s C++ entry as the reference calls it.  Returns [out, softmax_lse(None)]."""
+    if window_right not in (-1, 0) or softcap:
+        raise NotImplementedError("flash_attn_2_cuda.fwd_kvcache shim: sliding window / softcap are not built")
+    o = _fa(q, k_cache, v_cache, k=k, v=v, rotary_cos=rotary_cos, rotary_sin=rotary_sin, cache_seqlens=cache_seqlens,
+            cache_batch_idx=cache_batch_idx, cache_leftpad=cache_leftpad, block_table=block_table,
+            softmax_scale=softmax_scale, causal=causal, alibi_slopes=alibi_slopes)
+    if out is not None:
+        out.copy_(o)
+        o = out
+    return [o, None]

@@ -77,6 +77,8 @@ PROTOTYPES = {
     "exl2_gemm_half_q_half_chain": (ci, [vp, vp, ci, vp, cf, vp, vp, ci, vp]),
     "exl2_embed_rows_chain": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp]),
     "exl2_gather_f16": (ci, [vp, vp, vp, ci, vp]),
+    "exl2_chain_overlap_begin": (ci, [vp, ci, vp, vp]),
+    "exl2_chain_overlap_end": (ci, [C.POINTER(ci)]),
     # graphs
     "exl2_graph_begin_capture": (ci, [vp]),
     "exl2_graph_end_capture": (ci, [vp, C.POINTER(vp)]),

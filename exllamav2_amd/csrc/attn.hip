@@ -12,6 +12,7 @@
 // algorithmic bytes = 2 * ctx * kv_heads * head_dim * 2 per layer per token.
 #include "hw.h"
 #include "errors.h"
+#include "chain_sync.h"
 #include <string.h>
 
 #define ATT_WAVES 4
@@ -219,6 +220,9 @@ struct FusedArgs
     int page_size, page_shift, pages_per_seq;
     int past_const, nsplit, rope, keys_per_split_min;
     float scale;
+    // overlapped chain (chain_sync.h): q / k_new / v_new are read behind the wait; the workgroup that writes a group's final
+    // output signals once (batch * kv_heads * row_blocks signals per launch)
+    const u32* sync_wait; u32* sync_signal; u32 sync_target;
 };
 
 // where feature d of query row qrow = (token row) * H + head goes
@@ -281,6 +285,8 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     kps = (kps + 15) & ~15;
     const int k_start = split * kps;
     const int k_end = min(total, k_start + kps);
+
+    if (a.sync_wait) flag_wait_agent(a.sync_wait, a.sync_target);
 
     f16x8 qf[RB];
     int limit[RB];
@@ -413,7 +419,9 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
         const size_t qrow = ((size_t)b * a.s + j) * a.H + kh * G + g;
         if (eff == 1)
         {
-            a.out[fused_out_index<HDIM>(a, qrow, d)] = (f16)(L > 0.0f ? O / L : 0.0f);
+            const f16 y = (f16)(L > 0.0f ? O / L : 0.0f);
+            if (a.sync_signal) store_agent_f16(a.out + fused_out_index<HDIM>(a, qrow, d), y);
+            else a.out[fused_out_index<HDIM>(a, qrow, d)] = y;
         }
         else
         {
@@ -427,7 +435,14 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
             }
         }
     }
-    if (eff == 1) return;
+    // (overlapped chain: the outputs above / below are agent-scope stores; one signal once the workgroup's have completed)
+    auto signal_done = [&]() {
+        if (!a.sync_signal) return;
+        release_agent();
+        block_sync();
+        if (tid() == 0) (void)ticket_add_agent(a.sync_signal, 1u);
+    };
+    if (eff == 1) { signal_done(); return; }
 
     // hand-off: the last split to arrive merges
     wait_vmcnt0();
@@ -451,9 +466,12 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
             L += load_agent_f32(a.part_ml + (qrow * a.nsplit + s2) * 2 + 1) * w;
             O += load_agent_f32(a.part_o + (qrow * a.nsplit + s2) * HDIM + d) * w;
         }
-        a.out[fused_out_index<HDIM>(a, qrow, d)] = (f16)(L > 0.0f ? O / L : 0.0f);
+        const f16 y = (f16)(L > 0.0f ? O / L : 0.0f);
+        if (a.sync_signal) store_agent_f16(a.out + fused_out_index<HDIM>(a, qrow, d), y);
+        else a.out[fused_out_index<HDIM>(a, qrow, d)] = y;
     }
     if (tid() == 0) store_relaxed_agent(counter, 0u);
+    signal_done();
 }
 
 // ---- RoPE on q / new k + append of new k, v into the (paged) cache at device-side positions ---------------------------
@@ -692,6 +710,15 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
     dim3 grid((unsigned)num_kv_heads, (unsigned)nsplit, (unsigned)(batch * rblocks));
     const int lpk = head_dim / 8, kpw = 64 / lpk;
     const size_t lds = (size_t)ATT_WAVES * kpw * rb * (head_dim + 2) * 4 + 16;
+    const bool overlapped = chain_sync_active();
+    if (overlapped)
+    {
+        ChainLaunch cl;
+        const int e = chain_sync_next(&cl);
+        if (e) return e;
+        a.sync_wait = cl.wait; a.sync_target = cl.target; a.sync_signal = cl.signal;
+        stream = cl.stream;
+    }
 #define FUSED_CASE(HDIM_, RB_) LAUNCH((attn_fused_kernel<HDIM_, RB_>), grid, dim3(ATT_WAVES * 64), lds, stream, a)
 #define FUSED_HD(HDIM_) \
     do { static bool attr_done[EXL2_MAX_DEVICES] = {false}; \
@@ -705,6 +732,7 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
 #undef FUSED_HD
 #undef FUSED_CASE
     HIP_TRY(hipGetLastError());
+    if (overlapped) { const int e = chain_sync_done((u32)(batch * num_kv_heads * rblocks), 0u); if (e) return e; }
     return EXL2_OK;
 }
 

@@ -193,6 +193,28 @@ DEV float load_agent_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_
 // write-through store at agent scope (sc1): visible to the other XCDs without flushing the whole L2 (buffer_wbl2)
 DEV void store_agent_f32(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void store_relaxed_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void store_agent_f16(f16* p, f16 v) { __hip_atomic_store((u16*)p, as_u16(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV u32 load_agent_u32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---- hand-off BETWEEN launches that overlap (two streams, the dependency carried by a counter in memory instead of the
+// kernel boundary): the consumer has issued everything that does not depend on the producer (weights, tables) and waits
+// here for the producer's `target` signals; then an agent-scope acquire (buffer_inv sc1) before it reads the activations.
+// The spin is bounded: a missing producer must show up as wrong numbers in a test, never as a hung GPU.
+#define FLAG_SPIN_LIMIT (1 << 15)              // ~ 10 ms: a legitimate wait is a few microseconds
+DEV void flag_wait_agent(const u32* flag, u32 target)
+{
+    int spins = 0;
+    while (uniform((int)load_agent_u32(flag)) < (int)target && ++spins < FLAG_SPIN_LIMIT) __builtin_amdgcn_s_sleep(2);
+    // a wait that gave up is counted in the word behind the counter (tests assert it stays zero)
+    if (spins >= FLAG_SPIN_LIMIT && lane_id() == 0) (void)__hip_atomic_fetch_add((u32*)flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // agent-scope acquire spelled as the instruction (what __builtin_amdgcn_fence(acquire, "agent") emits on gfx950): the
+    // builtin fence makes the compiler keep a stack copy of by-value kernel arguments that are indexed at run time
+    asm volatile("buffer_inv sc1" ::: "memory");
+}
+// producer side: agent-scope release spelled as instructions (write back what the L2 still holds dirty, wait for every
+// store of this wave), then one signal.  The outputs themselves are agent-scope (write-through) stores.
+DEV void release_agent() { asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); }
+DEV void flag_signal_agent(u32* flag) { release_agent(); if (lane_id() == 0) (void)ticket_add_agent(flag, 1u); }
 
 // dynamic LDS (16-byte aligned base, guide G17)
 #define DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]

@@ -10,6 +10,7 @@
 // device), instead of the reference's per-module graphs with patched kernel arguments (graph.cu:141-164).
 #include "qmatrix.h"
 #include "qgemv_flat.h"
+#include "chain_sync.h"
 #include "errors.h"
 #include <string.h>
 #include <stdlib.h>
@@ -149,6 +150,64 @@ KERNEL void __launch_bounds__(256) moe_combine_kernel(f16* x, const f16* part, c
 }
 
 static bool hidden_ok(const QMoEMLP* m) { return (m->hidden & 7) == 0; }
+
+// ---- overlapped chain (chain_sync.h) ---------------------------------------------------------------------------------------------
+struct ChainSyncState { u32* flags; int n_flags; void* stream[2]; int next; u32 prev_signals; bool open; };
+static thread_local ChainSyncState g_chain = {nullptr, 0, {nullptr, nullptr}, 0, 0, false};
+static hipEvent_t g_chain_event[2] = {nullptr, nullptr};
+
+bool chain_sync_active() { return g_chain.open; }
+
+int chain_sync_next(ChainLaunch* out)
+{
+    EXL2_REQUIRE(g_chain.open, "chain: no overlapped chain is open");
+    EXL2_REQUIRE(g_chain.next < g_chain.n_flags - 1, "chain: more than %d launches in one overlapped chain", g_chain.n_flags - 1);
+    const int k = g_chain.next;
+    out->wait = k > 0 ? g_chain.flags + (size_t)(k - 1) * CHAIN_FLAG_STRIDE : nullptr;
+    out->target = g_chain.prev_signals;
+    out->signal = g_chain.flags + (size_t)k * CHAIN_FLAG_STRIDE;
+    out->arrive = k == 0 ? g_chain.flags + (size_t)(g_chain.n_flags - 1) * CHAIN_FLAG_STRIDE : nullptr;     // last counter: the gate's
+    out->stream = g_chain.stream[k & 1];
+    return EXL2_OK;
+}
+
+// one wave: holds launch 1 back until every workgroup of launch 0 sits on its CU (chain_sync.h)
+KERNEL void __launch_bounds__(64) chain_gate_kernel(const u32* arrived, u32 target) { flag_wait_agent(arrived, target); }
+
+int chain_sync_done(u32 signals, u32 arrivals)
+{
+    if (g_chain.next == 0)
+    {
+        EXL2_REQUIRE(arrivals > 0, "chain: the first launch of an overlapped chain must be a chained q_gemm");
+        LAUNCH(chain_gate_kernel, dim3(1, 1, 1), dim3(64, 1, 1), 0, g_chain.stream[1],
+               (const u32*)(g_chain.flags + (size_t)(g_chain.n_flags - 1) * CHAIN_FLAG_STRIDE), arrivals);
+        HIP_TRY(hipGetLastError());
+    }
+    g_chain.next++; g_chain.prev_signals = signals;
+    return EXL2_OK;
+}
+
+// One chained launch.  While an overlapped chain is open (chain_sync.h) the launch takes its stream and its counters from it.
+static int flat_try(FlatIn& in, void* stream, int* wgs, const char* what)
+{
+    ChainLaunch cl = {nullptr, 0, nullptr, nullptr, stream};
+    const bool overlapped = chain_sync_active();
+    if (overlapped)
+    {
+        const int e = chain_sync_next(&cl);
+        if (e) return e;
+        in.sync_wait = cl.wait; in.sync_target = cl.target; in.sync_signal = cl.signal; in.sync_arrive = cl.arrive;
+    }
+    int n_wgs = 0;
+    const int rc = qgemv_flat_launch(in, cl.stream, &n_wgs);
+    if (rc > 0) EXL2_FAIL(EXL2_E_INVALID, "%s: shape not covered by the chained decode kernel", what);
+    if (rc < 0) EXL2_FAIL(EXL2_E_INVALID, "%s: launch configuration rejected (%d)", what, rc);
+    HIP_TRY(hipGetLastError());
+    if (overlapped) { const int e = chain_sync_done((u32)n_wgs * (u32)in.M, (u32)n_wgs); if (e) return e; }    // M combining waves per workgroup signal
+    if (wgs) *wgs = n_wgs;
+    return EXL2_OK;
+}
+#define FLAT_TRY(in, stream, wgs, what) do { const int _rc = flat_try(in, stream, wgs, what); if (_rc) return _rc; } while (0)
 
 extern "C" {
 
@@ -501,11 +560,32 @@ int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream)
 
 // ---- chained decode (qgemv_flat.hip) -----------------------------------------------------------------------------------------
 
-#define FLAT_TRY(in, stream, wgs, what) do { \
-    const int _rc = qgemv_flat_launch(in, stream, wgs); \
-    if (_rc > 0) EXL2_FAIL(EXL2_E_INVALID, "%s: shape not covered by the chained decode kernel", what); \
-    if (_rc < 0) EXL2_FAIL(EXL2_E_INVALID, "%s: launch configuration rejected (%d)", what, _rc); \
-    HIP_TRY(hipGetLastError()); } while (0)
+int exl2_chain_overlap_begin(void* flags, int n_flags, void* stream_a, void* stream_b)
+{
+    EXL2_REQUIRE(flags && n_flags > 0, "chain_overlap_begin: no counters");
+    EXL2_REQUIRE(!g_chain.open, "chain_overlap_begin: a chain is already open on this thread");
+    // counters back to zero, then stream B joins behind everything A has been given so far (fork; under capture this pulls
+    // B into the capture)
+    HIP_TRY(hipMemsetAsync(flags, 0, (size_t)n_flags * CHAIN_FLAG_STRIDE * sizeof(u32), (hipStream_t)stream_a));
+    for (int i = 0; i < 2; i++)
+        if (!g_chain_event[i]) HIP_TRY(hipEventCreateWithFlags(&g_chain_event[i], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(g_chain_event[0], (hipStream_t)stream_a));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_b, g_chain_event[0], 0));
+    g_chain.flags = (u32*)flags; g_chain.n_flags = n_flags; g_chain.stream[0] = stream_a; g_chain.stream[1] = stream_b;
+    g_chain.next = 0; g_chain.prev_signals = 0; g_chain.open = true;
+    return EXL2_OK;
+}
+
+// Closes the chain: stream A continues behind everything both streams were given (join).  Returns the number of launches.
+int exl2_chain_overlap_end(int* n_launches)
+{
+    EXL2_REQUIRE(g_chain.open, "chain_overlap_end: no chain is open");
+    g_chain.open = false;
+    if (n_launches) *n_launches = g_chain.next;
+    HIP_TRY(hipEventRecord(g_chain_event[1], (hipStream_t)g_chain.stream[1]));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)g_chain.stream[0], g_chain_event[1], 0));
+    return EXL2_OK;
+}
 
 int exl2_q_attn_chain_info(void* handle, int* capable, const void** in_invperm, const void** o_invperm)
 {

@@ -17,6 +17,10 @@ struct FlatIn
     int pair;                     // 2 matrices (gate, up): output = act(gate) * up, written through mat 0's c / c_invperm
     int act_gelu, c_mode;         // C_STORE / C_ACCUM (residual)
     f16* xp_out; const u16* xp_invperm; float* ss_out; int ldxp;     // chain-out (nullable)
+    // overlapped chain (chain_sync.h): wait for *sync_wait >= sync_target before the activations are read; outputs are
+    // agent-scope stores and every workgroup adds M to *sync_signal when they have completed.  Both nullable.
+    const u32* sync_wait; u32 sync_target; u32* sync_signal;
+    u32* sync_arrive;             // first launch of a chain: every workgroup adds 1 on entry (chain_sync.h: the gate)
 };
 
 // 0: launched; 1: shape not covered; < 0: error.  *wgs_out = grid size = partial sums a chain-out launch writes per row

@@ -87,6 +87,7 @@ struct FlatHdr
     u32 lds_sc_off, sc_piece, lds_zp_off, lds_cg_off, cg_stride, lds_red_off;
     int r_stride, mul_r;          // grouped launches: row stride of r_weights; multiply the result by the weight (down projection)
     long long a_gstride;          // grouped launches: elements between the inputs of consecutive groups
+    const u32* sync_wait; u32* sync_signal; u32* sync_arrive; u32 sync_target;     // overlapped chain (DEP instantiation; chain_sync.h)
 };
 
 // one launch = one set of <= 4 fused matrices ...
@@ -236,7 +237,9 @@ DEV void flat_stream_any(const Seg& s, const PhaseCtx& ph, int lane, f32x4& acc)
 // BIG: some matrix of the launch has a second run of >= 2 items per wave (e.g. 4 / 3-bit halves): those runs stream through
 // the register ring after the main slice.  A separate instantiation: the extra streaming code costs the common case
 // (one dominant width + a few percent of others) ~10 % through its sheer size (measured).
-template <bool GPTQ, typename ARGS, bool BIG>
+// DEP: the launch overlaps its predecessor (chain_sync.h): nothing that depends on the predecessor is touched before the
+// wait, which sits between the ring fill and the activation loads; outputs are agent-scope stores followed by a signal.
+template <bool GPTQ, typename ARGS, bool BIG, bool DEP = false>
 KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
 {
     DYN_SMEM(smem);
@@ -323,21 +326,32 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
     const bool one_pass = args.a_mode == A_NORM_PRE && M * oct <= nw * 64 && (oct & 63) == 0 && args.npart <= 256;
     const int row1 = one_pass ? t / oct : 0, oc1 = one_pass ? t - row1 * oct : 0;
     float ssp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (args.a_mode == A_DIRECT)
-    {
-        const f16* a = a_in; const int lda = args.lda;
-        for (int rr = 0; rr < M; rr++)
-            dma_units16([&](int u) { return (const void*)(a + (size_t)rr * lda + (size_t)u * 8); }, a_lds + (size_t)rr * args.a_stride, oct, wv, nw, lane, rr % nw);
-    }
-    else if (one_pass && t < M * oct)
-    {
-        xr = *(const f16x8*)(args.a + (size_t)row1 * args.lda + (size_t)oc1 * 8);
-        wr = *(const f16x8*)(args.norm_w + (size_t)oc1 * 8);
-        // partial sums of squares: every wave reduces its row's partials itself (fixed order), no LDS round trip
-        const float* sp = args.ss + (size_t)row1 * args.npart;
-        #pragma unroll
-        for (int i = 0; i < 4; i++) if (lane + 64 * i < args.npart) ssp[i] = sp[lane + 64 * i];
-    }
+    // (a macro, not a lambda: in the DEP instantiation it is expanded inside every copy of `head`, where a nested closure
+    // would send xr / wr / ssp through memory)
+    // (the fields it needs are read from the argument block once, here: every further mention of `args` inside the six copies
+    // of `head` counts against the compiler's use limit for keeping a by-value kernel argument out of the stack)
+    const int act_mode = args.a_mode, act_lda = args.lda, act_stride = args.a_stride, act_npart = args.npart;
+    const f16* const act_a = args.a; const f16* const act_nw = args.norm_w; const float* const act_ss = args.ss;
+    const u32* const dep_wait = DEP ? args.sync_wait : nullptr; const u32 dep_target = DEP ? args.sync_target : 0u;
+    if constexpr (DEP) if (args.sync_arrive && t == 0) (void)ticket_add_agent(args.sync_arrive, 1u);      // "this workgroup holds its CU"
+#define FLAT_ISSUE_ACTS() do { \
+        if (act_mode == A_DIRECT) \
+        { \
+            for (int rr = 0; rr < M; rr++) \
+                dma_units16([&](int u) { return (const void*)(a_in + (size_t)rr * act_lda + (size_t)u * 8); }, a_lds + (size_t)rr * act_stride, oct, wv, nw, lane, rr % nw); \
+        } \
+        else if (one_pass && t < M * oct) \
+        { \
+            xr = *(const f16x8*)(act_a + (size_t)row1 * act_lda + (size_t)oc1 * 8); \
+            wr = *(const f16x8*)(act_nw + (size_t)oc1 * 8); \
+            /* partial sums of squares: every wave reduces its row's partials itself (fixed order), no LDS round trip */ \
+            const float* sp_ = act_ss + (size_t)row1 * act_npart; \
+            _Pragma("unroll") \
+            for (int i = 0; i < 4; i++) if (lane + 64 * i < act_npart) ssp[i] = sp_[lane + 64 * i]; \
+        } } while (0)
+    // DEP: the predecessor's outputs are read only behind the wait (head, below); everything issued here is static data
+#define FLAT_AWAIT_INPUTS() do { if (dep_wait) flag_wait_agent(dep_wait, dep_target); FLAT_ISSUE_ACTS(); } while (0)
+    if constexpr (!DEP) FLAT_ISSUE_ACTS();
     // tables: matrix j = wave & 3 is served by the four waves with that residue; a matrix' scale tables of this
     // workgroup's tiles are one contiguous piece of its [tile][G][16] table, the chunk -> group map sits behind the table
     {
@@ -519,10 +533,12 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
         ring_fill<BITS, DD, 0, DD>(b, first.ptr, first.n, lane);
         FTRACE(9);
         const int mdma = issue_minors();
+        if constexpr (DEP) FLAT_AWAIT_INPUTS();
         prologue();
         FTRACE(3);
         // the LDS-DMA copies (rows in A_DIRECT mode, tables) were issued before the ring loads: wait for them only
-        wait_vmcnt_dyn(DD * LPI + mdma);
+        // (DEP: the rows were issued last, everything has to have landed)
+        if constexpr (DEP) wait_vmcnt_le<0>(); else wait_vmcnt_dyn(DD * LPI + mdma);
         block_sync_lds();
         FTRACE(4);
         set_tables();
@@ -531,6 +547,7 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
     if (!early)
     {
         (void)issue_minors();
+        if constexpr (DEP) FLAT_AWAIT_INPUTS();
         prologue();
         FTRACE(3);
         wait_vmcnt_le<0>();
@@ -678,10 +695,11 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
                 if (args.c_mode == C_ACCUM) v += (float)*cp;
                 y = (f16)v;
             }
-            *cp = y;
+            if constexpr (DEP) store_agent_f16(cp, y); else *cp = y;
             if (args.xp_out)
             {
-                args.xp_out[(size_t)row * args.ldxp + (args.xp_invperm ? (int)args.xp_invperm[n] : n)] = y;
+                f16* xo = args.xp_out + (size_t)row * args.ldxp + (args.xp_invperm ? (int)args.xp_invperm[n] : n);
+                if constexpr (DEP) store_agent_f16(xo, y); else *xo = y;
                 const float f = fmaxf(-65504.0f, fminf((float)y, 65504.0f));
                 sq = fmaf(f, f, sq);
             }
@@ -690,8 +708,9 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
     if (args.ss_out)
     {
         sq = wave_allreduce_add(sq);
-        if (lane == 0) args.ss_out[(size_t)row * args.wgs + b] = sq;
+        if (lane == 0) { if constexpr (DEP) store_agent_f32(args.ss_out + (size_t)row * args.wgs + b, sq); else args.ss_out[(size_t)row * args.wgs + b] = sq; }
     }
+    if constexpr (DEP) if (args.sync_signal) flag_signal_agent(args.sync_signal);       // one signal per combining wave: wgs * M
     FTRACE(8);
 }
 
@@ -869,6 +888,7 @@ static void flat_attrs()
 #define FLAT_ATTR(...) (void)hipFuncSetAttribute((const void*)qgemv_flat_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
     FLAT_ATTR(false, FlatArgs, false); FLAT_ATTR(false, FlatArgs, true); FLAT_ATTR(true, FlatArgs, false);
     FLAT_ATTR(false, FlatGroupArgs, false); FLAT_ATTR(false, FlatGroupArgs, true); FLAT_ATTR(true, FlatGroupArgs, false);
+    FLAT_ATTR(false, FlatArgs, false, true); FLAT_ATTR(false, FlatArgs, true, true); FLAT_ATTR(true, FlatArgs, false, true);
 #undef FLAT_ATTR
 }
 
@@ -894,8 +914,17 @@ int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out)
     if (!lds) return 1;
     flat_attrs();
     dim3 grid((unsigned)wgs, 1, 1), block(FLAT_WAVES * 64, 1, 1);
-    if (in.qm[0]->is_gptq) LAUNCH((qgemv_flat_kernel<true, FlatArgs, false>), grid, block, lds, stream, args);      // (GPTQ: one run)
-    else if (flat_any_big(args.cold_, in.n_mats)) LAUNCH((qgemv_flat_kernel<false, FlatArgs, true>), grid, block, lds, stream, args);
+    const bool big = flat_any_big(args.cold_, in.n_mats);
+    if (in.sync_wait || in.sync_signal || in.sync_arrive)
+    {
+        args.sync_wait = in.sync_wait; args.sync_target = in.sync_target; args.sync_signal = in.sync_signal;
+        args.sync_arrive = in.sync_arrive;
+        if (in.qm[0]->is_gptq) LAUNCH((qgemv_flat_kernel<true, FlatArgs, false, true>), grid, block, lds, stream, args);
+        else if (big)          LAUNCH((qgemv_flat_kernel<false, FlatArgs, true, true>), grid, block, lds, stream, args);
+        else                   LAUNCH((qgemv_flat_kernel<false, FlatArgs, false, true>), grid, block, lds, stream, args);
+    }
+    else if (in.qm[0]->is_gptq) LAUNCH((qgemv_flat_kernel<true, FlatArgs, false>), grid, block, lds, stream, args);      // (GPTQ: one run)
+    else if (big)          LAUNCH((qgemv_flat_kernel<false, FlatArgs, true>), grid, block, lds, stream, args);
     else                   LAUNCH((qgemv_flat_kernel<false, FlatArgs, false>), grid, block, lds, stream, args);
     if (wgs_out) *wgs_out = wgs;
     return 0;

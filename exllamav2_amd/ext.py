@@ -497,6 +497,19 @@ class ExtC:
             self._ptr(norm_w_perm, torch.float16, "norm_w_perm"), float(eps), q_handle, self._ptr(c, torch.float16, "c"),
             int(rows), self._stream(xp)))
 
+    CHAIN_FLAG_STRIDE = 32
+
+    def chain_overlap_begin(self, flags, stream_a, stream_b) -> None:
+        """csrc/chain_sync.h: until chain_overlap_end() the chained launches alternate between the two streams and carry
+        their dependency in `flags` (int32 [n, 32], one counter per launch)."""
+        n = flags.numel() // self.CHAIN_FLAG_STRIDE
+        self.lib.check(self.lib.exl2_chain_overlap_begin(self._ptr(flags, torch.int32, "flags"), n, stream_a, stream_b))
+
+    def chain_overlap_end(self) -> int:
+        n = C.c_int(0)
+        self.lib.check(self.lib.exl2_chain_overlap_end(C.byref(n)))
+        return n.value
+
     def embed_rows_chain(self, table, ids, x, next_invperm, xp_out, ss_out) -> None:
         self.lib.check(self.lib.exl2_embed_rows_chain(
             self._ptr(table, torch.float16, "table"), self._ptr(ids, torch.int32, "ids"), self._ptr(x, torch.float16, "x"),

@@ -202,6 +202,11 @@ class GreedyGraphDecoder:
             "ss_a": torch.zeros((self.b, 256), dtype=torch.float32, device=dev),
             "ss_b": torch.zeros((self.b, 256), dtype=torch.float32, device=dev),
         }
+        # overlapped chain (csrc/chain_sync.h): launches alternate between the decoder's stream and a second one, each
+        # waits for its predecessor through a counter.  5 launches per layer + the head.
+        if os.environ.get("EXL2_CHAIN_OVERLAP", "0") != "0":
+            self.chain["flags"] = torch.zeros((5 * len(plan) + 4, ext.CHAIN_FLAG_STRIDE), dtype=torch.int32, device=dev)
+            self.chain["stream_b"] = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
 
     def step_chain(self):
         m, ext, cfg, ch = self.model, self.model.ext, self.model.config, self.chain
@@ -212,15 +217,24 @@ class GreedyGraphDecoder:
         v = m.temp_v[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
         xp_a, xp_b, ss_a, ss_b = ch["xp_a"], ch["xp_b"], ch["ss_a"], ch["ss_b"]
         ext.embed_rows_chain(m.embed_tokens, self.ids, x2, plan[0][0], xp_a, ss_a)
-        npart = 1
-        for i, (attn, mlp) in enumerate(m.layers):
-            in_a, o_inv, in_m = plan[i]
-            ext.q_attn_forward_1_chain(attn.q_handle, xp_a, ss_a, npart, b, q, k, v)
-            ao = attn.attend_chain(q, k, v, self.cache, self.cache_seqlens, self.block_table, o_inv)
-            npart = ext.q_attn_forward_2_chain(attn.q_handle, x2, ao, b, in_m, xp_b, ss_b)
-            nxt = plan[i + 1][0] if i + 1 < len(plan) else ch["head_inv"]
-            npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, xp_b, ss_b, npart, b, nxt, xp_a, ss_a)
-        ext.gemm_half_q_half_chain(xp_a, ss_a, npart, ch["norm_head"], cfg.norm_eps, m.lm_head.q_handle, self.logits, b)
+        overlap = "flags" in ch
+        if overlap:
+            sa = self.stream.cuda_stream if self.stream is not None else None
+            sb = ch["stream_b"].cuda_stream if ch["stream_b"] is not None else None
+            ext.chain_overlap_begin(ch["flags"], sa, sb)
+        try:
+            npart = 1
+            for i, (attn, mlp) in enumerate(m.layers):
+                in_a, o_inv, in_m = plan[i]
+                ext.q_attn_forward_1_chain(attn.q_handle, xp_a, ss_a, npart, b, q, k, v)
+                ao = attn.attend_chain(q, k, v, self.cache, self.cache_seqlens, self.block_table, o_inv)
+                npart = ext.q_attn_forward_2_chain(attn.q_handle, x2, ao, b, in_m, xp_b, ss_b)
+                nxt = plan[i + 1][0] if i + 1 < len(plan) else ch["head_inv"]
+                npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, xp_b, ss_b, npart, b, nxt, xp_a, ss_a)
+            ext.gemm_half_q_half_chain(xp_a, ss_a, npart, ch["norm_head"], cfg.norm_eps, m.lm_head.q_handle, self.logits, b)
+        finally:
+            if overlap:
+                ext.chain_overlap_end()
         ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens, pos_inc=1)
 
     def step_eager(self):

@@ -193,6 +193,15 @@ int exl2_embed_rows_chain(const void* table, const int* ids, void* x, int rows, 
                           const void* next_invperm, void* xp_out, float* ss_out, void* stream);
 /* dst[i] = src[perm[i]] (u16 perm, nullable = copy), n elements */
 int exl2_gather_f16(const void* src, const void* perm, void* dst, int n, void* stream);
+/* Overlapped chain (csrc/chain_sync.h; no reference counterpart -- the reference serialises every launch of a decode step on
+   one stream, q_attn.cu:153-345 / q_mlp.cu:153-236).  Between _begin and _end every chained launch of the calling thread
+   (exl2_q_attn_forward_1_chain, exl2_attn_decode_fused, exl2_q_attn_forward_2_chain, exl2_q_mlp_forward_chain (two launches),
+   exl2_gemm_half_q_half_chain) ignores its own `stream` argument: launch k goes to stream_a / stream_b alternately, waits for
+   launch k-1 through counter k-1 and signals counter k.  `flags`: n_flags * 32 u32 of device memory (zeroed here, on
+   stream_a); _begin forks stream_b behind stream_a, _end joins stream_a behind stream_b.  Capturable (both streams end up in
+   the capture of stream_a). */
+int exl2_chain_overlap_begin(void* flags, int n_flags, void* stream_a, void* stream_b);
+int exl2_chain_overlap_end(int* n_launches);
 
 /* ---- decode-loop utilities and graphs (replace cuda/graph.cu and the host-side embedding / argmax round trips) ------- */
 

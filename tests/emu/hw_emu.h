@@ -259,6 +259,20 @@ DEV u32 ticket_add_agent(u32* p, u32 v) { return __atomic_fetch_add(p, v, __ATOM
 DEV float load_agent_f32(const float* p) { return *(const volatile float*)p; }
 DEV void store_agent_f32(float* p, float v) { *(volatile float*)p = v; }
 DEV void store_relaxed_agent(u32* p, u32 v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+DEV void store_agent_f16(f16* p, f16 v) { *p = v; }
+DEV u32 load_agent_u32(const u32* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+// launches run to completion one after the other here: a consumer finds its producer's signals already there, and a
+// missing or short count is a bug in the host's bookkeeping -- reported, not waited for
+DEV void flag_wait_agent(const u32* flag, u32 target)
+{
+    if (load_agent_u32(flag) < target)
+    {
+        fprintf(stderr, "emu: overlapped launch would wait forever (flag %u < target %u)\n", load_agent_u32(flag), target);
+        abort();
+    }
+}
+DEV void release_agent() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+DEV void flag_signal_agent(u32* flag) { if (lane_id() == 0) (void)__atomic_fetch_add(flag, 1u, __ATOMIC_SEQ_CST); }
 
 #define DYN_SMEM(name) unsigned char* name = emu_ctx_->dyn_smem
 #define SHARED static
@@ -288,6 +302,13 @@ DEV hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 DEV const char* hipGetErrorString(hipError_t) { return "emu"; }
 DEV hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 4; return hipSuccess; }
 DEV hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+
+// events: launches complete before they return here, so ordering between "streams" is program order
+typedef void* hipEvent_t;
+enum { hipEventDisableTiming = 2 };
+DEV hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*)1; return hipSuccess; }
+DEV hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+DEV hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 
 // graphs cannot be emulated: capture is refused, callers fall back to eager launches in the emu tests
 typedef void* hipGraph_t;

@@ -95,6 +95,48 @@ def test_chain_tokens_equal_unchained_route(be, monkeypatch):
     assert (outs[0][0] == outs[1][0]).mean() >= 0.8
 
 
+@pytest.mark.parametrize("recipe,batch", [("4.0bpw", 1), ("3.5bpw", 3), ("gptq-4bit-128g", 2)])
+def test_overlapped_chain_equals_serial_chain(be, monkeypatch, recipe, batch):
+    """EXL2_CHAIN_OVERLAP=1 (csrc/chain_sync.h, EXPERIMENTAL, off by default): the same launches on two alternating streams,
+    dependencies through counters.  Same kernels, same arithmetic, same order of every sum: logits and tokens are
+    bit-identical to the one-stream chain.  Checked on the emulator only (bookkeeping: stream alternation, targets, gate,
+    every launch signalled, no wait gave up).  On the MI355X the mode is NOT validated: replayed from a captured graph
+    the two branches did not make progress the way the hand-off assumes -- waits ran into their spin limit and tokens came
+    out different (round 2, DESIGN.md section 3a''); the test is skipped there instead of pretending."""
+    if not be.is_emu:
+        pytest.skip("overlapped chain is experimental and not validated on the GPU (DESIGN.md 3a'')")
+    cfg = tiny_cfg(num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2, intermediate_size=384)
+    outs = []
+    for overlap in ("0", "1"):
+        monkeypatch.setenv("EXL2_CHAIN_OVERLAP", overlap)
+        ck = synth_checkpoint(cfg, be.device, recipe=recipe, seed=21, act_order=not recipe.startswith("gptq"))
+        model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+        cache = ExLlamaV2Cache(model, batch_size=batch)
+        dec = GreedyGraphDecoder(model, cache, batch_size=batch)
+        assert dec.chain is not None and ("flags" in dec.chain) == (overlap == "1")
+        if not be.is_emu:
+            dec.capture()
+        dec.reset(torch.arange(batch) + 5, 0)
+        logits = []
+        for _ in range(6):
+            dec.run(1, use_graph=not be.is_emu)
+            logits.append(be.n(dec.logits).copy())
+        outs.append((be.n(dec.tokens(0, 6)).copy(), np.stack(logits)))
+        if overlap == "1":
+            # every launch of the step went through the chain: 5 per layer + the head
+            with dec._on_stream():
+                dec.step_eager()
+            if not be.is_emu:
+                torch.cuda.synchronize()
+            flags = be.n(dec.chain["flags"])
+            assert flags[:5 * 3 + 1, 0].min() > 0 and flags[5 * 3 + 1:-1, 0].max() == 0
+            assert flags[-1, 0] > 0                                      # the gate's counter: workgroups of the first launch
+            assert flags[:, 1].sum() == 0                                # no wait gave up
+        dec.free(); model.unload()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_q4_cache_stays_unchained(be):
     cfg = tiny_cfg()
     ck = synth_checkpoint(cfg, be.device, seed=16)

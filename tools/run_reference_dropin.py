@@ -77,5 +77,39 @@ def main(model_dir: str, out: str, steps: int = 4):
     np.savez(out, **res)
 
 
+def main_tp(model_dir: str, out: str, steps: int = 4):
+    """The reference's single-process tensor parallel: model.load_tp (model.py:354-473: every linear split by output columns,
+    linear.py:540-619) + ExLlamaV2Cache_TP + the same greedy loop.  Attention goes through tp_attn_forward_ (attn.py:1198-
+    1259), the MLP through tp_mlp_forward_ (mlp.py:365-399), norm / head through rms_norm_tp / gemm_half_q_half_tp, the
+    exchanges through tp_broadcast / tp_gather and the pinned host buffers -- all served by exllamav2_amd/ext_tp.py.
+    Split over every visible device (one on the GPU box of this build)."""
+    from exllamav2 import ExLlamaV2, ExLlamaV2Config, ExLlamaV2Cache, ExLlamaV2Cache_TP
+    from exllamav2.ext import ext_c
+    assert ext_c.__name__ == "exllamav2_ext" and "dropin" in ext_c.__file__, ext_c.__file__
+    config = ExLlamaV2Config(model_dir)
+    config.max_seq_len = 256
+    config.max_input_len = 32
+    model = ExLlamaV2(config)
+    model.load_tp(gpu_split=[8.0] * torch.cuda.device_count(), progress=False)
+    assert model.tp_context is not None
+    cache = ExLlamaV2Cache_TP(model, base=ExLlamaV2Cache, max_seq_len=256)
+    ids = torch.tensor([[3, 17, 42, 7]])
+    logits = model.forward(ids, cache, last_id_only=False)
+    all_logits = [logits.float().cpu().numpy()]
+    toks = []
+    for _ in range(steps):
+        sample = torch.argmax(logits[0, -1]).cpu().unsqueeze(0).unsqueeze(0)
+        toks.append(int(sample))
+        ids = torch.cat((ids, sample), dim=-1)
+        logits = model.forward(ids[:, -1:], cache)
+        all_logits.append(logits.float().cpu().numpy())
+    np.savez(out, prefill=all_logits[0], steps=np.concatenate(all_logits[1:], axis=1), tokens=np.array(toks),
+             devices=np.array(model.tp_context.all_devs))
+    print("reference-on-dropin ok (load_tp, ExLlamaV2Cache_TP, greedy loop):", toks, "devices", model.tp_context.all_devs)
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) > 3 and sys.argv[3] == "tp":
+        main_tp(sys.argv[1], sys.argv[2])
+    else:
+        main(sys.argv[1], sys.argv[2])
