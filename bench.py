@@ -124,23 +124,42 @@ def time_gemv_calls(model, dec, reps: int = 5):
 
     one_step = one_step_chain if ch is not None else one_step_modules
     stream = dec.stream
+    two = ch is not None and "flags" in ch                      # overlapped chain: two graphs, one per stream, side by side
     with torch.cuda.stream(stream):
-        launches, nbytes = one_step()                           # warm-up, eager
-        stream.synchronize()
-        ext.graph_begin_capture(stream.cuda_stream)
-        try:
-            one_step()
-        finally:
-            graph = ext.graph_end_capture(stream.cuda_stream)
-        ext.graph_launch(graph, stream.cuda_stream)
+        if two:
+            sb = ch["stream_b"]
+            dec._ordered(one_step)                              # warm-up, eager (stream B ordered behind / ahead of stream A)
+            stream.wait_event(ch["ev_b"]); stream.synchronize(); sb.synchronize()
+            launches, nbytes = 0, 0
+            ext.graph_begin_capture(stream.cuda_stream); ext.graph_begin_capture(sb.cuda_stream)
+            try:
+                launches, nbytes = one_step()
+            finally:
+                graph = ext.graph_end_capture(stream.cuda_stream)
+                graph_b = ext.graph_end_capture(sb.cuda_stream)
+            replay = lambda: dec._ordered(lambda: (ext.graph_launch(graph, stream.cuda_stream), ext.graph_launch(graph_b, sb.cuda_stream)))
+        else:
+            launches, nbytes = one_step()                       # warm-up, eager
+            stream.synchronize()
+            ext.graph_begin_capture(stream.cuda_stream)
+            try:
+                one_step()
+            finally:
+                graph = ext.graph_end_capture(stream.cuda_stream)
+            graph_b = None
+            replay = lambda: ext.graph_launch(graph, stream.cuda_stream)
+        replay()
+        if two: stream.wait_event(ch["ev_b"])
         stream.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(reps):
-            ext.graph_launch(graph, stream.cuda_stream)
+            replay()
+        if two: stream.wait_event(ch["ev_b"])
         e1.record(stream)
         stream.synchronize()
         ext.graph_free(graph)
+        if graph_b is not None: ext.graph_free(graph_b)
     return e0.elapsed_time(e1) / reps, launches, nbytes
 
 
@@ -377,8 +396,9 @@ def main():
         extra = {}
         if dec.chain is not None and "flags" in dec.chain:
             # overlapped chain (EXL2_CHAIN_OVERLAP=1): waits that gave up would make the timing meaningless -- must be 0
-            extra["chain_overlap"] = {"launches": int((dec.chain["flags"][:-1, 0] > 0).sum()),
-                                      "wait_timeouts": int(dec.chain["flags"][:, 1].sum())}
+            extra["chain_overlap"] = {"hand_off_words_left_set": int((dec.chain["flags"][:, [0] + [32 * (1 + c) for c in range(8)]] != 0).sum()),
+                                      "waits_given_up": int(dec.chain["flags"][:, 2].sum()),
+                                      "given_up_by_launch": {int(i): int(v) for i, v in enumerate(dec.chain["flags"][:, 2].tolist()) if v}}
         if args.model == "llama2-7b" and args.ctx == 0 and not args.no_ctx_window:
             # SURVEY.md 8d's second window: the same decode with 1920 tokens already in the cache (steps 1921..1984)
             dec.reset(torch.tensor([1] * args.batch), 1920)

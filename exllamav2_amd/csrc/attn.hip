@@ -220,9 +220,9 @@ struct FusedArgs
     int page_size, page_shift, pages_per_seq;
     int past_const, nsplit, rope, keys_per_split_min;
     float scale;
-    // overlapped chain (chain_sync.h): q / k_new / v_new are read behind the wait; the workgroup that writes a group's final
-    // output signals once (batch * kv_heads * row_blocks signals per launch)
-    const u32* sync_wait; u32* sync_signal; u32 sync_target;
+    // overlapped chain (chain_sync.h / hw.h): q / k_new / v_new are read behind the wait, with agent-scope loads; the
+    // workgroup that writes a group's final output arrives once (sync_total = batch * kv_heads * row_blocks per launch)
+    const u32* sync_wait; u32* sync_signal; u32 sync_total;
 };
 
 // where feature d of query row qrow = (token row) * H + head goes
@@ -286,7 +286,8 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     const int k_start = split * kps;
     const int k_end = min(total, k_start + kps);
 
-    if (a.sync_wait) flag_wait_agent(a.sync_wait, a.sync_target);
+    const bool dep = a.sync_signal != nullptr;                 // overlapped chain: producer may still be running
+    if (a.sync_wait) { if (wv == 0) sync_wait_go(a.sync_wait, kh + split); block_sync(); }
 
     f16x8 qf[RB];
     int limit[RB];
@@ -295,7 +296,8 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     {
         const int rr = r0 + (r < nrows ? r : 0);
         const int j = rr / G, g = rr - j * G;
-        f16x8 raw = *(const f16x8*)(a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM + dl * 8);
+        const f16* qp = a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM + dl * 8;
+        f16x8 raw = dep ? load_agent_f16x8(qp) : *(const f16x8*)qp;
         if (a.rope) raw = rope_neox_frag<LPK>(raw, a.sin, a.cos, past + j, dl);
         qf[r] = raw;
         limit[r] = past + j + 1;
@@ -373,8 +375,8 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
         const bool in_range = kpos < k_end;
         const int kp = in_range ? kpos : k_end - 1;
         const size_t src = (((size_t)b * a.s + (kp - past)) * a.KVH + kh) * HDIM + dl * 8;
-        f16x8 kf = *(const f16x8*)(a.k_new + src);
-        const f16x8 vf = *(const f16x8*)(a.v_new + src);
+        f16x8 kf = dep ? load_agent_f16x8(a.k_new + src) : *(const f16x8*)(a.k_new + src);
+        const f16x8 vf = dep ? load_agent_f16x8(a.v_new + src) : *(const f16x8*)(a.v_new + src);
         if (a.rope) kf = rope_neox_frag<LPK>(kf, a.sin, a.cos, kp, dl);
         if (in_range && rblk == 0 && a.k_cache)
         {
@@ -438,9 +440,9 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     // (overlapped chain: the outputs above / below are agent-scope stores; one signal once the workgroup's have completed)
     auto signal_done = [&]() {
         if (!a.sync_signal) return;
-        release_agent();
+        wait_vmcnt0();
         block_sync();
-        if (tid() == 0) (void)ticket_add_agent(a.sync_signal, 1u);
+        if (wv == 0) sync_arrive_publish(a.sync_signal, a.sync_total, a.sync_wait);
     };
     if (eff == 1) { signal_done(); return; }
 
@@ -716,7 +718,7 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
         ChainLaunch cl;
         const int e = chain_sync_next(&cl);
         if (e) return e;
-        a.sync_wait = cl.wait; a.sync_target = cl.target; a.sync_signal = cl.signal;
+        a.sync_wait = cl.wait; a.sync_signal = cl.signal; a.sync_total = (u32)(batch * num_kv_heads * rblocks);
         stream = cl.stream;
     }
 #define FUSED_CASE(HDIM_, RB_) LAUNCH((attn_fused_kernel<HDIM_, RB_>), grid, dim3(ATT_WAVES * 64), lds, stream, a)
@@ -732,7 +734,7 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
 #undef FUSED_HD
 #undef FUSED_CASE
     HIP_TRY(hipGetLastError());
-    if (overlapped) { const int e = chain_sync_done((u32)(batch * num_kv_heads * rblocks), 0u); if (e) return e; }
+    if (overlapped) { const int e = chain_sync_done(0u); if (e) return e; }
     return EXL2_OK;
 }
 

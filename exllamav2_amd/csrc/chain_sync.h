@@ -17,14 +17,13 @@
 #pragma once
 #include "hw.h"
 
-#define CHAIN_FLAG_STRIDE 32          // u32 per counter: one 128-byte line each
 
-struct ChainLaunch { const u32* wait; u32 target; u32* signal; u32* arrive; void* stream; };
+struct ChainLaunch { const u32* wait; u32* signal; u32* arrive; void* stream; };      // blocks of SYNC_BLOCK_WORDS (hw.h)
 
 // true while a chain is open on this thread
 bool chain_sync_active();
 // stream / counters of the next launch; returns < 0 (error set) when the chain has run out of counters
 int chain_sync_next(ChainLaunch* out);
-// the launch took place: it will add `signals` to its counter in total; `arrivals` = its workgroups (first launch: the gate
-// on the other stream is launched with this target).  Returns < 0 on error.
-int chain_sync_done(u32 signals, u32 arrivals);
+// the launch took place; `arrivals` = its workgroups (first launch only: the gate on the other stream is launched with this
+// target).  Returns < 0 on error.
+int chain_sync_done(u32 arrivals);

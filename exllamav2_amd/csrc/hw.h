@@ -196,25 +196,63 @@ DEV void store_relaxed_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_
 DEV void store_agent_f16(f16* p, f16 v) { __hip_atomic_store((u16*)p, as_u16(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV u32 load_agent_u32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// ---- hand-off BETWEEN launches that overlap (two streams, the dependency carried by a counter in memory instead of the
-// kernel boundary): the consumer has issued everything that does not depend on the producer (weights, tables) and waits
-// here for the producer's `target` signals; then an agent-scope acquire (buffer_inv sc1) before it reads the activations.
-// The spin is bounded: a missing producer must show up as wrong numbers in a test, never as a hung GPU.
-#define FLAG_SPIN_LIMIT (1 << 15)              // ~ 10 ms: a legitimate wait is a few microseconds
-DEV void flag_wait_agent(const u32* flag, u32 target)
+// ---- hand-off BETWEEN launches that overlap (two streams; the dependency is carried by words in memory instead of the
+// kernel boundary; chain_sync.h).  Measured on the MI355X (tools/probes/fork_probe.hip, profiles/r02_fork_probe.txt):
+//   * thousands of waves polling the counter the producers add to starve those adds (25-45 us per hand-off): producers add
+//     to a counter nobody polls, the LAST one publishes "go" words, ONE wave per workgroup polls the copy of its class;
+//   * an agent-scope acquire fence (buffer_inv sc1) per wave costs ~25 us per kernel: none is issued -- what the consumer
+//     reads from its producer is read with agent-scope loads, what the producer writes is written with agent-scope stores;
+//   * then a hand-off costs ~3.2 us after the producer's last workgroup, about what a kernel boundary costs (3.1 us) -- the
+//     gain is the consumer's start-up (arguments, tables, weight ring) running during it.
+// Block of one launch: word 0 = arrivals counter, words 32 (1 + c) = copy c of "go" (own 128-byte lines), word 2 = waits
+// that gave up (debug).  The spin is bounded: a missing producer must show up as wrong numbers in a test, never as a hung GPU.
+#define SYNC_BLOCK_WORDS 320
+#define SYNC_GO_COPIES 8
+#define FLAG_SPIN_LIMIT (1 << 21)              // ~ 1 s (a poll is ~0.5 us): longer than any host hiccup between the two graph launches
+DEV const u32* sync_go_word(const u32* block, int cls) { return block + 32 * (1 + (cls & (SYNC_GO_COPIES - 1))); }
+// consumer: the calling WAVE polls (one wave per workgroup; the others wait at the workgroup barrier behind it)
+DEV void sync_wait_go(const u32* producer_block, int cls)
+{
+    const u32* go = sync_go_word(producer_block, cls);
+    int spins = 0;
+    while (uniform((int)load_agent_u32(go)) == 0 && ++spins < FLAG_SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+    if (spins >= FLAG_SPIN_LIMIT && lane_id() == 0) (void)ticket_add_agent((u32*)producer_block + 2, 1u);
+}
+// producer: the calling wave's outputs were agent-scope stores; when they have completed it arrives; the last of `total`
+// arrivals publishes "go", zeroes its own counter and the "go" words this launch waited on (every consumer of those has
+// passed: this launch is finished) -- the words are back to zero for the next replay without any memset.
+DEV void sync_arrive_publish(u32* own_block, u32 total, const u32* waited_block)
+{
+    wait_vmcnt0();
+    if (lane_id() != 0) return;
+    const u32 old = ticket_add_agent(own_block, 1u);
+    if (old + 1 != total) return;
+    for (int c = 0; c < SYNC_GO_COPIES; c++) store_relaxed_agent((u32*)sync_go_word(own_block, c), 1u);
+    store_relaxed_agent(own_block, 0u);
+    if (waited_block) for (int c = 0; c < SYNC_GO_COPIES; c++) store_relaxed_agent((u32*)sync_go_word(waited_block, c), 0u);
+}
+// the gate ahead of the chain's second launch (chain_sync.h): one wave waits for `target` arrivals, then zeroes the counter
+DEV void sync_gate_wait(u32* arrived, u32 target)
 {
     int spins = 0;
-    while (uniform((int)load_agent_u32(flag)) < (int)target && ++spins < FLAG_SPIN_LIMIT) __builtin_amdgcn_s_sleep(2);
-    // a wait that gave up is counted in the word behind the counter (tests assert it stays zero)
-    if (spins >= FLAG_SPIN_LIMIT && lane_id() == 0) (void)__hip_atomic_fetch_add((u32*)flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // agent-scope acquire spelled as the instruction (what __builtin_amdgcn_fence(acquire, "agent") emits on gfx950): the
-    // builtin fence makes the compiler keep a stack copy of by-value kernel arguments that are indexed at run time
-    asm volatile("buffer_inv sc1" ::: "memory");
+    while (uniform((int)load_agent_u32(arrived)) < (int)target && ++spins < FLAG_SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+    if (lane_id() == 0) store_relaxed_agent(arrived, 0u);
 }
-// producer side: agent-scope release spelled as instructions (write back what the L2 still holds dirty, wait for every
-// store of this wave), then one signal.  The outputs themselves are agent-scope (write-through) stores.
-DEV void release_agent() { asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); }
-DEV void flag_signal_agent(u32* flag) { release_agent(); if (lane_id() == 0) (void)ticket_add_agent(flag, 1u); }
+// agent-scope loads of what a still-running producer has written (no acquire fence: see above)
+DEV f16 load_agent_f16(const f16* p) { return __builtin_bit_cast(f16, (u16)__hip_atomic_load((const u16*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+DEV f16x8 load_agent_f16x8(const f16* p)
+{
+    struct Pair { u64 a, b; } v;
+    v.a = __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.b = __hip_atomic_load((const u64*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_bit_cast(f16x8, v);
+}
+// LDS-DMA at agent scope (sc1)
+DEV void dma_to_lds16_agent(const void* g_lane_ptr, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane_ptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 16);
+}
 
 // dynamic LDS (16-byte aligned base, guide G17)
 #define DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]

@@ -152,58 +152,62 @@ KERNEL void __launch_bounds__(256) moe_combine_kernel(f16* x, const f16* part, c
 static bool hidden_ok(const QMoEMLP* m) { return (m->hidden & 7) == 0; }
 
 // ---- overlapped chain (chain_sync.h) ---------------------------------------------------------------------------------------------
-struct ChainSyncState { u32* flags; int n_flags; void* stream[2]; int next; u32 prev_signals; bool open; };
-static thread_local ChainSyncState g_chain = {nullptr, 0, {nullptr, nullptr}, 0, 0, false};
-static hipEvent_t g_chain_event[2] = {nullptr, nullptr};
+struct ChainSyncState { u32* flags; int n_blocks; void* stream[2]; int next; bool open; };
+static thread_local ChainSyncState g_chain = {nullptr, 0, {nullptr, nullptr}, 0, false};
 
 bool chain_sync_active() { return g_chain.open; }
+
+static u32* chain_block(int k) { return g_chain.flags + (size_t)k * SYNC_BLOCK_WORDS; }
 
 int chain_sync_next(ChainLaunch* out)
 {
     EXL2_REQUIRE(g_chain.open, "chain: no overlapped chain is open");
-    EXL2_REQUIRE(g_chain.next < g_chain.n_flags - 1, "chain: more than %d launches in one overlapped chain", g_chain.n_flags - 1);
+    EXL2_REQUIRE(g_chain.next < g_chain.n_blocks - 1, "chain: more than %d launches in one overlapped chain", g_chain.n_blocks - 1);
     const int k = g_chain.next;
-    out->wait = k > 0 ? g_chain.flags + (size_t)(k - 1) * CHAIN_FLAG_STRIDE : nullptr;
-    out->target = g_chain.prev_signals;
-    out->signal = g_chain.flags + (size_t)k * CHAIN_FLAG_STRIDE;
-    out->arrive = k == 0 ? g_chain.flags + (size_t)(g_chain.n_flags - 1) * CHAIN_FLAG_STRIDE : nullptr;     // last counter: the gate's
+    out->wait = k > 0 ? chain_block(k - 1) : nullptr;
+    out->signal = chain_block(k);
+    out->arrive = k == 0 ? chain_block(g_chain.n_blocks - 1) : nullptr;            // last block: the gate's arrivals counter
     out->stream = g_chain.stream[k & 1];
     return EXL2_OK;
 }
 
-// one wave: holds launch 1 back until every workgroup of launch 0 sits on its CU (chain_sync.h)
-KERNEL void __launch_bounds__(64) chain_gate_kernel(const u32* arrived, u32 target) { flag_wait_agent(arrived, target); }
+// one wave: holds launch 1 back until every workgroup of launch 0 sits on its CU (chain_sync.h); zeroes the counter again
+KERNEL void __launch_bounds__(64) chain_gate_kernel(u32* arrived, u32 target) { sync_gate_wait(arrived, target); }
+// end of a chain: nobody waits for the last launch's "go" -- back to zero for the next replay (runs behind it in its stream)
+KERNEL void __launch_bounds__(64) chain_tail_kernel(u32* block)
+{
+    if (lane_id() < SYNC_GO_COPIES) store_relaxed_agent((u32*)sync_go_word(block, lane_id()), 0u);
+}
 
-int chain_sync_done(u32 signals, u32 arrivals)
+int chain_sync_done(u32 arrivals)
 {
     if (g_chain.next == 0)
     {
         EXL2_REQUIRE(arrivals > 0, "chain: the first launch of an overlapped chain must be a chained q_gemm");
-        LAUNCH(chain_gate_kernel, dim3(1, 1, 1), dim3(64, 1, 1), 0, g_chain.stream[1],
-               (const u32*)(g_chain.flags + (size_t)(g_chain.n_flags - 1) * CHAIN_FLAG_STRIDE), arrivals);
+        LAUNCH(chain_gate_kernel, dim3(1, 1, 1), dim3(64, 1, 1), 0, g_chain.stream[1], chain_block(g_chain.n_blocks - 1), arrivals);
         HIP_TRY(hipGetLastError());
     }
-    g_chain.next++; g_chain.prev_signals = signals;
+    g_chain.next++;
     return EXL2_OK;
 }
 
 // One chained launch.  While an overlapped chain is open (chain_sync.h) the launch takes its stream and its counters from it.
 static int flat_try(FlatIn& in, void* stream, int* wgs, const char* what)
 {
-    ChainLaunch cl = {nullptr, 0, nullptr, nullptr, stream};
+    ChainLaunch cl = {nullptr, nullptr, nullptr, stream};
     const bool overlapped = chain_sync_active();
     if (overlapped)
     {
         const int e = chain_sync_next(&cl);
         if (e) return e;
-        in.sync_wait = cl.wait; in.sync_target = cl.target; in.sync_signal = cl.signal; in.sync_arrive = cl.arrive;
+        in.sync_wait = cl.wait; in.sync_signal = cl.signal; in.sync_arrive = cl.arrive;
     }
     int n_wgs = 0;
     const int rc = qgemv_flat_launch(in, cl.stream, &n_wgs);
     if (rc > 0) EXL2_FAIL(EXL2_E_INVALID, "%s: shape not covered by the chained decode kernel", what);
     if (rc < 0) EXL2_FAIL(EXL2_E_INVALID, "%s: launch configuration rejected (%d)", what, rc);
     HIP_TRY(hipGetLastError());
-    if (overlapped) { const int e = chain_sync_done((u32)n_wgs * (u32)in.M, (u32)n_wgs); if (e) return e; }    // M combining waves per workgroup signal
+    if (overlapped) { const int e = chain_sync_done((u32)n_wgs); if (e) return e; }
     if (wgs) *wgs = n_wgs;
     return EXL2_OK;
 }
@@ -347,7 +351,8 @@ int exl2_make_q_attn(void** handle, const void* layernorm, const void* layernorm
     EXL2_REQUIRE(!layernorm || layernorm_is_rms, "make_q_attn: only RMSNorm pre-norm is built (LayerNorm archs out of scope)");
     EXL2_REQUIRE(!q_norm && !k_norm, "make_q_attn: q/k head norms are not built (non-Llama archs out of scope)");
     EXL2_REQUIRE(!residual_fp32, "make_q_attn: fp32 residual stream is not built");
-    EXL2_REQUIRE(!layernorm || temp_state, "make_q_attn: temp_state required");
+    // (temp_state may be absent: the reference's tensor-parallel loader makes the handle without scratch, attn.py:259-272,
+    // and never runs a forward on it; the forwards below refuse such a handle)
     QAttn* a = (QAttn*)calloc(1, sizeof(QAttn));
     if (!a) EXL2_FAIL(EXL2_E_OOM, "make_q_attn: host out of memory");
     a->layernorm = (const f16*)layernorm; a->layernorm_bias = (const f16*)layernorm_bias;
@@ -395,6 +400,7 @@ int exl2_q_attn_forward_1(void* handle, const void* x, int batch_size, int q_len
     QAttn* a = (QAttn*)handle;
     const int rows = batch_size * q_len;
     if (rows <= 0) return EXL2_OK;
+    EXL2_REQUIRE(a->temp_state || !a->layernorm, "q_attn_forward_1: handle was made without scratch (tensor-parallel load)");
     // temp_state (and the caller's temp_q/k/v) are sized for max_rows (attn.py:377-379 keeps chunks inside it)
     EXL2_REQUIRE(rows <= a->max_rows, "q_attn_forward_1: %d rows exceed max_rows %d", rows, a->max_rows);
     const bool gptq = a->q_proj->is_gptq;
@@ -441,6 +447,7 @@ int exl2_q_attn_forward_2(void* handle, void* x, const void* attn_output, int ba
     const int rows = batch_size * q_len;
     if (rows <= 0) return EXL2_OK;
     EXL2_REQUIRE(rows <= a->max_rows, "q_attn_forward_2: %d rows exceed max_rows %d", rows, a->max_rows);
+    EXL2_REQUIRE(a->temp_state || !a->post_layernorm, "q_attn_forward_2: handle was made without scratch (tensor-parallel load)");
     GemvJob j;
     if (!a->post_layernorm)
     {
@@ -463,7 +470,7 @@ int exl2_make_q_mlp(void** handle, const void* layernorm, const void* layernorm_
     EXL2_REQUIRE(handle && q_up && q_down, "make_q_mlp: null projection handle");
     EXL2_REQUIRE(!layernorm || layernorm_is_rms, "make_q_mlp: only RMSNorm pre-norm is built (LayerNorm archs out of scope)");
     EXL2_REQUIRE(!residual_fp32, "make_q_mlp: fp32 residual stream is not built");
-    EXL2_REQUIRE(temp_a && (!q_gate || temp_b), "make_q_mlp: temp buffers required");
+    // (scratch may be absent -- tensor-parallel load, mlp.py:169-190: the forwards refuse such a handle)
     QMLP* m = (QMLP*)calloc(1, sizeof(QMLP));
     if (!m) EXL2_FAIL(EXL2_E_OOM, "make_q_mlp: host out of memory");
     m->layernorm = (const f16*)layernorm; m->layernorm_bias = (const f16*)layernorm_bias; m->layernorm_is_rms = layernorm_is_rms;
@@ -476,7 +483,7 @@ int exl2_make_q_mlp(void** handle, const void* layernorm, const void* layernorm_
     {
         QMatrix* gu[2] = {m->gate, m->up};
         const bool gq = m->up->is_gptq;
-        m->chain_ok = m->layernorm && m->layernorm_is_rms && !m->layernorm_bias && !m->post_layernorm && m->has_residual
+        m->chain_ok = m->temp_a && m->layernorm && m->layernorm_is_rms && !m->layernorm_bias && !m->post_layernorm && m->has_residual
                       && m->gate->is_gptq == gq && m->down->is_gptq == gq && m->gate->width == m->up->width
                       && m->down->height == m->up->width && m->down->width == m->up->height && same_perm(gu, 2);
         if (m->chain_ok) { m->norm_w_perm = permuted_norm(m->layernorm, m->up); if (!m->norm_w_perm) m->chain_ok = false; }
@@ -500,6 +507,8 @@ int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream)
     QMLP* m = (QMLP*)handle;
     if (rows <= 0) return EXL2_OK;
     EXL2_REQUIRE(rows <= m->max_rows, "q_mlp_forward_: %d rows exceed max_rows %d", rows, m->max_rows);
+    EXL2_REQUIRE(m->temp_a && (!m->gate || m->temp_b) && (m->temp_state || !(m->layernorm || m->post_layernorm)),
+                 "q_mlp_forward_: handle was made without scratch (tensor-parallel load)");
     const int hidden = m->up->height;
     const bool gptq = m->up->is_gptq;
     const bool skinny = rows <= MAX_GEMV_ROWS;
@@ -560,30 +569,26 @@ int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream)
 
 // ---- chained decode (qgemv_flat.hip) -----------------------------------------------------------------------------------------
 
-int exl2_chain_overlap_begin(void* flags, int n_flags, void* stream_a, void* stream_b)
+int exl2_chain_overlap_begin(void* flags, int n_blocks, void* stream_a, void* stream_b)
 {
-    EXL2_REQUIRE(flags && n_flags > 0, "chain_overlap_begin: no counters");
+    EXL2_REQUIRE(flags && n_blocks > 2, "chain_overlap_begin: no counters");
     EXL2_REQUIRE(!g_chain.open, "chain_overlap_begin: a chain is already open on this thread");
-    // counters back to zero, then stream B joins behind everything A has been given so far (fork; under capture this pulls
-    // B into the capture)
-    HIP_TRY(hipMemsetAsync(flags, 0, (size_t)n_flags * CHAIN_FLAG_STRIDE * sizeof(u32), (hipStream_t)stream_a));
-    for (int i = 0; i < 2; i++)
-        if (!g_chain_event[i]) HIP_TRY(hipEventCreateWithFlags(&g_chain_event[i], hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(g_chain_event[0], (hipStream_t)stream_a));
-    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_b, g_chain_event[0], 0));
-    g_chain.flags = (u32*)flags; g_chain.n_flags = n_flags; g_chain.stream[0] = stream_a; g_chain.stream[1] = stream_b;
-    g_chain.next = 0; g_chain.prev_signals = 0; g_chain.open = true;
+    g_chain.flags = (u32*)flags; g_chain.n_blocks = n_blocks; g_chain.stream[0] = stream_a; g_chain.stream[1] = stream_b;
+    g_chain.next = 0; g_chain.open = true;
     return EXL2_OK;
 }
 
-// Closes the chain: stream A continues behind everything both streams were given (join).  Returns the number of launches.
+// Closes the chain.  Returns the number of launches; the last one went to stream (n - 1) & 1, and so does the tail kernel.
 int exl2_chain_overlap_end(int* n_launches)
 {
     EXL2_REQUIRE(g_chain.open, "chain_overlap_end: no chain is open");
     g_chain.open = false;
     if (n_launches) *n_launches = g_chain.next;
-    HIP_TRY(hipEventRecord(g_chain_event[1], (hipStream_t)g_chain.stream[1]));
-    HIP_TRY(hipStreamWaitEvent((hipStream_t)g_chain.stream[0], g_chain_event[1], 0));
+    if (g_chain.next > 0)
+    {
+        LAUNCH(chain_tail_kernel, dim3(1, 1, 1), dim3(64, 1, 1), 0, g_chain.stream[(g_chain.next - 1) & 1], chain_block(g_chain.next - 1));
+        HIP_TRY(hipGetLastError());
+    }
     return EXL2_OK;
 }
 

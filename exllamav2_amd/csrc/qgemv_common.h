@@ -333,14 +333,15 @@ template <int MB> struct RingLoads
 // contiguous global -> LDS copy of `units` 16-byte units, all waves of the workgroup; unit u of the copy comes from
 // src_of(u).  LDS destination dst + 16 u.
 // `first`: the wave that takes units [0, 64) -- small copies start on different waves so that no wave issues them all.
-template <typename F>
+// AGENT: the source was written by a launch that may still be running (overlapped chain): agent-scope loads
+template <bool AGENT = false, typename F>
 DEV void dma_units16(F src_of, void* dst, int units, int wv, int nw, int lane, int first = 0)
 {
     int vw = wv - first; if (vw < 0) vw += nw;
     for (int base = vw * 64; base < units; base += nw * 64)
     {
         const int u = base + lane;
-        if (u < units) dma_to_lds16(src_of(u), (char*)dst + (size_t)base * 16);
+        if (u < units) { if constexpr (AGENT) dma_to_lds16_agent(src_of(u), (char*)dst + (size_t)base * 16); else dma_to_lds16(src_of(u), (char*)dst + (size_t)base * 16); }
     }
 }
 template <typename F>

@@ -17,9 +17,10 @@ struct FlatIn
     int pair;                     // 2 matrices (gate, up): output = act(gate) * up, written through mat 0's c / c_invperm
     int act_gelu, c_mode;         // C_STORE / C_ACCUM (residual)
     f16* xp_out; const u16* xp_invperm; float* ss_out; int ldxp;     // chain-out (nullable)
-    // overlapped chain (chain_sync.h): wait for *sync_wait >= sync_target before the activations are read; outputs are
-    // agent-scope stores and every workgroup adds M to *sync_signal when they have completed.  Both nullable.
-    const u32* sync_wait; u32 sync_target; u32* sync_signal;
+    // overlapped chain (chain_sync.h / hw.h): sync_wait = the producer launch's block (its "go" word is polled before the
+    // activations are read, with agent-scope loads), sync_signal = this launch's block (outputs are agent-scope stores;
+    // every combining wave arrives there, the last publishes "go").  Both nullable.
+    const u32* sync_wait; u32* sync_signal;
     u32* sync_arrive;             // first launch of a chain: every workgroup adds 1 on entry (chain_sync.h: the gate)
 };
 

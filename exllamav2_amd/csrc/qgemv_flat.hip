@@ -87,7 +87,7 @@ struct FlatHdr
     u32 lds_sc_off, sc_piece, lds_zp_off, lds_cg_off, cg_stride, lds_red_off;
     int r_stride, mul_r;          // grouped launches: row stride of r_weights; multiply the result by the weight (down projection)
     long long a_gstride;          // grouped launches: elements between the inputs of consecutive groups
-    const u32* sync_wait; u32* sync_signal; u32* sync_arrive; u32 sync_target;     // overlapped chain (DEP instantiation; chain_sync.h)
+    const u32* sync_wait; u32* sync_signal; u32* sync_arrive; u32 sync_total;      // overlapped chain (DEP instantiation; chain_sync.h)
 };
 
 // one launch = one set of <= 4 fused matrices ...
@@ -332,25 +332,25 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
     // of `head` counts against the compiler's use limit for keeping a by-value kernel argument out of the stack)
     const int act_mode = args.a_mode, act_lda = args.lda, act_stride = args.a_stride, act_npart = args.npart;
     const f16* const act_a = args.a; const f16* const act_nw = args.norm_w; const float* const act_ss = args.ss;
-    const u32* const dep_wait = DEP ? args.sync_wait : nullptr; const u32 dep_target = DEP ? args.sync_target : 0u;
+    const u32* const dep_wait = DEP ? args.sync_wait : nullptr;
     if constexpr (DEP) if (args.sync_arrive && t == 0) (void)ticket_add_agent(args.sync_arrive, 1u);      // "this workgroup holds its CU"
 #define FLAT_ISSUE_ACTS() do { \
         if (act_mode == A_DIRECT) \
         { \
             for (int rr = 0; rr < M; rr++) \
-                dma_units16([&](int u) { return (const void*)(a_in + (size_t)rr * act_lda + (size_t)u * 8); }, a_lds + (size_t)rr * act_stride, oct, wv, nw, lane, rr % nw); \
+                dma_units16<DEP>([&](int u) { return (const void*)(a_in + (size_t)rr * act_lda + (size_t)u * 8); }, a_lds + (size_t)rr * act_stride, oct, wv, nw, lane, rr % nw); \
         } \
         else if (one_pass && t < M * oct) \
         { \
-            xr = *(const f16x8*)(act_a + (size_t)row1 * act_lda + (size_t)oc1 * 8); \
+            xr = DEP ? load_agent_f16x8(act_a + (size_t)row1 * act_lda + (size_t)oc1 * 8) : *(const f16x8*)(act_a + (size_t)row1 * act_lda + (size_t)oc1 * 8); \
             wr = *(const f16x8*)(act_nw + (size_t)oc1 * 8); \
             /* partial sums of squares: every wave reduces its row's partials itself (fixed order), no LDS round trip */ \
             const float* sp_ = act_ss + (size_t)row1 * act_npart; \
             _Pragma("unroll") \
-            for (int i = 0; i < 4; i++) if (lane + 64 * i < act_npart) ssp[i] = sp_[lane + 64 * i]; \
+            for (int i = 0; i < 4; i++) if (lane + 64 * i < act_npart) ssp[i] = DEP ? load_agent_f32(sp_ + lane + 64 * i) : sp_[lane + 64 * i]; \
         } } while (0)
     // DEP: the predecessor's outputs are read only behind the wait (head, below); everything issued here is static data
-#define FLAT_AWAIT_INPUTS() do { if (dep_wait) flag_wait_agent(dep_wait, dep_target); FLAT_ISSUE_ACTS(); } while (0)
+#define FLAT_AWAIT_INPUTS() do { FTRACE(10); if (dep_wait) { if (wv == 0) sync_wait_go(dep_wait, bid_x()); block_sync_lds(); } FTRACE(11); FLAT_ISSUE_ACTS(); } while (0)
     if constexpr (!DEP) FLAT_ISSUE_ACTS();
     // tables: matrix j = wave & 3 is served by the four waves with that residue; a matrix' scale tables of this
     // workgroup's tiles are one contiguous piece of its [tile][G][16] table, the chunk -> group map sits behind the table
@@ -412,12 +412,12 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
         {
             float ss = 0.0f;
             const float* sp = args.ss + (size_t)rr * args.npart;
-            for (int i = lane; i < args.npart; i += 64) ss += sp[i];
+            for (int i = lane; i < args.npart; i += 64) ss += DEP ? load_agent_f32(sp + i) : sp[i];
             ss = wave_allreduce_add(ss);
             const float rms = fast_rsqrt(ss * (1.0f / (float)K) + args.eps);
             for (int o = t; o < oct; o += nw * 64)
             {
-                const f16x8 x = *(const f16x8*)(args.a + (size_t)rr * args.lda + (size_t)o * 8);
+                const f16x8 x = DEP ? load_agent_f16x8(args.a + (size_t)rr * args.lda + (size_t)o * 8) : *(const f16x8*)(args.a + (size_t)rr * args.lda + (size_t)o * 8);
                 const f16x8 w = *(const f16x8*)(args.norm_w + (size_t)o * 8);
                 f16x8 v;
                 #pragma unroll
@@ -692,7 +692,7 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
                     if (bp) v += (float)bp[n];
                 }
                 if (ARGS::grouped && args.mul_r) v *= (float)rwt;
-                if (args.c_mode == C_ACCUM) v += (float)*cp;
+                if (args.c_mode == C_ACCUM) v += DEP ? (float)load_agent_f16(cp) : (float)*cp;
                 y = (f16)v;
             }
             if constexpr (DEP) store_agent_f16(cp, y); else *cp = y;
@@ -710,7 +710,7 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
         sq = wave_allreduce_add(sq);
         if (lane == 0) { if constexpr (DEP) store_agent_f32(args.ss_out + (size_t)row * args.wgs + b, sq); else args.ss_out[(size_t)row * args.wgs + b] = sq; }
     }
-    if constexpr (DEP) if (args.sync_signal) flag_signal_agent(args.sync_signal);       // one signal per combining wave: wgs * M
+    if constexpr (DEP) if (args.sync_signal) sync_arrive_publish(args.sync_signal, args.sync_total, args.sync_wait);    // wgs * M arrivals
     FTRACE(8);
 }
 
@@ -865,7 +865,11 @@ static u32 flat_plan(FlatHdr& hdr, const FlatIn& in, const FlatPlanAcc& acc, u32
     hdr.lds_minor_off = total; hdr.minor_wave_bytes = al16(minor_wave_bytes); total += FLAT_WAVES * hdr.minor_wave_bytes;
     if (total > 160 * 1024) return 0;
 #ifdef EXL2_TRACE
-    hdr.trace = (g_ftrace_buf && g_ftrace_count++ == g_ftrace_which) ? g_ftrace_buf : nullptr;
+    // (two consecutive launches are stamped: producer + consumer of an overlapped hand-off; second buffer behind the first)
+    {
+        const int idx = g_ftrace_count++;
+        hdr.trace = (g_ftrace_buf && (idx == g_ftrace_which || idx == g_ftrace_which + 1)) ? g_ftrace_buf + (size_t)(idx - g_ftrace_which) * 256 * 16 * 16 : nullptr;
+    }
 #endif
     if (wgs_out) *wgs_out = wgs;
     return total;
@@ -917,7 +921,7 @@ int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out)
     const bool big = flat_any_big(args.cold_, in.n_mats);
     if (in.sync_wait || in.sync_signal || in.sync_arrive)
     {
-        args.sync_wait = in.sync_wait; args.sync_target = in.sync_target; args.sync_signal = in.sync_signal;
+        args.sync_wait = in.sync_wait; args.sync_signal = in.sync_signal; args.sync_total = (u32)wgs * (u32)in.M;
         args.sync_arrive = in.sync_arrive;
         if (in.qm[0]->is_gptq) LAUNCH((qgemv_flat_kernel<true, FlatArgs, false, true>), grid, block, lds, stream, args);
         else if (big)          LAUNCH((qgemv_flat_kernel<false, FlatArgs, true, true>), grid, block, lds, stream, args);

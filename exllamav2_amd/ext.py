@@ -497,12 +497,12 @@ class ExtC:
             self._ptr(norm_w_perm, torch.float16, "norm_w_perm"), float(eps), q_handle, self._ptr(c, torch.float16, "c"),
             int(rows), self._stream(xp)))
 
-    CHAIN_FLAG_STRIDE = 32
+    SYNC_BLOCK_WORDS = 320
 
     def chain_overlap_begin(self, flags, stream_a, stream_b) -> None:
         """csrc/chain_sync.h: until chain_overlap_end() the chained launches alternate between the two streams and carry
-        their dependency in `flags` (int32 [n, 32], one counter per launch)."""
-        n = flags.numel() // self.CHAIN_FLAG_STRIDE
+        their dependency in `flags` (int32 [n, 320], one block per launch, zero at first use)."""
+        n = flags.numel() // self.SYNC_BLOCK_WORDS
         self.lib.check(self.lib.exl2_chain_overlap_begin(self._ptr(flags, torch.int32, "flags"), n, stream_a, stream_b))
 
     def chain_overlap_end(self) -> int:

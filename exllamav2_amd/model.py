@@ -202,11 +202,14 @@ class GreedyGraphDecoder:
             "ss_a": torch.zeros((self.b, 256), dtype=torch.float32, device=dev),
             "ss_b": torch.zeros((self.b, 256), dtype=torch.float32, device=dev),
         }
-        # overlapped chain (csrc/chain_sync.h): launches alternate between the decoder's stream and a second one, each
-        # waits for its predecessor through a counter.  5 launches per layer + the head.
+        # overlapped chain (csrc/chain_sync.h, EXPERIMENTAL): launches alternate between the decoder's stream and a second
+        # one, each waits for its predecessor through words in memory.  5 launches per layer + the head (+ the gate's block).
         if os.environ.get("EXL2_CHAIN_OVERLAP", "0") != "0":
-            self.chain["flags"] = torch.zeros((5 * len(plan) + 4, ext.CHAIN_FLAG_STRIDE), dtype=torch.int32, device=dev)
+            self.chain["flags"] = torch.zeros((5 * len(plan) + 4, ext.SYNC_BLOCK_WORDS), dtype=torch.int32, device=dev)
             self.chain["stream_b"] = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+            if dev.type == "cuda":
+                self.chain["ev_pre"], self.chain["ev_b"] = torch.cuda.Event(), torch.cuda.Event()
+            self.graph_b = None
 
     def step_chain(self):
         m, ext, cfg, ch = self.model, self.model.ext, self.model.config, self.chain
@@ -233,11 +236,37 @@ class GreedyGraphDecoder:
                 npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, xp_b, ss_b, npart, b, nxt, xp_a, ss_a)
             ext.gemm_half_q_half_chain(xp_a, ss_a, npart, ch["norm_head"], cfg.norm_eps, m.lm_head.q_handle, self.logits, b)
         finally:
-            if overlap:
-                ext.chain_overlap_end()
-        ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens, pos_inc=1)
+            n_launches = ext.chain_overlap_end() if overlap else 0
+        # greedy sampling + position increment behind the head: on the stream the head went to
+        import contextlib
+        on_b = overlap and ch["stream_b"] is not None and (n_launches - 1) % 2 == 1
+        with (torch.cuda.stream(ch["stream_b"]) if on_b else contextlib.nullcontext()):
+            ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens, pos_inc=1)
+
+    def _overlapped(self) -> bool:
+        return self.chain is not None and "flags" in self.chain and self.chain.get("stream_b") is not None
+
+    def _ordered(self, launch):
+        """One step of the overlapped chain = launches on two streams that are not joined inside the step.  At the step's
+        boundaries each stream is put behind the other: stream B behind everything stream A was given before the step (the
+        previous step's half included), stream A behind stream B's previous half; after the last step of run() stream A
+        is put behind stream B once more.  (Events between graph launches, not inside them.)"""
+        ch = self.chain
+        ch["ev_pre"].record(self.stream)
+        ch["stream_b"].wait_event(ch["ev_pre"])
+        self.stream.wait_event(ch["ev_b"])
+        launch()
+        ch["ev_b"].record(ch["stream_b"])
 
     def step_eager(self):
+        if self._overlapped():
+            self._ordered(self._launch_step)
+            if self._overlapped():
+                self.stream.wait_event(self.chain["ev_b"])
+            return
+        self._launch_step()
+
+    def _launch_step(self):
         if self.chain is not None:
             try:
                 return self.step_chain()
@@ -274,11 +303,24 @@ class GreedyGraphDecoder:
             self.step_eager()                               # warm-up: lazy one-time setup must not happen under capture
             self.cache_seqlens.fill_(scratch_pos)
             self.stream.synchronize()
-            ext.graph_begin_capture(self.stream.cuda_stream)
-            try:
-                self.step_eager()
-            finally:
-                self.graph = ext.graph_end_capture(self.stream.cuda_stream)
+            if self._overlapped():
+                # two graphs, one per stream, replayed side by side (the branches of ONE forked graph are run one after the
+                # other on this stack: tools/probes/fork_probe.hip)
+                sb = self.chain["stream_b"]
+                sb.synchronize()
+                ext.graph_begin_capture(self.stream.cuda_stream)
+                ext.graph_begin_capture(sb.cuda_stream)
+                try:
+                    self._launch_step()
+                finally:
+                    self.graph = ext.graph_end_capture(self.stream.cuda_stream)
+                    self.graph_b = ext.graph_end_capture(sb.cuda_stream)
+            else:
+                ext.graph_begin_capture(self.stream.cuda_stream)
+                try:
+                    self._launch_step()
+                finally:
+                    self.graph = ext.graph_end_capture(self.stream.cuda_stream)
             self.cache_seqlens.copy_(saved_state[0]); self.ids.copy_(saved_state[1])
             for t, s in zip(slot_tensors, saved_kv):
                 t[:, scratch_pos].copy_(s)
@@ -298,11 +340,17 @@ class GreedyGraphDecoder:
         self.pos += n_tokens
         with self._on_stream():
             sptr = self.stream.cuda_stream if self.stream is not None else None
+            two = use_graph and self.graph is not None and getattr(self, "graph_b", None) is not None and self._overlapped()
             for _ in range(n_tokens):
-                if use_graph and self.graph is not None:
+                if two:
+                    bptr = self.chain["stream_b"].cuda_stream
+                    self._ordered(lambda: (ext.graph_launch(self.graph, sptr), ext.graph_launch(self.graph_b, bptr)))
+                elif use_graph and self.graph is not None:
                     ext.graph_launch(self.graph, sptr)
                 else:
                     self.step_eager()
+            if two:
+                self.stream.wait_event(self.chain["ev_b"])
 
     def tokens(self, start: int, n: int) -> torch.Tensor:
         """tokens generated at positions start+1 .. start+n (history[b, pos] = token sampled after `pos` cached tokens)."""
@@ -312,3 +360,6 @@ class GreedyGraphDecoder:
         if self.graph is not None:
             self.model.ext.graph_free(self.graph)
             self.graph = None
+        if getattr(self, "graph_b", None) is not None:
+            self.model.ext.graph_free(self.graph_b)
+            self.graph_b = None

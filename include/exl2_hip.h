@@ -197,10 +197,11 @@ int exl2_gather_f16(const void* src, const void* perm, void* dst, int n, void* s
    one stream, q_attn.cu:153-345 / q_mlp.cu:153-236).  Between _begin and _end every chained launch of the calling thread
    (exl2_q_attn_forward_1_chain, exl2_attn_decode_fused, exl2_q_attn_forward_2_chain, exl2_q_mlp_forward_chain (two launches),
    exl2_gemm_half_q_half_chain) ignores its own `stream` argument: launch k goes to stream_a / stream_b alternately, waits for
-   launch k-1 through counter k-1 and signals counter k.  `flags`: n_flags * 32 u32 of device memory (zeroed here, on
-   stream_a); _begin forks stream_b behind stream_a, _end joins stream_a behind stream_b.  Capturable (both streams end up in
-   the capture of stream_a). */
-int exl2_chain_overlap_begin(void* flags, int n_flags, void* stream_a, void* stream_b);
+   launch k-1 through block k-1 of `flags` and publishes through block k.  `flags`: n_blocks * 320 u32 of device memory,
+   zero when first used (the kernels leave them zero again).  The two streams are NOT joined here: the caller orders them at
+   the boundaries of a step (events), and captures them as two graphs when it wants graphs -- the branches of one forked
+   HIP graph are not executed concurrently on this stack (tools/probes/fork_probe.hip).  EXPERIMENTAL. */
+int exl2_chain_overlap_begin(void* flags, int n_blocks, void* stream_a, void* stream_b);
 int exl2_chain_overlap_end(int* n_launches);
 
 /* ---- decode-loop utilities and graphs (replace cuda/graph.cu and the host-side embedding / argmax round trips) ------- */

@@ -261,18 +261,37 @@ DEV void store_agent_f32(float* p, float v) { *(volatile float*)p = v; }
 DEV void store_relaxed_agent(u32* p, u32 v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 DEV void store_agent_f16(f16* p, f16 v) { *p = v; }
 DEV u32 load_agent_u32(const u32* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
-// launches run to completion one after the other here: a consumer finds its producer's signals already there, and a
-// missing or short count is a bug in the host's bookkeeping -- reported, not waited for
-DEV void flag_wait_agent(const u32* flag, u32 target)
+// hand-off between overlapped launches (hw.h): launches run to completion one after the other here, so a consumer finds its
+// producer's "go" already published; a missing one is a bug in the host's bookkeeping -- reported, not waited for
+#define SYNC_BLOCK_WORDS 320
+#define SYNC_GO_COPIES 8
+DEV const u32* sync_go_word(const u32* block, int cls) { return block + 32 * (1 + (cls & (SYNC_GO_COPIES - 1))); }
+DEV void sync_wait_go(const u32* producer_block, int cls)
 {
-    if (load_agent_u32(flag) < target)
+    if (__atomic_load_n(sync_go_word(producer_block, cls), __ATOMIC_SEQ_CST) == 0)
     {
-        fprintf(stderr, "emu: overlapped launch would wait forever (flag %u < target %u)\n", load_agent_u32(flag), target);
+        fprintf(stderr, "emu: overlapped launch would wait forever (no go word)\n");
         abort();
     }
 }
-DEV void release_agent() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-DEV void flag_signal_agent(u32* flag) { if (lane_id() == 0) (void)__atomic_fetch_add(flag, 1u, __ATOMIC_SEQ_CST); }
+DEV void sync_arrive_publish(u32* own_block, u32 total, const u32* waited_block)
+{
+    if (lane_id() != 0) return;
+    const u32 old = __atomic_fetch_add(own_block, 1u, __ATOMIC_SEQ_CST);
+    if (old + 1 != total) return;
+    for (int c = 0; c < SYNC_GO_COPIES; c++) *(u32*)sync_go_word(own_block, c) = 1u;
+    *own_block = 0u;
+    if (waited_block) for (int c = 0; c < SYNC_GO_COPIES; c++) *(u32*)sync_go_word(waited_block, c) = 0u;
+}
+DEV void sync_gate_wait(u32* arrived, u32 target)
+{
+    if (lane_id() != 0) return;                  // (lanes run one after the other here: only the lane that zeroes may look)
+    if (__atomic_load_n(arrived, __ATOMIC_SEQ_CST) < target) { fprintf(stderr, "emu: gate would wait forever (%u arrivals of %u)\n", __atomic_load_n(arrived, __ATOMIC_SEQ_CST), target); abort(); }
+    if (lane_id() == 0) *arrived = 0u;
+}
+DEV f16 load_agent_f16(const f16* p) { return *p; }
+DEV f16x8 load_agent_f16x8(const f16* p) { return *(const f16x8*)p; }
+DEV void dma_to_lds16_agent(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
 
 #define DYN_SMEM(name) unsigned char* name = emu_ctx_->dyn_smem
 #define SHARED static

@@ -98,13 +98,9 @@ def test_chain_tokens_equal_unchained_route(be, monkeypatch):
 @pytest.mark.parametrize("recipe,batch", [("4.0bpw", 1), ("3.5bpw", 3), ("gptq-4bit-128g", 2)])
 def test_overlapped_chain_equals_serial_chain(be, monkeypatch, recipe, batch):
     """EXL2_CHAIN_OVERLAP=1 (csrc/chain_sync.h, EXPERIMENTAL, off by default): the same launches on two alternating streams,
-    dependencies through counters.  Same kernels, same arithmetic, same order of every sum: logits and tokens are
-    bit-identical to the one-stream chain.  Checked on the emulator only (bookkeeping: stream alternation, targets, gate,
-    every launch signalled, no wait gave up).  On the MI355X the mode is NOT validated: replayed from a captured graph
-    the two branches did not make progress the way the hand-off assumes -- waits ran into their spin limit and tokens came
-    out different (round 2, DESIGN.md section 3a''); the test is skipped there instead of pretending."""
-    if not be.is_emu:
-        pytest.skip("overlapped chain is experimental and not validated on the GPU (DESIGN.md 3a'')")
+    dependencies through words in memory.  Same kernels, same arithmetic, same order of every sum: logits and tokens are
+    bit-identical to the one-stream chain -- on the GPU through two captured graphs (one per stream) replayed side by side
+    for several steps; the hand-off words are back to zero after every step and no wait gave up."""
     cfg = tiny_cfg(num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2, intermediate_size=384)
     outs = []
     for overlap in ("0", "1"):
@@ -123,15 +119,13 @@ def test_overlapped_chain_equals_serial_chain(be, monkeypatch, recipe, batch):
             logits.append(be.n(dec.logits).copy())
         outs.append((be.n(dec.tokens(0, 6)).copy(), np.stack(logits)))
         if overlap == "1":
-            # every launch of the step went through the chain: 5 per layer + the head
+            # the hand-off words are back to zero after every step (their consumers zero them), no wait gave up
             with dec._on_stream():
                 dec.step_eager()
             if not be.is_emu:
                 torch.cuda.synchronize()
             flags = be.n(dec.chain["flags"])
-            assert flags[:5 * 3 + 1, 0].min() > 0 and flags[5 * 3 + 1:-1, 0].max() == 0
-            assert flags[-1, 0] > 0                                      # the gate's counter: workgroups of the first launch
-            assert flags[:, 1].sum() == 0                                # no wait gave up
+            assert np.all(flags == 0), np.nonzero(flags)
         dec.free(); model.unload()
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
