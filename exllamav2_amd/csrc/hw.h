@@ -208,7 +208,7 @@ DEV u32 load_agent_u32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELA
 // that gave up (debug).  The spin is bounded: a missing producer must show up as wrong numbers in a test, never as a hung GPU.
 #define SYNC_BLOCK_WORDS 320
 #define SYNC_GO_COPIES 8
-#define FLAG_SPIN_LIMIT (1 << 21)              // ~ 1 s (a poll is ~0.5 us): longer than any host hiccup between the two graph launches
+#define FLAG_SPIN_LIMIT (1 << 17)              // ~ 50 ms (a poll is ~0.4 us)
 DEV const u32* sync_go_word(const u32* block, int cls) { return block + 32 * (1 + (cls & (SYNC_GO_COPIES - 1))); }
 // consumer: the calling WAVE polls (one wave per workgroup; the others wait at the workgroup barrier behind it)
 DEV void sync_wait_go(const u32* producer_block, int cls)

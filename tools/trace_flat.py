@@ -49,13 +49,15 @@ def main():
     assert dec.chain is not None
     dec.reset(torch.tensor([1] * batch), 0)
     dec.run(3, use_graph=False); torch.cuda.synchronize()
-    buf = torch.zeros((256 * 16 * 16,), dtype=torch.int64, device="cuda")
+    # (the trace hook stamps two consecutive launches: the one asked for + its successor, second buffer behind the first)
+    buf2 = torch.zeros((2 * 256 * 16 * 16,), dtype=torch.int64, device="cuda")
+    buf = buf2[:256 * 16 * 16]
     # flat launches of one step: layer0 {qkv, o, gate|up, down}, layer1 {...}, head
     for which, name in ((4, "q|k|v (A_NORM_PRE)"), (5, "o (A_DIRECT, residual, chain-out)"), (6, "gate|up (A_NORM_PRE, pair)"),
                         (7, "down (A_DIRECT, residual, chain-out)"), (8, "head (A_NORM_PRE)")):
         for rep in range(2):
-            buf.zero_(); torch.cuda.synchronize()
-            set_trace(buf.data_ptr(), which)
+            buf2.zero_(); torch.cuda.synchronize()
+            set_trace(buf2.data_ptr(), which)
             dec.run(1, use_graph=False); torch.cuda.synchronize()
         report(buf, name)
     set_trace(None, 0)
