@@ -123,9 +123,8 @@ class ExLlamaV2Attention:
             if not fused:
                 ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, past if not paged else 0,
                                    sl if paged else none_tensor, bt if paged else none_tensor, cfg.rope_style)
-                if big and not paged and q_len > 16:
-                    self._attn_library(q, kc, vc, attn_out, past, q_len)
-                else:
+                # many query rows: MFMA flash attention (csrc/attn_prefill.hip); decode-shaped: the split-KV kernel
+                if not (q_len > 16 and ext.flash_prefill(q, kc, vc, attn_out, sl, bt, len_const=past, len_offset=q_len)):
                     ext.paged_attn(q, kc, vc, attn_out, sl, bt, len_const=past, len_offset=q_len, scratch=m.attn_scratch)
             if paged:
                 cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
@@ -155,29 +154,3 @@ class ExLlamaV2Attention:
             ext.q_attn_forward_2(self.q_handle, hidden_states, attn_out, b, q_len)
         return hidden_states
 
-    def _attn_library(self, q, kc, vc, out, past: int, q_len: int):
-        """Long-query attention over a contiguous cache the way the reference does it without flash-attn (_attn_torch,
-        attn.py:869-937): torch SDPA / matmul with a lower-right causal mask, GQA by head repetition.  The decode-shaped
-        HIP kernel (attn.hip) streams the keys once per 8 query rows and is not the right tool for q_len in the
-        thousands; an MFMA flash-prefill kernel is listed in DESIGN.md as next."""
-        cfg = self.model.config
-        total = past + q_len
-        g = cfg.num_attention_heads // cfg.num_key_value_heads
-        qh = q.transpose(1, 2)                                                   # [b, H, s, hd]
-        kh = kc[:, :total].transpose(1, 2)
-        vh = vc[:, :total].transpose(1, 2)
-        if g > 1:
-            kh = kh.repeat_interleave(g, dim=1)
-            vh = vh.repeat_interleave(g, dim=1)
-        if q.device.type == "cuda":
-            if past == 0:
-                o = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, is_causal=True)
-            else:
-                mask = torch.ones((q_len, total), dtype=torch.bool, device=q.device).tril(diagonal=past)
-                o = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, attn_mask=mask)
-        else:
-            s = torch.matmul(qh.float(), kh.float().transpose(-1, -2)) * (cfg.head_dim ** -0.5)
-            mask = torch.ones((q_len, total), dtype=torch.bool).tril(diagonal=past)
-            s = s.masked_fill(~mask, float("-inf"))
-            o = torch.matmul(torch.softmax(s, dim=-1), vh.float()).half()
-        out.copy_(o.transpose(1, 2))

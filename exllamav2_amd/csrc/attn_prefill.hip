@@ -1,0 +1,248 @@
+// attn_prefill.hip -- MFMA flash attention for prefill-shaped steps (many query rows per sequence) over the FP16 KV cache.
+//
+// Replaces, on the product path, what the reference does for long queries without flash-attn: `_attn_torch`
+// (attn.py:869-937: torch SDPA / matmul-softmax-matmul with a lower-right causal mask, GQA by head repetition), and what it
+// gets from flash-attn with it (`flash_attn_func` / `flash_attn_with_kvcache` with q_len > 1, attn.py:602-613, 960-977).
+// Same contract as exl2_paged_attn (attn.hip): q [b, s, H, hd] already rotated, K/V already appended to the cache; the cache
+// is [pages, page_size, KVH, hd] behind a block table or [b, T, KVH, hd] without one; total keys of sequence b =
+// len_const + cache_seqlens[b] + len_offset, query row j sits at position total - s + j (lower-right aligned causal mask).
+//
+// Shape of the kernel (gfx950, 64-wide waves, v_mfma_f32_16x16x32_f16):
+//   * one workgroup = 64 query rows of one (sequence, head): 4 waves x 16 rows; grid (ceil(s / 64), H, b) -- a 2048-token
+//     prefill of a 32-head model is 1024 workgroups per sequence, >> 256 CUs;
+//   * keys in tiles of 32: K and V tiles row-major in LDS (16-byte coalesced loads, 16-byte LDS writes); the next tile's
+//     global loads are in flight while the current one is computed;
+//   * scores are computed transposed, S^T = K Q^T (A = K rows from LDS, B = Q rows held in registers for the whole kernel):
+//     the accumulator layout of S^T -- lane (q = lane % 16, g = lane / 16) holds keys 4g .. 4g+3 of a 16-key block -- IS the
+//     B-operand layout of the second product O^T = V^T P^T once the 32 keys of a tile are taken in the order
+//     {4g .. 4g+3 of block 0, 4g .. 4g+3 of block 1}: the probabilities never leave their registers, and V^T's A operand
+//     is two transposing LDS reads (ds_read_b64_tr_b16: lane (feature i, g) gets keys 4g .. 4g+3 of feature column i) per 16
+//     output features.  (The first version wrote V transposed with 2-byte LDS stores: 32-way bank conflicts, 100 TFLOP/s.)
+//   * online softmax per query = per accumulator column: 8 local values + two cross-lane steps (lanes l, l^16, l^32, l^48),
+//     fp32 statistics, exp in fp32, P rounded to fp16 for the MFMA (as flash-attn does);
+//   * O^T accumulators: hd / 16 blocks of 4 fp32 per lane; final 1 / l, 8-byte stores.
+// Bound: MFMA (2 * s * T * hd FLOP per head) -- 16 MFMAs per 32 keys per wave against ~60 VALU ops of softmax.
+#include "hw.h"
+#include "errors.h"
+#include <string.h>
+
+#define FP_BQ 64
+#ifndef FP_BK
+#define FP_BK 64
+#endif
+#define FP_WAVES 4
+#define FP_NEG_BIG (-1.0e30f)
+
+struct FlashArgs
+{
+    const f16* q; const f16* k_cache; const f16* v_cache; f16* out;
+    const int* cache_seqlens; const int* block_table;
+    int b, s, H, KVH;
+    int page_size, page_shift, pages_per_seq;
+    int len_const, len_offset;
+    float scale;
+    int causal;
+};
+
+
+template <int HDIM>
+KERNEL void __launch_bounds__(FP_WAVES * 64) flash_prefill_kernel(const FlashArgs a)
+{
+    DYN_SMEM(smem);
+    constexpr int KSTR = HDIM + 8;                 // halfs per K row (272-byte rows at hd 128: conflict-free 16-byte reads)
+    constexpr int VSTR = HDIM + 16;                // halfs per V row: rows 8 banks apart (mod 64) -> conflict-free tr reads
+    constexpr int KK = HDIM / 32;                  // MFMAs (k = 32 features) per 16-key score block
+    constexpr int DB = HDIM / 16;                  // 16-feature output blocks
+    constexpr int CHUNKS = FP_BK * HDIM / 8;       // 16-byte pieces of a K (or V) tile
+    constexpr int CPT = (CHUNKS + FP_WAVES * 64 - 1) / (FP_WAVES * 64);
+    f16* k_lds = (f16*)smem;
+    f16* v_lds = k_lds + FP_BK * KSTR;
+
+    const int t = tid(), lane = lane_id(), wv = wave_id();
+    const int qi = lane & 15, g = lane >> 4;
+    const int q0 = bid_x() * FP_BQ, h = bid_y(), b = bid_z();
+    const int kh = h / (a.H / a.KVH);
+
+    int total = a.len_const + a.len_offset;
+    if (a.cache_seqlens) { const int p = a.cache_seqlens[b]; total += p > 0 ? p : 0; }
+    const int qpos0 = total - a.s;                                            // position of query row 0
+    const int kend = a.causal ? min(total, qpos0 + q0 + FP_BQ) : total;       // keys this workgroup can see
+    const int n_tiles = (kend + FP_BK - 1) / FP_BK;
+    const size_t row_stride = (size_t)a.KVH * HDIM;
+
+    auto slot_of = [&](int kp) -> size_t {
+        if (a.block_table)
+            return (size_t)a.block_table[(size_t)b * a.pages_per_seq + (kp >> a.page_shift)] * a.page_size + (kp & (a.page_size - 1));
+        return (size_t)b * a.page_size + kp;
+    };
+
+    // this wave's 16 query rows as the B operand of S^T = K Q^T: lane (qi, g) holds Q[row qi][32 kk + 8 g .. + 8]
+    const int qrow = q0 + wv * 16 + qi;
+    const int qrow_c = qrow < a.s ? qrow : a.s - 1;
+    f16x8 qb[KK];
+    {
+        const f16* qp = a.q + (((size_t)b * a.s + qrow_c) * a.H + h) * HDIM + 8 * g;
+        #pragma unroll
+        for (int kk = 0; kk < KK; kk++) qb[kk] = *(const f16x8*)(qp + 32 * kk);
+    }
+    const int qpos = qpos0 + qrow;                                            // last key this query may see (causal)
+    const int wave_kmax = a.causal ? qpos0 + q0 + wv * 16 + 15 : total - 1;   // nothing beyond it matters to this wave
+
+    f32x4 ot[DB];
+    #pragma unroll
+    for (int d = 0; d < DB; d++) ot[d] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float m_run = FP_NEG_BIG, l_run = 0.0f;
+
+    // tile loads: thread -> 16-byte pieces c = t + 256 i; piece c = (key row c / (HDIM / 8), feature octet c % (HDIM / 8))
+    f16x8 kreg[CPT], vreg[CPT];
+    auto fetch = [&](int tile) {
+        #pragma unroll
+        for (int i = 0; i < CPT; i++)
+        {
+            const int c = t + i * FP_WAVES * 64;
+            if (c < CHUNKS)
+            {
+                const int row = c / (HDIM / 8), oct = c % (HDIM / 8);
+                int kp = tile * FP_BK + row;
+                if (kp >= total) kp = total - 1;                              // keep the address valid; masked below
+                const size_t off = slot_of(kp) * row_stride + (size_t)kh * HDIM + oct * 8;
+                kreg[i] = *(const f16x8*)(a.k_cache + off);
+                vreg[i] = *(const f16x8*)(a.v_cache + off);
+            }
+        }
+    };
+    auto stage = [&]() {
+        #pragma unroll
+        for (int i = 0; i < CPT; i++)
+        {
+            const int c = t + i * FP_WAVES * 64;
+            if (c < CHUNKS)
+            {
+                const int row = c / (HDIM / 8), oct = c % (HDIM / 8);
+                *(f16x8*)(k_lds + row * KSTR + oct * 8) = kreg[i];
+                *(f16x8*)(v_lds + row * VSTR + oct * 8) = vreg[i];
+            }
+        }
+    };
+
+    if (n_tiles > 0) fetch(0);
+    for (int tile = 0; tile < n_tiles; tile++)
+    {
+        block_sync();                                                         // everybody is done with the previous tile
+        stage();
+        block_sync();
+        if (tile + 1 < n_tiles) fetch(tile + 1);                              // in flight during the MFMAs below
+        const int k0 = tile * FP_BK;
+        if (k0 > wave_kmax) continue;                                         // fully masked for this wave's rows
+
+        // S^T: FP_BK / 16 blocks of 16 keys
+        constexpr int NBLK = FP_BK / 16;
+        f32x4 st[NBLK];
+        #pragma unroll
+        for (int blk = 0; blk < NBLK; blk++)
+        {
+            st[blk] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            const f16* kp = k_lds + (16 * blk + qi) * KSTR + 8 * g;
+            #pragma unroll
+            for (int kk = 0; kk < KK; kk++) st[blk] = mfma_16x16x32_f16(*(const f16x8*)(kp + 32 * kk), qb[kk], st[blk]);
+        }
+        // mask + online softmax for column qi (lane holds keys k0 + 16 blk + 4 g + r)
+        float sc[4 * NBLK];
+        float m_loc = FP_NEG_BIG;
+        #pragma unroll
+        for (int blk = 0; blk < NBLK; blk++)
+            #pragma unroll
+            for (int r = 0; r < 4; r++)
+            {
+                const int kpos = k0 + 16 * blk + 4 * g + r;
+                const bool valid = kpos < total && (!a.causal || kpos <= qpos);
+                const float v = valid ? st[blk][r] * a.scale : FP_NEG_BIG;
+                sc[blk * 4 + r] = v;
+                m_loc = fmaxf(m_loc, v);
+            }
+        m_loc = fmaxf(m_loc, shfl_xor_f32(m_loc, 16));
+        m_loc = fmaxf(m_loc, shfl_xor_f32(m_loc, 32));
+        const float m_new = fmaxf(m_run, m_loc);
+        const float alpha = fast_exp(m_run - m_new);
+        float p_sum = 0.0f;
+        f16x8 pb[NBLK / 2];                          // B operands: 32 keys each = {block 2n keys 4g..4g+3, block 2n+1 keys 4g..4g+3}
+        #pragma unroll
+        for (int e = 0; e < 4 * NBLK; e++)
+        {
+            const float p = sc[e] > 0.5f * FP_NEG_BIG ? fast_exp(sc[e] - m_new) : 0.0f;
+            p_sum += p;
+            pb[e / 8][e % 8] = (f16)p;
+        }
+        p_sum += shfl_xor_f32(p_sum, 16);
+        p_sum += shfl_xor_f32(p_sum, 32);
+        l_run = l_run * alpha + p_sum;
+        m_run = m_new;
+        // O^T = alpha O^T + V^T P^T: A = V^T rows (feature 16 db + qi), keys {4g..4g+3, 16+4g..16+4g+3} -- transposing reads:
+        // this lane points at key row 4 g + qi / 4, features 16 db + 4 (qi % 4) .. + 3 and receives column qi of the block
+        const f16* vbase = v_lds + (4 * g + (qi >> 2)) * VSTR + 4 * (qi & 3);
+        #pragma unroll
+        for (int d = 0; d < DB; d++)
+        {
+            f32x4 acc = ot[d];
+            acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+            #pragma unroll
+            for (int n = 0; n < NBLK / 2; n++)
+            {
+                const f16x4 lo = lds_read_tr16_b64(vbase + (32 * n) * VSTR + 16 * d), hi = lds_read_tr16_b64(vbase + (32 * n + 16) * VSTR + 16 * d);
+                const f16x8 va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc = mfma_16x16x32_f16(va, pb[n], acc);
+            }
+            ot[d] = acc;
+        }
+    }
+
+    // O^T[feature 16 d + 4 g + r][query qi] / l -> out[query][feature]: 4 consecutive features per lane
+    if (qrow < a.s)
+    {
+        const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+        f16* op = a.out + (((size_t)b * a.s + qrow) * a.H + h) * HDIM + 4 * g;
+        #pragma unroll
+        for (int d = 0; d < DB; d++)
+        {
+            const f16x4 y = {(f16)(ot[d][0] * inv), (f16)(ot[d][1] * inv), (f16)(ot[d][2] * inv), (f16)(ot[d][3] * inv)};
+            *(f16x4*)(op + 16 * d) = y;
+        }
+    }
+}
+
+static int fp_ilog2_exact(int x) { int s = 0; while ((1 << s) < x) s++; return (1 << s) == x ? s : -1; }
+
+extern "C" {
+
+// Prefill-shaped attention over the FP16 cache (see the header of this file).  Returns 1 (nothing launched) for a head_dim
+// outside {64, 128, 256}: the caller then uses exl2_paged_attn.
+int exl2_flash_prefill(const void* q, const void* k_cache, const void* v_cache, void* out, const int* cache_seqlens,
+                       const int* block_table, int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                       int page_size, int pages_per_seq, int len_const, int len_offset, float softmax_scale, int causal,
+                       void* stream)
+{
+    EXL2_REQUIRE(q && k_cache && v_cache && out, "flash_prefill: null argument");
+    EXL2_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "flash_prefill: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
+    if (batch <= 0 || q_len <= 0) return EXL2_OK;
+    if (!(head_dim == 64 || head_dim == 128 || head_dim == 256)) return 1;
+    FlashArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = (const f16*)q; a.k_cache = (const f16*)k_cache; a.v_cache = (const f16*)v_cache; a.out = (f16*)out;
+    a.cache_seqlens = cache_seqlens; a.block_table = block_table;
+    a.b = batch; a.s = q_len; a.H = num_heads; a.KVH = num_kv_heads;
+    a.page_size = page_size; a.pages_per_seq = pages_per_seq; a.page_shift = fp_ilog2_exact(page_size);
+    EXL2_REQUIRE(!block_table || a.page_shift >= 0, "flash_prefill: page_size %d must be a power of two", page_size);
+    a.len_const = len_const; a.len_offset = len_offset; a.scale = softmax_scale; a.causal = causal;
+    dim3 grid((unsigned)((q_len + FP_BQ - 1) / FP_BQ), (unsigned)num_heads, (unsigned)batch);
+    const size_t lds = ((size_t)FP_BK * (head_dim + 8) + (size_t)FP_BK * (head_dim + 16)) * sizeof(f16);
+    switch (head_dim)
+    {
+        case 64:  LAUNCH(flash_prefill_kernel<64>, grid, dim3(FP_WAVES * 64), lds, stream, a); break;
+        case 128: LAUNCH(flash_prefill_kernel<128>, grid, dim3(FP_WAVES * 64), lds, stream, a); break;
+        default:  LAUNCH(flash_prefill_kernel<256>, grid, dim3(FP_WAVES * 64), lds, stream, a); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
+}
+
+}  // extern "C"

@@ -137,6 +137,18 @@ DEV f32x4 mfma_16x16x32_f16(f16x8 a, f16x8 b, f32x4 c) {
 // fp32 += dot(half2, half2): v_dot2_f32_f16
 DEV float dot2_f32_f16(f16x2 a, f16x2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
 
+// ds_read_b64_tr_b16 (gfx950): LDS read with a 4 x 16 transpose inside every 16-lane group.  Lane 16 g + i supplies the
+// (8-byte aligned) address of 4 consecutive f16; taking the group's 16 x 4 elements as a row-major [4][16] block (lane i ->
+// row i / 4, columns 4 (i % 4) .. + 3; the row stride is whatever the addresses say), lane i receives COLUMN i: rows 0 .. 3.
+// (Checked on the MI355X: tools/probes/tr_probe.hip.)  This is what turns a row-major [key][feature] image of V into the
+// A operand of O^T = V^T P^T without a transposing write.
+DEV f16x4 lds_read_tr16_b64(const f16* p)
+{
+    typedef __fp16 hx4 __attribute__((__vector_size__(8)));
+    const hx4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hx4*)p);
+    return __builtin_bit_cast(f16x4, v);
+}
+
 // ---- memory --------------------------------------------------------------------------------------------------------
 // streamed-once data (packed weights, KV pages): non-temporal so it does not displace the activation vector / tables
 // ---- asynchronous global -> LDS copies (no VGPR round trip; cdna_hip_programming.md "LDS DMA") --------------------------

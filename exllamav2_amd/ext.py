@@ -298,6 +298,22 @@ class ExtC:
             b, s, nh, kvh, hd, page_size, pps, int(len_const), int(len_offset), float(scale), int(causal), int(nsplit),
             self._ptr(scratch), sb, self._stream(q)))
 
+    def flash_prefill(self, q, k_cache, v_cache, out, cache_seqlens, block_table, len_const: int = 0, len_offset: int = 0,
+                      softmax_scale: float | None = None, causal: bool = True) -> bool:
+        """csrc/attn_prefill.hip: paged_attn's contract for many query rows (MFMA flash attention).  False when the head
+        size is outside {64, 128, 256} (nothing launched)."""
+        b, s, nh, hd = q.shape
+        kvh = k_cache.shape[2]
+        page_size = k_cache.shape[1]
+        pps = 0 if _is_none(block_table) else block_table.shape[1]
+        scale = hd ** -0.5 if softmax_scale is None else softmax_scale
+        rc = self.lib.check(self.lib.exl2_flash_prefill(
+            self._ptr(q, torch.float16, "q"), self._ptr(k_cache, torch.float16, "k_cache"),
+            self._ptr(v_cache, torch.float16, "v_cache"), self._ptr(out, torch.float16, "out"),
+            self._ptr(cache_seqlens, torch.int32, "cache_seqlens"), self._ptr(block_table, torch.int32, "block_table"),
+            b, s, nh, kvh, hd, page_size, pps, int(len_const), int(len_offset), float(scale), int(causal), self._stream(q)))
+        return rc == 0
+
     def paged_attn_q4(self, q, k_codes, k_scales, v_codes, v_scales, out, cache_seqlens, block_table, len_const: int = 0,
                       len_offset: int = 0, softmax_scale: float | None = None, causal: bool = True, nsplit: int = 0,
                       scratch=None, k_new=None, v_new=None) -> bool:
@@ -360,9 +376,12 @@ class ExtC:
         s = q.shape[1]
         if k is not None:
             self.rope_kv_append(q, k, v, k_cache, v_cache, none_tensor, none_tensor, 0, cache_seqlens, block_table, 0)
-            self.paged_attn(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, s, softmax_scale, causal, 0, scratch)
+            # many query rows (prefill chunks): MFMA flash attention; decode-shaped: the split-KV kernel
+            if not (s > 16 and self.flash_prefill(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, s, softmax_scale, causal)):
+                self.paged_attn(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, s, softmax_scale, causal, 0, scratch)
         else:
-            self.paged_attn(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, 0, softmax_scale, causal, 0, scratch)
+            if not (s > 16 and self.flash_prefill(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, 0, softmax_scale, causal)):
+                self.paged_attn(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, 0, softmax_scale, causal, 0, scratch)
         return out
 
     # ---- fused modules (ext_qattn.cpp, ext_qmlp.cpp) -------------------------------------------------------------------

@@ -79,9 +79,9 @@ def test_chunked_prefill_equals_oracle(be):
 
 @pytest.mark.parametrize("native", [False, True])
 def test_prefill_sized_forward_equals_oracle(be, native):
-    """rows > LIB_GEMM_MIN_ROWS: the unfused module route (reconstruct + library GEMM, library attention) and, with
-    native_prefill, the HIP route (qgemm_prefill.hip + attn.hip) must both match the oracle; then one decode step on the
-    cache they filled."""
+    """rows > LIB_GEMM_MIN_ROWS: the unfused module route (reconstruct + library GEMM) and, with native_prefill, the HIP route
+    (qgemm_prefill.hip) must both match the oracle -- attention in both is the MFMA flash-prefill kernel (attn_prefill.hip);
+    then one decode step on the cache they filled."""
     cfg = tiny_cfg(max_input_len=128, max_seq_len=256, num_hidden_layers=1)
     model, oracle = build(be, cfg, seed=3)
     model.native_prefill = native
@@ -91,6 +91,10 @@ def test_prefill_sized_forward_equals_oracle(be, native):
     logits = model.forward(torch.from_numpy(ids), cache)
     want = oracle.forward(ids)[:, -1:]
     check_logits(be.n(logits), want)
+    # a second long chunk on top of the first (flash-prefill attention with past > 0: csrc/attn_prefill.hip)
+    ids2 = np.random.default_rng(4).integers(0, cfg.vocab_size, size=(1, 40))
+    logits = model.forward(torch.from_numpy(ids2), cache, last_id_only=False)
+    check_logits(be.n(logits), oracle.forward(ids2))
     nxt = np.array([[5]])
     logits = model.forward(torch.from_numpy(nxt), cache)
     check_logits(be.n(logits), oracle.forward(nxt)[:, -1:])

@@ -167,6 +167,56 @@ def test_attention_contiguous(be, hd, nh, kvh, s):
         assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want)), nsplit
 
 
+@pytest.mark.parametrize("hd,nh,kvh,s,past", [(128, 4, 2, 70, 0), (128, 2, 2, 64, 37), (64, 4, 1, 33, 5), (256, 2, 1, 20, 0),
+                                              (128, 4, 4, 130, 3)])
+def test_flash_prefill_contiguous(be, hd, nh, kvh, s, past):
+    """csrc/attn_prefill.hip against attn.py:905-933 semantics (fp64 oracle): many query rows, lower-right causal mask, GQA,
+    query tiles of 64 with a ragged last tile, key tiles of 32 with a ragged last tile, rows whose first tiles are fully
+    masked, head sizes 64 / 128 / 256.  P is rounded to fp16 before the second product (as flash-attn does): same tolerance as
+    the decode kernel."""
+    rng = np.random.default_rng(hd + s)
+    b, T = 2, 200
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    k = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    v = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    total = past + s
+    want = OM.attention(q, k[:, :total], v[:, :total])
+    out = torch.full((b, s, nh, hd), 77.0, dtype=torch.float16, device=be.device)
+    assert be.ext.flash_prefill(be.t(q), be.t(k), be.t(v), out, None, None, len_const=past, len_offset=s)
+    got = be.n(out)
+    assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want)), \
+        float(np.abs(got.astype(np.float32) - want.astype(np.float32)).max())
+    # not causal: every query sees every key
+    out2 = torch.zeros_like(out)
+    assert be.ext.flash_prefill(be.t(q), be.t(k), be.t(v), out2, None, None, len_const=past, len_offset=s, causal=False)
+    qq = q.astype(np.float64); kk = k[:, :total].astype(np.float64); vv = v[:, :total].astype(np.float64)
+    g = nh // kvh
+    want2 = np.zeros((b, s, nh, hd))
+    for hh in range(nh):
+        sc = np.einsum("bsd,btd->bst", qq[:, :, hh], kk[:, :, hh // g]) * hd ** -0.5
+        p = np.exp(sc - sc.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+        want2[:, :, hh] = np.einsum("bst,btd->bsd", p, vv[:, :, hh // g])
+    assert np.all(np.abs(be.n(out2).astype(np.float64) - want2) <= _attn_tol(want2.astype(np.float32)))
+
+
+def test_flash_prefill_paged(be):
+    """the same through a block table with per-sequence lengths on the device (the dynamic generator's prefill chunks,
+    dynamic.py:1139-1294): keys already appended, query rows are the last s positions of each sequence"""
+    rng = np.random.default_rng(8)
+    pages, ps, kvh, hd, nh = 6, 256, 2, 128, 4
+    b, s = 2, 40
+    seqlens = np.array([250, 300], dtype=np.int32)                  # cached tokens BEFORE this chunk
+    table = np.array([[2, 0, 4], [1, 3, 5]], dtype=np.int32)
+    kc = rng.standard_normal((pages, ps, kvh, hd)).astype(F16)
+    vc = rng.standard_normal((pages, ps, kvh, hd)).astype(F16)
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    out = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+    assert be.ext.flash_prefill(be.t(q), be.t(kc), be.t(vc), out, be.t(seqlens), be.t(table), len_const=0, len_offset=s)
+    want = OM.paged_attention(q, None, None, kc, vc, seqlens + s, table)
+    got = be.n(out)
+    assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want))
+
+
 def test_attention_paged_with_append(be):
     """flash_attn_with_kvcache contract (attn.py:602-613): append new k/v at cache_seqlens through the block table,
     attend bottom-right causal."""

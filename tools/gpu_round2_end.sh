@@ -34,6 +34,7 @@ timeout -k 10 300 python bench.py --model mixtral-8x7b --recipe 3.5bpw --steps 3
 timeout -k 10 300 python bench.py --model mixtral-8x7b --recipe 3.5bpw --batch 16 --steps 32 --warmup 4 --no-cpu-baseline --no-prefill 2>/dev/null | tail -1 > $R/r02_bench_mixtral_b16.json; cut -c1-200 $R/r02_bench_mixtral_b16.json
 timeout -k 10 200 python tools/moe_bench.py 2>/dev/null > $R/r02_moe_bench.jsonl; cut -c1-130 $R/r02_moe_bench.jsonl
 if [ -f exllamav2_amd/libexl2_hip_trace.so ]; then timeout -k 10 200 python tools/trace_flat.py 2>/dev/null > $R/r02_trace_flat.txt; grep "waves\|span" $R/r02_trace_flat.txt; timeout -k 10 200 python tools/trace_overlap.py > $R/r02_trace_overlap.txt 2>/dev/null; grep "producer last end" $R/r02_trace_overlap.txt; fi
+timeout -k 10 120 python tools/attn_prefill_bench.py 2>/dev/null > $R/r02_attn_prefill_bench.jsonl; cut -c1-160 $R/r02_attn_prefill_bench.jsonl
 echo "== probes"; timeout -k 5 60 tools/probes/fork_probe 800 > $R/r02_fork_probe.txt 2>&1; tail -3 $R/r02_fork_probe.txt
 (for v in off on; do echo "== kernarg preload $v"; timeout -k 5 60 tools/probes/preload_${v}_probe; done) > $R/r02_preload_probe.txt 2>&1
 echo "== overlapped chain vs serial chain (same box)"
