@@ -287,29 +287,34 @@ def cpu_baseline(cfg, recipe: str, seed: int = 0):
 
 def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq: int = 2048):
     """BASELINE configs[2] beside the headline: test_inference.py -ps procedure (:533-579), forward(ids[8, 2048],
-    preprocess_only=True) on a fresh synthetic model; reported for the default host policy (reconstruct + library GEMM
-    above 64 rows) and, on 4 layers, for the all-native kernels."""
+    preprocess_only=True) on a fresh synthetic model, all layers, the product route (row pre-pass + dequantize-into-MFMA
+    GEMMs + flash-prefill attention: no library GEMM)."""
     import torch
     from exllamav2_amd import ExLlamaV2, ExLlamaV2Cache
     from exllamav2_amd.config import ExLlamaV2Config
     from exllamav2_amd.synth import synth_checkpoint
     out = {"workload": f"{model_name} EXL2 {recipe}, {batch} x {seq} tokens, forward(preprocess_only=True)", "unit": "tokens/s"}
-    for tag, layers, native in (("policy_route", None, False), ("native_kernels_4_layers", 4, True)):
-        cfg = ExLlamaV2Config.llama2_7b(max_seq_len=seq, max_input_len=2048, max_batch_size=batch)
-        if layers: cfg.num_hidden_layers = layers
-        model = ExLlamaV2(cfg, device=device).load(synth_checkpoint(cfg, device, recipe=recipe, seed=1))
-        model.native_prefill = native
-        cache = ExLlamaV2Cache(model, batch_size=batch, max_seq_len=seq)
-        ids = torch.randint(0, cfg.vocab_size - 1, (batch, seq), generator=torch.Generator().manual_seed(0)).to(device)
-        model.forward(ids, cache, preprocess_only=True); torch.cuda.synchronize()
+    cfg = ExLlamaV2Config.llama2_7b(max_seq_len=seq, max_input_len=2048, max_batch_size=batch)
+    model = ExLlamaV2(cfg, device=device).load(synth_checkpoint(cfg, device, recipe=recipe, seed=1))
+    cache = ExLlamaV2Cache(model, batch_size=batch, max_seq_len=seq)
+    ids = torch.randint(0, cfg.vocab_size - 1, (batch, seq), generator=torch.Generator().manual_seed(0)).to(device)
+    model.forward(ids, cache, preprocess_only=True); torch.cuda.synchronize()
+    best = None
+    for _ in range(2):
         t0 = time.perf_counter()
         cache.current_seq_len = 0
         model.forward(ids, cache, preprocess_only=True)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        out[tag] = {"value": round(batch * seq / dt, 1), "ms": round(dt * 1e3, 2), "layers": cfg.num_hidden_layers}
-        model.unload(); del model, cache
-        torch.cuda.empty_cache()
+        best = dt if best is None or dt < best else best
+    flops = 0.0
+    for attn, mlp in model.layers:
+        for lin in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj):
+            flops += 2.0 * batch * seq * lin.in_features * lin.out_features
+    out["native"] = {"value": round(batch * seq / best, 1), "ms": round(best * 1e3, 2), "layers": cfg.num_hidden_layers,
+                     "linear_TFLOPs": round(flops / best / 1e12, 1)}
+    model.unload(); del model, cache
+    torch.cuda.empty_cache()
     return out
 
 

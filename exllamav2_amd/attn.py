@@ -50,13 +50,11 @@ class ExLlamaV2Attention:
         Paged mode (attn.py:466-638): `cache_seqlens` int32 [b] + `block_table` int32 [b, pages] on the device,
         cache viewed [pages, 256, kvh, hd]; positions are read on the device (graph-capturable)."""
         b, q_len, _ = hidden_states.shape
-        rows = b * q_len
-        big = rows > ExLlamaV2Linear.LIB_GEMM_MIN_ROWS and not self.model.native_prefill
-        q, k, v = self._project_qkv(hidden_states, b, q_len, big)
-        attn_out = self._attend(q, k, v, cache, past_len, cache_seqlens, block_table, big)
-        return self._project_out(hidden_states, attn_out, b, q_len, big)
+        q, k, v = self._project_qkv(hidden_states, b, q_len)
+        attn_out = self._attend(q, k, v, cache, past_len, cache_seqlens, block_table)
+        return self._project_out(hidden_states, attn_out, b, q_len)
 
-    def _project_qkv(self, hidden_states, b: int, q_len: int, big: bool):
+    def _project_qkv(self, hidden_states, b: int, q_len: int):
         """Front half (q_attn_forward_1, q_attn.cu:153-317): RMSNorm + q/k/v projections into the scratch rows; RoPE is
         applied later, inside the attention launch."""
         cfg, m, ext = self.model.config, self.model, self.ext
@@ -64,19 +62,11 @@ class ExLlamaV2Attention:
         q = m.temp_q[:rows].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
         k = m.temp_k[:rows].view(b, q_len, cfg.num_key_value_heads, cfg.head_dim)
         v = m.temp_v[:rows].view(b, q_len, cfg.num_key_value_heads, cfg.head_dim)
-        if big:
-            # prefill-sized: unfused projections (reconstruct + library GEMM), reference forward_torch shape (attn.py:1198-)
-            xn = m.temp_state[:rows]
-            ext.rms_norm(hidden_states.view(rows, -1), self.pre_layernorm, xn, cfg.norm_eps)
-            q.view(rows, -1).copy_(self.q_proj.forward(xn))
-            k.view(rows, -1).copy_(self.k_proj.forward(xn))
-            v.view(rows, -1).copy_(self.v_proj.forward(xn))
-        else:
-            ext.q_attn_forward_1(self.q_handle, hidden_states, b, q_len, 0, none_tensor, q, k, v, m.sin, m.cos,
-                                 apply_rope=False)
+        ext.q_attn_forward_1(self.q_handle, hidden_states, b, q_len, 0, none_tensor, q, k, v, m.sin, m.cos,
+                             apply_rope=False)
         return q, k, v
 
-    def _attend(self, q, k, v, cache, past_len, cache_seqlens, block_table, big: bool):
+    def _attend(self, q, k, v, cache, past_len, cache_seqlens, block_table):
         """RoPE(q, new k) + KV append + attention over the (paged or contiguous, FP16 or Q4) cache -> attn_out rows."""
         cfg, m, ext = self.model.config, self.model, self.ext
         b, q_len = q.shape[0], q.shape[1]
@@ -88,7 +78,7 @@ class ExLlamaV2Attention:
         # Q4 cache, decode-sized step: attend straight from the codes (attn_q4.hip) -- the reference unpacks the whole live
         # range to an fp16 temp for every layer of every step (cache.py:472-514)
         # (the step's own K/V are attended in fp16 and quantised afterwards, the reference's order)
-        q4_direct = (getattr(cache, "wbits", 0) == 4 and hasattr(cache, "q4_views") and not big and self.q4_fused and q_len <= 8
+        q4_direct = (getattr(cache, "wbits", 0) == 4 and hasattr(cache, "q4_views") and self.q4_fused and q_len <= 8
                      and q_len * (cfg.num_attention_heads // cfg.num_key_value_heads) <= 64
                      and cfg.head_dim in (64, 128, 256)
                      and (cfg.num_key_value_heads * cfg.head_dim) % 512 == 0)     # codec blocks (512 elements) must not span tokens
@@ -118,7 +108,7 @@ class ExLlamaV2Attention:
                 raise RuntimeError("ExLlamaV2Attention: fused Q4 attention rejected a shape it was selected for")
         else:
             # decode-shaped steps: one launch does RoPE + append + attention + split merge; otherwise three launches
-            fused = (not big) and self.fused_decode and ext.attn_decode_fused(
+            fused = self.fused_decode and ext.attn_decode_fused(
                 q, k, v, kc, vc, attn_out, m.sin, m.cos, sl, bt, past, cfg.rope_style, m.attn_scratch, m.attn_counters)
             if not fused:
                 ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, past if not paged else 0,
@@ -144,13 +134,8 @@ class ExLlamaV2Attention:
             raise RuntimeError("attend_chain: shape not covered by the one-launch attention kernel")
         return attn_out
 
-    def _project_out(self, hidden_states, attn_out, b: int, q_len: int, big: bool):
+    def _project_out(self, hidden_states, attn_out, b: int, q_len: int):
         """Back half (q_attn_forward_2, q_attn.cu:319-345): x += attn_out . Wo"""
-        ext = self.ext
-        rows = b * q_len
-        if big:
-            hidden_states.view(rows, -1).add_(self.o_proj.forward(attn_out.view(rows, -1)))
-        else:
-            ext.q_attn_forward_2(self.q_handle, hidden_states, attn_out, b, q_len)
+        self.ext.q_attn_forward_2(self.q_handle, hidden_states, attn_out, b, q_len)
         return hidden_states
 

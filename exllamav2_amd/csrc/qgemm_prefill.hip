@@ -16,7 +16,7 @@
 //     a wave may use at 2 waves per SIMD), K step = one super-chunk (<= 128 rows); fp32 accumulation, bias / residual in
 //     the epilogue.
 // MFMA-bound by design: per K step a wave issues 128 MFMAs against ~500 VALU ops of decode.
-#include "qgemv_common.h"
+#include "qgemm_prefill.h"
 #include "errors.h"
 #include <stdlib.h>
 #include <string.h>
@@ -39,15 +39,6 @@
 #define PF_BUF_BYTES (PF_A_BYTES + 2 * PF_SC_BYTES)   // one stage: A tile + scales + zero points
 #define PF_TAB_OFF (2 * PF_BUF_BYTES)                 // chunk -> group map and (EXL2) per-group scale maxima, loaded once
 #define PF_LDS_BYTES(K, G) (PF_TAB_OFF + ((((K) >> 5) * 2 + 15) & ~15) + (((G) * 2 + 15) & ~15))
-
-struct PrefillArgs
-{
-    QMatDev m;
-    const f16* a;           // [M, K] in packed K order, row stride K
-    f16* c; int ldc;
-    const u16* c_invperm;
-    int M, c_mode;
-};
 
 // scale (and GPTQ zero point) of column n for the (up to 4) chunks of one step, as the fp16 values reconstruct() uses
 // cg_lds / smax_lds: LDS copies of chunk_group and (EXL2) scale_src made at kernel start -- one global round trip per
@@ -598,7 +589,8 @@ int stage_rows_for_decode(const GemvJob* jobs, int n_jobs, int M, void* stream, 
     return EXL2_OK;
 }
 
-#define PF_ROW_CHUNK 4096
+#define PF_ROW_CHUNK 16384             // rows staged (and multiplied) per pass: 16384 x 11008 halves = 360 MB of scratch at most
+#define PF_MFMA_MIN_ROWS 129           // from here up the 256-column LDS-decode kernel (qgemm_mfma.hip) takes the pass
 
 // returns 0 when done, 1 when the prefill kernel does not apply (caller falls back), < 0 on error
 int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream)
@@ -624,9 +616,12 @@ int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stre
     }
     int k_max = 0;
     for (int i = 0; i < n_jobs; i++) if (jobs[i].m.K > k_max) k_max = jobs[i].m.K;
+    int mfma_min_rows = PF_MFMA_MIN_ROWS;
+    if (const char* e = getenv("EXL2_PREFILL_MFMA_MIN_ROWS")) mfma_min_rows = atoi(e);      // tests / A-B runs (0 = never)
     const int chunk = M < PF_ROW_CHUNK ? M : PF_ROW_CHUNK;
     f16* stage = nullptr;
-    { const int rc = stage_scratch((size_t)chunk * k_max * 2, stream, &stage); if (rc) return rc; }
+    // + 256 rows: qgemm_mfma.hip reads whole row blocks (rows >= M hold stale values, feed only rows that are never stored)
+    { const int rc = stage_scratch((size_t)(chunk + 256) * k_max * 2, stream, &stage); if (rc) return rc; }
 
     for (int r0 = 0; r0 < M; r0 += chunk)
     {
@@ -644,6 +639,12 @@ int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stre
             memset(&p, 0, sizeof(p));
             p.m = j.m; p.a = stage; p.c = j.c + (size_t)r0 * j.ldc; p.ldc = j.ldc; p.c_invperm = j.c_invperm;
             p.M = rows; p.c_mode = j.c_mode;
+            if (mfma_min_rows > 0 && rows >= mfma_min_rows)
+            {
+                const int rc = qgemm_mfma_launch(p, gptq, stream);
+                if (rc) return rc;
+                continue;
+            }
             dim3 grid((unsigned)((j.m.N + PF_BN - 1) / PF_BN), (unsigned)((rows + PF_BM - 1) / PF_BM), 1);
             const size_t lds = PF_LDS_BYTES(j.m.K, j.m.G);
             if (gptq) LAUNCH((qgemm_prefill_kernel<true>), grid, dim3(PF_THREADS), lds, stream, p);

@@ -7,11 +7,9 @@ from .ext import none_tensor
 
 
 class ExLlamaV2Linear:
-    # rows above which forward() uses reconstruct + library GEMM (the reference's own M > 32 method,
-    # cuda/q_gemm.cu:243-263 / linear.py:370-379).  Measured on MI355X (tools/prefill_bench.py): hipBLASLt on the
-    # reconstructed fp16 matrix reaches ~1.0 PFLOP/s at M = 16384, the round-1 dequantize-into-MFMA kernel
-    # (qgemm_prefill.hip) ~0.33; below this row count the decode kernel in 16-row passes is faster than either.
-    LIB_GEMM_MIN_ROWS = 64
+    # Every row count goes to the HIP library: <= 16 rows the decode kernels, above that the dequantize-into-MFMA kernels
+    # (qgemm_prefill.hip / qgemm_mfma.hip).  The reference's own M > 32 method -- reconstruct the fp16 matrix, library GEMM
+    # (cuda/q_gemm.cu:243-263) -- exists here only where the reference exposes it as an argument: force_recons.
 
     def __init__(self, ext, key: str, in_features: int, out_features: int, model=None):
         self.model = model
@@ -37,12 +35,9 @@ class ExLlamaV2Linear:
         self.q_tensors = None
 
     def forward(self, hidden_states: torch.Tensor, force_recons: bool = False, force_cuda: bool = False) -> torch.Tensor:
-        """linear.py:361-379: gemm_half_q_half, or reconstruct + torch.matmul when force_recons."""
+        """linear.py:361-379: gemm_half_q_half; reconstruct + torch.matmul ONLY when the caller asks for it (force_recons,
+        the reference's argument of the same name)."""
         n = self.out_features + self.padding
-        rows = hidden_states.numel() // self.in_features
-        if not force_recons and not force_cuda and self.model is not None and rows > self.LIB_GEMM_MIN_ROWS \
-                and not self.model.native_prefill:
-            force_recons = True
         if force_recons:
             if self.model is not None:
                 w = self.model.dq_scratch(self.in_features, n, hidden_states.device)

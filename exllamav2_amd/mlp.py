@@ -35,20 +35,7 @@ class ExLlamaV2MLP:
             lin.unload()
 
     def forward(self, hidden_states: torch.Tensor):
-        """mlp.py:353: ext_c.q_mlp_forward_ in place.  Prefill-sized calls take the reference's unfused route
-        (mlp.py:410-470 forward_torch shape: norm -> gate/up -> act*mul -> down -> residual) so that the three GEMMs can
-        use reconstruct + library GEMM (ExLlamaV2Linear.LIB_GEMM_MIN_ROWS)."""
-        m, ext = self.model, self.ext
-        rows = hidden_states.numel() // hidden_states.shape[-1]
-        if rows <= ExLlamaV2Linear.LIB_GEMM_MIN_ROWS or m.native_prefill:
-            ext.q_mlp_forward_(self.q_handle, hidden_states)
-            return hidden_states
-        h = hidden_states.shape[-1]
-        x2 = hidden_states.view(rows, h)
-        xn = m.temp_state[:rows]
-        ext.rms_norm(x2, self.post_attention_layernorm, xn, m.config.norm_eps)
-        g = self.gate_proj.forward(xn)
-        u = self.up_proj.forward(xn)
-        ext.act_mul_(g, u)                                                       # silu(g) * u in place on g
-        x2.add_(self.down_proj.forward(g))
+        """mlp.py:353: ext_c.q_mlp_forward_ in place, for every row count (<= 16 rows: the fused decode launches; above:
+        row pre-pass + dequantize-into-MFMA GEMMs, csrc/modules.hip:exl2_q_mlp_forward)."""
+        self.ext.q_mlp_forward_(self.q_handle, hidden_states)
         return hidden_states

@@ -46,8 +46,7 @@ class ExLlamaV2:
         sb = self.ext.paged_attn_scratch_bytes(min(r, 64) * cfg.num_attention_heads, cfg.head_dim, 64)
         self.attn_scratch = torch.empty((sb // 4 + 16,), dtype=torch.float32, device=dev)
         self.attn_counters = torch.zeros((4096,), dtype=torch.int32, device=dev)     # split hand-off tickets (attn.hip)
-        self._dq = None                                   # reconstruct target of the library-GEMM prefill path (temp_dq)
-        self.native_prefill = os.environ.get("EXL2_NATIVE_PREFILL", "0") == "1"    # force qgemm_prefill.hip / attn.hip
+        self._dq = None                                   # reconstruct target of ExLlamaV2Linear.forward(force_recons=True)
         self.sin, self.cos = rope_tables(cfg, dev)
         self.modules = []
         self.layers = []

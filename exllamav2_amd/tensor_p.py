@@ -142,7 +142,7 @@ class TPAttention(ExLlamaV2Attention):
     # runs on the shards with the LOCAL head counts of model.config; the handle's o_proj slot (the o shard) is only
     # used by q_attn_forward_2, which this class replaces:
 
-    def _project_out(self, hidden_states, attn_out, b, q_len, big):
+    def _project_out(self, hidden_states, attn_out, b, q_len):
         rows = b * q_len
         tp = self.model.tp
         full = tp.all_gather_columns(attn_out.view(rows, -1))                  # [rows, H * hd], heads in rank order

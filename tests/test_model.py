@@ -77,14 +77,15 @@ def test_chunked_prefill_equals_oracle(be):
     model.unload()
 
 
-@pytest.mark.parametrize("native", [False, True])
-def test_prefill_sized_forward_equals_oracle(be, native):
-    """rows > LIB_GEMM_MIN_ROWS: the unfused module route (reconstruct + library GEMM) and, with native_prefill, the HIP route
-    (qgemm_prefill.hip) must both match the oracle -- attention in both is the MFMA flash-prefill kernel (attn_prefill.hip);
-    then one decode step on the cache they filled."""
+@pytest.mark.parametrize("kernel", ["tile128", "tile256"])
+def test_prefill_sized_forward_equals_oracle(be, kernel, monkeypatch):
+    """rows > 16 through the module handles (q_attn_forward_1 / _2, q_mlp_forward_): row pre-pass + dequantize-into-MFMA GEMM,
+    once with the 128 x 128 register-decode kernel (qgemm_prefill.hip) and once with the 256-column LDS-decode kernel
+    (qgemm_mfma.hip) forced for every row count; attention is the MFMA flash-prefill kernel (attn_prefill.hip); then one
+    decode step on the cache they filled.  No torch GEMM / SDPA anywhere on this route."""
+    monkeypatch.setenv("EXL2_PREFILL_MFMA_MIN_ROWS", "0" if kernel == "tile128" else "17")
     cfg = tiny_cfg(max_input_len=128, max_seq_len=256, num_hidden_layers=1)
     model, oracle = build(be, cfg, seed=3)
-    model.native_prefill = native
     cache = ExLlamaV2Cache(model, batch_size=1)
     oracle.reset(1)
     ids = np.random.default_rng(3).integers(0, cfg.vocab_size, size=(1, 70))
