@@ -106,43 +106,13 @@ for _n in ("layer_norm", "layer_norm_", "head_norm", "head_norm_", "softcap_", "
     globals()[_n] = _out_of_scope(_n, "outside the quantized forward path (SURVEY.md 2.2: OUT OF SCOPE)")
 
 
-# ---- load path: thin host code, as SURVEY.md 8b asks (the reference's are CPU loops too) ---------------------------------
-
-def stloader_read(filename: str, offset: int, size: int, target) -> None:
-    """ext_stloader.cpp:11-157: `size` bytes at `offset` of `filename` -> the contiguous tensor `target` (CPU or device).
-    The reference reads 1 MiB blocks on 8 threads into a bounce buffer; here one read + one copy (the bytes end up the
-    same; what the loader is FOR -- time to first token -- is SURVEY.md 8f row N3, not this path)."""
-    if size == 0:
-        return
-    nbytes = target.numel() * target.element_size()
-    if size != nbytes:
-        raise RuntimeError(f"stloader_read: {size} bytes requested for a tensor of {nbytes} bytes")
-    if not target.is_contiguous():
-        raise RuntimeError("stloader_read: target must be contiguous")
-    buf = _np.fromfile(filename, dtype=_np.uint8, count=size, offset=offset)
-    if buf.size != size:
-        raise RuntimeError(f"stloader_read: short read from {filename} ({buf.size} of {size} bytes)")
-    target.view(-1).view(_torch.uint8).copy_(_torch.from_numpy(buf))
-
-
-def tensor_remap(tensor, index) -> None:
-    """ext_stloader.cpp:160-184: in place, new[:, c] = old[:, index[c]] (int32 CPU tensors): the MLP act-order folding of
-    linear.py:156-158."""
-    if tensor.dtype != _torch.int32 or index.dtype != _torch.int32 or tensor.dim() != 2 or index.shape[0] != tensor.shape[1]:
-        raise RuntimeError("tensor_remap: expects int32 [rows, cols] and int32 [cols]")
-    tensor.copy_(tensor[:, index.long()])
-
-
-def tensor_remap_4bit(tensor, index) -> None:
-    """ext_stloader.cpp:186-219: the same on 4-bit values packed 8 per int32 along the columns (q_scale)."""
-    if tensor.dtype != _torch.int32 or index.dtype != _torch.int32 or tensor.dim() != 2 or index.shape[0] != tensor.shape[1] * 8:
-        raise RuntimeError("tensor_remap_4bit: expects int32 [rows, cols / 8] and int32 [cols]")
-    w = tensor.numpy().view(_np.uint32)
-    shifts = _np.arange(8, dtype=_np.uint32) * 4
-    nib = ((w[:, :, None] >> shifts) & 0xF).reshape(w.shape[0], -1)            # [rows, cols]
-    nib = nib[:, index.numpy().astype(_np.int64)].reshape(w.shape[0], -1, 8)
-    packed = (nib.astype(_np.uint32) << shifts).sum(axis=-1, dtype=_np.uint32)
-    w[...] = packed
+# ---- load path: csrc/stloader.hip through the C ABI -------------------------------------------------
+# stloader_read: host targets are read in place by 8 readers; device targets go through a ring of pinned slots with the
+# host-to-device copies overlapping the reads.  tensor_remap / tensor_remap_4bit: the CPU column re-orderings of
+# linear.py:156-158.
+stloader_read = _e.stloader_read
+tensor_remap = _e.tensor_remap
+tensor_remap_4bit = _e.tensor_remap_4bit
 
 
 def fast_fill_cpu_ones_bool(tensor) -> None:                          # ext_sampling.cpp: logit-filter helper of the sampler

@@ -46,6 +46,10 @@ PROTOTYPES = {
     "exl2_fp8_to_fp16": (ci, [vp, vp, ci, cll, ci, ci, ci, vp]),
     "exl2_cache_rotate": (ci, [vp, vp, cll, ci, vp]),
     "exl2_count_match": (ci, [vp, vp, ci, ci, vp]),
+    # load path
+    "exl2_stloader_read": (ci, [C.c_char_p, C.c_ulonglong, C.c_ulonglong, vp, ci, vp]),
+    "exl2_tensor_remap": (ci, [vp, ci, ci, vp]),
+    "exl2_tensor_remap_4bit": (ci, [vp, ci, ci, vp]),
     # attention
     "exl2_paged_attn_scratch_bytes": (cll, [ci, ci, ci]),
     "exl2_flash_prefill": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, vp]),

@@ -22,15 +22,36 @@ def needs_build() -> bool:
     return os.path.getmtime(OUT) < max(os.path.getmtime(f) for f in deps)
 
 
+def _obj_dir() -> str:
+    d = os.path.join(HERE, "build")                      # git-ignored; objects are a cache, only the .so is loaded
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    """One object per .hip file (compiled in parallel, re-compiled only when the file or a header is newer), one link."""
     if not force and not needs_build():
         return OUT
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-I", CSRC, "-o", OUT] + sources()
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I", CSRC]
+    headers = glob.glob(os.path.join(CSRC, "*.h"))
+    hdr_time = max(os.path.getmtime(f) for f in headers) if headers else 0.0
+    objs, jobs = [], []
+    for src in sources():
+        obj = os.path.join(_obj_dir(), os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 4))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", OUT] + objs)
     return OUT
 
 

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import os
 
 import torch
 
@@ -276,6 +277,41 @@ class ExtC:
         self.lib.check(self.lib.exl2_count_match(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()),
                                                  min(int(max_a), a.shape[-1]), b.shape[-1], ctypes.byref(out)))
         return int(out.value)
+
+    # ---- load path (ext_stloader.cpp) ---------------------------------------------------------------
+
+    def stloader_read(self, filename: str, offset: int, size: int, target) -> None:
+        """ext_stloader.cpp:11-157: `size` bytes at `offset` of `filename` -> the contiguous tensor `target` (CPU or device)."""
+        if size == 0:
+            return
+        nbytes = target.numel() * target.element_size()
+        if size != nbytes:
+            raise RuntimeError(f"stloader_read: {size} bytes requested for a tensor of {nbytes} bytes")
+        if not target.is_contiguous():
+            raise RuntimeError("stloader_read: target must be contiguous")
+        dev = -1 if target.device.type == "cpu" else (target.device.index or 0)
+        self.lib.check(self.lib.exl2_stloader_read(os.fsencode(filename), int(offset), int(size), target.data_ptr(), dev,
+                                                   self._stream(target)))
+
+    def tensor_remap(self, tensor, index) -> None:
+        """ext_stloader.cpp:160-184: in place new[:, c] = old[:, index[c]] (int32 CPU tensors; linear.py:156-158)."""
+        if tensor.dtype != torch.int32 or index.dtype != torch.int32 or tensor.dim() != 2 or index.dim() != 1 \
+                or index.shape[0] != tensor.shape[1] or tensor.device.type != "cpu" or index.device.type != "cpu":
+            raise RuntimeError("tensor_remap: expects CPU int32 [rows, cols] and int32 [cols]")
+        if not tensor.is_contiguous():
+            raise RuntimeError("tensor_remap: tensor must be contiguous")
+        index = index.contiguous()
+        self.lib.check(self.lib.exl2_tensor_remap(tensor.data_ptr(), tensor.shape[0], tensor.shape[1], index.data_ptr()))
+
+    def tensor_remap_4bit(self, tensor, index) -> None:
+        """ext_stloader.cpp:186-219: the same on 4-bit values packed 8 per int32 along the columns (q_scale)."""
+        if tensor.dtype != torch.int32 or index.dtype != torch.int32 or tensor.dim() != 2 or index.dim() != 1 \
+                or index.shape[0] != tensor.shape[1] * 8 or tensor.device.type != "cpu" or index.device.type != "cpu":
+            raise RuntimeError("tensor_remap_4bit: expects CPU int32 [rows, cols / 8] and int32 [cols]")
+        if not tensor.is_contiguous():
+            raise RuntimeError("tensor_remap_4bit: tensor must be contiguous")
+        index = index.contiguous()
+        self.lib.check(self.lib.exl2_tensor_remap_4bit(tensor.data_ptr(), tensor.shape[0], index.shape[0], index.data_ptr()))
 
     # ---- attention (replaces flash_attn_with_kvcache / _attn_torch; SURVEY.md A.7) -------------------------------------
 

@@ -94,6 +94,19 @@ int exl2_cache_rotate(void* cache, const int* order, long long page_bytes, int n
 /* count_match (ext_cache.cpp:285-302): host; leading positions at which two int64 token rows agree, <= min(max_a, len_b) */
 int exl2_count_match(const long long* a, const long long* b, int max_a, int len_b, int* match);
 
+/* ---- load path ------------------------------------------------------------------------------- */
+
+/* stloader_read (ext_stloader.cpp:11-157; called by stloader.py:160 for every tensor of a checkpoint): `size` bytes at
+   `offset` of `filename` -> `target`.  target_device < 0: host memory (8 readers, contiguous shares, straight into the
+   tensor).  target_device >= 0: device memory of that GPU through a ring of pinned slots (allocated once per device),
+   one hipMemcpyAsync per 4 MiB chunk on `stream`, overlapped with the reads; returns after the last copy has completed. */
+int exl2_stloader_read(const char* filename, unsigned long long offset, unsigned long long size, void* target,
+                       int target_device, void* stream);
+/* tensor_remap (ext_stloader.cpp:160-184), host: in place new[r][c] = old[r][index[c]], int32 [rows, cols] */
+int exl2_tensor_remap(int* tensor, int rows, int cols, const int* index);
+/* tensor_remap_4bit (ext_stloader.cpp:186-219), host: the same on nibbles packed 8 per int32: tensor [rows, cols / 8] */
+int exl2_tensor_remap_4bit(int* tensor, int rows, int cols, const int* index);
+
 /* ---- attention (replaces flash_attn_with_kvcache, attn.py:602-613, and _attn_torch, attn.py:869-937) ---------------- */
 
 long long exl2_paged_attn_scratch_bytes(int rows, int head_dim, int nsplit);

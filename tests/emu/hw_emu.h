@@ -346,6 +346,8 @@ enum { hipEventDisableTiming = 2 };
 DEV hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*)1; return hipSuccess; }
 DEV hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 DEV hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+DEV hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+DEV hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = aligned_alloc(4096, (n + 4095) / 4096 * 4096); return *p ? hipSuccess : hipErrorOutOfMemory; }
 
 // graphs cannot be emulated: capture is refused, callers fall back to eager launches in the emu tests
 typedef void* hipGraph_t;

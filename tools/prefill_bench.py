@@ -11,31 +11,48 @@ from exllamav2_amd.synth import synth_linear
 MFMA_PEAK_F16 = 2500.0          # dense TFLOP/s, MI355X_MICROARCH.md
 
 
-def bench_linear(k, n, m, recipe, reps=5):
+def _time(fn, reps):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+# kernel selection of csrc/qgemm_prefill.hip's host driver (read per call): the shipped choice, each tile height of the
+# 256-column LDS-decode kernel (qgemm_mfma.hip), and the 128 x 128 register-decode kernel (qgemm_prefill.hip)
+VARIANTS = {"auto": {}, "tile256_mt8": {"EXL2_PREFILL_MT": "8"}, "tile256_mt4": {"EXL2_PREFILL_MT": "4"},
+            "tile128": {"EXL2_PREFILL_MFMA_MIN_ROWS": "0"}}
+
+
+def bench_linear(k, n, m, recipe, reps=5, variants=("auto", "tile256_mt8", "tile256_mt4", "tile128")):
     gen = torch.Generator(device="cuda"); gen.manual_seed(0)
     w = synth_linear(k, n, recipe, "cuda", gen)
     h = ext.make_q_matrix_from_dict(w, none_tensor)
     a = torch.randn((m, k), device="cuda", dtype=torch.float16)
     c = torch.empty((m, n), device="cuda", dtype=torch.float16)
-    ext.gemm_half_q_half(a, h, c); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps): ext.gemm_half_q_half(a, h, c)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    tf = 2.0 * m * k * n / ms / 1e9
-    # reference method for M > 32: reconstruct + fp16 GEMM (q_gemm.cu:243-263), here torch.matmul = hipBLASLt
+    out = {"k": k, "n": n, "m": m, "recipe": str(recipe)}
+    ref = None
+    for name in variants:
+        for key in ("EXL2_PREFILL_MT", "EXL2_PREFILL_MFMA_MIN_ROWS"): os.environ.pop(key, None)
+        os.environ.update(VARIANTS[name])
+        ms = _time(lambda: ext.gemm_half_q_half(a, h, c), reps)
+        out[name] = {"ms": round(ms, 4), "TFLOPs": round(2.0 * m * k * n / ms / 1e9, 1),
+                     "frac_mfma_peak": round(2.0 * m * k * n / ms / 1e9 / MFMA_PEAK_F16, 4)}
+        if ref is None: ref = c.clone()
+        else: out[name]["max_abs_diff_vs_auto"] = float((c.float() - ref.float()).abs().max())
+    for key in ("EXL2_PREFILL_MT", "EXL2_PREFILL_MFMA_MIN_ROWS"): os.environ.pop(key, None)
+    # the reference's method for M > 32: reconstruct + fp16 library GEMM (q_gemm.cu:243-263), here torch.matmul = hipBLASLt
     wd = torch.empty((k, n), device="cuda", dtype=torch.float16)
-    ext.reconstruct(h, wd); torch.matmul(a, wd, out=c); torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
+    def lib():
         ext.reconstruct(h, wd); torch.matmul(a, wd, out=c)
-    e1.record(); torch.cuda.synchronize()
-    ms_ref = e0.elapsed_time(e1) / reps
+    ms_ref = _time(lib, reps)
+    out["reconstruct_plus_hipblaslt"] = {"ms": round(ms_ref, 4), "TFLOPs": round(2.0 * m * k * n / ms_ref / 1e9, 1)}
+    out["auto_speedup_vs_reconstruct_gemm"] = round(ms_ref / out[variants[0]]["ms"], 3)
+    out["max_abs_diff_lib_vs_auto"] = float((c.float() - ref.float()).abs().max())
     ext.free_q_matrix(h)
-    return {"k": k, "n": n, "m": m, "recipe": str(recipe), "ms": round(ms, 4), "TFLOPs": round(tf, 1),
-            "frac_mfma_peak": round(tf / MFMA_PEAK_F16, 4), "reconstruct_plus_hipblaslt_ms": round(ms_ref, 4),
-            "speedup_vs_reconstruct_gemm": round(ms_ref / ms, 3)}
+    return out
 
 
 def bench_model(batch=8, seq=2048, layers=None, reps=2):
@@ -66,6 +83,8 @@ if __name__ == "__main__":
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--model", action="store_true")
     ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--variants", default="auto,tile256_mt8,tile256_mt4,tile128", help="kernel selections to time (first = the baseline)")
+    ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
     if args.model:
         print(json.dumps(bench_model(layers=args.layers or None)), flush=True)
@@ -75,4 +94,4 @@ if __name__ == "__main__":
              (4096, 11008, 2048, r4), (4096, 11008, 256, r4), (4096, 11008, 64, r4)]
     if args.quick: cases = cases[1:2] + cases[3:4]
     for k, n, m, rec in cases:
-        print(json.dumps(bench_linear(k, n, m, rec)), flush=True)
+        print(json.dumps(bench_linear(k, n, m, rec, reps=args.reps, variants=tuple(args.variants.split(",")))), flush=True)
