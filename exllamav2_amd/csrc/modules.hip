@@ -57,6 +57,7 @@ struct QAttn
     const f16* q_norm; const f16* k_norm; const f16* post_layernorm; const f16* post_layernorm_bias;
     bool residual_fp32; bool use_graphs;
     bool chain_ok; f16* norm_w_perm;            // chained decode: layernorm gathered through q/k/v's shared q_perm (owned)
+    bool qkv_same_perm;                         // q, k, v share one act-order permutation (prefill: rows staged once)
 };
 
 struct QMLP
@@ -67,6 +68,7 @@ struct QMLP
     int max_rows; bool act_gelu; bool has_residual;
     const f16* post_layernorm; const f16* post_layernorm_bias; bool residual_fp32; bool use_graphs;
     bool chain_ok; f16* norm_w_perm;            // chained decode: layernorm gathered through gate/up's shared q_perm (owned)
+    bool gu_same_perm;                          // gate and up share one act-order permutation (prefill: rows staged once)
 };
 
 // true when every matrix carries the same act-order permutation (or none does)
@@ -376,6 +378,7 @@ int exl2_make_q_attn(void** handle, const void* layernorm, const void* layernorm
         a->chain_ok = a->layernorm && a->layernorm_is_rms && !a->post_layernorm && a->has_residual && !a->layernorm_bias
                       && a->k_proj->is_gptq == gq && a->v_proj->is_gptq == gq && a->o_proj->is_gptq == gq
                       && a->o_proj->height == num_heads * head_dim && a->o_proj->width == hidden_size && same_perm(qkv, 3);
+        a->qkv_same_perm = a->chain_ok || same_perm(qkv, 3);
         if (a->chain_ok) { a->norm_w_perm = permuted_norm(a->layernorm, a->q_proj); if (!a->norm_w_perm) a->chain_ok = false; }
     }
     *handle = a;
@@ -405,30 +408,16 @@ int exl2_q_attn_forward_1(void* handle, const void* x, int batch_size, int q_len
     EXL2_REQUIRE(rows <= a->max_rows, "q_attn_forward_1: %d rows exceed max_rows %d", rows, a->max_rows);
     const bool gptq = a->q_proj->is_gptq;
     EXL2_REQUIRE(a->k_proj->is_gptq == gptq && a->v_proj->is_gptq == gptq, "q_attn_forward_1: mixed EXL2/GPTQ projections");
+    // RMSNorm rides in the staging of the rows for every row count: <= 16 rows in the decode kernel's prologue, above that in
+    // the row pre-pass of the prefill kernels (stage_rows_kernel: act-order gather + norm, once for q | k | v)
     GemvJob jobs[3];
-    if (rows <= MAX_GEMV_ROWS)
-    {
-        const int mode = a->layernorm ? A_RMSNORM : A_PLAIN;
-        fill_job(jobs[0], a->q_proj, (const f16*)x, (f16*)temp_q, mode, C_STORE);
-        fill_job(jobs[1], a->k_proj, (const f16*)x, (f16*)temp_k, mode, C_STORE);
-        fill_job(jobs[2], a->v_proj, (const f16*)x, (f16*)temp_v, mode, C_STORE);
-        for (int i = 0; i < 3; i++) { jobs[i].norm_w = a->layernorm; jobs[i].norm_eps = a->norm_epsilon; }
-        LAUNCH_JOBS(jobs, 3, rows, gptq, stream, "q_attn_forward_1");
-    }
-    else
-    {
-        const f16* ns = (const f16*)x;
-        if (a->layernorm)
-        {
-            const int rc = exl2_rms_norm(x, a->layernorm, a->temp_state, a->norm_epsilon, rows, a->hidden_size, 0, 0, 0, stream);
-            if (rc) return rc;
-            ns = a->temp_state;
-        }
-        fill_job(jobs[0], a->q_proj, ns, (f16*)temp_q, A_PLAIN, C_STORE);
-        fill_job(jobs[1], a->k_proj, ns, (f16*)temp_k, A_PLAIN, C_STORE);
-        fill_job(jobs[2], a->v_proj, ns, (f16*)temp_v, A_PLAIN, C_STORE);
-        LAUNCH_JOBS(jobs, 3, rows, gptq, stream, "q_attn_forward_1");
-    }
+    const int mode = a->layernorm ? A_RMSNORM : A_PLAIN;
+    fill_job(jobs[0], a->q_proj, (const f16*)x, (f16*)temp_q, mode, C_STORE);
+    fill_job(jobs[1], a->k_proj, (const f16*)x, (f16*)temp_k, mode, C_STORE);
+    fill_job(jobs[2], a->v_proj, (const f16*)x, (f16*)temp_v, mode, C_STORE);
+    for (int i = 0; i < 3; i++) { jobs[i].norm_w = a->layernorm; jobs[i].norm_eps = a->norm_epsilon; }
+    jobs[1].rows_as_prev = jobs[2].rows_as_prev = a->qkv_same_perm ? 1 : 0;
+    LAUNCH_JOBS(jobs, 3, rows, gptq, stream, "q_attn_forward_1");
     if (apply_rope && a->rope_style != 0)
     {
         EXL2_REQUIRE(sin && cos, "q_attn_forward_1: sin/cos tables missing");
@@ -486,6 +475,7 @@ int exl2_make_q_mlp(void** handle, const void* layernorm, const void* layernorm_
         m->chain_ok = m->temp_a && m->layernorm && m->layernorm_is_rms && !m->layernorm_bias && !m->post_layernorm && m->has_residual
                       && m->gate->is_gptq == gq && m->down->is_gptq == gq && m->gate->width == m->up->width
                       && m->down->height == m->up->width && m->down->width == m->up->height && same_perm(gu, 2);
+        m->gu_same_perm = m->chain_ok || same_perm(gu, 2);
         if (m->chain_ok) { m->norm_w_perm = permuted_norm(m->layernorm, m->up); if (!m->norm_w_perm) m->chain_ok = false; }
     }
     *handle = m;
@@ -517,48 +507,25 @@ int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream)
     GemvJob jobs[2];
 
     const f16* ns = (const f16*)x;
-    int in_mode = A_PLAIN;
-    if (m->layernorm)
-    {
-        if (skinny) in_mode = A_RMSNORM;
-        else
-        {
-            const int rc = exl2_rms_norm(x, m->layernorm, m->temp_state, m->norm_epsilon, rows, hidden, 0, 0, 0, stream);
-            if (rc) return rc;
-            ns = m->temp_state;
-        }
-    }
+    const int in_mode = m->layernorm ? A_RMSNORM : A_PLAIN;     // norm in the staging of the rows (decode prologue / prefill pre-pass)
     int n = 0;
     if (m->gate) { fill_job(jobs[n], m->gate, ns, m->temp_a, in_mode, C_STORE); n++; fill_job(jobs[n], m->up, ns, m->temp_b, in_mode, C_STORE); n++; }
     else         { fill_job(jobs[n], m->up, ns, m->temp_a, in_mode, C_STORE); n++; }
     for (int i = 0; i < n; i++) { jobs[i].norm_w = m->layernorm; jobs[i].norm_eps = m->norm_epsilon; }
+    if (n == 2) jobs[1].rows_as_prev = m->gu_same_perm ? 1 : 0;
     // decode-shaped calls: gate / up write their columns straight into down's packed (act-order) row order, so down
     // stages a contiguous row instead of gathering through q_perm (temp_a / temp_b have no other reader)
     const bool scatter = skinny && m->down->dev.perm && m->down->q_invperm;
     if (scatter) for (int i = 0; i < n; i++) jobs[i].c_invperm = m->down->q_invperm;
     LAUNCH_JOBS(jobs, n, rows, gptq, stream, "q_mlp_forward_");
 
+    // activation folded into the staging of down's input (no intermediate round trip, one launch less) for every row count
     GemvJob d;
-    if (skinny)
     {
-        // activation folded into the staging of down's input (no intermediate round trip, one launch less)
         const int amode = m->gate ? (m->act_gelu ? A_GELU_MUL : A_SILU_MUL) : (m->act_gelu ? A_GELU : A_SILU);
         fill_job(d, m->down, m->temp_a, down_dst, amode, down_mode);
         d.a2 = m->temp_b;
         if (scatter) d.m.perm = nullptr;
-    }
-    else
-    {
-        if (m->gate)
-        {
-            const int rc = exl2_act_mul(m->temp_a, m->temp_b, rows, m->up->width, m->act_gelu, nullptr, 0, stream);
-            if (rc) return rc;
-            fill_job(d, m->down, m->temp_a, down_dst, A_PLAIN, down_mode);
-        }
-        else
-        {
-            fill_job(d, m->down, m->temp_a, down_dst, m->act_gelu ? A_GELU : A_SILU, down_mode);
-        }
     }
     LAUNCH_JOBS(&d, 1, rows, m->down->is_gptq, stream, "q_mlp_forward_");
     if (m->post_layernorm)

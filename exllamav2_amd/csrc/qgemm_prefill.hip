@@ -629,11 +629,19 @@ int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stre
         for (int i = 0; i < n_jobs; i++)
         {
             const GemvJob& j = jobs[i];
-            RowStageArgs s;
-            memset(&s, 0, sizeof(s));
-            s.a = j.a + (size_t)r0 * j.lda; s.a2 = j.a2 ? j.a2 + (size_t)r0 * j.lda : nullptr;
-            s.norm_w = j.norm_w; s.perm = j.m.perm; s.out = stage; s.K = j.m.K; s.lda = j.lda; s.mode = j.a_mode; s.eps = j.norm_eps;
-            LAUNCH(stage_rows_kernel, dim3((unsigned)rows), dim3(256), (size_t)j.m.K * 2 + 64, stream, s);
+            // q | k | v and gate | up multiply the same rows in the same packed order (one act-order permutation, checked at
+            // make time: GemvJob::rows_as_prev): the staged copy of the previous job of this pass is still in the scratch
+            const bool same_rows = i > 0 && j.rows_as_prev && jobs[i - 1].a == j.a && jobs[i - 1].a2 == j.a2 &&
+                                   jobs[i - 1].lda == j.lda && jobs[i - 1].m.K == j.m.K && jobs[i - 1].a_mode == j.a_mode &&
+                                   jobs[i - 1].norm_w == j.norm_w && jobs[i - 1].norm_eps == j.norm_eps;
+            if (!same_rows)
+            {
+                RowStageArgs s;
+                memset(&s, 0, sizeof(s));
+                s.a = j.a + (size_t)r0 * j.lda; s.a2 = j.a2 ? j.a2 + (size_t)r0 * j.lda : nullptr;
+                s.norm_w = j.norm_w; s.perm = j.m.perm; s.out = stage; s.K = j.m.K; s.lda = j.lda; s.mode = j.a_mode; s.eps = j.norm_eps;
+                LAUNCH(stage_rows_kernel, dim3((unsigned)rows), dim3(256), (size_t)j.m.K * 2 + 64, stream, s);
+            }
 
             PrefillArgs p;
             memset(&p, 0, sizeof(p));

@@ -72,6 +72,8 @@ struct GemvJob
     int a_mode, c_mode;
     int mul_r_weights;
     float norm_eps;
+    int rows_as_prev;             // prefill passes: same input rows, transform and packed order as the previous job of the call
+                                  // (q | k | v, gate | up with one act-order permutation): its staged copy is reused
     int tile0;                    // first block index (x) of this job inside a fused launch
     int a_stride;                 // LDS row stride of the staged activations, in halfs
     int rows_per_phase;           // max K rows staged per phase

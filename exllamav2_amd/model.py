@@ -34,7 +34,9 @@ class ExLlamaV2:
         self.ext = ext or ext_c
         cfg = config
         # per-device scratch arena (device.py:102-115): sized for one forward chunk
-        self.max_rows = max(cfg.max_input_len, cfg.max_batch_size)
+        # rows of one forward chunk: max_input_len x max_batch_size, as the reference sizes its scratch (model.py:195,
+        # attn.py:315, mlp.py:216) -- prefill GEMMs want the tallest chunk the arena allows (288 GB: 8 x 2048 rows of a 7B are 1 GB)
+        self.max_rows = cfg.max_input_len * max(1, cfg.max_batch_size)
         r, dev = self.max_rows, self.device
         self.temp_state = torch.empty((r, cfg.hidden_size), dtype=torch.float16, device=dev)
         self.temp_a = torch.empty((r, cfg.intermediate_size), dtype=torch.float16, device=dev)
@@ -129,7 +131,7 @@ class ExLlamaV2:
                 input_mask=None):
         """model.py:764-933: contiguous-cache forward with chunked prefill; advances cache.current_seq_len."""
         b, q_len = input_ids.shape
-        chunk = max(1, self.config.max_input_len // b)
+        chunk = max(1, self.max_rows // b)                    # model.py:833 effective_max_input_len
         past = cache.current_seq_len
         assert past + q_len <= cache.max_seq_len, "sequence exceeds cache"
         out = None

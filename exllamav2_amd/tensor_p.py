@@ -220,7 +220,7 @@ class ExLlamaV2TP(ExLlamaV2):
     def __init__(self, config, rank: int, world: int, device="cuda:0", ext=None, group=None):
         if getattr(config, "num_experts", 0):
             raise RuntimeError("tensor parallel: MoE blocks are not split (architecture.py:291-305 has no supports_tp)")
-        max_rows = max(config.max_input_len, config.max_batch_size)
+        max_rows = config.max_input_len * max(1, config.max_batch_size)
         self.full_config = config
         self.tp = TPContext(config, rank, world, device, max_rows, group)
         local = dataclasses.replace(
