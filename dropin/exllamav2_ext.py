@@ -101,7 +101,7 @@ matrix_fp16_to_q4 = _e.matrix_fp16_to_q4
 matrix_q4_to_fp16 = _e.matrix_q4_to_fp16
 for _n in ("layer_norm", "layer_norm_", "head_norm", "head_norm_", "softcap_", "gen_mrope_pos_ids", "gemm_half_half_half",
            "had_paley", "had_paley2", "pack_rows_4", "pack_columns", "quantize", "quantize_err", "quantize_range",
-           "quantize_range_inplace", "sim_anneal", "apply_rep_penalty", "logit_filter_exclusive",
+           "quantize_range_inplace", "sim_anneal", "logit_filter_exclusive",
            "dump_profile_results", "stloader_open_file", "stloader_close_file"):
     globals()[_n] = _out_of_scope(_n, "outside the quantized forward path (SURVEY.md 2.2: OUT OF SCOPE)")
 
@@ -150,19 +150,78 @@ def partial_strings_match(match, offsets, strings) -> int:
     return -1
 
 
+def apply_rep_penalty(sequence, penalty_max, sustain, decay, alpha_frequency, alpha_presence, logits) -> None:
+    """ext_sampling.cpp:32-72 over cpp/sampling.cpp:20-110 (host helper of the sampler, like fast_fadd_cpu): walks the last
+    `sustain + decay` tokens of each sequence backwards; the first encounter of a token divides (positive logit) or
+    multiplies its logit by the repetition penalty and subtracts the presence penalty, every encounter subtracts the
+    frequency penalty; inside the decay range the three penalties move linearly towards 1 / 0 / 0 (fp32 steps).
+    sequence int64 [bsz, seq_len], logits fp32 [bsz, 1, vocab] on the host, modified in place."""
+    f32 = _np.float32
+    seq = sequence.numpy()
+    lg = logits.view(logits.shape[0], -1).numpy()
+    vocab, seq_len = lg.shape[-1], seq.shape[-1]
+    for b in range(seq.shape[0]):
+        row = lg[b]
+        rep_p, freq_p, pres_p = f32(penalty_max), f32(alpha_frequency), f32(alpha_presence)
+        d_rep = d_freq = d_pres = f32(0.0)
+        if decay:
+            d_rep = (f32(1.0) - rep_p) / f32(decay)
+            d_freq = (f32(0.0) - freq_p) / f32(decay)
+            d_pres = (f32(0.0) - pres_p) / f32(decay)
+        sust = seq_len if sustain == -1 else int(sustain)
+        beg = max(seq_len - sust - int(decay), 0)
+        seen = set()
+        i = seq_len
+        while i > beg:
+            i -= 1
+            t = int(seq[b, i])
+            if 0 <= t < vocab:
+                if t not in seen:
+                    row[t] = (row[t] / rep_p) if row[t] > 0.0 else (row[t] * rep_p)
+                    row[t] = row[t] - pres_p
+                    seen.add(t)
+                row[t] = row[t] - freq_p
+            sust -= 1
+            if sust < 0:
+                rep_p = f32(rep_p + d_rep); freq_p = f32(freq_p + d_freq); pres_p = f32(pres_p + d_pres)
+
+
 def sample_basic(logits, temperature, top_k, top_p, top_a, min_p, tfs, typical, random, output_tokens, output_probs,
                  output_kprobs, output_ktokens, logit_filter, mirostat, mirostat_mu, mirostat_tau, mirostat_eta,
                  post_temperature, xtc_mask, xtc_probability, xtc_threshold, min_temp, max_temp, temp_exponent,
                  smoothing_factor, skew):
-    """ext_sampling.cpp sample_basic, the GREEDY case only (top_k == 1 or temperature == 0): what
-    ExLlamaV2Sampler.Settings.greedy() asks for and what the reference's test_inference.py measures.  The AVX2 sampler
-    chain (top-p / min-p / typical / mirostat / XTC ...) is outside the quantized forward path and raises."""
-    greedy = top_k == 1 or temperature == 0.0
-    if not greedy or mirostat or (xtc_probability and xtc_probability > 0.0):
-        raise NotImplementedError("exllamav2_ext.sample_basic: only greedy sampling (top_k = 1) is built in this drop-in; "
-                                  "the CPU sampler is outside the quantized forward path (SURVEY.md 2.2)")
+    """ext_sampling.cpp:93-301.  Greedy (top_k == 1 or temperature ~ 0: what ExLlamaV2Sampler.Settings.greedy() asks for and
+    test_inference.py measures) is an arg-max under the logit filter.  Temperature / top-k (1..500) / top-p / min-p -- the
+    reference's default Settings (sampler.py:54-69) -- run on the DEVICE sampler (csrc/sampling.hip: same candidates, same
+    order, same fp32 threshold sums, same random recurrence as the CPU sampler).  Everything else of the sampler chain
+    (top-a, tfs, typical, mirostat, XTC, skew, smoothing, dynamic temperature, the top-token report with sampling, top_k = 0
+    or > 500) is outside the quantized forward path and raises."""
+    greedy = top_k == 1 or temperature < 0.01
+    has_filter = logit_filter is not None and logit_filter.device.type != "meta"
+    if not greedy:
+        unsupported = [n for n, on in (("top_a", top_a > 0.0), ("tfs", 0.0 < tfs < 1.0), ("typical", 0.0 < typical < 1.0),
+                                       ("mirostat", bool(mirostat)), ("xtc", bool(xtc_probability and xtc_probability > 0.0)),
+                                       ("post_temperature / dynamic temperature", post_temperature != 1.0 or max_temp > min_temp),
+                                       ("smoothing_factor", smoothing_factor > 0.0), ("skew", skew != 0.0),
+                                       ("return_top_tokens", output_ktokens is not None and output_ktokens.device.type != "meta"),
+                                       ("top_k outside 1..500", not (1 <= top_k <= 500 and top_k < logits.shape[-1])))
+                       if on]
+        if unsupported:
+            raise NotImplementedError("exllamav2_ext.sample_basic: " + ", ".join(unsupported) + " not built in this drop-in "
+                                      "(device sampler: temperature, top_k 1..500, top_p, min_p, logit filter; SURVEY.md 2.2)")
+        dev = _torch.device("cuda", _torch.cuda.current_device())
+        x = logits.reshape(-1, logits.shape[-1]).to(dev, dtype=_torch.float32).contiguous()
+        f = logit_filter.reshape(x.shape).to(dev).contiguous() if has_filter else None
+        tok = _torch.empty((x.shape[0],), dtype=_torch.int32, device=dev)
+        prob = _torch.empty((x.shape[0],), dtype=_torch.float32, device=dev)
+        _e.sample_rows(x, temperature, top_k, top_p, min_p, random, tok, prob, logit_filter=f)
+        output_tokens.copy_(tok.to(output_tokens.device, dtype=output_tokens.dtype).view(output_tokens.shape))
+        output_probs.copy_(prob.to(output_probs.device).view(output_probs.shape))
+        return []
+    if mirostat or (xtc_probability and xtc_probability > 0.0):
+        raise NotImplementedError("exllamav2_ext.sample_basic: mirostat / XTC are not built in this drop-in (SURVEY.md 2.2)")
     x = logits.reshape(-1, logits.shape[-1]).float()
-    if logit_filter is not None and logit_filter.device.type != "meta":
+    if has_filter:
         x = x.masked_fill(~logit_filter.reshape(x.shape).bool(), float("-inf"))
     tok = _torch.argmax(x, dim=-1)
     output_tokens.copy_(tok.view(output_tokens.shape))

@@ -1,0 +1,298 @@
+// sampling.hip -- temperature / top-k / top-p / min-p sampling on the device.
+//
+// Replaces the reference's CPU sampler for these settings: sample_basic (exllamav2_ext/ext_sampling.cpp:93-301) over
+// softmax_cpu / top_k_cpu / top_p_cpu / min_p_cpu / normalize_cpu / multinomial_cpu (exllamav2_ext/cpp/sampling.cpp), which the
+// reference reaches after copying a row of fp32 logits to the host (dynamic.py:1224-1225).  Here the logits stay in HBM (fp16 as the
+// head projection wrote them, or fp32), one workgroup of 1024 threads owns a row, and only the token id and its probability
+// are written.
+//
+// Parity with the reference is TOKEN parity for the same `random`, so the candidate set, its order and the fp32 sums that are
+// compared with thresholds follow the reference exactly:
+//   * softmax: first maximum, expf((l - max) * (1 / T)), p = e * (1 / sum); only the order of the 32 K-term sum differs (tree);
+//   * top-k is what the reference's min-heap of (p, index) pairs leaves (sampling.cpp:484-515), found without a heap: the k-th
+//     largest probability theta by a 4 x 8-bit radix select over the fp32 bit patterns; every p > theta is kept; of the entries
+//     EQUAL to theta the heap keeps those inside the prefix that ends at the k-th entry >= theta, minus the lowest-indexed ones
+//     evicted by the larger entries that arrive later -- i.e. the LAST m of them in that prefix, m = k - #(p > theta); order =
+//     descending (p, index);
+//   * normalize / top-p / min-p / multinomial run on that <= 501-entry array in LDS, in place, by one thread, in the reference's
+//     fp32 operation order (they are sequential sums compared with thresholds).  top_p_cpu's heap is a stack on input sorted this
+//     way (every new pair is smaller than all pairs held); keep_threshold (sampling.cpp:569-592) is reproduced including its
+//     return of n + 1 entries when every entry passes (it swaps the last entry with position n, where the array still holds what
+//     an earlier stage left: the raw softmax probability of token k after top-k, or the first entry top-p dropped);
+//   * the random point is scaled by 0.9998 and, for rows after the first, advanced by the reference's recurrence
+//     (ext_sampling.cpp:273, 286-296).
+// Not built (the host refuses, never approximates): top_k = 0 or > 500 (the reference's quicksort regime has no defined tie
+// order), top-a, tfs, typical, mirostat, XTC, skew, smoothing, dynamic temperature, the top-token report.
+#include "hw.h"
+#include "errors.h"
+
+#define SAMPLE_THREADS 1024
+#define SAMPLE_KMAX 500
+
+struct SampleArgs
+{
+    const void* logits; int ld; int vocab;
+    const u8* filter;                 // [rows, vocab] bool, nullable
+    float temperature; int top_k; float top_p; float min_p; float random;
+    int* out_tokens; float* out_probs;
+    float* ws;                        // [rows, vocab] fp32: the row's probabilities (the reference's temp_probs)
+};
+
+template <typename T> DEV float logit_at(const T* row, int i) { return (float)row[i]; }
+
+// inclusive scan over the 64 lanes of a wave (every lane must call)
+DEV u32 wave_scan_incl(u32 v)
+{
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const u32 o = shfl_idx_u32(v, (lane_id() - d) & 63);
+        if (lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+template <typename T>
+KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
+{
+    SHARED float red_v[16];
+    SHARED int   red_i[16];
+    SHARED u32   hist[256];
+    SHARED u32   scan_ge[16], scan_eq[16];
+    SHARED u32   sel[8];              // 0: prefix key, 1: need, 2: P (prefix end), 3: c, 4: slot counter
+    SHARED float raw_p[SAMPLE_KMAX];
+    SHARED int   raw_i[SAMPLE_KMAX];
+    SHARED float cand_p[SAMPLE_KMAX + 2];
+    SHARED int   cand_i[SAMPLE_KMAX + 2];
+    SHARED float stk_p[SAMPLE_KMAX + 2];
+    SHARED int   stk_i[SAMPLE_KMAX + 2];
+
+    const int row = bid_x(), t = tid(), V = a.vocab, K = a.top_k;
+    const T* lr = (const T*)a.logits + (size_t)row * a.ld;
+    const u8* fr = a.filter ? a.filter + (size_t)row * V : nullptr;
+    float* ws = a.ws + (size_t)row * V;
+
+    // ---- 1. first maximum among the unfiltered logits (softmax_cpu_nonavx2: `logits[i] > maxl`, ascending i) -----------
+    float bv = -1e38f; int bi = 0x7fffffff;
+    for (int i = t; i < V; i += SAMPLE_THREADS)
+    {
+        if (fr && !fr[i]) continue;
+        const float v = logit_at(lr, i);
+        if (v > bv) { bv = v; bi = i; }
+    }
+    for (int mask = 1; mask < 64; mask <<= 1)
+    {
+        const float ov = shfl_xor_f32(bv, mask);
+        const int oi = (int)shfl_xor_u32((u32)bi, mask);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane_id() == 0) { red_v[wave_id()] = bv; red_i[wave_id()] = bi; }
+    block_sync();
+    for (int w = 0; w < 16; w++)
+        if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; }
+    const float maxl = bv; const int maxi = bi < V ? bi : 0;      // (a row with every entry filtered has no maximum)
+    block_sync();
+
+    // ---- 2. e = expf((l - max) / T), sum, p = e / sum ------------------------------------------------------------------
+    const float itemp = 1.0f / a.temperature;
+    float part = 0.0f;
+    for (int i = t; i < V; i += SAMPLE_THREADS)
+    {
+        float e = 0.0f;
+        if (!fr || fr[i]) { e = expf((logit_at(lr, i) - maxl) * itemp); part += e; }
+        ws[i] = e;
+    }
+    for (int mask = 1; mask < 64; mask <<= 1) part += shfl_xor_f32(part, mask);
+    if (lane_id() == 0) red_v[wave_id()] = part;
+    block_sync();
+    float esum = 0.0f;
+    for (int w = 0; w < 16; w++) esum += red_v[w];
+    const float isum = 1.0f / esum;
+    for (int i = t; i < V; i += SAMPLE_THREADS) ws[i] = ws[i] * isum;
+    if (t == 0) { sel[0] = 0; sel[1] = (u32)K; sel[4] = 0; }
+    block_sync();                      // (workgroup-scope: the row's probabilities are visible to every thread from here)
+
+    if (K == 1)
+    {
+        // top_k_cpu's greedy branch (sampling.cpp:459-481): the arg-max alone; normalize_cpu on one entry
+        if (t == 0)
+        {
+            const float p = ws[maxi];
+            a.out_tokens[row] = maxi;
+            a.out_probs[row] = p * (1.0f / p);
+        }
+        return;
+    }
+
+    // ---- 3. theta = k-th largest probability: radix select on the bit patterns (p >= 0: integer order = float order) ----
+    u32 prefix = 0, maskbits = 0;
+    for (int pass = 0; pass < 4; pass++)
+    {
+        const int shift = 24 - 8 * pass;
+        if (t < 256) hist[t] = 0;
+        block_sync();
+        for (int i = t; i < V; i += SAMPLE_THREADS)
+        {
+            const u32 key = f32_bits(ws[i]);
+            if ((key & maskbits) == prefix) atomic_add_u32(&hist[(key >> shift) & 255], 1u);
+        }
+        block_sync();
+        if (t == 0)
+        {
+            u32 need = sel[1], acc = 0; int d = 255;
+            for (; d > 0; d--) { if (acc + hist[d] >= need) break; acc += hist[d]; }
+            sel[0] = prefix | ((u32)d << shift);
+            sel[1] = need - acc;
+        }
+        block_sync();
+        prefix = sel[0]; maskbits |= 0xFFu << shift;
+    }
+    const u32 theta = prefix;
+    const u32 m = sel[1];              // entries equal to theta that survive
+
+    // ---- 4. which of the entries equal to theta: the last m inside the prefix ending at the k-th entry >= theta ----------
+    const int chunk = (V + SAMPLE_THREADS - 1) / SAMPLE_THREADS;
+    const int c0 = min(t * chunk, V), c1 = min(c0 + chunk, V);
+    u32 n_ge = 0, n_eq = 0;
+    for (int i = c0; i < c1; i++) { const u32 key = f32_bits(ws[i]); n_ge += key >= theta; n_eq += key == theta; }
+    const u32 inc_ge = wave_scan_incl(n_ge), inc_eq = wave_scan_incl(n_eq);
+    if (lane_id() == 63) { scan_ge[wave_id()] = inc_ge; scan_eq[wave_id()] = inc_eq; }
+    block_sync();
+    u32 ge_before = inc_ge - n_ge, eq_before = inc_eq - n_eq;
+    for (int w = 0; w < wave_id(); w++) { ge_before += scan_ge[w]; eq_before += scan_eq[w]; }
+    if (ge_before < (u32)K && ge_before + n_ge >= (u32)K)
+    {
+        u32 g = ge_before, e = eq_before;
+        for (int i = c0; i < c1; i++)
+        {
+            const u32 key = f32_bits(ws[i]);
+            g += key >= theta; e += key == theta;
+            if (g == (u32)K && key >= theta) { sel[2] = (u32)i; sel[3] = e; break; }
+        }
+    }
+    block_sync();
+    const int P = (int)sel[2];
+    const u32 first_rank = sel[3] - m;             // 0-based rank (among the entries == theta, ascending index) of the first kept
+    {
+        u32 e = eq_before;
+        for (int i = c0; i < c1; i++)
+        {
+            const float p = ws[i];
+            const u32 key = f32_bits(p);
+            bool take = key > theta;
+            if (key == theta) { take = (i <= P) && (e >= first_rank); e++; }
+            if (take)
+            {
+                const u32 slot = atomic_add_u32(&sel[4], 1u);
+                if (slot < (u32)SAMPLE_KMAX) { raw_p[slot] = p; raw_i[slot] = i; }
+            }
+        }
+    }
+    block_sync();
+
+    // ---- 5. descending (p, index) order by rank (the pairs are distinct); position k = what top_k_cpu left there -------
+    if (t < K)
+    {
+        const float p = raw_p[t]; const int ix = raw_i[t];
+        int rank = 0;
+        for (int j = 0; j < K; j++) { const float q = raw_p[j]; rank += (q > p) || (q == p && raw_i[j] > ix); }
+        cand_p[rank] = p; cand_i[rank] = ix;
+    }
+    if (t == SAMPLE_THREADS - 1) { cand_p[K] = ws[K]; cand_i[K] = K; cand_p[K + 1] = 0.0f; cand_i[K + 1] = 0; }
+    block_sync();
+    if (t != 0) return;
+
+    // ---- 6. the reference's sequential stages on the candidate array, in place (one thread; sums in the reference's order) ----
+    int n = K;
+    auto normalize = [&](int cnt)                                   // sampling.cpp:265-281
+    {
+        float s = 0.0f;
+        for (int i = 0; i < cnt; i++) s += cand_p[i];
+        const float is = 1.0f / s;
+        for (int i = 0; i < cnt; i++) cand_p[i] *= is;
+    };
+    normalize(n);
+    if (n > 1 && a.top_p > 0.0f && a.top_p < 1.0f)                  // sampling.cpp:524-566 (heap == stack on this order)
+    {
+        int top = 0;                                                // the heap's content = stk[0 .. top), minimum on top
+        float s = 0.0f;
+        for (int i = 0; i < n; i++)
+        {
+            const float p = cand_p[i];
+            if (p < 1e-6f) continue;
+            if (s > a.top_p && p < stk_p[top - 1]) continue;
+            stk_p[top] = p; stk_i[top] = cand_i[i]; top++;
+            s += p;
+            while (s > a.top_p && top > 1) { s -= stk_p[top - 1]; top--; }
+        }
+        // the result overwrites positions 0 .. top-1; everything behind keeps the previous stage's entries (min-p can reach one)
+        for (int i = 0; i < top; i++) { cand_p[i] = stk_p[i]; cand_i[i] = stk_i[i]; }
+        n = top;
+        normalize(n);
+    }
+    if (n > 1 && a.min_p > 0.0f && a.min_p < 1.0f)                  // sampling.cpp:620-640 + keep_threshold :569-592
+    {
+        float topv = cand_p[0];
+        for (int i = 1; i < n; i++) if (cand_p[i] > topv) topv = cand_p[i];
+        const float thr = topv * a.min_p;
+        int i = 0, j = n - 1;
+        while (j >= i)
+        {
+            while (cand_p[i] >= thr && j >= i) i++;
+            if (cand_p[j] >= thr)
+            {
+                const float tp_ = cand_p[i]; cand_p[i] = cand_p[j]; cand_p[j] = tp_;
+                const int ti_ = cand_i[i]; cand_i[i] = cand_i[j]; cand_i[j] = ti_;
+                i++;
+            }
+            j--;
+        }
+        n = i;
+        normalize(n);
+    }
+    float random = a.random;
+    for (int r = 0; r < row; r++)                                   // ext_sampling.cpp:286-296, once per earlier row
+    {
+        float x = random;
+        for (int j = 0; j < 10; j++) { x = (float)((double)x + (1.337 + (double)random)); x *= x; x = fmodf(x, 1.0f); }
+        random = x;
+    }
+    const float radj = (float)((double)random * 0.9998);            // :273
+    int idx = 0;
+    float accum = cand_p[0];
+    while (true)                                                    // sampling.cpp:894-906
+    {
+        if (accum >= radj) break;
+        if (idx == n - 1) { while (idx > 0 && cand_p[idx] == 0.0f) idx--; break; }
+        idx++;
+        accum += cand_p[idx];
+    }
+    a.out_tokens[row] = cand_i[idx];
+    a.out_probs[row] = cand_p[idx];
+}
+
+extern "C" {
+
+int exl2_sample_rows(const void* logits, int logits_f32, int rows, int vocab, int ld, const void* logit_filter,
+                     float temperature, int top_k, float top_p, float min_p, float random,
+                     int* out_tokens, float* out_probs, float* workspace, void* stream)
+{
+    EXL2_REQUIRE(logits && out_tokens && out_probs && workspace, "sample_rows: null argument");
+    EXL2_REQUIRE(vocab >= 2 && ld >= vocab, "sample_rows: vocab %d, row stride %d", vocab, ld);
+    if (temperature < 0.01f) { temperature = 1.0f; top_k = 1; }                       // ext_sampling.cpp:143-147
+    if (top_k < 1 || top_k > SAMPLE_KMAX || top_k >= vocab)
+        EXL2_FAIL(EXL2_E_UNSUPPORTED, "sample_rows: top_k %d outside [1, %d] (and < vocab): the reference's heap regime is what is built",
+                  top_k, SAMPLE_KMAX);
+    EXL2_REQUIRE(random >= 0.0f && random < 1.0f, "sample_rows: random %f not in [0, 1)", (double)random);
+    if (rows <= 0) return EXL2_OK;
+    SampleArgs a;
+    a.logits = logits; a.ld = ld; a.vocab = vocab; a.filter = (const u8*)logit_filter;
+    a.temperature = temperature; a.top_k = top_k; a.top_p = top_p; a.min_p = min_p; a.random = random;
+    a.out_tokens = out_tokens; a.out_probs = out_probs; a.ws = workspace;
+    if (logits_f32) LAUNCH(sample_rows_kernel<float>, dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a);
+    else            LAUNCH(sample_rows_kernel<f16>, dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
+}
+
+}  // extern "C"

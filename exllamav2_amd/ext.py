@@ -592,6 +592,34 @@ class ExtC:
                                                  self._ptr(hist_pos, torch.int32, "hist_pos"),
                                                  0 if history is None else history.shape[-1], int(pos_inc), self._stream(logits)))
 
+    def sample_rows(self, logits, temperature: float, top_k: int, top_p: float, min_p: float, random: float,
+                    out_tokens, out_probs, logit_filter=None, workspace=None, vocab: int | None = None):
+        """Temperature / top-k / top-p / min-p sampling on the device, one token per row, with the reference's candidate
+        order, thresholds and random recurrence (sample_basic, ext_sampling.cpp:93-301; csrc/sampling.hip).  logits fp16 or
+        fp32 [..., ld]; out_tokens int32 [rows], out_probs fp32 [rows]; logit_filter bool / uint8 [rows, vocab] or None;
+        workspace fp32 [rows, vocab] (allocated here when None).  Returns the workspace (the rows' probabilities)."""
+        ld = logits.shape[-1]
+        rows = logits.numel() // ld
+        v = int(vocab or ld)
+        if logits.dtype not in (torch.float16, torch.float32):
+            raise RuntimeError(f"sample_rows: logits must be fp16 or fp32, got {logits.dtype}")
+        if workspace is None:
+            workspace = torch.empty((rows, v), dtype=torch.float32, device=logits.device)
+        if workspace.numel() < rows * v:
+            raise RuntimeError("sample_rows: workspace smaller than rows x vocab")
+        f = None
+        if not _is_none(logit_filter):
+            f = logit_filter.view(torch.uint8) if logit_filter.dtype == torch.bool else logit_filter
+            if f.numel() != rows * v:
+                raise RuntimeError("sample_rows: logit_filter must be [rows, vocab]")
+        self.lib.check(self.lib.exl2_sample_rows(self._ptr(logits, None, "logits"), int(logits.dtype == torch.float32), rows, v, ld,
+                                                 self._ptr(f, torch.uint8, "logit_filter"), float(temperature), int(top_k),
+                                                 float(top_p), float(min_p), float(random),
+                                                 self._ptr(out_tokens, torch.int32, "out_tokens"),
+                                                 self._ptr(out_probs, torch.float32, "out_probs"),
+                                                 self._ptr(workspace, torch.float32, "workspace"), self._stream(logits)))
+        return workspace
+
     def add_i32_(self, t, value: int) -> None:
         self.lib.check(self.lib.exl2_add_i32(self._ptr(t, torch.int32, "t"), t.numel(), int(value), self._stream(t)))
 

@@ -234,6 +234,18 @@ int exl2_embed_rows(const void* table, const int* ids, void* out, int rows, int 
 int exl2_argmax_rows(const void* logits, int* out_ids, int rows, int vocab, int ld,
                      int* history, int* hist_pos, int hist_stride, int pos_inc, void* stream);
 int exl2_add_i32(int* p, int n, int value, void* stream);
+/* temperature / top-k / top-p / min-p sampling on the device, one token per row (csrc/sampling.hip).  Replaces, for these
+   settings, sample_basic (exllamav2_ext/ext_sampling.cpp:93-301; binding ext_bindings.cpp:37) and the CPU stages it calls
+   (exllamav2_ext/cpp/sampling.cpp: softmax_cpu :113-192, top_k_cpu :443-520, normalize_cpu :265-281, top_p_cpu :524-566,
+   min_p_cpu :620-640 + keep_threshold :569-592, multinomial_cpu :872-915) together with the logits' trip to the host
+   (dynamic.py:1224-1225).  logits: [rows, ld] fp16 (logits_f32 = 0) or fp32 (1), vocab <= ld; logit_filter: nullable
+   bool [rows, vocab] (0 = token excluded); random in [0, 1): the point of the first row, later rows advance it with the
+   reference's recurrence (:286-296).  temperature < 0.01 means greedy (:143-147).  top_k must end up in [1, 500] and below
+   vocab (the reference's heap regime) -- anything else is EXL2_E_UNSUPPORTED, never an approximation.  out_tokens int32
+   [rows], out_probs fp32 [rows] (probability of the token among the final candidates), workspace fp32 [rows, vocab]. */
+int exl2_sample_rows(const void* logits, int logits_f32, int rows, int vocab, int ld, const void* logit_filter,
+                     float temperature, int top_k, float top_p, float min_p, float random,
+                     int* out_tokens, float* out_probs, float* workspace, void* stream);
 int exl2_graph_begin_capture(void* stream);
 int exl2_graph_end_capture(void* stream, void** graph_exec);
 int exl2_graph_launch(void* graph_exec, void* stream);

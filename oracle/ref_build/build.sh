@@ -9,9 +9,9 @@ OUT="$HERE/../_ref"
 [ -d "$REF/cuda/quant" ] || { echo "reference sources not found under $REF" >&2; exit 3; }
 mkdir -p "$OUT"
 # up to date?  (every output newer than the recipe's files and than the reference sources it compiles)
-if [ -z "$EXL2_REF_FORCE" ] && [ -f "$OUT/libqdq_ref.so" ] && [ -f "$OUT/libcacheq_ref.so" ] && [ -f "$OUT/libqmatrix_ref.so" ] && [ -f "$OUT/librope_ref.so" ] && [ -f "$OUT/librmsnorm_ref.so" ] && [ -f "$OUT/libmoe_ref.so" ] && [ -f "$OUT/libactmul_ref.so" ] && [ -f "$OUT/reference_py/exllamav2/model.py" ]; then
-    OLDEST=$(ls -t "$OUT"/libqdq_ref.so "$OUT"/libcacheq_ref.so "$OUT"/libqmatrix_ref.so "$OUT"/librope_ref.so "$OUT"/librmsnorm_ref.so "$OUT"/libmoe_ref.so "$OUT"/libactmul_ref.so | tail -1)
-    if [ -z "$(find "$HERE" "$REF/cuda/quant" "$REF/cuda/cache_q.cuh" "$REF/cuda/cache.cu" "$REF/cuda/q_matrix.cu" "$REF/cuda/rope.cu" "$REF/cuda/rms_norm.cu" "$REF/cuda/q_mlp_softmax.cuh" "$REF/cuda/q_mlp_activation.cuh" "$REF/cuda/q_gemm_kernel.cuh" "$REF/cuda/q_gemm_kernel_gptq.cuh" "$REF/cuda/matrix_view.cuh" "$REF/config.h" -type f -newer "$OLDEST" 2>/dev/null | head -1)" ]; then
+if [ -z "$EXL2_REF_FORCE" ] && [ -f "$OUT/libqdq_ref.so" ] && [ -f "$OUT/libcacheq_ref.so" ] && [ -f "$OUT/libqmatrix_ref.so" ] && [ -f "$OUT/librope_ref.so" ] && [ -f "$OUT/librmsnorm_ref.so" ] && [ -f "$OUT/libmoe_ref.so" ] && [ -f "$OUT/libactmul_ref.so" ] && [ -f "$OUT/libsampling_ref.so" ] && [ -f "$OUT/reference_py/exllamav2/model.py" ]; then
+    OLDEST=$(ls -t "$OUT"/libqdq_ref.so "$OUT"/libcacheq_ref.so "$OUT"/libqmatrix_ref.so "$OUT"/librope_ref.so "$OUT"/librmsnorm_ref.so "$OUT"/libmoe_ref.so "$OUT"/libactmul_ref.so "$OUT"/libsampling_ref.so | tail -1)
+    if [ -z "$(find "$HERE" "$REF/cuda/quant" "$REF/cuda/cache_q.cuh" "$REF/cuda/cache.cu" "$REF/cuda/q_matrix.cu" "$REF/cuda/rope.cu" "$REF/cuda/rms_norm.cu" "$REF/cuda/q_mlp_softmax.cuh" "$REF/cuda/q_mlp_activation.cuh" "$REF/cuda/q_gemm_kernel.cuh" "$REF/cuda/q_gemm_kernel_gptq.cuh" "$REF/cuda/matrix_view.cuh" "$REF/config.h" "$REF/cpp/sampling.cpp" "$REF/cpp/sampling_avx2.cpp" -type f -newer "$OLDEST" 2>/dev/null | head -1)" ]; then
         echo "oracle/_ref is up to date"; exit 0
     fi
 fi
@@ -76,6 +76,11 @@ echo "built $OUT/libmoe_ref.so"
 $CXX -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-value -I"$HERE" -I"$HERE/stubs" -I"$REF" \
     "$HERE/act_mul_driver.cpp" "$HERE/simt_host.cpp" -o "$OUT/libactmul_ref.so"
 echo "built $OUT/libactmul_ref.so"
+# cpp/sampling.cpp (+ its AVX2 twin and the profiling stubs it calls): the CPU sampler, plain C++, compiled as it lies
+# (g++: clang++ rejects a template call in sampling.cpp that g++ -- the reference's compiler -- accepts)
+${HOSTCXX:-g++} -std=c++17 -O2 -fPIC -shared -Wno-unused-value -I"$REF" -I"$REF/cpp" \
+    "$HERE/sampling_driver.cpp" "$REF/cpp/sampling.cpp" "$REF/cpp/sampling_avx2.cpp" "$REF/cpp/profiling.cpp" -o "$OUT/libsampling_ref.so"
+echo "built $OUT/libsampling_ref.so"
 # The reference's HOST code (its Python package, *.py only -- no kernels, no C++) mirrored for the GPU box, which has no
 # /root/reference: tests/test_dropin_reference.py runs that unmodified package on top of dropin/exllamav2_ext.py there.
 # Build-time mirror into the git-ignored oracle/_ref (like the kernel text above); nothing of it is committed.

@@ -1,0 +1,187 @@
+"""Device sampler (csrc/sampling.hip) against the reference's CPU sampler.
+
+Chain of evidence: the reference's own cpp/sampling.cpp, compiled for the host and driven in sample_basic's order
+(oracle/ref_build/sampling_driver.cpp), produced tests/golden/reference_sampling.npz; oracle/sampling.py restates it and must
+reproduce the fixture bit for bit (tokens, probabilities, candidate counts -- including keep_threshold's n + 1 quirk); the
+kernel must then sample the SAME TOKEN as the oracle for the same random number, on every row whose decisions do not hinge
+on the last bits of a sum (the oracle reports how close the closest threshold comparison was; the kernel's softmax sum is a
+tree sum, the reference's a sequential one)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_golden_sampling as gold          # noqa: E402
+from oracle import sampling as osamp         # noqa: E402
+
+MARGIN = 2e-5                                 # decisions closer than this to a threshold are not compared (fp32 sums near 1)
+
+
+def test_oracle_reproduces_the_executed_reference_fixture():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "reference_sampling.npz"))
+    quirk = 0
+    for i, (lg, flt, st, rnd) in enumerate(gold.cases()):
+        tok, pr, _, nc = osamp.sample_basic(lg, st[0], st[1], st[2], st[3], rnd, flt)
+        assert np.array_equal(tok, z["tokens"][i]), (i, st)
+        assert np.array_equal(pr.view(np.uint32), z["probs"][i].view(np.uint32)), (i, st)
+        assert np.array_equal(nc, z["num_candidates"][i]), (i, st)
+        quirk += int((nc > st[1]).sum())
+    # the fixture exercises keep_threshold's "every entry passes -> n + 1 entries" path (cpp/sampling.cpp:569-592)
+    assert quirk >= 1
+
+
+def test_oracle_reproduces_the_live_reference():
+    if not os.path.exists(gold.LIB):
+        pytest.skip("oracle/_ref/libsampling_ref.so not built (needs /root/reference at build time)")
+    lib = gold.load()
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        v = int(rng.integers(40, 700))
+        lg = np.ascontiguousarray((rng.standard_normal((2, v)) * rng.uniform(0.5, 5)).astype(np.float16), dtype=np.float32)
+        st = (float(rng.uniform(0.3, 1.6)), int(rng.integers(1, min(v - 1, 300))), float(rng.choice([0.0, 0.4, 0.9])),
+              float(rng.choice([0.0, 0.02, 0.2])))
+        rnd = float(rng.random())
+        tok, pr, nc = gold.run_reference(lib, lg, None, st, rnd, 0)
+        t2, p2, _, n2 = osamp.sample_basic(lg, st[0], st[1], st[2], st[3], rnd, None)
+        assert np.array_equal(tok, t2) and np.array_equal(pr.view(np.uint32), p2.view(np.uint32)) and np.array_equal(nc, n2), (trial, st)
+
+
+def _run_kernel(be, lg, flt, st, rnd, dtype=np.float32):
+    torch = be.torch
+    rows = lg.shape[0]
+    out_t = torch.zeros(rows, dtype=torch.int32, device=be.device)
+    out_p = torch.zeros(rows, dtype=torch.float32, device=be.device)
+    f = None if flt is None else be.t(flt.astype(np.uint8))
+    be.ext.sample_rows(be.t(lg.astype(dtype)), st[0], st[1], st[2], st[3], rnd, out_t, out_p, logit_filter=f)
+    return be.n(out_t), be.n(out_p)
+
+
+@pytest.mark.hip_unverified
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_sample_rows_equals_oracle_on_the_fixture_cases(be, dtype):
+    compared = total = 0
+    for i, (lg, flt, st, rnd) in enumerate(gold.cases()):
+        tok, pr, margin, _ = osamp.sample_basic(lg, st[0], st[1], st[2], st[3], rnd, flt)
+        got_t, got_p = _run_kernel(be, lg, flt, st, rnd, dtype)
+        for r in range(lg.shape[0]):
+            total += 1
+            if margin[r] < MARGIN:
+                continue
+            compared += 1
+            assert got_t[r] == tok[r], (i, r, st, got_t, tok, margin)
+            assert abs(float(got_p[r]) - float(pr[r])) <= 2e-5 * max(1.0, float(pr[r])) + 1e-6, (i, r, st, got_p, pr)
+    assert compared >= 0.8 * total, (compared, total)
+
+
+@pytest.mark.hip_unverified
+def test_sample_rows_random_sweep_ties_and_the_extra_candidate(be):
+    """One row, coarse logits (exact ties across the top-k boundary), a min-p low enough that every candidate passes (the
+    reference then samples from k + 1 entries), swept over the whole range of the random point."""
+    rng = np.random.default_rng(21)
+    lg = (np.round(rng.standard_normal((1, 300)) * 8) / 4).astype(np.float32)
+    compared = 0
+    seen = set()
+    for st in [(1.5, 12, 0.0, 0.001), (1.0, 30, 0.0, 0.0), (2.5, 7, 0.97, 0.001), (1.0, 64, 0.6, 0.0)]:
+        for rnd in np.linspace(0.0, 0.99999, 41):
+            tok, pr, margin, nc = osamp.sample_basic(lg, st[0], st[1], st[2], st[3], float(rnd), None)
+            got_t, got_p = _run_kernel(be, lg, None, st, float(rnd))
+            if margin[0] < MARGIN:
+                continue
+            compared += 1
+            seen.add((st[1], int(nc[0])))
+            assert got_t[0] == tok[0], (st, rnd, got_t, tok, nc, margin)
+    assert compared > 120
+    assert (12, 13) in seen                   # keep_threshold handed back k + 1 entries and the kernel followed
+
+
+@pytest.mark.hip_unverified
+def test_sample_rows_full_vocabulary_fp16_logits(be):
+    rng = np.random.default_rng(8)
+    lg = (rng.standard_normal((2, 32000)) * 2.5).astype(np.float16)
+    for st, rnd in [((0.8, 50, 0.8, 0.0), 0.37), ((1.0, 500, 0.95, 0.01), 0.81)]:
+        tok, pr, margin, _ = osamp.sample_basic(lg, st[0], st[1], st[2], st[3], rnd, None)
+        got_t, got_p = _run_kernel(be, lg, None, st, rnd, np.float16)
+        for r in range(2):
+            if margin[r] >= MARGIN:
+                assert got_t[r] == tok[r], (st, r, got_t, tok)
+
+
+@pytest.mark.hip_unverified
+def test_sample_rows_greedy_is_the_first_maximum(be):
+    lg = np.zeros((2, 900), dtype=np.float32)
+    lg[0, 17] = lg[0, 400] = 5.0
+    lg[1, 3] = 2.0
+    got_t, got_p = _run_kernel(be, lg, None, (0.0, 50, 0.8, 0.0), 0.5)       # temperature < 0.01 -> greedy (ext_sampling.cpp:143-147)
+    assert got_t.tolist() == [17, 3]
+    flt = np.ones((2, 900), dtype=bool); flt[0, 17] = False
+    got_t, _ = _run_kernel(be, lg, flt, (1.0, 1, 0.0, 0.0), 0.5)
+    assert got_t.tolist() == [400, 3]
+
+
+def test_sample_rows_refuses_what_is_not_built(be):
+    torch = be.torch
+    lg = be.t(np.zeros((1, 64), dtype=np.float32))
+    t, p = torch.zeros(1, dtype=torch.int32, device=be.device), torch.zeros(1, dtype=torch.float32, device=be.device)
+    for k in (0, 501, 64):
+        with pytest.raises(RuntimeError):
+            be.ext.sample_rows(lg, 1.0, k, 0.0, 0.0, 0.5, t, p)
+    with pytest.raises(RuntimeError):
+        be.ext.sample_rows(lg, 1.0, 10, 0.0, 0.0, 1.5, t, p)
+
+
+def test_dropin_apply_rep_penalty_reproduces_the_executed_reference():
+    """dropin apply_rep_penalty (host helper of the sampler, ext_sampling.cpp:32-72) against the reference's
+    apply_rep_penalty_cpu run on the host: bit for bit, every setting of the fixture (decay ramps, ids outside the vocabulary)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    try:
+        import exllamav2_ext as dropin
+    except (OSError, RuntimeError) as e:                      # the drop-in binds libexl2_hip.so at import
+        pytest.skip(f"drop-in not importable here: {e}")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "reference_sampling.npz"))
+    seq, lg = gold.rep_cases()
+    for i, st in enumerate(gold.REP_SETTINGS):
+        got = torch.from_numpy(lg.copy()).view(2, 1, -1)
+        dropin.apply_rep_penalty(torch.from_numpy(seq), st[0], st[1], st[2], st[3], st[4], got)
+        assert np.array_equal(got.view(2, -1).numpy().view(np.uint32), z["rep_penalty_logits"][i].view(np.uint32)), st
+
+
+@pytest.mark.gpu
+@pytest.mark.hip_unverified
+def test_dropin_sample_basic_with_the_reference_default_settings():
+    """ext_c.sample_basic as ExLlamaV2Sampler.sample calls it (sampler.py:540-568: fp32 logits [bsz, 1, vocab] on the host,
+    int64 / fp32 outputs on the host, `none_tensor` on the meta device for the unused ones) with the reference's default
+    Settings (temperature 0.8, top_k 50, top_p 0.8; sampler.py:54-69) after its default repetition penalty."""
+    import torch
+    if os.environ.get("EXL2_RUN_UNVERIFIED", "0") != "1":
+        pytest.skip("not yet run on a GPU (EXL2_RUN_UNVERIFIED=1 to run)")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    import exllamav2_ext as dropin
+    rng = np.random.default_rng(3)
+    none = torch.empty((1, 1), device="meta")
+    ok = 0
+    for trial in range(6):
+        lg = (rng.standard_normal((2, 4096)) * 3).astype(np.float16).astype(np.float32)
+        seq = rng.integers(0, 4096, size=(2, 20)).astype(np.int64)
+        logits = torch.from_numpy(lg.copy()).view(2, 1, -1)
+        dropin.apply_rep_penalty(torch.from_numpy(seq), 1.025, -1, 0, 0.0, 0.0, logits)
+        rnd = float(rng.random())
+        out_t = torch.empty((2, 1), dtype=torch.long)
+        out_p = torch.empty((2, 1), dtype=torch.float)
+        dropin.sample_basic(logits, 0.8, 50, 0.8, 0.0, 0.0, 0.0, 0.0, rnd, out_t, out_p, none, none, none, False, [], 1.5, 0.1,
+                            1.0, none, 0.0, 0.1, 0.0, 0.0, 1.0, 0.0, 0.0)
+        tok, pr, margin, _ = osamp.sample_basic(logits.view(2, -1).numpy(), 0.8, 50, 0.8, 0.0, rnd, None)
+        for r in range(2):
+            if margin[r] >= MARGIN:
+                assert int(out_t[r, 0]) == int(tok[r]), (trial, r, out_t, tok)
+                ok += 1
+    assert ok >= 8
+    with pytest.raises(NotImplementedError):
+        dropin.sample_basic(logits, 0.8, 50, 0.8, 0.0, 0.0, 0.5, 0.0, 0.5, out_t, out_p, none, none, none, False, [], 1.5, 0.1,
+                            1.0, none, 0.0, 0.1, 0.0, 0.0, 1.0, 0.0, 0.0)       # tfs
