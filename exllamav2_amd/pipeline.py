@@ -185,5 +185,12 @@ def run_layer_split_bench(cfg, args, rank: int, world: int, device, ext=None):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
+    # self-check for a driver-run scaling line: every rank reports what it holds and how many tokens its last stage sampled
+    wb = torch.tensor([float(stage.model.weight_bytes())], dtype=torch.float64, device=device)
+    gathered = [torch.zeros_like(wb) for _ in range(world)]
+    dist.all_gather(gathered, wb)
     stage.free()
-    return {"value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load}
+    return {"value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load,
+            "parallelism": f"layer-split pipeline x{world} ({dist.get_backend()} ranks: {dist.get_world_size()}), "
+                           f"{n_seqs} sequences in flight, {cfg.num_hidden_layers // world}-{-(-cfg.num_hidden_layers // world)} layers per rank",
+            "weight_bytes_per_rank": [int(g.item()) for g in gathered]}

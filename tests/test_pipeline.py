@@ -71,6 +71,10 @@ def _bench_worker(rank, world, port):
     args = argparse.Namespace(ctx=3, steps=4, warmup=2, ramp=2, recipe="4.0bpw", no_graph=True, cache="fp16")
     r = run_layer_split_bench(_cfg(), args, rank, world, "cpu", ext=_emu_ext())
     assert r["value"] > 0 and r["ms_per_step"] > 0
+    # the self-check fields of a driver-run scaling line: one weight figure per rank (the last rank also holds the head)
+    wb = r["weight_bytes_per_rank"]
+    assert len(wb) == world and all(b > 0 for b in wb) and wb[-1] > wb[0]
+    assert f"ranks: {world}" in r["parallelism"]
     dist.destroy_process_group()
 
 
