@@ -37,6 +37,9 @@ def parse():
     p.add_argument("--recipe", default="4.0bpw")
     p.add_argument("--ctx", type=int, default=0, help="tokens already in the KV cache when timing starts")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-baseline-only", action="store_true",
+                   help="print only the cpu_baseline object (how the main run obtains it: in a child process, so that a host "
+                        "out-of-memory kill or a hang there cannot take the GPU line with it)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-parity-check", action="store_true", help="skip the pre-timing oracle check of the device logits")
     p.add_argument("--no-ctx-window", action="store_true", help="skip the extra ctx-1920 decode window")
@@ -291,6 +294,13 @@ def cpu_baseline(cfg, recipe: str, seed: int = 0):
     try:
         import psutil
         avail = psutil.virtual_memory().available
+        for f in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):    # a container's own limit
+            try:
+                lim = open(f).read().strip()
+                if lim.isdigit():
+                    avail = min(avail, int(lim))
+            except OSError:
+                pass
     except Exception:
         avail = 0
     if avail > 2.5 * full_gb * 1e9 and full_gb < 200:
@@ -332,6 +342,23 @@ def cpu_baseline(cfg, recipe: str, seed: int = 0):
     return out
 
 
+def cpu_baseline_in_child(args, timeout_s: int = 420):
+    """Runs `bench.py --cpu-baseline-only` as a child process and returns its JSON object: the baseline allocates tens of GB
+    of host memory and runs for tens of seconds -- a kill or a hang there must not cost the GPU line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--model", args.model, "--recipe", args.recipe]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"value": None, "error": f"child rc={r.returncode}: {(r.stderr or '').strip()[-160:]}"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": f"child exceeded {timeout_s} s"}
+    except Exception as e:
+        return {"value": None, "error": str(e)[:200]}
+
+
 def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq: int = 2048):
     """BASELINE configs[2] beside the headline: test_inference.py -ps procedure (:533-579), forward(ids[8, 2048],
     preprocess_only=True) on a fresh synthetic model, all layers, the product route (row pre-pass + dequantize-into-MFMA
@@ -367,6 +394,9 @@ def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq:
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(make_cfg(args.model, 2048), args.recipe)))
+        return
     import torch
     import torch.distributed as dist
 
@@ -510,10 +540,7 @@ def finish(args, cfg, result, rank, world, n_gpus, device, dist):
             except Exception as e:  # informational; never lose the headline number
                 out["prefill"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and n_gpus == 1:
-            try:
-                out["cpu_baseline"] = cpu_baseline(cfg, args.recipe)
-            except Exception as e:  # baseline is informational; never lose the GPU number
-                out["cpu_baseline"] = {"value": None, "error": str(e)[:200]}
+            out["cpu_baseline"] = cpu_baseline_in_child(args)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

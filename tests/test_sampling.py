@@ -60,7 +60,6 @@ def _run_kernel(be, lg, flt, st, rnd, dtype=np.float32):
     return be.n(out_t), be.n(out_p)
 
 
-@pytest.mark.hip_unverified
 @pytest.mark.parametrize("dtype", [np.float32, np.float16])
 def test_sample_rows_equals_oracle_on_the_fixture_cases(be, dtype):
     compared = total = 0
@@ -77,7 +76,6 @@ def test_sample_rows_equals_oracle_on_the_fixture_cases(be, dtype):
     assert compared >= 0.8 * total, (compared, total)
 
 
-@pytest.mark.hip_unverified
 def test_sample_rows_random_sweep_ties_and_the_extra_candidate(be):
     """One row, coarse logits (exact ties across the top-k boundary), a min-p low enough that every candidate passes (the
     reference then samples from k + 1 entries), swept over the whole range of the random point."""
@@ -98,7 +96,6 @@ def test_sample_rows_random_sweep_ties_and_the_extra_candidate(be):
     assert (12, 13) in seen                   # keep_threshold handed back k + 1 entries and the kernel followed
 
 
-@pytest.mark.hip_unverified
 def test_sample_rows_full_vocabulary_fp16_logits(be):
     rng = np.random.default_rng(8)
     lg = (rng.standard_normal((2, 32000)) * 2.5).astype(np.float16)
@@ -110,7 +107,6 @@ def test_sample_rows_full_vocabulary_fp16_logits(be):
                 assert got_t[r] == tok[r], (st, r, got_t, tok)
 
 
-@pytest.mark.hip_unverified
 def test_sample_rows_greedy_is_the_first_maximum(be):
     lg = np.zeros((2, 900), dtype=np.float32)
     lg[0, 17] = lg[0, 400] = 5.0
@@ -151,14 +147,11 @@ def test_dropin_apply_rep_penalty_reproduces_the_executed_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.hip_unverified
 def test_dropin_sample_basic_with_the_reference_default_settings():
     """ext_c.sample_basic as ExLlamaV2Sampler.sample calls it (sampler.py:540-568: fp32 logits [bsz, 1, vocab] on the host,
     int64 / fp32 outputs on the host, `none_tensor` on the meta device for the unused ones) with the reference's default
     Settings (temperature 0.8, top_k 50, top_p 0.8; sampler.py:54-69) after its default repetition penalty."""
     import torch
-    if os.environ.get("EXL2_RUN_UNVERIFIED", "0") != "1":
-        pytest.skip("not yet run on a GPU (EXL2_RUN_UNVERIFIED=1 to run)")
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     sys.path.insert(0, os.path.join(ROOT, "dropin"))
