@@ -38,7 +38,54 @@ struct SampleArgs
     float* ws;                        // [rows, vocab] fp32: the row's probabilities (the reference's temp_probs)
 };
 
-template <typename T> DEV float logit_at(const T* row, int i) { return (float)row[i]; }
+// Row walks.  A row whose length and stride are multiples of 4 elements on a 16-byte-aligned base (every real vocabulary) is
+// walked in quads -- 16-byte (fp32) / 8-byte (fp16) accesses, four independent loads in flight per thread: one workgroup owns
+// a row, so what bounds a pass is load latency, not bandwidth -- any other row element by element.  Ascending index per thread.
+DEV f32x4 load_quad(const float* p) { return *(const f32x4*)p; }
+DEV f32x4 load_quad(const f16* p) { const f16x4 h = *(const f16x4*)p; return (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w}; }
+
+// fn(i, value) for every element of row[0 .. V), elements dealt to the threads quad by quad (vec) or one by one
+template <typename T, typename F>
+DEV void for_row(const T* row, int V, bool vec, F fn)
+{
+    const int t = tid();
+    if (vec)
+    {
+        const int nq = V >> 2;
+        for (int q0 = t; q0 < nq; q0 += 4 * SAMPLE_THREADS)
+        {
+            f32x4 v[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) { const int q = q0 + u * SAMPLE_THREADS; if (q < nq) v[u] = load_quad(row + 4 * (size_t)q); }
+            #pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const int q = q0 + u * SAMPLE_THREADS;
+                if (q < nq) { fn(4 * q, v[u].x); fn(4 * q + 1, v[u].y); fn(4 * q + 2, v[u].z); fn(4 * q + 3, v[u].w); }
+            }
+        }
+    }
+    else for (int i = t; i < V; i += SAMPLE_THREADS) fn(i, (float)row[i]);
+}
+
+// fn(i, value) for the contiguous range [c0, c1) of an fp32 row, in ascending order (c0, c1 multiples of 4 when vec)
+template <typename F>
+DEV void for_range(const float* row, int c0, int c1, bool vec, F fn)
+{
+    if (vec)
+    {
+        for (int i0 = c0; i0 < c1; i0 += 16)
+        {
+            f32x4 v[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) if (i0 + 4 * u < c1) v[u] = load_quad(row + i0 + 4 * u);
+            #pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i0 + 4 * u < c1) { const int i = i0 + 4 * u; fn(i, v[u].x); fn(i + 1, v[u].y); fn(i + 2, v[u].z); fn(i + 3, v[u].w); }
+        }
+    }
+    else for (int i = c0; i < c1; i++) fn(i, row[i]);
+}
 
 // inclusive scan over the 64 lanes of a wave (every lane must call)
 DEV u32 wave_scan_incl(u32 v)
@@ -72,14 +119,11 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     const u8* fr = a.filter ? a.filter + (size_t)row * V : nullptr;
     float* ws = a.ws + (size_t)row * V;
 
+    const bool vec = ((V & 3) == 0) && ((a.ld & 3) == 0) && ((((size_t)a.logits) & 15) == 0) && ((((size_t)a.ws) & 15) == 0);
+
     // ---- 1. first maximum among the unfiltered logits (softmax_cpu_nonavx2: `logits[i] > maxl`, ascending i) -----------
     float bv = -1e38f; int bi = 0x7fffffff;
-    for (int i = t; i < V; i += SAMPLE_THREADS)
-    {
-        if (fr && !fr[i]) continue;
-        const float v = logit_at(lr, i);
-        if (v > bv) { bv = v; bi = i; }
-    }
+    for_row(lr, V, vec, [&](int i, float v) { if ((!fr || fr[i]) && v > bv) { bv = v; bi = i; } });
     for (int mask = 1; mask < 64; mask <<= 1)
     {
         const float ov = shfl_xor_f32(bv, mask);
@@ -96,10 +140,27 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     // ---- 2. e = expf((l - max) / T), sum, p = e / sum ------------------------------------------------------------------
     const float itemp = 1.0f / a.temperature;
     float part = 0.0f;
-    for (int i = t; i < V; i += SAMPLE_THREADS)
+    if (vec)
+    {
+        const int nq = V >> 2;
+        for (int q = t; q < nq; q += SAMPLE_THREADS)
+        {
+            const f32x4 l = load_quad(lr + 4 * (size_t)q);
+            f32x4 e;
+            #pragma unroll
+            for (int c = 0; c < 4; c++)
+            {
+                float x = 0.0f;
+                if (!fr || fr[4 * q + c]) { x = expf((l[c] - maxl) * itemp); part += x; }
+                e[c] = x;
+            }
+            *(f32x4*)(ws + 4 * (size_t)q) = e;
+        }
+    }
+    else for (int i = t; i < V; i += SAMPLE_THREADS)
     {
         float e = 0.0f;
-        if (!fr || fr[i]) { e = expf((logit_at(lr, i) - maxl) * itemp); part += e; }
+        if (!fr || fr[i]) { e = expf(((float)lr[i] - maxl) * itemp); part += e; }
         ws[i] = e;
     }
     for (int mask = 1; mask < 64; mask <<= 1) part += shfl_xor_f32(part, mask);
@@ -108,7 +169,14 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     float esum = 0.0f;
     for (int w = 0; w < 16; w++) esum += red_v[w];
     const float isum = 1.0f / esum;
-    for (int i = t; i < V; i += SAMPLE_THREADS) ws[i] = ws[i] * isum;
+    if (vec)
+        for (int q = t; q < (V >> 2); q += SAMPLE_THREADS)
+        {
+            f32x4 e = *(const f32x4*)(ws + 4 * (size_t)q);
+            e.x *= isum; e.y *= isum; e.z *= isum; e.w *= isum;
+            *(f32x4*)(ws + 4 * (size_t)q) = e;
+        }
+    else for (int i = t; i < V; i += SAMPLE_THREADS) ws[i] = ws[i] * isum;
     if (t == 0) { sel[0] = 0; sel[1] = (u32)K; sel[4] = 0; }
     block_sync();                      // (workgroup-scope: the row's probabilities are visible to every thread from here)
 
@@ -125,17 +193,24 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     }
 
     // ---- 3. theta = k-th largest probability: radix select on the bit patterns (p >= 0: integer order = float order) ----
+    // A thread adds a run of equal digits with ONE LDS atomic: in the first pass nearly every entry of a row has the same top
+    // byte, and one atomic per entry would serialise 32 K adds on a single LDS word.
     u32 prefix = 0, maskbits = 0;
     for (int pass = 0; pass < 4; pass++)
     {
         const int shift = 24 - 8 * pass;
         if (t < 256) hist[t] = 0;
         block_sync();
-        for (int i = t; i < V; i += SAMPLE_THREADS)
+        u32 run_digit = 0, run_len = 0;
+        for_row(ws, V, vec, [&](int, float p)
         {
-            const u32 key = f32_bits(ws[i]);
-            if ((key & maskbits) == prefix) atomic_add_u32(&hist[(key >> shift) & 255], 1u);
-        }
+            const u32 key = f32_bits(p);
+            if ((key & maskbits) != prefix) return;
+            const u32 d = (key >> shift) & 255;
+            if (d != run_digit && run_len) { atomic_add_u32(&hist[run_digit], run_len); run_len = 0; }
+            run_digit = d; run_len++;
+        });
+        if (run_len) atomic_add_u32(&hist[run_digit], run_len);
         block_sync();
         if (t == 0)
         {
@@ -151,10 +226,10 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     const u32 m = sel[1];              // entries equal to theta that survive
 
     // ---- 4. which of the entries equal to theta: the last m inside the prefix ending at the k-th entry >= theta ----------
-    const int chunk = (V + SAMPLE_THREADS - 1) / SAMPLE_THREADS;
+    const int chunk = (((V + SAMPLE_THREADS - 1) / SAMPLE_THREADS) + 3) & ~3;      // contiguous share of a thread, in whole quads
     const int c0 = min(t * chunk, V), c1 = min(c0 + chunk, V);
     u32 n_ge = 0, n_eq = 0;
-    for (int i = c0; i < c1; i++) { const u32 key = f32_bits(ws[i]); n_ge += key >= theta; n_eq += key == theta; }
+    for_range(ws, c0, c1, vec, [&](int, float p) { const u32 key = f32_bits(p); n_ge += key >= theta; n_eq += key == theta; });
     const u32 inc_ge = wave_scan_incl(n_ge), inc_eq = wave_scan_incl(n_eq);
     if (lane_id() == 63) { scan_ge[wave_id()] = inc_ge; scan_eq[wave_id()] = inc_eq; }
     block_sync();
@@ -162,22 +237,21 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     for (int w = 0; w < wave_id(); w++) { ge_before += scan_ge[w]; eq_before += scan_eq[w]; }
     if (ge_before < (u32)K && ge_before + n_ge >= (u32)K)
     {
-        u32 g = ge_before, e = eq_before;
-        for (int i = c0; i < c1; i++)
+        u32 g = ge_before, e = eq_before; bool found = false;
+        for_range(ws, c0, c1, vec, [&](int i, float p)
         {
-            const u32 key = f32_bits(ws[i]);
+            const u32 key = f32_bits(p);
             g += key >= theta; e += key == theta;
-            if (g == (u32)K && key >= theta) { sel[2] = (u32)i; sel[3] = e; break; }
-        }
+            if (!found && g == (u32)K && key >= theta) { sel[2] = (u32)i; sel[3] = e; found = true; }
+        });
     }
     block_sync();
     const int P = (int)sel[2];
     const u32 first_rank = sel[3] - m;             // 0-based rank (among the entries == theta, ascending index) of the first kept
     {
         u32 e = eq_before;
-        for (int i = c0; i < c1; i++)
+        for_range(ws, c0, c1, vec, [&](int i, float p)
         {
-            const float p = ws[i];
             const u32 key = f32_bits(p);
             bool take = key > theta;
             if (key == theta) { take = (i <= P) && (e >= first_rank); e++; }
@@ -186,7 +260,7 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
                 const u32 slot = atomic_add_u32(&sel[4], 1u);
                 if (slot < (u32)SAMPLE_KMAX) { raw_p[slot] = p; raw_i[slot] = i; }
             }
-        }
+        });
     }
     block_sync();
 
