@@ -195,7 +195,7 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     // ---- 3. theta = k-th largest probability: radix select on the bit patterns (p >= 0: integer order = float order) ----
     // A thread adds a run of equal digits with ONE LDS atomic: in the first pass nearly every entry of a row has the same top
     // byte, and one atomic per entry would serialise 32 K adds on a single LDS word.
-    u32 prefix = 0, maskbits = 0;
+    u32 prefix = 0, maskbits = 0, need = (u32)K;
     for (int pass = 0; pass < 4; pass++)
     {
         const int shift = 24 - 8 * pass;
@@ -212,18 +212,27 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
         });
         if (run_len) atomic_add_u32(&hist[run_digit], run_len);
         block_sync();
-        if (t == 0)
+        // the digit whose bucket holds the need-th largest key: buckets taken from 255 down, one per thread of waves 0-3, a
+        // wave scan + four wave totals (a single thread walking the 256 counters costs ~12 us per pass in LDS round trips)
+        u32 h = 0, inc = 0;
+        if (t < 256)
         {
-            u32 need = sel[1], acc = 0; int d = 255;
-            for (; d > 0; d--) { if (acc + hist[d] >= need) break; acc += hist[d]; }
-            sel[0] = prefix | ((u32)d << shift);
-            sel[1] = need - acc;
+            h = hist[255 - t];
+            inc = wave_scan_incl(h);
+            if (lane_id() == 63) scan_ge[wave_id()] = inc;
         }
         block_sync();
-        prefix = sel[0]; maskbits |= 0xFFu << shift;
+        if (t < 256)
+        {
+            u32 above = inc - h;                                   // keys in buckets with a larger digit
+            for (int w = 0; w < wave_id(); w++) above += scan_ge[w];
+            if (above < need && above + h >= need) { sel[0] = prefix | ((u32)(255 - t) << shift); sel[1] = need - above; }
+        }
+        block_sync();
+        prefix = sel[0]; need = sel[1]; maskbits |= 0xFFu << shift;
     }
     const u32 theta = prefix;
-    const u32 m = sel[1];              // entries equal to theta that survive
+    const u32 m = need;                // entries equal to theta that survive
 
     // ---- 4. which of the entries equal to theta: the last m inside the prefix ending at the k-th entry >= theta ----------
     const int chunk = (((V + SAMPLE_THREADS - 1) / SAMPLE_THREADS) + 3) & ~3;      // contiguous share of a thread, in whole quads
