@@ -11,6 +11,7 @@ Works with any torch.distributed backend: nccl (= RCCL) on GPUs, gloo in the CPU
 """
 from __future__ import annotations
 
+import os
 import time
 
 import torch
@@ -60,9 +61,83 @@ class PipelineStage:
         self.graphs = {}
         self.pos = [0] * n_seqs                                   # host mirror of seqlens: the kernels do not bound-check
         self.limit = min(max_seq_len, cfg.max_seq_len)
+        self.chain = None
+        if os.environ.get("EXL2_CHAIN", "1") != "0":
+            self._setup_chain()
+
+    def _setup_chain(self):
+        """The chained decode route of model.GreedyGraphDecoder (csrc/qgemv_flat.hip: producers leave the residual stream in
+        the consumer's packed order + partial sums of squares) inside a stage.  Same conditions: dense chain-capable layers,
+        FP16 cache.  What differs at a stage boundary: a stage that is not the first receives x in natural order and
+        PUBLISHES it for its first layer with the embedding kernel reading the one-row table `msg_in` (id 0); a stage that is
+        not the last hands over the natural-order copy every chained epilogue also writes."""
+        m, ext, cfg = self.model, self.ext, self.cfg
+        if getattr(self.cache, "wbits", 0) or not m.layers:
+            return
+        plan = []
+        for attn, mlp in m.layers:
+            if not hasattr(mlp, "gate_proj") or mlp.q_handle is None or attn.q_handle is None:
+                return
+            cap_a, in_a, o_inv = ext.q_attn_chain_info(attn.q_handle)
+            cap_m, in_m = ext.q_mlp_chain_info(mlp.q_handle)
+            if not (cap_a and cap_m):
+                return
+            plan.append((in_a, o_inv, in_m))
+        dev, h = self.device, cfg.hidden_size
+        ch = {"plan": plan,
+              "xp_a": torch.zeros((1, h), dtype=torch.float16, device=dev), "xp_b": torch.zeros((1, h), dtype=torch.float16, device=dev),
+              "ss_a": torch.zeros((1, 256), dtype=torch.float32, device=dev), "ss_b": torch.zeros((1, 256), dtype=torch.float32, device=dev),
+              "id0": torch.zeros((1,), dtype=torch.int32, device=dev)}
+        if self.last:
+            if m.lm_head is None:
+                return
+            head_perm, head_inv = ext.q_matrix_perm_info(m.lm_head.q_handle)
+            ch["head_inv"] = head_inv
+            ch["norm_head"] = torch.empty_like(m.norm.weight)
+            ext.gather_f16(m.norm.weight, head_perm, ch["norm_head"])
+        self.chain = ch
+
+    def _step_chain(self, s: int):
+        m, ext, cfg, ch = self.model, self.ext, self.cfg, self.chain
+        plan = ch["plan"]
+        x2 = self.x.view(1, cfg.hidden_size)
+        q = m.temp_q[:1].view(1, 1, cfg.num_attention_heads, cfg.head_dim)
+        k = m.temp_k[:1].view(1, 1, cfg.num_key_value_heads, cfg.head_dim)
+        v = m.temp_v[:1].view(1, 1, cfg.num_key_value_heads, cfg.head_dim)
+        xp_a, xp_b, ss_a, ss_b = ch["xp_a"], ch["xp_b"], ch["ss_a"], ch["ss_b"]
+        if self.first:
+            self.ids.copy_(self.msg_in[:2].view(torch.int32))
+            ext.embed_rows_chain(m.embed_tokens, self.ids, x2, plan[0][0], xp_a, ss_a)
+        else:
+            ext.embed_rows_chain(self.msg_in.view(1, cfg.hidden_size), ch["id0"], x2, plan[0][0], xp_a, ss_a)
+        sl, bt = self.seqlens[s:s + 1], self.block_table[s:s + 1]
+        npart = 1
+        for i, (attn, mlp) in enumerate(m.layers):
+            in_a, o_inv, in_m = plan[i]
+            ext.q_attn_forward_1_chain(attn.q_handle, xp_a, ss_a, npart, 1, q, k, v)
+            ao = attn.attend_chain(q, k, v, self.cache, sl, bt, o_inv)
+            npart = ext.q_attn_forward_2_chain(attn.q_handle, x2, ao, 1, in_m, xp_b, ss_b)
+            # behind the stage's last layer of a non-last stage nothing reads the packed copy: any layer's order will do
+            nxt = plan[i + 1][0] if i + 1 < len(plan) else (ch["head_inv"] if self.last else plan[0][0])
+            npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, xp_b, ss_b, npart, 1, nxt, xp_a, ss_a)
+        ext.add_i32_(sl, 1)
+        if self.last:
+            ext.gemm_half_q_half_chain(xp_a, ss_a, npart, ch["norm_head"], cfg.norm_eps, m.lm_head.q_handle, self.logits, 1)
+            ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history[s:s + 1], sl)
+            self.msg_out.zero_()
+            self.msg_out[:2].view(torch.int32).copy_(self.ids)
+        else:
+            self.msg_out.copy_(self.x.view(-1))
 
     # one stage step for sequence s: msg_in -> (layers) -> msg_out
     def _step_eager(self, s: int):
+        if self.chain is not None:
+            try:
+                return self._step_chain(s)
+            except RuntimeError as e:
+                if "not covered" not in str(e):
+                    raise
+                self.chain = None               # a shape outside the chained kernels: the module-by-module route below
         m, ext, cfg = self.model, self.ext, self.cfg
         if self.first:
             self.ids.copy_(self.msg_in[:2].view(torch.int32))

@@ -169,3 +169,61 @@ def test_pipeline_stage_graph_on_gpu():
         assert dec.tokens(0, 3).cpu().numpy()[0].tolist() == toks[s]
         dec.free()
     stage.free()
+
+
+def _stages_by_hand(be, world, chain, n_tokens, firsts, use_graph):
+    """All `world` stages of a layer split in ONE process on the backend's device, messages passed by hand (what RCCL / gloo
+    do between ranks): first, middle and last stages, chained decode route on or off."""
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.pipeline import PipelineStage
+    cfg = ExLlamaV2Config(hidden_size=128, intermediate_size=256, num_hidden_layers=world + 1, num_attention_heads=2,
+                          num_key_value_heads=1, head_dim=64, vocab_size=96, max_seq_len=256, max_input_len=32)
+    old = os.environ.get("EXL2_CHAIN")
+    os.environ["EXL2_CHAIN"] = "1" if chain else "0"
+    try:
+        stages = [PipelineStage(cfg, r, world, be.device, n_seqs=len(firsts), max_seq_len=256, seed=5, ext=be.ext,
+                                use_graph=use_graph) for r in range(world)]
+    finally:
+        if old is None: os.environ.pop("EXL2_CHAIN")
+        else: os.environ["EXL2_CHAIN"] = old
+    assert all((st.chain is not None) == chain for st in stages)
+    for st in stages:
+        st.capture()
+    out = {s: [] for s in range(len(firsts))}
+    cur = dict(enumerate(firsts))
+    for _ in range(n_tokens):
+        for s in range(len(firsts)):
+            msg = torch.zeros_like(stages[0].msg_in)
+            msg[:2].view(torch.int32).copy_(torch.tensor([cur[s]], dtype=torch.int32))
+            for st in stages:
+                with st._on_stream():
+                    st.msg_in.copy_(msg)
+                st.step(s)
+                if be.device != "cpu":
+                    torch.cuda.synchronize()
+                msg = st.msg_out.clone()
+            cur[s] = int(msg[:2].view(torch.int32).item())
+            out[s].append(cur[s])
+    for st in stages:
+        st.free()
+    return cfg, out
+
+
+def test_pipeline_first_middle_last_stage_chained_equals_unchained_equals_single_process(be):
+    """Three stages over four layers (so one stage holds two layers): the chained decode route inside a stage (what
+    `bench.py --gpus N` runs) against the module-by-module route and against the single-process decoder, token for token."""
+    from exllamav2_amd.cache import ExLlamaV2Cache
+    from exllamav2_amd.model import ExLlamaV2, GreedyGraphDecoder
+    from exllamav2_amd.synth import synth_checkpoint
+    graph = be.device != "cpu"
+    cfg, chained = _stages_by_hand(be, 3, True, 4, [3, 11], graph)
+    _, plain = _stages_by_hand(be, 3, False, 4, [3, 11], graph)
+    assert chained == plain
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(synth_checkpoint(cfg, be.device, seed=5))
+    for s, tok0 in enumerate([3, 11]):
+        cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=256)
+        dec = GreedyGraphDecoder(model, cache, batch_size=1)
+        dec.reset(torch.tensor([tok0]), 0)
+        dec.run(4, use_graph=False)
+        assert be.n(dec.tokens(0, 4))[0].tolist() == chained[s], (s, chained[s])
+    model.unload()
