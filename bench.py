@@ -266,31 +266,79 @@ def cpu_baseline(cfg, recipe: str, seed: int = 0):
     del ws
     tokens = 8
     ncpu = os.cpu_count() or 1
-    best = None
+    layer_elems = sum(k * n for _, k, n in shapes)
+    full_gb = 4 * (cfg.num_hidden_layers * layer_elems + h * cfg.vocab_size) / 1e9
+    head_scale = (h * cfg.vocab_size) / layer_elems
+    silu = torch.nn.functional.silu
+
+    # mode "blas": torch.mv with the BLAS library's own threading.  mode "rows": every matrix cut into one row block per
+    # worker, each worker a single-threaded torch.mv on its block (a token = two fork/joins per layer: q|k|v|gate|up, then
+    # o|down) -- on many-core hosts the library's M = 1 threading is the bottleneck, not DRAM.  Both are timed on a one-layer
+    # probe over a few pool sizes; the faster one runs the full pass.
+    def layer_blas(lw, x):
+        q = torch.mv(lw[0], x); torch.mv(lw[1], x); torch.mv(lw[2], x); o = torch.mv(lw[3], q)
+        g = torch.mv(lw[4], x); u = torch.mv(lw[5], x); d = torch.mv(lw[6], silu(g) * u)
+        return x + 1e-3 * (o + d)
+
+    class RowPool:
+        def __init__(self, T):
+            from concurrent.futures import ThreadPoolExecutor
+            self.T, self.pool = T, ThreadPoolExecutor(T)
+        def cut(self, w, own=False):
+            """row blocks of one [N, K] matrix, one per worker; own=True: each worker makes its own copy (first touch on its node)"""
+            n = w.shape[0]
+            bounds = [(i * n // self.T, (i + 1) * n // self.T) for i in range(self.T)]
+            if not own:
+                return [w[a:b] for a, b in bounds]
+            return list(self.pool.map(lambda ab: w[ab[0]:ab[1]].clone(), bounds))
+        def stage(self, blocks_list, vec_list, outs):
+            """outs[m][rows of worker i] = blocks_list[m][i] @ vec_list[m] for every matrix m, one task per worker"""
+            def work(i):
+                for blocks, vec, out in zip(blocks_list, vec_list, outs):
+                    n = out.shape[0]
+                    torch.mv(blocks[i], vec, out=out[i * n // self.T:(i + 1) * n // self.T])
+            list(self.pool.map(work, range(self.T)))
+        def layer(self, lb, x, bufs):
+            self.stage([lb[0], lb[1], lb[2], lb[4], lb[5]], [x] * 5, [bufs[0], bufs[1], bufs[2], bufs[4], bufs[5]])
+            act = silu(bufs[4]) * bufs[5]
+            self.stage([lb[3], lb[6]], [bufs[0], act], [bufs[3], bufs[6]])
+            return x + 1e-3 * (bufs[3] + bufs[6])
+        def close(self):
+            self.pool.shutdown()
+
+    bufs = [torch.empty(w.shape[0]) for w in wts]
+    best = None                                             # (seconds per layer-token, mode, threads)
     for threads in sorted({ncpu, max(1, ncpu // 2), min(ncpu, 64), min(ncpu, 32)}, reverse=True):
         torch.set_num_threads(threads)
         x = torch.randn(h)
-        dt = None
         for rep in range(tokens + 1):                      # first pass = warm-up (thread pool start, page faults)
             if rep == 1: t0 = time.perf_counter()
-            q = torch.mv(wts[0], x); k = torch.mv(wts[1], x); v = torch.mv(wts[2], x); o = torch.mv(wts[3], q)
-            g = torch.mv(wts[4], x); u = torch.mv(wts[5], x); d = torch.mv(wts[6], torch.nn.functional.silu(g) * u)
-            x = x + 1e-3 * (o + d)
+            x = layer_blas(wts, x)
         dt = (time.perf_counter() - t0) / tokens
-        if best is None or dt < best[0]: best = (dt, threads)
-    dt, threads = best
-    head_scale = (h * cfg.vocab_size) / sum(k * n for _, k, n in shapes)
+        if best is None or dt < best[0]: best = (dt, "blas", threads)
+    torch.set_num_threads(1)
+    for threads in sorted({min(ncpu, 128), min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+        rp = RowPool(threads)
+        lb = [rp.cut(w) for w in wts]
+        x = torch.randn(h)
+        for rep in range(tokens + 1):
+            if rep == 1: t0 = time.perf_counter()
+            x = rp.layer(lb, x, bufs)
+        dt = (time.perf_counter() - t0) / tokens
+        rp.close()
+        if dt < best[0] or (os.environ.get("EXL2_CPU_BASELINE_MODE") == "rows" and best[1] == "blas"): best = (dt, "rows", threads)
+    dt, mode, threads = best
+    how = ("torch.mv with the BLAS library's threading" if mode == "blas" else
+           "one row block per worker thread, single-threaded torch.mv on each block")
     per_token = dt * (cfg.num_hidden_layers + head_scale)
-    layer_elems = sum(k * n for _, k, n in shapes)
-    full_gb = 4 * (cfg.num_hidden_layers * layer_elems + h * cfg.vocab_size) / 1e9
     out = {"value": round(1.0 / per_token, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
            "sample": f"variant B (BASELINE.md 3): 1 of {cfg.num_hidden_layers} layers (7 linears, pre-dequantized fp32 [N, K] rows, "
-                     f"torch.mv, best of 4 thread-pool sizes) x {tokens} tokens, extrapolated to {cfg.num_hidden_layers} layers + head; "
+                     f"{how}, best of 8 threading set-ups) x {tokens} tokens, extrapolated to {cfg.num_hidden_layers} layers + head; "
                      f"a full pass streams {full_gb:.1f} GB of fp32 per token"}
     # the UNSAMPLED pass (SURVEY.md 8d variant 2: "Llama-2-7B ~ 26 GB in fp32 fits"): every layer gets its own copy of the
     # layer's fp32 matrices (distinct memory, so a token streams the full weight set from DRAM instead of re-reading one
-    # layer), plus the head; a warm-up token and 3 timed ones with the best pool size found above.  Only when the host has
-    # the memory to spare; otherwise the extrapolated figure above stands and says so.
+    # layer), plus the head; a warm-up token and 3 timed ones with the set-up found above.  Only when the host has the
+    # memory to spare; otherwise the extrapolated figure above stands and says so.
     try:
         import psutil
         avail = psutil.virtual_memory().available
@@ -305,26 +353,36 @@ def cpu_baseline(cfg, recipe: str, seed: int = 0):
         avail = 0
     if avail > 2.5 * full_gb * 1e9 and full_gb < 200:
         try:
-            torch.set_num_threads(threads)
-            layers = [wts] + [[w.clone() for w in wts] for _ in range(cfg.num_hidden_layers - 1)]
             head = torch.randn(cfg.vocab_size, h) * 0.02
             x = torch.randn(h)
             n_timed = 3
-            for rep in range(n_timed + 1):
-                if rep == 1: t0 = time.perf_counter()
-                for lw in layers:
-                    q = torch.mv(lw[0], x); k = torch.mv(lw[1], x); v = torch.mv(lw[2], x); o = torch.mv(lw[3], q)
-                    g = torch.mv(lw[4], x); u = torch.mv(lw[5], x); d = torch.mv(lw[6], torch.nn.functional.silu(g) * u)
-                    x = x + 1e-3 * (o + d)
-                lg = torch.mv(head, x)
-                x = x + 1e-6 * lg[:h]
+            if mode == "blas":
+                torch.set_num_threads(threads)
+                layers = [wts] + [[w.clone() for w in wts] for _ in range(cfg.num_hidden_layers - 1)]
+                for rep in range(n_timed + 1):
+                    if rep == 1: t0 = time.perf_counter()
+                    for lw in layers:
+                        x = layer_blas(lw, x)
+                    x = x + 1e-6 * torch.mv(head, x)[:h]
+            else:
+                torch.set_num_threads(1)
+                rp = RowPool(threads)
+                layers = [[rp.cut(w, own=True) for w in wts] for _ in range(cfg.num_hidden_layers)]
+                hb, hout = rp.cut(head, own=True), torch.empty(cfg.vocab_size)
+                for rep in range(n_timed + 1):
+                    if rep == 1: t0 = time.perf_counter()
+                    for lb in layers:
+                        x = rp.layer(lb, x, bufs)
+                    rp.stage([hb], [x], [hout])
+                    x = x + 1e-6 * hout[:h]
+                rp.close()
             dt_full = (time.perf_counter() - t0) / n_timed
             out["sampled_extrapolated"] = {"value": out["value"], "sample": out["sample"]}
             out["value"] = round(1.0 / dt_full, 4)
             out["sample"] = (f"variant B (BASELINE.md 3), UNSAMPLED: {n_timed} tokens (after 1 warm-up) through all {cfg.num_hidden_layers} layers "
                              f"+ head, {full_gb:.1f} GB of pre-dequantized fp32 weights in distinct memory per token (each layer holds "
-                             f"its own copy of one synthesized layer's 7 matrices), torch.mv on [N, K] rows, {threads} threads "
-                             f"(fastest of 4 pool sizes on a 1-layer probe); {full_gb / dt_full:.0f} GB/s of host DRAM")
+                             f"its own copy of one synthesized layer's 7 matrices), [N, K] rows, {how}, {threads} threads "
+                             f"(fastest of 8 threading set-ups on a 1-layer probe); {full_gb / dt_full:.0f} GB/s of host DRAM")
             del layers, head
         except Exception as e:                             # never lose the baseline to an allocation failure
             out["full_pass_error"] = str(e)[:160]
