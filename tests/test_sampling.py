@@ -178,3 +178,27 @@ def test_dropin_sample_basic_with_the_reference_default_settings():
     with pytest.raises(NotImplementedError):
         dropin.sample_basic(logits, 0.8, 50, 0.8, 0.0, 0.0, 0.5, 0.0, 0.5, out_t, out_p, none, none, none, False, [], 1.5, 0.1,
                             1.0, none, 0.0, 0.1, 0.0, 0.0, 1.0, 0.0, 0.0)       # tfs
+
+
+@pytest.mark.hip_unverified
+def test_sample_rows_row_lengths_off_the_quad_path(be):
+    """Vocabulary sizes that are not multiples of 4 (and a row stride wider than the vocabulary) take the element-wise row
+    walk of the kernel instead of the quad one: same tokens."""
+    rng = np.random.default_rng(31)
+    compared = 0
+    for v, ld in ((997, 997), (1001, 1008), (130, 131)):
+        lg = np.zeros((2, ld), dtype=np.float32)
+        lg[:, :v] = (rng.standard_normal((2, v)) * 3).astype(np.float16)
+        lg[:, v:] = 50.0                                             # padding columns must never be looked at
+        for st, rnd in (((0.8, 50, 0.8, 0.0), 0.41), ((1.2, 9, 0.0, 0.05), 0.77)):
+            tok, pr, margin, _ = osamp.sample_basic(lg[:, :v], st[0], st[1], st[2], st[3], rnd, None)
+            torch = be.torch
+            out_t = torch.zeros(2, dtype=torch.int32, device=be.device)
+            out_p = torch.zeros(2, dtype=torch.float32, device=be.device)
+            be.ext.sample_rows(be.t(lg), st[0], st[1], st[2], st[3], rnd, out_t, out_p, vocab=v)
+            got = be.n(out_t)
+            for r in range(2):
+                if margin[r] >= MARGIN:
+                    assert got[r] == tok[r], (v, ld, st, r, got, tok)
+                    compared += 1
+    assert compared >= 8
