@@ -353,6 +353,43 @@ class GreedyGraphDecoder:
             if two:
                 self.stream.wait_event(self.chain["ev_b"])
 
+    def run_sampled(self, n_tokens: int, temperature: float, top_k: int, top_p: float = 0.0, min_p: float = 0.0,
+                    randoms=None, seed: int = 0, use_graph: bool = True):
+        """Decode `n_tokens` tokens per sequence with the DEVICE sampler (csrc/sampling.hip; the reference's sample_basic for
+        these settings: ext_sampling.cpp:93-301) instead of the arg-max: per token the step's graph, then one
+        `sample_rows` launch on the step's logits that overwrites the token fed to the next step, then the token log.
+        The only thing the host supplies per token is the random point (`randoms[i]`, or `random.Random(seed)` like the
+        reference's `random.random()` per sampling call, sampler.py:351) -- as a launch argument; nothing is read back, so
+        the loop stays asynchronous like run().  Rows of a batch share the point through the reference's recurrence."""
+        import random as _random
+        ext, cfg = self.model.ext, self.model.config
+        if self._overlapped():
+            raise RuntimeError("run_sampled: not available on the experimental overlapped chain")
+        if self.pos + n_tokens > self.limit:
+            raise RuntimeError(f"decode: {self.pos} cached + {n_tokens} new tokens exceed the cache / max_seq_len ({self.limit})")
+        if randoms is None:
+            rng = _random.Random(seed)
+            randoms = [rng.random() for _ in range(n_tokens)]
+        if len(randoms) < n_tokens:
+            raise RuntimeError("run_sampled: one random point per token is needed")
+        if getattr(self, "_sample_ws", None) is None:
+            dev = self.logits.device
+            self._sample_ws = torch.empty((self.b, cfg.vocab_size), dtype=torch.float32, device=dev)
+            self._sample_probs = torch.zeros((self.b,), dtype=torch.float32, device=dev)
+        p0 = self.pos
+        self.pos += n_tokens
+        with self._on_stream():
+            sptr = self.stream.cuda_stream if self.stream is not None else None
+            for i in range(n_tokens):
+                if use_graph and self.graph is not None:
+                    ext.graph_launch(self.graph, sptr)
+                else:
+                    self.step_eager()
+                # the step's own arg-max has written its token to ids / history[:, p0 + i + 1]; the sampled one replaces both
+                ext.sample_rows(self.logits, temperature, top_k, top_p, min_p, float(randoms[i]), self.ids, self._sample_probs,
+                                workspace=self._sample_ws, vocab=cfg.vocab_size)
+                self.history[:, p0 + i + 1].copy_(self.ids)
+
     def tokens(self, start: int, n: int) -> torch.Tensor:
         """tokens generated at positions start+1 .. start+n (history[b, pos] = token sampled after `pos` cached tokens)."""
         return self.history[:, start + 1:start + 1 + n]

@@ -202,3 +202,51 @@ def test_sample_rows_row_lengths_off_the_quad_path(be):
                     assert got[r] == tok[r], (v, ld, st, r, got, tok)
                     compared += 1
     assert compared >= 8
+
+
+@pytest.mark.hip_unverified
+def test_decoder_run_sampled(be):
+    """GreedyGraphDecoder.run_sampled: the device sampler inside the decode loop (token fed back on the device, token log,
+    no host read-back).  (1) with top_k = 1 it must reproduce run()'s greedy tokens exactly; (2) with the reference's default
+    settings every token must be the one the oracle's sampler draws from THAT step's device logits with that step's random
+    point, for both rows of the batch (second row: the reference's recurrence of the point)."""
+    import torch
+    from exllamav2_amd.cache import ExLlamaV2Cache
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.model import ExLlamaV2, GreedyGraphDecoder
+    from exllamav2_amd.synth import synth_checkpoint
+    cfg = ExLlamaV2Config(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                          num_key_value_heads=1, head_dim=64, vocab_size=96, max_seq_len=256, max_input_len=32)
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(synth_checkpoint(cfg, be.device, seed=3))
+    graph = be.device != "cpu"
+
+    def decoder():
+        cache = ExLlamaV2Cache(model, batch_size=2, max_seq_len=256)
+        dec = GreedyGraphDecoder(model, cache, batch_size=2)
+        if graph:
+            dec.capture()
+        dec.reset(torch.tensor([5, 17]), 0)
+        return dec
+
+    dec = decoder(); dec.run(5, use_graph=graph)
+    greedy = be.n(dec.tokens(0, 5)).copy(); dec.free()
+    dec = decoder(); dec.run_sampled(5, 1.0, 1, use_graph=graph)
+    assert np.array_equal(be.n(dec.tokens(0, 5)), greedy)
+    dec.free()
+
+    dec = decoder()
+    rnds = [0.13, 0.58, 0.91, 0.34, 0.77, 0.05]
+    compared = 0
+    for i, rnd in enumerate(rnds):
+        dec.run_sampled(1, 0.8, 50, 0.8, 0.0, randoms=[rnd], use_graph=graph)
+        lg = be.n(dec.logits)[:, :cfg.vocab_size].astype(np.float32)
+        tok, _, margin, _ = osamp.sample_basic(lg, 0.8, 50, 0.8, 0.0, rnd, None)
+        got = be.n(dec.tokens(i, 1))[:, 0]
+        assert np.array_equal(be.n(dec.ids), got)                   # the logged token is the one fed to the next step
+        for r in range(2):
+            if margin[r] >= MARGIN:
+                assert got[r] == tok[r], (i, r, got, tok)
+                compared += 1
+    assert compared >= 8
+    dec.free()
+    model.unload()
