@@ -180,7 +180,6 @@ def test_dropin_sample_basic_with_the_reference_default_settings():
                             1.0, none, 0.0, 0.1, 0.0, 0.0, 1.0, 0.0, 0.0)       # tfs
 
 
-@pytest.mark.hip_unverified
 def test_sample_rows_row_lengths_off_the_quad_path(be):
     """Vocabulary sizes that are not multiples of 4 (and a row stride wider than the vocabulary) take the element-wise row
     walk of the kernel instead of the quad one: same tokens."""
@@ -204,7 +203,6 @@ def test_sample_rows_row_lengths_off_the_quad_path(be):
     assert compared >= 8
 
 
-@pytest.mark.hip_unverified
 def test_decoder_run_sampled(be):
     """GreedyGraphDecoder.run_sampled: the device sampler inside the decode loop (token fed back on the device, token log,
     no host read-back).  (1) with top_k = 1 it must reproduce run()'s greedy tokens exactly; (2) with the reference's default
