@@ -28,6 +28,8 @@ cites the reference file:line it follows.  Parity status:
   the RoPE rotation (`rope_cuda_arr_neox` / `_gptj` of `cuda/rope.cu`, `tests/golden/reference_rope.npz`) and
   `rms_norm_kernel` (`cuda/rms_norm.cu`; the float64-sum oracle is within one fp16 ulp of it); the MoE
   routing kernels of `cuda/q_mlp_softmax.cuh` (`tests/golden/reference_moe_routing.npz`);
+  the CPU sampler (`cpp/sampling.cpp`, plain C++: compiled as it lies and driven in `sample_basic`'s order,
+  `tests/golden/reference_sampling.npz`): `oracle/sampling.py` bit for bit -- tokens, probabilities, candidate counts;
   likewise the pure torch functions of the reference that run on CPU (group map, RMSNorm, attention,
   RoPE tables, MLP activation: `tests/golden/make_golden.py`);
 * **unpinned by execution, pinned by relation**: the multiply itself (the reference has no CPU q_gemm
