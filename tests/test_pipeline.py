@@ -31,7 +31,9 @@ def _worker(rank, world, port, n_ticks, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from exllamav2_amd.pipeline import PipelineStage, run_pipeline
     stage = PipelineStage(_cfg(), rank, world, "cpu", n_seqs=world, max_seq_len=256, seed=5, ext=_emu_ext(), use_graph=False)
+    assert stage.chain is not None                      # dense chain-capable layers: the stage runs the chained decode route
     sampled = run_pipeline(stage, [3, 11], n_ticks)
+    assert stage.chain is not None                      # ... and did not fall back on the way
     if rank == world - 1:
         np.save(out_path, stage.history.numpy())
         assert sampled == n_ticks - (world - 1)
