@@ -36,4 +36,5 @@ echo "== sampler / prefill tools"
 timeout -k 5 60 python tools/sampler_bench.py > $R/r03_sampler_bench.jsonl 2>/dev/null; cut -c1-160 $R/r03_sampler_bench.jsonl | head -4
 timeout -k 10 200 python tools/prefill_bench.py > $R/r03_prefill_gemm.jsonl 2>/dev/null; cut -c1-200 $R/r03_prefill_gemm.jsonl | head -4
 echo "== memory-side cache probe"; timeout -k 5 90 tools/probes/mall_probe > $R/r03_mall_probe.txt 2>&1; cat $R/r03_mall_probe.txt
+echo "== persistent-kernel upper bound"; timeout -k 5 60 tools/probes/persist_probe > $R/r03_persist_probe.txt 2>&1; cat $R/r03_persist_probe.txt; timeout -k 5 120 tools/probes/chain_probe 2>&1 | head -3 >> $R/r03_persist_probe.txt
 rocm-smi --showproductname 2>/dev/null | grep -i "card series\|gfx" | head -3 > $R/r03_gpu.txt
