@@ -3,6 +3,7 @@
 # smoke, all -m gpu parity tests, the default bench line (decode + prefill + both CPU-baseline variants in their child process),
 # rocprofv3 kernel stats of the decode loop and of the prefill tool, the PMC FETCH_SIZE pass, sampler timing.
 # Outputs -> gpurun_out/ (copy what is to be judged into profiles/).  ~4-5 GPU-minutes.
+# (probe binaries: run tools/probes/build.sh in the build container first)
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT/gpurun_out
 cd $GRAFT_REPO_ROOT
 echo "== smoke"; timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $R/r03_smoke.log 2>&1; echo "rc=$?"; tail -1 $R/r03_smoke.log
