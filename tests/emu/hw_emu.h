@@ -96,6 +96,10 @@ extern int emu_tid_;
 extern EmuDim emu_bid_;
 extern EmuCtx* emu_ctx_;
 void emu_launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+// every workgroup of a small grid alive at once (kernels whose workgroups wait for each other inside one launch); a thread
+// polling another workgroup's writes calls emu_spin_yield() in its loop.  See emu_runtime.cpp.
+void emu_launch_coop(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+void emu_spin_yield();
 
 DEV int lane_id() { return emu_tid_ & 63; }
 DEV int wave_id() { return emu_tid_ >> 6; }
@@ -316,6 +320,8 @@ DEV void dma_to_lds16_agent(const void* g_lane_ptr, void* lds_wave_base) { memcp
 
 #define LAUNCH(kernel, grid, block, smem, stream, ...) \
     emu_launch(grid, block, smem, [&]() { kernel(__VA_ARGS__); })
+#define LAUNCH_COOP(kernel, grid, block, smem, stream, ...) \
+    emu_launch_coop(grid, block, smem, [&]() { kernel(__VA_ARGS__); })
 
 // ---- HIP runtime shims used by host code -----------------------------------------------------------------------------
 typedef int hipError_t;
