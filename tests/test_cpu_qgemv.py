@@ -59,3 +59,22 @@ def test_cpu_qgemv_equals_the_oracle_decode(qgemv, threads):
                 assert np.array_equal(pool.gemv(m.clone(), x), y)          # a clone in its own memory is the same matrix
     finally:
         pool.close()
+
+
+def test_bench_cpu_baseline_child_prints_one_json_object_with_both_variants():
+    """`bench.py --cpu-baseline-only` (what the main bench run starts as a child process so that an out-of-memory kill or a hang
+    in the CPU leg cannot cost the GPU line): one JSON object, variant B at the top level, variant A (the C port) beside it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-baseline-only", "--model", "tiny"],
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-400:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["kind"] == "port" and d["unit"] == "tokens/s" and d["value"] > 0 and d["cores"] >= 1 and "UNSAMPLED" in d["sample"]
+    a = d["variant_a"]
+    assert a.get("error") is None and a["value"] > 0 and "oracle/cpu_qgemv.c" in a["sample"]
