@@ -8,6 +8,14 @@ timed region starts.  Rank 0 prints ONE JSON line.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--model llama2-7b|llama2-70b|mixtral-8x7b|tinyllama|tiny]
                   [--recipe 4.0bpw|3.5bpw|2.5bpw|gptq-4bit-128g] [--ctx C] [--batch B] [--cache fp16|q4] [--no-cpu-baseline]
+                  [--no-prefill] [--no-parity-check] [--no-ctx-window] [--no-graph] [--parallel pipeline|tp]
+  python bench.py --cpu-baseline-only [--model ...] [--recipe ...]     (what the main run starts as a child for `cpu_baseline`)
+
+Beside the headline value the line carries `roofline` (q_gemm launches: algorithmic bytes / HIP-event time per launch against
+8 TB/s), `parity_check` (device logits vs the oracle on the first two layers + head of the timed checkpoint, before timing),
+`extra.ctx1920_tokens_per_s` (SURVEY.md 8d's second window), `prefill` (BASELINE configs[2]: 8 x 2048 tokens on the native
+kernels) and `cpu_baseline` (the oracle "port" on the host cores: variant B unsampled fp32 GEMV pass, variant A the C port
+on the packed tensors; run in a child process).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): layer-split ("gpu_split", model.py:176-263) as a pipeline:
 rank r owns layers [r L/N, (r+1) L/N); N independent sequences are in flight, one per stage, hidden states hop
