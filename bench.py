@@ -186,10 +186,72 @@ def oracle_for_parity(cfg, ck, layers: int = 2):
     return OracleModel(ocfg, keep)
 
 
-def parity_check(model, oracle, device, n_decode: int = 3):
-    """Before anything is timed: the device (eager product path, same kernels the graph replays) runs a 4-token prompt and
-    `n_decode` greedy steps through the first layers + head; logits must match the oracle within the model-level fp16
-    tolerance of tests/test_model.py (0.03 + |x| 2^-8), token ids wherever the oracle's top-1/top-2 margin is confident."""
+def parity_check(model, oracle, device, n_decode: int = 6):
+    """Before anything is timed, on the first layers + head of the very checkpoint the bench times: a 4-token prompt through
+    `model.forward` (the prefill route), then `n_decode` greedy steps through **GreedyGraphDecoder -- the captured chain the
+    timed region replays** (same kernels, same graph mechanism; `route` in the result says which decode route it took).
+    Every step's device logits (`dec.logits`) must match the oracle within the model-level fp16 tolerance of
+    tests/test_model.py (0.03 + |x| 2^-8); the device's own greedy token must be the oracle's wherever the oracle's
+    top-1 / top-2 margin exceeds 4x that tolerance, and at least 3 steps must be that confident (the synthetic head is
+    structured for it: exllamav2_amd/synth.py)."""
+    import numpy as np
+    import torch
+    from exllamav2_amd import ExLlamaV2Cache, GreedyGraphDecoder
+    layers = oracle.cfg.num_hidden_layers
+    full = model.layers
+    model.layers = full[:layers]
+    dec = None
+    try:
+        cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=256)
+        cache.key_states, cache.value_states = cache.key_states[:layers], cache.value_states[:layers]
+        ids = np.array([[1, 15043, 3186, 29892]]) % model.config.vocab_size
+        oracle.reset(1)
+        worst, checked, tok_checked = 0.0, 0, 0
+
+        def compare(got, want, what):
+            nonlocal worst, checked
+            err = np.abs(got - want)
+            tol = 0.03 + np.abs(want) * 2.0 ** -8
+            worst = max(worst, float((err / tol).max()))
+            checked += want.size
+            if not np.all(err <= tol):
+                raise SystemExit(f"[bench] parity check FAILED at {what}: max |logit - oracle| = {err.max():.4f}")
+
+        want = oracle.forward(ids)[:, -1]
+        got = model.forward(torch.from_numpy(ids), cache).float().cpu().numpy()[:, -1].astype(np.float64)
+        compare(got, want, "the prompt")
+        tok = int(want[0].argmax())
+        dec = GreedyGraphDecoder(model, cache, batch_size=1).capture()
+        route = "chain (qgemv chain kernels, one HIP graph per step)" if dec.chain is not None else "module by module"
+        dec.reset(torch.tensor([tok]), ids.shape[1])
+        for step in range(n_decode):
+            dec.run(1)
+            torch.cuda.synchronize()
+            want = oracle.forward(np.array([[tok]]))[:, -1]
+            got = dec.logits.float().cpu().numpy()[:, :model.config.vocab_size].astype(np.float64)
+            compare(got, want, f"decode step {step}")
+            dev_tok = int(dec.tokens(ids.shape[1] + step, 1).cpu().numpy()[0, 0])
+            top2 = np.sort(want[0])[-2:]
+            if top2[1] - top2[0] > 0.12:
+                tok_checked += 1
+                if dev_tok != int(want[0].argmax()):
+                    raise SystemExit(f"[bench] parity check FAILED at decode step {step}: greedy token {dev_tok} != oracle {int(want[0].argmax())}")
+            tok = dev_tok                                    # follow the device: each step is checked alone
+        if tok_checked < 3:
+            raise SystemExit(f"[bench] parity check FAILED: only {tok_checked} of {n_decode} steps had a confident oracle margin")
+        del cache
+    finally:
+        if dec is not None:
+            dec.free()
+        model.layers = full
+    return {"layers": layers, "steps": 1 + n_decode, "decode_route": route, "logits_checked": checked, "worst_err_over_tol": round(worst, 3),
+            "confident_tokens_equal": tok_checked, "tolerance": "0.03 + |x| * 2^-8 (fp16, tests/test_model.py)"}
+
+
+def prefill_parity_check(model, oracle, ids):
+    """The prefill leg's kernels against the oracle: the SAME [batch, seq] call shape the leg times (so the same row counts reach
+    the same dequantize-into-MFMA / flash-prefill variants) through the first layers + head; last-position logits of sequence 0
+    vs the oracle run on that sequence alone (causal attention: sequences are independent)."""
     import numpy as np
     import torch
     from exllamav2_amd import ExLlamaV2Cache
@@ -197,32 +259,21 @@ def parity_check(model, oracle, device, n_decode: int = 3):
     full = model.layers
     model.layers = full[:layers]
     try:
-        cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=256)
+        b, s = ids.shape
+        cache = ExLlamaV2Cache(model, batch_size=b, max_seq_len=s)
         cache.key_states, cache.value_states = cache.key_states[:layers], cache.value_states[:layers]
-        ids = np.array([[1, 15043, 3186, 29892]]) % model.config.vocab_size
+        got = model.forward(ids, cache, last_id_only=True).float().cpu().numpy()[0, -1].astype(np.float64)
         oracle.reset(1)
-        worst, checked, tok_checked = 0.0, 0, 0
-        cur = ids
-        for step in range(1 + n_decode):
-            want = oracle.forward(cur)[:, -1]
-            got = model.forward(torch.from_numpy(cur), cache).float().cpu().numpy()[:, -1].astype(np.float64)
-            err = np.abs(got - want)
-            tol = 0.03 + np.abs(want) * 2.0 ** -8
-            worst = max(worst, float((err / tol).max()))
-            if not np.all(err <= tol):
-                raise SystemExit(f"[bench] parity check FAILED at step {step}: max |logit - oracle| = {err.max():.4f}")
-            top2 = np.sort(want[0])[-2:]
-            if top2[1] - top2[0] > 0.12:
-                tok_checked += 1
-                if int(got[0].argmax()) != int(want[0].argmax()):
-                    raise SystemExit(f"[bench] parity check FAILED at step {step}: greedy token differs from the oracle")
-            checked += want.size
-            cur = np.array([[int(want[0].argmax())]])
+        want = oracle.forward(ids[:1].cpu().numpy())[0, -1]
+        err = np.abs(got - want)
+        tol = 0.03 + np.abs(want) * 2.0 ** -8
+        if not np.all(err <= tol):
+            raise RuntimeError(f"prefill parity check FAILED: max |logit - oracle| = {err.max():.4f} (not timed)")
         del cache
     finally:
         model.layers = full
-    return {"layers": layers, "steps": 1 + n_decode, "logits_checked": checked, "worst_err_over_tol": round(worst, 3),
-            "confident_tokens_equal": tok_checked, "tolerance": "0.03 + |x| * 2^-8 (fp16, tests/test_model.py)"}
+    return {"layers": layers, "rows": int(ids.numel()), "logits_checked": int(want.size), "worst_err_over_tol": round(float((err / tol).max()), 3),
+            "token_equal": bool(int(got.argmax()) == int(want.argmax())), "tolerance": "0.03 + |x| * 2^-8"}
 
 
 def pmc_traffic_gb(launches_per_step, kernel_prefix: str):
@@ -471,7 +522,7 @@ def cpu_baseline_in_child(args, timeout_s: int = 420):
         return {"value": None, "error": str(e)[:200]}
 
 
-def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq: int = 2048):
+def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq: int = 2048, parity: bool = True):
     """BASELINE configs[2] beside the headline: test_inference.py -ps procedure (:533-579), forward(ids[8, 2048],
     preprocess_only=True) on a fresh synthetic model, all layers, the product route (row pre-pass + dequantize-into-MFMA
     GEMMs + flash-prefill attention: no library GEMM)."""
@@ -481,9 +532,16 @@ def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq:
     from exllamav2_amd.synth import synth_checkpoint
     out = {"workload": f"{model_name} EXL2 {recipe}, {batch} x {seq} tokens, forward(preprocess_only=True)", "unit": "tokens/s"}
     cfg = ExLlamaV2Config.llama2_7b(max_seq_len=seq, max_input_len=2048, max_batch_size=batch)
-    model = ExLlamaV2(cfg, device=device).load(synth_checkpoint(cfg, device, recipe=recipe, seed=1))
-    cache = ExLlamaV2Cache(model, batch_size=batch, max_seq_len=seq)
+    ck = synth_checkpoint(cfg, device, recipe=recipe, seed=1)
+    oracle = oracle_for_parity(cfg, ck) if parity else None               # checker; before load() re-lays q_weight out
+    model = ExLlamaV2(cfg, device=device).load(ck)
     ids = torch.randint(0, cfg.vocab_size - 1, (batch, seq), generator=torch.Generator().manual_seed(0)).to(device)
+    if parity:
+        t0 = time.perf_counter()
+        out["parity_check"] = prefill_parity_check(model, oracle, ids)
+        out["parity_check"]["seconds"] = round(time.perf_counter() - t0, 1)
+        del oracle
+    cache = ExLlamaV2Cache(model, batch_size=batch, max_seq_len=seq)
     model.forward(ids, cache, preprocess_only=True); torch.cuda.synchronize()
     best = None
     for _ in range(2):
@@ -648,7 +706,7 @@ def finish(args, cfg, result, rank, world, n_gpus, device, dist):
             if k in result: out[k] = result[k]
         if not args.no_prefill and n_gpus == 1 and args.model == "llama2-7b" and args.batch == 1:
             try:
-                out["prefill"] = prefill_rate(args.model, args.recipe, device)
+                out["prefill"] = prefill_rate(args.model, args.recipe, device, parity=not args.no_parity_check)
             except Exception as e:  # informational; never lose the headline number
                 out["prefill"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and n_gpus == 1:

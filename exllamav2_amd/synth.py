@@ -105,16 +105,73 @@ def synth_linear_gptq(k: int, n: int, group_size: int, device, gen: torch.Genera
     return w
 
 
+def pack_codes(codes: torch.Tensor, bits: int) -> torch.Tensor:
+    """codes int64 [K, N] in [0, 2^bits) -> int32 [K * bits / 32, N] in the EXL2 bitstream (pack_tensor.cu:118-248):
+    per column the 32 codes of a 32-row chunk are concatenated LSB-first into `bits` little-endian words."""
+    k, n = codes.shape
+    assert k % 32 == 0
+    c = codes.reshape(k // 32, 32, n)
+    words = torch.zeros((k // 32, bits + 1, n), dtype=torch.int64, device=codes.device)
+    for i in range(32):
+        w0, off = (i * bits) // 32, (i * bits) % 32
+        words[:, w0] |= (c[:, i] << off) & 0xFFFFFFFF
+        if off + bits > 32:
+            words[:, w0 + 1] |= c[:, i] >> (32 - off)
+    words = words[:, :bits].reshape(k // 32 * bits, n)
+    return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+
+
+def structure_head(w: dict, emb: torch.Tensor, vpad: int) -> None:
+    """Overwrite the codes / scales of a synthetic head (synth_linear / synth_linear_gptq output, [K = hidden, N = vpad]) with the
+    quantized, shifted transpose of the embedding table `emb` [vocab, hidden] (see synth_checkpoint: structured_head)."""
+    vocab, h = emb.shape
+    dev = emb.device
+    beta = 1.5 / math.sqrt(h)
+    src = torch.roll(emb.float(), shifts=1, dims=0)                    # row v = E[v - 1]
+    wt = torch.zeros((h, vpad), dtype=torch.float32, device=dev)
+    wt[:, :vocab] = src.t() * beta                                     # W[k, v], original feature order
+    if "q_weight" in w:                                                # EXL2: uniform bit width per recipe (lm_head: 6 bit)
+        qg = w["q_groups"].cpu().tolist()
+        bits = qg[0]
+        assert all(b == bits for b in qg[0::2]), "structured head: one bit width expected"
+        half = 1 << (bits - 1)
+        sc = 3.5 * beta / (half - 1)
+        sc16 = float(torch.tensor(sc).half())
+        codes = torch.clamp(torch.round(wt / sc16) + half, 0, 2 * half - 1).to(torch.int64)
+        codes = codes[w["q_perm"].long()]                              # packed row i holds original feature q_perm[i]
+        w["q_weight"] = pack_codes(codes, bits)
+        w["q_scale"] = torch.zeros_like(w["q_scale"])                  # every nibble 0: scale = 1^2 * q_scale_max / 256 (ext.py:336)
+        w["q_scale_max"] = torch.full_like(w["q_scale_max"], sc16 * 256.0)
+    else:                                                              # GPTQ 4 bit, zero 8
+        sc = 3.0 * beta / 7
+        sc16 = float(torch.tensor(sc).half())
+        codes = torch.clamp(torch.round(wt / sc16) + 8, 0, 15).to(torch.int64)
+        c = codes.reshape(h // 8, 8, vpad)
+        words = torch.zeros((h // 8, vpad), dtype=torch.int64, device=dev)
+        for i in range(8):
+            words |= c[:, i] << (4 * i)
+        w["qweight"] = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+        w["scales"] = torch.full_like(w["scales"], sc16)
+
+
 def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_order: bool = True,
                      layers=None, with_embed: bool = True, with_head: bool = True, shared_perm: bool = True,
-                     down_act_order: bool = False) -> dict:
+                     down_act_order: bool = False, structured_head: bool = True) -> dict:
     """{'model.layers.0.self_attn.q_proj': {...}, ..., 'model.norm': tensor, 'model.embed_tokens': tensor}.
     Every layer draws from its own generator (seed, layer index), so a rank of a layer-split run can build exactly its
     slice of the same checkpoint (`layers` = iterable of layer indices).
     shared_perm (EXL2): q/k/v share one act-order permutation, gate/up (and every expert's w1/w3) another -- as in every
     checkpoint the reference's quantizer writes: the permutation is argsort(diag(H)) (adaptivegptq.py:236-251) and k/v
     reuse q's Hessian, gate reuses up's, the experts reuse w1.0's (conversion/quantize.py:138-139,165,190-192).
-    shared_perm=False draws one permutation per linear (format-legal, never produced by the quantizer)."""
+    shared_perm=False draws one permutation per linear (format-legal, never produced by the quantizer).
+    structured_head (greedy-parity caveat, option ii: "give the synthetic model structure ... so the model has
+    a confident next token"): the head is the QUANTIZED transpose of the embedding table shifted by one token,
+    W[k, v] = beta * E[(v - 1) mod vocab, k] with beta = 1.5 / sqrt(hidden), so the logit of token t + 1 collects the
+    part of the residual stream that still is E[t] (~ 1.5 sqrt(hidden) x that fraction: 10 .. 80) while every other logit
+    stays ~ N(0, 1.5^2) like a random head's.  The oracle's top-1 / top-2 margin is then tens of times the stated logit
+    tolerance on every step instead of a fraction of it, so the greedy-token comparisons are never vacuous; weights are
+    still in the on-disk format (6-bit codes / 4-bit GPTQ nibbles, one scale per group), bytes and shapes are unchanged.
+    structured_head=False draws the head at random like every other linear."""
     if recipe in GPTQ_RECIPES:
         gs = GPTQ_RECIPES[recipe]
         rec = {k: gs for k in RECIPES["4.0bpw"]}
@@ -168,4 +225,7 @@ def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_ord
         ck["model.norm"] = (1 + 0.1 * torch.randn(h, device=device, generator=gen)).half()
         vpad = (cfg.vocab_size + 31) // 32 * 32                               # linear.py:82-88 pads out_features to x32
         ck["lm_head"] = make(h, vpad, rec["lm_head"], device, gen, s_attn, act_order)
+        if structured_head:
+            emb = torch.randn(cfg.vocab_size, h, device=device, generator=gen_for(0)).half()      # == model.embed_tokens
+            structure_head(ck["lm_head"], emb, vpad)
     return ck

@@ -53,6 +53,7 @@ def test_prefill_then_decode_contiguous(be):
     want = oracle.forward(ids)
     check_logits(be.n(logits), want)
     nxt = np.argmax(want[:, -1], axis=-1)[:, None]
+    n_conf = 0
     for _ in range(2):
         logits = model.forward(torch.from_numpy(nxt), cache)
         want = oracle.forward(nxt)
@@ -60,7 +61,9 @@ def test_prefill_then_decode_contiguous(be):
         got_tok = be.n(logits)[:, -1].argmax(-1)
         conf = confident(want[:, -1])
         assert np.array_equal(got_tok[conf], np.argmax(want[:, -1], -1)[conf])
+        n_conf += int(conf.sum())
         nxt = np.argmax(want[:, -1], axis=-1)[:, None]
+    assert n_conf >= 1, "vacuous token check"
     model.unload()
 
 
@@ -135,11 +138,14 @@ def test_device_side_greedy_decode_paged(be):
     got = be.n(dec.tokens(0, n))[0]
     oracle.reset(1)
     tok = 7
+    n_conf = 0
     for i in range(n):
         want = oracle.forward(np.array([[tok]]))[0, -1]
         if confident(want[None])[0]:
             assert got[i] == int(np.argmax(want)), (i, got, np.argmax(want))
+            n_conf += 1
         tok = int(got[i])                                 # follow the device's own choice: each step is checked alone
+    assert n_conf >= 1, "vacuous token check"
     assert be.n(dec.cache_seqlens)[0] == n
     # the kernels index cache pages and sin/cos rows unchecked: running past the cache is refused on the host
     dec.reset(torch.tensor([7]), cache.max_seq_len - 2)
@@ -191,7 +197,7 @@ def test_q4_cache_decode_close_to_fp16(be):
     a = be.n(m16.forward(nxt, c16)).astype(np.float64)
     b = be.n(m4.forward(nxt, c4)).astype(np.float64)
     d = np.abs(a - b)
-    assert d.max() < 0.5 and d.mean() < 0.1             # 4-bit keys/values: small but non-zero drift
+    assert d.max() < 0.5 and d.mean() < 0.15            # 4-bit keys/values: small but non-zero drift (head: logits of sigma ~1.5)
     assert np.any(d > 0)
     m16.unload(); m4.unload()
 
@@ -212,13 +218,16 @@ def test_gptq_model_equals_oracle(be, recipe, act_order):
     want = oracle.forward(ids)
     check_logits(be.n(logits), want)
     nxt = np.argmax(want[:, -1], axis=-1)[:, None]
+    n_conf = 0
     for _ in range(2):
         logits = model.forward(torch.from_numpy(nxt), cache)
         want = oracle.forward(nxt)
         check_logits(be.n(logits), want)
         conf = confident(want[:, -1])
         assert np.array_equal(be.n(logits)[:, -1].argmax(-1)[conf], np.argmax(want[:, -1], -1)[conf])
+        n_conf += int(conf.sum())
         nxt = np.argmax(want[:, -1], axis=-1)[:, None]
+    assert n_conf >= 1, "vacuous token check"
     model.unload()
 
 
@@ -256,6 +265,7 @@ def test_llama2_7b_width_two_layers_equals_oracle():
             assert toks[i] == int(np.argmax(w)), (i, toks[i], int(np.argmax(w)))
             n_conf += 1
         tok = int(toks[i])
+    assert n_conf >= 4, f"only {n_conf} of 6 decode steps had a confident oracle margin (synth logit_gain)"
     # the last step's logits are still in the decoder's buffer
     check_logits(be.n(dec.logits)[:, :cfg.vocab_size].reshape(1, 1, -1), w[None, None])
     dec.free()

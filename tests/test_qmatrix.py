@@ -106,6 +106,66 @@ def test_prefill_vs_oracle(be, m):
     be.ext.free_q_matrix(h)
 
 
+@pytest.mark.parametrize("m", [300, 1024])
+def test_prefill_tile256_variant_forced(be, m, monkeypatch):
+    """The 256 x 256 instantiation of the dequantize-into-MFMA kernel (qgemm_mfma_kernel<., 8>), forced at shapes both backends
+    can run: one-hot rows return rows of reconstruct() bit for bit, random rows land within the fp16 bar of the oracle
+    (the reference's relation, tests/test_gemv.py:155-165)."""
+    monkeypatch.setenv("EXL2_PREFILL_MT", "8")
+    k, n, spec = SPECS["mixed_5_4"]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=21, bias=False)
+    rng = np.random.default_rng(22)
+    a = rng.standard_normal((m, k)).astype(np.float16)
+    hot = rng.choice(m, size=64, replace=False)
+    hot_k = rng.integers(0, k, size=64)
+    a[hot] = 0
+    a[hot, hot_k] = 1.0
+    c = torch.zeros((m, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    got = be.n(c)
+    assert np.array_equal(got[hot].view(np.uint16), ref[hot_k].view(np.uint16))
+    want = OX.gemm_ref(a, ref, exact=True)
+    assert np.all(np.abs(got.astype(np.float64) - want) <= half_tol(want, k))
+    be.ext.free_q_matrix(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("role", ["q_proj", "gate_proj", "down_proj"])
+@pytest.mark.parametrize("force", [None, "8"])
+def test_prefill_llama2_7b_shapes_4096_rows(role, force, monkeypatch):
+    """BASELINE configs[2]'s kernel at the three Llama-2-7B linear shapes, M = 4096 rows (the natural selection there is the
+    256 x 256 tile -- the variant the 8 x 2048 prefill runs -- and it is also forced): 256 sampled one-hot rows == reconstruct()
+    bit for bit, 64 random rows within the fp16 bar of the float64 product with the oracle's reconstruct()."""
+    from tests.conftest import Backend
+    from exllamav2_amd.synth import RECIPES, synth_linear
+    be = Backend("hip")
+    if force: monkeypatch.setenv("EXL2_PREFILL_MT", force)
+    monkeypatch.setenv("EXL2_PREFILL_TRACE", "1")
+    k, n = {"q_proj": (4096, 4096), "gate_proj": (4096, 11008), "down_proj": (11008, 4096)}[role]
+    gen = torch.Generator(); gen.manual_seed(321)
+    w = synth_linear(k, n, RECIPES["4.0bpw"][role], "cpu", gen, sigma=0.02, act_order=True)
+    ref = OX.exl2_reconstruct({kk: vv.numpy().copy() for kk, vv in w.items() if kk != "q_perm"})
+    h = be.ext.make_q_matrix_from_dict({kk: vv.to(be.device) for kk, vv in w.items()}, None)
+    m = 4096
+    rng = np.random.default_rng(7)
+    a = rng.standard_normal((m, k)).astype(np.float16)
+    hot = rng.choice(m, size=256, replace=False)
+    hot_k = rng.integers(0, k, size=256)
+    a[hot] = 0
+    a[hot, hot_k] = 1.0
+    c = torch.zeros((m, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    got = be.n(c)
+    assert np.array_equal(got[hot].view(np.uint16), ref[hot_k].view(np.uint16))
+    rows = np.setdiff1d(np.arange(m), hot)[:64]
+    want = a[rows].astype(np.float64) @ ref.astype(np.float64)
+    w_rms = float(np.sqrt(np.mean(ref.astype(np.float32) ** 2)))
+    tol = np.abs(want) * 2.0 ** -10 + 1.5e-3 + 6.0 * 2.0 ** -11 * np.sqrt(k) * w_rms      # (test_full_size_linear's bar)
+    err = np.abs(got[rows].astype(np.float64) - want)
+    assert np.all(err <= tol), float(err.max())
+    be.ext.free_q_matrix(h)
+
+
 def test_prefill_gptq_identity(be):
     k, n, gs = 384, 48, 128
     t = OX.synth_gptq(k, n, gs, seed=17, act_order=True)

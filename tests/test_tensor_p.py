@@ -97,6 +97,7 @@ def test_tensor_parallel_matches_single_process(tmp_path):
             assert int(t0[0, i]) == int(np.argmax(w))
             checked += 1
         tok = int(t0[0, i])
+    assert checked >= 1, "vacuous token check"
     b0, b1 = (int(np.load(tmp_path / f"bytes{r}.npy")[0]) for r in range(world))
     full = model.weight_bytes()
     assert b0 == b1 and 0.5 * full <= b0 <= 0.62 * full                              # ~1/N of the bytes (+ shared tables)
@@ -213,10 +214,13 @@ def test_tp_shard_path_on_gpu():
     torch.cuda.synchronize()
     toks = dec.tokens(len(PROMPT), N_DECODE).cpu().numpy()[0]
     tok = int(np.argmax(want[0, -1]))
+    checked = 0
     for i in range(N_DECODE):
         w = oracle.forward(np.array([[tok]]))[0, -1]
         top = np.sort(w)[-2:]
         if top[1] - top[0] > 4 * LOGIT_TOL:
             assert int(toks[i]) == int(np.argmax(w))
+            checked += 1
         tok = int(toks[i])
+    assert checked >= 1, "vacuous token check"
     tp.unload(); model.unload()
