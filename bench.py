@@ -638,14 +638,18 @@ def main():
             if parity is not None: result["parity_check"] = parity
             dec.free()
             return finish(args, cfg, result, rank, world, n_gpus, device, dist)
+        model.ext.chain_route_counts(reset=True)
         gemv_ms, launches, gemv_bytes = time_gemv_calls(model, dec)
+        n_lean, n_flat = model.ext.chain_route_counts(reset=True)
         kv_bytes = 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2 * (args.ctx + args.warmup + args.steps // 2)
         achieved = gemv_bytes / (gemv_ms * 1e-3) / 1e9
         # the committed PMC pass is of the headline configuration only
         chained = getattr(dec, "chain", None) is not None
-        kname = "qgemv_flat_kernel<false" if chained else "qgemv_stream_kernel<false, 4"
+        kname = ("qgemv_lean_kernel<false" if n_lean >= n_flat else "qgemv_flat_kernel<false") if chained else "qgemv_stream_kernel<false, 4"
         traffic_gb, traffic_src = pmc_traffic_gb(launches, kname) if (args.model == "llama2-7b" and args.recipe == "4.0bpw") else (None, None)
         extra = {}
+        if chained:
+            extra["chain_route_launches"] = {"qgemv_lean_kernel": int(n_lean), "qgemv_flat_kernel": int(n_flat)}
         if dec.chain is not None and "flags" in dec.chain:
             # overlapped chain (EXL2_CHAIN_OVERLAP=1): waits that gave up would make the timing meaningless -- must be 0
             extra["chain_overlap"] = {"hand_off_words_left_set": int((dec.chain["flags"][:, [0] + [32 * (1 + c) for c in range(8)]] != 0).sum()),
@@ -662,7 +666,7 @@ def main():
             "value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load,
             "weight_bytes_per_rank": [int(model.weight_bytes())],
             "roofline": {
-                "bound": "hbm", "kernel": ("qgemv_flat_kernel" if chained else "qgemv_stream_kernel<false, MB>") + " (all q_gemm launches of a decode step: fused q|k|v, o, fused gate|up, down per layer + head)",
+                "bound": "hbm", "kernel": (kname.split("<")[0] if chained else "qgemv_stream_kernel<false, MB>") + " (all q_gemm launches of a decode step: fused q|k|v, o, fused gate|up, down per layer + head)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None if traffic_gb is None else round(traffic_gb * 1e9 / launches),
                 "traffic_unit": "HBM bytes per q_gemm launch (PMC FETCH_SIZE x2)", "traffic_source": traffic_src,

@@ -178,6 +178,10 @@ DEV void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :::
 // all LDS reads of this wave have returned (before an LDS-DMA may overwrite what they read: the compiler does not order
 // a global_load_lds behind a pending ds_read)
 DEV void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// wave-private LDS hand-over between the lanes of ONE wave (lane A wrote / copied, lane B reads): the lanes execute in
+// lockstep and a wave's LDS operations complete in order, so nothing is needed here; the CPU emulation (tests/emu), whose
+// lanes are fibers that run one after the other, meets at a per-wave barrier
+DEV void wave_converge() { }
 
 // v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {hi:lo} (selector 0-3 -> lo, 4-7 -> hi, 0x0C -> 0x00)
 DEV u32 byte_perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }

@@ -10,6 +10,7 @@
 // device), instead of the reference's per-module graphs with patched kernel arguments (graph.cu:141-164).
 #include "qmatrix.h"
 #include "qgemv_flat.h"
+#include "qgemv_lean.h"
 #include "chain_sync.h"
 #include "errors.h"
 #include <string.h>
@@ -193,6 +194,14 @@ int chain_sync_done(u32 arrivals)
     return EXL2_OK;
 }
 
+static long long g_route_lean = 0, g_route_flat = 0;        // launches taken by qgemv_lean.hip / qgemv_flat.hip (exl2_chain_route_counts)
+
+static bool lean_enabled()
+{
+    const char* e = getenv("EXL2_LEAN");
+    return !(e && e[0] == '0');
+}
+
 // One chained launch.  While an overlapped chain is open (chain_sync.h) the launch takes its stream and its counters from it.
 static int flat_try(FlatIn& in, void* stream, int* wgs, const char* what)
 {
@@ -205,7 +214,12 @@ static int flat_try(FlatIn& in, void* stream, int* wgs, const char* what)
         in.sync_wait = cl.wait; in.sync_signal = cl.signal; in.sync_arrive = cl.arrive;
     }
     int n_wgs = 0;
-    const int rc = qgemv_flat_launch(in, cl.stream, &n_wgs);
+    // round 3: the lean kernel (qgemv_lean.hip) takes what it covers (<= LEAN_MAX_M rows, serial chain); EXL2_LEAN=0 keeps
+    // the round-2 kernel for A/B runs
+    int rc = 1;
+    if (!overlapped && lean_enabled()) rc = qgemv_lean_launch(in, cl.stream, &n_wgs);
+    if (rc == 0) g_route_lean++;
+    if (rc == 1) { rc = qgemv_flat_launch(in, cl.stream, &n_wgs); if (rc == 0) g_route_flat++; }
     if (rc > 0) EXL2_FAIL(EXL2_E_INVALID, "%s: shape not covered by the chained decode kernel", what);
     if (rc < 0) EXL2_FAIL(EXL2_E_INVALID, "%s: launch configuration rejected (%d)", what, rc);
     HIP_TRY(hipGetLastError());
@@ -535,6 +549,14 @@ int exl2_q_mlp_forward(void* handle, void* x, int rows, void* stream)
 
 
 // ---- chained decode (qgemv_flat.hip) -----------------------------------------------------------------------------------------
+
+int exl2_chain_route_counts(long long* lean, long long* flat, int reset)
+{
+    if (lean) *lean = g_route_lean;
+    if (flat) *flat = g_route_flat;
+    if (reset) { g_route_lean = 0; g_route_flat = 0; }
+    return EXL2_OK;
+}
 
 int exl2_chain_overlap_begin(void* flags, int n_blocks, void* stream_a, void* stream_b)
 {

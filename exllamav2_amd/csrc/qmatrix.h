@@ -51,6 +51,7 @@ struct QMatrix
     f16* temp_dq; int max_dq_rows;
     // host copies used by launch heuristics
     int max_bits;
+    u16* cg_host;                 // host copy of the chunk -> group map [K / 32] (launch-time work split of qgemv_lean.hip)
     long long weight_bytes;       // algorithmic bytes (packed weights + scales + perm + group map), for roofline reports
 };
 

@@ -312,6 +312,9 @@ int qmatrix_create(QMatrix** out, int device, int K, int N, int G,
     qm->device = device; qm->height = K; qm->width = N; qm->groups = G; qm->is_gptq = is_gptq;
     qm->q_weight = q_weight; qm->q_perm = q_perm; qm->q_invperm = q_invperm;
     qm->temp_dq = temp_dq; qm->max_dq_rows = max_dq_rows; qm->max_bits = max_bits;
+    qm->cg_host = (u16*)malloc((size_t)n_chunks * sizeof(u16));
+    if (!qm->cg_host) EXL2_FAIL(EXL2_E_OOM, "make_q_matrix: host out of memory");
+    memcpy(qm->cg_host, chunk_group.data(), (size_t)n_chunks * sizeof(u16));
 
     const size_t weight_words = (size_t)total_qrows * N;
     u32*& temp = hold.temp;
@@ -443,6 +446,7 @@ void qmatrix_destroy(QMatrix* qm)
     if (qm->pack_buf) (void)hipFree(qm->pack_buf);
     if (qm->sc_tab_buf) (void)hipFree(qm->sc_tab_buf);
     if (qm->zp_tab_buf) (void)hipFree(qm->zp_tab_buf);
+    free(qm->cg_host);
     free(qm);
 }
 

@@ -552,6 +552,12 @@ class ExtC:
             self._ptr(norm_w_perm, torch.float16, "norm_w_perm"), float(eps), q_handle, self._ptr(c, torch.float16, "c"),
             int(rows), self._stream(xp)))
 
+    def chain_route_counts(self, reset: bool = False):
+        """(launches taken by csrc/qgemv_lean.hip, launches taken by csrc/qgemv_flat.hip) since the last reset"""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        self.lib.check(self.lib.exl2_chain_route_counts(C.byref(a), C.byref(b), 1 if reset else 0))
+        return a.value, b.value
+
     SYNC_BLOCK_WORDS = 320
 
     def chain_overlap_begin(self, flags, stream_a, stream_b) -> None:

@@ -223,6 +223,10 @@ int exl2_gather_f16(const void* src, const void* perm, void* dst, int n, void* s
    the boundaries of a step (events), and captures them as two graphs when it wants graphs -- the branches of one forked
    HIP graph are not executed concurrently on this stack (tools/probes/fork_probe.hip).  EXPERIMENTAL. */
 int exl2_chain_overlap_begin(void* flags, int n_blocks, void* stream_a, void* stream_b);
+/* how many chained q_gemm launches of this process went to the round-3 kernel (csrc/qgemv_lean.hip: <= 4 rows) and how many to
+   the round-2 kernel (csrc/qgemv_flat.hip: what the former declines); reset != 0 zeroes the counters.  Diagnostics for tests and
+   bench.py (no reference counterpart). */
+int exl2_chain_route_counts(long long* lean, long long* flat, int reset);
 int exl2_chain_overlap_end(int* n_launches);
 
 /* ---- decode-loop utilities and graphs (replace cuda/graph.cu and the host-side embedding / argmax round trips) ------- */

@@ -250,6 +250,7 @@ DEV u64 realtime_stamp() { return 0; }
 DEV void dma_to_lds16(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
 DEV void dma_to_lds16_nt(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
 DEV void wait_lds_reads() { }
+DEV void wave_converge() { emu_ctx_->wave[wave_id()].bar.wait(); }
 DEV void dma_to_lds4(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 4, g_lane_ptr, 4); }
 template <int N> DEV void wait_vmcnt_le() { }
 DEV void block_sync_lds() { block_sync(); }

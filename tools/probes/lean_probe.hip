@@ -31,12 +31,12 @@ struct LeanArgs
     f16* out;               // [16 n_tiles]
     float* part;            // [tile][S][16]
     u32* tick;              // [tile]
-    int F, S, n_tiles, pad;
+    int F, S, n_tiles, pad;     // pad: runtime item count of the GUARD variants (== NI)
 };
 
 template <int N> DEV void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <int WAVES, int NI, int XMODE, int COMB>
+template <int WAVES, int NI, int XMODE, int COMB, bool GUARD = false>
 KERNEL void __launch_bounds__(WAVES * 64) lean_kernel(const LeanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -47,6 +47,7 @@ KERNEL void __launch_bounds__(WAVES * 64) lean_kernel(const LeanArgs a)
     if (tile >= a.n_tiles) return;                                     // (grids are exact multiples in this probe)
     const int c = lane & 15, j = lane >> 4;
     const int i0 = r * NI;
+    const int n_rt = GUARD ? a.pad : NI;                               // GUARD: the count is a run-time value, every item sits behind a branch
 
     // x: issued first so that it is the oldest outstanding request
     f16* xl;
@@ -85,7 +86,7 @@ KERNEL void __launch_bounds__(WAVES * 64) lean_kernel(const LeanArgs a)
     LaneWords<4> w[NI];
     const u32* wp = a.w + ((size_t)tile * a.F + i0) * 256;
     #pragma unroll
-    for (int i = 0; i < NI; i++) load_lane_words<4>(wp + (size_t)i * 256, lane, w[i]);
+    for (int i = 0; i < NI; i++) if (!GUARD || i < n_rt) load_lane_words<4>(wp + (size_t)i * 256, lane, w[i]);
 
     if constexpr (XMODE == 1)
     {
@@ -97,11 +98,13 @@ KERNEL void __launch_bounds__(WAVES * 64) lean_kernel(const LeanArgs a)
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     const ZC zc = make_zc((f16)8.0f);
     const ZC z4[4] = {zc, zc, zc, zc};
+    if constexpr (GUARD) vm_wait<0>();
     #pragma unroll
     for (int i = 0; i < NI; i++)
     {
+        if (GUARD && i >= n_rt) continue;
         // wait for item i (loads complete in issue order)
-        switch (NI - 1 - i)
+        if constexpr (!GUARD) switch (NI - 1 - i)
         {
             case 0: vm_wait<0>(); break; case 1: vm_wait<1>(); break; case 2: vm_wait<2>(); break; case 3: vm_wait<3>(); break;
             case 4: vm_wait<4>(); break; case 5: vm_wait<5>(); break; case 6: vm_wait<6>(); break; case 7: vm_wait<7>(); break;
@@ -123,6 +126,7 @@ KERNEL void __launch_bounds__(WAVES * 64) lean_kernel(const LeanArgs a)
         const float sf = (float)s[i];
         #pragma unroll
         for (int e = 0; e < 4; e++) acc[e] = fmaf(sf, part[e], acc[e]);
+        if constexpr (GUARD) __builtin_amdgcn_sched_barrier(0);
     }
 
     // combine: row 0 of the product sits in lanes 0..15, acc[0]
@@ -187,10 +191,13 @@ struct Phase { const char* name; int n_tiles, F; };
 static const Phase PH[4] = {{"o", 256, 32}, {"gate|up", 1376, 32}, {"down", 256, 88}, {"q|k|v", 768, 32}};
 
 typedef void (*LeanFn)(const LeanArgs);
-struct Variant { const char* name; LeanFn fn; int waves, ni, xmode, comb; };
+struct Variant { const char* name; LeanFn fn; int waves, ni, xmode, comb; int cold_sc = 0; };
 #define V(W, N, X, C) {#W "w NI" #N " x" #X " c" #C, lean_kernel<W, N, X, C>, W, N, X, C}
+#define VG(W, N, X, C) {#W "w NI" #N " x" #X " c" #C " guard", lean_kernel<W, N, X, C, true>, W, N, X, C}
+#define VC(W, N, X, C) {#W "w NI" #N " x" #X " c" #C " coldsc", lean_kernel<W, N, X, C>, W, N, X, C, 1}
+#define VGC(W, N, X, C) {#W "w NI" #N " x" #X " c" #C " guard coldsc", lean_kernel<W, N, X, C, true>, W, N, X, C, 1}
 
-struct Bufs { char* w; f16* x; f16* sc; f16* out; float* part; u32* tick; u32* sink; size_t w_bytes; };
+struct Bufs { char* w; f16* x; f16* sc; char* sc_big; f16* out; float* part; u32* tick; u32* sink; size_t w_bytes; };
 
 static size_t lds_bytes(const Variant& v, int F)
 {
@@ -210,8 +217,12 @@ static bool fits(const Variant& v, const Phase& p)
 static void launch_phase(const Variant& v, const Phase& p, const Bufs& b, size_t w_off, hipStream_t st)
 {
     LeanArgs a;
-    a.w = (const u32*)(b.w + w_off); a.x = b.x; a.sc = b.sc; a.out = b.out; a.part = b.part; a.tick = b.tick;
-    a.F = p.F; a.S = p.F / v.ni; a.n_tiles = p.n_tiles; a.pad = 0;
+    // cold_sc: the scale table of every launch lives somewhere else (as in the real model: one table per matrix), 4 MB apart
+    static size_t sc_rot = 0;
+    const f16* sc = b.sc;
+    if (v.cold_sc) { sc = (const f16*)((const char*)b.sc_big + (sc_rot % 200) * (4u << 20)); sc_rot++; }
+    a.w = (const u32*)(b.w + w_off); a.x = b.x; a.sc = sc; a.out = b.out; a.part = b.part; a.tick = b.tick;
+    a.F = p.F; a.S = p.F / v.ni; a.n_tiles = p.n_tiles; a.pad = v.ni;
     const int wgs = (int)((long long)p.n_tiles * a.S / v.waves);
     hipLaunchKernelGGL(v.fn, dim3(wgs), dim3(v.waves * 64), lds_bytes(v, p.F), st, a);
 }
@@ -237,6 +248,7 @@ int main()
     CK(hipMalloc(&b.w, b.w_bytes + (64 << 20))); CK(hipMemset(b.w, 0x37, b.w_bytes));
     CK(hipMalloc(&b.x, 16384 * 2)); CK(hipMemset(b.x, 0, 16384 * 2));
     CK(hipMalloc(&b.sc, (size_t)1376 * 88 * 32)); CK(hipMemset(b.sc, 0, (size_t)1376 * 88 * 32));
+    CK(hipMalloc(&b.sc_big, (size_t)204 * (4u << 20))); CK(hipMemset(b.sc_big, 0, (size_t)204 * (4u << 20)));
     CK(hipMalloc(&b.out, 1376 * 32)); CK(hipMemset(b.out, 0, 1376 * 32));
     CK(hipMalloc(&b.part, (size_t)1376 * 64 * 64)); CK(hipMalloc(&b.tick, 1376 * 4)); CK(hipMemset(b.tick, 0, 1376 * 4));
     CK(hipMalloc(&b.sink, 1 << 22));
@@ -244,16 +256,11 @@ int main()
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 
     std::vector<Variant> vars = {
-        V(16, 2, 1, 0), V(16, 2, 0, 0), V(16, 4, 1, 0), V(16, 8, 1, 0), V(16, 8, 0, 0), V(16, 11, 1, 0), V(16, 11, 0, 0),
-        V(8, 4, 1, 0), V(8, 4, 0, 0), V(8, 8, 1, 0), V(8, 8, 0, 0), V(8, 11, 1, 0), V(8, 11, 0, 0),
-        V(4, 8, 1, 0), V(4, 8, 0, 0), V(4, 8, 2, 0),
-        V(4, 2, 0, 1), V(4, 4, 0, 1), V(4, 4, 1, 1), V(4, 8, 0, 1), V(4, 11, 0, 1), V(4, 11, 1, 1), V(4, 4, 2, 1),
-        V(8, 2, 0, 1), V(8, 4, 0, 1), V(8, 8, 0, 1), V(8, 11, 0, 1),
-        V(2, 4, 0, 1), V(2, 8, 0, 1), V(1, 8, 0, 1), V(1, 4, 0, 1),
-        V(16, 2, 3, 0), V(16, 8, 3, 0), V(16, 11, 3, 0), V(8, 4, 3, 0), V(8, 8, 3, 0), V(8, 11, 3, 0), V(4, 8, 3, 0),
-        V(4, 2, 3, 1), V(4, 4, 3, 1), V(4, 8, 3, 1), V(4, 11, 3, 1), V(8, 2, 3, 1), V(8, 4, 3, 1), V(8, 8, 3, 1), V(8, 11, 3, 1),
-        V(2, 4, 3, 1), V(2, 8, 3, 1), V(1, 4, 3, 1), V(1, 8, 3, 1),
+        V(8, 4, 0, 0), VG(8, 4, 0, 0), VC(8, 4, 0, 0), VGC(8, 4, 0, 0),
+        V(8, 8, 0, 0), VG(8, 8, 0, 0), V(8, 11, 0, 0), VG(8, 11, 0, 0), VGC(8, 11, 0, 0),
+        V(16, 2, 0, 0), VG(16, 2, 0, 0), V(16, 4, 0, 0), VG(16, 4, 0, 0), VGC(16, 4, 0, 0),
     };
+
     for (const Variant& v : vars) CK(hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
 
     printf("per-phase time (graph of 128 launches of the phase over distinct weights), us per launch incl. the boundary\n");
