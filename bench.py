@@ -110,15 +110,15 @@ def time_gemv_calls(model, dec, reps: int = 5):
     def chain_launches(plan, x2, npart):
         launches, nbytes = 0, 0
         for i, (attn, mlp) in enumerate(model.layers):
-            in_a, o_inv, in_m = plan[i]
+            in_a, o_inv, in_m, nw_a, nw_m = plan[i]
             ext.q_attn_forward_1_chain(attn.q_handle, ch["xp_a"], ch["ss_a"], npart, b, q, k, v)
-            npart = ext.q_attn_forward_2_chain(attn.q_handle, x2, ao, b, in_m, ch["xp_b"], ch["ss_b"])
-            nxt = plan[i + 1][0] if i + 1 < len(plan) else ch["head_inv"]
-            npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, ch["xp_b"], ch["ss_b"], npart, b, nxt, ch["xp_a"], ch["ss_a"])
+            npart = ext.q_attn_forward_2_chain(attn.q_handle, x2, ao, b, in_m, nw_m, ch["xp_b"], ch["ss_b"])
+            nxt, nxt_w = (plan[i + 1][0], plan[i + 1][3]) if i + 1 < len(plan) else (ch["head_inv"], ch["norm_head"])
+            npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, ch["xp_b"], ch["ss_b"], npart, b, nxt, nxt_w, ch["xp_a"], ch["ss_a"])
             launches += 4
             nbytes += sum(l.weight_bytes() for l in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj,
                                                      mlp.gate_proj, mlp.up_proj, mlp.down_proj))
-        ext.gemm_half_q_half_chain(ch["xp_a"], ch["ss_a"], npart, ch["norm_head"], cfg.norm_eps, model.lm_head.q_handle, dec.logits, b)
+        ext.gemm_half_q_half_chain(ch["xp_a"], ch["ss_a"], npart, cfg.norm_eps, model.lm_head.q_handle, dec.logits, b)
         return launches + 1, nbytes + model.lm_head.weight_bytes()
 
     def one_step_modules():

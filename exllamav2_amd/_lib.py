@@ -74,14 +74,14 @@ PROTOTYPES = {
     "exl2_q_moe_mlp_forward": (ci, [vp, vp, ci, vp]),
     "exl2_moe_route": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     # chained decode (csrc/qgemv_flat.hip)
-    "exl2_q_attn_chain_info": (ci, [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp)]),
-    "exl2_q_mlp_chain_info": (ci, [vp, C.POINTER(ci), C.POINTER(vp)]),
+    "exl2_q_attn_chain_info": (ci, [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+    "exl2_q_mlp_chain_info": (ci, [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp)]),
     "exl2_q_matrix_perm_info": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
     "exl2_q_attn_forward_1_chain": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, vp]),
-    "exl2_q_attn_forward_2_chain": (ci, [vp, vp, vp, ci, vp, vp, vp, C.POINTER(ci), vp]),
-    "exl2_q_mlp_forward_chain": (ci, [vp, vp, vp, vp, ci, ci, vp, vp, vp, C.POINTER(ci), vp]),
-    "exl2_gemm_half_q_half_chain": (ci, [vp, vp, ci, vp, cf, vp, vp, ci, vp]),
-    "exl2_embed_rows_chain": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp]),
+    "exl2_q_attn_forward_2_chain": (ci, [vp, vp, vp, ci, vp, vp, vp, vp, C.POINTER(ci), vp]),
+    "exl2_q_mlp_forward_chain": (ci, [vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, C.POINTER(ci), vp]),
+    "exl2_gemm_half_q_half_chain": (ci, [vp, vp, ci, cf, vp, vp, ci, vp]),
+    "exl2_embed_rows_chain": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp]),
     "exl2_gather_f16": (ci, [vp, vp, vp, ci, vp]),
     "exl2_chain_overlap_begin": (ci, [vp, ci, vp, vp]),
     "exl2_chain_overlap_end": (ci, [C.POINTER(ci)]),

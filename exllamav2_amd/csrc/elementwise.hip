@@ -265,10 +265,10 @@ KERNEL void __launch_bounds__(256) embed_rows_kernel(const f16* table, const int
     for (int i = tid(); i < (hidden >> 3); i += 256) dst[i] = src[i];
 }
 
-// embedding row -> x, x in the first consumer's packed order, and the row's sum of squares (npart = 1): what the chained
-// decode (qgemv_flat.hip) expects from the producer of a residual stream
+// embedding row -> x, x times the first consumer's norm weight in that consumer's packed order, and the row's sum of squares
+// (npart = 1): what the chained decode (qgemv_flat.h: A_NORM_PRE) expects from the producer of a residual stream
 KERNEL void __launch_bounds__(256) embed_rows_chain_kernel(const f16* table, const int* ids, f16* out, int hidden, int vocab,
-                                                           const u16* invperm, f16* xp, float* ss)
+                                                           const u16* invperm, const f16* next_w, f16* xp, float* ss)
 {
     SHARED float part[4];
     const int row = bid_x();
@@ -282,15 +282,25 @@ KERNEL void __launch_bounds__(256) embed_rows_chain_kernel(const f16* table, con
     {
         const f16x8 v = src[i];
         dst[i] = v;
+        u32 idx[8];
         if (invperm)
         {
             const u32x4 pv = ((const u32x4*)invperm)[i];
-            xr[pv.x & 0xFFFF] = v[0]; xr[pv.x >> 16] = v[1]; xr[pv.y & 0xFFFF] = v[2]; xr[pv.y >> 16] = v[3];
-            xr[pv.z & 0xFFFF] = v[4]; xr[pv.z >> 16] = v[5]; xr[pv.w & 0xFFFF] = v[6]; xr[pv.w >> 16] = v[7];
+            idx[0] = pv.x & 0xFFFF; idx[1] = pv.x >> 16; idx[2] = pv.y & 0xFFFF; idx[3] = pv.y >> 16;
+            idx[4] = pv.z & 0xFFFF; idx[5] = pv.z >> 16; idx[6] = pv.w & 0xFFFF; idx[7] = pv.w >> 16;
         }
-        else ((f16x8*)xr)[i] = v;
+        else
+        {
+            #pragma unroll
+            for (int e = 0; e < 8; e++) idx[e] = (u32)(8 * i + e);
+        }
         #pragma unroll
-        for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)); sq = fmaf(f, f, sq); }
+        for (int e = 0; e < 8; e++)
+        {
+            const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f));
+            sq = fmaf(f, f, sq);
+            xr[idx[e]] = next_w ? (f16)fmaxf(-65504.0f, fminf(f * (float)next_w[idx[e]], 65504.0f)) : v[e];
+        }
     }
     sq = wave_allreduce_add(sq);
     if (lane_id() == 0) part[wave_id()] = sq;
@@ -372,14 +382,14 @@ int exl2_embed_rows(const void* table, const int* ids, void* out, int rows, int 
 }
 
 int exl2_embed_rows_chain(const void* table, const int* ids, void* x, int rows, int hidden, int vocab,
-                          const void* next_invperm, void* xp_out, float* ss_out, void* stream)
+                          const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, void* stream)
 {
     EXL2_REQUIRE(table && ids && x && xp_out && ss_out, "embed_rows_chain: null argument");
     EXL2_REQUIRE(hidden % 8 == 0, "embed_rows_chain: hidden %d must be a multiple of 8", hidden);
     EXL2_REQUIRE(!next_invperm || (((size_t)next_invperm) & 15) == 0, "embed_rows_chain: invperm must be 16-byte aligned");
     if (rows <= 0) return EXL2_OK;
     LAUNCH(embed_rows_chain_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const f16*)table, ids, (f16*)x, hidden, vocab,
-           (const u16*)next_invperm, (f16*)xp_out, ss_out);
+           (const u16*)next_invperm, (const f16*)next_norm_w, (f16*)xp_out, ss_out);
     HIP_TRY(hipGetLastError());
     return EXL2_OK;
 }

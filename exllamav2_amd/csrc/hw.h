@@ -270,6 +270,15 @@ DEV void dma_to_lds16_agent(const void* g_lane_ptr, void* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 16);
 }
 
+// a pointer to GLOBAL memory from its two halves (kernel-argument words fetched as raw dwords): the integer goes through the
+// global address space so that the accesses stay global_load / global_store (a bare integer -> pointer cast would make
+// them flat_* instructions, which also tick the LDS counter)
+DEV void* global_ptr_of(u32 lo, u32 hi)
+{
+    typedef __attribute__((address_space(1))) char* GP;
+    return (void*)(GP)(((u64)hi << 32) | lo);
+}
+
 // dynamic LDS (16-byte aligned base, guide G17)
 #define DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define SHARED __shared__

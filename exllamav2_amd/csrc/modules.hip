@@ -581,22 +581,24 @@ int exl2_chain_overlap_end(int* n_launches)
     return EXL2_OK;
 }
 
-int exl2_q_attn_chain_info(void* handle, int* capable, const void** in_invperm, const void** o_invperm)
+int exl2_q_attn_chain_info(void* handle, int* capable, const void** in_invperm, const void** o_invperm, const void** norm_w_perm)
 {
     EXL2_REQUIRE(handle, "q_attn_chain_info: null handle");
     QAttn* a = (QAttn*)handle;
     if (capable) *capable = a->chain_ok ? 1 : 0;
     if (in_invperm) *in_invperm = a->q_proj->q_perm ? a->q_proj->q_invperm : nullptr;
     if (o_invperm) *o_invperm = a->o_proj->q_perm ? a->o_proj->q_invperm : nullptr;
+    if (norm_w_perm) *norm_w_perm = a->norm_w_perm;
     return EXL2_OK;
 }
 
-int exl2_q_mlp_chain_info(void* handle, int* capable, const void** in_invperm)
+int exl2_q_mlp_chain_info(void* handle, int* capable, const void** in_invperm, const void** norm_w_perm)
 {
     EXL2_REQUIRE(handle, "q_mlp_chain_info: null handle");
     QMLP* m = (QMLP*)handle;
     if (capable) *capable = m->chain_ok ? 1 : 0;
     if (in_invperm) *in_invperm = m->up->q_perm ? m->up->q_invperm : nullptr;
+    if (norm_w_perm) *norm_w_perm = m->norm_w_perm;
     return EXL2_OK;
 }
 
@@ -622,13 +624,13 @@ int exl2_q_attn_forward_1_chain(void* handle, const void* xp, const float* ss, i
     void* cs[3] = {temp_q, temp_k, temp_v};
     for (int i = 0; i < 3; i++) { in.qm[i] = ms[i]; in.c[i] = (f16*)cs[i]; in.ldc[i] = ms[i]->width; }
     in.n_mats = 3; in.M = rows; in.a_mode = A_NORM_PRE; in.a = (const f16*)xp; in.lda = a->hidden_size;
-    in.norm_w = a->norm_w_perm; in.ss = ss; in.npart = npart; in.eps = a->norm_epsilon; in.c_mode = C_STORE;
+    in.ss = ss; in.npart = npart; in.eps = a->norm_epsilon; in.c_mode = C_STORE;
     FLAT_TRY(in, stream, nullptr, "q_attn_forward_1_chain");
     return EXL2_OK;
 }
 
 int exl2_q_attn_forward_2_chain(void* handle, void* x, const void* attn_out_packed, int rows, const void* next_invperm,
-                                void* xp_out, float* ss_out, int* npart_out, void* stream)
+                                const void* next_norm_w, void* xp_out, float* ss_out, int* npart_out, void* stream)
 {
     EXL2_REQUIRE(handle && x && attn_out_packed, "q_attn_forward_2_chain: null argument");
     QAttn* a = (QAttn*)handle;
@@ -639,7 +641,8 @@ int exl2_q_attn_forward_2_chain(void* handle, void* x, const void* attn_out_pack
     in.qm[0] = a->o_proj; in.c[0] = (f16*)x; in.ldc[0] = a->o_proj->width;
     in.n_mats = 1; in.M = rows; in.a_mode = A_DIRECT; in.a = (const f16*)attn_out_packed; in.lda = a->o_proj->height;
     in.c_mode = C_ACCUM;
-    in.xp_out = (f16*)xp_out; in.xp_invperm = (const u16*)next_invperm; in.ss_out = xp_out ? ss_out : nullptr; in.ldxp = a->hidden_size;
+    in.xp_out = (f16*)xp_out; in.xp_invperm = (const u16*)next_invperm; in.xp_w = (const f16*)next_norm_w;
+    in.ss_out = xp_out ? ss_out : nullptr; in.ldxp = a->hidden_size;
     int wgs = 0;
     FLAT_TRY(in, stream, &wgs, "q_attn_forward_2_chain");
     if (npart_out) *npart_out = wgs;
@@ -647,7 +650,7 @@ int exl2_q_attn_forward_2_chain(void* handle, void* x, const void* attn_out_pack
 }
 
 int exl2_q_mlp_forward_chain(void* handle, void* x, const void* xp, const float* ss, int npart, int rows,
-                             const void* next_invperm, void* xp_out, float* ss_out, int* npart_out, void* stream)
+                             const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, int* npart_out, void* stream)
 {
     EXL2_REQUIRE(handle && x && xp && ss, "q_mlp_forward_chain: null argument");
     QMLP* m = (QMLP*)handle;
@@ -661,7 +664,7 @@ int exl2_q_mlp_forward_chain(void* handle, void* x, const void* xp, const float*
         in.qm[0] = m->gate; in.qm[1] = m->up; in.c[0] = m->temp_a; in.c[1] = m->temp_a; in.ldc[0] = inter; in.ldc[1] = inter;
         in.c_invperm[0] = m->down->q_perm ? m->down->q_invperm : nullptr;
         in.n_mats = 2; in.pair = 1; in.M = rows; in.a_mode = A_NORM_PRE; in.a = (const f16*)xp; in.lda = hidden;
-        in.norm_w = m->norm_w_perm; in.ss = ss; in.npart = npart; in.eps = m->norm_epsilon; in.c_mode = C_STORE;
+        in.ss = ss; in.npart = npart; in.eps = m->norm_epsilon; in.c_mode = C_STORE;
         in.act_gelu = m->act_gelu ? 1 : 0;
         FLAT_TRY(in, stream, nullptr, "q_mlp_forward_chain");
     }
@@ -669,7 +672,8 @@ int exl2_q_mlp_forward_chain(void* handle, void* x, const void* xp, const float*
         FlatIn in; memset(&in, 0, sizeof(in));
         in.qm[0] = m->down; in.c[0] = (f16*)x; in.ldc[0] = hidden;
         in.n_mats = 1; in.M = rows; in.a_mode = A_DIRECT; in.a = m->temp_a; in.lda = inter; in.c_mode = C_ACCUM;
-        in.xp_out = (f16*)xp_out; in.xp_invperm = (const u16*)next_invperm; in.ss_out = xp_out ? ss_out : nullptr; in.ldxp = hidden;
+        in.xp_out = (f16*)xp_out; in.xp_invperm = (const u16*)next_invperm; in.xp_w = (const f16*)next_norm_w;
+        in.ss_out = xp_out ? ss_out : nullptr; in.ldxp = hidden;
         int wgs = 0;
         FLAT_TRY(in, stream, &wgs, "q_mlp_forward_chain");
         if (npart_out) *npart_out = wgs;
@@ -677,17 +681,17 @@ int exl2_q_mlp_forward_chain(void* handle, void* x, const void* xp, const float*
     return EXL2_OK;
 }
 
-int exl2_gemm_half_q_half_chain(const void* xp, const float* ss, int npart, const void* norm_w_perm, float eps,
+int exl2_gemm_half_q_half_chain(const void* xp, const float* ss, int npart, float eps,
                                 void* q_matrix, void* c, int rows, void* stream)
 {
-    EXL2_REQUIRE(xp && ss && norm_w_perm && q_matrix && c, "gemm_half_q_half_chain: null argument");
+    EXL2_REQUIRE(xp && ss && q_matrix && c, "gemm_half_q_half_chain: null argument");
     QMatrix* q = (QMatrix*)q_matrix;
     if (rows <= 0) return EXL2_OK;
     EXL2_REQUIRE(rows <= MAX_GEMV_ROWS, "gemm_half_q_half_chain: %d rows", rows);
     FlatIn in; memset(&in, 0, sizeof(in));
     in.qm[0] = q; in.c[0] = (f16*)c; in.ldc[0] = q->width;
     in.n_mats = 1; in.M = rows; in.a_mode = A_NORM_PRE; in.a = (const f16*)xp; in.lda = q->height;
-    in.norm_w = (const f16*)norm_w_perm; in.ss = ss; in.npart = npart; in.eps = eps; in.c_mode = C_STORE;
+    in.ss = ss; in.npart = npart; in.eps = eps; in.c_mode = C_STORE;
     FLAT_TRY(in, stream, nullptr, "gemm_half_q_half_chain");
     return EXL2_OK;
 }

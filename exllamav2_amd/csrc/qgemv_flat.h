@@ -3,20 +3,25 @@
 #include "qmatrix.h"
 
 #define FLAT_MAX_MATS 4
+// A_DIRECT: `a` rows are the activations, in the matrices' packed K order.
+// A_NORM_PRE: `a` rows are x * w -- the residual stream times the consumer's RMSNorm weight, rounded to fp16 by the PRODUCER
+// (xp_w below), in packed order -- and `ss` holds the partial sums of squares of x: the product is scaled by
+// rsqrt(mean(x^2) + eps) at the very end (fp32), so a consumer's prologue is a plain copy and the per-element
+// normalisation is done once (by the producer) instead of once per 16-column tile.
 enum { A_DIRECT = 0, A_NORM_PRE = 1 };
 
 struct FlatIn
 {
     const QMatrix* qm[FLAT_MAX_MATS]; f16* c[FLAT_MAX_MATS]; const u16* c_invperm[FLAT_MAX_MATS]; int ldc[FLAT_MAX_MATS];
     int n_mats, M;
-    int a_mode;                   // A_DIRECT: `a` rows are in the matrices' packed K order; A_NORM_PRE: xp + ss + norm_w
+    int a_mode;                   // A_DIRECT / A_NORM_PRE
     const f16* a; int lda;
-    const f16* norm_w;            // A_NORM_PRE: RMSNorm weight in packed order [K]
     const float* ss; int npart;   // A_NORM_PRE: partial sums of squares [M, npart]
     float eps;
     int pair;                     // 2 matrices (gate, up): output = act(gate) * up, written through mat 0's c / c_invperm
     int act_gelu, c_mode;         // C_STORE / C_ACCUM (residual)
-    f16* xp_out; const u16* xp_invperm; float* ss_out; int ldxp;     // chain-out (nullable)
+    f16* xp_out; const u16* xp_invperm; float* ss_out; int ldxp;     // chain-out (nullable): x in the next consumer's order ...
+    const f16* xp_w;              // ... times that consumer's norm weight (in ITS packed order; nullable = 1), + partial sums of x^2
     // overlapped chain (chain_sync.h / hw.h): sync_wait = the producer launch's block (its "go" word is polled before the
     // activations are read, with agent-scope loads), sync_signal = this launch's block (outputs are agent-scope stores;
     // every combining wave arrives there, the last publishes "go").  Both nullable.

@@ -73,7 +73,7 @@ struct alignas(64) FpMatCold
 struct FlatHdr
 {
     const f16* a;                 // A_DIRECT: rows in packed order [M, lda]; A_NORM_PRE: xp [M, lda]
-    const f16* norm_w;            // A_NORM_PRE: norm weight in packed order [K]
+    const f16* xp_w;              // chain-out: the next consumer's norm weight in its packed order (nullable = 1); see qgemv_flat.h
     const float* ss;              // A_NORM_PRE: partial sums of squares [M, npart]
     f16* xp_out; const u16* xp_invperm; float* ss_out;      // chain-out (nullable): x in the next consumer's order + partials
     const f16* r_weights;         // grouped (MoE) launches: routing weights [M, r_stride], column = group; nullable
@@ -331,7 +331,7 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
     // (the fields it needs are read from the argument block once, here: every further mention of `args` inside the six copies
     // of `head` counts against the compiler's use limit for keeping a by-value kernel argument out of the stack)
     const int act_mode = args.a_mode, act_lda = args.lda, act_stride = args.a_stride, act_npart = args.npart;
-    const f16* const act_a = args.a; const f16* const act_nw = args.norm_w; const float* const act_ss = args.ss;
+    const f16* const act_a = args.a; const float* const act_ss = args.ss;
     const u32* const dep_wait = DEP ? args.sync_wait : nullptr;
     if constexpr (DEP) if (args.sync_arrive && t == 0) (void)ticket_add_agent(args.sync_arrive, 1u);      // "this workgroup holds its CU"
 #define FLAT_ISSUE_ACTS() do { \
@@ -343,7 +343,7 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
         else if (one_pass && t < M * oct) \
         { \
             xr = DEP ? load_agent_f16x8(act_a + (size_t)row1 * act_lda + (size_t)oc1 * 8) : *(const f16x8*)(act_a + (size_t)row1 * act_lda + (size_t)oc1 * 8); \
-            wr = *(const f16x8*)(act_nw + (size_t)oc1 * 8); \
+            wr = (f16x8){1, 1, 1, 1, 1, 1, 1, 1};      /* the producer multiplied by the norm weight (qgemv_flat.h: A_NORM_PRE) */ \
             /* partial sums of squares: every wave reduces its row's partials itself (fixed order), no LDS round trip */ \
             const float* sp_ = act_ss + (size_t)row1 * act_npart; \
             _Pragma("unroll") \
@@ -393,9 +393,8 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
         {
             if (t < M * oct)
             {
-                float ss = (ssp[0] + ssp[1]) + (ssp[2] + ssp[3]);
-                ss = wave_allreduce_add(ss);
-                const float rms = fast_rsqrt(ss * (1.0f / (float)K) + args.eps);
+                const float rms = 1.0f;                 // (1 / rms(x) multiplies the finished sums: qgemv_flat.h, A_NORM_PRE)
+                (void)ssp;
                 f16x8 v;
                 #pragma unroll
                 for (int e = 0; e < 8; e++)
@@ -410,15 +409,11 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
         // many rows: row by row, every wave reduces the row's partials itself
         for (int rr = 0; rr < M; rr++)
         {
-            float ss = 0.0f;
-            const float* sp = args.ss + (size_t)rr * args.npart;
-            for (int i = lane; i < args.npart; i += 64) ss += DEP ? load_agent_f32(sp + i) : sp[i];
-            ss = wave_allreduce_add(ss);
-            const float rms = fast_rsqrt(ss * (1.0f / (float)K) + args.eps);
+            const float rms = 1.0f;                     // (1 / rms(x) multiplies the finished sums)
             for (int o = t; o < oct; o += nw * 64)
             {
                 const f16x8 x = DEP ? load_agent_f16x8(args.a + (size_t)rr * args.lda + (size_t)o * 8) : *(const f16x8*)(args.a + (size_t)rr * args.lda + (size_t)o * 8);
-                const f16x8 w = *(const f16x8*)(args.norm_w + (size_t)o * 8);
+                const f16x8 w = {1, 1, 1, 1, 1, 1, 1, 1};      // (the producer multiplied by the norm weight)
                 f16x8 v;
                 #pragma unroll
                 for (int e = 0; e < 8; e++)
@@ -657,6 +652,16 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
         return v;
     };
     float sq = 0.0f;
+    // A_NORM_PRE: the activations were x * w (qgemv_flat.h); 1 / rms(x) of this row from the producer's partial sums (fixed order)
+    float rms_row = 1.0f;
+    if (args.a_mode == A_NORM_PRE)
+    {
+        float ss = 0.0f;
+        const float* sp = args.ss + (size_t)row * args.npart;
+        for (int i = lane; i < args.npart; i += 64) ss += DEP ? load_agent_f32(sp + i) : sp[i];
+        ss = wave_allreduce_add(ss);
+        rms_row = fast_rsqrt(ss * (1.0f / (float)K) + args.eps);
+    }
     const f16 rwt = (ARGS::grouped && rw) ? rw[(size_t)row * args.r_stride] : (f16)1.0f;
     const bool row_on = !(ARGS::grouped && rw) || as_u16(rwt) != 0;      // rows the group is not routed to are left alone
     #pragma unroll
@@ -675,7 +680,7 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
             f16 y;
             if (args.pair)
             {
-                float gv = slot_sum(2 * o), uv = slot_sum(2 * o + 1);
+                float gv = slot_sum(2 * o) * rms_row, uv = slot_sum(2 * o + 1) * rms_row;
                 if (args.any_bias)
                 {
                     if (args.cold(0).bias) gv += (float)args.cold(0).bias[n];
@@ -685,7 +690,7 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
             }
             else
             {
-                float v = slot_sum(o);
+                float v = slot_sum(o) * rms_row;
                 if (args.any_bias)
                 {
                     const f16* bp = j == 0 ? args.cold(0).bias : j == 1 ? args.cold(1).bias : j == 2 ? args.cold(2).bias : args.cold(3).bias;
@@ -698,9 +703,11 @@ KERNEL void __launch_bounds__(1024) qgemv_flat_kernel(const ARGS args)
             if constexpr (DEP) store_agent_f16(cp, y); else *cp = y;
             if (args.xp_out)
             {
-                f16* xo = args.xp_out + (size_t)row * args.ldxp + (args.xp_invperm ? (int)args.xp_invperm[n] : n);
-                if constexpr (DEP) store_agent_f16(xo, y); else *xo = y;
+                const int xi = args.xp_invperm ? (int)args.xp_invperm[n] : n;
+                f16* xo = args.xp_out + (size_t)row * args.ldxp + xi;
                 const float f = fmaxf(-65504.0f, fminf((float)y, 65504.0f));
+                const f16 yw = args.xp_w ? (f16)fmaxf(-65504.0f, fminf(f * (float)args.xp_w[xi], 65504.0f)) : y;      // x * the consumer's norm weight
+                if constexpr (DEP) store_agent_f16(xo, yw); else *xo = yw;
                 sq = fmaf(f, f, sq);
             }
         }
@@ -850,7 +857,7 @@ static u32 flat_plan(FlatHdr& hdr, const FlatIn& in, const FlatPlanAcc& acc, u32
         const u32 b = minor_bytes_of_S(S, ctx);
         if (b > minor_wave_bytes) minor_wave_bytes = b;
     }
-    hdr.a = in.a; hdr.norm_w = in.norm_w; hdr.ss = in.ss; hdr.npart = in.npart; hdr.lda = in.lda; hdr.K = K; hdr.M = M;
+    hdr.a = in.a; hdr.xp_w = in.xp_w; hdr.ss = in.ss; hdr.npart = in.npart; hdr.lda = in.lda; hdr.K = K; hdr.M = M;
     hdr.a_mode = in.a_mode; hdr.n_mats = in.n_mats; hdr.pair = in.pair; hdr.eps = in.eps;
     hdr.a_stride = K + 8; hdr.c_mode = in.c_mode; hdr.act_gelu = in.act_gelu; hdr.any_bias = acc.any_bias ? 1 : 0;
     hdr.xp_out = in.xp_out; hdr.xp_invperm = in.xp_invperm; hdr.ss_out = in.ss_out; hdr.ldxp = in.ldxp; hdr.wgs = wgs;
@@ -880,7 +887,7 @@ static bool flat_in_ok(const FlatIn& in)
     if (in.n_mats < 1 || in.n_mats > FLAT_MAX_MATS || in.M < 1 || in.M > MAX_GEMV_ROWS) return false;
     if (in.qm[0]->height & 7) return false;
     if (!ptr16(in.a) || (in.lda & 7)) return false;
-    if (in.a_mode == A_NORM_PRE && (!ptr16(in.norm_w) || !in.ss || in.npart < 1 || in.npart > 256)) return false;
+    if (in.a_mode == A_NORM_PRE && (!in.ss || in.npart < 1 || in.npart > 256)) return false;
     if (in.pair && (in.n_mats != 2 || in.qm[0]->width != in.qm[1]->width)) return false;
     return true;
 }

@@ -36,13 +36,12 @@
 #include <vector>
 #include <mutex>
 
-#define LEAN_SEGS 3
 // tuning switches (A/B builds through tools/build_variant.sh; the defaults are what the MI355X runs picked)
-#ifndef LEAN_NORM_LDS
-#define LEAN_NORM_LDS 1               // 1: RMSNorm of the slice in place in LDS after it has landed; 0: in registers on its way in (one row, <= 64 units)
-#endif
 #ifndef LEAN_PRESCALE
 #define LEAN_PRESCALE 1               // 1: general items scale the weights (fp16, reconstruct()'s rounding); 0: four scales on four partial sums
+#endif
+#ifndef LEAN_KILL
+#define LEAN_KILL 0                   // instruction-count experiments (results are WRONG): 1 no decode, 2 no norm arithmetic, 4 no epilogue
 #endif
 #ifndef LEAN_LOWBITS
 #define LEAN_LOWBITS 1                // 0: no 2 / 3-bit register stream (code-size experiment; such segments would be wrong)
@@ -52,24 +51,20 @@
 #define LEAN_MAX_PART 256             // partial sums of squares per row a chain-out launch may publish (consumer side: 4 per lane)
 #define LEAN_LDS_BUDGET (40u * 1024u)  // per 8 waves: four 8-wave / two 16-wave workgroups stay resident on a CU
 
-// one contiguous run of items (super-chunks) of one bit width inside a tile's K range
-struct LeanSeg
-{
-    u32 off;                          // word offset of the first item for tile 0 (in qw, or in tail)
-    u32 tstride;                      // words between consecutive tiles
-    u32 meta;                         // n (0..9) | bits (10..13) | nvalid_last (14..16) | in_tail (17) | gshift (18..20) | gphase (21..30) | uniform (31)
-    u32 place;                        // first 32-row chunk (0..15) | scale-table row of that chunk relative to the wave's first row (16..31)
-};
-// what one wave of a workgroup does for its tile: <= LEAN_SEGS segments (the first one is requested into registers and holds
-// full items only, the others are staged in LDS), one contiguous range of the activation row, one contiguous range of
-// scale-table rows, its private LDS area.  64 bytes = one scalar load.
+// What one wave of a workgroup does for its tile: ONE run of full items of one bit width (requested into registers, <= LeanDepth
+// of them) plus, when the run ends in a partial super-chunk and this wave holds its end, that partial item (it lives in the
+// matrix' side buffer); one contiguous range of the activation row, one contiguous range of scale-table rows, its private LDS
+// area.  64 bytes = one scalar load.
 struct alignas(64) LeanWave
 {
+    u32 w_off, w_tstride;             // full items: word offset of the first one for tile 0 in qw, words between consecutive tiles
+    u32 t_off, t_tstride;             // the partial item: the same in the side buffer
+    u32 meta;                         // n (0..7) | bits (8..11) | nvalid of the partial item, 0 = none (12..14) | uniform (15) | gshift (16..18) | gphase (19..28)
     u32 xr;                           // first chunk (0..15) | number of chunks (16..31) of the activation slice
     u32 gr;                           // first scale-table row (0..15) | number of rows (16..31)
     u32 lds_off;                      // byte offset of the wave's LDS area inside its slot's area
-    u32 pad;
-    LeanSeg seg[LEAN_SEGS];
+    u32 place;                        // first 32-row chunk of the run's part (0..15) | scale-table row of that chunk relative to the wave's first row (16..31)
+    u32 pad[7];
 };
 // per matrix: 64 bytes; the first 40 are what a wave needs at entry, the rest is read by the finalising waves
 struct alignas(64) LeanMat
@@ -82,7 +77,7 @@ struct alignas(64) LeanMat
 // what every wave needs before anything else: the first 64 bytes; the rest is read by the finalising waves when they get there
 struct alignas(64) LeanHdr
 {
-    const f16* a; const f16* norm_w;
+    const f16* a; const f16* xp_w;    // xp_w: chain-out, the next consumer's norm weight in its packed order (nullable = 1)
     const float* ss; float eps; int M;
     int K, lda, npart; u32 flags;     // flags: a_mode (0) | gelu (3) | c_accum (4) | any_bias (5)
     u32 slot_bytes, red_off;          // LDS bytes of one slot's waves; offset of the partial sums
@@ -226,56 +221,7 @@ DEV void lean_item_general(const LaneWords<BITS>& lw, const LeanCtx& cx, int chu
 }
 #endif
 
-// a lane's words of an item that sits in LDS in its memory layout ([piece][lane][words], qlayout.h)
-template <int BITS> DEV void lean_lds_words(const u32* slot, int lane, LaneWords<BITS>& r)
-{
-    if constexpr (BITS == 4)
-    {
-        const u32x4 v = ((const u32x4*)slot)[lane];
-        r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
-    }
-    else if constexpr (BITS == 8)
-    {
-        const u32x4 v0 = ((const u32x4*)slot)[lane];
-        const u32x4 v1 = ((const u32x4*)(slot + 256))[lane];
-        r.w[0] = v0.x; r.w[1] = v0.y; r.w[2] = v0.z; r.w[3] = v0.w;
-        r.w[4] = v1.x; r.w[5] = v1.y; r.w[6] = v1.z; r.w[7] = v1.w;
-    }
-    else if constexpr (BITS == 6)
-    {
-        const u32x4 v0 = ((const u32x4*)slot)[lane];
-        const u32x2 v1 = ((const u32x2*)(slot + 256))[lane];
-        r.w[0] = v0.x; r.w[1] = v0.y; r.w[2] = v0.z; r.w[3] = v0.w;
-        r.w[4] = v1.x; r.w[5] = v1.y;
-    }
-    else if constexpr (BITS == 5)
-    {
-        const u32x4 v0 = ((const u32x4*)slot)[lane];
-        r.w[0] = v0.x; r.w[1] = v0.y; r.w[2] = v0.z; r.w[3] = v0.w;
-        r.w[4] = slot[256 + lane];
-    }
-    else if constexpr (BITS == 3)
-    {
-        const u32* p = slot + lane * 3;
-        r.w[0] = p[0]; r.w[1] = p[1]; r.w[2] = p[2];
-    }
-    else
-    {
-        const u32x2 v = ((const u32x2*)slot)[lane];
-        r.w[0] = v.x; r.w[1] = v.y;
-    }
-}
-
-// copy one item (16 * bits units of 16 bytes) global -> LDS, non-temporal
-DEV void lean_item_to_lds(const u32* src, u8* slot, int bits, int lane)
-{
-    const int units = 16 * bits;
-    for (int base = 0; base < units; base += 64)
-        if (base + lane < units) dma_to_lds16_nt(src + (size_t)(base + lane) * 4, slot + (size_t)base * 16);
-}
-
-struct LeanSegV { const u32* ptr; int n, bits, nvalid, chunk0, g0, gshift, gphase; bool uni; };
-DEV const void* ptr_of(u32 lo, u32 hi) { return (const void*)(((u64)hi << 32) | lo); }
+DEV const void* ptr_of(u32 lo, u32 hi) { return (const void*)global_ptr_of(lo, hi); }
 
 // Geometry (template): S = waves per tile (8 / 16), NSLOTS = tiles per workgroup (1 / 2), PAIR = the two tiles are tile u of
 // matrix 0 (gate) and of matrix 1 (up) and the epilogue writes act(gate) * up.  Otherwise blockIdx.y = matrix.
@@ -294,223 +240,149 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     const int u = bid_x();
     const int slot = wv / S, r = wv % S;
     const int mj = PAIR ? slot : bid_y();
-    // ---- arguments: header, matrix block, wave record -- addresses from built-in ids only: one batch of scalar loads ----------
+    // ---- arguments: header, matrix block, wave record -- addresses from built-in ids only: one batch of scalar loads.
+    // What the weight requests need (matrix pointers, the record's run) is unpacked first; everything else is unpacked AFTER
+    // the requests have been issued: the waves of a CU share one scalar unit, so every scalar instruction ahead of the
+    // requests delays the requests of all of them (profiles/r03_trace_lean_v4.txt: 1-3 us before this ordering).
     const u32x4* hb = (const u32x4*)&args.hdr;
     const u32x4* mb = (const u32x4*)&args.mat[mj];
     const u32x4* wb = (const u32x4*)&args.wave[mj * S + r];
-    const u32x4 h0 = hb[0], h1 = hb[1], h2 = hb[2], h3 = hb[3];
-    const u32x4 m0 = mb[0], m1 = mb[1];
-    const u32x2 m2 = *(const u32x2*)(mb + 2);
-    const u32x4 w0 = wb[0], w1 = wb[1], w2 = wb[2], w3 = wb[3];
+    const u32x4 m0v = mb[0];
+    const u32x2 m2v = *(const u32x2*)(mb + 2);
+    const u32x4 w0v = wb[0];
+    u32 meta_ = ((const u32*)wb)[4];
+    // (pinned: the eleven words arrive as ONE batch of scalar loads here, not one dependent load per early-exit test)
+    u32 m0x = m0v.x, m0y = m0v.y, m0z = m0v.z, m0w = m0v.w, m2x = m2v.x, m2y = m2v.y, w0x = w0v.x, w0y = w0v.y, w0z = w0v.z, w0w = w0v.w;
+    pin_scalar(m0x); pin_scalar(m0y); pin_scalar(m0z); pin_scalar(m0w); pin_scalar(m2x); pin_scalar(m2y);
+    pin_scalar(w0x); pin_scalar(w0y); pin_scalar(w0z); pin_scalar(w0w); pin_scalar(meta_);
+    const u32x4 m0 = {m0x, m0y, m0z, m0w}; const u32x2 m2 = {m2x, m2y}; const u32x4 w0 = {w0x, w0y, w0z, w0w};
 #ifdef EXL2_TRACE
-    u64* const trace = (u64*)ptr_of(h3.z, h3.w);
+    u64* const trace = args.hdr.trace;
 #define LTRACE(i) do { if (trace && lane_id() == 0 && bid_x() < 2048) trace[(((size_t)bid_y() * 2048 + bid_x()) * LEAN_MAX_WAVES + wave_id()) * 8 + (i)] = realtime_stamp(); } while (0)
 #else
 #define LTRACE(i) do { } while (0)
 #endif
     LTRACE(0);
-    const f16* const in_a = (const f16*)ptr_of(h0.x, h0.y);
-    const f16* const in_nw = (const f16*)ptr_of(h0.z, h0.w);
-    const float* const in_ss = (const float*)ptr_of(h1.x, h1.y);
-    const float eps = as_f32(h1.z);
-    const int M = (int)h1.w, K = (int)h2.x, lda = (int)h2.y, npart = (int)h2.z;
-    const u32 flags = h2.w;
-    const u32 slot_bytes = h3.x, red_off = h3.y;
-    const bool norm_mode = (flags & LF_NORM) != 0;
-    const int oct = K >> 3;
-    const u32* const qw = (const u32*)ptr_of(m0.x, m0.y); const u32* const tl = (const u32*)ptr_of(m0.z, m0.w);
-    const f16* const sc_tab = (const f16*)ptr_of(m1.x, m1.y); const f16* const zp_tab = (const f16*)ptr_of(m1.z, m1.w);
-    const int G = (int)m2.x, n_tiles = (int)m2.y;
-
-    // ---- this wave's tile ---------------------------------------------------------------------------------------------------
+    const int n_tiles = (int)m2.y;
     const int tile = PAIR ? u : u * NSLOTS + slot;
     if (!PAIR && u * NSLOTS >= n_tiles) return;                          // (matrices of one launch may have different widths)
     const bool active = tile < n_tiles;
-    const u32 xr = active ? w0.x : 0u, gr = active ? w0.y : 0u;
-    const int xc0 = (int)(xr & 0xFFFFu), xchunks = (int)(xr >> 16);
-    const int gw0 = (int)(gr & 0xFFFFu), ng = (int)(gr >> 16);
-    auto seg_of = [&](const u32x4& sg) -> LeanSegV {
-        const u32 meta = active ? sg.z : 0u, place = sg.w;
-        LeanSegV v;
-        v.n = (int)(meta & 0x3FFu); v.bits = (int)((meta >> 10) & 0xFu); v.nvalid = (int)((meta >> 14) & 0x7u);
-        v.gshift = (int)((meta >> 18) & 0x7u); v.gphase = (int)((meta >> 21) & 0x3FFu); v.uni = (meta >> 31) != 0;
-        v.chunk0 = (int)(place & 0xFFFFu); v.g0 = (int)(place >> 16);
-        v.ptr = (((meta >> 17) & 1u) ? tl : qw) + sg.x + (size_t)(active ? tile : 0) * sg.y;
-        return v;
-    };
-    const LeanSegV s0 = seg_of(w1), s1 = seg_of(w2), s2 = seg_of(w3);
-
-    // the wave's LDS area: [M rows of the activation slice][norm weight slice (norm mode)][scale rows][zero-point rows][staged items]
-    const int x_stride = xchunks * 32 + 8;
-    u8* const wbase = smem + (size_t)slot * slot_bytes + w0.z;
-    f16* const x_lds = (f16*)wbase;
-    const u32 off_nw = ((u32)M * (u32)x_stride * 2u + 15u) & ~15u;
-    f16* const nw_lds = (f16*)(wbase + off_nw);
-    const u32 off_sc = off_nw + (norm_mode ? (u32)xchunks * 64u : 0u);
-    const u32 sc_bytes = ((u32)ng * 32u + 15u) & ~15u;
-    f16* const sc_lds = (f16*)(wbase + off_sc);
-    f16* const zp_lds = (f16*)(wbase + off_sc + sc_bytes);
-    u8* const minor_lds = wbase + off_sc + (GPTQ ? 2u : 1u) * sc_bytes;
-    float* const red = (float*)(smem + red_off);
+    const u32 meta = active ? meta_ : 0u;
+    const int n = (int)(meta & 0xFFu), bits = (int)((meta >> 8) & 0xFu), tail_nv = (int)((meta >> 12) & 0x7u);
+    const int t_ = active ? tile : 0;
+    const u32* const wptr = (const u32*)ptr_of(m0.x, m0.y) + w0.x + (size_t)t_ * w0.y;
+    const u32* const tptr = (const u32*)ptr_of(m0.z, m0.w) + w0.z + (size_t)t_ * w0.w;
     LTRACE(1);
 
-    // ---- prologue requests: scale rows, activation slice ----------------------------------------------------------------
-    if (active)
-    {
-        const int units = 2 * ng;                                           // 16-byte units: a row = 16 halfs
-        const f16* st = sc_tab + ((size_t)tile * G + gw0) * 16;
-        for (int base = 0; base < units; base += 64)
-            if (base + lane < units) dma_to_lds16(st + (size_t)(base + lane) * 8, (u8*)sc_lds + (size_t)base * 16);
-        if constexpr (GPTQ)
+    // ---- everything else a wave needs before it can decode: unpacked and requested behind its weight requests -----------------
+    struct Rest { LeanCtx cx; float* red; int M; u32 flags; int chunk0, g0, gshift, gphase; bool uni; };
+    auto prologue_rest = [&](Rest& R) {
+        const u32x4 h0 = hb[0], h1 = hb[1], h2 = hb[2];
+        const u32x2 h3 = *(const u32x2*)(hb + 3);
+        const u32x4 m1 = mb[1];
+        const u32x4 w1 = wb[1];
+        const u32 w2x = ((const u32*)wb)[8];
+        const f16* const in_a = (const f16*)ptr_of(h0.x, h0.y);
+        const int M = (int)h1.w, K = (int)h2.x, lda = (int)h2.y;
+        R.M = M; R.flags = h2.w;
+        const u32 slot_bytes = h3.x, red_off = h3.y;
+        const int oct = K >> 3;
+        const f16* const sc_tab = (const f16*)ptr_of(m1.x, m1.y); const f16* const zp_tab = (const f16*)ptr_of(m1.z, m1.w);
+        const int G = (int)m2.x;
+        R.uni = ((meta >> 15) & 1u) != 0;
+        R.gshift = (int)((meta >> 16) & 0x7u); R.gphase = (int)((meta >> 19) & 0x3FFu);
+        const u32 xr = active ? w1.y : 0u, gr = active ? w1.z : 0u;
+        const int xc0 = (int)(xr & 0xFFFFu), xchunks = (int)(xr >> 16);
+        const int gw0 = (int)(gr & 0xFFFFu), ng = (int)(gr >> 16);
+        R.chunk0 = (int)(w2x & 0xFFFFu); R.g0 = (int)(w2x >> 16);
+        // the wave's LDS area: [M rows of the activation slice][scale rows][zero-point rows]
+        const int x_stride = xchunks * 32 + 8;
+        u8* const wbase = smem + (size_t)slot * slot_bytes + w1.w;
+        f16* const x_lds = (f16*)wbase;
+        const u32 off_sc = ((u32)M * (u32)x_stride * 2u + 15u) & ~15u;
+        f16* const sc_lds = (f16*)(wbase + off_sc);
+        f16* const zp_lds = (f16*)(wbase + off_sc + (((u32)ng * 32u + 15u) & ~15u));
+        R.red = (float*)(smem + red_off);
+        R.cx.x_lds = x_lds; R.cx.sc_lds = sc_lds; R.cx.zp_lds = zp_lds; R.cx.x_stride = x_stride; R.cx.xc0 = xc0; R.cx.M = M;
+        // requests: scale rows, activation slice.  The common case -- one row, <= 64 units (16 bytes) of each -- is straight-line
+        // code, one LDS-DMA instruction per table (the compiler's loop skeletons around run-time trip counts cost more
+        // instructions per wave than the decode of an item)
+        const int xunits = xchunks * 4;                                   // 16-byte units of the slice (a chunk = 32 halfs)
+        const int xu0 = xc0 * 4;
+        const int sc_units = 2 * ng;                                      // 16-byte units of the scale rows (a row = 16 halfs)
+        const f16* const st = sc_tab + ((size_t)t_ * G + gw0) * 16;
+        if (M == 1 && xunits <= 64 && sc_units <= 64)
         {
-            const f16* zt = zp_tab + ((size_t)tile * G + gw0) * 16;
-            for (int base = 0; base < units; base += 64)
-                if (base + lane < units) dma_to_lds16(zt + (size_t)(base + lane) * 8, (u8*)zp_lds + (size_t)base * 16);
+            if (lane < sc_units) dma_to_lds16(st + (size_t)lane * 8, (u8*)sc_lds);
+            if constexpr (GPTQ) { if (lane < sc_units) dma_to_lds16(zp_tab + ((size_t)t_ * G + gw0) * 16 + (size_t)lane * 8, (u8*)zp_lds); }
+            if (lane < xunits && xu0 + lane < oct) dma_to_lds16(in_a + (size_t)(xu0 + lane) * 8, (u8*)x_lds);
         }
-    }
-    const int xunits = xchunks * 4;                                         // 16-byte units of the slice (a chunk = 32 halfs)
-    const int xu0 = xc0 * 4;
-    // the rows of the slice (raw: in norm mode they are normalised in place once they have landed), the norm weight slice
-#if !LEAN_NORM_LDS
-    f16x8 nx = {0, 0, 0, 0, 0, 0, 0, 0}, nw = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool norm_fast = norm_mode && M == 1 && xunits <= 64 && npart <= 256;
-    if (norm_fast && lane < xunits && xu0 + lane < oct)
-    {
-        nx = *(const f16x8*)(in_a + (size_t)(xu0 + lane) * 8);
-        nw = *(const f16x8*)(in_nw + (size_t)(xu0 + lane) * 8);
-    }
-#else
-    const bool norm_fast = false;
-#endif
-    if (!norm_fast)
-        for (int rr = 0; rr < M; rr++)
-            for (int base = 0; base < xunits; base += 64)
-                if (base + lane < xunits && xu0 + base + lane < oct)
-                    dma_to_lds16(in_a + (size_t)rr * lda + (size_t)(xu0 + base + lane) * 8, (u8*)(x_lds + (size_t)rr * x_stride) + (size_t)base * 16);
-    float ssp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const bool ss_early = norm_mode && M == 1 && npart <= 256;            // the partial sums of squares of the one row: requested now
-    if (norm_mode)
-    {
-        if (!norm_fast)
-            for (int base = 0; base < xunits; base += 64)
-                if (base + lane < xunits && xu0 + base + lane < oct)
-                    dma_to_lds16(in_nw + (size_t)(xu0 + base + lane) * 8, (u8*)nw_lds + (size_t)base * 16);
-        if (ss_early)
+        else
         {
-            #pragma unroll
-            for (int i = 0; i < 4; i++) if (lane + 64 * i < npart) ssp[i] = in_ss[lane + 64 * i];
-        }
-    }
-
-    // ---- the other segments of this wave (other bit widths, partial super-chunks): staged in LDS, decoded after the stream ----
-    {
-        u32 off = 0;
-        #pragma nounroll
-        for (int i = 0; i < s1.n; i++) { lean_item_to_lds(s1.ptr + (size_t)i * (64u * s1.bits), minor_lds + off, s1.bits, lane); off += 256u * s1.bits; }
-        #pragma nounroll
-        for (int i = 0; i < s2.n; i++) { lean_item_to_lds(s2.ptr + (size_t)i * (64u * s2.bits), minor_lds + off, s2.bits, lane); off += 256u * s2.bits; }
-    }
-    LTRACE(2);
-
-    // RMSNorm of the wave's slice, in place once the raw rows and the weight slice have landed: x * w * rsqrt(mean(x^2) + eps),
-    // the producer left the partial sums of squares.  (LDS -> LDS with transient registers: holding the slice in registers
-    // across the weight requests costs 15 VGPRs = one workgroup per CU fewer.)
-    auto norm_prologue = [&]() {
-        if (!norm_mode) return;
-#if !LEAN_NORM_LDS
-        if (norm_fast)
-        {
-            float ss = (ssp[0] + ssp[1]) + (ssp[2] + ssp[3]);
-            ss = wave_allreduce_add(ss);
-            const float rms = fast_rsqrt(ss * (1.0f / (float)K) + eps);
-            if (lane < xunits && xu0 + lane < oct)
+            #pragma nounroll
+            for (int base = 0; base < sc_units; base += 64)
+                if (base + lane < sc_units) dma_to_lds16(st + (size_t)(base + lane) * 8, (u8*)sc_lds + (size_t)base * 16);
+            if constexpr (GPTQ)
             {
-                f16x8 v;
-                #pragma unroll
-                for (int e = 0; e < 8; e++)
-                {
-                    const float f = fmaxf(-65504.0f, fminf((float)nx[e], 65504.0f));
-                    v[e] = (f16)((f * (float)nw[e]) * rms);
-                }
-                *(f16x8*)(x_lds + (size_t)lane * 8) = v;
+                const f16* zt = zp_tab + ((size_t)t_ * G + gw0) * 16;
+                #pragma nounroll
+                for (int base = 0; base < sc_units; base += 64)
+                    if (base + lane < sc_units) dma_to_lds16(zt + (size_t)(base + lane) * 8, (u8*)zp_lds + (size_t)base * 16);
             }
-            return;
-        }
-#endif
-        for (int rr = 0; rr < M; rr++)
-        {
-            float ss = 0.0f;
-            if (ss_early) ss = (ssp[0] + ssp[1]) + (ssp[2] + ssp[3]);
-            else
+            #pragma nounroll
+            for (int rr = 0; rr < M; rr++)
             {
-                const float* sp = in_ss + (size_t)rr * npart;
-                for (int i = lane; i < npart; i += 64) ss += sp[i];
-            }
-            ss = wave_allreduce_add(ss);
-            const float rms = fast_rsqrt(ss * (1.0f / (float)K) + eps);
-            for (int uu = lane; uu < xunits; uu += 64)
-            {
-                if (xu0 + uu >= oct) continue;
-                f16* xp_ = x_lds + (size_t)rr * x_stride + (size_t)uu * 8;
-                const f16x8 x = *(const f16x8*)xp_;
-                const f16x8 w = *(const f16x8*)(nw_lds + (size_t)uu * 8);
-                f16x8 v;
-                #pragma unroll
-                for (int e = 0; e < 8; e++)
-                {
-                    const float f = fmaxf(-65504.0f, fminf((float)x[e], 65504.0f));
-                    v[e] = (f16)((f * (float)w[e]) * rms);
-                }
-                *(f16x8*)xp_ = v;
+                #pragma nounroll
+                for (int base = 0; base < xunits; base += 64)
+                    if (base + lane < xunits && xu0 + base + lane < oct)
+                        dma_to_lds16(in_a + (size_t)rr * lda + (size_t)(xu0 + base + lane) * 8, (u8*)(x_lds + (size_t)rr * x_stride) + (size_t)base * 16);
             }
         }
     };
 
-    LeanCtx cx;
-    cx.x_lds = x_lds; cx.sc_lds = sc_lds; cx.zp_lds = zp_lds; cx.x_stride = x_stride; cx.xc0 = xc0; cx.M = M;
-
-    // ---- the first segment (full items only, <= LeanDepth of them): everything requested at once, decoded item by item ----------
+    // ---- the wave's items: everything requested at once into registers, decoded item by item ------------------------------------
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    Rest R;
     auto head = [&](auto bits_tag) {
         constexpr int BITS = decltype(bits_tag)::value;
         constexpr int D = LeanDepth<BITS>::v;
         constexpr size_t STEP = 64 * BITS;
-        LaneWords<BITS> b[D];
-        const int n = s0.n;
+        LaneWords<BITS> b[D], bt;
         #pragma unroll
-        for (int q = 0; q < D; q++) if (q < n) load_lane_words<BITS>(s0.ptr + (size_t)q * STEP, lane, b[q]);
+        for (int q = 0; q < D; q++) if (q < n) load_lane_words<BITS>(wptr + (size_t)q * STEP, lane, b[q]);
+        if (tail_nv) load_lane_words<BITS>(tptr, lane, bt);
+        LTRACE(2);
+        prologue_rest(R);
         LTRACE(3);
-        wait_vmcnt_le<0>();                  // LDS-DMA copies landed (and the weights: measured free, profiles/r03_lean_probe.txt x0 vs x3)
-        wave_converge();
-        norm_prologue();
-        wait_lds_reads();
+        wait_vmcnt_le<0>();                  // everything landed (weights first, the LDS-DMA copies behind them)
         wave_converge();
         LTRACE(4);
-        if (s0.uni)
+        if (LEAN_KILL & 1) { }
+        else if (R.uni)
         {
             #pragma unroll
             for (int q = 0; q < D; q++)
-                if (q < n) { lean_item_uniform<BITS, GPTQ>(b[q], cx, s0.chunk0 + 4 * q, s0.g0 + ((4 * q + s0.gphase) >> s0.gshift), lane, acc); sched_fence(); }
+                if (q < n) { lean_item_uniform<BITS, GPTQ>(b[q], R.cx, R.chunk0 + 4 * q, R.g0 + ((4 * q + R.gphase) >> R.gshift), lane, acc); sched_fence(); }
         }
         else
         {
             #pragma unroll
             for (int q = 0; q < D; q++)
-                if (q < n) { lean_item_general<BITS, GPTQ>(b[q], cx, s0.chunk0 + 4 * q, 4 * q, s0.g0, s0.gshift, s0.gphase, 4, lane, acc); sched_fence(); }
+                if (q < n) { lean_item_general<BITS, GPTQ>(b[q], R.cx, R.chunk0 + 4 * q, 4 * q, R.g0, R.gshift, R.gphase, 4, lane, acc); sched_fence(); }
         }
+        if (tail_nv) lean_item_general<BITS, GPTQ>(bt, R.cx, R.chunk0 + 4 * n, 4 * n, R.g0, R.gshift, R.gphase, tail_nv, lane, acc);
     };
-    if (s0.n == 0)
+    if (n == 0 && tail_nv == 0)
     {
+        LTRACE(2);
+        prologue_rest(R);
         LTRACE(3);
         wait_vmcnt_le<0>();
-        wave_converge();
-        norm_prologue();
-        wait_lds_reads();
         wave_converge();
         LTRACE(4);
     }
     else if constexpr (GPTQ) head(std::integral_constant<int, 4>());
-    else switch (s0.bits)
+    else switch (bits)
     {
         case 4: head(std::integral_constant<int, 4>()); break;
         case 8: head(std::integral_constant<int, 8>()); break;
@@ -523,39 +395,11 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         default: break;
 #endif
     }
-
-    // ---- the staged segments, from LDS ------------------------------------------------------------------------------------
-    if (s1.n > 0)
-    {
-        u32 off = 0;
-        auto staged = [&](const LeanSegV& sg) {
-            #pragma nounroll
-            for (int i = 0; i < sg.n; i++)
-            {
-                const u32* slot_ptr = (const u32*)(minor_lds + off);
-                off += 256u * sg.bits;
-                const int nv = (i == sg.n - 1) ? sg.nvalid : 4;
-                auto consume = [&](auto bits_tag) {
-                    constexpr int BITS = decltype(bits_tag)::value;
-                    LaneWords<BITS> w;
-                    lean_lds_words<BITS>(slot_ptr, lane, w);
-                    lean_item_general<BITS, GPTQ>(w, cx, sg.chunk0 + 4 * i, 4 * i, sg.g0, sg.gshift, sg.gphase, nv, lane, acc);
-                };
-                if constexpr (GPTQ) consume(std::integral_constant<int, 4>());
-                else switch (sg.bits)
-                {
-                    case 4: consume(std::integral_constant<int, 4>()); break;
-                    case 8: consume(std::integral_constant<int, 8>()); break;
-                    case 6: consume(std::integral_constant<int, 6>()); break;
-                    case 5: consume(std::integral_constant<int, 5>()); break;
-                    case 3: consume(std::integral_constant<int, 3>()); break;
-                    default: consume(std::integral_constant<int, 2>()); break;
-                }
-            }
-        };
-        staged(s1);
-        staged(s2);
-    }
+    const int M = R.M;
+    const u32 flags = R.flags;
+    float* const red = R.red;
+    const int n_tiles_ep = n_tiles;
+    (void)n_tiles_ep;
 
     // ---- partial sums meet in LDS ---------------------------------------------------------------------------------------------
     {
@@ -567,6 +411,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
             if (row < M) red[(wv * M + row) * 16 + c] = acc[q];
         }
     }
+    if (wv >= M) { LTRACE(5); block_sync_lds(); return; }
     // the finalising waves (wave `row` finalises row `row`; they sit in slot 0, so the block of THEIR matrix is the output's):
     // lane -> output slot lane >> 4 (pair: the one act(gate) * up output), column lane & 15.  What the epilogue needs from
     // memory is requested before the barrier.
@@ -574,25 +419,41 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     constexpr int N_OUT = PAIR ? 1 : NSLOTS;
     const int ep_slot = lane >> 4, ep_c = lane & 15;
     const int ep_tile = tile + (PAIR ? 0 : ep_slot);                    // (finalising waves sit in slot 0)
-    const bool ep_on = wv < M && ep_slot < N_OUT && ep_tile < n_tiles;
+    const bool ep_on = ep_slot < N_OUT && ep_tile < n_tiles;
     const int ep_n = ep_tile * 16 + ep_c;
     f16* cp = nullptr;
     f16 c_old = (f16)0.0f;
     int xp_idx = ep_n;
-    f16* const xp_out = wv < M ? args.hdr.xp_out : nullptr;
+    f16* const xp_out = args.hdr.xp_out;
+    f16 xw_next = (f16)1.0f;
     if (ep_on)
     {
         const u16* const c_invperm = args.mat[mj].c_invperm;
         const u16* const xp_invperm = args.hdr.xp_invperm;
         const int c_idx = c_invperm ? (int)c_invperm[ep_n] : ep_n;
         if (xp_out && xp_invperm) xp_idx = (int)xp_invperm[ep_n];
+        if (xp_out && args.hdr.xp_w) xw_next = args.hdr.xp_w[xp_idx];
         cp = args.mat[mj].c + (size_t)row * args.hdr.ldc[mj] + c_idx;
         if (flags & LF_ACCUM) c_old = *cp;
+    }
+    // A_NORM_PRE: the activations were x * w (qgemv_flat.h); 1 / rms(x) multiplies the finished sum.  The partial sums of
+    // squares of this row: requested before the barrier, reduced behind it (fixed order)
+    float ssq = 0.0f;
+    if (flags & LF_NORM)
+    {
+        const float* sp = args.hdr.ss + (size_t)row * args.hdr.npart;
+        #pragma nounroll
+        for (int i = lane; i < args.hdr.npart; i += 64) ssq += sp[i];
     }
     LTRACE(5);
     block_sync_lds();
     LTRACE(6);
-    if (wv >= M) return;
+    float rms = 1.0f;
+    if (flags & LF_NORM)
+    {
+        ssq = wave_allreduce_add(ssq);
+        rms = fast_rsqrt(ssq * (1.0f / (float)args.hdr.K) + args.hdr.eps);
+    }
 
     // ---- combine (fixed order) + epilogue ------------------------------------------------------------------------------------
     auto slot_sum = [&](int s) -> float {
@@ -601,12 +462,12 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         return v;
     };
     float sq = 0.0f;
-    if (ep_on)
+    if (ep_on && !(LEAN_KILL & 4))
     {
         f16 y;
         if constexpr (PAIR)
         {
-            float gv = slot_sum(0), uv = slot_sum(1);
+            float gv = slot_sum(0) * rms, uv = slot_sum(1) * rms;
             if (flags & LF_BIAS)
             {
                 if (args.mat[0].bias) gv += (float)args.mat[0].bias[ep_n];
@@ -616,7 +477,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         }
         else
         {
-            float v = slot_sum(ep_slot);
+            float v = slot_sum(ep_slot) * rms;
             if (flags & LF_BIAS) { const f16* bias = args.mat[mj].bias; if (bias) v += (float)bias[ep_n]; }
             if (flags & LF_ACCUM) v += (float)c_old;
             y = (f16)v;
@@ -624,8 +485,10 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         *cp = y;
         if (xp_out)
         {
-            xp_out[(size_t)row * args.hdr.ldxp + xp_idx] = y;
+            // chain-out: x for the next consumer = x * ITS norm weight (one rounding, saturated), in its packed order; the sum of
+            // squares is x's own
             const float f = fmaxf(-65504.0f, fminf((float)y, 65504.0f));
+            xp_out[(size_t)row * args.hdr.ldxp + xp_idx] = (f16)fmaxf(-65504.0f, fminf(f * (float)xw_next, 65504.0f));
             sq = f * f;
         }
     }
@@ -648,96 +511,88 @@ extern "C" void exl2_debug_set_lean_trace(void* p, int which) { g_ltrace_buf = (
 
 static inline u32 al16(u32 x) { return (x + 15u) & ~15u; }
 
-struct LeanItemRun { int F; int bits; int nvalid; int chunk0; u32 off, tstride; int in_tail; };
+// one bit-width section of a tile's K range: F full items + (optionally) a partial last item in the side buffer
+struct LeanRun { int F, bits, chunk0; u32 off, tstride; int tail_nv; u32 t_off, t_tstride; };
 
-// Splits one tile's items (all runs, K order) over S waves in contiguous ranges of about equal byte cost; fills wave[0 .. S)
-// (segments, activation slice, scale rows, LDS offsets for M rows).  Returns the LDS bytes of the S waves together, 0 when
-// the matrix is not covered with S waves (more segments per wave than the record carries, more items of the register
-// segment than a wave holds, a chunk -> group map that is not affine inside a segment, ...).
+// Splits one tile's items over S waves: every wave gets a contiguous part of ONE run (a wave never mixes bit widths: one
+// decoder per wave, everything in registers); the waves are dealt out to the runs in proportion to their bytes.  Fills
+// wave[0 .. S) and returns the LDS bytes of the S waves together, 0 when the matrix is not covered with S waves (more runs
+// than waves, more items than a wave's registers hold, a chunk -> group map that is not affine inside a part, ...).
 static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave* wave)
 {
     const QMatDev& d = qm->dev;
     if (d.n_runs <= 0 || !qm->cg_host || !d.sc_tab || (qm->is_gptq && !d.zp_tab)) return 0;
-    std::vector<LeanItemRun> runs;
-    long long total = 0;
+    // QRun list (K order): a full run, optionally followed by its partial super-chunk -> logical runs
+    std::vector<LeanRun> runs;
     for (int i = 0; i < d.n_runs; i++)
     {
         const QRun& r = d.runs[i];
-        LeanItemRun t;
-        t.F = r.n_super; t.bits = r.bits; t.nvalid = r.nvalid_last; t.chunk0 = (int)r.k_base >> 5;
-        t.off = r.base_word; t.tstride = r.tile_stride; t.in_tail = r.in_tail;
-        runs.push_back(t);
-        total += (long long)r.n_super * r.bits;
-    }
-    if (total <= 0) return 0;
-    const int n_chunks = d.K / 32;
-    u32 lds_total = 0;
-    // walk the items in K order; wave w takes items until the running cost reaches (w + 1) / S of the total
-    size_t ri = 0; int ii = 0; long long done = 0;
-    for (int w = 0; w < S; w++)
-    {
-        LeanWave& lw = wave[w];
-        memset(&lw, 0, sizeof(lw));
-        lw.lds_off = lds_total;
-        const long long goal = total * (w + 1) / S;
-        int nseg = 0;
-        struct Tmp { LeanItemRun r; int i0, n; } segs[LEAN_SEGS];
-        while (ri < runs.size() && (done < goal || w == S - 1))
+        const int c0 = (int)r.k_base >> 5;
+        if (!r.in_tail)
         {
-            const LeanItemRun& r = runs[ri];
-            // items of this run the wave takes: up to the goal, rounded to the nearest item (at least one); the last wave takes the rest
-            long long want = (goal - done + r.bits / 2) / r.bits;
-            if (want < 1) want = 1;
-            if (w == S - 1) want = r.F - ii;
-            const int take = (int)(want < (long long)(r.F - ii) ? want : (long long)(r.F - ii));
-            if (nseg >= LEAN_SEGS) return 0;
-            segs[nseg].r = r; segs[nseg].i0 = ii; segs[nseg].n = take; nseg++;
-            done += (long long)take * r.bits;
-            ii += take;
-            if (ii >= r.F) { ri++; ii = 0; }
-            else break;                                   // the run goes on: the next wave continues it
+            if (r.nvalid_last != 4) return 0;
+            LeanRun t; memset(&t, 0, sizeof(t));
+            t.F = r.n_super; t.bits = r.bits; t.chunk0 = c0; t.off = r.base_word; t.tstride = r.tile_stride;
+            runs.push_back(t);
         }
-        if (nseg == 0) continue;
-        // segment 0 is requested into registers: the largest one made of full items; a partial super-chunk is always staged
-        auto full = [&](const Tmp& t) { return !(t.i0 + t.n == t.r.F && t.r.nvalid != 4); };
-        int big = -1;
-        for (int q = 0; q < nseg; q++)
-            if (full(segs[q]) && (big < 0 || (long long)segs[q].n * segs[q].r.bits > (long long)segs[big].n * segs[big].r.bits)) big = q;
-        if (big >= 0 && segs[big].n > lean_depth(segs[big].r.bits)) return 0;
-        Tmp ord[LEAN_SEGS]; int no = 0;
-        const bool has0 = big >= 0;
-        if (has0) ord[no++] = segs[big]; else no = 1;
-        for (int q = 0; q < nseg; q++) if (q != big) { if (no >= LEAN_SEGS) return 0; ord[no++] = segs[q]; }
-        const int first = has0 ? 0 : 1;
-        // ranges of chunks and groups the wave touches
-        int c_lo = 0x7fffffff, c_end = -1, g_lo = 0x7fffffff, g_hi = -1;
-        for (int q = first; q < no; q++)
+        else
         {
-            const Tmp& t = ord[q];
-            const bool last_of_run = t.i0 + t.n == t.r.F;
-            const int c0 = t.r.chunk0 + 4 * t.i0;
-            const int nch = 4 * (t.n - 1) + (last_of_run ? t.r.nvalid : 4);
-            if (c0 + nch > n_chunks) return 0;
-            if (c0 < c_lo) c_lo = c0;
-            if (c0 + 4 * t.n > c_end) c_end = c0 + 4 * t.n;      // a partial item reads 4 chunks' worth of activations (clamped to the row)
-            for (int cc = c0; cc < c0 + nch; cc++)
+            if (r.n_super != 1 || r.nvalid_last < 1 || r.nvalid_last > 3) return 0;
+            if (!runs.empty() && runs.back().bits == r.bits && runs.back().tail_nv == 0 && runs.back().chunk0 + 4 * runs.back().F == c0)
             {
-                const int g = qm->cg_host[cc];
-                if (g < g_lo) g_lo = g;
-                if (g > g_hi) g_hi = g;
+                runs.back().tail_nv = r.nvalid_last; runs.back().t_off = r.base_word; runs.back().t_tstride = r.tile_stride;
+            }
+            else
+            {
+                LeanRun t; memset(&t, 0, sizeof(t));
+                t.F = 0; t.bits = r.bits; t.chunk0 = c0; t.tail_nv = r.nvalid_last; t.t_off = r.base_word; t.t_tstride = r.tile_stride;
+                runs.push_back(t);
             }
         }
-        if (c_lo > 0xFFFF || c_end - c_lo > 0xFFFF || g_lo > 0xFFFF || g_hi - g_lo + 1 > 0xFFFF) return 0;
-        lw.xr = (u32)c_lo | ((u32)(c_end - c_lo) << 16);
-        lw.gr = (u32)g_lo | ((u32)(g_hi - g_lo + 1) << 16);
-        u32 minor = 0;
-        for (int q = first; q < no; q++)
+    }
+    const int R = (int)runs.size();
+    if (R < 1 || R > S) return 0;
+    // waves per run: proportional to bytes, at least one, largest remainders first
+    std::vector<int> nw(R, 1);
+    long long total = 0;
+    std::vector<long long> cost(R);
+    for (int i = 0; i < R; i++) { cost[i] = (long long)runs[i].bits * (runs[i].F + (runs[i].tail_nv ? 1 : 0)); total += cost[i]; }
+    for (int left = S - R; left > 0; left--)
+    {
+        int best = -1; double worst = 0.0;
+        for (int i = 0; i < R; i++)
         {
-            const Tmp& t = ord[q];
-            const bool last_of_run = t.i0 + t.n == t.r.F;
-            const int c0 = t.r.chunk0 + 4 * t.i0;
-            const int nch = 4 * (t.n - 1) + (last_of_run ? t.r.nvalid : 4);
-            // affine group map inside the segment: row(chunk) = g0 + ((chunk - c0 + phase) >> shift)
+            if (nw[i] >= runs[i].F) continue;                          // (a wave needs at least one full item to be worth adding)
+            const double per = (double)cost[i] / nw[i];
+            if (per > worst) { worst = per; best = i; }
+        }
+        if (best < 0) break;
+        nw[best]++;
+    }
+    const int n_chunks = d.K / 32;
+    u32 lds_total = 0;
+    int w = 0;
+    for (int s2 = 0; s2 < S; s2++) memset(&wave[s2], 0, sizeof(LeanWave));
+    for (int i = 0; i < R; i++)
+    {
+        const LeanRun& r = runs[i];
+        int i0 = 0;
+        for (int k = 0; k < nw[i]; k++, w++)
+        {
+            const int n = (r.F - i0 + (nw[i] - k) - 1) / (nw[i] - k);        // even split, larger parts first
+            const bool last = k == nw[i] - 1;
+            const int tail_nv = last ? r.tail_nv : 0;
+            if (n > lean_depth(r.bits) || n > 255) return 0;
+            LeanWave& lw = wave[w];
+            lw.lds_off = lds_total;
+            const int c0 = r.chunk0 + 4 * i0;
+            const int nch = 4 * n + tail_nv;                                   // chunks this wave multiplies
+            if (nch <= 0) continue;
+            if (c0 + nch > n_chunks) return 0;
+            const int c_end = c0 + 4 * n + (tail_nv ? 4 : 0);                  // a partial item reads 4 chunks' worth of activations (clamped to the row)
+            int g_lo = 0x7fffffff, g_hi = -1;
+            for (int cc = c0; cc < c0 + nch; cc++) { const int g = qm->cg_host[cc]; if (g < g_lo) g_lo = g; if (g > g_hi) g_hi = g; }
+            // affine group map: row(chunk) = g0 + ((chunk - c0 + phase) >> shift)
             const int g0 = qm->cg_host[c0];
             int phase = 0; while (c0 - phase - 1 >= 0 && qm->cg_host[c0 - phase - 1] == g0 && phase < 1023) phase++;
             int shift = -1;
@@ -748,20 +603,21 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
                 for (int cc = 0; cc < nch && ok; cc++) ok = qm->cg_host[c0 + cc] == g0 + ((cc + phase) >> sh);
                 if (ok) shift = sh;
             }
-            if (shift < 0 || t.n > 0x3FF) return 0;
-            const bool uni = shift >= 2 && (phase & 3) == 0;                   // the four chunks of every item share a group
-            LeanSeg& o = lw.seg[q];
-            o.off = t.r.off + (u32)t.i0 * 64u * (u32)t.r.bits;
-            o.tstride = t.r.tstride;
-            o.meta = (u32)t.n | ((u32)t.r.bits << 10) | ((u32)(last_of_run ? t.r.nvalid : 4) << 14) | ((u32)(t.r.in_tail ? 1 : 0) << 17) |
-                     ((u32)shift << 18) | ((u32)phase << 21) | (uni ? 0x80000000u : 0u);
-            o.place = (u32)c0 | ((u32)(g0 - g_lo) << 16);
-            if (q > 0) minor += (u32)t.n * 256u * (u32)t.r.bits;
+            if (shift < 0 || c0 > 0xFFFF || c_end - c0 > 0xFFFF || g_lo > 0xFFFF || g_hi - g_lo + 1 > 0xFFFF) return 0;
+            const bool uni = shift >= 2 && (phase & 3) == 0;                   // the four chunks of every full item share a group
+            lw.w_off = r.off + (u32)i0 * 64u * (u32)r.bits; lw.w_tstride = r.tstride;
+            lw.t_off = r.t_off; lw.t_tstride = r.t_tstride;
+            lw.meta = (u32)n | ((u32)r.bits << 8) | ((u32)tail_nv << 12) | (uni ? 1u << 15 : 0u) | ((u32)shift << 16) | ((u32)phase << 19);
+            lw.xr = (u32)c0 | ((u32)(c_end - c0) << 16);
+            lw.gr = (u32)g_lo | ((u32)(g_hi - g_lo + 1) << 16);
+            lw.place = (u32)c0 | ((u32)(g0 - g_lo) << 16);
+            const u32 x_stride = (u32)(c_end - c0) * 32u + 8u;
+            (void)norm;
+        lds_total += al16((u32)M * x_stride * 2u) + al16((u32)(g_hi - g_lo + 1) * 32u) * (qm->is_gptq ? 2u : 1u);
+            i0 += n;
         }
-        const u32 x_stride = (u32)(c_end - c_lo) * 32u + 8u;
-        lds_total += al16((u32)M * x_stride * 2u) + (norm ? (u32)(c_end - c_lo) * 64u : 0u) + al16((u32)(g_hi - g_lo + 1) * 32u) * (qm->is_gptq ? 2u : 1u) + al16(minor);
+        if (i0 != r.F) return 0;
     }
-    if (ri < runs.size()) return 0;
     return lds_total ? lds_total : 16u;
 }
 
@@ -795,7 +651,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     const QMatrix* q0 = in.qm[0];
     const int K = q0->height;
     if ((K & 7) || (((size_t)in.a) & 15) || (in.lda & 7)) return 1;
-    if (in.a_mode == A_NORM_PRE && ((((size_t)in.norm_w) & 15) || !in.ss || in.npart < 1)) return 1;
+    if (in.a_mode == A_NORM_PRE && (!in.ss || in.npart < 1)) return 1;
     if (in.pair && (in.n_mats != 2 || in.qm[0]->width != in.qm[1]->width)) return 1;
     static LeanArgs args_store;                                    // (large: off the stack; the launch copies it)
     static std::mutex mtx;
@@ -844,7 +700,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
         m.c = in.c[j]; m.c_invperm = in.c_invperm[j]; m.bias = d.bias;
         m.G = d.G; m.n_tiles = d.N / TILE_N; h.ldc[j] = in.ldc[j];
     }
-    h.a = in.a; h.norm_w = in.norm_w; h.ss = in.ss; h.xp_out = in.xp_out; h.xp_invperm = in.xp_invperm; h.ss_out = in.ss_out;
+    h.a = in.a; h.xp_w = in.xp_w; h.ss = in.ss; h.xp_out = in.xp_out; h.xp_invperm = in.xp_invperm; h.ss_out = in.ss_out;
     h.eps = in.eps; h.M = in.M; h.K = K; h.lda = in.lda; h.ldxp = in.ldxp; h.npart = in.npart; h.wgs = wgs;
     h.flags = (in.a_mode == A_NORM_PRE ? LF_NORM : 0u) | (in.act_gelu ? LF_GELU : 0u) | (in.c_mode == C_ACCUM ? LF_ACCUM : 0u) | (any_bias ? LF_BIAS : 0u);
     h.slot_bytes = slot_bytes; h.red_off = slot_bytes * (u32)nslots;
@@ -861,13 +717,10 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
             for (int w = 0; w < S; w++)
             {
                 const LeanWave& lw = a.wave[j * S + w];
-                fprintf(stderr, "[lean]  mat %d wave %d: lds+%u, x chunks %u+%u, sc rows %u+%u;", j, w, lw.lds_off, lw.xr & 0xFFFF, lw.xr >> 16, lw.gr & 0xFFFF, lw.gr >> 16);
-                for (int q = 0; q < LEAN_SEGS; q++)
-                    if (lw.seg[q].meta & 0x3FF)
-                        fprintf(stderr, "  %d:[%u x %ub nv%u%s chunk %u row+%u sh%u ph%u%s]", q, lw.seg[q].meta & 0x3FF, (lw.seg[q].meta >> 10) & 0xF, (lw.seg[q].meta >> 14) & 7,
-                                ((lw.seg[q].meta >> 17) & 1) ? " tail" : "", lw.seg[q].place & 0xFFFF, lw.seg[q].place >> 16, (lw.seg[q].meta >> 18) & 7,
-                                (lw.seg[q].meta >> 21) & 0x3FF, (lw.seg[q].meta >> 31) ? " uni" : "");
-                fprintf(stderr, "\n");
+                fprintf(stderr, "[lean]  mat %d wave %d: lds+%u, x chunks %u+%u, sc rows %u+%u; %u x %ub%s chunk %u row+%u sh%u ph%u%s\n", j, w, lw.lds_off,
+                        lw.xr & 0xFFFF, lw.xr >> 16, lw.gr & 0xFFFF, lw.gr >> 16, lw.meta & 0xFF, (lw.meta >> 8) & 0xF,
+                        ((lw.meta >> 12) & 7) ? " + partial" : "", lw.place & 0xFFFF, lw.place >> 16, (lw.meta >> 16) & 7, (lw.meta >> 19) & 0x3FF,
+                        ((lw.meta >> 15) & 1) ? " uni" : "");
             }
     }
     dim3 grid((unsigned)wgs, (unsigned)(in.pair ? 1 : in.n_mats), 1), block((unsigned)waves * 64, 1, 1);

@@ -507,15 +507,22 @@ class ExtC:
     # ---- chained decode (csrc/qgemv_flat.hip; ours) -----------------------------------------------------------------------
 
     def q_attn_chain_info(self, q_attn: int):
-        """(capable, in_invperm pointer or None, o_invperm pointer or None)"""
-        cap, a, b = C.c_int(0), C.c_void_p(), C.c_void_p()
-        self.lib.check(self.lib.exl2_q_attn_chain_info(q_attn, C.byref(cap), C.byref(a), C.byref(b)))
-        return bool(cap.value), a.value, b.value
+        """(capable, in_invperm pointer or None, o_invperm pointer or None, pointer to the norm weight in q/k/v's packed order)"""
+        cap, a, b, w = C.c_int(0), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.lib.check(self.lib.exl2_q_attn_chain_info(q_attn, C.byref(cap), C.byref(a), C.byref(b), C.byref(w)))
+        return bool(cap.value), a.value, b.value, w.value
 
     def q_mlp_chain_info(self, q_mlp: int):
-        cap, a = C.c_int(0), C.c_void_p()
-        self.lib.check(self.lib.exl2_q_mlp_chain_info(q_mlp, C.byref(cap), C.byref(a)))
-        return bool(cap.value), a.value
+        """(capable, in_invperm pointer or None, pointer to the norm weight in gate/up's packed order)"""
+        cap, a, w = C.c_int(0), C.c_void_p(), C.c_void_p()
+        self.lib.check(self.lib.exl2_q_mlp_chain_info(q_mlp, C.byref(cap), C.byref(a), C.byref(w)))
+        return bool(cap.value), a.value, w.value
+
+    def _w_ptr(self, w):
+        """next_norm_w: a raw device pointer (from *_chain_info), an fp16 tensor, or None (= all ones)"""
+        if w is None or isinstance(w, int):
+            return w or None
+        return self._ptr(w, torch.float16, "next_norm_w")
 
     def q_matrix_perm_info(self, q_handle: int):
         """(q_perm pointer or None, q_invperm pointer or None) of a q_matrix (u16 device arrays)"""
@@ -529,28 +536,29 @@ class ExtC:
             self._ptr(q_temp, torch.float16, "q_temp"), self._ptr(k_temp, torch.float16, "k_temp"),
             self._ptr(v_temp, torch.float16, "v_temp"), self._stream(xp)))
 
-    def q_attn_forward_2_chain(self, q_attn, x, attn_out_packed, rows: int, next_invperm, xp_out, ss_out) -> int:
-        """Returns the number of partial sums per row written to ss_out."""
+    def q_attn_forward_2_chain(self, q_attn, x, attn_out_packed, rows: int, next_invperm, next_norm_w, xp_out, ss_out) -> int:
+        """x += attn_out . Wo; publishes xp_out = x * next_norm_w in the next consumer's order + partial sums of x^2.
+        Returns the number of partial sums per row written to ss_out."""
         n = C.c_int(0)
         self.lib.check(self.lib.exl2_q_attn_forward_2_chain(
             q_attn, self._ptr(x, torch.float16, "x"), self._ptr(attn_out_packed, torch.float16, "attn_out"), int(rows),
-            next_invperm or None, self._ptr(xp_out, torch.float16, "xp_out"), self._ptr(ss_out, torch.float32, "ss_out"),
-            C.byref(n), self._stream(x)))
-        return n.value
-
-    def q_mlp_forward_chain(self, q_mlp, x, xp, ss, npart: int, rows: int, next_invperm, xp_out, ss_out) -> int:
-        n = C.c_int(0)
-        self.lib.check(self.lib.exl2_q_mlp_forward_chain(
-            q_mlp, self._ptr(x, torch.float16, "x"), self._ptr(xp, torch.float16, "xp"), self._ptr(ss, torch.float32, "ss"),
-            int(npart), int(rows), next_invperm or None, self._ptr(xp_out, torch.float16, "xp_out"),
+            next_invperm or None, self._w_ptr(next_norm_w), self._ptr(xp_out, torch.float16, "xp_out"),
             self._ptr(ss_out, torch.float32, "ss_out"), C.byref(n), self._stream(x)))
         return n.value
 
-    def gemm_half_q_half_chain(self, xp, ss, npart: int, norm_w_perm, eps: float, q_handle: int, c, rows: int) -> None:
+    def q_mlp_forward_chain(self, q_mlp, x, xp, ss, npart: int, rows: int, next_invperm, next_norm_w, xp_out, ss_out) -> int:
+        n = C.c_int(0)
+        self.lib.check(self.lib.exl2_q_mlp_forward_chain(
+            q_mlp, self._ptr(x, torch.float16, "x"), self._ptr(xp, torch.float16, "xp"), self._ptr(ss, torch.float32, "ss"),
+            int(npart), int(rows), next_invperm or None, self._w_ptr(next_norm_w), self._ptr(xp_out, torch.float16, "xp_out"),
+            self._ptr(ss_out, torch.float32, "ss_out"), C.byref(n), self._stream(x)))
+        return n.value
+
+    def gemm_half_q_half_chain(self, xp, ss, npart: int, eps: float, q_handle: int, c, rows: int) -> None:
+        """c = rmsnorm(x) . W from xp = x * norm weight (applied by xp's producer, in W's packed order) and ss"""
         self.lib.check(self.lib.exl2_gemm_half_q_half_chain(
             self._ptr(xp, torch.float16, "xp"), self._ptr(ss, torch.float32, "ss"), int(npart),
-            self._ptr(norm_w_perm, torch.float16, "norm_w_perm"), float(eps), q_handle, self._ptr(c, torch.float16, "c"),
-            int(rows), self._stream(xp)))
+            float(eps), q_handle, self._ptr(c, torch.float16, "c"), int(rows), self._stream(xp)))
 
     def chain_route_counts(self, reset: bool = False):
         """(launches taken by csrc/qgemv_lean.hip, launches taken by csrc/qgemv_flat.hip) since the last reset"""
@@ -571,11 +579,11 @@ class ExtC:
         self.lib.check(self.lib.exl2_chain_overlap_end(C.byref(n)))
         return n.value
 
-    def embed_rows_chain(self, table, ids, x, next_invperm, xp_out, ss_out) -> None:
+    def embed_rows_chain(self, table, ids, x, next_invperm, next_norm_w, xp_out, ss_out) -> None:
         self.lib.check(self.lib.exl2_embed_rows_chain(
             self._ptr(table, torch.float16, "table"), self._ptr(ids, torch.int32, "ids"), self._ptr(x, torch.float16, "x"),
-            ids.numel(), table.shape[1], table.shape[0], next_invperm or None, self._ptr(xp_out, torch.float16, "xp_out"),
-            self._ptr(ss_out, torch.float32, "ss_out"), self._stream(x)))
+            ids.numel(), table.shape[1], table.shape[0], next_invperm or None, self._w_ptr(next_norm_w),
+            self._ptr(xp_out, torch.float16, "xp_out"), self._ptr(ss_out, torch.float32, "ss_out"), self._stream(x)))
 
     def gather_f16(self, src, perm_ptr, dst) -> None:
         self.lib.check(self.lib.exl2_gather_f16(self._ptr(src, torch.float16, "src"), perm_ptr or None,

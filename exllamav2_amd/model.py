@@ -187,11 +187,11 @@ class GreedyGraphDecoder:
         for attn, mlp in m.layers:
             if not hasattr(mlp, "gate_proj") or mlp.q_handle is None or attn.q_handle is None:
                 return
-            cap_a, in_a, o_inv = ext.q_attn_chain_info(attn.q_handle)
-            cap_m, in_m = ext.q_mlp_chain_info(mlp.q_handle)
+            cap_a, in_a, o_inv, nw_a = ext.q_attn_chain_info(attn.q_handle)
+            cap_m, in_m, nw_m = ext.q_mlp_chain_info(mlp.q_handle)
             if not (cap_a and cap_m):
                 return
-            plan.append((in_a, o_inv, in_m))
+            plan.append((in_a, o_inv, in_m, nw_a, nw_m))
         dev = m.device
         head_perm, head_inv = ext.q_matrix_perm_info(m.lm_head.q_handle)
         norm_head = torch.empty_like(m.norm.weight)
@@ -220,7 +220,7 @@ class GreedyGraphDecoder:
         k = m.temp_k[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
         v = m.temp_v[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
         xp_a, xp_b, ss_a, ss_b = ch["xp_a"], ch["xp_b"], ch["ss_a"], ch["ss_b"]
-        ext.embed_rows_chain(m.embed_tokens, self.ids, x2, plan[0][0], xp_a, ss_a)
+        ext.embed_rows_chain(m.embed_tokens, self.ids, x2, plan[0][0], plan[0][3], xp_a, ss_a)
         overlap = "flags" in ch
         if overlap:
             sa = self.stream.cuda_stream if self.stream is not None else None
@@ -229,13 +229,14 @@ class GreedyGraphDecoder:
         try:
             npart = 1
             for i, (attn, mlp) in enumerate(m.layers):
-                in_a, o_inv, in_m = plan[i]
+                in_a, o_inv, in_m, nw_a, nw_m = plan[i]
                 ext.q_attn_forward_1_chain(attn.q_handle, xp_a, ss_a, npart, b, q, k, v)
                 ao = attn.attend_chain(q, k, v, self.cache, self.cache_seqlens, self.block_table, o_inv)
-                npart = ext.q_attn_forward_2_chain(attn.q_handle, x2, ao, b, in_m, xp_b, ss_b)
-                nxt = plan[i + 1][0] if i + 1 < len(plan) else ch["head_inv"]
-                npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, xp_b, ss_b, npart, b, nxt, xp_a, ss_a)
-            ext.gemm_half_q_half_chain(xp_a, ss_a, npart, ch["norm_head"], cfg.norm_eps, m.lm_head.q_handle, self.logits, b)
+                # every producer of the residual stream publishes it times its consumer's norm weight, in that consumer's order
+                npart = ext.q_attn_forward_2_chain(attn.q_handle, x2, ao, b, in_m, nw_m, xp_b, ss_b)
+                nxt, nxt_w = (plan[i + 1][0], plan[i + 1][3]) if i + 1 < len(plan) else (ch["head_inv"], ch["norm_head"])
+                npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, xp_b, ss_b, npart, b, nxt, nxt_w, xp_a, ss_a)
+            ext.gemm_half_q_half_chain(xp_a, ss_a, npart, cfg.norm_eps, m.lm_head.q_handle, self.logits, b)
         finally:
             n_launches = ext.chain_overlap_end() if overlap else 0
         # greedy sampling + position increment behind the head: on the stream the head went to

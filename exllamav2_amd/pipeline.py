@@ -78,11 +78,11 @@ class PipelineStage:
         for attn, mlp in m.layers:
             if not hasattr(mlp, "gate_proj") or mlp.q_handle is None or attn.q_handle is None:
                 return
-            cap_a, in_a, o_inv = ext.q_attn_chain_info(attn.q_handle)
-            cap_m, in_m = ext.q_mlp_chain_info(mlp.q_handle)
+            cap_a, in_a, o_inv, nw_a = ext.q_attn_chain_info(attn.q_handle)
+            cap_m, in_m, nw_m = ext.q_mlp_chain_info(mlp.q_handle)
             if not (cap_a and cap_m):
                 return
-            plan.append((in_a, o_inv, in_m))
+            plan.append((in_a, o_inv, in_m, nw_a, nw_m))
         dev, h = self.device, cfg.hidden_size
         ch = {"plan": plan,
               "xp_a": torch.zeros((1, h), dtype=torch.float16, device=dev), "xp_b": torch.zeros((1, h), dtype=torch.float16, device=dev),
@@ -107,22 +107,24 @@ class PipelineStage:
         xp_a, xp_b, ss_a, ss_b = ch["xp_a"], ch["xp_b"], ch["ss_a"], ch["ss_b"]
         if self.first:
             self.ids.copy_(self.msg_in[:2].view(torch.int32))
-            ext.embed_rows_chain(m.embed_tokens, self.ids, x2, plan[0][0], xp_a, ss_a)
+            ext.embed_rows_chain(m.embed_tokens, self.ids, x2, plan[0][0], plan[0][3], xp_a, ss_a)
         else:
-            ext.embed_rows_chain(self.msg_in.view(1, cfg.hidden_size), ch["id0"], x2, plan[0][0], xp_a, ss_a)
+            ext.embed_rows_chain(self.msg_in.view(1, cfg.hidden_size), ch["id0"], x2, plan[0][0], plan[0][3], xp_a, ss_a)
         sl, bt = self.seqlens[s:s + 1], self.block_table[s:s + 1]
         npart = 1
         for i, (attn, mlp) in enumerate(m.layers):
-            in_a, o_inv, in_m = plan[i]
+            in_a, o_inv, in_m, nw_a, nw_m = plan[i]
             ext.q_attn_forward_1_chain(attn.q_handle, xp_a, ss_a, npart, 1, q, k, v)
             ao = attn.attend_chain(q, k, v, self.cache, sl, bt, o_inv)
-            npart = ext.q_attn_forward_2_chain(attn.q_handle, x2, ao, 1, in_m, xp_b, ss_b)
+            npart = ext.q_attn_forward_2_chain(attn.q_handle, x2, ao, 1, in_m, nw_m, xp_b, ss_b)
             # behind the stage's last layer of a non-last stage nothing reads the packed copy: any layer's order will do
-            nxt = plan[i + 1][0] if i + 1 < len(plan) else (ch["head_inv"] if self.last else plan[0][0])
-            npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, xp_b, ss_b, npart, 1, nxt, xp_a, ss_a)
+            if i + 1 < len(plan): nxt, nxt_w = plan[i + 1][0], plan[i + 1][3]
+            elif self.last: nxt, nxt_w = ch["head_inv"], ch["norm_head"]
+            else: nxt, nxt_w = plan[0][0], plan[0][3]
+            npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, xp_b, ss_b, npart, 1, nxt, nxt_w, xp_a, ss_a)
         ext.add_i32_(sl, 1)
         if self.last:
-            ext.gemm_half_q_half_chain(xp_a, ss_a, npart, ch["norm_head"], cfg.norm_eps, m.lm_head.q_handle, self.logits, 1)
+            ext.gemm_half_q_half_chain(xp_a, ss_a, npart, cfg.norm_eps, m.lm_head.q_handle, self.logits, 1)
             ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history[s:s + 1], sl)
             self.msg_out.zero_()
             self.msg_out[:2].view(torch.int32).copy_(self.ids)

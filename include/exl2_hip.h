@@ -187,14 +187,20 @@ int exl2_q_moe_mlp_forward(void* handle, void* x, int rows, void* stream);
 int exl2_moe_route(const void* x, const void* gate, void* logits, int rows, int hidden, int num_experts, int topk, void* stream);
 
 /* ---- chained decode (ours; replaces the COMPOSITION q_attn.cu:153-345 / q_mlp.cu:153-236 make of rms_norm + q_gemm +
-   act_mul launches on the decode path; csrc/qgemv_flat.hip).  A producer leaves the residual stream in the form its consumer's
-   prologue wants: `xp` = x in the consumer's packed (act-order) K order [rows, hidden], `ss` = one partial sum of squares
-   per producer workgroup [rows, npart] (RMSNorm needs only their sum).  A module is chain-capable when its fused input
+   act_mul launches on the decode path; csrc/qgemv_lean.hip for <= 4 rows, csrc/qgemv_flat.hip beyond).  A producer leaves the
+   residual stream in the form its consumer's prologue wants: `xp` = x TIMES THE CONSUMER'S RMSNorm WEIGHT (fp32 product,
+   one rounding to fp16, saturated), in the consumer's packed (act-order) K order [rows, hidden]; `ss` = one partial sum
+   of squares of x per producer workgroup [rows, npart].  The consumer multiplies xp with its matrices and scales the
+   finished fp32 sums by rsqrt(sum(ss) / hidden + eps): the per-element normalisation happens once, in the producer,
+   instead of once per 16-column tile of every consumer (round-3 PMC runs: it was 30 % of a consumer wave's
+   instructions), and the same number of fp16 roundings as rms_norm-then-q_gemm (rms_norm.cu:33-175) is made.
+   `next_norm_w` below = the norm weight of the NEXT consumer gathered through that consumer's q_perm (exl2_*_chain_info
+   return it for modules, exl2_gather_f16 makes it for a head); NULL = all ones.  A module is chain-capable when its fused input
    projections share one act-order permutation (they do in every EXL2 checkpoint: the quantizer reuses one Hessian for
    q/k/v and for gate/up, conversion/quantize.py:138-139,165) and it is a plain pre-RMSNorm residual block.
    rows <= 16.  All of these return EXL2_E_INVALID "not covered" for shapes outside the kernel's reach (nothing launched). */
-int exl2_q_attn_chain_info(void* handle, int* capable, const void** in_invperm, const void** o_invperm);
-int exl2_q_mlp_chain_info(void* handle, int* capable, const void** in_invperm);
+int exl2_q_attn_chain_info(void* handle, int* capable, const void** in_invperm, const void** o_invperm, const void** norm_w_perm);
+int exl2_q_mlp_chain_info(void* handle, int* capable, const void** in_invperm, const void** norm_w_perm);
 int exl2_q_matrix_perm_info(void* q_matrix, const void** perm, const void** invperm);
 /* q, k, v = proj(rmsnorm(x)) from (xp, ss); no RoPE (the attention launch rotates) */
 int exl2_q_attn_forward_1_chain(void* handle, const void* xp, const float* ss, int npart, int rows,
@@ -202,16 +208,16 @@ int exl2_q_attn_forward_1_chain(void* handle, const void* xp, const float* ss, i
 /* x += attn_out . Wo with attn_out already in o_proj's packed order (exl2_attn_decode_fused out_invperm); publishes
    (xp_out, ss_out) for the next consumer through next_invperm (nullable = identity); *npart_out = partials per row */
 int exl2_q_attn_forward_2_chain(void* handle, void* x, const void* attn_out_packed, int rows, const void* next_invperm,
-                                void* xp_out, float* ss_out, int* npart_out, void* stream);
+                                const void* next_norm_w, void* xp_out, float* ss_out, int* npart_out, void* stream);
 /* x += (act(n Wg) * (n Wu)) Wd, n from (xp, ss); publishes (xp_out, ss_out) for the next consumer */
 int exl2_q_mlp_forward_chain(void* handle, void* x, const void* xp, const float* ss, int npart, int rows,
-                             const void* next_invperm, void* xp_out, float* ss_out, int* npart_out, void* stream);
-/* c = rmsnorm(x) . W from (xp, ss); norm_w_perm = the norm weight gathered through W's q_perm (exl2_gather_f16) */
-int exl2_gemm_half_q_half_chain(const void* xp, const float* ss, int npart, const void* norm_w_perm, float eps,
+                             const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, int* npart_out, void* stream);
+/* c = rmsnorm(x) . W from (xp, ss); the producer of xp applied the norm weight gathered through W's q_perm (exl2_gather_f16) */
+int exl2_gemm_half_q_half_chain(const void* xp, const float* ss, int npart, float eps,
                                 void* q_matrix, void* c, int rows, void* stream);
 /* embedding rows -> x, and published as (xp_out, ss_out with npart = 1) for the first consumer */
 int exl2_embed_rows_chain(const void* table, const int* ids, void* x, int rows, int hidden, int vocab,
-                          const void* next_invperm, void* xp_out, float* ss_out, void* stream);
+                          const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, void* stream);
 /* dst[i] = src[perm[i]] (u16 perm, nullable = copy), n elements */
 int exl2_gather_f16(const void* src, const void* perm, void* dst, int n, void* stream);
 /* Overlapped chain (csrc/chain_sync.h; no reference counterpart -- the reference serialises every launch of a decode step on

@@ -316,6 +316,8 @@ DEV f16 load_agent_f16(const f16* p) { return *p; }
 DEV f16x8 load_agent_f16x8(const f16* p) { return *(const f16x8*)p; }
 DEV void dma_to_lds16_agent(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
 
+DEV void* global_ptr_of(u32 lo, u32 hi) { return (void*)(((u64)hi << 32) | lo); }
+
 #define DYN_SMEM(name) unsigned char* name = emu_ctx_->dyn_smem
 #define SHARED static
 

@@ -167,7 +167,8 @@ CHAIN_SPECS = {   # full runs and partial super-chunks of every bit width
 @pytest.mark.parametrize("spec_name", list(CHAIN_SPECS))
 @pytest.mark.parametrize("rows", [1, 2, 7])
 def test_gemm_chain_norm_pre(be, rows, spec_name):
-    """exl2_gemm_half_q_half_chain: c = rmsnorm(x) . W from (xp, ss partials, permuted norm weight); every bit width in K"""
+    """exl2_gemm_half_q_half_chain: c = rmsnorm(x) . W from (xp = x * permuted norm weight as its producer leaves it, ss partials);
+    every bit width in K"""
     k, spec = CHAIN_SPECS[spec_name]
     n = 96
     t, ref, w, h = _mk(be, k, n, spec, 21)
@@ -175,12 +176,13 @@ def test_gemm_chain_norm_pre(be, rows, spec_name):
     x = (rng.standard_normal((rows, k)) * 2).astype(np.float16)
     nw = (1 + 0.1 * rng.standard_normal(k)).astype(np.float16)
     perm = np.argsort(t["q_invperm"]).astype(np.int64)                 # packed row -> input feature
-    xp = x[:, perm]
+    # what a producer publishes: x times the consumer's norm weight (fp32 product, one rounding), in the consumer's packed order
+    xp = (x.astype(np.float32) * nw.astype(np.float32)).astype(np.float16)[:, perm]
     npart = 5                                                          # any split of the sum of squares into partials
     sq = x.astype(np.float32) ** 2
     ss = np.stack([sq[:, i::npart].sum(-1) for i in range(npart)], axis=-1).astype(np.float32)
     c = torch.zeros((rows, n), dtype=torch.float16, device=be.device)
-    be.ext.gemm_half_q_half_chain(be.t(xp), be.t(ss), npart, be.t(nw[perm]), 1e-5, h, c, rows)
+    be.ext.gemm_half_q_half_chain(be.t(xp), be.t(ss), npart, 1e-5, h, c, rows)
     want = OX.gemm_ref(OM.rms_norm(x, nw, 1e-5), ref, exact=True)
     # the normalised activations may sit one fp16 ulp from the oracle's (fp32 partial sums vs float64): K independent
     # 2^-11 relative perturbations add ~ sqrt(K) * 2^-11 * |x| |w| on top of the output rounding
@@ -199,9 +201,14 @@ def test_embed_rows_chain(be):
     xp = torch.zeros_like(x)
     ss = torch.zeros((3, 256), dtype=torch.float32, device=be.device)
     inv_t = be.t(invperm.view(np.int16))
-    be.ext.embed_rows_chain(be.t(table), be.t(ids), x, inv_t.data_ptr(), xp, ss)
+    be.ext.embed_rows_chain(be.t(table), be.t(ids), x, inv_t.data_ptr(), None, xp, ss)
     assert np.array_equal(be.n(x), table[ids])
     want_xp = np.zeros_like(table[ids]); want_xp[:, invperm] = table[ids]
     assert np.array_equal(be.n(xp), want_xp)
+    # with the first consumer's norm weight (given in that consumer's packed order): xp = fp16(x * w)
+    nw = (1 + 0.1 * rng.standard_normal(hidden)).astype(np.float16)
+    nw_t = be.t(nw)
+    be.ext.embed_rows_chain(be.t(table), be.t(ids), x, inv_t.data_ptr(), nw_t, xp, ss)
+    assert np.array_equal(be.n(xp), (want_xp.astype(np.float32) * nw.astype(np.float32)).astype(np.float16))
     want_ss = (table[ids].astype(np.float32) ** 2).sum(-1)
     assert np.allclose(be.n(ss).reshape(-1)[:3], want_ss, rtol=1e-5)      # [rows, npart = 1]
