@@ -170,6 +170,9 @@ DEV void dma_to_lds4(const void* g_lane_ptr, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane_ptr,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
+// vmcnt(0) the COMPILER sees (it forgets its pending LDS-DMAs here; the inline-asm waits below are invisible to it): gfx9
+// encoding vmcnt = 0, expcnt = 7, lgkmcnt = 15
+DEV void wait_vmcnt_builtin0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 // wait until at most N vector-memory operations of this wave are still in flight (they complete in issue order)
 template <int N> DEV void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for every

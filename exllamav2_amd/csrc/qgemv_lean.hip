@@ -98,8 +98,16 @@ struct LeanArgs
 #define LF_BIAS 32u
 
 // items of one bit width a wave may hold in registers (<= 25 dwords per lane in flight)
-template <int BITS> struct LeanDepth { static constexpr int v = BITS == 8 ? 3 : BITS == 6 ? 4 : BITS == 5 ? 5 : BITS == 4 ? 6 : 8; };
-static int lean_depth(int bits) { return bits == 8 ? 3 : bits == 6 ? 4 : bits == 5 ? 5 : bits == 4 ? 6 : 8; }
+// (S = 4: the 8-wave gate|up workgroup, built for 6 waves per SIMD = 80 registers -- a wave there holds 8 items of <= 4 bits)
+template <int BITS, int S> struct LeanDepth
+{
+    static constexpr int v = S == 4 ? (BITS == 8 ? 4 : BITS == 6 ? 5 : BITS == 5 ? 6 : 8)
+                                    : (BITS == 8 ? 3 : BITS == 6 ? 4 : BITS == 5 ? 5 : BITS == 4 ? 6 : 8);
+};
+static int lean_depth(int bits, int S)
+{
+    return S == 4 ? (bits == 8 ? 4 : bits == 6 ? 5 : bits == 5 ? 6 : 8) : (bits == 8 ? 3 : bits == 6 ? 4 : bits == 5 ? 5 : bits == 4 ? 6 : 8);
+}
 
 struct LeanCtx
 {
@@ -311,11 +319,12 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         const int xu0 = xc0 * 4;
         const int sc_units = 2 * ng;                                      // 16-byte units of the scale rows (a row = 16 halfs)
         const f16* const st = sc_tab + ((size_t)t_ * G + gw0) * 16;
-        if (M == 1 && xunits <= 64 && sc_units <= 64)
+        if (M == 1 && xunits <= (S == 4 ? 128 : 64) && sc_units <= 64)
         {
             if (lane < sc_units) dma_to_lds16(st + (size_t)lane * 8, (u8*)sc_lds);
             if constexpr (GPTQ) { if (lane < sc_units) dma_to_lds16(zp_tab + ((size_t)t_ * G + gw0) * 16 + (size_t)lane * 8, (u8*)zp_lds); }
             if (lane < xunits && xu0 + lane < oct) dma_to_lds16(in_a + (size_t)(xu0 + lane) * 8, (u8*)x_lds);
+            if constexpr (S == 4) { if (64 + lane < xunits && xu0 + 64 + lane < oct) dma_to_lds16(in_a + (size_t)(xu0 + 64 + lane) * 8, (u8*)x_lds + 1024); }
         }
         else
         {
@@ -345,7 +354,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     Rest R;
     auto head = [&](auto bits_tag) {
         constexpr int BITS = decltype(bits_tag)::value;
-        constexpr int D = LeanDepth<BITS>::v;
+        constexpr int D = LeanDepth<BITS, S>::v;
         constexpr size_t STEP = 64 * BITS;
         LaneWords<BITS> b[D], bt;
         #pragma unroll
@@ -582,7 +591,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
             const int n = (r.F - i0 + (nw[i] - k) - 1) / (nw[i] - k);        // even split, larger parts first
             const bool last = k == nw[i] - 1;
             const int tail_nv = last ? r.tail_nv : 0;
-            if (n > lean_depth(r.bits) || n > 255) return 0;
+            if (n > lean_depth(r.bits, S) || n > 255) return 0;
             LeanWave& lw = wave[w];
             lw.lds_off = lds_total;
             const int c0 = r.chunk0 + 4 * i0;
@@ -621,7 +630,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
     return lds_total ? lds_total : 16u;
 }
 
-#define LEAN_FOR_EACH_GEOMETRY(X, OCC) X(8, 1, false, OCC) X(16, 1, false, OCC) X(8, 2, false, OCC) X(8, 2, true, OCC)
+#define LEAN_FOR_EACH_GEOMETRY(X, OCC) X(8, 1, false, OCC) X(16, 1, false, OCC) X(8, 2, false, OCC) X(8, 2, true, OCC) X(4, 2, true, OCC)
 // register budgets built side by side (EXL2_LEAN_OCC = 4 / 6 / 8 waves per SIMD; measured on the MI355X): the
 // default is what the A/B runs picked
 #ifndef LEAN_OCC_DEFAULT
@@ -674,10 +683,20 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     if (!in.pair && in.n_mats == 1 && in.ss_out && max_tiles > LEAN_MAX_PART) nslots = 2;
     if (const char* e = getenv("EXL2_LEAN_TPW")) { const int v = atoi(e); if (!in.pair && in.n_mats == 1 && (v == 1 || v == 2)) nslots = v; }
     if (const char* e = getenv("EXL2_LEAN_S16")) { if (atoi(e) && nslots == 1 && in.n_mats <= 2) S = 16; }
+    // candidates, in order: a one-row pair tries 4 waves per tile first (8-wave workgroups: three per CU at 6 waves per SIMD, so
+    // the 688 workgroups of a 7B gate|up launch are resident at once; with 16-wave workgroups a quarter of them starts when
+    // the first ones have finished: profiles/r03_trace_lean_v6.txt, workgroup entry p90 9.5 us)
+    int cand[2], n_cand = 0;
+    static const int pair4 = []() { const char* e = getenv("EXL2_LEAN_PAIR4"); return e ? atoi(e) : 1; }();
+    if (in.pair && in.M == 1 && pair4) cand[n_cand++] = 4;
+    cand[n_cand++] = S;
+    if (!in.pair && nslots == 1 && S == 8) cand[n_cand++] = 16;        // finer split of the tile
     u32 slot_bytes = 0;
-    for (int attempt = 0; attempt < 2; attempt++)
+    bool planned = false;
+    for (int ci = 0; ci < n_cand && !planned; ci++)
     {
-        if (in.n_mats * S > LEAN_RECORDS) return 1;
+        S = cand[ci];
+        if (in.n_mats * S > LEAN_RECORDS) continue;
         bool ok = true;
         slot_bytes = 0;
         for (int j = 0; j < in.n_mats && ok; j++)
@@ -686,10 +705,9 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
             if (!b) ok = false;
             if (b > slot_bytes) slot_bytes = b;
         }
-        if (ok && (u32)nslots * slot_bytes + (u32)(S * nslots) * (u32)in.M * 64u <= LEAN_LDS_BUDGET * (u32)(S * nslots / 8)) break;
-        if (attempt == 1 || nslots != 1 || S == 16) return 1;
-        S = 16;                                                       // finer split of the tile
+        planned = ok && (u32)nslots * slot_bytes + (u32)(S * nslots) * (u32)in.M * 64u <= LEAN_LDS_BUDGET * (u32)((S * nslots + 7) / 8);
     }
+    if (!planned) return 1;
     const int wgs = in.pair ? max_tiles : (max_tiles + nslots - 1) / nslots;
     if (in.ss_out && wgs > LEAN_MAX_PART) return 1;
     for (int j = 0; j < in.n_mats; j++)
@@ -727,6 +745,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     const bool gptq = q0->is_gptq;
     int occ = LEAN_OCC_DEFAULT;
     if (const char* e = getenv("EXL2_LEAN_OCC")) { const int v = atoi(e); if (v == 4 || v == 6 || v == 8) occ = v; }
+    if (S == 4 && occ > 6) occ = 6;                                    // (8 items in registers per wave)
 #define LEAN_GO(SS, NS, P, OCC) \
     if (!gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_GEOMETRY(LEAN_GO, 4) LEAN_FOR_EACH_GEOMETRY(LEAN_GO, 6) LEAN_FOR_EACH_GEOMETRY(LEAN_GO, 8)

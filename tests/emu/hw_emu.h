@@ -253,6 +253,7 @@ DEV void wait_lds_reads() { }
 DEV void wave_converge() { emu_ctx_->wave[wave_id()].bar.wait(); }
 DEV void dma_to_lds4(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 4, g_lane_ptr, 4); }
 template <int N> DEV void wait_vmcnt_le() { }
+DEV void wait_vmcnt_builtin0() { }
 DEV void block_sync_lds() { block_sync(); }
 DEV u32 byte_perm(u32 hi, u32 lo, u32 sel)
 {

@@ -59,6 +59,15 @@ def test_chain_decode_equals_oracle(be, recipe, batch):
     _decode_and_check(be, cfg, recipe, batch, seed=11)
 
 
+@pytest.mark.parametrize("recipe", ["4.0bpw", "3.5bpw"])
+def test_chain_decode_wide_k(be, recipe):
+    """hidden 4096 (32 items per tile): the one-row gate|up launch takes 4 waves per tile with 8 items each in registers, two
+    LDS-DMA instructions per activation slice (qgemv_lean.hip, S = 4 pair geometry); q|k|v 8 waves x 4 items"""
+    cfg = tiny_cfg(hidden_size=4096, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                   head_dim=128)
+    _decode_and_check(be, cfg, recipe, 1, steps=2, seed=5)
+
+
 def test_chain_decode_many_rows(be):
     """16 sequences: the row loop of the A_NORM_PRE prologue, 16 finalising waves"""
     cfg = tiny_cfg(max_batch_size=16)
