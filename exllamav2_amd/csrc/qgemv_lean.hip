@@ -41,7 +41,7 @@
 #define LEAN_PRESCALE 1               // 1: general items scale the weights (fp16, reconstruct()'s rounding); 0: four scales on four partial sums
 #endif
 #ifndef LEAN_KILL
-#define LEAN_KILL 0                   // instruction-count experiments (results are WRONG): 1 no decode, 2 no norm arithmetic, 4 no epilogue
+#define LEAN_KILL 0                   // instruction-count / timing experiments (results are WRONG): 1 no decode (the loads vanish too), 4 no epilogue, 8 loads kept, decode = xor
 #endif
 #ifndef LEAN_LOWBITS
 #define LEAN_LOWBITS 1                // 0: no 2 / 3-bit register stream (code-size experiment; such segments would be wrong)
@@ -366,7 +366,16 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         wait_vmcnt_le<0>();                  // everything landed (weights first, the LDS-DMA copies behind them)
         wave_converge();
         LTRACE(4);
-        if (LEAN_KILL & 1) { }
+        if (LEAN_KILL & 8)
+        {
+            // timing experiment: the loads stay, the decode is an xor (what does the launch cost without the decode's VALU work?)
+            u32 xr = 0;
+            #pragma unroll
+            for (int q = 0; q < D; q++) if (q < n) { for (int e = 0; e < BITS; e++) xr ^= b[q].w[e]; }
+            if (tail_nv) for (int e = 0; e < BITS; e++) xr ^= bt.w[e];
+            acc[0] = __builtin_bit_cast(float, xr & 0x3fffffffu) + (float)R.cx.x_lds[lane] + (float)R.cx.sc_lds[lane & 15];
+        }
+        else if (LEAN_KILL & 1) { }
         else if (R.uni)
         {
             #pragma unroll
