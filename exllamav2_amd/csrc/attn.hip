@@ -234,21 +234,32 @@ template <int HDIM> DEV size_t fused_out_index(const FusedArgs& a, size_t qrow, 
     return tok * ((size_t)a.H * HDIM) + a.out_invperm[head * HDIM + d];
 }
 
-template <int LPK> DEV f16x8 rope_neox_frag(f16x8 x, const f16* sin, const f16* cos, int pos, int dl)
+// rotary table rows of position pos for lane dl (columns [8 dl, 8 dl + 8) and their partner columns): requested ...
+template <int LPK> DEV void rope_neox_load(const f16* sin, const f16* cos, int pos, int dl, f16x8& cs, f16x8& sn)
 {
-    // lane dl holds columns [8 dl, 8 dl + 8); its partner columns (+- HDIM/2) sit in lane dl ^ (LPK/2)
+    constexpr int HL = LPK / 2;
+    const size_t off = (size_t)pos * (LPK * 8) + (size_t)(dl % HL) * 8;
+    cs = *(const f16x8*)(cos + off);
+    sn = *(const f16x8*)(sin + off);
+}
+// ... applied: lane dl holds columns [8 dl, 8 dl + 8); its partner columns (+- HDIM/2) sit in lane dl ^ (LPK/2)
+template <int LPK> DEV f16x8 rope_neox_apply(f16x8 x, f16x8 cs, f16x8 sn, int dl)
+{
     constexpr int HL = LPK / 2;
     u32x4 u = __builtin_bit_cast(u32x4, x);
     u32x4 pu;
     #pragma unroll
     for (int i = 0; i < 4; i++) pu[i] = swz_xor_u32<HL>(u[i]);
     const f16x8 partner = __builtin_bit_cast(f16x8, pu);
-    const size_t off = (size_t)pos * (LPK * 8) + (size_t)(dl % HL) * 8;
-    const f16x8 cs = *(const f16x8*)(cos + off);
-    f16x8 sn = *(const f16x8*)(sin + off);
     if (dl < HL) sn = -sn;                               // left half: l' = l cos + r (-sin); right: r' = r cos + l sin
     const f16x8 t = partner * sn;
     return __builtin_elementwise_fma(x, cs, t);
+}
+template <int LPK> DEV f16x8 rope_neox_frag(f16x8 x, const f16* sin, const f16* cos, int pos, int dl)
+{
+    f16x8 cs, sn;
+    rope_neox_load<LPK>(sin, cos, pos, dl, cs, sn);
+    return rope_neox_apply<LPK>(x, cs, sn, dl);
 }
 
 template <int HDIM, int RB>
@@ -275,20 +286,27 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     const int group = lane / LPK;
     const int dl = lane % LPK;
 
-    int past = a.past_const;
-    if (a.cache_seqlens) { const int p = a.cache_seqlens[b]; past += p > 0 ? p : 0; }
-    const int total = past + a.s;
-    int eff = (total + a.keys_per_split_min - 1) / a.keys_per_split_min;
-    eff = eff < 1 ? 1 : (eff > a.nsplit ? a.nsplit : eff);
-    if (split >= eff) return;
-    int kps = (total + eff - 1) / eff;
-    kps = (kps + 15) & ~15;
-    const int k_start = split * kps;
-    const int k_end = min(total, k_start + kps);
-
     const bool dep = a.sync_signal != nullptr;                 // overlapped chain: producer may still be running
-    if (a.sync_wait) { if (wv == 0) sync_wait_go(a.sync_wait, kh + split); block_sync(); }
 
+    // ---- request level 1: everything whose address does not depend on the cache length goes out TOGETHER -- the length
+    // itself, the first page of the sequence (split 0 starts at key 0), the query rows, the new key / value row this stream
+    // takes first, the output position of the element this thread finalises.  (One dependent round trip each before:
+    // length -> page -> keys -> new key -> rotary rows -> output position, 6.9 us per launch at 64 keys;
+    // profiles/r03_kernel_stats.csv.)
+    int p_raw = 0;
+    if (a.cache_seqlens) p_raw = a.cache_seqlens[b];
+    const bool spec = a.block_table != nullptr && split == 0;
+    int tab_spec = 0;
+    if (spec) tab_spec = a.block_table[(size_t)b * a.pages_per_seq];
+    if (a.sync_wait)
+    {
+        // overlapped chain: q / k_new / v_new are read behind the wait; workgroups of unused splits leave before it
+        const int total_e = a.past_const + (p_raw > 0 ? p_raw : 0) + a.s;
+        const int eff_e = (total_e + a.keys_per_split_min - 1) / a.keys_per_split_min;
+        if (split >= (eff_e < 1 ? 1 : (eff_e > a.nsplit ? a.nsplit : eff_e))) return;
+        if (wv == 0) sync_wait_go(a.sync_wait, kh + split);
+        block_sync();
+    }
     f16x8 qf[RB];
     int limit[RB];
     #pragma unroll
@@ -297,10 +315,77 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
         const int rr = r0 + (r < nrows ? r : 0);
         const int j = rr / G, g = rr - j * G;
         const f16* qp = a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM + dl * 8;
-        f16x8 raw = dep ? load_agent_f16x8(qp) : *(const f16x8*)qp;
-        if (a.rope) raw = rope_neox_frag<LPK>(raw, a.sin, a.cos, past + j, dl);
-        qf[r] = raw;
-        limit[r] = past + j + 1;
+        qf[r] = dep ? load_agent_f16x8(qp) : *(const f16x8*)qp;
+        limit[r] = j + 1;
+    }
+    const int j0 = wv * KPW + group;                            // the new key this stream takes first
+    const int jn = j0 < a.s ? j0 : a.s - 1;
+    const size_t src0 = (((size_t)b * a.s + jn) * a.KVH + kh) * HDIM + dl * 8;
+    f16x8 kn0 = dep ? load_agent_f16x8(a.k_new + src0) : *(const f16x8*)(a.k_new + src0);
+    const f16x8 vn0 = dep ? load_agent_f16x8(a.v_new + src0) : *(const f16x8*)(a.v_new + src0);
+    int out_pre = 0;
+    if (a.out_invperm && tid() < nrows * HDIM)
+    {
+        const int r = tid() / HDIM, d = tid() - r * HDIM;
+        const int rr = r0 + r;
+        const int g = rr - (rr / G) * G;
+        out_pre = (int)a.out_invperm[(kh * G + g) * HDIM + d];
+    }
+
+    const int past = a.past_const + (p_raw > 0 ? p_raw : 0);
+    const int total = past + a.s;
+    int eff = (total + a.keys_per_split_min - 1) / a.keys_per_split_min;
+    eff = eff < 1 ? 1 : (eff > a.nsplit ? a.nsplit : eff);
+    if (split >= eff) return;
+    int kps = (total + eff - 1) / eff;
+    kps = (kps + 15) & ~15;
+    const int k_start = split * kps;
+    const int k_end = min(total, k_start + kps);
+    #pragma unroll
+    for (int r = 0; r < RB; r++) limit[r] += past;
+
+    auto slot_of = [&](const int kp) -> size_t
+    {
+        if (a.block_table)
+        {
+            const int pg = kp >> a.page_shift;
+            const int page = (spec && pg == 0) ? tab_spec : a.block_table[(size_t)b * a.pages_per_seq + pg];
+            return (size_t)page * a.page_size + (kp & (a.page_size - 1));
+        }
+        return (size_t)b * a.page_size + kp;
+    };
+    const size_t row_stride = (size_t)a.KVH * HDIM;
+    const int k_old_end = min(k_end, past);
+    constexpr int STEP = ATT_WAVES * KPW;
+    constexpr int UNR = RB <= 2 ? 2 * ATT_UNROLL : ATT_UNROLL;   // keys of UNR steps requested together (128 = a whole split at 1-2 rows)
+
+    // ---- request level 2: what needs the length -- the first batch of cached keys, the rotary rows of the queries and of
+    // the new key -- again together, before anything is used
+    f16x8 kf[UNR], vf[UNR];
+    const int base_first = k_start + wv * KPW;
+    auto request_batch = [&](const int base0)
+    {
+        #pragma unroll
+        for (int u = 0; u < UNR; u++)
+        {
+            const int kpos = base0 + u * STEP + group;
+            const int kp = kpos < k_old_end ? kpos : k_start;       // keep the address valid, mask the score
+            const size_t off = slot_of(kp) * row_stride + (size_t)kh * HDIM + dl * 8;
+            kf[u] = ld_nt((const f16x8*)(a.k_cache + off));
+            vf[u] = ld_nt((const f16x8*)(a.v_cache + off));
+        }
+    };
+    if (base_first < k_old_end) request_batch(base_first);
+    const bool pre_new = k_start <= past;                       // the stream's first new key is row j0 of this step
+    if (a.rope)
+    {
+        f16x8 cs_q[RB], sn_q[RB], cs_k, sn_k;
+        #pragma unroll
+        for (int r = 0; r < RB; r++) rope_neox_load<LPK>(a.sin, a.cos, limit[r] - 1, dl, cs_q[r], sn_q[r]);
+        rope_neox_load<LPK>(a.sin, a.cos, past + jn, dl, cs_k, sn_k);
+        #pragma unroll
+        for (int r = 0; r < RB; r++) qf[r] = rope_neox_apply<LPK>(qf[r], cs_q[r], sn_q[r], dl);
+        kn0 = rope_neox_apply<LPK>(kn0, cs_k, sn_k, dl);
     }
 
     float m[RB], l[RB], o[RB][8];
@@ -336,55 +421,41 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
             }
         }
     };
-    auto slot_of = [&](const int kp) -> size_t
+    // keys already in the cache: the K/V rows of UNR steps are requested together (one round trip per batch instead of one
+    // per step); the first batch is already in flight
+    for (int base0 = base_first; base0 < k_old_end; base0 += UNR * STEP)
     {
-        if (a.block_table)
-            return (size_t)a.block_table[(size_t)b * a.pages_per_seq + (kp >> a.page_shift)] * a.page_size
-                   + (kp & (a.page_size - 1));
-        return (size_t)b * a.page_size + kp;
-    };
-
-    const size_t row_stride = (size_t)a.KVH * HDIM;
-    // keys already in the cache: the K/V rows of ATT_UNROLL steps are requested together (one round trip per batch instead
-    // of one per step -- a split covers ~128 keys = 8 steps, each step a dependent pair of loads otherwise)
-    const int k_old_end = min(k_end, past);
-    constexpr int STEP = ATT_WAVES * KPW;
-    for (int base0 = k_start + wv * KPW; base0 < k_old_end; base0 += ATT_UNROLL * STEP)
-    {
-        f16x8 kf[ATT_UNROLL], vf[ATT_UNROLL];
+        if (base0 != base_first) request_batch(base0);
         #pragma unroll
-        for (int u = 0; u < ATT_UNROLL; u++)
-        {
-            const int kpos = base0 + u * STEP + group;
-            const int kp = kpos < k_old_end ? kpos : k_start;       // keep the address valid, mask the score
-            const size_t off = slot_of(kp) * row_stride + (size_t)kh * HDIM + dl * 8;
-            kf[u] = ld_nt((const f16x8*)(a.k_cache + off));
-            vf[u] = ld_nt((const f16x8*)(a.v_cache + off));
-        }
-        #pragma unroll
-        for (int u = 0; u < ATT_UNROLL; u++)
+        for (int u = 0; u < UNR; u++)
         {
             const int kpos = base0 + u * STEP + group;
             if (base0 + u * STEP < k_old_end) attend(kf[u], vf[u], kpos, kpos < k_old_end);
         }
     }
-    // keys of this step: rotate, use, append
-    for (int base = max(k_start, past) + wv * KPW; base < k_end; base += ATT_WAVES * KPW)
+    // keys of this step: rotate, use, append (the stream's first one was requested and rotated above)
+    const int base_new = max(k_start, past) + wv * KPW;
+    for (int base = base_new; base < k_end; base += ATT_WAVES * KPW)
     {
         const int kpos = base + group;
         const bool in_range = kpos < k_end;
         const int kp = in_range ? kpos : k_end - 1;
-        const size_t src = (((size_t)b * a.s + (kp - past)) * a.KVH + kh) * HDIM + dl * 8;
-        f16x8 kf = dep ? load_agent_f16x8(a.k_new + src) : *(const f16x8*)(a.k_new + src);
-        const f16x8 vf = dep ? load_agent_f16x8(a.v_new + src) : *(const f16x8*)(a.v_new + src);
-        if (a.rope) kf = rope_neox_frag<LPK>(kf, a.sin, a.cos, kp, dl);
+        f16x8 kfn, vfn;
+        if (pre_new && base == base_new) { kfn = kn0; vfn = vn0; }
+        else
+        {
+            const size_t src = (((size_t)b * a.s + (kp - past)) * a.KVH + kh) * HDIM + dl * 8;
+            kfn = dep ? load_agent_f16x8(a.k_new + src) : *(const f16x8*)(a.k_new + src);
+            vfn = dep ? load_agent_f16x8(a.v_new + src) : *(const f16x8*)(a.v_new + src);
+            if (a.rope) kfn = rope_neox_frag<LPK>(kfn, a.sin, a.cos, kp, dl);
+        }
         if (in_range && rblk == 0 && a.k_cache)
         {
             const size_t off = slot_of(kp) * row_stride + (size_t)kh * HDIM + dl * 8;
-            *(f16x8*)(a.k_cache + off) = kf;
-            *(f16x8*)(a.v_cache + off) = vf;
+            *(f16x8*)(a.k_cache + off) = kfn;
+            *(f16x8*)(a.v_cache + off) = vfn;
         }
-        attend(kf, vf, kpos, in_range);
+        attend(kfn, vfn, kpos, in_range);
     }
 
     // merge the NSTREAM independent softmax streams of this workgroup
@@ -422,8 +493,9 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
         if (eff == 1)
         {
             const f16 y = (f16)(L > 0.0f ? O / L : 0.0f);
-            if (a.sync_signal) store_agent_f16(a.out + fused_out_index<HDIM>(a, qrow, d), y);
-            else a.out[fused_out_index<HDIM>(a, qrow, d)] = y;
+            const size_t oi = (a.out_invperm && idx == tid()) ? (qrow / a.H) * ((size_t)a.H * HDIM) + (size_t)out_pre : fused_out_index<HDIM>(a, qrow, d);
+            if (a.sync_signal) store_agent_f16(a.out + oi, y);
+            else a.out[oi] = y;
         }
         else
         {
