@@ -17,6 +17,9 @@
 
 #define ATT_WAVES 4
 #define ATT_UNROLL 4
+#ifndef ATT_KPS_DEFAULT
+#define ATT_KPS_DEFAULT 128
+#endif
 #define NEG_BIG (-1.0e30f)
 
 struct AttnArgs
@@ -765,7 +768,11 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
     a.page_size = page_size; a.pages_per_seq = pages_per_seq; a.page_shift = ilog2_exact(page_size);
     EXL2_REQUIRE(!block_table || a.page_shift >= 0, "attn_decode_fused: page_size %d must be a power of two", page_size);
     a.past_const = past_const; a.rope = rope_style != 0; a.scale = softmax_scale;
-    a.keys_per_split_min = 128;
+    {
+        // keys one workgroup takes before the step is split over several (a split costs the partial-result hand-off)
+        static const int kps = []() { const char* e = getenv("EXL2_ATT_KPS"); const int v = e ? atoi(e) : 0; return v >= 16 ? v : ATT_KPS_DEFAULT; }();
+        a.keys_per_split_min = kps;
+    }
     if (nsplit <= 0)
     {
         const long long base = (long long)num_kv_heads * batch * rblocks;
