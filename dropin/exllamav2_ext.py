@@ -14,18 +14,25 @@ import torch as _torch
 from exllamav2_amd.ext import ext_c as _e
 from exllamav2_amd import ext_tp as _tp
 
-# make_q_matrix (ext_qmatrix.cpp:21-111) may re-lay q_weight out in place -- the reference shuffles it in place too
-# (q_matrix.cu:123-196).  But the reference's tensor-parallel loader later slices that tensor by output columns
-# (linear.py:572-576) and hands the slices to make_q_matrix_split: its own shuffle is column-local, so the slices stay valid;
-# the tile-major layout of libexl2_hip.so is not.  The drop-in therefore re-lays out a PRIVATE copy and leaves the caller's
-# tensor as loaded (one extra copy of the packed weights while the handle lives; EXL2_DROPIN_INPLACE=1 restores the in-place
-# behaviour and gives up `model.load_tp`).
+# make_q_matrix (ext_qmatrix.cpp:21-111) re-lays q_weight out IN PLACE -- the reference shuffles it in place too
+# (q_matrix.cu:123-196) and keeps its own q_tensors alive, so no second copy of the packed weights exists (a private copy per
+# handle doubled the weight VRAM of every drop-in user).
+# The one consumer of the ORIGINAL layout is the reference's single-process tensor-parallel loader: after load() it slices
+# q_weight by output columns (linear.py:572-576) and hands the slices to make_q_matrix_split.  Its own shuffle is column-local,
+# so its slices stay valid; the tile-major layout of libexl2_hip.so is not sliceable.  Processes that call `model.load_tp`
+# therefore opt in with EXL2_DROPIN_TP=1 BEFORE loading: make_q_matrix then re-lays out a private copy (held while the handle
+# lives) and leaves the caller's tensor as loaded.  Without the opt-in make_q_matrix_split raises instead of building
+# matrices from a re-laid-out tensor.
 _private_weights = {}
+
+
+def _tp_opt_in():
+    return _os.environ.get("EXL2_DROPIN_TP", "0") != "0"
 
 
 def make_q_matrix(q_weight, q_perm, q_invperm, q_scale, q_scale_max, q_groups, q_group_map, gptq_qzeros, gptq_scales,
                   gptq_g_idx, bias, temp_dq, max_dq_rows):
-    if _os.environ.get("EXL2_DROPIN_INPLACE", "0") != "0":
+    if not _tp_opt_in():
         return _e.make_q_matrix(q_weight, q_perm, q_invperm, q_scale, q_scale_max, q_groups, q_group_map, gptq_qzeros,
                                 gptq_scales, gptq_g_idx, bias, temp_dq, max_dq_rows)
     own = q_weight.clone()
@@ -38,6 +45,15 @@ def make_q_matrix(q_weight, q_perm, q_invperm, q_scale, q_scale_max, q_groups, q
 def free_q_matrix(handle):
     _e.free_q_matrix(handle)
     _private_weights.pop(handle, None)
+
+
+def make_q_matrix_split(*args):
+    # (its inputs are fresh contiguous column slices of the tensors load() kept: re-laid out in place)
+    if not _tp_opt_in():
+        raise RuntimeError("exllamav2_ext.make_q_matrix_split (model.load_tp): set EXL2_DROPIN_TP=1 before loading the model -- "
+                           "without it make_q_matrix re-lays q_weight out in place and column slices of it are not weights "
+                           "(dropin/exllamav2_ext.py)")
+    return _e.make_q_matrix_split(*args)
 
 
 reconstruct = _e.reconstruct
@@ -76,7 +92,6 @@ def _out_of_scope(name, why):
     return f
 
 
-make_q_matrix_split = _e.make_q_matrix_split          # (its inputs are fresh contiguous slices: re-laid out in place)
 # the reference's single-process tensor parallel (ext_tp.cpp, tp_* of ext_qattn.cpp / ext_qmlp.cpp): host staging through
 # pinned buffers + per-device kernels, mirrored in exllamav2_amd/ext_tp.py
 make_tp_context = _tp.make_tp_context
@@ -160,30 +175,47 @@ def apply_rep_penalty(sequence, penalty_max, sustain, decay, alpha_frequency, al
     seq = sequence.numpy()
     lg = logits.view(logits.shape[0], -1).numpy()
     vocab, seq_len = lg.shape[-1], seq.shape[-1]
+    # Vectorised (the reference's default settings call this on every generated token over the whole context: a Python loop
+    # per token made the drop-in's generators host-bound).  Same fp32 operations in the same order PER TOKEN ID as the walk:
+    # the penalties in force at walk step w (w = 0 is the last token) are sequential fp32 sums, the first encounter of an id
+    # applies repetition then presence, and the k-th encounters of all ids are subtracted together, k = 0, 1, ...
+    sust0 = seq_len if sustain == -1 else int(sustain)
+    beg = max(seq_len - sust0 - int(decay), 0)
+    n = seq_len - beg
+    if n <= 0:
+        return
+    rep0, freq0, pres0 = f32(penalty_max), f32(alpha_frequency), f32(alpha_presence)
+    if decay:
+        d = (f32(1.0) - rep0) / f32(decay), (f32(0.0) - freq0) / f32(decay), (f32(0.0) - pres0) / f32(decay)
+    else:
+        d = f32(0.0), f32(0.0), f32(0.0)
+    n_upd = max(0, n - 1 - sust0)                              # updates applied before the last walk step
+    def ramp(v0, dv):
+        seq_v = _np.add.accumulate(_np.concatenate([_np.array([v0], dtype=f32), _np.full(n_upd, dv, dtype=f32)]), dtype=f32)
+        w = _np.arange(n)
+        return seq_v[_np.maximum(w - sust0, 0)]                # value in force at walk step w
+    rep_w, freq_w, pres_w = ramp(rep0, d[0]), ramp(freq0, d[1]), ramp(pres0, d[2])
+    any_freq = bool(_np.any(freq_w != 0))
     for b in range(seq.shape[0]):
         row = lg[b]
-        rep_p, freq_p, pres_p = f32(penalty_max), f32(alpha_frequency), f32(alpha_presence)
-        d_rep = d_freq = d_pres = f32(0.0)
-        if decay:
-            d_rep = (f32(1.0) - rep_p) / f32(decay)
-            d_freq = (f32(0.0) - freq_p) / f32(decay)
-            d_pres = (f32(0.0) - pres_p) / f32(decay)
-        sust = seq_len if sustain == -1 else int(sustain)
-        beg = max(seq_len - sust - int(decay), 0)
-        seen = set()
-        i = seq_len
-        while i > beg:
-            i -= 1
-            t = int(seq[b, i])
-            if 0 <= t < vocab:
-                if t not in seen:
-                    row[t] = (row[t] / rep_p) if row[t] > 0.0 else (row[t] * rep_p)
-                    row[t] = row[t] - pres_p
-                    seen.add(t)
-                row[t] = row[t] - freq_p
-            sust -= 1
-            if sust < 0:
-                rep_p = f32(rep_p + d_rep); freq_p = f32(freq_p + d_freq); pres_p = f32(pres_p + d_pres)
+        toks = seq[b, beg:][::-1]                              # walk order
+        steps = _np.nonzero((toks >= 0) & (toks < vocab))[0]
+        if steps.size == 0:
+            continue
+        t = toks[steps].astype(_np.int64)
+        order = _np.argsort(t, kind="stable")                  # groups of equal ids, walk order inside a group
+        ts, ws = t[order], steps[order]
+        first = _np.ones(ts.size, dtype=bool); first[1:] = ts[1:] != ts[:-1]
+        ids, w1 = ts[first], ws[first]
+        x = row[ids]
+        x = _np.where(x > 0.0, x / rep_w[w1], x * rep_w[w1]).astype(f32)
+        row[ids] = x - pres_w[w1]
+        if any_freq:
+            start = _np.nonzero(first)[0]
+            rank = _np.arange(ts.size) - _np.repeat(start, _np.diff(_np.append(start, ts.size)))
+            for k in range(int(rank.max()) + 1):
+                sel = rank == k
+                row[ts[sel]] = row[ts[sel]] - freq_w[ws[sel]]
 
 
 def sample_basic(logits, temperature, top_k, top_p, top_a, min_p, tfs, typical, random, output_tokens, output_probs,

@@ -47,6 +47,10 @@ PROTOTYPES = {
     "exl2_fp8_to_fp16": (ci, [vp, vp, ci, cll, ci, ci, ci, vp]),
     "exl2_cache_rotate": (ci, [vp, vp, cll, ci, vp]),
     "exl2_count_match": (ci, [vp, vp, ci, ci, vp]),
+    # peer copies (single-process tensor parallel)
+    "exl2_release_scratch": (cll, [vp, ci]),
+    "exl2_memcpy_2d_async": (ci, [vp, cll, vp, cll, cll, cll, vp]),
+    "exl2_enable_peer_access": (ci, [C.POINTER(ci), ci]),
     # load path
     "exl2_stloader_read": (ci, [C.c_char_p, C.c_ulonglong, C.c_ulonglong, vp, ci, vp]),
     "exl2_tensor_remap": (ci, [vp, ci, ci, vp]),

@@ -235,6 +235,16 @@ int exl2_flash_prefill(const void* q, const void* k_cache, const void* v_cache, 
     a.len_const = len_const; a.len_offset = len_offset; a.scale = softmax_scale; a.causal = causal;
     dim3 grid((unsigned)((q_len + FP_BQ - 1) / FP_BQ), (unsigned)num_heads, (unsigned)batch);
     const size_t lds = ((size_t)FP_BK * (head_dim + 8) + (size_t)FP_BK * (head_dim + 16)) * sizeof(f16);
+    {
+        // head_dim 256 asks for 68,608 bytes of dynamic LDS: above the 64 KB default limit like the other large kernels
+        static bool attr[EXL2_MAX_DEVICES] = {false};
+        if (exl2_first_on_device(attr))
+        {
+            (void)hipFuncSetAttribute((const void*)flash_prefill_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)flash_prefill_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)flash_prefill_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+    }
     switch (head_dim)
     {
         case 64:  LAUNCH(flash_prefill_kernel<64>, grid, dim3(FP_WAVES * 64), lds, stream, a); break;

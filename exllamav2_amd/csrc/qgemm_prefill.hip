@@ -512,8 +512,9 @@ KERNEL void __launch_bounds__(256) stage_rows_multi_kernel(const RowStageMulti a
 // never share a buffer.  A buffer that has been handed out is NEVER freed -- a captured graph (GreedyGraphDecoder,
 // PipelineStage) may have its address baked into kernel arguments -- so a larger request allocates a new one (at least
 // twice the old size, which bounds the retired total by the live size) and the old one stays allocated.  Growing inside
-// a capture is refused.
-struct StageSlot { int dev; void* stream; f16* buf; size_t bytes; };
+// a capture is refused.  exl2_release_scratch (model unload, after the graphs that used the stream have been destroyed) frees
+// the live and the retired buffers of a stream, so processes that cycle through models or streams do not accumulate them.
+struct StageSlot { int dev; void* stream; f16* buf; size_t bytes; std::vector<f16*> retired; };
 static std::vector<StageSlot> g_stage_slots;
 static std::mutex g_stage_mutex;
 
@@ -523,7 +524,7 @@ static int stage_scratch(size_t bytes, void* stream, f16** out)
     std::lock_guard<std::mutex> lock(g_stage_mutex);
     StageSlot* slot = nullptr;
     for (StageSlot& s : g_stage_slots) if (s.dev == dev && s.stream == stream) { slot = &s; break; }
-    if (!slot) { g_stage_slots.push_back(StageSlot{dev, stream, nullptr, 0}); slot = &g_stage_slots.back(); }
+    if (!slot) { g_stage_slots.push_back(StageSlot{dev, stream, nullptr, 0, {}}); slot = &g_stage_slots.back(); }
     if (slot->bytes < bytes)
     {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -542,11 +543,32 @@ static int stage_scratch(size_t bytes, void* stream, f16** out)
                 EXL2_FAIL(EXL2_E_OOM, "HIP out of memory (prefill staging scratch: %zu bytes)", bytes);
             }
         }
-        slot->buf = fresh;                    // the previous buffer stays allocated (see above)
+        if (slot->buf) slot->retired.push_back(slot->buf);      // stays allocated until exl2_release_scratch (see above)
+        slot->buf = fresh;
         slot->bytes = want;
     }
     *out = slot->buf;
     return EXL2_OK;
+}
+
+// Frees the staging buffers (live and retired) of the current device: those of `stream`, or of every stream when all_streams
+// != 0.  The caller guarantees that no captured graph that ran a prefill / batched-decode launch on those streams will be
+// replayed again (model.unload() calls it after its decoders' graphs are gone).  Returns the number of bytes released.
+extern "C" long long exl2_release_scratch(void* stream, int all_streams)
+{
+    const int dev = exl2_current_device();
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
+    long long freed = 0;
+    for (size_t i = 0; i < g_stage_slots.size();)
+    {
+        StageSlot& s = g_stage_slots[i];
+        if (s.dev != dev || !(all_streams || s.stream == stream)) { i++; continue; }
+        (void)hipDeviceSynchronize();
+        if (s.buf) { (void)hipFree(s.buf); freed += (long long)s.bytes; }
+        for (f16* r : s.retired) (void)hipFree(r);
+        g_stage_slots.erase(g_stage_slots.begin() + i);
+    }
+    return freed;
 }
 
 // Pre-pass for the phased decode kernel (qgemv_stream.hip): rows of every job in its packed K order, into the per-device

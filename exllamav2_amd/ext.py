@@ -278,6 +278,36 @@ class ExtC:
                                                  min(int(max_a), a.shape[-1]), b.shape[-1], ctypes.byref(out)))
         return int(out.value)
 
+    # ---- peer copies of the single-process tensor parallel (csrc/peer.hip; used by ext_tp.py) -------------------------------
+
+    def copy_2d_async(self, dst, src, stream: int | None) -> None:
+        """dst[r, :] = src[r, :] for 2-D views of equal shape whose rows are contiguous (dst / src may be column slices of
+        wider matrices, on the host (pinned), this device or a peer device); asynchronous on `stream`."""
+        if dst.dim() != 2 or src.dim() != 2 or dst.shape != src.shape or dst.dtype != src.dtype:
+            raise RuntimeError(f"copy_2d_async: shapes / dtypes differ ({tuple(dst.shape)} {dst.dtype} <- {tuple(src.shape)} {src.dtype})")
+        if (dst.shape[1] > 1 and (dst.stride(1) != 1 or src.stride(1) != 1)) or dst.shape[0] == 0 or dst.shape[1] == 0:
+            if dst.numel() == 0:
+                return
+            raise RuntimeError("copy_2d_async: rows must be contiguous")
+        es = dst.element_size()
+        dp = dst.stride(0) * es if dst.shape[0] > 1 else dst.shape[1] * es
+        sp = src.stride(0) * es if src.shape[0] > 1 else src.shape[1] * es
+        self.lib.check(self.lib.exl2_memcpy_2d_async(dst.data_ptr(), dp, src.data_ptr(), sp, dst.shape[1] * es, dst.shape[0], stream))
+
+    def release_scratch(self, device=None) -> int:
+        """frees the prefill / batched-decode staging buffers of every stream of `device` (default: the current one);
+        call only when no captured graph that used them will be replayed (include/exl2_hip.h)"""
+        if device is not None and torch.device(device).type == "cuda":
+            with torch.cuda.device(device):
+                return int(self.lib.exl2_release_scratch(None, 1))
+        return int(self.lib.exl2_release_scratch(None, 1))
+
+    def enable_peer_access(self, devices) -> int:
+        import ctypes
+        devs = [int(d) for d in devices]
+        arr = (ctypes.c_int * max(1, len(devs)))(*devs)
+        return self.lib.check(self.lib.exl2_enable_peer_access(arr, len(devs)))
+
     # ---- load path (ext_stloader.cpp; SURVEY.md 8f row N3) ---------------------------------------------------------------
 
     def stloader_read(self, filename: str, offset: int, size: int, target) -> None:

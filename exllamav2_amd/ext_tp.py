@@ -84,6 +84,8 @@ _contexts: dict[int, ExtTPContext] = {}
 
 def make_tp_context(kv_split, id_split, vc_split, rs_split, q_split, pinned_temp, streams) -> int:
     ctx = ExtTPContext(kv_split, id_split, vc_split, rs_split, q_split, pinned_temp, streams)
+    if not ctx.host_only and len(ctx.all_devices) > 1:
+        ctx.unreachable_pairs = _e.enable_peer_access(ctx.all_devices)          # xGMI peer copies in tp_gather / tp_broadcast
     _contexts[id(ctx)] = ctx
     return id(ctx)
 
@@ -120,39 +122,54 @@ def tp_cross_device_barrier(tp_context: int, broadcast_type: int = 0, t_device: 
 
 
 def tp_broadcast(tp_context: int, buffer: int, source, broadcast_type: int, targets, dim: int, t_device: int = -1) -> None:
-    """ext_tp.cpp:129-180: source -> pinned_temp[buffer] -> every target (one per device of the split)."""
+    """ext_tp.cpp:129-180: source -> every target (one per device of the split).  A host source is the staging buffer
+    pinned_temp[buffer] (or is copied into it first) and goes up to each device on that device's stream, as in the reference.
+    A DEVICE source is copied to pinned_temp[buffer] too (the contract of the buffer), but the targets are written directly
+    from the source over xGMI on their own streams -- no host bounce on the path the next kernel waits for."""
     ctx = _ctx(tp_context)
     if t_device != -1:
         raise NotImplementedError("tp_broadcast: per-thread form (TP_MULTITHREADED) is compiled out in the reference too")
     rows_cols = (source.numel() // source.shape[-1], source.shape[-1])
     pin = _pinned_view(ctx, buffer, *rows_cols, dtype=source.dtype)
-    staged = None
+    src2 = source.reshape(rows_cols)
+    produced = None
     if source.device.type == "cuda":
         sdev = source.device.index
-        # D2H on the source device's stream (its current stream in the reference: the same global stream)
         with ctx.on(sdev):
-            pin.copy_(source.reshape(rows_cols), non_blocking=True)
-            staged = torch.cuda.Event()
-            staged.record(ctx.streams[sdev])
-    elif ctx.host_only and source.data_ptr() != pin.data_ptr():
-        pin.copy_(source.reshape(rows_cols))
+            produced = torch.cuda.Event()
+            produced.record(ctx.streams[sdev])
+            _e.copy_2d_async(pin, src2, ctx.streams[sdev].cuda_stream)          # D2H, source device's stream
     elif source.data_ptr() != pin.data_ptr():
-        pin.copy_(source.reshape(rows_cols))            # a host tensor that is not the staging buffer yet
+        # a host tensor that is not the staging buffer yet: earlier uploads FROM the buffer may still be in flight on the
+        # device streams -- they must have read it before it is overwritten
+        if not ctx.host_only:
+            for d in ctx.all_devices:
+                ctx.streams[d].synchronize()
+        pin.copy_(src2)
     for i, (dev, _, _) in enumerate(ctx.split(broadcast_type)):
         tgt = targets[i]
         if tgt.data_ptr() == source.data_ptr():
             continue
+        if ctx.host_only:
+            tgt.view(rows_cols).copy_(pin)
+            continue
         with ctx.on(dev):
-            if staged is not None:
-                ctx.streams[dev].wait_event(staged)
-            tgt.view(rows_cols).copy_(pin, non_blocking=True)
+            if produced is not None:
+                ctx.streams[dev].wait_event(produced)
+                _e.copy_2d_async(tgt.view(rows_cols), src2, ctx.streams[dev].cuda_stream)      # peer copy, target's stream
+            else:
+                _e.copy_2d_async(tgt.view(rows_cols), pin, ctx.streams[dev].cuda_stream)       # H2D from the pinned buffer
     tp_cross_device_barrier(tp_context, broadcast_type, t_device)
 
 
 def tp_gather(tp_context: int, buffer: int, inputs, broadcast_type: int, targets, broadcast_type_target: int, dim: int,
               t_device: int = -1) -> None:
-    """ext_tp.cpp:182-287: column slices [rows, (b - a) * dim] of the split's devices -> pinned_temp[buffer] as one
-    [rows, last * dim] matrix; then (broadcast_type_target >= 0) that matrix back to every device of the target split."""
+    """ext_tp.cpp:182-287: column slices [rows, (b - a) * dim] of the split's devices form one [rows, last * dim] matrix.
+    broadcast_type_target < 0: the matrix is wanted on the HOST (pinned_temp[buffer]; the reference's ctx.gather reads it
+    there): one strided 2-D copy per slice on its device's stream (hipMemcpy2DAsync: asynchronous also when rows > 1 and the
+    destination rows are not contiguous).  broadcast_type_target >= 0: it is wanted on the devices of the target split
+    (ctx.allgather): every target pulls every slice directly over xGMI on its own stream -- the reference's round trip
+    through the host buffer (one copy down per source, one up per target) is not made."""
     ctx = _ctx(tp_context)
     if t_device != -1:
         raise NotImplementedError("tp_gather: per-thread form (TP_MULTITHREADED) is compiled out in the reference too")
@@ -160,19 +177,35 @@ def tp_gather(tp_context: int, buffer: int, inputs, broadcast_type: int, targets
     rows = inputs[0].shape[0]
     cols = split[-1][2] * dim
     pin = _pinned_view(ctx, buffer, rows, cols, dtype=inputs[0].dtype)
-    for i, (dev, a, _) in enumerate(split):
-        src = inputs[i]
-        with ctx.on(dev):
-            pin[:, a * dim:a * dim + src.shape[1]].copy_(src, non_blocking=True)
-    if broadcast_type_target == -2:
+    if ctx.host_only:
+        for i, (dev, a, _) in enumerate(split):
+            pin[:, a * dim:a * dim + inputs[i].shape[1]].copy_(inputs[i])
+        if broadcast_type_target >= 0:
+            for i, (dev, _, _) in enumerate(ctx.split(broadcast_type_target)):
+                targets[i].view(rows, cols).copy_(pin)
         return
-    tp_cross_device_barrier(tp_context, broadcast_type, t_device)
-    if broadcast_type_target == -1:
+    if broadcast_type_target < 0:
+        for i, (dev, a, _) in enumerate(split):
+            src = inputs[i]
+            with ctx.on(dev):
+                _e.copy_2d_async(pin[:, a * dim:a * dim + src.shape[1]], src, ctx.streams[dev].cuda_stream)
+        if broadcast_type_target == -2:
+            return
+        tp_cross_device_barrier(tp_context, broadcast_type, t_device)
         return
-    for i, (dev, _, _) in enumerate(ctx.split(broadcast_type_target)):
-        tgt = targets[i]
-        with ctx.on(dev):
-            tgt.view(rows, cols).copy_(pin, non_blocking=True)
+    # device targets: slice i is complete on its device's stream at this point
+    for dev, _, _ in split:
+        ctx.record(dev)
+    for t, (tdev, _, _) in enumerate(ctx.split(broadcast_type_target)):
+        tgt = targets[t].view(rows, cols)
+        with ctx.on(tdev):
+            for i, (dev, a, _) in enumerate(split):
+                src = inputs[i]
+                if dev != tdev:
+                    ctx.wait(tdev, dev)
+                _e.copy_2d_async(tgt[:, a * dim:a * dim + src.shape[1]], src, ctx.streams[tdev].cuda_stream)
+    # the sources may be reused by their devices only after every target has pulled them
+    tp_cross_device_barrier(tp_context, broadcast_type_target, t_device)
 
 
 def tp_all_reduce(tp_context: int, buffer: int, tensors, residuals) -> None:

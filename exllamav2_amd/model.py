@@ -92,6 +92,9 @@ class ExLlamaV2:
             attn.unload(); mlp.unload()
         if self.lm_head: self.lm_head.unload()
         self.layers, self.modules, self.loaded = [], [], False
+        # the activation staging buffers of this device's streams (csrc/qgemm_prefill.hip: up to 360 MB per stream); decoders
+        # built on this model must have been freed (their graphs hold the addresses)
+        self.ext.release_scratch(self.device)
 
     def weight_bytes(self) -> int:
         """Algorithmic bytes one token streams through the linears.  A sparse-MoE layer streams
@@ -175,6 +178,9 @@ class GreedyGraphDecoder:
         self.limit = min(cache.max_seq_len, cfg.max_seq_len)      # the kernels index pages / sin-cos rows unchecked
         if os.environ.get("EXL2_CHAIN", "1") != "0":
             self._setup_chain()
+        if os.environ.get("EXL2_CHAIN_OVERLAP", "0") != "0" and (self.chain is None or "flags" not in self.chain):
+            raise RuntimeError("EXL2_CHAIN_OVERLAP=1 asked for the experimental overlapped chain, but this model / cache / batch is "
+                               "not chain-capable (dense layers with shared q|k|v and gate|up permutations, FP16 cache, <= 16 rows)")
 
     def _setup_chain(self):
         """Chained decode (csrc/qgemv_flat.hip): every producer of the residual stream leaves it in its consumer's packed
@@ -275,6 +281,11 @@ class GreedyGraphDecoder:
             except RuntimeError as e:
                 if "not covered" not in str(e):
                     raise
+                if self._overlapped():
+                    # the experimental overlapped mode never falls back silently: a run that asked for it and did not get it
+                    # must not be mistaken for a measurement of it
+                    raise RuntimeError("EXL2_CHAIN_OVERLAP=1: a launch of the step is outside the chained kernels (" + str(e) +
+                                       "); unset EXL2_CHAIN_OVERLAP") from e
                 self.chain = None               # a shape outside the chained kernels: the module-by-module route below
         m, ext, cfg = self.model, self.model.ext, self.model.config
         ext.embed_rows(m.embed_tokens, self.ids, self.x.view(self.b, cfg.hidden_size))

@@ -94,6 +94,21 @@ int exl2_cache_rotate(void* cache, const int* order, long long page_bytes, int n
 /* count_match (ext_cache.cpp:285-302): host; leading positions at which two int64 token rows agree, <= min(max_a, len_b) */
 int exl2_count_match(const long long* a, const long long* b, int max_a, int len_b, int* match);
 
+/* ---- copies between the devices of a single-process tensor-parallel split (csrc/peer.hip) --------------------------------
+   The reference's tp_gather / tp_broadcast (ext_tp.cpp:129-287) bounce every exchange through a pinned host buffer; here the
+   device targets are written directly over xGMI (exllamav2_amd/ext_tp.py).
+   exl2_memcpy_2d_async: `height` rows of `width_bytes`, row r from src + r * spitch to dst + r * dpitch, on `stream`; either
+   side may be pinned host memory, memory of the current device or of a peer device.
+   exl2_enable_peer_access: peer access between every ordered pair of `devices`; returns the number of ordered pairs without
+   a direct path (their copies are staged by the runtime), < 0 on error. */
+/* Frees the activation staging buffers the prefill / batched-decode launches keep per (device, stream) on the CURRENT device:
+   those of `stream`, or of all streams (all_streams != 0).  Only when no captured graph that used them will be replayed
+   again.  Returns the bytes released (retired buffers of grown slots are freed too). */
+long long exl2_release_scratch(void* stream, int all_streams);
+int exl2_memcpy_2d_async(void* dst, long long dpitch, const void* src, long long spitch, long long width_bytes,
+                         long long height, void* stream);
+int exl2_enable_peer_access(const int* devices, int n);
+
 /* ---- load path ------------------------------------------------------------------------------- */
 
 /* stloader_read (ext_stloader.cpp:11-157; called by stloader.py:160 for every tensor of a checkpoint): `size` bytes at

@@ -98,9 +98,22 @@ def test_broadcast_gather_all_reduce(be, tp):
     outs = [torch.zeros((rows, HID), dtype=torch.float16, device=be.device) for _ in tp["rs"]]
     TP.tp_gather(tp["h"], 0, parts, TP.BROADCAST_RS, outs, TP.BROADCAST_RS, 1, -1)
     _sync(be)
-    assert np.array_equal(pin0.numpy(), x)
     for o in outs:
         assert np.array_equal(be.n(o), x)
+    # gather to the host only (ctx.gather of the reference, tensor_p.py:298-322: the result is read from pinned_temp[buffer]);
+    # more than one row: the slices' rows are not contiguous in the gathered matrix
+    pin1 = tp["pinned"][1][:rows * HID].view(rows, HID)
+    pin1.zero_()
+    parts3 = [be.t(np.ascontiguousarray((x * 3).astype(F16)[:, a:b])) for _, a, b in tp["rs"]]
+    TP.tp_gather(tp["h"], 1, parts3, TP.BROADCAST_RS, [], -1, 1, -1)
+    _sync(be)
+    assert np.array_equal(pin1.numpy(), (x * 3).astype(F16))
+    # a host source that is NOT the staging buffer (copied into it first, behind the uploads still reading it)
+    y = rng.standard_normal((rows, HID)).astype(F16)
+    TP.tp_broadcast(tp["h"], 0, torch.from_numpy(y), TP.BROADCAST_RS, targets, 1, -1)
+    _sync(be)
+    for t in targets:
+        assert np.array_equal(be.n(t), y)
     # all-reduce through the host buffer: every residual ends up as sum_i (residual_0 + tensors_i) chained
     ts = [be.t(rng.standard_normal((rows, HID)).astype(F16)) for _ in tp["rs"]]
     rs = [be.t(np.zeros((rows, HID), dtype=F16)) for _ in tp["rs"]]
@@ -204,3 +217,67 @@ def test_tp_attn_forward_prefill_then_decode(be, tp):
         past += q_len
     for h in q_h + k_h + v_h + o_h:
         be.ext.free_q_matrix(h)
+
+
+def test_copy_2d_async_strided(be):
+    """csrc/peer.hip exl2_memcpy_2d_async: rows of a narrow matrix into a column range of a wider one and back (device <->
+    device, device <-> pinned host)"""
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((7, 24)).astype(F16)
+    wide = torch.zeros((7, 64), dtype=torch.float16, device=be.device)
+    stream = None if be.is_emu else torch.cuda.current_stream().cuda_stream
+    be.ext.copy_2d_async(wide[:, 16:40], be.t(a), stream)
+    host = torch.zeros((7, 64), dtype=torch.float16, pin_memory=not be.is_emu)
+    be.ext.copy_2d_async(host[:, 8:32], wide[:, 16:40], stream)
+    back = torch.zeros((7, 24), dtype=torch.float16, device=be.device)
+    _sync(be)
+    be.ext.copy_2d_async(back, host[:, 8:32], stream)
+    _sync(be)
+    w = be.n(wide)
+    assert np.array_equal(w[:, 16:40], a) and not w[:, :16].any() and not w[:, 40:].any()
+    assert np.array_equal(host.numpy()[:, 8:32], a) and np.array_equal(be.n(back), a)
+    with pytest.raises(RuntimeError):
+        be.ext.copy_2d_async(back, host[:, 8:30], stream)
+
+
+@pytest.mark.gpu
+def test_two_device_broadcast_gather_over_peer_copies():
+    """The two-device form of tp_broadcast / tp_gather on real hardware: slices on cuda:0 and cuda:1, device targets written
+    by peer copies on the targets' streams, host target by strided copies into the pinned buffer.  Needs two visible GPUs
+    (the build's GPU box has one; the emulator covers the two-way split's indexing)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from exllamav2_amd.ext import ext_c
+    TP._Lib.bound = None
+    devs = [torch.device("cuda", 0), torch.device("cuda", 1)]
+    rs = [(0, 0, 128), (1, 128, 256)]
+    kv, q = [(0, 0, 1), (1, 1, 2)], [(0, 0, 2), (1, 2, 4)]
+    idc = [(0, 0, 256), (1, 256, 512)]
+    pinned = [torch.empty((MAXROWS * INTER,), dtype=torch.float16, pin_memory=True) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=d) for d in devs]
+    h = TP.make_tp_context(kv, idc, rs, rs, q, pinned, [s.cuda_stream for s in streams])
+    try:
+        rng = np.random.default_rng(9)
+        rows = 5
+        x = rng.standard_normal((rows, HID)).astype(F16)
+        src = torch.from_numpy(x).to(devs[1])
+        for s in streams:
+            s.synchronize()
+        targets = [torch.zeros((rows, HID), dtype=torch.float16, device=d) for d in devs]
+        TP.tp_broadcast(h, 0, src, TP.BROADCAST_RS, targets, 1, -1)                  # device source on cuda:1
+        torch.cuda.synchronize(0); torch.cuda.synchronize(1)
+        for t in targets:
+            assert np.array_equal(t.cpu().numpy(), x)
+        assert np.array_equal(pinned[0][:rows * HID].view(rows, HID).numpy(), x)
+        parts = [torch.from_numpy(np.ascontiguousarray(x[:, a:b])).to(devs[d]) for d, a, b in rs]
+        outs = [torch.zeros((rows, HID), dtype=torch.float16, device=d) for d in devs]
+        TP.tp_gather(h, 1, parts, TP.BROADCAST_RS, outs, TP.BROADCAST_RS, 1, -1)     # all-gather over peer copies
+        torch.cuda.synchronize(0); torch.cuda.synchronize(1)
+        for o in outs:
+            assert np.array_equal(o.cpu().numpy(), x)
+        pinned[1].zero_()
+        TP.tp_gather(h, 1, parts, TP.BROADCAST_RS, [], -1, 1, -1)                    # gather to the host
+        torch.cuda.synchronize(0); torch.cuda.synchronize(1)
+        assert np.array_equal(pinned[1][:rows * HID].view(rows, HID).numpy(), x)
+    finally:
+        TP.free_tp_context(h)
