@@ -122,11 +122,32 @@ class ExLlamaV2Attention:
                 cache.store_kv_state(self.layer_idx, b, past_len, q_len)
         return attn_out
 
+    def q4_chain_capable(self, cache) -> bool:
+        """the chained step can attend straight from this Q4 cache's codes (the conditions of _attend's q4_direct at q_len 1)"""
+        cfg = self.model.config
+        return (getattr(cache, "wbits", 0) == 4 and hasattr(cache, "q4_views") and self.q4_fused
+                and cfg.num_attention_heads // cfg.num_key_value_heads <= 64 and cfg.head_dim in (64, 128, 256)
+                and (cfg.num_key_value_heads * cfg.head_dim) % 512 == 0)
+
     def attend_chain(self, q, k, v, cache, cache_seqlens, block_table, out_invperm):
-        """Decode attention of the chained step (model.GreedyGraphDecoder): the one-launch kernel, output written in o_proj's
-        packed order.  Paged FP16 cache only; raises when the shape needs another path (the decoder then un-chains)."""
+        """Decode attention of the chained step (model.GreedyGraphDecoder), output written in o_proj's packed order.  Paged
+        FP16 cache: the one-launch kernel.  Paged Q4 cache: RoPE + staging of the new rows, their quantisation into the cache,
+        attention straight from the codes (csrc/attn_q4.hip) -- the three launches of _attend's q4_direct route.  Raises when
+        the shape needs another path (the decoder then un-chains)."""
         cfg, m, ext = self.model.config, self.model, self.ext
         b, q_len = q.shape[0], q.shape[1]
+        if getattr(cache, "wbits", 0):
+            if not self.q4_chain_capable(cache):
+                raise RuntimeError("attend_chain: shape not covered by the Q4 attention kernel")
+            attn_out = m.temp_attn[:b * q_len].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
+            kc, vc = cache.paged_view(self.layer_idx)
+            ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, 0, cache_seqlens, block_table, cfg.rope_style)
+            cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
+            kq, ks, vq, vs = cache.q4_views(self.layer_idx, True)
+            if not ext.paged_attn_q4(q, kq, ks, vq, vs, attn_out, cache_seqlens, block_table, len_const=0, len_offset=q_len,
+                                     scratch=m.attn_scratch, k_new=k, v_new=v, out_invperm=out_invperm):
+                raise RuntimeError("attend_chain: shape not covered by the Q4 attention kernel")
+            return attn_out
         kc, vc = cache.paged_view(self.layer_idx)
         attn_out = m.temp_attn[:b * q_len].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
         if not ext.attn_decode_fused(q, k, v, kc, vc, attn_out, m.sin, m.cos, cache_seqlens, block_table, 0, cfg.rope_style,

@@ -29,11 +29,21 @@ struct AttnQ4Args
     const f16* k_new; const f16* v_new;          // nullable: [b, s, KVH, hd] fp16 (k rotated): keys >= total - s come from here
     const int* cache_seqlens; const int* block_table;
     f16* out; float* part_o; float* part_ml;
+    const u16* out_invperm;       // nullable: feature n of a token row is stored at out[row, out_invperm[n]] (the consumer's packed order)
     int b, s, H, KVH;
     int page_size, page_shift, pages_per_seq;
     int len_const, len_offset, nsplit, causal;
     float scale;
 };
+
+// where feature d of query row qrow = (token row) * H + head goes (exl2_attn_decode_fused's convention)
+DEV size_t q4_out_index(const AttnQ4Args& a, size_t qrow, int hd, int d)
+{
+    if (!a.out_invperm) return qrow * hd + d;
+    const size_t tok = qrow / a.H;
+    const int head = (int)(qrow - tok * a.H);
+    return tok * ((size_t)a.H * hd) + a.out_invperm[head * hd + d];
+}
 
 DEV int q4_eff_splits(int total, int nsplit)
 {
@@ -377,7 +387,7 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
         const size_t qrow = ((size_t)b * a.s + j) * a.H + kh * G + g;
         if (eff == 1)
         {
-            a.out[qrow * HDIM + e] = (f16)(L > 0.0f ? acc / L : 0.0f);
+            a.out[q4_out_index(a, qrow, HDIM, e)] = (f16)(L > 0.0f ? acc / L : 0.0f);
         }
         else
         {
@@ -409,7 +419,7 @@ KERNEL void __launch_bounds__(256) attn_q4_combine_kernel(const AttnQ4Args a, in
             L += a.part_ml[(qrow * a.nsplit + s2) * 2 + 1] * w;
             O += a.part_o[(qrow * a.nsplit + s2) * hd + d] * w;
         }
-        a.out[qrow * hd + d] = (f16)(L > 0.0f ? O / L : 0.0f);
+        a.out[q4_out_index(a, qrow, hd, d)] = (f16)(L > 0.0f ? O / L : 0.0f);
     }
 }
 
@@ -447,7 +457,8 @@ int exl2_paged_attn_q4(const void* q, const void* k_codes, const void* k_scales,
                        const void* k_new, const void* v_new, void* out, const int* cache_seqlens, const int* block_table,
                        int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
                        int page_size, int pages_per_seq, int len_const, int len_offset,
-                       float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes, void* stream)
+                       float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
+                       const void* out_invperm, void* stream)
 {
     EXL2_REQUIRE(q && k_codes && k_scales && v_codes && v_scales && out, "paged_attn_q4: null argument");
     EXL2_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged_attn_q4: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
@@ -461,7 +472,7 @@ int exl2_paged_attn_q4(const void* q, const void* k_codes, const void* k_scales,
     a.q = (const f16*)q; a.k_codes = (const u8*)k_codes; a.k_scales = (const f16*)k_scales;
     a.v_codes = (const u8*)v_codes; a.v_scales = (const f16*)v_scales; a.out = (f16*)out;
     EXL2_REQUIRE((k_new == nullptr) == (v_new == nullptr), "paged_attn_q4: k_new and v_new go together");
-    a.k_new = (const f16*)k_new; a.v_new = (const f16*)v_new;
+    a.k_new = (const f16*)k_new; a.v_new = (const f16*)v_new; a.out_invperm = (const u16*)out_invperm;
     a.cache_seqlens = cache_seqlens; a.block_table = block_table;
     a.b = batch; a.s = q_len; a.H = num_heads; a.KVH = num_kv_heads;
     a.page_size = page_size; a.pages_per_seq = pages_per_seq; a.page_shift = ilog2_exact_q4(page_size);

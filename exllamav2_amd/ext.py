@@ -382,9 +382,10 @@ class ExtC:
 
     def paged_attn_q4(self, q, k_codes, k_scales, v_codes, v_scales, out, cache_seqlens, block_table, len_const: int = 0,
                       len_offset: int = 0, softmax_scale: float | None = None, causal: bool = True, nsplit: int = 0,
-                      scratch=None, k_new=None, v_new=None) -> bool:
+                      scratch=None, k_new=None, v_new=None, out_invperm: int | None = None) -> bool:
         """Attention over Q4 codes + scales ([b | pages, T | page_size, KVH, hd/2] uint8, [.., KVH, hd/32] fp16) without
-        unpacking them; False when the shape needs the unpack route."""
+        unpacking them; False when the shape needs the unpack route.  out_invperm (device pointer, u16 [H * hd]): output in
+        o_proj's packed order (chained decode)."""
         b, s, nh, hd = q.shape
         kvh = k_codes.shape[2]
         page_size = k_codes.shape[1]
@@ -398,7 +399,7 @@ class ExtC:
             self._ptr(v_new, torch.float16, "v_new"), self._ptr(out, torch.float16, "out"),
             self._ptr(cache_seqlens, torch.int32, "cache_seqlens"), self._ptr(block_table, torch.int32, "block_table"),
             b, s, nh, kvh, hd, page_size, pps, int(len_const), int(len_offset), float(scale), int(causal), int(nsplit),
-            self._ptr(scratch), sb, self._stream(q)))
+            self._ptr(scratch), sb, out_invperm or None, self._stream(q)))
         return rc == 0
 
     def rope_kv_append(self, q, k_new, v_new, k_cache, v_cache, sin, cos, past_len: int, past_lens, block_table,

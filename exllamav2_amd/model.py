@@ -185,9 +185,11 @@ class GreedyGraphDecoder:
     def _setup_chain(self):
         """Chained decode (csrc/qgemv_flat.hip): every producer of the residual stream leaves it in its consumer's packed
         (act-order) order + partial sums of squares.  Needs: dense layers whose q/k/v and gate/up share a permutation (every
-        quantizer-written checkpoint), an FP16 paged-view cache, a head on this device, <= 16 rows."""
+        quantizer-written checkpoint), an FP16 or Q4 paged-view cache, a head on this device, <= 16 rows."""
         m, ext, cfg = self.model, self.model.ext, self.model.config
-        if self.b > 16 or m.lm_head is None or m.embed_tokens is None or getattr(self.cache, "wbits", 0):
+        if self.b > 16 or m.lm_head is None or m.embed_tokens is None:
+            return
+        if getattr(self.cache, "wbits", 0) and not all(attn.q4_chain_capable(self.cache) for attn, _ in m.layers):
             return
         plan = []
         for attn, mlp in m.layers:

@@ -165,7 +165,9 @@ int exl2_paged_attn_q4(const void* q, const void* k_codes, const void* k_scales,
                        const void* k_new, const void* v_new, void* out, const int* cache_seqlens, const int* block_table,
                        int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
                        int page_size, int pages_per_seq, int len_const, int len_offset,
-                       float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes, void* stream);
+                       float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
+                       const void* out_invperm, void* stream);
+/* (out_invperm: nullable, as in exl2_attn_decode_fused -- the chained decode step over a Q4 cache) */
 
 /* ---- fused modules --------------------------------------------------------------------------------------------------- */
 

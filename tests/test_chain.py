@@ -144,13 +144,39 @@ def test_overlapped_chain_equals_serial_chain(be, monkeypatch, recipe, batch):
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
-def test_q4_cache_stays_unchained(be):
-    cfg = tiny_cfg()
-    ck = synth_checkpoint(cfg, be.device, seed=16)
-    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
-    dec = GreedyGraphDecoder(model, ExLlamaV2Cache_Q4(model, batch_size=1), batch_size=1)
-    assert dec.chain is None
-    dec.free(); model.unload()
+@pytest.mark.parametrize("recipe,batch", [("4.0bpw", 1), ("2.5bpw", 2)])
+def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch):
+    """Q4 KV cache (configs[3]) on the chained route: q|k|v from the chain, RoPE + quantised append, attention straight from
+    the codes with the output in o_proj's packed order (attn_q4.hip out_invperm), o / gate|up / down chained.  Checker: the
+    module-by-module route over the same cache codec (tests/test_model.py checks THAT route against the reference's
+    unpack-everything route and the FP16 oracle): the codes written must be identical, the logits equal up to the fp32
+    summation order of the chained kernels, the tokens equal."""
+    cfg = tiny_cfg(num_attention_heads=8, num_key_value_heads=8, head_dim=64, hidden_size=512, intermediate_size=512,
+                   num_hidden_layers=2)
+    outs = []
+    for chain in ("1", "0"):
+        monkeypatch.setenv("EXL2_CHAIN", chain)
+        ck = synth_checkpoint(cfg, be.device, recipe=recipe, seed=16)
+        model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+        cache = ExLlamaV2Cache_Q4(model, batch_size=batch)
+        dec = GreedyGraphDecoder(model, cache, batch_size=batch)
+        assert (dec.chain is not None) == (chain == "1")
+        be.ext.chain_route_counts(reset=True)
+        if not be.is_emu:
+            dec.capture()
+        dec.reset(torch.tensor([3, 50][:batch]), 0)
+        dec.run(4, use_graph=not be.is_emu)
+        outs.append((be.n(dec.tokens(0, 4)).copy(), be.n(dec.logits).astype(np.float64).copy(),
+                     [be.n(t[:, :4]).copy() for t in cache.key_states], sum(be.ext.chain_route_counts())))
+        assert (dec.chain is not None) == (chain == "1")
+        dec.free(); model.unload()
+    assert outs[0][3] > 0 and outs[1][3] == 0                    # chained launches ran / did not run
+    # (both routes within the fp16 tolerance of the model tests of each other; a flipped cache nibble moves a logit by more
+    # than the summation order alone does)
+    assert np.all(np.abs(outs[0][1] - outs[1][1]) <= 2 * (0.03 + np.abs(outs[1][1]) * 2.0 ** -8)), np.abs(outs[0][1] - outs[1][1]).max()
+    assert (outs[0][0] == outs[1][0]).mean() >= 0.75
+    same = [np.mean(a == b) for a, b in zip(outs[0][2], outs[1][2])]
+    assert min(same) > 0.99, same                                # (codes: a rounding tie may flip one nibble in a block)
 
 
 # ---- op level: the chain entry points one by one ------------------------------------------------------------------------
