@@ -702,9 +702,12 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     if (!in.pair && nslots == 1 && S == 8) cand[n_cand++] = 16;        // finer split of the tile
     u32 slot_bytes = 0;
     bool planned = false;
-    for (int ci = 0; ci < n_cand && !planned; ci++)
+    // (second round: a split that fits only with the whole LDS of a CU -- 2-4 rows of a K = 11008 matrix -- is still better
+    // than leaving the chain: the decoder would fall back to the module-by-module route for EVERY launch)
+    for (int ci = 0; ci < 2 * n_cand && !planned; ci++)
     {
-        S = cand[ci];
+        S = cand[ci % n_cand];
+        const u32 budget = ci < n_cand ? LEAN_LDS_BUDGET * (u32)((S * nslots + 7) / 8) : 150u * 1024u;
         if (in.n_mats * S > LEAN_RECORDS) continue;
         bool ok = true;
         slot_bytes = 0;
@@ -714,7 +717,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
             if (!b) ok = false;
             if (b > slot_bytes) slot_bytes = b;
         }
-        planned = ok && (u32)nslots * slot_bytes + (u32)(S * nslots) * (u32)in.M * 64u <= LEAN_LDS_BUDGET * (u32)((S * nslots + 7) / 8);
+        planned = ok && (u32)nslots * slot_bytes + (u32)(S * nslots) * (u32)in.M * 64u <= budget;
     }
     if (!planned) return 1;
     const int wgs = in.pair ? max_tiles : (max_tiles + nslots - 1) / nslots;
