@@ -47,8 +47,10 @@
 #define LEAN_LOWBITS 1                // 0: no 2 / 3-bit register stream (code-size experiment; such segments would be wrong)
 #endif
 #define LEAN_MAX_WAVES 16
-#define LEAN_RECORDS 32               // wave records in the argument block: matrices x waves per tile
-#define LEAN_MAX_PART 256             // partial sums of squares per row a chain-out launch may publish (consumer side: 4 per lane)
+#define LEAN_RECORDS 48               // wave records in the argument block: matrices x waves per tile (q|k|v at 16 waves)
+#define LEAN_MAX_PASSES 4             // 16-wave geometry: a wave's share may be this many register loads (qgemv_lean_kernel, further passes)
+#define LEAN_MAX_PART 512             // partial sums of squares per row a chain-out launch may publish (hidden 8192 = 512 tiles; the
+                                      // host's ss buffers are [rows, 512]; the round-2 kernel reads at most 256 and declines more)
 #define LEAN_LDS_BUDGET (40u * 1024u)  // per 8 waves: four 8-wave / two 16-wave workgroups stay resident on a CU
 
 // What one wave of a workgroup does for its tile: ONE run of full items of one bit width (requested into registers, <= LeanDepth
@@ -101,12 +103,13 @@ struct LeanArgs
 // (S = 4: the 8-wave gate|up workgroup, built for 6 waves per SIMD = 80 registers -- a wave there holds 8 items of <= 4 bits)
 template <int BITS, int S> struct LeanDepth
 {
-    static constexpr int v = S == 4 ? (BITS == 8 ? 4 : BITS == 6 ? 5 : BITS == 5 ? 6 : 8)
-                                    : (BITS == 8 ? 3 : BITS == 6 ? 4 : BITS == 5 ? 5 : BITS == 4 ? 6 : 8);
+    static constexpr int v = S == 4 ? (BITS == 8 ? 4 : BITS == 6 ? 5 : BITS == 5 ? 6 : BITS == 2 ? 10 : 8)
+                                    : (BITS == 8 ? 3 : BITS == 6 ? 4 : BITS == 5 ? 5 : BITS == 4 ? 6 : BITS == 2 ? 10 : 8);
 };
 static int lean_depth(int bits, int S)
 {
-    return S == 4 ? (bits == 8 ? 4 : bits == 6 ? 5 : bits == 5 ? 6 : 8) : (bits == 8 ? 3 : bits == 6 ? 4 : bits == 5 ? 5 : bits == 4 ? 6 : 8);
+    return S == 4 ? (bits == 8 ? 4 : bits == 6 ? 5 : bits == 5 ? 6 : bits == 2 ? 10 : 8)
+                  : (bits == 8 ? 3 : bits == 6 ? 4 : bits == 5 ? 5 : bits == 4 ? 6 : bits == 2 ? 10 : 8);
 }
 
 struct LeanCtx
@@ -388,6 +391,32 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
             for (int q = 0; q < D; q++)
                 if (q < n) { lean_item_general<BITS, GPTQ>(b[q], R.cx, R.chunk0 + 4 * q, 4 * q, R.g0, R.gshift, R.gphase, 4, lane, acc); sched_fence(); }
         }
+        // more items than the wave's registers hold (K = 28672 split over 16 waves: 14-15 items of 3 bits): further passes of D
+        // items, each its own round trip -- only the 16-wave geometry, the last one the host tries, plans such shares
+        if constexpr (S == 16)
+        {
+            if (!(LEAN_KILL & 9))
+            {
+                #pragma nounroll
+                for (int q0 = D; q0 < n; q0 += D)
+                {
+                    #pragma unroll
+                    for (int q = 0; q < D; q++) if (q0 + q < n) load_lane_words<BITS>(wptr + (size_t)(q0 + q) * STEP, lane, b[q]);
+                    if (R.uni)
+                    {
+                        #pragma unroll
+                        for (int q = 0; q < D; q++)
+                            if (q0 + q < n) { lean_item_uniform<BITS, GPTQ>(b[q], R.cx, R.chunk0 + 4 * (q0 + q), R.g0 + ((4 * (q0 + q) + R.gphase) >> R.gshift), lane, acc); sched_fence(); }
+                    }
+                    else
+                    {
+                        #pragma unroll
+                        for (int q = 0; q < D; q++)
+                            if (q0 + q < n) { lean_item_general<BITS, GPTQ>(b[q], R.cx, R.chunk0 + 4 * (q0 + q), 4 * (q0 + q), R.g0, R.gshift, R.gphase, 4, lane, acc); sched_fence(); }
+                    }
+                }
+            }
+        }
         if (tail_nv) lean_item_general<BITS, GPTQ>(bt, R.cx, R.chunk0 + 4 * n, 4 * n, R.g0, R.gshift, R.gphase, tail_nv, lane, acc);
     };
     if (n == 0 && tail_nv == 0)
@@ -600,7 +629,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
             const int n = (r.F - i0 + (nw[i] - k) - 1) / (nw[i] - k);        // even split, larger parts first
             const bool last = k == nw[i] - 1;
             const int tail_nv = last ? r.tail_nv : 0;
-            if (n > lean_depth(r.bits, S) || n > 255) return 0;
+            if (n > lean_depth(r.bits, S) * (S == 16 ? LEAN_MAX_PASSES : 1) || n > 255) return 0;
             LeanWave& lw = wave[w];
             lw.lds_off = lds_total;
             const int c0 = r.chunk0 + 4 * i0;

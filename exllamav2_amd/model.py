@@ -208,8 +208,8 @@ class GreedyGraphDecoder:
             "plan": plan, "head_inv": head_inv, "norm_head": norm_head,
             "xp_a": torch.zeros((self.b, cfg.hidden_size), dtype=torch.float16, device=dev),
             "xp_b": torch.zeros((self.b, cfg.hidden_size), dtype=torch.float16, device=dev),
-            "ss_a": torch.zeros((self.b, 256), dtype=torch.float32, device=dev),
-            "ss_b": torch.zeros((self.b, 256), dtype=torch.float32, device=dev),
+            "ss_a": torch.zeros((self.b, 512), dtype=torch.float32, device=dev),
+            "ss_b": torch.zeros((self.b, 512), dtype=torch.float32, device=dev),
         }
         # overlapped chain (csrc/chain_sync.h, EXPERIMENTAL): launches alternate between the decoder's stream and a second
         # one, each waits for its predecessor through words in memory.  5 launches per layer + the head (+ the gate's block).

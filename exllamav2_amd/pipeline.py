@@ -86,7 +86,7 @@ class PipelineStage:
         dev, h = self.device, cfg.hidden_size
         ch = {"plan": plan,
               "xp_a": torch.zeros((1, h), dtype=torch.float16, device=dev), "xp_b": torch.zeros((1, h), dtype=torch.float16, device=dev),
-              "ss_a": torch.zeros((1, 256), dtype=torch.float32, device=dev), "ss_b": torch.zeros((1, 256), dtype=torch.float32, device=dev),
+              "ss_a": torch.zeros((1, 512), dtype=torch.float32, device=dev), "ss_b": torch.zeros((1, 512), dtype=torch.float32, device=dev),
               "id0": torch.zeros((1,), dtype=torch.int32, device=dev)}
         if self.last:
             if m.lm_head is None:

@@ -223,7 +223,8 @@ int exl2_q_matrix_perm_info(void* q_matrix, const void** perm, const void** invp
 int exl2_q_attn_forward_1_chain(void* handle, const void* xp, const float* ss, int npart, int rows,
                                 void* temp_q, void* temp_k, void* temp_v, void* stream);
 /* x += attn_out . Wo with attn_out already in o_proj's packed order (exl2_attn_decode_fused out_invperm); publishes
-   (xp_out, ss_out) for the next consumer through next_invperm (nullable = identity); *npart_out = partials per row */
+   (xp_out, ss_out) for the next consumer through next_invperm (nullable = identity); *npart_out = partials per row
+   (ss_out: room for 512 floats per row) */
 int exl2_q_attn_forward_2_chain(void* handle, void* x, const void* attn_out_packed, int rows, const void* next_invperm,
                                 const void* next_norm_w, void* xp_out, float* ss_out, int* npart_out, void* stream);
 /* x += (act(n Wg) * (n Wu)) Wd, n from (xp, ss); publishes (xp_out, ss_out) for the next consumer */
