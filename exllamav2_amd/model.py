@@ -211,6 +211,11 @@ class GreedyGraphDecoder:
             "ss_a": torch.zeros((self.b, 512), dtype=torch.float32, device=dev),
             "ss_b": torch.zeros((self.b, 512), dtype=torch.float32, device=dev),
         }
+        # 7-8 sequences: two groups of 4 rows on the round-3 kernel beat the round-2 kernels (2622 vs 2073 tok/s at 8); at 5-6
+        # and from 9 up they do not (profiles/r03_rowgroups.txt) -- every group streams the weights again
+        rg = os.environ.get("EXL2_CHAIN_ROWGROUPS", "auto")
+        if (rg == "auto" and self.b in (7, 8)) or (rg not in ("auto", "0") and self.b > 4):
+            self.chain["group_rows"] = 4
         # overlapped chain (csrc/chain_sync.h, EXPERIMENTAL): launches alternate between the decoder's stream and a second
         # one, each waits for its predecessor through words in memory.  5 launches per layer + the head (+ the gate's block).
         if os.environ.get("EXL2_CHAIN_OVERLAP", "0") != "0":
@@ -228,8 +233,15 @@ class GreedyGraphDecoder:
         k = m.temp_k[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
         v = m.temp_v[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
         xp_a, xp_b, ss_a, ss_b = ch["xp_a"], ch["xp_b"], ch["ss_a"], ch["ss_b"]
-        ext.embed_rows_chain(m.embed_tokens, self.ids, x2, plan[0][0], plan[0][3], xp_a, ss_a)
         overlap = "flags" in ch
+        # Row groups: the round-3 kernel (csrc/qgemv_lean.hip) takes <= 4 rows per launch; 5..16 sequences run every q_gemm
+        # launch once per group of 4 rows (the second and later groups find the weights in the memory-side cache) instead of
+        # leaving it for the round-2 kernels (measured at 8 rows: tools/gpu_r3_batch.sh).  A group's (xp, ss) live in its own
+        # rows of the buffers; attention takes all rows in one launch.
+        g = ch.get("group_rows", b)
+        groups = [(r, min(r + g, b)) for r in range(0, b, g)] if (g < b and not overlap) else [(0, b)]
+        for r0, r1 in groups:
+            ext.embed_rows_chain(m.embed_tokens, self.ids[r0:r1], x2[r0:r1], plan[0][0], plan[0][3], xp_a[r0:r1], ss_a[r0:r1])
         if overlap:
             sa = self.stream.cuda_stream if self.stream is not None else None
             sb = ch["stream_b"].cuda_stream if ch["stream_b"] is not None else None
@@ -238,13 +250,18 @@ class GreedyGraphDecoder:
             npart = 1
             for i, (attn, mlp) in enumerate(m.layers):
                 in_a, o_inv, in_m, nw_a, nw_m = plan[i]
-                ext.q_attn_forward_1_chain(attn.q_handle, xp_a, ss_a, npart, b, q, k, v)
+                for r0, r1 in groups:
+                    ext.q_attn_forward_1_chain(attn.q_handle, xp_a[r0:r1], ss_a[r0:r1], npart, r1 - r0, q[r0:r1], k[r0:r1], v[r0:r1])
                 ao = attn.attend_chain(q, k, v, self.cache, self.cache_seqlens, self.block_table, o_inv)
                 # every producer of the residual stream publishes it times its consumer's norm weight, in that consumer's order
-                npart = ext.q_attn_forward_2_chain(attn.q_handle, x2, ao, b, in_m, nw_m, xp_b, ss_b)
+                for r0, r1 in groups:
+                    np_o = ext.q_attn_forward_2_chain(attn.q_handle, x2[r0:r1], ao[r0:r1], r1 - r0, in_m, nw_m, xp_b[r0:r1], ss_b[r0:r1])
                 nxt, nxt_w = (plan[i + 1][0], plan[i + 1][3]) if i + 1 < len(plan) else (ch["head_inv"], ch["norm_head"])
-                npart = ext.q_mlp_forward_chain(mlp.q_handle, x2, xp_b, ss_b, npart, b, nxt, nxt_w, xp_a, ss_a)
-            ext.gemm_half_q_half_chain(xp_a, ss_a, npart, cfg.norm_eps, m.lm_head.q_handle, self.logits, b)
+                for r0, r1 in groups:
+                    npart = ext.q_mlp_forward_chain(mlp.q_handle, x2[r0:r1], xp_b[r0:r1], ss_b[r0:r1], np_o, r1 - r0, nxt, nxt_w,
+                                                    xp_a[r0:r1], ss_a[r0:r1])
+            for r0, r1 in groups:
+                ext.gemm_half_q_half_chain(xp_a[r0:r1], ss_a[r0:r1], npart, cfg.norm_eps, m.lm_head.q_handle, self.logits[r0:r1], r1 - r0)
         finally:
             n_launches = ext.chain_overlap_end() if overlap else 0
         # greedy sampling + position increment behind the head: on the stream the head went to
