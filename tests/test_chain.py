@@ -68,10 +68,12 @@ def test_chain_decode_wide_k(be, recipe):
     _decode_and_check(be, cfg, recipe, 1, steps=2, seed=5)
 
 
-def test_chain_decode_many_rows(be):
-    """16 sequences: the row loop of the A_NORM_PRE prologue, 16 finalising waves"""
+@pytest.mark.parametrize("batch", [16, 8, 4])
+def test_chain_decode_many_rows(be, batch):
+    """16 sequences: the row loop of the A_NORM_PRE prologue, 16 finalising waves (round-2 kernel); 8: two row groups of 4 on the
+    round-3 kernel (model.step_chain); 4: one launch of the round-3 kernel with four finalising waves"""
     cfg = tiny_cfg(max_batch_size=16)
-    _decode_and_check(be, cfg, "4.0bpw", 16, steps=2, seed=12)
+    _decode_and_check(be, cfg, "4.0bpw", batch, steps=2, seed=12)
 
 
 @pytest.mark.parametrize("recipe,act_order", [("gptq-4bit-128g", False), ("gptq-4bit-32g", True)])
