@@ -285,9 +285,11 @@ def pmc_traffic_gb(launches_per_step, kernel_prefix: str):
         files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
         for f in reversed(files):
             d = json.load(open(os.path.join(ROOT, "profiles", f)))
-            kb = [v["avg"] for k, v in d.items() if k.startswith("FETCH_SIZE:") and kernel_prefix in k]
-            if kb:
-                return round(kb[0] * 1024 * 2 * launches_per_step / 1e9, 3), "committed profile profiles/" + f
+            # every instantiation of the kernel (geometries of one template), weighted by its launches
+            hits = [(v["avg"], v.get("launches", 1)) for k, v in d.items() if k.startswith("FETCH_SIZE:") and kernel_prefix in k]
+            if hits:
+                kb = sum(a * n for a, n in hits) / sum(n for _, n in hits)
+                return round(kb * 1024 * 2 * launches_per_step / 1e9, 3), "committed profile profiles/" + f
     except Exception:
         pass
     return None, None

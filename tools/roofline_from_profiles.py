@@ -5,7 +5,7 @@ summary and the bench line under profiles/.  What the judge does by hand:
     achieved = algorithmic bytes per q_gemm launch / weighted average duration of the q_gemm kernels (rocprofv3 --stats)
     frac     = achieved / 8 TB/s;   traffic ratio = PMC FETCH_SIZE x 2 (gfx950 correction) / algorithmic bytes
 
-Usage: python tools/roofline_from_profiles.py [round prefix, default r02]"""
+Usage: python tools/roofline_from_profiles.py [round prefix, default r03]"""
 import csv
 import json
 import os
@@ -16,7 +16,7 @@ HBM_PEAK = 8.0e12
 
 
 def main():
-    pre = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    pre = sys.argv[1] if len(sys.argv) > 1 else "r03"
     prof = os.path.join(ROOT, "profiles")
     bench = json.loads(open(os.path.join(prof, f"{pre}_bench.json")).read().strip().splitlines()[-1])
     rf = bench["roofline"]
@@ -38,10 +38,14 @@ def main():
     pmc_path = os.path.join(prof, f"{pre}_pmc_summary.json")
     if os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
+        tot, n = 0.0, 0
         for k, v in pmc.items():
             if k.startswith("FETCH_SIZE:") and "qgemv_" in k:
                 traffic = v["avg"] * 1024 * 2
-                print(f"HBM traffic per launch (FETCH_SIZE x 2): {traffic / 1e6:.2f} MB = {traffic / alg:.3f} x algorithmic   [{k[11:60]}..., {v['launches']} launches]")
+                tot += traffic * v["launches"]; n += v["launches"]
+                print(f"HBM traffic per launch (FETCH_SIZE x 2): {traffic / 1e6:.2f} MB   [{k[11:70]}..., {v['launches']} launches]")
+        if n:
+            print(f"launch-weighted                        : {tot / n / 1e6:.2f} MB = {tot / n / alg:.3f} x algorithmic")
     step_us = bench["ms_per_step"] * 1e3
     print(f"step: {step_us:.1f} us; q_gemm launches {rf['launches_per_step']} x {rf['avg_launch_us']} = {rf['launches_per_step'] * rf['avg_launch_us']:.0f} us "
           f"({rf['launches_per_step'] * rf['avg_launch_us'] / step_us:.1%} of the step); whole-step weight roofline fraction {rf['step_frac_of_weight_roofline']}")
