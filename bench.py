@@ -559,6 +559,30 @@ def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq:
             flops += 2.0 * batch * seq * lin.in_features * lin.out_features
     out["native"] = {"value": round(batch * seq / best, 1), "ms": round(best * 1e3, 2), "layers": cfg.num_hidden_layers,
                      "linear_TFLOPs": round(flops / best / 1e12, 1)}
+    # roofline of the dominant prefill kernel (qgemm_mfma_kernel, csrc/qgemm_mfma.hip): the largest linear of a layer alone, the
+    # same 16384-row pass the forward above makes, timed with HIP events on the launch stream; dense fp16 MFMA peak 2.5 PFLOP/s
+    # (MI355X_MICROARCH.md).  MFMA-busy counters of the same kernel: profiles/r02_pmc_prefill_summary.json (35 %).
+    try:
+        lin = model.layers[0][1].gate_proj
+        rows = batch * seq
+        x = (torch.randn((rows, lin.in_features), dtype=torch.float32, device=device) * 0.5).half()
+        y = torch.empty((rows, lin.out_features), dtype=torch.float16, device=device)
+        model.ext.gemm_half_q_half(x, lin.q_handle, y); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            model.ext.gemm_half_q_half(x, lin.q_handle, y)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        fl = 2.0 * rows * lin.in_features * lin.out_features
+        out["roofline"] = {"bound": "mfma", "kernel": "qgemm_mfma_kernel (gate_proj %d x %d at %d rows: row pre-pass + GEMM launches of one call)" % (lin.in_features, lin.out_features, rows),
+                           "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                           "frac": round(fl / (ms * 1e-3) / 2.5e15, 4), "traffic": None, "flops_per_call": fl, "avg_call_us": round(ms * 1e3, 1),
+                           "pmc_source": "profiles/r02_pmc_prefill_summary.json (SQ_VALU_MFMA_BUSY_CYCLES, same kernel)"}
+        del x, y
+    except Exception as e:  # informational
+        out["roofline"] = {"error": str(e)[:200]}
     model.unload(); del model, cache
     torch.cuda.empty_cache()
     return out

@@ -669,8 +669,9 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
 }
 
 #define LEAN_FOR_EACH_GEOMETRY(X, OCC) X(8, 1, false, OCC) X(16, 1, false, OCC) X(8, 2, false, OCC) X(8, 2, true, OCC) X(4, 2, true, OCC)
-// register budgets built side by side (EXL2_LEAN_OCC = 4 / 6 / 8 waves per SIMD; measured on the MI355X): the
-// default is what the A/B runs picked
+// register budget: 6 waves per SIMD (80 registers: no spills on the common paths, three 8-wave workgroups per CU).  4 and 8
+// were built side by side during the round and measured (4 slower; 8 equal within noise once gate|up used 8-wave workgroups,
+// with spills): tools/build_variant.sh -DLEAN_OCC_DEFAULT=... rebuilds them
 #ifndef LEAN_OCC_DEFAULT
 #define LEAN_OCC_DEFAULT 6
 #endif
@@ -681,7 +682,7 @@ static void lean_attrs()
     if (!exl2_first_on_device(attr)) return;
 #define LEAN_ATTR(S, NS, P, OCC) \
     (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, S, NS, P, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    LEAN_FOR_EACH_GEOMETRY(LEAN_ATTR, 4) LEAN_FOR_EACH_GEOMETRY(LEAN_ATTR, 6) LEAN_FOR_EACH_GEOMETRY(LEAN_ATTR, 8)
+    LEAN_FOR_EACH_GEOMETRY(LEAN_ATTR, LEAN_OCC_DEFAULT)
 #undef LEAN_ATTR
 #define LEAN_ATTR(S, NS, P, OCC) \
     (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -784,12 +785,10 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     }
     dim3 grid((unsigned)wgs, (unsigned)(in.pair ? 1 : in.n_mats), 1), block((unsigned)waves * 64, 1, 1);
     const bool gptq = q0->is_gptq;
-    int occ = LEAN_OCC_DEFAULT;
-    if (const char* e = getenv("EXL2_LEAN_OCC")) { const int v = atoi(e); if (v == 4 || v == 6 || v == 8) occ = v; }
-    if (S == 4 && occ > 6) occ = 6;                                    // (8 items in registers per wave)
+    const int occ = LEAN_OCC_DEFAULT;
 #define LEAN_GO(SS, NS, P, OCC) \
     if (!gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a);
-    LEAN_FOR_EACH_GEOMETRY(LEAN_GO, 4) LEAN_FOR_EACH_GEOMETRY(LEAN_GO, 6) LEAN_FOR_EACH_GEOMETRY(LEAN_GO, 8)
+    LEAN_FOR_EACH_GEOMETRY(LEAN_GO, LEAN_OCC_DEFAULT)
 #undef LEAN_GO
 #define LEAN_GO(SS, NS, P, OCC) \
     if (gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC>), grid, block, lds, stream, a);
