@@ -26,7 +26,18 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef MF_KILL
+#define MF_KILL 0                        // timing experiments (results WRONG): 1 no X copies, 2 no weight decode, 4 no multiply
+#endif
+#ifdef MF_NOFENCE
+#define MF_FENCE() do { } while (0)
+#else
+#define MF_FENCE() sched_fence()
+#endif
 #define MF_BN 256
+#ifndef MF_WPRE_MIN_ROWS
+#define MF_WPRE_MIN_ROWS 2048            // rows from which the weights are decoded once per call (wfrag_kernel) instead of per workgroup
+#endif
 #define MF_THREADS 512
 #define MF_W_STAGE 32768                        // 16 tiles x 2 chunks x 64 lanes x 16 bytes
 #define MF_X_STAGE(MT) ((MT) * 32 * 128)        // rows x 64 halves
@@ -70,6 +81,7 @@ DEV void load_raw(TileRaw& R, const QMatDev& m, const u32* sc_ptr, u32 tile_stri
 template <int BITS, bool GPTQ, int H>
 DEV void decode_half(const TileRaw& R, u8* w_stage, int wv, int lane)
 {
+    if (MF_KILL & 2) { if (lane == 99) *(u32*)(w_stage + wv * 64) = R.w[0][0] ^ R.w[1][0]; return; }
     #pragma unroll
     for (int t = 0; t < 2; t++)
     {
@@ -96,7 +108,7 @@ DEV void decode_half(const TileRaw& R, u8* w_stage, int wv, int lane)
             const f16x8 b = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
             *(f16x8*)(w_stage + ((size_t)(((2 * wv + t) * 2 + qq) * 64 + lane)) * 16) = b;
         }
-        sched_fence();          // one tile's decode temporaries at a time (register budget: the accumulators stay live)
+        MF_FENCE();             // one tile's decode temporaries at a time (register budget: the accumulators stay live)
     }
 }
 
@@ -136,6 +148,7 @@ template <int MT>
 DEV void multiply_stage(const u8* x_stage, const u8* w_stage, int nv, int wm, int wn, int lane, f32x4 (&acc)[MT][4])
 {
     const int i16 = lane & 15, j4 = lane >> 4, sw = (lane >> 1) & 7;
+    if (MF_KILL & 4) return;
     #pragma unroll
     for (int kq = 0; kq < 2; kq++)
     {
@@ -154,7 +167,7 @@ DEV void multiply_stage(const u8* x_stage, const u8* w_stage, int nv, int wm, in
                 for (int nt = 0; nt < 4; nt++) acc[mt][nt] = mfma_16x16x32_f16(wf[nt], xf, acc[mt][nt]);
             }
         }
-        sched_fence();          // fragments of one chunk at a time
+        MF_FENCE();             // fragments of one chunk at a time
     }
 }
 
@@ -176,6 +189,7 @@ template <int MT>
 DEV void issue_x(const MfCtx& x, int k0, int nv, u8* stage)
 {
     constexpr int PIECES = MT / 2;
+    if (MF_KILL & 1) return;
     #pragma unroll
     for (int i = 0; i < PIECES; i++)
     {
@@ -225,7 +239,97 @@ DEV void run_section(const MfCtx& x, int bits, const u32* base, u32 tile_stride,
     }
 }
 
-template <bool GPTQ, int MT>
+// ---- many rows: weights decoded ONCE per call (wfrag_kernel below) instead of once per workgroup ------------------------------
+// With 16384 rows a column block's weights are decoded by 64 workgroups, and the decode is what a K step waits for: the kernel
+// with the decode compiled out runs 31 % faster, with the multiply compiled out it still takes half the time
+// (profiles/r03_prefill_kill.txt).  The pre-pass writes every K step's W stage image (32 KB: [16 tiles][2 chunks][64 lanes][16 B])
+// to a scratch buffer; the GEMM then fills its W stages by LDS-DMA like its X stages -- no decode, no packed words, no
+// scale tables in the K loop.
+
+// this wave's eighth of one K step's decoded weights -> stage
+DEV void issue_w(const u8* slot, u8* stage, int wv, int lane)
+{
+    #pragma unroll
+    for (int i = 0; i < 4; i++) dma_to_lds16(slot + (size_t)((wv * 4 + i) * 64 + lane) * 16, stage + (size_t)(wv * 4 + i) * 1024);
+}
+
+template <int MT>
+DEV void run_section_pre(const MfCtx& x, const u8* slots, int F, int k_base, int nvl, f32x4 (&acc)[MT][4])
+{
+    issue_x<MT>(x, k_base, F == 1 ? min(2, nvl) : 2, x.x_st[0]);
+    issue_w(slots, x.w_st[0], x.wv, x.lane);
+    for (int s = 0; s < F; s++)
+    {
+        const int k0 = k_base + s * SUPER_ROWS;
+        const int nvalid = (s == F - 1) ? nvl : 4;
+        const int nv0 = min(2, nvalid), nv1 = nvalid - nv0;
+        const bool more = s + 1 < F;
+        const int nvalid_next = (s + 1 == F - 1) ? nvl : 4;
+        const u8* const sl = slots + (size_t)(2 * s) * MF_W_STAGE;
+        // K step 0: multiply stage 0; stage 1 <- the second half of this super-chunk
+        wait_vmcnt_le<0>();
+        block_sync();
+        issue_x<MT>(x, k0 + 64, nv1, x.x_st[1]);
+        issue_w(sl + MF_W_STAGE, x.w_st[1], x.wv, x.lane);
+        multiply_stage<MT>(x.x_st[0], x.w_st[0], nv0, x.wm, x.wn, x.lane, acc);
+        // K step 1: multiply stage 1; stage 0 <- the first half of the next super-chunk
+        wait_vmcnt_le<0>();
+        block_sync();
+        if (more)
+        {
+            issue_x<MT>(x, k0 + SUPER_ROWS, min(2, nvalid_next), x.x_st[0]);
+            issue_w(sl + 2 * MF_W_STAGE, x.w_st[0], x.wv, x.lane);
+        }
+        multiply_stage<MT>(x.x_st[1], x.w_st[1], nv1, x.wm, x.wn, x.lane, acc);
+    }
+}
+
+// the pre-pass: workgroup (column block, super-chunk) decodes the 256 columns x 128 K rows into the two W stage images of its
+// K steps.  Same loads, same decoders, same rounding as the in-kernel decode: the GEMM's results do not change by a bit.
+template <bool GPTQ>
+KERNEL void __launch_bounds__(MF_THREADS) wfrag_kernel(const QMatDev m, u8* out, int steps_per_block)
+{
+    const int lane = lane_id();
+    const int wv = uniform(wave_id());
+    const int n_tiles = m.N / TILE_N;
+    const int vn = bid_x();
+    int sup = bid_y();                                        // super-chunk index over all sections, in the GEMM's K order
+    const int n_items = m.n_runs > 0 ? m.n_runs : m.n_desc;
+    int step0 = 0;
+    for (int r = 0; r < n_items; r++)
+    {
+        const u32* base; u32 tile_stride; int F, k_base, bits, nvl;
+        if (m.n_runs > 0)
+        {
+            const QRun& R = m.runs[r];
+            base = (uniform((int)R.in_tail) ? m.tail : m.qw) + uniform(R.base_word);
+            tile_stride = uniform(R.tile_stride); F = uniform((int)R.n_super); k_base = uniform((int)R.k_base);
+            bits = uniform((int)R.bits); nvl = uniform((int)R.nvalid_last);
+        }
+        else
+        {
+            const QDesc* D = m.desc + r;
+            base = (uniform((int)D->in_tail) ? m.tail : m.qw) + uniform(D->base_word);
+            tile_stride = uniform(D->tile_stride); F = uniform((int)D->n_super); k_base = uniform((int)D->k_base);
+            bits = uniform((int)D->bits); nvl = uniform((int)D->nvalid_last);
+        }
+        if (F <= 0) continue;
+        if (sup >= F) { sup -= F; step0 += 2 * F; continue; }
+        int tile[2];
+        #pragma unroll
+        for (int i = 0; i < 2; i++) tile[i] = min(vn * 16 + 2 * wv + i, n_tiles - 1);
+        const int k0 = k_base + sup * SUPER_ROWS;
+        const int nvalid = (sup == F - 1) ? nvl : 4;
+        TileRaw raw;
+        load_raw_sw<GPTQ>(bits, raw, m, base, sup, tile_stride, k0 >> 5, nvalid, tile, m.chunk_group, lane);
+        u8* const slot = out + ((size_t)vn * steps_per_block + step0 + 2 * sup) * MF_W_STAGE;
+        decode_half_sw<GPTQ, 0>(bits, raw, slot, wv, lane);
+        decode_half_sw<GPTQ, 1>(bits, raw, slot + MF_W_STAGE, wv, lane);
+        return;
+    }
+}
+
+template <bool GPTQ, int MT, bool WPRE>
 KERNEL void __launch_bounds__(MF_THREADS, 2) qgemm_mfma_kernel(const PrefillArgs args)
 {
     // five separate LDS objects, not one dynamic block: hipcc then knows that the LDS-DMA into one X stage does not alias the
@@ -286,6 +390,7 @@ KERNEL void __launch_bounds__(MF_THREADS, 2) qgemm_mfma_kernel(const PrefillArgs
 
     block_sync();                                            // chunk -> group map is in LDS
     const int n_items = m.n_runs > 0 ? m.n_runs : m.n_desc;
+    int step0 = 0;                                           // (WPRE) first K step of the section inside this column block's slots
     for (int r = 0; r < n_items; r++)
     {
         const u32* base; u32 tile_stride; int F, k_base, bits, nvl;
@@ -304,7 +409,12 @@ KERNEL void __launch_bounds__(MF_THREADS, 2) qgemm_mfma_kernel(const PrefillArgs
             bits = uniform((int)D->bits); nvl = uniform((int)D->nvalid_last);
         }
         if (F <= 0) continue;
-        run_section<GPTQ, MT>(x, bits, base, tile_stride, F, k_base, nvl, acc);
+        if constexpr (WPRE)
+        {
+            run_section_pre<MT>(x, args.wfrag + ((size_t)vn * args.wfrag_steps + step0) * MF_W_STAGE, F, k_base, nvl, acc);
+            step0 += 2 * F;
+        }
+        else run_section<GPTQ, MT>(x, bits, base, tile_stride, F, k_base, nvl, acc);
     }
 
     // ---- epilogue: lane (i = lane & 15, j = lane >> 4) holds C[row i of the row tile][columns 4 j .. 4 j + 3 of the column tile]
@@ -360,14 +470,14 @@ KERNEL void __launch_bounds__(MF_THREADS, 2) qgemm_mfma_kernel(const PrefillArgs
 
 // ---- host ---------------------------------------------------------------------------------------------------------------
 
-template <bool GPTQ, int MT>
+template <bool GPTQ, int MT, bool WPRE = false>
 static int launch_one(const PrefillArgs& p, void* stream)
 {
     const int nb_n = (p.m.N + MF_BN - 1) / MF_BN, nb_m = (p.M + 32 * MT - 1) / (32 * MT);
     EXL2_REQUIRE((p.m.K >> 5) <= MF_MAX_CHUNKS, "q_gemm (prefill): K = %d too large for the group map in LDS", p.m.K);
     const size_t lds = 0;                               // all LDS is static
     if (getenv("EXL2_PREFILL_TRACE")) fprintf(stderr, "[qgemm_mfma] M=%d K=%d N=%d MT=%d gptq=%d\n", p.M, p.m.K, p.m.N, MT, (int)GPTQ);
-    LAUNCH((qgemm_mfma_kernel<GPTQ, MT>), dim3((unsigned)(nb_n * nb_m)), dim3(MF_THREADS), lds, stream, p);
+    LAUNCH((qgemm_mfma_kernel<GPTQ, MT, WPRE>), dim3((unsigned)(nb_n * nb_m)), dim3(MF_THREADS), lds, stream, p);
     return EXL2_OK;
 }
 
@@ -387,6 +497,27 @@ int qgemm_mfma_launch(const PrefillArgs& p, bool gptq, void* stream)
     const long r8 = (nb_n * ((p.M + 255) / 256) + cus - 1) / cus, r4 = (nb_n * ((p.M + 127) / 128) + cus - 1) / cus;
     int mt = (r8 * 20 <= r4 * 11) ? 8 : 4;
     if (const char* e = getenv("EXL2_PREFILL_MT")) { const int v = atoi(e); if (v == 4 || v == 8) mt = v; }
+    // many rows: decode the weights once per call into fragment images (wfrag_kernel), multiply from those
+    int wpre_min = MF_WPRE_MIN_ROWS;                          // (read per call: tests force both routes)
+    if (const char* e = getenv("EXL2_PREFILL_WPRE_MIN_ROWS")) wpre_min = atoi(e);
+    if (wpre_min > 0 && p.M >= wpre_min)
+    {
+        int supers = 0;
+        const int n_items = p.m.n_runs > 0 ? p.m.n_runs : 0;
+        for (int r = 0; r < n_items; r++) supers += p.m.runs[r].n_super > 0 ? p.m.runs[r].n_super : 0;
+        if (supers > 0 && supers <= 65535)
+        {
+            f16* buf = nullptr;
+            const size_t bytes = (size_t)nb_n * (size_t)(2 * supers) * MF_W_STAGE;
+            const int rc = prefill_scratch(bytes, stream, 1, &buf);
+            if (rc) return rc;
+            if (gptq) LAUNCH((wfrag_kernel<true>), dim3((unsigned)nb_n, (unsigned)supers), dim3(MF_THREADS), 0, stream, p.m, (u8*)buf, 2 * supers);
+            else      LAUNCH((wfrag_kernel<false>), dim3((unsigned)nb_n, (unsigned)supers), dim3(MF_THREADS), 0, stream, p.m, (u8*)buf, 2 * supers);
+            PrefillArgs q = p;
+            q.wfrag = (const u8*)buf; q.wfrag_steps = 2 * supers;
+            return mt == 8 ? launch_one<false, 8, true>(q, stream) : launch_one<false, 4, true>(q, stream);
+        }
+    }
     if (gptq) return mt == 8 ? launch_one<true, 8>(p, stream) : launch_one<true, 4>(p, stream);
     return mt == 8 ? launch_one<false, 8>(p, stream) : launch_one<false, 4>(p, stream);
 }

@@ -10,7 +10,14 @@ struct PrefillArgs
     f16* c; int ldc;
     const u16* c_invperm;
     int M, c_mode;
+    // qgemm_mfma.hip, many rows: the decoded weights as MFMA fragments, written once per call by wfrag_kernel (one 32 KB slot per
+    // column block and K step, exactly the W stage's LDS image); null = decode inside the GEMM
+    const u8* wfrag; int wfrag_steps;
 };
+
+// qgemm_prefill.hip: per (device, stream) scratch that lives until exl2_release_scratch; kind 0 = staged activation rows,
+// 1 = decoded weight fragments (two buffers of one call must not alias)
+int prefill_scratch(size_t bytes, void* stream, int kind, f16** out);
 
 // qgemm_mfma.hip: 0 = launched, < 0 = error (message set)
 int qgemm_mfma_launch(const PrefillArgs& p, bool gptq, void* stream);

@@ -514,17 +514,17 @@ KERNEL void __launch_bounds__(256) stage_rows_multi_kernel(const RowStageMulti a
 // twice the old size, which bounds the retired total by the live size) and the old one stays allocated.  Growing inside
 // a capture is refused.  exl2_release_scratch (model unload, after the graphs that used the stream have been destroyed) frees
 // the live and the retired buffers of a stream, so processes that cycle through models or streams do not accumulate them.
-struct StageSlot { int dev; void* stream; f16* buf; size_t bytes; std::vector<f16*> retired; };
+struct StageSlot { int dev; void* stream; int kind; f16* buf; size_t bytes; std::vector<f16*> retired; };
 static std::vector<StageSlot> g_stage_slots;
 static std::mutex g_stage_mutex;
 
-static int stage_scratch(size_t bytes, void* stream, f16** out)
+int prefill_scratch(size_t bytes, void* stream, int kind, f16** out)
 {
     const int dev = exl2_current_device();
     std::lock_guard<std::mutex> lock(g_stage_mutex);
     StageSlot* slot = nullptr;
-    for (StageSlot& s : g_stage_slots) if (s.dev == dev && s.stream == stream) { slot = &s; break; }
-    if (!slot) { g_stage_slots.push_back(StageSlot{dev, stream, nullptr, 0, {}}); slot = &g_stage_slots.back(); }
+    for (StageSlot& s : g_stage_slots) if (s.dev == dev && s.stream == stream && s.kind == kind) { slot = &s; break; }
+    if (!slot) { g_stage_slots.push_back(StageSlot{dev, stream, kind, nullptr, 0, {}}); slot = &g_stage_slots.back(); }
     if (slot->bytes < bytes)
     {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -550,6 +550,7 @@ static int stage_scratch(size_t bytes, void* stream, f16** out)
     *out = slot->buf;
     return EXL2_OK;
 }
+static int stage_scratch(size_t bytes, void* stream, f16** out) { return prefill_scratch(bytes, stream, 0, out); }
 
 // Frees the staging buffers (live and retired) of the current device: those of `stream`, or of every stream when all_streams
 // != 0.  The caller guarantees that no captured graph that ran a prefill / batched-decode launch on those streams will be

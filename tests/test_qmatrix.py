@@ -106,12 +106,15 @@ def test_prefill_vs_oracle(be, m):
     be.ext.free_q_matrix(h)
 
 
+@pytest.mark.parametrize("wpre", ["0", "1"])
 @pytest.mark.parametrize("m", [300, 1024])
-def test_prefill_tile256_variant_forced(be, m, monkeypatch):
-    """The 256 x 256 instantiation of the dequantize-into-MFMA kernel (qgemm_mfma_kernel<., 8>), forced at shapes both backends
-    can run: one-hot rows return rows of reconstruct() bit for bit, random rows land within the fp16 bar of the oracle
-    (the reference's relation, tests/test_gemv.py:155-165)."""
+def test_prefill_tile256_variant_forced(be, m, wpre, monkeypatch):
+    """The 256 x 256 instantiation of the dequantize-into-MFMA kernel (qgemm_mfma_kernel<., 8, .>), forced at shapes both backends
+    can run, with the weights decoded inside the GEMM (wpre 0) and decoded once per call into fragment images by wfrag_kernel
+    (wpre 1: the route of >= 2048 rows): one-hot rows return rows of reconstruct() bit for bit, random rows land within the fp16
+    bar of the oracle (the reference's relation, tests/test_gemv.py:155-165)."""
     monkeypatch.setenv("EXL2_PREFILL_MT", "8")
+    monkeypatch.setenv("EXL2_PREFILL_WPRE_MIN_ROWS", wpre)
     k, n, spec = SPECS["mixed_5_4"]
     t, ref, w, h = make_exl2(be, k, n, spec, seed=21, bias=False)
     rng = np.random.default_rng(22)
@@ -131,7 +134,7 @@ def test_prefill_tile256_variant_forced(be, m, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("role", ["q_proj", "gate_proj", "down_proj"])
-@pytest.mark.parametrize("force", [None, "8"])
+@pytest.mark.parametrize("force", [None, "8", "in-kernel decode"])
 def test_prefill_llama2_7b_shapes_4096_rows(role, force, monkeypatch):
     """BASELINE configs[2]'s kernel at the three Llama-2-7B linear shapes, M = 4096 rows (the natural selection there is the
     256 x 256 tile -- the variant the 8 x 2048 prefill runs -- and it is also forced): 256 sampled one-hot rows == reconstruct()
@@ -139,13 +142,15 @@ def test_prefill_llama2_7b_shapes_4096_rows(role, force, monkeypatch):
     from tests.conftest import Backend
     from exllamav2_amd.synth import RECIPES, synth_linear
     be = Backend("hip")
-    if force: monkeypatch.setenv("EXL2_PREFILL_MT", force)
+    if force == "in-kernel decode": monkeypatch.setenv("EXL2_PREFILL_WPRE_MIN_ROWS", "0")      # (default at 4096 rows: wfrag_kernel)
+    elif force: monkeypatch.setenv("EXL2_PREFILL_MT", force)
     monkeypatch.setenv("EXL2_PREFILL_TRACE", "1")
     k, n = {"q_proj": (4096, 4096), "gate_proj": (4096, 11008), "down_proj": (11008, 4096)}[role]
     gen = torch.Generator(); gen.manual_seed(321)
     w = synth_linear(k, n, RECIPES["4.0bpw"][role], "cpu", gen, sigma=0.02, act_order=True)
     ref = OX.exl2_reconstruct({kk: vv.numpy().copy() for kk, vv in w.items() if kk != "q_perm"})
-    h = be.ext.make_q_matrix_from_dict({kk: vv.to(be.device) for kk, vv in w.items()}, None)
+    wd = {kk: vv.to(be.device) for kk, vv in w.items()}      # kept alive: the handle re-lays q_weight out in place and reads it
+    h = be.ext.make_q_matrix_from_dict(wd, None)
     m = 4096
     rng = np.random.default_rng(7)
     a = rng.standard_normal((m, k)).astype(np.float16)

@@ -23,7 +23,8 @@ def _time(fn, reps):
 # kernel selection of csrc/qgemm_prefill.hip's host driver (read per call): the shipped choice, each tile height of the
 # 256-column LDS-decode kernel (qgemm_mfma.hip), and the 128 x 128 register-decode kernel (qgemm_prefill.hip)
 VARIANTS = {"auto": {}, "tile256_mt8": {"EXL2_PREFILL_MT": "8"}, "tile256_mt4": {"EXL2_PREFILL_MT": "4"},
-            "tile128": {"EXL2_PREFILL_MFMA_MIN_ROWS": "0"}}
+            "tile128": {"EXL2_PREFILL_MFMA_MIN_ROWS": "0"},
+            "decode_in_gemm": {"EXL2_PREFILL_WPRE_MIN_ROWS": "0"}}       # round 3: >= 2048 rows decode the weights once per call (auto)
 
 
 def bench_linear(k, n, m, recipe, reps=5, variants=("auto", "tile256_mt8", "tile256_mt4", "tile128")):
@@ -35,14 +36,14 @@ def bench_linear(k, n, m, recipe, reps=5, variants=("auto", "tile256_mt8", "tile
     out = {"k": k, "n": n, "m": m, "recipe": str(recipe)}
     ref = None
     for name in variants:
-        for key in ("EXL2_PREFILL_MT", "EXL2_PREFILL_MFMA_MIN_ROWS"): os.environ.pop(key, None)
+        for key in ("EXL2_PREFILL_MT", "EXL2_PREFILL_MFMA_MIN_ROWS", "EXL2_PREFILL_WPRE_MIN_ROWS"): os.environ.pop(key, None)
         os.environ.update(VARIANTS[name])
         ms = _time(lambda: ext.gemm_half_q_half(a, h, c), reps)
         out[name] = {"ms": round(ms, 4), "TFLOPs": round(2.0 * m * k * n / ms / 1e9, 1),
                      "frac_mfma_peak": round(2.0 * m * k * n / ms / 1e9 / MFMA_PEAK_F16, 4)}
         if ref is None: ref = c.clone()
         else: out[name]["max_abs_diff_vs_auto"] = float((c.float() - ref.float()).abs().max())
-    for key in ("EXL2_PREFILL_MT", "EXL2_PREFILL_MFMA_MIN_ROWS"): os.environ.pop(key, None)
+    for key in ("EXL2_PREFILL_MT", "EXL2_PREFILL_MFMA_MIN_ROWS", "EXL2_PREFILL_WPRE_MIN_ROWS"): os.environ.pop(key, None)
     # the reference's method for M > 32: reconstruct + fp16 library GEMM (q_gemm.cu:243-263), here torch.matmul = hipBLASLt
     wd = torch.empty((k, n), device="cuda", dtype=torch.float16)
     def lib():
