@@ -565,7 +565,7 @@ def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq:
     try:
         lin = model.layers[0][1].gate_proj
         rows = batch * seq
-        x = (torch.randn((rows, lin.in_features), dtype=torch.float32, device=device) * 0.5).half()
+        x = torch.randn((rows, lin.in_features), dtype=torch.float32, device=device).half()      # (sigma 1, like tools/prefill_bench.py)
         y = torch.empty((rows, lin.out_features), dtype=torch.float16, device=device)
         model.ext.gemm_half_q_half(x, lin.q_handle, y); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
