@@ -36,7 +36,8 @@
 #endif
 #define MF_BN 256
 #ifndef MF_WPRE_MIN_ROWS
-#define MF_WPRE_MIN_ROWS 2048            // rows from which the weights are decoded once per call (wfrag_kernel) instead of per workgroup
+#define MF_WPRE_MIN_ROWS 129             // rows from which the weights are decoded once per call (wfrag_kernel): every call this file
+                                        // serves -- it wins from 192 rows up (profiles/r03_prefill_wpre_threshold.txt)
 #endif
 #define MF_THREADS 512
 #define MF_W_STAGE 32768                        // 16 tiles x 2 chunks x 64 lanes x 16 bytes
