@@ -40,6 +40,7 @@ PROTOTYPES = {
     "exl2_argmax_rows": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp]),
     "exl2_add_i32": (ci, [vp, ci, ci, vp]),
     "exl2_sample_rows": (ci, [vp, ci, ci, ci, ci, vp, cf, ci, cf, cf, cf, vp, vp, vp, vp]),
+    "exl2_sample_rows_step": (ci, [vp, ci, ci, ci, ci, vp, cf, ci, cf, cf, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, vp]),
     # quantized KV cache
     "exl2_fp16_to_q_kv": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, ci, vp]),
     "exl2_q_to_fp16_kv": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, ci, vp]),

@@ -25,6 +25,7 @@
 // order), top-a, tfs, typical, mirostat, XTC, skew, smoothing, dynamic temperature, the top-token report.
 #include "hw.h"
 #include "errors.h"
+#include <string.h>
 
 #define SAMPLE_THREADS 1024
 #define SAMPLE_KMAX 500
@@ -36,6 +37,10 @@ struct SampleArgs
     float temperature; int top_k; float top_p; float min_p; float random;
     int* out_tokens; float* out_probs;
     float* ws;                        // [rows, vocab] fp32: the row's probabilities (the reference's temp_probs)
+    // inside a decode-step graph (exl2_sample_rows_step): the random point comes from device memory -- randoms[*counter % n_randoms],
+    // filled by the host many tokens ahead -- and the token goes where the arg-max kernel puts it (history, position increment)
+    const float* randoms; const int* counter; int n_randoms;
+    int* history; int* hist_pos; int hist_stride, pos_inc;
 };
 
 // Row walks.  A row whose length and stride are multiples of 4 elements on a 16-byte-aligned base (every real vocabulary) is
@@ -333,7 +338,7 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
         n = i;
         normalize(n);
     }
-    float random = a.random;
+    float random = a.randoms ? a.randoms[(unsigned)a.counter[0] % (unsigned)a.n_randoms] : a.random;
     for (int r = 0; r < row; r++)                                   // ext_sampling.cpp:286-296, once per earlier row
     {
         float x = random;
@@ -352,30 +357,66 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     }
     a.out_tokens[row] = cand_i[idx];
     a.out_probs[row] = cand_p[idx];
+    if (a.hist_pos)
+    {
+        const int pos = a.hist_pos[row] + a.pos_inc;
+        if (a.history) a.history[(size_t)row * a.hist_stride + pos] = cand_i[idx];
+        if (a.pos_inc) a.hist_pos[row] = pos;
+    }
 }
 
 extern "C" {
+
+static int sample_launch(SampleArgs a, int logits_f32, int rows, float random, void* stream)
+{
+    EXL2_REQUIRE(a.logits && a.out_tokens && a.out_probs && a.ws, "sample_rows: null argument");
+    EXL2_REQUIRE(a.vocab >= 2 && a.ld >= a.vocab, "sample_rows: vocab %d, row stride %d", a.vocab, a.ld);
+    if (a.temperature < 0.01f) { a.temperature = 1.0f; a.top_k = 1; }                 // ext_sampling.cpp:143-147
+    if (a.top_k < 1 || a.top_k > SAMPLE_KMAX || a.top_k >= a.vocab)
+        EXL2_FAIL(EXL2_E_UNSUPPORTED, "sample_rows: top_k %d outside [1, %d] (and < vocab): the reference's heap regime is what is built",
+                  a.top_k, SAMPLE_KMAX);
+    EXL2_REQUIRE(a.randoms || (random >= 0.0f && random < 1.0f), "sample_rows: random %f not in [0, 1)", (double)random);
+    if (rows <= 0) return EXL2_OK;
+    a.random = random;
+    if (logits_f32) LAUNCH(sample_rows_kernel<float>, dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a);
+    else            LAUNCH(sample_rows_kernel<f16>, dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
+}
 
 int exl2_sample_rows(const void* logits, int logits_f32, int rows, int vocab, int ld, const void* logit_filter,
                      float temperature, int top_k, float top_p, float min_p, float random,
                      int* out_tokens, float* out_probs, float* workspace, void* stream)
 {
-    EXL2_REQUIRE(logits && out_tokens && out_probs && workspace, "sample_rows: null argument");
-    EXL2_REQUIRE(vocab >= 2 && ld >= vocab, "sample_rows: vocab %d, row stride %d", vocab, ld);
-    if (temperature < 0.01f) { temperature = 1.0f; top_k = 1; }                       // ext_sampling.cpp:143-147
-    if (top_k < 1 || top_k > SAMPLE_KMAX || top_k >= vocab)
-        EXL2_FAIL(EXL2_E_UNSUPPORTED, "sample_rows: top_k %d outside [1, %d] (and < vocab): the reference's heap regime is what is built",
-                  top_k, SAMPLE_KMAX);
-    EXL2_REQUIRE(random >= 0.0f && random < 1.0f, "sample_rows: random %f not in [0, 1)", (double)random);
-    if (rows <= 0) return EXL2_OK;
     SampleArgs a;
+    memset(&a, 0, sizeof(a));
     a.logits = logits; a.ld = ld; a.vocab = vocab; a.filter = (const u8*)logit_filter;
-    a.temperature = temperature; a.top_k = top_k; a.top_p = top_p; a.min_p = min_p; a.random = random;
+    a.temperature = temperature; a.top_k = top_k; a.top_p = top_p; a.min_p = min_p;
     a.out_tokens = out_tokens; a.out_probs = out_probs; a.ws = workspace;
-    if (logits_f32) LAUNCH(sample_rows_kernel<float>, dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a);
-    else            LAUNCH(sample_rows_kernel<f16>, dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a);
-    HIP_TRY(hipGetLastError());
-    return EXL2_OK;
+    return sample_launch(a, logits_f32, rows, random, stream);
+}
+
+// The same sampler as the last launch of a decode-step graph: the random point of the step is randoms[*counter % n_randoms]
+// (device memory: the host fills randoms ahead of the run and nothing of the launch changes from token to token, so the step
+// replays from ONE graph), the token is written to out_tokens, logged at history[row, hist_pos[row] + pos_inc] and the position
+// is advanced -- exactly what exl2_argmax_rows does for greedy decoding.  *counter is NOT advanced here (every row reads it):
+// the graph appends exl2_add_i32(counter, 1, 1).  Values in randoms must lie in [0, 1) (host contract; not checked on the device).
+int exl2_sample_rows_step(const void* logits, int logits_f32, int rows, int vocab, int ld, const void* logit_filter,
+                          float temperature, int top_k, float top_p, float min_p,
+                          const float* randoms, int n_randoms, const int* counter,
+                          int* out_tokens, float* out_probs, float* workspace,
+                          int* history, int* hist_pos, int hist_stride, int pos_inc, void* stream)
+{
+    EXL2_REQUIRE(randoms && counter && n_randoms >= 1, "sample_rows_step: random buffer / counter missing");
+    EXL2_REQUIRE(!history || hist_pos, "sample_rows_step: history needs hist_pos");
+    SampleArgs a;
+    memset(&a, 0, sizeof(a));
+    a.logits = logits; a.ld = ld; a.vocab = vocab; a.filter = (const u8*)logit_filter;
+    a.temperature = temperature; a.top_k = top_k; a.top_p = top_p; a.min_p = min_p;
+    a.out_tokens = out_tokens; a.out_probs = out_probs; a.ws = workspace;
+    a.randoms = randoms; a.n_randoms = n_randoms; a.counter = counter;
+    a.history = history; a.hist_pos = hist_pos; a.hist_stride = hist_stride; a.pos_inc = pos_inc;
+    return sample_launch(a, logits_f32, rows, 0.0f, stream);
 }
 
 }  // extern "C"

@@ -665,6 +665,24 @@ class ExtC:
                                                  self._ptr(workspace, torch.float32, "workspace"), self._stream(logits)))
         return workspace
 
+    def sample_rows_step(self, logits, temperature: float, top_k: int, top_p: float, min_p: float, randoms, counter,
+                         out_tokens, out_probs, workspace, history, hist_pos, pos_inc: int = 1, vocab: int | None = None) -> None:
+        """sample_rows as the last launch of a decode-step graph (include/exl2_hip.h exl2_sample_rows_step): the random point is
+        randoms[counter[0] % len(randoms)] (fp32 / int32 device tensors), the token is logged and the position advanced like
+        argmax_rows does.  The caller appends add_i32_(counter, 1)."""
+        ld = logits.shape[-1]
+        rows = logits.numel() // ld
+        v = int(vocab or ld)
+        if workspace.numel() < rows * v:
+            raise RuntimeError("sample_rows_step: workspace smaller than rows x vocab")
+        self.lib.check(self.lib.exl2_sample_rows_step(
+            self._ptr(logits, None, "logits"), int(logits.dtype == torch.float32), rows, v, ld, None,
+            float(temperature), int(top_k), float(top_p), float(min_p),
+            self._ptr(randoms, torch.float32, "randoms"), randoms.numel(), self._ptr(counter, torch.int32, "counter"),
+            self._ptr(out_tokens, torch.int32, "out_tokens"), self._ptr(out_probs, torch.float32, "out_probs"),
+            self._ptr(workspace, torch.float32, "workspace"), self._ptr(history, torch.int32, "history"),
+            self._ptr(hist_pos, torch.int32, "hist_pos"), history.shape[-1], int(pos_inc), self._stream(logits)))
+
     def add_i32_(self, t, value: int) -> None:
         self.lib.check(self.lib.exl2_add_i32(self._ptr(t, torch.int32, "t"), t.numel(), int(value), self._stream(t)))
 

@@ -268,7 +268,19 @@ class GreedyGraphDecoder:
         import contextlib
         on_b = overlap and ch["stream_b"] is not None and (n_launches - 1) % 2 == 1
         with (torch.cuda.stream(ch["stream_b"]) if on_b else contextlib.nullcontext()):
+            self._select_token()
+
+    def _select_token(self):
+        """last launch(es) of a step: greedy arg-max, or -- while a sampled graph is being captured / run eagerly -- the device
+        sampler reading its random point from the decoder's buffer, + the counter increment"""
+        ext, cfg = self.model.ext, self.model.config
+        sm = getattr(self, "_sampling", None)
+        if sm is None:
             ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens, pos_inc=1)
+            return
+        ext.sample_rows_step(self.logits, sm["temperature"], sm["top_k"], sm["top_p"], sm["min_p"], sm["randoms"], sm["counter"],
+                             self.ids, sm["probs"], sm["ws"], self.history, self.cache_seqlens, pos_inc=1, vocab=cfg.vocab_size)
+        ext.add_i32_(sm["counter"], 1)
 
     def _overlapped(self) -> bool:
         return self.chain is not None and "flags" in self.chain and self.chain.get("stream_b") is not None
@@ -313,7 +325,7 @@ class GreedyGraphDecoder:
             mlp.forward(self.x)
         ext.rms_norm(self.x.view(self.b, -1), m.norm.weight, self.xn.view(self.b, -1), cfg.norm_eps)
         ext.gemm_half_q_half(self.xn.view(self.b, -1), m.lm_head.q_handle, self.logits)
-        ext.argmax_rows(self.logits, self.ids, cfg.vocab_size, self.history, self.cache_seqlens, pos_inc=1)
+        self._select_token()
 
     def _on_stream(self):
         import contextlib
@@ -384,6 +396,33 @@ class GreedyGraphDecoder:
             if two:
                 self.stream.wait_event(self.chain["ev_b"])
 
+    def capture_sampled(self, temperature: float, top_k: int, top_p: float = 0.0, min_p: float = 0.0, n_randoms: int = 4096):
+        """A second step graph whose last launches are the device sampler (exl2_sample_rows_step) + its counter increment instead
+        of the arg-max: `run_sampled` with these settings then replays ONE graph per token -- the random points are read from a
+        device buffer the host fills before the run (n_randoms tokens ahead at most per fill)."""
+        ext, cfg = self.model.ext, self.model.config
+        if self._overlapped():
+            raise RuntimeError("capture_sampled: not available on the experimental overlapped chain")
+        dev = self.logits.device
+        sm = {"temperature": float(temperature), "top_k": int(top_k), "top_p": float(top_p), "min_p": float(min_p),
+              "randoms": torch.zeros((int(n_randoms),), dtype=torch.float32, device=dev),
+              "counter": torch.zeros((1,), dtype=torch.int32, device=dev),
+              "probs": torch.zeros((self.b,), dtype=torch.float32, device=dev),
+              "ws": torch.empty((self.b, cfg.vocab_size), dtype=torch.float32, device=dev)}
+        sm["graph"] = None
+        if dev.type == "cuda":
+            greedy_graph, self.graph = self.graph, None
+            self._sampling = sm
+            try:
+                self.capture()                                   # same warm-up / scratch-slot protocol, the sampler as the last launches
+                sm["graph"] = self.graph
+            finally:
+                self.graph = greedy_graph
+                self._sampling = None
+        sm["counter"].zero_()
+        self._sampled = sm
+        return self
+
     def run_sampled(self, n_tokens: int, temperature: float, top_k: int, top_p: float = 0.0, min_p: float = 0.0,
                     randoms=None, seed: int = 0, use_graph: bool = True):
         """Decode `n_tokens` tokens per sequence with the DEVICE sampler (csrc/sampling.hip; the reference's sample_basic for
@@ -403,6 +442,28 @@ class GreedyGraphDecoder:
             randoms = [rng.random() for _ in range(n_tokens)]
         if len(randoms) < n_tokens:
             raise RuntimeError("run_sampled: one random point per token is needed")
+        sm = getattr(self, "_sampled", None)
+        if (sm is not None and n_tokens <= sm["randoms"].numel()
+                and (sm["temperature"], sm["top_k"], sm["top_p"], sm["min_p"]) == (float(temperature), int(top_k), float(top_p), float(min_p))):
+            # settings of capture_sampled: the sampler is part of the step; the random points travel as ONE copy before the run,
+            # then one graph launch per token (eager steps of the same launches where there is no graph)
+            pts = torch.tensor([float(r) for r in randoms[:n_tokens]], dtype=torch.float32)
+            self.pos += n_tokens
+            with self._on_stream():
+                sptr = self.stream.cuda_stream if self.stream is not None else None
+                sm["randoms"][:n_tokens].copy_(pts, non_blocking=False)
+                sm["counter"].zero_()
+                if use_graph and sm.get("graph") is not None:
+                    for _ in range(n_tokens):
+                        ext.graph_launch(sm["graph"], sptr)
+                else:
+                    self._sampling = sm
+                    try:
+                        for _ in range(n_tokens):
+                            self.step_eager()
+                    finally:
+                        self._sampling = None
+            return
         if getattr(self, "_sample_ws", None) is None:
             dev = self.logits.device
             self._sample_ws = torch.empty((self.b, cfg.vocab_size), dtype=torch.float32, device=dev)
@@ -426,6 +487,10 @@ class GreedyGraphDecoder:
         return self.history[:, start + 1:start + 1 + n]
 
     def free(self):
+        sm = getattr(self, "_sampled", None)
+        if sm is not None and sm.get("graph") is not None:
+            self.model.ext.graph_free(sm["graph"])
+            self._sampled = None
         if self.graph is not None:
             self.model.ext.graph_free(self.graph)
             self.graph = None

@@ -274,6 +274,15 @@ int exl2_add_i32(int* p, int n, int value, void* stream);
 int exl2_sample_rows(const void* logits, int logits_f32, int rows, int vocab, int ld, const void* logit_filter,
                      float temperature, int top_k, float top_p, float min_p, float random,
                      int* out_tokens, float* out_probs, float* workspace, void* stream);
+/* The same sampler as the LAST launch of a decode-step graph: the step's random point is randoms[*counter % n_randoms] (device
+   memory the host fills ahead of the run), the token goes to out_tokens, to history[row, hist_pos[row] + pos_inc] and the
+   position is advanced -- what exl2_argmax_rows does for greedy decoding -- so a sampled step replays from one graph with no
+   per-token launch argument.  *counter is not advanced here (every row reads it): append exl2_add_i32(counter, 1, 1). */
+int exl2_sample_rows_step(const void* logits, int logits_f32, int rows, int vocab, int ld, const void* logit_filter,
+                          float temperature, int top_k, float top_p, float min_p,
+                          const float* randoms, int n_randoms, const int* counter,
+                          int* out_tokens, float* out_probs, float* workspace,
+                          int* history, int* hist_pos, int hist_stride, int pos_inc, void* stream);
 int exl2_graph_begin_capture(void* stream);
 int exl2_graph_end_capture(void* stream, void** graph_exec);
 int exl2_graph_launch(void* graph_exec, void* stream);

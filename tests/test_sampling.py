@@ -247,4 +247,29 @@ def test_decoder_run_sampled(be):
                 compared += 1
     assert compared >= 8
     dec.free()
+
+    # (3) the sampler INSIDE the step (capture_sampled: exl2_sample_rows_step reads the point from a device buffer, logs the token,
+    # advances the position; one graph launch per token on the GPU): same tokens as (2)'s route step by step, and several
+    # tokens per call consume consecutive points
+    dec = decoder()
+    dec.capture_sampled(0.8, 50, 0.8, 0.0, n_randoms=8)
+    compared = 0
+    for i, rnd in enumerate(rnds):
+        dec.run_sampled(1, 0.8, 50, 0.8, 0.0, randoms=[rnd], use_graph=graph)
+        lg = be.n(dec.logits)[:, :cfg.vocab_size].astype(np.float32)
+        tok, _, margin, _ = osamp.sample_basic(lg, 0.8, 50, 0.8, 0.0, rnd, None)
+        got = be.n(dec.tokens(i, 1))[:, 0]
+        assert np.array_equal(be.n(dec.ids), got)
+        for r in range(2):
+            if margin[r] >= MARGIN:
+                assert got[r] == tok[r], (i, r, got, tok)
+                compared += 1
+    assert compared >= 8
+    one_by_one = be.n(dec.tokens(0, len(rnds))).copy()
+    dec.free()
+    dec = decoder()
+    dec.capture_sampled(0.8, 50, 0.8, 0.0, n_randoms=8)
+    dec.run_sampled(len(rnds), 0.8, 50, 0.8, 0.0, randoms=rnds, use_graph=graph)
+    assert np.array_equal(be.n(dec.tokens(0, len(rnds))), one_by_one)
+    dec.free()
     model.unload()
