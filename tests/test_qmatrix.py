@@ -106,14 +106,15 @@ def test_prefill_vs_oracle(be, m):
     be.ext.free_q_matrix(h)
 
 
+@pytest.mark.parametrize("mt", ["8", "4"])
 @pytest.mark.parametrize("wpre", ["0", "1"])
 @pytest.mark.parametrize("m", [300, 1024])
-def test_prefill_tile256_variant_forced(be, m, wpre, monkeypatch):
+def test_prefill_tile256_variant_forced(be, m, wpre, mt, monkeypatch):
     """The 256 x 256 instantiation of the dequantize-into-MFMA kernel (qgemm_mfma_kernel<., 8, .>), forced at shapes both backends
     can run, with the weights decoded inside the GEMM (wpre 0) and decoded once per call into fragment images by wfrag_kernel
     (wpre 1: the route of >= 2048 rows): one-hot rows return rows of reconstruct() bit for bit, random rows land within the fp16
     bar of the oracle (the reference's relation, tests/test_gemv.py:155-165)."""
-    monkeypatch.setenv("EXL2_PREFILL_MT", "8")
+    monkeypatch.setenv("EXL2_PREFILL_MT", mt)                    # (256-row and 128-row tile of the same kernel)
     monkeypatch.setenv("EXL2_PREFILL_WPRE_MIN_ROWS", wpre)
     k, n, spec = SPECS["mixed_5_4"]
     t, ref, w, h = make_exl2(be, k, n, spec, seed=21, bias=False)
