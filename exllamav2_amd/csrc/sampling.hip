@@ -26,6 +26,7 @@
 #include "hw.h"
 #include "errors.h"
 #include <string.h>
+#include <stdlib.h>
 
 #define SAMPLE_THREADS 1024
 #define SAMPLE_KMAX 500
@@ -104,7 +105,12 @@ DEV u32 wave_scan_incl(u32 v)
     return v;
 }
 
-template <typename T>
+// REG: the row lives in registers from its one read to the end of the radix select (8 quads per thread: vocabularies up to
+// 32768 on the quad path, no logit filter) -- the maximum, the exponentials, their normalisation and the four radix passes then
+// cost no memory pass at all; the probabilities are written to the workspace once (the later stages and the caller read them
+// there).  Same element -> thread assignment and the same operation order as the memory walks: results identical bit for bit.
+#define SAMPLE_REG_QUADS 8
+template <typename T, bool REG>
 KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
 {
     SHARED float red_v[16];
@@ -126,9 +132,31 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
 
     const bool vec = ((V & 3) == 0) && ((a.ld & 3) == 0) && ((((size_t)a.logits) & 15) == 0) && ((((size_t)a.ws) & 15) == 0);
 
+    // (REG) quad q = t + 1024 u of the row in pr[u]
+    f32x4 pr[SAMPLE_REG_QUADS];
+    const int nq_reg = V >> 2;
+    auto for_regs = [&](auto fn) {
+        #pragma unroll
+        for (int u = 0; u < SAMPLE_REG_QUADS; u++)
+        {
+            const int q = t + u * SAMPLE_THREADS;
+            if (q < nq_reg) { fn(4 * q, pr[u].x); fn(4 * q + 1, pr[u].y); fn(4 * q + 2, pr[u].z); fn(4 * q + 3, pr[u].w); }
+        }
+    };
+    if constexpr (REG)
+    {
+        #pragma unroll
+        for (int u = 0; u < SAMPLE_REG_QUADS; u++)
+        {
+            const int q = t + u * SAMPLE_THREADS;
+            pr[u] = q < nq_reg ? load_quad(lr + 4 * (size_t)q) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+
     // ---- 1. first maximum among the unfiltered logits (softmax_cpu_nonavx2: `logits[i] > maxl`, ascending i) -----------
     float bv = -1e38f; int bi = 0x7fffffff;
-    for_row(lr, V, vec, [&](int i, float v) { if ((!fr || fr[i]) && v > bv) { bv = v; bi = i; } });
+    if constexpr (REG) for_regs([&](int i, float v) { if (v > bv) { bv = v; bi = i; } });
+    else for_row(lr, V, vec, [&](int i, float v) { if ((!fr || fr[i]) && v > bv) { bv = v; bi = i; } });
     for (int mask = 1; mask < 64; mask <<= 1)
     {
         const float ov = shfl_xor_f32(bv, mask);
@@ -145,7 +173,19 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     // ---- 2. e = expf((l - max) / T), sum, p = e / sum ------------------------------------------------------------------
     const float itemp = 1.0f / a.temperature;
     float part = 0.0f;
-    if (vec)
+    if constexpr (REG)
+    {
+        #pragma unroll
+        for (int u = 0; u < SAMPLE_REG_QUADS; u++)
+        {
+            if (t + u * SAMPLE_THREADS < nq_reg)
+            {
+                #pragma unroll
+                for (int c = 0; c < 4; c++) { const float x = expf((pr[u][c] - maxl) * itemp); part += x; pr[u][c] = x; }
+            }
+        }
+    }
+    else if (vec)
     {
         const int nq = V >> 2;
         for (int q = t; q < nq; q += SAMPLE_THREADS)
@@ -174,7 +214,20 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     float esum = 0.0f;
     for (int w = 0; w < 16; w++) esum += red_v[w];
     const float isum = 1.0f / esum;
-    if (vec)
+    if constexpr (REG)
+    {
+        #pragma unroll
+        for (int u = 0; u < SAMPLE_REG_QUADS; u++)
+        {
+            const int q = t + u * SAMPLE_THREADS;
+            if (q < nq_reg)
+            {
+                pr[u].x *= isum; pr[u].y *= isum; pr[u].z *= isum; pr[u].w *= isum;
+                *(f32x4*)(ws + 4 * (size_t)q) = pr[u];
+            }
+        }
+    }
+    else if (vec)
         for (int q = t; q < (V >> 2); q += SAMPLE_THREADS)
         {
             f32x4 e = *(const f32x4*)(ws + 4 * (size_t)q);
@@ -207,14 +260,15 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
         if (t < 256) hist[t] = 0;
         block_sync();
         u32 run_digit = 0, run_len = 0;
-        for_row(ws, V, vec, [&](int, float p)
+        auto digit = [&](int, float p)
         {
             const u32 key = f32_bits(p);
             if ((key & maskbits) != prefix) return;
             const u32 d = (key >> shift) & 255;
             if (d != run_digit && run_len) { atomic_add_u32(&hist[run_digit], run_len); run_len = 0; }
             run_digit = d; run_len++;
-        });
+        };
+        if constexpr (REG) for_regs(digit); else for_row(ws, V, vec, digit);
         if (run_len) atomic_add_u32(&hist[run_digit], run_len);
         block_sync();
         // the digit whose bucket holds the need-th largest key: buckets taken from 255 down, one per thread of waves 0-3, a
@@ -378,8 +432,15 @@ static int sample_launch(SampleArgs a, int logits_f32, int rows, float random, v
     EXL2_REQUIRE(a.randoms || (random >= 0.0f && random < 1.0f), "sample_rows: random %f not in [0, 1)", (double)random);
     if (rows <= 0) return EXL2_OK;
     a.random = random;
-    if (logits_f32) LAUNCH(sample_rows_kernel<float>, dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a);
-    else            LAUNCH(sample_rows_kernel<f16>, dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a);
+    // the row in registers (see the kernel): quad path, <= 8 quads per thread, no filter
+    int reg_on = 1;                                          // (read per call: the tests compare both routes)
+    if (const char* e = getenv("EXL2_SAMPLE_REG")) reg_on = atoi(e);
+    const bool vec = ((a.vocab & 3) == 0) && ((a.ld & 3) == 0) && ((((size_t)a.logits) & 15) == 0) && ((((size_t)a.ws) & 15) == 0);
+    const bool reg = reg_on && vec && !a.filter && a.vocab <= 4 * SAMPLE_REG_QUADS * SAMPLE_THREADS;
+    if (logits_f32) { if (reg) LAUNCH((sample_rows_kernel<float, true>), dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a);
+                      else     LAUNCH((sample_rows_kernel<float, false>), dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a); }
+    else            { if (reg) LAUNCH((sample_rows_kernel<f16, true>), dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a);
+                      else     LAUNCH((sample_rows_kernel<f16, false>), dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a); }
     HIP_TRY(hipGetLastError());
     return EXL2_OK;
 }
