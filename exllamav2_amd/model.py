@@ -28,6 +28,7 @@ def rope_tables(cfg: ExLlamaV2Config, device):
 
 
 class ExLlamaV2:
+    _live_on_device: dict = {}          # loaded models per device (the library's staging scratch is per device and stream)
     def __init__(self, config: ExLlamaV2Config, device="cuda:0", ext=None):
         self.config = config
         self.device = torch.device(device)
@@ -84,6 +85,8 @@ class ExLlamaV2:
         if "lm_head" in ck:
             self.norm = ExLlamaV2RMSNorm(self.ext, "model.norm", ck["model.norm"], cfg.norm_eps)
             self.lm_head = ExLlamaV2Linear(self.ext, "lm_head", cfg.hidden_size, vpad, self).load(ck["lm_head"])
+        if not self.loaded:
+            ExLlamaV2._live_on_device[str(self.device)] = ExLlamaV2._live_on_device.get(str(self.device), 0) + 1
         self.loaded = True
         return self
 
@@ -91,10 +94,17 @@ class ExLlamaV2:
         for attn, mlp in self.layers:
             attn.unload(); mlp.unload()
         if self.lm_head: self.lm_head.unload()
+        was_loaded = self.loaded
         self.layers, self.modules, self.loaded = [], [], False
-        # the activation staging buffers of this device's streams (csrc/qgemm_prefill.hip: up to 360 MB per stream); decoders
-        # built on this model must have been freed (their graphs hold the addresses)
-        self.ext.release_scratch(self.device)
+        # the staging buffers of this device's streams (csrc/qgemm_prefill.hip: activations up to 360 MB per stream, decoded weight
+        # fragments K x N x 2 bytes) are shared by every model of the device and their addresses sit in captured graphs (a decoder
+        # of 5-16 sequences): they go when the LAST loaded model of the device goes -- a draft model unloading must not pull
+        # them from under the main model's graphs
+        if was_loaded:
+            k = str(self.device)
+            ExLlamaV2._live_on_device[k] = max(0, ExLlamaV2._live_on_device.get(k, 1) - 1)
+            if ExLlamaV2._live_on_device[k] == 0:
+                self.ext.release_scratch(self.device)
 
     def weight_bytes(self) -> int:
         """Algorithmic bytes one token streams through the linears.  A sparse-MoE layer streams
