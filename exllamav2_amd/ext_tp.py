@@ -138,6 +138,9 @@ def tp_broadcast(tp_context: int, buffer: int, source, broadcast_type: int, targ
         with ctx.on(sdev):
             produced = torch.cuda.Event()
             produced.record(ctx.streams[sdev])
+            if src2.data_ptr() != source.data_ptr():                # (reshape had to copy: keep the copy alive for the side streams)
+                for d in ctx.all_devices:
+                    src2.record_stream(ctx.streams[d])
             _e.copy_2d_async(pin, src2, ctx.streams[sdev].cuda_stream)          # D2H, source device's stream
     elif source.data_ptr() != pin.data_ptr():
         # a host tensor that is not the staging buffer yet: earlier uploads FROM the buffer may still be in flight on the
