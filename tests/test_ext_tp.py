@@ -89,6 +89,7 @@ def test_broadcast_gather_all_reduce(be, tp):
         assert np.array_equal(be.n(t), x)
     # device source -> staging buffer -> the other devices
     src = be.t((x * 2).astype(F16))
+    _sync(be)                                   # (be.t uploads on torch's default stream; the TP entry points work on the context's streams)
     TP.tp_broadcast(tp["h"], 1, src, TP.BROADCAST_RS, targets, 1, -1)
     _sync(be)
     for t in targets:
@@ -96,6 +97,7 @@ def test_broadcast_gather_all_reduce(be, tp):
     # gather of column slices, then back out to every device of another split
     parts = [be.t(np.ascontiguousarray(x[:, a:b])) for _, a, b in tp["rs"]]
     outs = [torch.zeros((rows, HID), dtype=torch.float16, device=be.device) for _ in tp["rs"]]
+    _sync(be)
     TP.tp_gather(tp["h"], 0, parts, TP.BROADCAST_RS, outs, TP.BROADCAST_RS, 1, -1)
     _sync(be)
     for o in outs:
@@ -105,6 +107,7 @@ def test_broadcast_gather_all_reduce(be, tp):
     pin1 = tp["pinned"][1][:rows * HID].view(rows, HID)
     pin1.zero_()
     parts3 = [be.t(np.ascontiguousarray((x * 3).astype(F16)[:, a:b])) for _, a, b in tp["rs"]]
+    _sync(be)
     TP.tp_gather(tp["h"], 1, parts3, TP.BROADCAST_RS, [], -1, 1, -1)
     _sync(be)
     assert np.array_equal(pin1.numpy(), (x * 3).astype(F16))
@@ -120,6 +123,7 @@ def test_broadcast_gather_all_reduce(be, tp):
     want = np.zeros((rows, HID), dtype=F16)
     for t in ts:
         want = (want.astype(np.float32) + be.n(t).astype(np.float32)).astype(F16)
+    _sync(be)
     TP.tp_all_reduce(tp["h"], 0, ts, rs)
     _sync(be)
     for r in rs:
