@@ -270,3 +270,25 @@ def test_llama2_7b_width_two_layers_equals_oracle():
     check_logits(be.n(dec.logits)[:, :cfg.vocab_size].reshape(1, 1, -1), w[None, None])
     dec.free()
     model.unload()
+
+
+def test_staging_scratch_goes_with_the_last_model_of_a_device(be, monkeypatch):
+    """model.unload() releases the library's per-stream staging buffers (exl2_release_scratch) only when no other loaded model of
+    the device is left: a second model's captured graphs may hold their addresses."""
+    cfg = tiny_cfg(num_hidden_layers=1)
+    calls = []
+    real = be.ext.release_scratch
+    monkeypatch.setattr(type(be.ext), "release_scratch", lambda self, device=None: calls.append(str(device)) or real(device))
+    base = ExLlamaV2._live_on_device.get(str(torch.device(be.device)), 0)
+    ma = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(synth_checkpoint(cfg, be.device, seed=1))
+    mb = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(synth_checkpoint(cfg, be.device, seed=2))
+    assert ExLlamaV2._live_on_device[str(torch.device(be.device))] == base + 2
+    ma.unload()
+    assert len(calls) == 0                                           # another model of the device is still loaded
+    n_before = len(calls)
+    mb.unload()
+    assert ExLlamaV2._live_on_device[str(torch.device(be.device))] == base
+    if base == 0:
+        assert len(calls) == n_before + 1                           # the last one out released the scratch
+    ma.unload()                                                      # unloading twice is harmless
+    assert ExLlamaV2._live_on_device[str(torch.device(be.device))] == base
