@@ -186,14 +186,19 @@ def oracle_for_parity(cfg, ck, layers: int = 2):
     return OracleModel(ocfg, keep)
 
 
-def parity_check(model, oracle, device, n_decode: int = 6):
+def parity_check(model, oracle, device, n_decode: int = 6, cache_type: str = "fp16"):
     """Before anything is timed, on the first layers + head of the very checkpoint the bench times: a 4-token prompt through
     `model.forward` (the prefill route), then `n_decode` greedy steps through **GreedyGraphDecoder -- the captured chain the
     timed region replays** (same kernels, same graph mechanism; `route` in the result says which decode route it took).
     Every step's device logits (`dec.logits`) must match the oracle within the model-level fp16 tolerance of
     tests/test_model.py (0.03 + |x| 2^-8); the device's own greedy token must be the oracle's wherever the oracle's
     top-1 / top-2 margin exceeds 4x that tolerance, and at least 3 steps must be that confident (the synthetic head is
-    structured for it: exllamav2_amd/synth.py)."""
+    structured for it: exllamav2_amd/synth.py).
+
+    cache_type "q4" (configs[3]): the check runs THROUGH an ExLlamaV2Cache_Q4 -- the cache type the timed region uses -- against
+    OracleModel.forward(q4_cache=True) (the reference's cache.py:472-556 semantics); after every step the oracle adopts the
+    device's codes (a 4-bit quantizer is discontinuous: oracle/model.py:q4_adopt) and the fraction of codes that differed from
+    the oracle's own is bounded."""
     import numpy as np
     import torch
     from exllamav2_amd import ExLlamaV2Cache, GreedyGraphDecoder
@@ -201,9 +206,28 @@ def parity_check(model, oracle, device, n_decode: int = 6):
     full = model.layers
     model.layers = full[:layers]
     dec = None
+    q4 = cache_type == "q4"
+    worst_flip = 0.0
     try:
-        cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=256)
+        if q4:
+            from exllamav2_amd.cache import ExLlamaV2Cache_Q4
+            cache = ExLlamaV2Cache_Q4(model, batch_size=1, max_seq_len=256)
+            cache.key_scales, cache.value_scales = cache.key_scales[:layers], cache.value_scales[:layers]
+        else:
+            cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=256)
         cache.key_states, cache.value_states = cache.key_states[:layers], cache.value_states[:layers]
+
+        def follow_codes(n_tokens, what):
+            nonlocal worst_flip
+            if not q4:
+                return
+            torch.cuda.synchronize()
+            for layer in range(layers):
+                f = oracle.q4_adopt(layer, cache.key_states[layer].cpu().numpy(), cache.key_scales[layer].cpu().numpy(),
+                                    cache.value_states[layer].cpu().numpy(), cache.value_scales[layer].cpu().numpy(), n_tokens)
+                worst_flip = max(worst_flip, f)
+                if f > 0.01:
+                    raise SystemExit(f"[bench] parity check FAILED at {what}: {f:.4f} of the Q4 cache codes of layer {layer} differ from the oracle's")
         ids = np.array([[1, 15043, 3186, 29892]]) % model.config.vocab_size
         oracle.reset(1)
         worst, checked, tok_checked = 0.0, 0, 0
@@ -217,9 +241,10 @@ def parity_check(model, oracle, device, n_decode: int = 6):
             if not np.all(err <= tol):
                 raise SystemExit(f"[bench] parity check FAILED at {what}: max |logit - oracle| = {err.max():.4f}")
 
-        want = oracle.forward(ids)[:, -1]
+        want = oracle.forward(ids, q4_cache=q4)[:, -1]
         got = model.forward(torch.from_numpy(ids), cache).float().cpu().numpy()[:, -1].astype(np.float64)
         compare(got, want, "the prompt")
+        follow_codes(ids.shape[1], "the prompt")
         tok = int(want[0].argmax())
         dec = GreedyGraphDecoder(model, cache, batch_size=1).capture()
         route = "chain (qgemv chain kernels, one HIP graph per step)" if dec.chain is not None else "module by module"
@@ -227,9 +252,10 @@ def parity_check(model, oracle, device, n_decode: int = 6):
         for step in range(n_decode):
             dec.run(1)
             torch.cuda.synchronize()
-            want = oracle.forward(np.array([[tok]]))[:, -1]
+            want = oracle.forward(np.array([[tok]]), q4_cache=q4)[:, -1]
             got = dec.logits.float().cpu().numpy()[:, :model.config.vocab_size].astype(np.float64)
             compare(got, want, f"decode step {step}")
+            follow_codes(ids.shape[1] + step + 1, f"decode step {step}")
             dev_tok = int(dec.tokens(ids.shape[1] + step, 1).cpu().numpy()[0, 0])
             top2 = np.sort(want[0])[-2:]
             if top2[1] - top2[0] > 0.12:
@@ -244,14 +270,22 @@ def parity_check(model, oracle, device, n_decode: int = 6):
         if dec is not None:
             dec.free()
         model.layers = full
-    return {"layers": layers, "steps": 1 + n_decode, "decode_route": route, "logits_checked": checked, "worst_err_over_tol": round(worst, 3),
-            "confident_tokens_equal": tok_checked, "tolerance": "0.03 + |x| * 2^-8 (fp16, tests/test_model.py)"}
+    res = {"layers": layers, "steps": 1 + n_decode, "decode_route": route, "cache": cache_type, "logits_checked": checked,
+           "worst_err_over_tol": round(worst, 3), "confident_tokens_equal": tok_checked,
+           "tolerance": "0.03 + |x| * 2^-8 (fp16, tests/test_model.py)"}
+    if q4:
+        res["q4_codes_differing_from_oracle_max_frac"] = round(worst_flip, 5)
+        res["oracle"] = "OracleModel.forward(q4_cache=True): cache.py:472-556 semantics, following the device's codes step by step"
+    return res
 
 
-def prefill_parity_check(model, oracle, ids):
+def prefill_parity_check(model, oracle, ids, tail: int = 128):
     """The prefill leg's kernels against the oracle: the SAME [batch, seq] call shape the leg times (so the same row counts reach
-    the same dequantize-into-MFMA / flash-prefill variants) through the first layers + head; last-position logits of sequence 0
-    vs the oracle run on that sequence alone (causal attention: sequences are independent)."""
+    the same dequantize-into-MFMA / flash-prefill variants) through the first layers + head; last-position logits of EVERY
+    sequence (their rows sit in different M-tiles of the same launches, and each sequence attends over its own seq K/V rows).
+    To keep the float64 oracle affordable the check's sequences share their first seq - `tail` tokens: the oracle runs the
+    common prefix once and every sequence's own tail on top of it (causal attention: exactly what the device computed for that
+    sequence); the device gets no such help -- it runs all batch x seq rows."""
     import numpy as np
     import torch
     from exllamav2_amd import ExLlamaV2Cache
@@ -260,20 +294,33 @@ def prefill_parity_check(model, oracle, ids):
     model.layers = full[:layers]
     try:
         b, s = ids.shape
+        tail = min(tail, s - 1)
+        ids = ids.clone()
+        ids[1:, :s - tail] = ids[0, :s - tail]
         cache = ExLlamaV2Cache(model, batch_size=b, max_seq_len=s)
         cache.key_states, cache.value_states = cache.key_states[:layers], cache.value_states[:layers]
-        got = model.forward(ids, cache, last_id_only=True).float().cpu().numpy()[0, -1].astype(np.float64)
+        got = model.forward(ids, cache, last_id_only=True).float().cpu().numpy()[:, -1].astype(np.float64)       # [b, vocab]
+        want = np.zeros_like(got)
+        ids_np = ids.cpu().numpy()
         oracle.reset(1)
-        want = oracle.forward(ids[:1].cpu().numpy())[0, -1]
+        oracle.forward(ids_np[:1, :s - tail])                # the shared prefix: fills the oracle's K/V rows [0, s - tail)
+        for i in range(b):
+            oracle.seq_len = s - tail                         # (rows >= s - tail are overwritten by this sequence's own tail)
+            want[i] = oracle.forward(ids_np[i:i + 1, s - tail:])[0, -1]
         err = np.abs(got - want)
         tol = 0.03 + np.abs(want) * 2.0 ** -8
         if not np.all(err <= tol):
-            raise RuntimeError(f"prefill parity check FAILED: max |logit - oracle| = {err.max():.4f} (not timed)")
+            bad = sorted(set(np.nonzero(err > tol)[0].tolist()))
+            raise RuntimeError(f"prefill parity check FAILED: max |logit - oracle| = {err.max():.4f} in sequences {bad} (not timed)")
         del cache
     finally:
         model.layers = full
-    return {"layers": layers, "rows": int(ids.numel()), "logits_checked": int(want.size), "worst_err_over_tol": round(float((err / tol).max()), 3),
-            "token_equal": bool(int(got.argmax()) == int(want.argmax())), "tolerance": "0.03 + |x| * 2^-8"}
+    top2 = np.sort(want, axis=-1)[:, -2:]
+    conf = (top2[:, 1] - top2[:, 0]) > 0.12
+    return {"layers": layers, "rows": int(ids.numel()), "sequences_checked": int(b), "logits_checked": int(want.size),
+            "worst_err_over_tol": round(float((err / tol).max()), 3),
+            "tokens_equal_where_confident": f"{int((got.argmax(-1) == want.argmax(-1))[conf].sum())} of {int(conf.sum())}",
+            "tolerance": "0.03 + |x| * 2^-8"}
 
 
 def pmc_traffic_gb(launches_per_step, kernel_prefix: str):
@@ -629,7 +676,7 @@ def main():
         model = ExLlamaV2(cfg, device=device).load(ck)
         torch.cuda.synchronize()
         t_load = time.perf_counter() - t_load
-        parity = parity_check(model, oracle, device) if do_parity else None
+        parity = parity_check(model, oracle, device, cache_type=args.cache) if do_parity else None
         del oracle
         if args.cache == "q4":
             from exllamav2_amd.cache import ExLlamaV2Cache_Q4

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "exl2_chain_overlap_begin": (ci, [vp, ci, vp, vp]),
     "exl2_chain_overlap_end": (ci, [C.POINTER(ci)]),
     "exl2_chain_route_counts": (ci, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), ci]),
+    "exl2_prefill_route_info": (ci, [C.POINTER(ci)]),
     # graphs
     "exl2_graph_begin_capture": (ci, [vp]),
     "exl2_graph_end_capture": (ci, [vp, C.POINTER(vp)]),

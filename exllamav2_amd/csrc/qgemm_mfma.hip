@@ -471,9 +471,13 @@ KERNEL void __launch_bounds__(MF_THREADS, 2) qgemm_mfma_kernel(const PrefillArgs
 
 // ---- host ---------------------------------------------------------------------------------------------------------------
 
+// the variant the last call of this process took (exl2_prefill_route_info: tests assert the route they forced)
+static int g_last_route[4] = {0, 0, 0, 0};                 // rows, tile rows / 32 (MT), weights pre-decoded (wfrag_kernel) 0 / 1, calls
+
 template <bool GPTQ, int MT, bool WPRE = false>
 static int launch_one(const PrefillArgs& p, void* stream)
 {
+    g_last_route[0] = p.M; g_last_route[1] = MT; g_last_route[2] = WPRE ? 1 : 0; g_last_route[3]++;
     const int nb_n = (p.m.N + MF_BN - 1) / MF_BN, nb_m = (p.M + 32 * MT - 1) / (32 * MT);
     EXL2_REQUIRE((p.m.K >> 5) <= MF_MAX_CHUNKS, "q_gemm (prefill): K = %d too large for the group map in LDS", p.m.K);
     const size_t lds = 0;                               // all LDS is static
@@ -508,17 +512,31 @@ int qgemm_mfma_launch(const PrefillArgs& p, bool gptq, void* stream)
         for (int r = 0; r < n_items; r++) supers += p.m.runs[r].n_super > 0 ? p.m.runs[r].n_super : 0;
         if (supers > 0 && supers <= 65535)
         {
+            // the fragment images are K * N * 2 bytes of per-(device, stream) scratch kept until exl2_release_scratch (470 MB for
+            // a 70B gate / up matrix, 2 GB for an 8192 x 128256 head): above a cap, or when the allocation fails, the call
+            // decodes inside the GEMM instead (no scratch) -- slower, never an error a caller did not have before this route
             f16* buf = nullptr;
             const size_t bytes = (size_t)nb_n * (size_t)(2 * supers) * MF_W_STAGE;
-            const int rc = prefill_scratch(bytes, stream, 1, &buf);
-            if (rc) return rc;
+            size_t cap = (size_t)1 << 30;
+            if (const char* e = getenv("EXL2_PREFILL_WPRE_MAX_BYTES")) cap = (size_t)strtoull(e, nullptr, 10);
+            const bool fits = bytes <= cap && prefill_scratch(bytes, stream, 1, &buf) == EXL2_OK;
+            if (!fits) { exl2_set_error("%s", ""); buf = nullptr; }
+            if (buf)
+            {
             if (gptq) LAUNCH((wfrag_kernel<true>), dim3((unsigned)nb_n, (unsigned)supers), dim3(MF_THREADS), 0, stream, p.m, (u8*)buf, 2 * supers);
             else      LAUNCH((wfrag_kernel<false>), dim3((unsigned)nb_n, (unsigned)supers), dim3(MF_THREADS), 0, stream, p.m, (u8*)buf, 2 * supers);
             PrefillArgs q = p;
             q.wfrag = (const u8*)buf; q.wfrag_steps = 2 * supers;
             return mt == 8 ? launch_one<false, 8, true>(q, stream) : launch_one<false, 4, true>(q, stream);
+            }
         }
     }
     if (gptq) return mt == 8 ? launch_one<true, 8>(p, stream) : launch_one<true, 4>(p, stream);
     return mt == 8 ? launch_one<false, 8>(p, stream) : launch_one<false, 4>(p, stream);
+}
+
+extern "C" int exl2_prefill_route_info(int* out4)
+{
+    if (out4) for (int i = 0; i < 4; i++) out4[i] = g_last_route[i];
+    return EXL2_OK;
 }

@@ -597,6 +597,12 @@ class ExtC:
         self.lib.check(self.lib.exl2_chain_route_counts(C.byref(a), C.byref(b), 1 if reset else 0))
         return a.value, b.value
 
+    def prefill_route_info(self):
+        """(rows, tile rows, weights pre-decoded by wfrag_kernel, calls so far) of the last prefill q_gemm call (>= 129 rows)"""
+        out = (C.c_int * 4)()
+        self.lib.check(self.lib.exl2_prefill_route_info(out))
+        return out[0], out[1] * 32, bool(out[2]), out[3]
+
     SYNC_BLOCK_WORDS = 320
 
     def chain_overlap_begin(self, flags, stream_a, stream_b) -> None:

@@ -257,21 +257,25 @@ class GreedyGraphDecoder:
             sb = ch["stream_b"].cuda_stream if ch["stream_b"] is not None else None
             ext.chain_overlap_begin(ch["flags"], sa, sb)
         try:
-            npart = 1
+            # partial sums of squares per row a launch published: PER GROUP -- the count depends on which kernel took the launch
+            # (qgemv_lean: one per 16-column tile, qgemv_flat: one per workgroup), and a 4-row group and a 3-row group of the
+            # same matrix may be taken by different kernels (LDS budget)
+            npart = [1] * len(groups)
+            np_o = [1] * len(groups)
             for i, (attn, mlp) in enumerate(m.layers):
                 in_a, o_inv, in_m, nw_a, nw_m = plan[i]
-                for r0, r1 in groups:
-                    ext.q_attn_forward_1_chain(attn.q_handle, xp_a[r0:r1], ss_a[r0:r1], npart, r1 - r0, q[r0:r1], k[r0:r1], v[r0:r1])
+                for gi, (r0, r1) in enumerate(groups):
+                    ext.q_attn_forward_1_chain(attn.q_handle, xp_a[r0:r1], ss_a[r0:r1], npart[gi], r1 - r0, q[r0:r1], k[r0:r1], v[r0:r1])
                 ao = attn.attend_chain(q, k, v, self.cache, self.cache_seqlens, self.block_table, o_inv)
                 # every producer of the residual stream publishes it times its consumer's norm weight, in that consumer's order
-                for r0, r1 in groups:
-                    np_o = ext.q_attn_forward_2_chain(attn.q_handle, x2[r0:r1], ao[r0:r1], r1 - r0, in_m, nw_m, xp_b[r0:r1], ss_b[r0:r1])
+                for gi, (r0, r1) in enumerate(groups):
+                    np_o[gi] = ext.q_attn_forward_2_chain(attn.q_handle, x2[r0:r1], ao[r0:r1], r1 - r0, in_m, nw_m, xp_b[r0:r1], ss_b[r0:r1])
                 nxt, nxt_w = (plan[i + 1][0], plan[i + 1][3]) if i + 1 < len(plan) else (ch["head_inv"], ch["norm_head"])
-                for r0, r1 in groups:
-                    npart = ext.q_mlp_forward_chain(mlp.q_handle, x2[r0:r1], xp_b[r0:r1], ss_b[r0:r1], np_o, r1 - r0, nxt, nxt_w,
-                                                    xp_a[r0:r1], ss_a[r0:r1])
-            for r0, r1 in groups:
-                ext.gemm_half_q_half_chain(xp_a[r0:r1], ss_a[r0:r1], npart, cfg.norm_eps, m.lm_head.q_handle, self.logits[r0:r1], r1 - r0)
+                for gi, (r0, r1) in enumerate(groups):
+                    npart[gi] = ext.q_mlp_forward_chain(mlp.q_handle, x2[r0:r1], xp_b[r0:r1], ss_b[r0:r1], np_o[gi], r1 - r0, nxt, nxt_w,
+                                                        xp_a[r0:r1], ss_a[r0:r1])
+            for gi, (r0, r1) in enumerate(groups):
+                ext.gemm_half_q_half_chain(xp_a[r0:r1], ss_a[r0:r1], npart[gi], cfg.norm_eps, m.lm_head.q_handle, self.logits[r0:r1], r1 - r0)
         finally:
             n_launches = ext.chain_overlap_end() if overlap else 0
         # greedy sampling + position increment behind the head: on the stream the head went to
@@ -430,6 +434,9 @@ class GreedyGraphDecoder:
                 self.graph = greedy_graph
                 self._sampling = None
         sm["counter"].zero_()
+        old = getattr(self, "_sampled", None)
+        if old is not None and old.get("graph") is not None:
+            ext.graph_free(old["graph"])                          # a re-capture with new settings replaces the old sampled graph
         self._sampled = sm
         return self
 
@@ -500,7 +507,7 @@ class GreedyGraphDecoder:
         sm = getattr(self, "_sampled", None)
         if sm is not None and sm.get("graph") is not None:
             self.model.ext.graph_free(sm["graph"])
-            self._sampled = None
+        self._sampled = None
         if self.graph is not None:
             self.model.ext.graph_free(self.graph)
             self.graph = None

@@ -252,6 +252,11 @@ int exl2_chain_overlap_begin(void* flags, int n_blocks, void* stream_a, void* st
    bench.py (no reference counterpart). */
 int exl2_chain_route_counts(long long* lean, long long* flat, int reset);
 int exl2_chain_overlap_end(int* n_launches);
+/* which variant of the prefill q_gemm (csrc/qgemm_mfma.hip, >= 129 rows) the LAST call of this process took: out4 = {rows, tile
+   rows / 32 (8 = 256-row tile, 4 = 128-row tile), 1 when the weights were decoded once per call by wfrag_kernel / 0 when inside
+   the GEMM, number of calls so far}.  Diagnostics for tests that force a variant (no reference counterpart; the reference's
+   dispatch is q_gemm.cu:201-313). */
+int exl2_prefill_route_info(int* out4);
 
 /* ---- decode-loop utilities and graphs (replace cuda/graph.cu and the host-side embedding / argmax round trips) ------- */
 

@@ -58,6 +58,71 @@ class OracleModel:
         self.k_cache = np.zeros(shape, dtype=F16)
         self.v_cache = np.zeros(shape, dtype=F16)
         self.seq_len = 0
+        # Q4 cache state (ExLlamaV2Cache_Q4, cache.py:409-470): codes + one fp16 scale per 32 elements per layer, and ONE fp16
+        # temp pair shared by all layers (cache.py:464-469) -- created on first use by forward(q4_cache=True)
+        self.q4 = None
+
+    def _q4_state(self, batch: int):
+        c = self.cfg
+        if self.q4 is None:
+            kv_dim = c.num_key_value_heads * c.head_dim
+            q_block = 1                                                    # cache.py:452-457
+            while (kv_dim * q_block) % 512:
+                q_block += 1
+            T = (c.max_seq_len + q_block - 1) // q_block * q_block
+            L = c.num_hidden_layers
+            self.q4 = dict(
+                q_block=q_block, kv_dim=kv_dim,
+                k_codes=np.zeros((L, batch, T * kv_dim // 2), dtype=np.uint8), v_codes=np.zeros((L, batch, T * kv_dim // 2), dtype=np.uint8),
+                k_scales=np.zeros((L, batch, T * kv_dim // 32), dtype=F16), v_scales=np.zeros((L, batch, T * kv_dim // 32), dtype=F16),
+                temp_k=np.zeros((batch, T * kv_dim), dtype=F16), temp_v=np.zeros((batch, T * kv_dim), dtype=F16))
+        return self.q4
+
+    def _q4_get(self, layer: int, past: int):
+        """ExLlamaV2Cache_Q.get_kv_state(layer, b, 0, past) (cache.py:472-514): the live range, widened to whole q_blocks of
+        tokens, is dequantized into the shared temp pair (q_to_fp16_kv_kernel, cache.cu:372-400); width 0 unpacks nothing."""
+        st = self.q4
+        if past == 0:
+            return
+        qb, d = st["q_block"], st["kv_dim"]
+        hi = (past + qb - 1) // qb * qb
+        for side in ("k", "v"):
+            for r in range(st["temp_" + side].shape[0]):
+                st["temp_" + side][r, :hi * d] = OM.q4_unpack(st[side + "_codes"][layer, r, :hi * d // 2], st[side + "_scales"][layer, r, :hi * d // 32])
+
+    def _q4_store(self, layer: int, past: int, s: int):
+        """store_kv_state(layer, b, past, s) (cache.py:517-556): the touched token range, widened to whole q_blocks, is
+        re-quantized from the temp pair (fp16_to_q_kv_kernel, cache.cu:196-220) -- earlier tokens of a shared block are
+        re-quantized from their DEQUANTIZED values, like the reference does."""
+        st = self.q4
+        qb, d = st["q_block"], st["kv_dim"]
+        lo = past // qb * qb
+        hi = (past + s + qb - 1) // qb * qb
+        for side in ("k", "v"):
+            for r in range(st["temp_" + side].shape[0]):
+                codes, scales = OM.q4_pack(st["temp_" + side][r, lo * d:hi * d])
+                st[side + "_codes"][layer, r, lo * d // 2:hi * d // 2] = codes
+                st[side + "_scales"][layer, r, lo * d // 32:hi * d // 32] = scales
+
+    def q4_adopt(self, layer: int, k_codes, k_scales, v_codes, v_scales, n_tokens: int) -> float:
+        """Checker's side of "follow the device": replaces the oracle's Q4 state of `layer`, tokens [0, n_tokens), by what the
+        path under test left in ITS cache (uint8 codes [b, ...], fp16 scales [b, ...], any trailing shape) and returns the
+        fraction of 4-bit codes that differed.  A 4-bit quantizer is discontinuous: a K/V element one fp16 ulp off flips a
+        code at a rounding boundary, and from then on the two caches hold different values -- a multi-step comparison must
+        either follow the device's codes (this) or accept a tolerance that grows with every step."""
+        st = self.q4
+        d = st["kv_dim"]
+        b = st["temp_k"].shape[0]
+        diff, total = 0, 0
+        for side, codes, scales in (("k", k_codes, k_scales), ("v", v_codes, v_scales)):
+            gc = np.asarray(codes).reshape(b, -1)[:, :n_tokens * d // 2]
+            gs = np.asarray(scales).reshape(b, -1)[:, :n_tokens * d // 32]
+            wc = st[side + "_codes"][layer][:, :n_tokens * d // 2]
+            diff += int(((gc & 0xF) != (wc & 0xF)).sum() + ((gc >> 4) != (wc >> 4)).sum())
+            total += 2 * gc.size
+            st[side + "_codes"][layer][:, :n_tokens * d // 2] = gc
+            st[side + "_scales"][layer][:, :n_tokens * d // 32] = gs.astype(F16)
+        return diff / max(total, 1)
 
     def forward(self, ids: np.ndarray, q4_cache: bool = False) -> np.ndarray:
         """ids int [b, q_len] -> logits float64 [b, q_len, vocab] (before the final fp16 rounding)."""
@@ -74,13 +139,22 @@ class OracleModel:
             pos = np.full((b,), past)
             q = OM.rope_(q, self.sin, self.cos, pos, c.rope_style == 2)
             k = OM.rope_(k, self.sin, self.cos, pos, c.rope_style == 2)
-            self.k_cache[i, :, past:past + s] = k
-            self.v_cache[i, :, past:past + s] = v
             if q4_cache:
-                # cache.py:517-556: the touched 512-element blocks are re-quantized after every step and the next step
-                # reads the dequantized values (cache.py:472-514); the current step attends over fp16 new tokens.
-                pass
-            a = OM.attention(q, self.k_cache[i, :, :past + s], self.v_cache[i, :, :past + s])
+                # attn.py:1108-1196 over an ExLlamaV2Cache_Q4: earlier tokens are read back DEQUANTIZED, the step's own K/V
+                # sit in the temp pair in fp16 while it attends, and are quantized into the codes afterwards
+                st = self._q4_state(b)
+                d = st["kv_dim"]
+                self._q4_get(i, past)
+                st["temp_k"][:, past * d:(past + s) * d] = k.reshape(b, s * d)
+                st["temp_v"][:, past * d:(past + s) * d] = v.reshape(b, s * d)
+                kk = st["temp_k"][:, :(past + s) * d].reshape(b, past + s, c.num_key_value_heads, c.head_dim)
+                vv = st["temp_v"][:, :(past + s) * d].reshape(b, past + s, c.num_key_value_heads, c.head_dim)
+                a = OM.attention(q, kk, vv)
+                self._q4_store(i, past, s)
+            else:
+                self.k_cache[i, :, past:past + s] = k
+                self.v_cache[i, :, past:past + s] = v
+                a = OM.attention(q, self.k_cache[i, :, :past + s], self.v_cache[i, :, :past + s])
             a = a.reshape(b * s, c.num_attention_heads * c.head_dim)
             x = (x.astype(np.float64) + self.linear(a, p + ".self_attn.o_proj")).astype(F16)
             n = OM.rms_norm(x, self.w[p + ".post_attention_layernorm"], c.norm_eps)

@@ -180,6 +180,43 @@ def test_q4_cache_direct_attention_equals_unpack_route(be):
     ma.unload(); mb.unload()
 
 
+@pytest.mark.parametrize("kvh,hd,fused", [(4, 128, True), (4, 128, False), (1, 64, False), (2, 128, False)])
+def test_q4_cache_model_equals_q4_oracle(be, kvh, hd, fused):
+    """Prefill + decode on an ExLlamaV2Cache_Q4 through model.forward (contiguous cache, attn.py:1017-1196) against
+    OracleModel.forward(q4_cache=True) = the reference's cache semantics (cache.py:472-556), including the widening of the
+    touched range to whole q_blocks of tokens when a token is smaller than a 512-element codec block (kv_dim 64 -> 8 tokens,
+    256 -> 2).  Both the attention-from-codes route and the unpack route; the oracle follows the device's codes from step to
+    step (oracle/model.py:q4_adopt), every step at the model tolerance."""
+    cfg = tiny_cfg(hidden_size=256, num_attention_heads=max(kvh, 2) if hd == 128 else 4, num_key_value_heads=kvh, head_dim=hd,
+                   num_hidden_layers=2, intermediate_size=128)
+    ck = synth_checkpoint(cfg, be.device, seed=7)
+    oracle = OracleModel(cfg, ck)
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    for attn, _ in model.layers:
+        attn.q4_fused = fused
+    cache = ExLlamaV2Cache_Q4(model, batch_size=2)
+    oracle.reset(2)
+    rng = np.random.default_rng(7)
+    ids = rng.integers(0, cfg.vocab_size, size=(2, 11))
+    past = 0
+
+    def step(chunk):
+        nonlocal past
+        got = be.n(model.forward(torch.from_numpy(chunk), cache, last_id_only=False))
+        want = oracle.forward(chunk, q4_cache=True)
+        check_logits(got[..., :cfg.vocab_size], want)
+        past += chunk.shape[1]
+        for layer in range(cfg.num_hidden_layers):
+            flipped = oracle.q4_adopt(layer, be.n(cache.key_states[layer]), be.n(cache.key_scales[layer]),
+                                      be.n(cache.value_states[layer]), be.n(cache.value_scales[layer]), past)
+            assert flipped < 0.01, (past, layer, flipped)
+
+    step(ids)                                                 # prefill: 11 tokens (an odd count: partial q_blocks)
+    for t in (5, 9, 3):
+        step(np.array([[t], [t + 1]]))
+    model.unload()
+
+
 def test_q4_cache_decode_close_to_fp16(be):
     """Q4 KV path end to end (cache.py:409-606): logits stay close to the FP16-cache logits (doc/qcache_eval.md)."""
     cfg = tiny_cfg()

@@ -378,6 +378,44 @@ def test_attention_from_q4_cache_with_fp16_new_tokens(be, hd, nh, kvh, s):
         assert np.all(err <= _attn_tol(want) + 2e-3), (nsplit, float(err.max()))
 
 
+@pytest.mark.parametrize("hd,nh,kvh,s,paged", [(128, 4, 4, 1, True), (64, 8, 8, 1, False), (128, 8, 2, 2, True)])
+def test_attention_from_q4_cache_in_consumer_order(be, hd, nh, kvh, s, paged):
+    """exl2_paged_attn_q4(out_invperm=...): the chained decode step's form -- feature n of a token row lands at
+    out[row, out_invperm[n]] (o_proj's packed K order, q_matrix.cu:606-642 act-order), the step's own K/V attended in fp16.
+    Checker: the oracle's attention over q4_unpack of the same codes + the fp16 new rows, permuted on the host."""
+    rng = np.random.default_rng(43)
+    b, T = 2, 512
+    total = np.array([130, 400], dtype=np.int32)
+    kf = rng.standard_normal((b, T, kvh, hd)).astype(F16); vf = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    kq, ks = OM.q4_pack(kf.reshape(-1)); vq, vs = OM.q4_pack(vf.reshape(-1))
+    k_un = OM.q4_unpack(kq, ks).reshape(b, T, kvh, hd); v_un = OM.q4_unpack(vq, vs).reshape(b, T, kvh, hd)
+    kn = rng.standard_normal((b, s, kvh, hd)).astype(F16); vn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    want = []
+    for i in range(b):
+        kk = np.concatenate([k_un[i, :total[i] - s], kn[i]])[None]; vv = np.concatenate([v_un[i, :total[i] - s], vn[i]])[None]
+        want.append(OM.attention(q[i:i + 1], kk, vv)[0])
+    want = np.stack(want).reshape(b * s, nh * hd)
+    invperm = rng.permutation(nh * hd).astype(np.uint16)
+    want_p = np.zeros_like(want); want_p[:, invperm] = want                       # out[row, invperm[n]] = natural[row, n]
+    inv_t = be.t(invperm.view(np.int16))                                          # (same 16-bit patterns; the kernel reads u16)
+    scratch = torch.zeros((be.ext.paged_attn_scratch_bytes(b * s * nh, hd, 16) // 4 + 1,), dtype=torch.float32, device=be.device)
+    kqt = be.t(kq.reshape(b, T, kvh, hd // 2)); kst = be.t(ks.reshape(b, T, kvh, hd // 32))
+    vqt = be.t(vq.reshape(b, T, kvh, hd // 2)); vst = be.t(vs.reshape(b, T, kvh, hd // 32))
+    table = None
+    if paged:
+        view = lambda x: x.view(-1, 256, kvh, x.shape[-1])
+        kqt, kst, vqt, vst = view(kqt), view(kst), view(vqt), view(vst)
+        table = be.t(np.array([[0, 1], [2, 3]], dtype=np.int32))
+    for nsplit in (1, 3):
+        out = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+        assert be.ext.paged_attn_q4(be.t(q), kqt, kst, vqt, vst, out, be.t(total - s), table, len_const=0, len_offset=s,
+                                    nsplit=nsplit, scratch=scratch, k_new=be.t(kn), v_new=be.t(vn), out_invperm=inv_t.data_ptr())
+        got = be.n(out).reshape(b * s, nh * hd)
+        err = np.abs(got.astype(np.float32) - want_p.astype(np.float32))
+        assert np.all(err <= _attn_tol(want_p) + 2e-3), (nsplit, float(err.max()))
+
+
 @pytest.mark.gpu
 def test_attention_fused_handoff_stress():
     """The split hand-off (ticket + agent-scope fences) under real concurrency: many back-to-back launches on the same

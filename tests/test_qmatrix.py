@@ -125,11 +125,31 @@ def test_prefill_tile256_variant_forced(be, m, wpre, mt, monkeypatch):
     a[hot] = 0
     a[hot, hot_k] = 1.0
     c = torch.zeros((m, n), dtype=torch.float16, device=be.device)
+    calls = be.ext.prefill_route_info()[3]
     be.ext.gemm_half_q_half(be.t(a), h, c)
     got = be.n(c)
+    assert be.ext.prefill_route_info() == (m, 32 * int(mt), wpre == "1", calls + 1)      # the variant that was forced is the one that ran
     assert np.array_equal(got[hot].view(np.uint16), ref[hot_k].view(np.uint16))
     want = OX.gemm_ref(a, ref, exact=True)
     assert np.all(np.abs(got.astype(np.float64) - want) <= half_tol(want, k))
+    be.ext.free_q_matrix(h)
+
+
+def test_prefill_predecode_scratch_cap_falls_back(be, monkeypatch):
+    """The weights-decoded-once route needs K * N * 2 bytes of scratch; above the cap (or when the allocation fails) the call must
+    run with the decode inside the GEMM instead of failing -- same result bit for bit (same decoders, same rounding)."""
+    k, n, spec = SPECS["mixed_5_4"]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=23, bias=False)
+    a = np.random.default_rng(24).standard_normal((300, k)).astype(np.float16)
+    outs = []
+    for cap in (None, "1"):
+        monkeypatch.setenv("EXL2_PREFILL_WPRE_MIN_ROWS", "1")
+        if cap: monkeypatch.setenv("EXL2_PREFILL_WPRE_MAX_BYTES", cap)
+        c = torch.zeros((300, n), dtype=torch.float16, device=be.device)
+        be.ext.gemm_half_q_half(be.t(a), h, c)
+        outs.append(be.n(c).copy())
+        assert be.ext.prefill_route_info()[2] == (cap is None)
+    assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
     be.ext.free_q_matrix(h)
 
 
@@ -160,8 +180,12 @@ def test_prefill_llama2_7b_shapes_4096_rows(role, force, monkeypatch):
     a[hot] = 0
     a[hot, hot_k] = 1.0
     c = torch.zeros((m, n), dtype=torch.float16, device=be.device)
+    calls = be.ext.prefill_route_info()[3]
     be.ext.gemm_half_q_half(be.t(a), h, c)
     got = be.n(c)
+    # the variant: 256-row tile at 4096 rows (natural selection and forced alike), weights decoded once per call unless forced
+    # into the GEMM
+    assert be.ext.prefill_route_info() == (m, 256, force != "in-kernel decode", calls + 1), be.ext.prefill_route_info()
     assert np.array_equal(got[hot].view(np.uint16), ref[hot_k].view(np.uint16))
     rows = np.setdiff1d(np.arange(m), hot)[:64]
     want = a[rows].astype(np.float64) @ ref.astype(np.float64)
