@@ -696,6 +696,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
 {
     if (in.n_mats < 1 || in.n_mats > FLAT_MAX_MATS || in.M < 1 || in.M > LEAN_MAX_M) return 1;
     if (in.sync_wait || in.sync_signal || in.sync_arrive) return 1;
+    if (const char* e = getenv("EXL2_LEAN_DECLINE_M")) { if (atoi(e) == in.M) return 1; }      // test hook: row groups on different kernels
     const QMatrix* q0 = in.qm[0];
     const int K = q0->height;
     if ((K & 7) || (((size_t)in.a) & 15) || (in.lda & 7)) return 1;

@@ -196,6 +196,19 @@ def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch):
         dec.free(); model.unload()
 
 
+def test_row_groups_taken_by_different_kernels(be, monkeypatch):
+    """7 sequences as row groups 4 + 3 where the 4-row group is declined by the round-3 kernel (here: forced; in the field: its
+    LDS budget at K ~ 20 k) and goes to the round-2 kernel while the 3-row group stays: the two kernels publish different
+    numbers of partial sums of squares per row, so every group must carry ITS OWN count to its consumer."""
+    monkeypatch.setenv("EXL2_CHAIN_ROWGROUPS", "4")
+    monkeypatch.setenv("EXL2_LEAN_DECLINE_M", "4")
+    cfg = tiny_cfg(num_attention_heads=4, num_key_value_heads=2, intermediate_size=384)
+    be.ext.chain_route_counts(reset=True)
+    _decode_and_check(be, cfg, "4.0bpw", 7, steps=2, seed=12)
+    lean, flat = be.ext.chain_route_counts(reset=True)
+    assert lean > 0 and flat > 0, (lean, flat)
+
+
 # ---- op level: the chain entry points one by one ------------------------------------------------------------------------
 
 def _mk(be, k, n, spec, seed, invperm=None):
