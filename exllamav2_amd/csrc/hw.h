@@ -175,6 +175,30 @@ DEV void dma_to_lds4(const void* g_lane_ptr, void* lds_wave_base)
 DEV void wait_vmcnt_builtin0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 // wait until at most N vector-memory operations of this wave are still in flight (they complete in issue order)
 template <int N> DEV void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// The same copy as an instruction the COMPILER DOES NOT COUNT.  The compiler models a pending global_load_lds like a flat access
+// that may return out of order and answers EVERY later wait on a loaded register with vmcnt(0) -- which drains all requests a wave
+// wanted to keep in flight.  The hardware completes a wave's vector-memory operations in issue order (the counted waits of
+// qgemv_flat.hip / qgemm_mfma.hip rely on it), so a kernel that orders its LDS reads behind these copies ITSELF (fence_load below)
+// loses nothing by hiding them: an untracked copy can only make a compiler-inserted wait stricter than needed, never weaker.
+// A kernel that uses this form must not use the builtin form as well (M0 is written behind the compiler's back).
+DEV void dma_to_lds16_raw(const void* g_lane_ptr, void* lds_wave_base)
+{
+    const u32 l = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)lds_wave_base);      // (flat address of LDS: the offset is its low half)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g_lane_ptr), "s"(l) : "memory");
+}
+// A "fence load": an ordinary 4-byte vector load the COMPILER tracks, issued behind LDS-DMA copies.  Vector-memory operations
+// of a wave complete in issue order, so when this load's value is available the copies issued before it have landed in LDS;
+// fence_load_use() makes the compiler wait for exactly this load -- it inserts `s_waitcnt vmcnt(n)` with n = the number of
+// vector-memory INSTRUCTIONS it scheduled behind the load (whatever their widths), which a hand-written count could get wrong.
+// Loads issued behind the fence load therefore stay in flight across the wait.  (The compiler does not order a ds_read behind
+// a pending global_load_lds by itself on this toolchain.)
+DEV u32 fence_load(const u32* p)
+{
+    asm volatile("" ::: "memory");                    // the LDS-DMA builtins above stay above
+    const u32 v = *p;
+    return v;
+}
+DEV void fence_load_use(u32 v) { asm volatile("" :: "v"(v) : "memory"); }
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for every
 // prefetched weight load of the wave before letting anybody pass
 DEV void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -46,6 +46,14 @@
 #ifndef LEAN_LOWBITS
 #define LEAN_LOWBITS 1                // 0: no 2 / 3-bit register stream (code-size experiment; such segments would be wrong)
 #endif
+#ifndef LEAN_RAW_DMA
+#define LEAN_RAW_DMA 1                // the wave-private staging copies as instructions the compiler does not count (hw.h: dma_to_lds16_raw)
+#endif
+#if LEAN_RAW_DMA
+#define LEAN_DMA dma_to_lds16_raw
+#else
+#define LEAN_DMA dma_to_lds16
+#endif
 #define LEAN_MAX_WAVES 16
 #define LEAN_RECORDS 48               // wave records in the argument block: matrices x waves per tile (q|k|v at 16 waves)
 #define LEAN_MAX_PASSES 4             // 16-wave geometry: a wave's share may be this many register loads (qgemv_lean_kernel, further passes)
@@ -61,7 +69,7 @@ struct alignas(64) LeanWave
 {
     u32 w_off, w_tstride;             // full items: word offset of the first one for tile 0 in qw, words between consecutive tiles
     u32 t_off, t_tstride;             // the partial item: the same in the side buffer
-    u32 meta;                         // n (0..7) | bits (8..11) | nvalid of the partial item, 0 = none (12..14) | uniform (15) | gshift (16..18) | gphase (19..28)
+    u32 meta;                         // n (0..7) | bits (8..11) | nvalid of the partial item, 0 = none (12..14) | uniform (15) | gshift (16..18) | gphase (19..28) | pipelined form off (29)
     u32 xr;                           // first chunk (0..15) | number of chunks (16..31) of the activation slice
     u32 gr;                           // first scale-table row (0..15) | number of rows (16..31)
     u32 lds_off;                      // byte offset of the wave's LDS area inside its slot's area
@@ -105,6 +113,16 @@ template <int BITS, int S> struct LeanDepth
 {
     static constexpr int v = S == 4 ? (BITS == 8 ? 4 : BITS == 6 ? 5 : BITS == 5 ? 6 : BITS == 2 ? 10 : 8)
                                     : (BITS == 8 ? 3 : BITS == 6 ? 4 : BITS == 5 ? 5 : BITS == 4 ? 6 : BITS == 2 ? 10 : 8);
+};
+// how many of those (the LAST ones of a share) are requested behind the fence load and decoded one by one as they land
+// (qgemv_lean_kernel: head); 0 = the round-3 form only.  LEAN_PIPE: 0 off, 1 = D / 2, 2 = D - 2 (at least 1)
+#ifndef LEAN_PIPE
+#define LEAN_PIPE 2
+#endif
+template <int BITS, int S> struct LeanTail
+{
+    static constexpr int D = LeanDepth<BITS, S>::v;
+    static constexpr int v = LEAN_PIPE == 0 ? 0 : LEAN_PIPE == 1 ? D / 2 : (D - 2 > 1 ? D - 2 : 1);
 };
 static int lean_depth(int bits, int S)
 {
@@ -280,6 +298,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     const bool active = tile < n_tiles;
     const u32 meta = active ? meta_ : 0u;
     const int n = (int)(meta & 0xFFu), bits = (int)((meta >> 8) & 0xFu), tail_nv = (int)((meta >> 12) & 0x7u);
+    const bool pipe_on = ((meta_ >> 29) & 1u) == 0;                       // (bit 29 of every record: the host's EXL2_LEAN_PIPE=0 switch)
     const int t_ = active ? tile : 0;
     const u32* const wptr = (const u32*)ptr_of(m0.x, m0.y) + w0.x + (size_t)t_ * w0.y;
     const u32* const tptr = (const u32*)ptr_of(m0.z, m0.w) + w0.z + (size_t)t_ * w0.w;
@@ -324,22 +343,22 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         const f16* const st = sc_tab + ((size_t)t_ * G + gw0) * 16;
         if (M == 1 && xunits <= (S == 4 ? 128 : 64) && sc_units <= 64)
         {
-            if (lane < sc_units) dma_to_lds16(st + (size_t)lane * 8, (u8*)sc_lds);
-            if constexpr (GPTQ) { if (lane < sc_units) dma_to_lds16(zp_tab + ((size_t)t_ * G + gw0) * 16 + (size_t)lane * 8, (u8*)zp_lds); }
-            if (lane < xunits && xu0 + lane < oct) dma_to_lds16(in_a + (size_t)(xu0 + lane) * 8, (u8*)x_lds);
-            if constexpr (S == 4) { if (64 + lane < xunits && xu0 + 64 + lane < oct) dma_to_lds16(in_a + (size_t)(xu0 + 64 + lane) * 8, (u8*)x_lds + 1024); }
+            if (lane < sc_units) LEAN_DMA(st + (size_t)lane * 8, (u8*)sc_lds);
+            if constexpr (GPTQ) { if (lane < sc_units) LEAN_DMA(zp_tab + ((size_t)t_ * G + gw0) * 16 + (size_t)lane * 8, (u8*)zp_lds); }
+            if (lane < xunits && xu0 + lane < oct) LEAN_DMA(in_a + (size_t)(xu0 + lane) * 8, (u8*)x_lds);
+            if constexpr (S == 4) { if (64 + lane < xunits && xu0 + 64 + lane < oct) LEAN_DMA(in_a + (size_t)(xu0 + 64 + lane) * 8, (u8*)x_lds + 1024); }
         }
         else
         {
             #pragma nounroll
             for (int base = 0; base < sc_units; base += 64)
-                if (base + lane < sc_units) dma_to_lds16(st + (size_t)(base + lane) * 8, (u8*)sc_lds + (size_t)base * 16);
+                if (base + lane < sc_units) LEAN_DMA(st + (size_t)(base + lane) * 8, (u8*)sc_lds + (size_t)base * 16);
             if constexpr (GPTQ)
             {
                 const f16* zt = zp_tab + ((size_t)t_ * G + gw0) * 16;
                 #pragma nounroll
                 for (int base = 0; base < sc_units; base += 64)
-                    if (base + lane < sc_units) dma_to_lds16(zt + (size_t)(base + lane) * 8, (u8*)zp_lds + (size_t)base * 16);
+                    if (base + lane < sc_units) LEAN_DMA(zt + (size_t)(base + lane) * 8, (u8*)zp_lds + (size_t)base * 16);
             }
             #pragma nounroll
             for (int rr = 0; rr < M; rr++)
@@ -347,7 +366,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                 #pragma nounroll
                 for (int base = 0; base < xunits; base += 64)
                     if (base + lane < xunits && xu0 + base + lane < oct)
-                        dma_to_lds16(in_a + (size_t)rr * lda + (size_t)(xu0 + base + lane) * 8, (u8*)(x_lds + (size_t)rr * x_stride) + (size_t)base * 16);
+                        LEAN_DMA(in_a + (size_t)rr * lda + (size_t)(xu0 + base + lane) * 8, (u8*)(x_lds + (size_t)rr * x_stride) + (size_t)base * 16);
             }
         }
     };
@@ -355,45 +374,67 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     // ---- the wave's items: everything requested at once into registers, decoded item by item ------------------------------------
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     Rest R;
-    auto head = [&](auto bits_tag) {
+    // NB = the LAST NB full items of the wave's share are requested unconditionally, behind the LDS-DMA copies and the fence load
+    // (hw.h): the wave waits for the fence load only -- i.e. for its first n - NB items, its activation slice and its scale rows
+    // -- and decodes those while the last NB items are still in flight, then each of them when IT has landed (the compiler's own
+    // counted waits: unconditional loads in straight-line code).  NB = 0 is the round-3 form: one wait for everything.  The
+    // conditional requests (q < nA) must come first: the compiler has to assume the smallest count behind them.
+    auto head = [&](auto bits_tag, auto nb_tag) {
         constexpr int BITS = decltype(bits_tag)::value;
+        constexpr int NB = decltype(nb_tag)::value;
         constexpr int D = LeanDepth<BITS, S>::v;
+        constexpr int DA = D - NB;
         constexpr size_t STEP = 64 * BITS;
-        LaneWords<BITS> b[D], bt;
+        LaneWords<BITS> a[DA > 0 ? DA : 1], b[NB > 0 ? NB : 1], bt;
+        const int nA = n - NB;
         #pragma unroll
-        for (int q = 0; q < D; q++) if (q < n) load_lane_words<BITS>(wptr + (size_t)q * STEP, lane, b[q]);
+        for (int q = 0; q < DA; q++) if (q < nA) load_lane_words<BITS>(wptr + (size_t)q * STEP, lane, a[q]);
         if (tail_nv) load_lane_words<BITS>(tptr, lane, bt);
         LTRACE(2);
         prologue_rest(R);
         LTRACE(3);
-        wait_vmcnt_le<0>();                  // everything landed (weights first, the LDS-DMA copies behind them)
+        const u32 fence = fence_load(wptr);
+        sched_fence();
+        if constexpr (NB > 0)
+        {
+            const u32* const bptr = wptr + (size_t)nA * STEP;
+            #pragma unroll
+            for (int q = 0; q < NB; q++) load_lane_words<BITS>(bptr + (size_t)q * STEP, lane, b[q]);
+            sched_fence();
+        }
+        fence_load_use(fence);               // the first part, the activation slice and the scale rows have landed
         wave_converge();
         LTRACE(4);
+        auto item = [&](const LaneWords<BITS>& w, int q) {
+            if (R.uni) lean_item_uniform<BITS, GPTQ>(w, R.cx, R.chunk0 + 4 * q, R.g0 + ((4 * q + R.gphase) >> R.gshift), lane, acc);
+            else lean_item_general<BITS, GPTQ>(w, R.cx, R.chunk0 + 4 * q, 4 * q, R.g0, R.gshift, R.gphase, 4, lane, acc);
+            sched_fence();
+        };
         if (LEAN_KILL & 8)
         {
             // timing experiment: the loads stay, the decode is an xor (what does the launch cost without the decode's VALU work?)
             u32 xr = 0;
             #pragma unroll
-            for (int q = 0; q < D; q++) if (q < n) { for (int e = 0; e < BITS; e++) xr ^= b[q].w[e]; }
+            for (int q = 0; q < DA; q++) if (q < nA) { for (int e = 0; e < BITS; e++) xr ^= a[q].w[e]; }
+            #pragma unroll
+            for (int q = 0; q < NB; q++) { for (int e = 0; e < BITS; e++) xr ^= b[q].w[e]; }
             if (tail_nv) for (int e = 0; e < BITS; e++) xr ^= bt.w[e];
             acc[0] = __builtin_bit_cast(float, xr & 0x3fffffffu) + (float)R.cx.x_lds[lane] + (float)R.cx.sc_lds[lane & 15];
         }
         else if (LEAN_KILL & 1) { }
-        else if (R.uni)
-        {
-            #pragma unroll
-            for (int q = 0; q < D; q++)
-                if (q < n) { lean_item_uniform<BITS, GPTQ>(b[q], R.cx, R.chunk0 + 4 * q, R.g0 + ((4 * q + R.gphase) >> R.gshift), lane, acc); sched_fence(); }
-        }
         else
         {
             #pragma unroll
-            for (int q = 0; q < D; q++)
-                if (q < n) { lean_item_general<BITS, GPTQ>(b[q], R.cx, R.chunk0 + 4 * q, 4 * q, R.g0, R.gshift, R.gphase, 4, lane, acc); sched_fence(); }
+            for (int q = 0; q < DA; q++) if (q < nA) item(a[q], q);
+            if constexpr (NB > 0)
+            {
+                #pragma unroll
+                for (int q = 0; q < NB; q++) item(b[q], nA + q);
+            }
         }
         // more items than the wave's registers hold (K = 28672 split over 16 waves: 14-15 items of 3 bits): further passes of D
         // items, each its own round trip -- only the 16-wave geometry, the last one the host tries, plans such shares
-        if constexpr (S == 16)
+        if constexpr (S == 16 && NB == 0)
         {
             if (!(LEAN_KILL & 9))
             {
@@ -401,23 +442,23 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                 for (int q0 = D; q0 < n; q0 += D)
                 {
                     #pragma unroll
-                    for (int q = 0; q < D; q++) if (q0 + q < n) load_lane_words<BITS>(wptr + (size_t)(q0 + q) * STEP, lane, b[q]);
-                    if (R.uni)
-                    {
-                        #pragma unroll
-                        for (int q = 0; q < D; q++)
-                            if (q0 + q < n) { lean_item_uniform<BITS, GPTQ>(b[q], R.cx, R.chunk0 + 4 * (q0 + q), R.g0 + ((4 * (q0 + q) + R.gphase) >> R.gshift), lane, acc); sched_fence(); }
-                    }
-                    else
-                    {
-                        #pragma unroll
-                        for (int q = 0; q < D; q++)
-                            if (q0 + q < n) { lean_item_general<BITS, GPTQ>(b[q], R.cx, R.chunk0 + 4 * (q0 + q), 4 * (q0 + q), R.g0, R.gshift, R.gphase, 4, lane, acc); sched_fence(); }
-                    }
+                    for (int q = 0; q < D; q++) if (q0 + q < n) load_lane_words<BITS>(wptr + (size_t)(q0 + q) * STEP, lane, a[q]);
+                    #pragma unroll
+                    for (int q = 0; q < D; q++) if (q0 + q < n) item(a[q], q0 + q);
                 }
             }
         }
         if (tail_nv) lean_item_general<BITS, GPTQ>(bt, R.cx, R.chunk0 + 4 * n, 4 * n, R.g0, R.gshift, R.gphase, tail_nv, lane, acc);
+    };
+    // a share of at least NB and at most D items takes the pipelined form
+    auto head_bits = [&](auto bits_tag) {
+        constexpr int BITS = decltype(bits_tag)::value;
+        constexpr int NB = LeanTail<BITS, S>::v;
+        if constexpr (NB > 0)
+        {
+            if (n >= NB && n <= LeanDepth<BITS, S>::v && pipe_on) { head(bits_tag, std::integral_constant<int, NB>()); return; }
+        }
+        head(bits_tag, std::integral_constant<int, 0>());
     };
     if (n == 0 && tail_nv == 0)
     {
@@ -428,16 +469,16 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         wave_converge();
         LTRACE(4);
     }
-    else if constexpr (GPTQ) head(std::integral_constant<int, 4>());
+    else if constexpr (GPTQ) head_bits(std::integral_constant<int, 4>());
     else switch (bits)
     {
-        case 4: head(std::integral_constant<int, 4>()); break;
-        case 8: head(std::integral_constant<int, 8>()); break;
-        case 6: head(std::integral_constant<int, 6>()); break;
-        case 5: head(std::integral_constant<int, 5>()); break;
+        case 4: head_bits(std::integral_constant<int, 4>()); break;
+        case 8: head_bits(std::integral_constant<int, 8>()); break;
+        case 6: head_bits(std::integral_constant<int, 6>()); break;
+        case 5: head_bits(std::integral_constant<int, 5>()); break;
 #if LEAN_LOWBITS
-        case 3: head(std::integral_constant<int, 3>()); break;
-        default: head(std::integral_constant<int, 2>()); break;
+        case 3: head_bits(std::integral_constant<int, 3>()); break;
+        default: head_bits(std::integral_constant<int, 2>()); break;
 #else
         default: break;
 #endif
@@ -654,7 +695,8 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
             const bool uni = shift >= 2 && (phase & 3) == 0;                   // the four chunks of every full item share a group
             lw.w_off = r.off + (u32)i0 * 64u * (u32)r.bits; lw.w_tstride = r.tstride;
             lw.t_off = r.t_off; lw.t_tstride = r.t_tstride;
-            lw.meta = (u32)n | ((u32)r.bits << 8) | ((u32)tail_nv << 12) | (uni ? 1u << 15 : 0u) | ((u32)shift << 16) | ((u32)phase << 19);
+            static const u32 pipe_off = []() { const char* e = getenv("EXL2_LEAN_PIPE"); return (e && atoi(e) == 0) ? 1u : 0u; }();   // A/B switch
+            lw.meta = (u32)n | ((u32)r.bits << 8) | ((u32)tail_nv << 12) | (uni ? 1u << 15 : 0u) | ((u32)shift << 16) | ((u32)phase << 19) | (pipe_off << 29);
             lw.xr = (u32)c0 | ((u32)(c_end - c0) << 16);
             lw.gr = (u32)g_lo | ((u32)(g_hi - g_lo + 1) << 16);
             lw.place = (u32)c0 | ((u32)(g0 - g_lo) << 16);

@@ -244,10 +244,13 @@ DEV f16x4 lds_read_tr16_b64(const f16* p)
 
 DEV u64 cycle_stamp() { return 0; }
 DEV void sched_fence() { }
+DEV u32 fence_load(const u32* p) { return *p; }
+DEV void fence_load_use(u32) { }
 
 // ---- memory ----------------------------------------------------------------------------------------------------------
 DEV u64 realtime_stamp() { return 0; }
 DEV void dma_to_lds16(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
+DEV void dma_to_lds16_raw(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
 DEV void dma_to_lds16_nt(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
 DEV void wait_lds_reads() { }
 DEV void wave_converge() { emu_ctx_->wave[wave_id()].bar.wait(); }

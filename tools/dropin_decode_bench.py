@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Decode tokens/s of the UNMODIFIED reference host (ExLlamaV2 / ExLlamaV2Cache / the `test_inference.py -s` loop,
+/root/reference/test_inference.py:584-618: model.forward(ids[:, -1:], cache) + host argmax + torch.cat per token) running on
+the drop-in (dropin/exllamav2_ext.py -> libexl2_hip.so), on a synthetic Llama-2-7B EXL2 4.0bpw MODEL DIRECTORY written to
+local disk first -- SURVEY.md 8(d)(i)'s definition of the headline metric, beside bench.py's GreedyGraphDecoder figure.
+
+  python tools/dropin_decode_bench.py [--tokens 128] [--layers 32] [--dir /tmp/synth7b]
+
+Prints one JSON line.  The reference package comes from /root/reference, or from the build-time mirror of its *.py files
+(oracle/_ref/reference_py) on a machine without it.  This is a measurement of the drop-in, not a parity test (parity of this
+very route: tests/test_dropin_reference.py)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--tokens", type=int, default=128)
+    p.add_argument("--layers", type=int, default=32)
+    p.add_argument("--dir", default="/tmp/synth7b")
+    p.add_argument("--recipe", default="4.0bpw")
+    args = p.parse_args()
+    ref = next((d for d in ("/root/reference", os.path.join(ROOT, "oracle", "_ref", "reference_py"))
+                if os.path.isfile(os.path.join(d, "exllamav2", "model.py"))), None)
+    if ref is None:
+        print(json.dumps({"error": "no reference package (neither /root/reference nor oracle/_ref/reference_py)"}))
+        return
+    sys.path[:0] = [os.path.join(ROOT, "dropin"), ROOT, ref]
+    import torch
+    from exllamav2_amd.config import ExLlamaV2Config as OurCfg
+    from exllamav2_amd.synth import synth_checkpoint
+    from exllamav2_amd.synth_dir import write_model_dir
+    t0 = time.perf_counter()
+    cfg = OurCfg.llama2_7b(max_seq_len=2048)
+    cfg.num_hidden_layers = args.layers
+    if not os.path.exists(os.path.join(args.dir, "model.safetensors")):
+        ck = synth_checkpoint(cfg, "cpu", recipe=args.recipe, seed=0)
+        write_model_dir(args.dir, cfg, ck)
+        del ck
+    t_write = time.perf_counter() - t0
+
+    from exllamav2 import ExLlamaV2, ExLlamaV2Config, ExLlamaV2Cache
+    from exllamav2.ext import ext_c
+    assert ext_c.__name__ == "exllamav2_ext" and "dropin" in ext_c.__file__, ext_c.__file__
+    t0 = time.perf_counter()
+    config = ExLlamaV2Config(args.dir)
+    config.max_seq_len = 2048
+    config.no_flash_attn = True            # (no flash-attn package on the box: the reference's own _attn_torch, attn.py:869-937)
+    config.no_sdpa = True                  # its matmul branch: the SDPA branch of v0.3.2 is not causal when cu_seqlens is unset
+    model = ExLlamaV2(config)
+    model.load()
+    torch.cuda.synchronize()
+    t_load = time.perf_counter() - t0
+    cache = ExLlamaV2Cache(model, max_seq_len=2048)
+    ids = torch.tensor([[1, 15043, 3186, 29892]])
+    # test_inference.py:590-618 (-s): prompt through forward(preprocess_only), then the timed per-token loop
+    model.forward(ids[:, :-1], cache, preprocess_only=True)
+    for _ in range(8):                     # untimed warm-up tokens (clock ramp, lazy set-up)
+        logits = model.forward(ids[:, -1:], cache)
+        sample = torch.argmax(logits[0, -1]).cpu().unsqueeze(0).unsqueeze(0)
+        ids = torch.cat((ids, sample), dim=-1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.tokens):
+        logits = model.forward(ids[:, -1:], cache)
+        sample = torch.argmax(logits[0, -1]).cpu().unsqueeze(0).unsqueeze(0)
+        ids = torch.cat((ids, sample), dim=-1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "decode tokens/s, unmodified reference host on the drop-in (test_inference.py -s loop)",
+                      "value": round(args.tokens / dt, 2), "unit": "tokens/s", "ms_per_token": round(dt / args.tokens * 1e3, 3),
+                      "tokens": args.tokens, "layers": args.layers, "recipe": args.recipe, "attention": "reference _attn_torch (matmul branch)",
+                      "write_dir_s": round(t_write, 1), "load_s": round(t_load, 1), "last_tokens": ids[0, -4:].tolist()}))
+
+
+if __name__ == "__main__":
+    main()

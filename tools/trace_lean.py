@@ -17,7 +17,7 @@ lib = _lib.Lib(os.path.join(ROOT, "exllamav2_amd", "libexl2_hip_trace.so"))
 ext = ExtC(lib)
 set_trace = lib.dll.exl2_debug_set_lean_trace
 set_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]; set_trace.restype = None
-NAMES = ["arguments arrived", "arguments unpacked", "weights requested", "rest unpacked, staged copies issued", "everything landed",
+NAMES = ["arguments arrived", "arguments unpacked", "weights requested", "rest unpacked, staged copies issued", "first part + staged copies landed (fence load)",
          "decoded, partials written", "barrier passed", "end (finalising waves)"]
 TICK_US = 0.01
 MATS, WGS, WAVES = 4, 2048, 16
