@@ -667,6 +667,21 @@ def main():
     elif n_gpus > 1:
         from exllamav2_amd.pipeline import run_layer_split_bench
         result = run_layer_split_bench(cfg, args, rank, world, device)
+        if os.environ.get("EXL2_BENCH_TP_LINE", "1") != "0" and not getattr(cfg, "num_experts", 0):
+            # the second labelled figure of an N > 1 run: ONE sequence decoded by all ranks together (tensor parallel, strong
+            # scaling) -- what a "bs=1 on N GPUs" reader expects; nested in the same JSON line (the contract is one line)
+            try:
+                from exllamav2_amd.tensor_p import run_tp_bench
+                torch.cuda.empty_cache()
+                tp = run_tp_bench(cfg, args, rank, world, device)
+                wb = tp.get("weight_bytes_per_rank")
+                result["strong_scaling_tp"] = {
+                    "metric": f"decode tokens/s, {args.model} {fmt_name(args.recipe)}, bs={args.batch} greedy, ONE sequence over {world} ranks",
+                    "value": round(tp["value"], 2), "unit": "tokens/s", "ms_per_step": round(tp["ms_per_step"], 4), "scaling": "strong",
+                    "parallelism": tp["parallelism"], "ranks": world, "weight_bytes_per_rank": wb,
+                    "per_gpu_weight_roofline_frac": ([round(b / (tp["ms_per_step"] * 1e-3) / 8.0e12, 4) for b in wb] if isinstance(wb, list) else None)}
+            except Exception as e:                                   # informational; never lose the headline line
+                result["strong_scaling_tp"] = {"error": str(e)[:300]}
     else:
         t_load = time.perf_counter()
         ck = synth_checkpoint(cfg, device, recipe=args.recipe, seed=0)
@@ -757,6 +772,18 @@ def main():
     return finish(args, cfg, result, rank, world, n_gpus, device, dist)
 
 
+def _metric_name(args, n_gpus: int, result: dict) -> str:
+    """says what ran: one GPU = the BASELINE metric; N > 1 layer split = aggregate over the sequences in flight (weak scaling),
+    N > 1 tensor parallel = one sequence (strong scaling)"""
+    model = "Llama-2-7B EXL2 4.0bpw" if (args.model == "llama2-7b" and args.recipe == "4.0bpw") else f"{args.model} {fmt_name(args.recipe)}"
+    if n_gpus == 1:
+        return f"decode tokens/s, {model}, bs={args.batch} greedy"
+    if result.get("scaling") == "strong":
+        return f"decode tokens/s, {model}, bs={args.batch} greedy, ONE sequence over {n_gpus} GPUs (tensor parallel, strong scaling)"
+    return (f"decode tokens/s AGGREGATE, {model}, greedy, {result.get('sequences_in_flight', n_gpus)} bs=1 sequences in flight over a "
+            f"{n_gpus}-GPU layer split (weak scaling: per-GPU weight bytes per token constant)")
+
+
 def fmt_name(recipe: str) -> str:
     return ("GPTQ " + recipe[5:]) if recipe.startswith("gptq-") else ("EXL2 " + recipe)
 
@@ -764,8 +791,7 @@ def fmt_name(recipe: str) -> str:
 def finish(args, cfg, result, rank, world, n_gpus, device, dist):
     if rank == 0:
         out = {
-            "metric": "decode tokens/s, Llama-2-7B EXL2 4.0bpw, bs=1 greedy" if (args.model == "llama2-7b" and args.batch == 1)
-                      else f"decode tokens/s, {args.model} {fmt_name(args.recipe)}, bs={args.batch} greedy",
+            "metric": _metric_name(args, n_gpus, result),
             "value": round(result["value"], 2), "unit": "tokens/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(result["ms_per_step"], 4), "higher_is_better": True,
             "scaling": result.get("scaling", "weak"),
@@ -779,7 +805,8 @@ def finish(args, cfg, result, rank, world, n_gpus, device, dist):
                        "parallelism": "single GPU" if n_gpus == 1 else
                                       result.get("parallelism", f"layer-split pipeline x{n_gpus}, {n_gpus} sequences in flight")},
         }
-        for k in ("roofline", "load_s", "weight_bytes_per_rank", "parity_check", "extra"):
+        for k in ("roofline", "load_s", "weight_bytes_per_rank", "per_gpu_weight_roofline_frac", "sequences_in_flight", "ranks",
+                  "strong_scaling_tp", "parity_check", "extra"):
             if k in result: out[k] = result[k]
         if not args.no_prefill and n_gpus == 1 and args.model == "llama2-7b" and args.batch == 1:
             try:

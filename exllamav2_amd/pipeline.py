@@ -2,10 +2,18 @@
 
 The reference keeps one process driving all GPUs and copies the hidden state device -> device at every split point
 (model.py:1014-1016, compat.py:53-139); only one GPU works at a time.  Here rank r owns layers [r L/N, (r+1) L/N) and
-N independent sequences are in flight, one per stage: at every tick each rank runs ITS layers on the sequence currently
+`depth` x N independent sequences are in flight: at every tick each rank runs ITS layers on the sequence currently
 at its stage and hands the [hidden] fp16 vector to rank r+1 with one RCCL point-to-point send (xGMI is a point-to-point
 fabric: a ring of sends uses one link per hop, no collective is needed).  The last rank samples (greedy) and sends the
 token id to rank 0 in the same fixed-size message.  Per-GPU work per token is constant in N (weak scaling).
+
+Hand-off (round 4; BASELINE north_star: "async copies overlapped on HIP streams").  depth = 1 is the lock-step form: one
+message buffer, the send / receive pair of tick t on the stage's compute stream, so a tick costs compute + hand-off.
+depth = 2 (default for N > 1) gives every message a whole tick to travel: 2 N sequences in flight, sequence s sits at
+rank r at ticks t = s + 2 r (mod 2 N), message buffers are double (index = parity of the tick = parity of the sequence,
+so the per-sequence graphs keep fixed addresses), and the send / receive pair of tick t runs on a SECOND stream behind an
+event of compute(t) while the compute stream goes straight on to tick t + 1 (the other buffer pair); compute(t + 2) waits
+for the event of that exchange.  A tick then costs max(compute, hand-off).
 
 Works with any torch.distributed backend: nccl (= RCCL) on GPUs, gloo in the CPU tests (with the emulation library).
 """
@@ -32,8 +40,9 @@ class PipelineStage:
     """One rank's slice of the model + per-sequence decode state (device-side positions, like GreedyGraphDecoder)."""
 
     def __init__(self, cfg, rank: int, world: int, device, n_seqs: int, max_seq_len: int, recipe: str = "4.0bpw",
-                 seed: int = 0, ext=None, use_graph: bool = True, cache_type: str = "fp16"):
-        self.cfg, self.rank, self.world, self.n_seqs = cfg, rank, world, n_seqs
+                 seed: int = 0, ext=None, use_graph: bool = True, cache_type: str = "fp16", depth: int = 1):
+        assert depth in (1, 2) and (depth == 1 or n_seqs % 2 == 0), "depth 2 needs an even number of sequences"
+        self.cfg, self.rank, self.world, self.n_seqs, self.depth = cfg, rank, world, n_seqs, depth
         self.first, self.last = rank == 0, rank == world - 1
         self.device = torch.device(device)
         layers = split_layers(cfg.num_hidden_layers, world, rank)
@@ -49,8 +58,10 @@ class PipelineStage:
         self.seqlens = torch.zeros((n_seqs,), dtype=torch.int32, device=dev)
         h = cfg.hidden_size
         # message = [hidden] fp16; the last -> first hop carries the token id in its first 4 bytes
-        self.msg_in = torch.zeros((h,), dtype=torch.float16, device=dev)
-        self.msg_out = torch.zeros((h,), dtype=torch.float16, device=dev)
+        # (depth 2: one pair per tick parity; self.msg_in / self.msg_out always name the pair of the sequence being stepped)
+        self.msg_in_buf = [torch.zeros((h,), dtype=torch.float16, device=dev) for _ in range(depth)]
+        self.msg_out_buf = [torch.zeros((h,), dtype=torch.float16, device=dev) for _ in range(depth)]
+        self.msg_in, self.msg_out = self.msg_in_buf[0], self.msg_out_buf[0]
         self.x = torch.zeros((1, 1, h), dtype=torch.float16, device=dev)
         self.xn = torch.zeros((1, h), dtype=torch.float16, device=dev)
         self.ids = torch.zeros((1,), dtype=torch.int32, device=dev)
@@ -58,6 +69,10 @@ class PipelineStage:
         self.history = torch.zeros((n_seqs, max_seq_len + 2), dtype=torch.int32, device=dev)
         self.use_graph = use_graph and self.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=dev) if self.device.type == "cuda" else None
+        # depth 2: the hand-off's own stream and, per buffer pair, "compute done" / "exchange done" events
+        self.comm_stream = torch.cuda.Stream(device=dev) if (self.device.type == "cuda" and depth == 2) else None
+        self.ev_compute = [torch.cuda.Event() for _ in range(depth)] if self.comm_stream is not None else None
+        self.ev_comm = [torch.cuda.Event() for _ in range(depth)] if self.comm_stream is not None else None
         self.graphs = {}
         self.pos = [0] * n_seqs                                   # host mirror of seqlens: the kernels do not bound-check
         self.limit = min(max_seq_len, cfg.max_seq_len)
@@ -131,8 +146,14 @@ class PipelineStage:
         else:
             self.msg_out.copy_(self.x.view(-1))
 
+    def _select_buffers(self, s: int):
+        p = s % self.depth
+        self.msg_in, self.msg_out = self.msg_in_buf[p], self.msg_out_buf[p]
+        return p
+
     # one stage step for sequence s: msg_in -> (layers) -> msg_out
     def _step_eager(self, s: int):
+        self._select_buffers(s)
         if self.chain is not None:
             try:
                 return self._step_chain(s)
@@ -195,15 +216,29 @@ class PipelineStage:
             else:
                 self._step_eager(s)
 
-    def exchange(self):
-        """msg_out -> next rank, msg_in <- previous rank (ring; last -> first carries the sampled token).  Issued on the
-        stage's own stream, so compute and hand-off are ordered without host synchronisation (RCCL: wait() is a stream
-        wait; gloo: it blocks the host)."""
+    def begin_tick(self, p: int):
+        """compute stream: the exchange that filled buffer pair p (two ticks ago) has completed"""
+        if self.comm_stream is not None:
+            self.stream.wait_event(self.ev_comm[p])
+
+    def exchange(self, p: int = 0):
+        """msg_out[p] -> next rank, msg_in[p] <- previous rank (ring; last -> first carries the sampled token).
+        depth 1: issued on the stage's compute stream, so compute and hand-off are ordered without host synchronisation
+        (RCCL: wait() is a stream wait; gloo: it blocks the host).  depth 2 on a GPU: issued on the hand-off stream behind
+        an event of this tick's compute -- the compute stream does not wait; the next use of pair p (two ticks on) does."""
         nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
-        with self._on_stream():
-            ops = [dist.P2POp(dist.isend, self.msg_out, nxt), dist.P2POp(dist.irecv, self.msg_in, prv)]
+        ops = [dist.P2POp(dist.isend, self.msg_out_buf[p], nxt), dist.P2POp(dist.irecv, self.msg_in_buf[p], prv)]
+        if self.comm_stream is None:
+            with self._on_stream():
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+            return
+        self.ev_compute[p].record(self.stream)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(self.ev_compute[p])      # msg_out[p] produced, msg_in[p] consumed
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
+            self.ev_comm[p].record(self.comm_stream)
 
     def free(self):
         for g in self.graphs.values():
@@ -211,63 +246,78 @@ class PipelineStage:
         self.graphs = {}
 
 
-def run_pipeline(stage: PipelineStage, first_tokens, n_ticks: int):
-    """Drive `n_ticks` ticks.  At tick t rank r works on sequence (t - r) mod n_seqs (idle while the pipe fills).
-    Sequence s starts from token first_tokens[s].  Returns the number of tokens sampled by the last rank."""
-    n = stage.n_seqs
+def tick(stage: PipelineStage, t: int, first_tokens=None) -> bool:
+    """One tick of the schedule on this rank: sequence s = (t - depth * rank) mod n_seqs is stepped when the pipe has reached
+    this stage, then the buffer pair of this tick is exchanged.  Returns True when the last stage sampled a token."""
+    n, d = stage.n_seqs, stage.depth
+    s = (t - d * stage.rank) % n
+    p = t % d
+    active = t >= d * stage.rank
+    stage.begin_tick(p)
+    if stage.first and first_tokens is not None and t < n:
+        # inject the prompt token of sequence t (instead of a token coming back from the last rank)
+        with stage._on_stream():
+            stage.msg_in_buf[p].zero_()
+            stage.msg_in_buf[p][:2].view(torch.int32).copy_(torch.tensor([int(first_tokens[t])], dtype=torch.int32).to(stage.device))
+    if active:
+        stage.step(s)
+    stage.exchange(p)
+    return active and stage.last
+
+
+def run_pipeline(stage: PipelineStage, first_tokens, n_ticks: int, t0: int = 0):
+    """Drive ticks t0 .. t0 + n_ticks.  At tick t rank r works on sequence (t - depth * r) mod n_seqs (idle while the pipe
+    fills).  Sequence s starts from token first_tokens[s].  Returns the number of tokens sampled by the last rank."""
     sampled = 0
-    for t in range(n_ticks):
-        s = (t - stage.rank) % n
-        active = t >= stage.rank
-        if stage.first and t < n:
-            # inject the prompt token of sequence t (instead of a token coming back from the last rank)
-            with stage._on_stream():
-                stage.msg_in.zero_()
-                stage.msg_in[:2].view(torch.int32).copy_(torch.tensor([int(first_tokens[t])], dtype=torch.int32).to(stage.device))
-        if active:
-            stage.step(s)
-            if stage.last:
-                sampled += 1
-        stage.exchange()
+    for t in range(t0, t0 + n_ticks):
+        sampled += int(tick(stage, t, first_tokens))
+    if stage.comm_stream is not None:
+        stage.stream.wait_stream(stage.comm_stream)            # whoever synchronises the compute stream sees the hand-offs done
     return sampled
 
 
 def run_layer_split_bench(cfg, args, rank: int, world: int, device, ext=None):
-    """bench.py backend for --gpus N > 1: N sequences in flight over an N-stage layer split."""
-    n_seqs = world
+    """bench.py backend for --gpus N > 1: depth x N sequences in flight over an N-stage layer split (depth 2 = overlapped
+    hand-off, EXL2_PIPELINE_DEPTH=1 = the lock-step form).  A "step" = one tick = one token sampled by the last stage once the
+    pipe is full; exactly args.steps ticks are timed between barriers."""
+    depth = int(os.environ.get("EXL2_PIPELINE_DEPTH", "2"))
+    n_seqs = depth * world
     on_gpu = torch.device(device).type == "cuda"
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     ramp = getattr(args, "ramp", 2048)   # untimed ticks before the warm-up (clock ramp of a freshly started GPU), same on every rank
     max_seq = max(2048, ((args.ctx + (args.steps + args.warmup + ramp) // n_seqs + 2 + 255) // 256) * 256)
     t_load = time.perf_counter()
     stage = PipelineStage(cfg, rank, world, device, n_seqs, max_seq, recipe=args.recipe, use_graph=not args.no_graph,
-                          cache_type=getattr(args, "cache", "fp16"), ext=ext)
+                          cache_type=getattr(args, "cache", "fp16"), ext=ext, depth=depth)
     stage.capture()
     stage.seqlens.fill_(args.ctx)
     sync()
     t_load = time.perf_counter() - t_load
     first = list(range(1, n_seqs + 1))
-    # fill the pipe + warm-up (a "step" = one token sampled somewhere in the pipe = one tick once the pipe is full)
-    run_pipeline(stage, first, world + ramp + args.warmup)
+    # fill the pipe + warm-up
+    base = depth * world + ramp + args.warmup
+    run_pipeline(stage, first, base)
     sync()
     dist.barrier()
     t0 = time.perf_counter()
-    n = stage.n_seqs
-    base = world + ramp + args.warmup
-    for t in range(base, base + args.steps):
-        stage.step((t - rank) % n)
-        stage.exchange()
+    run_pipeline(stage, None, args.steps, t0=base)
     sync()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
-    # self-check for a driver-run scaling line: every rank reports what it holds and how many tokens its last stage sampled
+    # self-check for a driver-run scaling line: every rank reports what it holds
     wb = torch.tensor([float(stage.model.weight_bytes())], dtype=torch.float64, device=device)
     gathered = [torch.zeros_like(wb) for _ in range(world)]
     dist.all_gather(gathered, wb)
+    per_rank = [int(g.item()) for g in gathered]
     stage.free()
-    return {"value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load,
+    tick_s = dt / args.steps
+    return {"value": args.steps / dt, "ms_per_step": tick_s * 1e3, "load_s": t_load,
+            "sequences_in_flight": n_seqs,
             "parallelism": f"layer-split pipeline x{world} ({dist.get_backend()} ranks: {dist.get_world_size()}), "
-                           f"{n_seqs} sequences in flight, {cfg.num_hidden_layers // world}-{-(-cfg.num_hidden_layers // world)} layers per rank",
-            "weight_bytes_per_rank": [int(g.item()) for g in gathered]}
+                           f"{n_seqs} sequences in flight ({'double-buffered hand-off on a second stream' if depth == 2 else 'lock-step hand-off'}), "
+                           f"{cfg.num_hidden_layers // world}-{-(-cfg.num_hidden_layers // world)} layers per rank",
+            "weight_bytes_per_rank": per_rank,
+            # every rank streams its own weights once per tick: fraction of ITS 8 TB/s
+            "per_gpu_weight_roofline_frac": [round(b / tick_s / 8.0e12, 4) for b in per_rank]}

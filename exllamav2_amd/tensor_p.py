@@ -354,9 +354,12 @@ def run_tp_bench(cfg, args, rank: int, world: int, device, ext=None):
     dt = float(dt.item())
     toks = dec.tokens(args.ctx + args.warmup, args.steps)
     assert int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab_size
+    wb = torch.tensor([float(model.weight_bytes())], dtype=torch.float64, device=device)
+    gathered = [torch.zeros_like(wb) for _ in range(world)]
+    dist.all_gather(gathered, wb)
     return {"value": args.batch * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load,
             "scaling": "strong", "parallelism": f"tensor parallel x{world} (column shards + all-gather over RCCL), eager launches",
-            "weight_bytes_per_rank": model.weight_bytes()}
+            "weight_bytes_per_rank": [int(g.item()) for g in gathered]}
 
 
 def _pad_head(ck: dict, vocab_padded: int):

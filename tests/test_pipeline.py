@@ -63,6 +63,46 @@ def test_layer_split_pipeline_matches_single_process(tmp_path):
     model.unload()
 
 
+def _worker_depth2(rank, world, port, n_ticks, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from exllamav2_amd.pipeline import PipelineStage, run_pipeline
+    stage = PipelineStage(_cfg(), rank, world, "cpu", n_seqs=2 * world, max_seq_len=256, seed=5, ext=_emu_ext(), use_graph=False,
+                          depth=2)
+    sampled = run_pipeline(stage, [3, 11, 40, 77], n_ticks)
+    if rank == world - 1:
+        np.save(out_path, stage.history.numpy())
+        assert sampled == n_ticks - 2 * (world - 1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_layer_split_pipeline_double_buffered_schedule(tmp_path):
+    """depth 2 (the overlapped hand-off's schedule: 2 N sequences in flight, sequence s at rank r at ticks s + 2 r mod 2 N,
+    message buffer pair = tick parity): every sequence's tokens equal the single-process decoder's.  (gloo executes the
+    exchanges on the host thread; the stream / event ordering of the GPU form is exercised on hardware.)"""
+    world, n_ticks = 2, 14                     # rank 1 samples at ticks 2..13: 3 tokens for each of the 4 sequences
+    out = str(tmp_path / "hist.npy")
+    build_emu_if_needed()
+    mp.spawn(_worker_depth2, args=(world, 29541, n_ticks, out), nprocs=world, join=True)
+    hist = np.load(out)
+    from exllamav2_amd.cache import ExLlamaV2Cache
+    from exllamav2_amd.model import ExLlamaV2, GreedyGraphDecoder
+    from exllamav2_amd.synth import synth_checkpoint
+    cfg = _cfg()
+    model = ExLlamaV2(cfg, device="cpu", ext=_emu_ext()).load(synth_checkpoint(cfg, "cpu", seed=5))
+    for s, tok0 in enumerate([3, 11, 40, 77]):
+        cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=256)
+        dec = GreedyGraphDecoder(model, cache, batch_size=1)
+        dec.reset(torch.tensor([tok0]), 0)
+        dec.run(3, use_graph=False)
+        want = dec.tokens(0, 3).numpy()[0]
+        assert np.array_equal(hist[s, 1:4], want), (s, hist[s, :5], want)
+    model.unload()
+
+
 def _bench_worker(rank, world, port):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -77,6 +117,7 @@ def _bench_worker(rank, world, port):
     wb = r["weight_bytes_per_rank"]
     assert len(wb) == world and all(b > 0 for b in wb) and wb[-1] > wb[0]
     assert f"ranks: {world}" in r["parallelism"]
+    assert r["sequences_in_flight"] == 2 * world and len(r["per_gpu_weight_roofline_frac"]) == world
     dist.destroy_process_group()
 
 

@@ -152,7 +152,7 @@ def _bench_worker(rank, world, port, out_dir):
     cfg.vocab_size = 90                                    # lm_head has 96 columns -> zero-extended to 128 = 2 x 64 (_pad_head)
     args = argparse.Namespace(ctx=2, steps=2, warmup=1, recipe="4.0bpw", batch=2, cache="fp16")
     r = run_tp_bench(cfg, args, rank, world, "cpu", ext=_emu_ext())
-    assert r["scaling"] == "strong" and r["value"] > 0 and r["weight_bytes_per_rank"] > 0
+    assert r["scaling"] == "strong" and r["value"] > 0 and len(r["weight_bytes_per_rank"]) == world and min(r["weight_bytes_per_rank"]) > 0
     dist.destroy_process_group()
 
 
