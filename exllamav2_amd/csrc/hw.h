@@ -175,23 +175,25 @@ DEV void dma_to_lds4(const void* g_lane_ptr, void* lds_wave_base)
 DEV void wait_vmcnt_builtin0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 // wait until at most N vector-memory operations of this wave are still in flight (they complete in issue order)
 template <int N> DEV void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-// The same copy as an instruction the COMPILER DOES NOT COUNT.  The compiler models a pending global_load_lds like a flat access
-// that may return out of order and answers EVERY later wait on a loaded register with vmcnt(0) -- which drains all requests a wave
-// wanted to keep in flight.  The hardware completes a wave's vector-memory operations in issue order (the counted waits of
-// qgemv_flat.hip / qgemm_mfma.hip rely on it), so a kernel that orders its LDS reads behind these copies ITSELF (fence_load below)
-// loses nothing by hiding them: an untracked copy can only make a compiler-inserted wait stricter than needed, never weaker.
-// A kernel that uses this form must not use the builtin form as well (M0 is written behind the compiler's back).
-DEV void dma_to_lds16_raw(const void* g_lane_ptr, void* lds_wave_base)
+// The same copy in its BUFFER form (buffer_load_dwordx4 ... lds): lane l moves the 16 bytes at base + voffset_bytes(l) to
+// lds_wave_base + l * 16; `base` must be wave-uniform.  Why a second form: the compiler models a pending global_load_lds like a
+// flat access that may return out of order and answers EVERY later wait on a loaded register with vmcnt(0) -- which drains all the
+// requests a wave wanted to keep in flight.  The buffer form is counted like any other vector load, so the compiler's own counted
+// waits stay exact with copies in flight (the hardware completes a wave's vector-memory operations in issue order).  What it
+// still does not do is order a ds_read behind the copy: fence_load below.
+DEV void dma_buf_to_lds16(const void* base, u32 voffset_bytes, void* lds_wave_base)
 {
-    const u32 l = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)lds_wave_base);      // (flat address of LDS: the offset is its low half)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g_lane_ptr), "s"(l) : "memory");
+    // raw buffer descriptor: base, stride 0, 2 GB of records, gfx9 data format word (out-of-range lanes would read zeros)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voffset_bytes, 0, 0, 0);
 }
 // A "fence load": an ordinary 4-byte vector load the COMPILER tracks, issued behind LDS-DMA copies.  Vector-memory operations
 // of a wave complete in issue order, so when this load's value is available the copies issued before it have landed in LDS;
 // fence_load_use() makes the compiler wait for exactly this load -- it inserts `s_waitcnt vmcnt(n)` with n = the number of
 // vector-memory INSTRUCTIONS it scheduled behind the load (whatever their widths), which a hand-written count could get wrong.
 // Loads issued behind the fence load therefore stay in flight across the wait.  (The compiler does not order a ds_read behind
-// a pending global_load_lds by itself on this toolchain.)
+// a pending LDS-DMA copy by itself on this toolchain.)  Use with dma_buf_to_lds16: with a global_load_lds pending the wait
+// degenerates to vmcnt(0).
 DEV u32 fence_load(const u32* p)
 {
     asm volatile("" ::: "memory");                    // the LDS-DMA builtins above stay above

@@ -46,13 +46,18 @@
 #ifndef LEAN_LOWBITS
 #define LEAN_LOWBITS 1                // 0: no 2 / 3-bit register stream (code-size experiment; such segments would be wrong)
 #endif
-#ifndef LEAN_RAW_DMA
-#define LEAN_RAW_DMA 1                // the wave-private staging copies as instructions the compiler does not count (hw.h: dma_to_lds16_raw)
+#ifndef LEAN_BUF_DMA
+#define LEAN_BUF_DMA 1                // the wave-private staging copies in the buffer form (hw.h: dma_buf_to_lds16): counted waits stay exact
 #endif
-#if LEAN_RAW_DMA
-#define LEAN_DMA dma_to_lds16_raw
+#if LEAN_BUF_DMA
+#define LEAN_DMA(base, off_bytes, lds) dma_buf_to_lds16(base, (u32)(off_bytes), lds)
 #else
-#define LEAN_DMA dma_to_lds16
+#define LEAN_DMA(base, off_bytes, lds) dma_to_lds16((const u8*)(base) + (size_t)(off_bytes), lds)
+#endif
+#ifndef EXL2_EMU
+#define LEAN_MARK(id) asm volatile("; lean mark %0" :: "n"(id))
+#else
+#define LEAN_MARK(id) do { } while (0)
 #endif
 #define LEAN_MAX_WAVES 16
 #define LEAN_RECORDS 48               // wave records in the argument block: matrices x waves per tile (q|k|v at 16 waves)
@@ -74,7 +79,9 @@ struct alignas(64) LeanWave
     u32 gr;                           // first scale-table row (0..15) | number of rows (16..31)
     u32 lds_off;                      // byte offset of the wave's LDS area inside its slot's area
     u32 place;                        // first 32-row chunk of the run's part (0..15) | scale-table row of that chunk relative to the wave's first row (16..31)
-    u32 pad[7];
+    u32 off_sc, off_zp;               // byte offsets of the wave's scale / zero-point rows inside its LDS area (the activation rows come first)
+    u32 x_stride;                     // halfs between the activation rows of the wave's LDS area (made at plan time: the launch's M is known)
+    u32 pad[4];
 };
 // per matrix: 64 bytes; the first 40 are what a wave needs at entry, the rest is read by the finalising waves
 struct alignas(64) LeanMat
@@ -304,36 +311,37 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     const u32* const tptr = (const u32*)ptr_of(m0.z, m0.w) + w0.z + (size_t)t_ * w0.w;
     LTRACE(1);
 
-    // ---- everything else a wave needs before it can decode: unpacked and requested behind its weight requests -----------------
+    // ---- everything else a wave needs before it can decode -------------------------------------------------------------------
+    // stage_copies: the LDS-DMA copies of the wave's activation slice and scale rows, with as few instructions in front of them as
+    // possible (offsets and strides were made by the host) -- the requests of the wave's LAST items are issued behind them;
+    // rest_ctx: everything else the decode needs, unpacked behind ALL requests.
     struct Rest { LeanCtx cx; float* red; int M; u32 flags; int chunk0, g0, gshift, gphase; bool uni; };
-    auto prologue_rest = [&](Rest& R) {
+    struct Staged { u8* wbase; u32 off_sc, off_zp; int x_stride, xc0, M; };
+    auto stage_copies = [&](Staged& P, auto tag) {
+        // (a distinct marker per instantiation: identical copies of this code in two instantiations of `head` get merged by the
+        // compiler otherwise, and then the registers of EITHER instantiation's pending requests count as pending here -- the
+        // compiler then waits for them (a wait that also drains the copies it does not see) before it reuses one)
+        LEAN_MARK(decltype(tag)::value);
         const u32x4 h0 = hb[0], h1 = hb[1], h2 = hb[2];
         const u32x2 h3 = *(const u32x2*)(hb + 3);
         const u32x4 m1 = mb[1];
         const u32x4 w1 = wb[1];
-        const u32 w2x = ((const u32*)wb)[8];
+        const u32x4 w2 = wb[2];
         const f16* const in_a = (const f16*)ptr_of(h0.x, h0.y);
         const int M = (int)h1.w, K = (int)h2.x, lda = (int)h2.y;
-        R.M = M; R.flags = h2.w;
-        const u32 slot_bytes = h3.x, red_off = h3.y;
         const int oct = K >> 3;
         const f16* const sc_tab = (const f16*)ptr_of(m1.x, m1.y); const f16* const zp_tab = (const f16*)ptr_of(m1.z, m1.w);
         const int G = (int)m2.x;
-        R.uni = ((meta >> 15) & 1u) != 0;
-        R.gshift = (int)((meta >> 16) & 0x7u); R.gphase = (int)((meta >> 19) & 0x3FFu);
         const u32 xr = active ? w1.y : 0u, gr = active ? w1.z : 0u;
         const int xc0 = (int)(xr & 0xFFFFu), xchunks = (int)(xr >> 16);
         const int gw0 = (int)(gr & 0xFFFFu), ng = (int)(gr >> 16);
-        R.chunk0 = (int)(w2x & 0xFFFFu); R.g0 = (int)(w2x >> 16);
         // the wave's LDS area: [M rows of the activation slice][scale rows][zero-point rows]
-        const int x_stride = xchunks * 32 + 8;
-        u8* const wbase = smem + (size_t)slot * slot_bytes + w1.w;
+        const int x_stride = (int)w2.w;
+        u8* const wbase = smem + (size_t)slot * h3.x + w1.w;
         f16* const x_lds = (f16*)wbase;
-        const u32 off_sc = ((u32)M * (u32)x_stride * 2u + 15u) & ~15u;
-        f16* const sc_lds = (f16*)(wbase + off_sc);
-        f16* const zp_lds = (f16*)(wbase + off_sc + (((u32)ng * 32u + 15u) & ~15u));
-        R.red = (float*)(smem + red_off);
-        R.cx.x_lds = x_lds; R.cx.sc_lds = sc_lds; R.cx.zp_lds = zp_lds; R.cx.x_stride = x_stride; R.cx.xc0 = xc0; R.cx.M = M;
+        u8* const sc_lds = wbase + w2.y;
+        u8* const zp_lds = wbase + w2.z;
+        P.wbase = wbase; P.off_sc = w2.y; P.off_zp = w2.z; P.x_stride = x_stride; P.xc0 = xc0; P.M = M;
         // requests: scale rows, activation slice.  The common case -- one row, <= 64 units (16 bytes) of each -- is straight-line
         // code, one LDS-DMA instruction per table (the compiler's loop skeletons around run-time trip counts cost more
         // instructions per wave than the decode of an item)
@@ -341,34 +349,45 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         const int xu0 = xc0 * 4;
         const int sc_units = 2 * ng;                                      // 16-byte units of the scale rows (a row = 16 halfs)
         const f16* const st = sc_tab + ((size_t)t_ * G + gw0) * 16;
-        if (M == 1 && xunits <= (S == 4 ? 128 : 64) && sc_units <= 64)
+        LEAN_MARK(decltype(tag)::value + 1);
         {
-            if (lane < sc_units) LEAN_DMA(st + (size_t)lane * 8, (u8*)sc_lds);
-            if constexpr (GPTQ) { if (lane < sc_units) LEAN_DMA(zp_tab + ((size_t)t_ * G + gw0) * 16 + (size_t)lane * 8, (u8*)zp_lds); }
-            if (lane < xunits && xu0 + lane < oct) LEAN_DMA(in_a + (size_t)(xu0 + lane) * 8, (u8*)x_lds);
-            if constexpr (S == 4) { if (64 + lane < xunits && xu0 + 64 + lane < oct) LEAN_DMA(in_a + (size_t)(xu0 + 64 + lane) * 8, (u8*)x_lds + 1024); }
-        }
-        else
-        {
-            #pragma nounroll
-            for (int base = 0; base < sc_units; base += 64)
-                if (base + lane < sc_units) LEAN_DMA(st + (size_t)(base + lane) * 8, (u8*)sc_lds + (size_t)base * 16);
+            // straight-line code, <= 2 copy instructions per table and row (M <= 4 rows, slices of <= 128 16-byte units, <= 64
+            // scale rows: what the host plans)
+            if (lane < sc_units) LEAN_DMA(st, lane * 16, sc_lds);
+            if (64 + lane < sc_units) LEAN_DMA(st, (64 + lane) * 16, sc_lds + 1024);
             if constexpr (GPTQ)
             {
                 const f16* zt = zp_tab + ((size_t)t_ * G + gw0) * 16;
-                #pragma nounroll
-                for (int base = 0; base < sc_units; base += 64)
-                    if (base + lane < sc_units) LEAN_DMA(zt + (size_t)(base + lane) * 8, (u8*)zp_lds + (size_t)base * 16);
+                if (lane < sc_units) LEAN_DMA(zt, lane * 16, zp_lds);
+                if (64 + lane < sc_units) LEAN_DMA(zt, (64 + lane) * 16, zp_lds + 1024);
             }
-            #pragma nounroll
-            for (int rr = 0; rr < M; rr++)
+            #pragma unroll
+            for (int rr = 0; rr < 4; rr++)
             {
-                #pragma nounroll
-                for (int base = 0; base < xunits; base += 64)
-                    if (base + lane < xunits && xu0 + base + lane < oct)
-                        LEAN_DMA(in_a + (size_t)rr * lda + (size_t)(xu0 + base + lane) * 8, (u8*)(x_lds + (size_t)rr * x_stride) + (size_t)base * 16);
+                if (rr < M)
+                {
+                    const f16* const row = in_a + (size_t)rr * lda;
+                    u8* const dst = (u8*)(x_lds + (size_t)rr * x_stride);
+                    if (lane < xunits && xu0 + lane < oct) LEAN_DMA(row, (xu0 + lane) * 16, dst);
+                    if (64 + lane < xunits && xu0 + 64 + lane < oct) LEAN_DMA(row, (xu0 + 64 + lane) * 16, dst + 1024);
+                }
             }
         }
+        // (larger slices are declined by the host, lean_plan_matrix: loops around copy instructions are not an option here -- behind
+        // a loop that issues vector-memory operations the compiler's count of the requests in flight is a guess, and it drains
+        // them in front of the next register it reuses: i.e. in front of the requests that are meant to stay in flight)
+    };
+    auto rest_ctx = [&](Rest& R, const Staged& P) {
+        const u32x4 h2 = hb[2];
+        const u32x2 h3 = *(const u32x2*)(hb + 3);
+        const u32 w2x = ((const u32*)wb)[8];
+        R.M = P.M; R.flags = h2.w;
+        R.uni = ((meta >> 15) & 1u) != 0;
+        R.gshift = (int)((meta >> 16) & 0x7u); R.gphase = (int)((meta >> 19) & 0x3FFu);
+        R.chunk0 = (int)(w2x & 0xFFFFu); R.g0 = (int)(w2x >> 16);
+        R.red = (float*)(smem + h3.y);
+        R.cx.x_lds = (const f16*)P.wbase; R.cx.sc_lds = (const f16*)(P.wbase + P.off_sc); R.cx.zp_lds = (const f16*)(P.wbase + P.off_zp);
+        R.cx.x_stride = P.x_stride; R.cx.xc0 = P.xc0; R.cx.M = P.M;
     };
 
     // ---- the wave's items: everything requested at once into registers, decoded item by item ------------------------------------
@@ -391,8 +410,9 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         for (int q = 0; q < DA; q++) if (q < nA) load_lane_words<BITS>(wptr + (size_t)q * STEP, lane, a[q]);
         if (tail_nv) load_lane_words<BITS>(tptr, lane, bt);
         LTRACE(2);
-        prologue_rest(R);
-        LTRACE(3);
+        Staged P;
+        stage_copies(P, std::integral_constant<int, 1000 * BITS + 10 * NB>());
+        LEAN_MARK(1000 * BITS + 10 * NB + 2);
         const u32 fence = fence_load(wptr);
         sched_fence();
         if constexpr (NB > 0)
@@ -402,6 +422,8 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
             for (int q = 0; q < NB; q++) load_lane_words<BITS>(bptr + (size_t)q * STEP, lane, b[q]);
             sched_fence();
         }
+        LTRACE(3);
+        rest_ctx(R, P);
         fence_load_use(fence);               // the first part, the activation slice and the scale rows have landed
         wave_converge();
         LTRACE(4);
@@ -463,8 +485,10 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     if (n == 0 && tail_nv == 0)
     {
         LTRACE(2);
-        prologue_rest(R);
+        Staged P;
+        stage_copies(P, std::integral_constant<int, 99000>());
         LTRACE(3);
+        rest_ctx(R, P);
         wait_vmcnt_le<0>();
         wave_converge();
         LTRACE(4);
@@ -692,6 +716,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
                 if (ok) shift = sh;
             }
             if (shift < 0 || c0 > 0xFFFF || c_end - c0 > 0xFFFF || g_lo > 0xFFFF || g_hi - g_lo + 1 > 0xFFFF) return 0;
+            if ((c_end - c0) * 4 > 128 || (g_hi - g_lo + 1) > 64 || M > 4) return 0;       // what the kernel's straight-line staging copies (stage_copies)
             const bool uni = shift >= 2 && (phase & 3) == 0;                   // the four chunks of every full item share a group
             lw.w_off = r.off + (u32)i0 * 64u * (u32)r.bits; lw.w_tstride = r.tstride;
             lw.t_off = r.t_off; lw.t_tstride = r.t_tstride;
@@ -702,7 +727,10 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
             lw.place = (u32)c0 | ((u32)(g0 - g_lo) << 16);
             const u32 x_stride = (u32)(c_end - c0) * 32u + 8u;
             (void)norm;
-        lds_total += al16((u32)M * x_stride * 2u) + al16((u32)(g_hi - g_lo + 1) * 32u) * (qm->is_gptq ? 2u : 1u);
+            lw.x_stride = x_stride;
+            lw.off_sc = al16((u32)M * x_stride * 2u);
+            lw.off_zp = lw.off_sc + al16((u32)(g_hi - g_lo + 1) * 32u);
+            lds_total += al16((u32)M * x_stride * 2u) + al16((u32)(g_hi - g_lo + 1) * 32u) * (qm->is_gptq ? 2u : 1u);
             i0 += n;
         }
         if (i0 != r.F) return 0;

@@ -190,3 +190,40 @@ def test_unmodified_reference_tensor_parallel_on_the_dropin(tmp_path):
         w = oracle.forward(np.array([[int(tok)]]))
         g = got["steps"][:, i:i + 1, :cfg.vocab_size].astype(np.float64)
         assert np.all(np.abs(g - w) <= tol(w)), i
+
+
+@pytest.mark.gpu
+def test_unmodified_reference_layer_split_on_the_dropin(tmp_path):
+    """The reference's own multi-GPU mode for every architecture: ONE process, `model.load(gpu_split=[...])`, modules dealt to
+    devices by byte budget (model.py:176-263), the hidden state hopping device to device (model.py:1012-1016) -- on the
+    drop-in, with two devices.  Gated on two visible GPUs (the build's box has one; the driver's 8-GPU node runs it)."""
+    ref = _reference_pkg()
+    if ref is None:
+        pytest.skip("no copy of the reference's host package on this machine")
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.synth import synth_checkpoint
+    from exllamav2_amd.synth_dir import write_model_dir
+    from oracle.model import OracleModel
+    cfg = ExLlamaV2Config(hidden_size=256, intermediate_size=512, num_hidden_layers=4, num_attention_heads=4,
+                          num_key_value_heads=2, head_dim=64, vocab_size=320, max_seq_len=256, max_input_len=32)
+    ck = synth_checkpoint(cfg, "cpu", seed=0, down_act_order=True)
+    oracle = OracleModel(cfg, ck)
+    model_dir = write_model_dir(str(tmp_path / "model"), cfg, ck)
+    out = str(tmp_path / "out_split.npz")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "dropin"), ROOT, ref]))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_dropin.py"), model_dir, out, "split"],
+                       env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    got = np.load(out)
+    assert set(int(d) for d in got["module_devices"] if d >= 0) == {0, 1}
+    ids = np.array([[3, 17, 42, 7]])
+    oracle.reset(1)
+    want = oracle.forward(ids)
+    tol = lambda w: 0.03 + np.abs(w) * 2.0 ** -8
+    assert np.all(np.abs(got["prefill"][..., :cfg.vocab_size].astype(np.float64) - want) <= tol(want))
+    for i, tok in enumerate(got["tokens"]):
+        w = oracle.forward(np.array([[int(tok)]]))
+        g = got["steps"][:, i:i + 1, :cfg.vocab_size].astype(np.float64)
+        assert np.all(np.abs(g - w) <= tol(w)), i

@@ -110,8 +110,56 @@ def main_tp(model_dir: str, out: str, steps: int = 4):
     print("reference-on-dropin ok (load_tp, ExLlamaV2Cache_TP, greedy loop):", toks, "devices", model.tp_context.all_devs)
 
 
+def main_split(model_dir: str, out: str, steps: int = 4):
+    """The reference's OWN layer split: one process, model.load(gpu_split=[...]) (model.py:176-263 set_device_map: modules are
+    dealt to devices by a byte budget; :1012-1016 the hidden state hops with safe_move_tensor at every device change), the same
+    greedy loop.  The budget of device 0 is bisected on set_device_map so that about half of the modules of this (small) model
+    land on each of the first two devices."""
+    from exllamav2 import ExLlamaV2, ExLlamaV2Config, ExLlamaV2Cache
+    from exllamav2.ext import ext_c
+    assert ext_c.__name__ == "exllamav2_ext" and "dropin" in ext_c.__file__, ext_c.__file__
+    assert torch.cuda.device_count() >= 2, "needs two visible devices"
+    config = ExLlamaV2Config(model_dir)
+    config.max_seq_len = 256
+    config.max_input_len = 32
+    config.no_flash_attn = True
+    config.no_sdpa = True
+    model = ExLlamaV2(config)
+    lo, hi = 0.0, 8.0
+    for _ in range(48):
+        mid = 0.5 * (lo + hi)
+        try:
+            model.set_device_map([mid, 8.0])
+            idxs = [m.device_idx for m in model.modules if m.device_idx is not None and m.device_idx >= 0]
+            on0 = sum(1 for i in idxs if i == 0)
+        except AssertionError:
+            on0 = 0
+        if on0 * 2 < len(idxs): lo = mid
+        else: hi = mid
+    model.load(gpu_split=[hi, 8.0])
+    devs = [m.device_idx for m in model.modules]
+    used = sorted(set(d for d in devs if d is not None and d >= 0))
+    assert used == [0, 1], devs
+    cache = ExLlamaV2Cache(model, max_seq_len=256)
+    ids = torch.tensor([[3, 17, 42, 7]])
+    logits = model.forward(ids, cache, last_id_only=False)
+    all_logits = [logits.float().cpu().numpy()]
+    toks = []
+    for _ in range(steps):
+        sample = torch.argmax(logits[0, -1]).cpu().unsqueeze(0).unsqueeze(0)
+        toks.append(int(sample))
+        ids = torch.cat((ids, sample), dim=-1)
+        logits = model.forward(ids[:, -1:], cache)
+        all_logits.append(logits.float().cpu().numpy())
+    np.savez(out, prefill=all_logits[0], steps=np.concatenate(all_logits[1:], axis=1), tokens=np.array(toks),
+             module_devices=np.array([-2 if d is None else d for d in devs]))
+    print("reference-on-dropin ok (load(gpu_split), layer split over devices", used, "):", toks)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[3] == "tp":
         main_tp(sys.argv[1], sys.argv[2])
+    elif len(sys.argv) > 3 and sys.argv[3] == "split":
+        main_split(sys.argv[1], sys.argv[2])
     else:
         main(sys.argv[1], sys.argv[2])
