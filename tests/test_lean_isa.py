@@ -1,0 +1,90 @@
+"""The request / wait structure of the pipelined decode kernel (csrc/qgemv_lean.hip: head) as the COMPILER emitted it.
+
+The kernel's point is that the requests of a wave's last NB items stay in flight while its first items are decoded: they are
+issued behind a "fence load" (hw.h) and the compiler must answer the fence's use with a COUNTED wait, `s_waitcnt vmcnt(n)`,
+n = the vector-memory instructions it placed behind the fence load.  Two ways this silently degrades to "wait for everything"
+were met while building it -- a pending global_load_lds (the compiler then answers every wait with vmcnt(0)) and a loop that
+issues vector-memory operations ahead of the region (the compiler then drains its guess of what is pending before the next
+register reuse, i.e. in FRONT of the requests) -- and neither changes a result, so no parity test can see them.  This test reads
+the gfx950 assembly: hipcc cross-compiles without a GPU.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from tests.conftest import ROOT
+
+
+_CACHE = {}
+
+
+def _asm(tmp_path):
+    if "s" not in _CACHE:
+        _CACHE["s"] = _compile(tmp_path)
+    return _CACHE["s"]
+
+
+def _compile(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / "lean.s")
+    src = os.path.join(ROOT, "exllamav2_amd", "csrc", "qgemv_lean.hip")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed",
+                           "-I", os.path.join(ROOT, "exllamav2_amd", "csrc"), "--cuda-device-only", "-S", src, "-o", out],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def test_pipelined_regions_keep_their_last_requests_in_flight(tmp_path):
+    s = _asm(tmp_path)
+    kernels = list(re.finditer(r"^(_Z17qgemv_lean_kernel\w+):", s, re.M))
+    assert len(kernels) >= 10                                       # 5 geometries x {EXL2, GPTQ}
+    checked = 0
+    for m in kernels:
+        body = s[m.end():s.index(".Lfunc_end", m.end())].splitlines()
+        for i, line in enumerate(body):
+            mk = re.search(r"; lean mark (0x[0-9a-f]+|\d+)", line)
+            if not mk:
+                continue
+            ident = int(mk.group(1), 0)
+            if ident % 10 != 2 or ident >= 99000:                  # (...2 = the marker in front of the fence load)
+                continue
+            nb = (ident % 1000) // 10
+            # the fence load, then the requests behind it, then the first wait on the vector-memory counter
+            j = i + 1
+            while not body[j].strip().startswith("global_load_dword "):
+                assert j < i + 12, (m.group(1), ident, "fence load not found behind its marker")
+                j += 1
+            loads, k = 0, j + 1
+            while True:
+                t = body[k].strip()
+                if t.startswith("s_waitcnt") and "vmcnt" in t:
+                    break
+                if t.startswith(("global_load", "buffer_load")):
+                    assert " lds" not in t, (m.group(1), ident, "a staging copy behind the fence load")
+                    loads += 1
+                assert k < j + 200, (m.group(1), ident, "no wait behind the fence load")
+                k += 1
+            wait = int(re.search(r"vmcnt\((\d+)\)", body[k]).group(1))
+            if nb == 0:
+                assert loads == 0 and wait == 0, (m.group(1), ident, loads, wait)
+            else:
+                # every one of the NB items' loads (1-2 instructions per item) sits between the fence load and the wait, and the wait
+                # leaves exactly those in flight
+                assert nb <= loads <= 2 * nb, (m.group(1), ident, nb, loads)
+                assert wait == loads, (m.group(1), ident, "the wait behind the fence load drains requests that were meant to stay in flight", loads, wait)
+            checked += 1
+    assert checked >= 40, checked
+
+
+def test_no_global_load_lds_in_the_lean_kernel(tmp_path):
+    """with one pending the compiler answers every later wait with vmcnt(0) (hw.h: dma_buf_to_lds16)"""
+    s = _asm(tmp_path)
+    for m in re.finditer(r"^(_Z17qgemv_lean_kernel\w+):", s, re.M):
+        body = s[m.end():s.index(".Lfunc_end", m.end())]
+        assert "global_load_lds" not in body, m.group(1)
+        assert "buffer_load_dwordx4" in body and " lds" in body
