@@ -1,7 +1,8 @@
-"""`flash_attn` shim: lets the reference's paged-attention mode (attn.py:35-59 detects `import flash_attn` and
-`__version__ >= 2.5.7`; attn.py:602-613 calls `flash_attn_with_kvcache`) run on MI355X without flash-attn, on top of
-libexl2_hip.so (`exl2_rope_kv_append` + `exl2_paged_attn`, csrc/attn.hip).  Only the call shape the reference uses is
-accepted; anything else raises instead of silently computing something different."""
+"""`flash_attn` shim: lets the reference's flash-attn modes (attn.py:35-59 detects `import flash_attn` and `__version__ >=
+2.5.7`; attn.py:602-613 calls `flash_attn_with_kvcache` in paged mode, attn.py:960-977 `flash_attn_func` otherwise) run on
+MI355X without flash-attn, on top of libexl2_hip.so (`exl2_rope_kv_append`, `exl2_paged_attn`, `exl2_flash_prefill`:
+csrc/attn.hip, csrc/attn_prefill.hip).  Only the call shapes the reference uses are accepted; anything else raises instead of
+silently computing something different."""
 import torch
 
 from exllamav2_amd.ext import ext_c as _e
@@ -25,9 +26,54 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     return _e.flash_attn_with_kvcache(q, k_cache, v_cache, k, v, cache_seqlens, block_table, causal, softmax_scale)
 
 
-def flash_attn_func(*a, **k):
-    raise NotImplementedError("flash_attn shim: the reference only needs flash_attn_with_kvcache for paged mode; "
-                              "non-paged attention goes through its own _attn_torch / SDPA path")
+_scratch = {}
 
 
-flash_attn_varlen_func = flash_attn_func
+def _split_scratch(q):
+    """per-device work space of the split-KV decode kernel (csrc/attn.hip), grown on demand"""
+    b, s, nh, hd = q.shape
+    need = _e.paged_attn_scratch_bytes(b * s * nh, hd, 16) // 4 + 1
+    t = _scratch.get(q.device)
+    if t is None or t.numel() < need:
+        t = torch.zeros((need,), dtype=torch.float32, device=q.device)
+        _scratch[q.device] = t
+    return t
+
+
+def _whole_rows(t):
+    """k / v as the reference hands them over: `batch_keys[:b, :past + q_len]` (attn.py:1166-1167), a view whose batch stride is
+    the cache's max_seq_len -> the [b, T, KVH, hd] tensor the kernels index (same storage)."""
+    if t.is_contiguous():
+        return t
+    b, n, kvh, hd = t.shape
+    if t.stride(3) != 1 or t.stride(2) != hd or t.stride(1) != kvh * hd or t.stride(0) % (kvh * hd):
+        return t.contiguous()
+    return torch.as_strided(t, (b, t.stride(0) // (kvh * hd), kvh, hd), (t.stride(0), kvh * hd, hd, 1))
+
+
+def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                    alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """The reference's NON-paged attention call (attn.py:960-977 `_attn_flash`, chosen by attn.py:1141-1142 whenever flash-attn
+    is importable): q [b, s, H, hd] against k / v [b, past + s, KVH, hd] = the live rows of the cache (RoPE already applied by
+    q_attn_forward_1), causal bottom-right.  One launch of csrc/attn.hip (decode-shaped) or csrc/attn_prefill.hip (many query
+    rows) instead of the ~8 torch launches per layer of the reference's own `_attn_torch` fallback."""
+    if dropout_p or alibi_slopes is not None or return_attn_probs:
+        raise NotImplementedError("flash_attn shim: only the arguments exllamav2 passes are supported")
+    if tuple(window_size) != (-1, -1) or softcap:
+        raise NotImplementedError("flash_attn shim: sliding window / softcap are not built (SURVEY.md 8a row a15)")
+    b, s, nh, hd = q.shape
+    n = k.shape[1]
+    if not causal and s > 1:
+        raise NotImplementedError("flash_attn shim: the kernels are causal (bottom-right aligned), like every call of the reference")
+    if not q.is_contiguous():
+        q = q.contiguous()
+    kf, vf = _whole_rows(k), _whole_rows(v)
+    out = torch.empty_like(q)
+    if not (s > 16 and _e.flash_prefill(q, kf, vf, out, None, None, n - s, s, softmax_scale, True)):
+        _e.paged_attn(q, kf, vf, out, None, None, n - s, s, softmax_scale, True, 0, _split_scratch(q))
+    return out
+
+
+def flash_attn_varlen_func(*a, **k):
+    raise NotImplementedError("flash_attn shim: block-diagonal (varlen) attention is not built; the reference takes this path only "
+                              "for attn_params.block_diag_layers (vision towers, SURVEY.md 2: out of scope)")

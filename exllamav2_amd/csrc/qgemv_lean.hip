@@ -317,6 +317,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     // rest_ctx: everything else the decode needs, unpacked behind ALL requests.
     struct Rest { LeanCtx cx; float* red; int M; u32 flags; int chunk0, g0, gshift, gphase; bool uni; };
     struct Staged { u8* wbase; u32 off_sc, off_zp; int x_stride, xc0, M; };
+    constexpr int LEAN_X_PIECES = S == 16 ? 4 : 2;                        // (K = 28672 over 16 waves: 1792 rows = 224 units per slice)
     auto stage_copies = [&](Staged& P, auto tag) {
         // (a distinct marker per instantiation: identical copies of this code in two instantiations of `head` get merged by the
         // compiler otherwise, and then the registers of EITHER instantiation's pending requests count as pending here -- the
@@ -351,8 +352,8 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         const f16* const st = sc_tab + ((size_t)t_ * G + gw0) * 16;
         LEAN_MARK(decltype(tag)::value + 1);
         {
-            // straight-line code, <= 2 copy instructions per table and row (M <= 4 rows, slices of <= 128 16-byte units, <= 64
-            // scale rows: what the host plans)
+            // straight-line code: <= 2 copy instructions per scale table, <= LEAN_X_PIECES per activation row (M <= 4 rows,
+            // slices of <= 64 * LEAN_X_PIECES 16-byte units, <= 64 scale rows: what the host plans)
             if (lane < sc_units) LEAN_DMA(st, lane * 16, sc_lds);
             if (64 + lane < sc_units) LEAN_DMA(st, (64 + lane) * 16, sc_lds + 1024);
             if constexpr (GPTQ)
@@ -368,8 +369,9 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                 {
                     const f16* const row = in_a + (size_t)rr * lda;
                     u8* const dst = (u8*)(x_lds + (size_t)rr * x_stride);
-                    if (lane < xunits && xu0 + lane < oct) LEAN_DMA(row, (xu0 + lane) * 16, dst);
-                    if (64 + lane < xunits && xu0 + 64 + lane < oct) LEAN_DMA(row, (xu0 + 64 + lane) * 16, dst + 1024);
+                    #pragma unroll
+                    for (int u = 0; u < LEAN_X_PIECES; u++)
+                        if (u * 64 + lane < xunits && xu0 + u * 64 + lane < oct) LEAN_DMA(row, (xu0 + u * 64 + lane) * 16, dst + u * 1024);
                 }
             }
         }
@@ -716,7 +718,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
                 if (ok) shift = sh;
             }
             if (shift < 0 || c0 > 0xFFFF || c_end - c0 > 0xFFFF || g_lo > 0xFFFF || g_hi - g_lo + 1 > 0xFFFF) return 0;
-            if ((c_end - c0) * 4 > 128 || (g_hi - g_lo + 1) > 64 || M > 4) return 0;       // what the kernel's straight-line staging copies (stage_copies)
+            if ((c_end - c0) * 4 > 64 * (S == 16 ? 4 : 2) || (g_hi - g_lo + 1) > 64 || M > 4) return 0;   // what the kernel's straight-line staging copies (stage_copies)
             const bool uni = shift >= 2 && (phase & 3) == 0;                   // the four chunks of every full item share a group
             lw.w_off = r.off + (u32)i0 * 64u * (u32)r.bits; lw.w_tstride = r.tstride;
             lw.t_off = r.t_off; lw.t_tstride = r.t_tstride;

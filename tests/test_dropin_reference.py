@@ -227,3 +227,40 @@ def test_unmodified_reference_layer_split_on_the_dropin(tmp_path):
         w = oracle.forward(np.array([[int(tok)]]))
         g = got["steps"][:, i:i + 1, :cfg.vocab_size].astype(np.float64)
         assert np.all(np.abs(g - w) <= tol(w)), i
+
+
+@pytest.mark.gpu
+def test_unmodified_reference_flash_attn_func_on_the_dropin(tmp_path):
+    """The reference's non-paged decode as it runs wherever flash-attn is importable (attn.py:1141-1142 -> _attn_flash ->
+    flash_attn_func, attn.py:960-977): dropin/flash_attn serves the call with one launch of csrc/attn.hip on the live rows of the
+    reference's own ExLlamaV2Cache (K/V written there by q_attn_forward_1, the reference's `direct` mode).  Prompt of 4 rows,
+    then the greedy loop; logits against the oracle."""
+    ref = _reference_pkg()
+    if ref is None:
+        pytest.skip("no copy of the reference's host package on this machine")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.synth import synth_checkpoint
+    from exllamav2_amd.synth_dir import write_model_dir
+    from oracle.model import OracleModel
+    cfg = ExLlamaV2Config(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                          num_key_value_heads=2, head_dim=64, vocab_size=320, max_seq_len=256, max_input_len=32)
+    ck = synth_checkpoint(cfg, "cpu", seed=0, down_act_order=True)
+    oracle = OracleModel(cfg, ck)
+    model_dir = write_model_dir(str(tmp_path / "model"), cfg, ck)
+    out = str(tmp_path / "out_flash.npz")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "dropin"), ROOT, ref]))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_dropin.py"), model_dir, out, "flash"],
+                       env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    got = np.load(out)
+    ids = np.array([[3, 17, 42, 7]])
+    oracle.reset(1)
+    want = oracle.forward(ids)
+    tol = lambda w: 0.03 + np.abs(w) * 2.0 ** -8
+    assert np.all(np.abs(got["prefill"][..., :cfg.vocab_size].astype(np.float64) - want) <= tol(want))
+    for i, tok in enumerate(got["tokens"]):
+        w = oracle.forward(np.array([[int(tok)]]))
+        g = got["steps"][:, i:i + 1, :cfg.vocab_size].astype(np.float64)
+        assert np.all(np.abs(g - w) <= tol(w)), i

@@ -24,6 +24,10 @@ def main():
     p.add_argument("--layers", type=int, default=32)
     p.add_argument("--dir", default="/tmp/synth7b")
     p.add_argument("--recipe", default="4.0bpw")
+    p.add_argument("--attn", default="flash", choices=["flash", "torch"],
+                   help="flash: the reference's _attn_flash -> dropin/flash_attn.flash_attn_func (what it does wherever flash-attn is "
+                        "importable); torch: its own _attn_torch fallback (matmul branch)")
+    p.add_argument("--profile", action="store_true", help="cProfile the timed loop and print the top host-side entries to stderr")
     args = p.parse_args()
     ref = next((d for d in ("/root/reference", os.path.join(ROOT, "oracle", "_ref", "reference_py"))
                 if os.path.isfile(os.path.join(d, "exllamav2", "model.py"))), None)
@@ -50,8 +54,9 @@ def main():
     t0 = time.perf_counter()
     config = ExLlamaV2Config(args.dir)
     config.max_seq_len = 2048
-    config.no_flash_attn = True            # (no flash-attn package on the box: the reference's own _attn_torch, attn.py:869-937)
-    config.no_sdpa = True                  # its matmul branch: the SDPA branch of v0.3.2 is not causal when cu_seqlens is unset
+    if args.attn == "torch":
+        config.no_flash_attn = True        # the reference's own _attn_torch fallback (attn.py:869-937) ...
+        config.no_sdpa = True              # ... its matmul branch: the SDPA branch of v0.3.2 is not causal when cu_seqlens is unset
     model = ExLlamaV2(config)
     model.load()
     torch.cuda.synchronize()
@@ -65,6 +70,10 @@ def main():
         sample = torch.argmax(logits[0, -1]).cpu().unsqueeze(0).unsqueeze(0)
         ids = torch.cat((ids, sample), dim=-1)
     torch.cuda.synchronize()
+    prof = None
+    if args.profile:
+        import cProfile
+        prof = cProfile.Profile(); prof.enable()
     t0 = time.perf_counter()
     for _ in range(args.tokens):
         logits = model.forward(ids[:, -1:], cache)
@@ -72,9 +81,13 @@ def main():
         ids = torch.cat((ids, sample), dim=-1)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(28)
     print(json.dumps({"metric": "decode tokens/s, unmodified reference host on the drop-in (test_inference.py -s loop)",
                       "value": round(args.tokens / dt, 2), "unit": "tokens/s", "ms_per_token": round(dt / args.tokens * 1e3, 3),
-                      "tokens": args.tokens, "layers": args.layers, "recipe": args.recipe, "attention": "reference _attn_torch (matmul branch)",
+                      "tokens": args.tokens, "layers": args.layers, "recipe": args.recipe, "attention": "reference _attn_flash -> dropin/flash_attn.flash_attn_func (csrc/attn.hip)" if args.attn == "flash" else "reference _attn_torch (matmul branch)",
                       "write_dir_s": round(t_write, 1), "load_s": round(t_load, 1), "last_tokens": ids[0, -4:].tolist()}))
 
 

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 
-def main(model_dir: str, out: str, steps: int = 4):
+def main(model_dir: str, out: str, steps: int = 4, flash: bool = False):
     import exllamav2
     from exllamav2 import ExLlamaV2, ExLlamaV2Config, ExLlamaV2Cache
     from exllamav2.ext import ext_c
@@ -21,10 +21,13 @@ def main(model_dir: str, out: str, steps: int = 4):
     config = ExLlamaV2Config(model_dir)
     config.max_seq_len = 256
     config.max_input_len = 32
-    config.no_flash_attn = True                 # contiguous cache + the reference's own _attn_torch for this run ...
-    config.no_sdpa = True                       # ... in its matmul form: the SDPA branch of v0.3.2 passes get_block_diag_mask()
+    if not flash:
+        config.no_flash_attn = True             # contiguous cache + the reference's own _attn_torch for this run ...
+        config.no_sdpa = True                   # ... in its matmul form: the SDPA branch of v0.3.2 passes get_block_diag_mask()
                                                 # == None as the mask when cu_seqlens is unset (attn.py:890-891), i.e. it is
                                                 # NOT causal for q_len > 1 -- a reference bug off the flash-attn path
+    # flash: what the reference does wherever flash-attn is importable (attn.py:1141-1142): _attn_flash -> flash_attn_func,
+    # served by dropin/flash_attn (one launch of csrc/attn.hip per layer)
     model = ExLlamaV2(config)
     model.load()
     cache = ExLlamaV2Cache(model, max_seq_len=256)
@@ -40,7 +43,12 @@ def main(model_dir: str, out: str, steps: int = 4):
         logits = model.forward(ids[:, -1:], cache)
         all_logits.append(logits.float().cpu().numpy())
     res = dict(prefill=all_logits[0], steps=np.concatenate(all_logits[1:], axis=1), tokens=np.array(toks))
-    print("reference-on-dropin ok (contiguous cache, greedy loop):", toks)
+    print("reference-on-dropin ok (contiguous cache, greedy loop%s):" % (", flash_attn_func shim" if flash else ""), toks)
+    if flash:
+        from exllamav2 import attn as ref_attn
+        assert ref_attn.has_flash_attn and not config.no_flash_attn
+        np.savez(out, **res)
+        return
 
     # ---- ExLlamaV2DynamicGenerator, paged mode: attn.py:466-638 forward_paged -> flash_attn_with_kvcache (dropin/flash_attn ->
     # exl2_rope_kv_append + exl2_paged_attn), page table / defragmenter / prefix matching of dynamic.py untouched
@@ -161,5 +169,7 @@ if __name__ == "__main__":
         main_tp(sys.argv[1], sys.argv[2])
     elif len(sys.argv) > 3 and sys.argv[3] == "split":
         main_split(sys.argv[1], sys.argv[2])
+    elif len(sys.argv) > 3 and sys.argv[3] == "flash":
+        main(sys.argv[1], sys.argv[2], flash=True)
     else:
         main(sys.argv[1], sys.argv[2])
