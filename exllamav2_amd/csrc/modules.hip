@@ -649,29 +649,35 @@ int exl2_q_attn_forward_2_chain(void* handle, void* x, const void* attn_out_pack
     return EXL2_OK;
 }
 
-int exl2_q_mlp_forward_chain(void* handle, void* x, const void* xp, const float* ss, int npart, int rows,
-                             const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, int* npart_out, void* stream)
+// part: 1 = gate | up only, 2 = down only, 3 = both (exl2_q_mlp_forward_chain).  Row groups (model.py): gate | up reads K = hidden,
+// down K = intermediate -- the rows whose staged copy fits in LDS differ, so a step may group the rows differently for the two.
+static int q_mlp_chain_part(void* handle, int part, void* x, const void* xp, const float* ss, int npart, int rows, int row0,
+                            const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, int* npart_out, void* stream)
 {
-    EXL2_REQUIRE(handle && x && xp && ss, "q_mlp_forward_chain: null argument");
+    EXL2_REQUIRE(handle && x, "q_mlp_forward_chain: null argument");
     QMLP* m = (QMLP*)handle;
     EXL2_REQUIRE(m->chain_ok, "q_mlp_forward_chain: module is not chain-capable");
     if (rows <= 0) return EXL2_OK;
-    EXL2_REQUIRE(rows <= m->max_rows && rows <= MAX_GEMV_ROWS, "q_mlp_forward_chain: %d rows", rows);
+    EXL2_REQUIRE(row0 >= 0 && row0 + rows <= m->max_rows && rows <= MAX_GEMV_ROWS, "q_mlp_forward_chain: rows %d + %d", row0, rows);
     const int hidden = m->up->height, inter = m->up->width;
+    f16* const act = m->temp_a + (size_t)row0 * inter;              // SiLU(gate) * up of rows [row0, row0 + rows), down's packed order
+    if (part & 1)
     {
+        EXL2_REQUIRE(xp && ss, "q_mlp_forward_chain: null argument");
         // gate | up from (xp, ss); SiLU(gate) * up in the epilogue, written in down's packed order
         FlatIn in; memset(&in, 0, sizeof(in));
-        in.qm[0] = m->gate; in.qm[1] = m->up; in.c[0] = m->temp_a; in.c[1] = m->temp_a; in.ldc[0] = inter; in.ldc[1] = inter;
+        in.qm[0] = m->gate; in.qm[1] = m->up; in.c[0] = act; in.c[1] = act; in.ldc[0] = inter; in.ldc[1] = inter;
         in.c_invperm[0] = m->down->q_perm ? m->down->q_invperm : nullptr;
         in.n_mats = 2; in.pair = 1; in.M = rows; in.a_mode = A_NORM_PRE; in.a = (const f16*)xp; in.lda = hidden;
         in.ss = ss; in.npart = npart; in.eps = m->norm_epsilon; in.c_mode = C_STORE;
         in.act_gelu = m->act_gelu ? 1 : 0;
         FLAT_TRY(in, stream, nullptr, "q_mlp_forward_chain");
     }
+    if (part & 2)
     {
         FlatIn in; memset(&in, 0, sizeof(in));
         in.qm[0] = m->down; in.c[0] = (f16*)x; in.ldc[0] = hidden;
-        in.n_mats = 1; in.M = rows; in.a_mode = A_DIRECT; in.a = m->temp_a; in.lda = inter; in.c_mode = C_ACCUM;
+        in.n_mats = 1; in.M = rows; in.a_mode = A_DIRECT; in.a = act; in.lda = inter; in.c_mode = C_ACCUM;
         in.xp_out = (f16*)xp_out; in.xp_invperm = (const u16*)next_invperm; in.xp_w = (const f16*)next_norm_w;
         in.ss_out = xp_out ? ss_out : nullptr; in.ldxp = hidden;
         int wgs = 0;
@@ -679,6 +685,21 @@ int exl2_q_mlp_forward_chain(void* handle, void* x, const void* xp, const float*
         if (npart_out) *npart_out = wgs;
     }
     return EXL2_OK;
+}
+
+int exl2_q_mlp_forward_chain(void* handle, void* x, const void* xp, const float* ss, int npart, int rows,
+                             const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, int* npart_out, void* stream)
+{
+    EXL2_REQUIRE(handle && x && xp && ss, "q_mlp_forward_chain: null argument");
+    return q_mlp_chain_part(handle, 3, x, xp, ss, npart, rows, 0, next_invperm, next_norm_w, xp_out, ss_out, npart_out, stream);
+}
+
+int exl2_q_mlp_forward_chain_part(void* handle, int part, int row0, void* x, const void* xp, const float* ss, int npart, int rows,
+                                  const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, int* npart_out,
+                                  void* stream)
+{
+    EXL2_REQUIRE(part == 1 || part == 2, "q_mlp_forward_chain_part: part %d", part);
+    return q_mlp_chain_part(handle, part, x, xp, ss, npart, rows, row0, next_invperm, next_norm_w, xp_out, ss_out, npart_out, stream);
 }
 
 int exl2_gemm_half_q_half_chain(const void* xp, const float* ss, int npart, float eps,

@@ -267,7 +267,13 @@ DEV const void* ptr_of(u32 lo, u32 hi) { return (const void*)global_ptr_of(lo, h
 #else
 #define LEAN_BOUNDS(T, OCC)
 #endif
-template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC>
+// ROWS (5 .. 16 rows; round 4): the M x K activations no longer fit as wave-private slices next to each other, so the
+// workgroup stages the WHOLE rows once, cooperatively (every wave copies a share; one barrier), into an area all its tiles
+// read: the pair geometry's gate and up tiles -- and their 16 waves -- share one copy.  One workgroup per CU then (128 KB at
+// 16 x 4096); no pipelined form (the barrier sits between the requests and the decode anyway), every finalising wave takes
+// several rows.  Replaces the row pre-pass + K-phased kernels (qgemv_stream.hip / qgemm_prefill.hip) on the chained path
+// wherever M x (K + 8) x 2 bytes fit in LDS; larger K is served as row groups of <= 4 rows by the host (model.py).
+template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false>
 KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs args)
 {
     DYN_SMEM(smem);
@@ -317,7 +323,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     // rest_ctx: everything else the decode needs, unpacked behind ALL requests.
     struct Rest { LeanCtx cx; float* red; int M; u32 flags; int chunk0, g0, gshift, gphase; bool uni; };
     struct Staged { u8* wbase; u32 off_sc, off_zp; int x_stride, xc0, M; };
-    constexpr int LEAN_X_PIECES = S == 16 ? 4 : 2;                        // (K = 28672 over 16 waves: 1792 rows = 224 units per slice)
+    constexpr int LEAN_X_PIECES = 4;                                      // (K = 28672 over 16 waves: 1792 rows = 224 16-byte units per slice)
     auto stage_copies = [&](Staged& P, auto tag) {
         // (a distinct marker per instantiation: identical copies of this code in two instantiations of `head` get merged by the
         // compiler otherwise, and then the registers of EITHER instantiation's pending requests count as pending here -- the
@@ -337,12 +343,14 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         const int xc0 = (int)(xr & 0xFFFFu), xchunks = (int)(xr >> 16);
         const int gw0 = (int)(gr & 0xFFFFu), ng = (int)(gr >> 16);
         // the wave's LDS area: [M rows of the activation slice][scale rows][zero-point rows]
-        const int x_stride = (int)w2.w;
-        u8* const wbase = smem + (size_t)slot * h3.x + w1.w;
+        // (ROWS: the workgroup's shared rows come first, x_stride = K + 8; a wave's own area holds its scale rows only)
+        const int x_stride = ROWS ? K + 8 : (int)w2.w;
+        const u32 rows_bytes = ROWS ? (((u32)M * (u32)x_stride * 2u + 15u) & ~15u) : 0u;
+        u8* const wbase = smem + rows_bytes + (size_t)slot * h3.x + w1.w;
         f16* const x_lds = (f16*)wbase;
         u8* const sc_lds = wbase + w2.y;
         u8* const zp_lds = wbase + w2.z;
-        P.wbase = wbase; P.off_sc = w2.y; P.off_zp = w2.z; P.x_stride = x_stride; P.xc0 = xc0; P.M = M;
+        P.wbase = wbase; P.off_sc = w2.y; P.off_zp = w2.z; P.x_stride = x_stride; P.xc0 = ROWS ? 0 : xc0; P.M = M;
         // requests: scale rows, activation slice.  The common case -- one row, <= 64 units (16 bytes) of each -- is straight-line
         // code, one LDS-DMA instruction per table (the compiler's loop skeletons around run-time trip counts cost more
         // instructions per wave than the decode of an item)
@@ -362,16 +370,34 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                 if (lane < sc_units) LEAN_DMA(zt, lane * 16, zp_lds);
                 if (64 + lane < sc_units) LEAN_DMA(zt, (64 + lane) * 16, zp_lds + 1024);
             }
-            #pragma unroll
-            for (int rr = 0; rr < 4; rr++)
+            if constexpr (!ROWS)
             {
-                if (rr < M)
+                #pragma unroll
+                for (int rr = 0; rr < 4; rr++)
+                {
+                    if (rr < M)
+                    {
+                        const f16* const row = in_a + (size_t)rr * lda;
+                        u8* const dst = (u8*)(x_lds + (size_t)rr * x_stride);
+                        #pragma unroll
+                        for (int u = 0; u < LEAN_X_PIECES; u++)
+                            if (u * 64 + lane < xunits && xu0 + u * 64 + lane < oct) LEAN_DMA(row, (xu0 + u * 64 + lane) * 16, dst + u * 1024);
+                    }
+                }
+            }
+            else
+            {
+                // the whole rows, dealt out over the workgroup's waves in 1 KB pieces (piece p of row rr -> wave (p + rr) mod waves)
+                constexpr int WAVES = S * NSLOTS;
+                const int pieces = (oct + 63) >> 6;
+                #pragma nounroll
+                for (int rr = 0; rr < M; rr++)
                 {
                     const f16* const row = in_a + (size_t)rr * lda;
-                    u8* const dst = (u8*)(x_lds + (size_t)rr * x_stride);
-                    #pragma unroll
-                    for (int u = 0; u < LEAN_X_PIECES; u++)
-                        if (u * 64 + lane < xunits && xu0 + u * 64 + lane < oct) LEAN_DMA(row, (xu0 + u * 64 + lane) * 16, dst + u * 1024);
+                    u8* const dst = smem + (size_t)rr * x_stride * 2;
+                    #pragma nounroll
+                    for (int pc = (wv + WAVES - (rr % WAVES)) % WAVES; pc < pieces; pc += WAVES)
+                        if (pc * 64 + lane < oct) LEAN_DMA(row, (pc * 64 + lane) * 16, dst + (size_t)pc * 1024);
                 }
             }
         }
@@ -388,7 +414,8 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         R.gshift = (int)((meta >> 16) & 0x7u); R.gphase = (int)((meta >> 19) & 0x3FFu);
         R.chunk0 = (int)(w2x & 0xFFFFu); R.g0 = (int)(w2x >> 16);
         R.red = (float*)(smem + h3.y);
-        R.cx.x_lds = (const f16*)P.wbase; R.cx.sc_lds = (const f16*)(P.wbase + P.off_sc); R.cx.zp_lds = (const f16*)(P.wbase + P.off_zp);
+        R.cx.x_lds = ROWS ? (const f16*)smem : (const f16*)P.wbase;
+        R.cx.sc_lds = (const f16*)(P.wbase + P.off_sc); R.cx.zp_lds = (const f16*)(P.wbase + P.off_zp);
         R.cx.x_stride = P.x_stride; R.cx.xc0 = P.xc0; R.cx.M = P.M;
     };
 
@@ -427,6 +454,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         LTRACE(3);
         rest_ctx(R, P);
         fence_load_use(fence);               // the first part, the activation slice and the scale rows have landed
+        if constexpr (ROWS) { wait_vmcnt_le<0>(); block_sync_lds(); }      // every wave's share of the rows has landed
         wave_converge();
         LTRACE(4);
         auto item = [&](const LaneWords<BITS>& w, int q) {
@@ -478,7 +506,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     auto head_bits = [&](auto bits_tag) {
         constexpr int BITS = decltype(bits_tag)::value;
         constexpr int NB = LeanTail<BITS, S>::v;
-        if constexpr (NB > 0)
+        if constexpr (NB > 0 && !ROWS)
         {
             if (n >= NB && n <= LeanDepth<BITS, S>::v && pipe_on) { head(bits_tag, std::integral_constant<int, NB>()); return; }
         }
@@ -492,6 +520,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         LTRACE(3);
         rest_ctx(R, P);
         wait_vmcnt_le<0>();
+        if constexpr (ROWS) block_sync_lds();
         wave_converge();
         LTRACE(4);
     }
@@ -525,92 +554,111 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
             if (row < M) red[(wv * M + row) * 16 + c] = acc[q];
         }
     }
-    if (wv >= M) { LTRACE(5); block_sync_lds(); return; }
-    // the finalising waves (wave `row` finalises row `row`; they sit in slot 0, so the block of THEIR matrix is the output's):
-    // lane -> output slot lane >> 4 (pair: the one act(gate) * up output), column lane & 15.  What the epilogue needs from
-    // memory is requested before the barrier.
-    const int row = wv;
+    // the finalising waves (wave `row` finalises row `row` -- ROWS: rows row, row + waves, ...; they sit in slot 0, so the block of
+    // THEIR matrix is the output's): lane -> output slot lane >> 4 (pair: the one act(gate) * up output), column lane & 15.
     constexpr int N_OUT = PAIR ? 1 : NSLOTS;
     const int ep_slot = lane >> 4, ep_c = lane & 15;
     const int ep_tile = tile + (PAIR ? 0 : ep_slot);                    // (finalising waves sit in slot 0)
     const bool ep_on = ep_slot < N_OUT && ep_tile < n_tiles;
     const int ep_n = ep_tile * 16 + ep_c;
-    f16* cp = nullptr;
-    f16 c_old = (f16)0.0f;
-    int xp_idx = ep_n;
     f16* const xp_out = args.hdr.xp_out;
-    f16 xw_next = (f16)1.0f;
-    if (ep_on)
-    {
-        const u16* const c_invperm = args.mat[mj].c_invperm;
-        const u16* const xp_invperm = args.hdr.xp_invperm;
-        const int c_idx = c_invperm ? (int)c_invperm[ep_n] : ep_n;
-        if (xp_out && xp_invperm) xp_idx = (int)xp_invperm[ep_n];
-        if (xp_out && args.hdr.xp_w) xw_next = args.hdr.xp_w[xp_idx];
-        cp = args.mat[mj].c + (size_t)row * args.hdr.ldc[mj] + c_idx;
-        if (flags & LF_ACCUM) c_old = *cp;
-    }
-    // A_NORM_PRE: the activations were x * w (qgemv_flat.h); 1 / rms(x) multiplies the finished sum.  The partial sums of
-    // squares of this row: requested before the barrier, reduced behind it (fixed order)
-    float ssq = 0.0f;
-    if (flags & LF_NORM)
-    {
-        const float* sp = args.hdr.ss + (size_t)row * args.hdr.npart;
-        #pragma nounroll
-        for (int i = lane; i < args.hdr.npart; i += 64) ssq += sp[i];
-    }
-    LTRACE(5);
-    block_sync_lds();
-    LTRACE(6);
-    float rms = 1.0f;
-    if (flags & LF_NORM)
-    {
-        ssq = wave_allreduce_add(ssq);
-        rms = fast_rsqrt(ssq * (1.0f / (float)args.hdr.K) + args.hdr.eps);
-    }
-
-    // ---- combine (fixed order) + epilogue ------------------------------------------------------------------------------------
-    auto slot_sum = [&](int s) -> float {
-        float v = 0.0f;
-        for (int w = s * S; w < s * S + S; w++) v += red[(w * M + row) * 16 + ep_c];
-        return v;
+    struct EpIn { f16* cp; f16 c_old; int xp_idx; f16 xw_next; float ssq; };
+    // what a row's epilogue needs from memory
+    auto ep_inputs = [&](int row, EpIn& e) {
+        e.cp = nullptr; e.c_old = (f16)0.0f; e.xp_idx = ep_n; e.xw_next = (f16)1.0f; e.ssq = 0.0f;
+        if (ep_on)
+        {
+            const u16* const c_invperm = args.mat[mj].c_invperm;
+            const u16* const xp_invperm = args.hdr.xp_invperm;
+            const int c_idx = c_invperm ? (int)c_invperm[ep_n] : ep_n;
+            if (xp_out && xp_invperm) e.xp_idx = (int)xp_invperm[ep_n];
+            if (xp_out && args.hdr.xp_w) e.xw_next = args.hdr.xp_w[e.xp_idx];
+            e.cp = args.mat[mj].c + (size_t)row * args.hdr.ldc[mj] + c_idx;
+            if (flags & LF_ACCUM) e.c_old = *e.cp;
+        }
+        // A_NORM_PRE: the activations were x * w (qgemv_flat.h); 1 / rms(x) multiplies the finished sum.  The partial sums of
+        // squares of this row (fixed order)
+        if (flags & LF_NORM)
+        {
+            const float* sp = args.hdr.ss + (size_t)row * args.hdr.npart;
+            #pragma nounroll
+            for (int i = lane; i < args.hdr.npart; i += 64) e.ssq += sp[i];
+        }
     };
-    float sq = 0.0f;
-    if (ep_on && !(LEAN_KILL & 4))
-    {
-        f16 y;
-        if constexpr (PAIR)
+    // combine (fixed order) + epilogue of one row
+    auto ep_finish = [&](int row, const EpIn& e) {
+        float rms = 1.0f;
+        if (flags & LF_NORM)
         {
-            float gv = slot_sum(0) * rms, uv = slot_sum(1) * rms;
-            if (flags & LF_BIAS)
+            const float ssq = wave_allreduce_add(e.ssq);
+            rms = fast_rsqrt(ssq * (1.0f / (float)args.hdr.K) + args.hdr.eps);
+        }
+        auto slot_sum = [&](int sl) -> float {
+            float v = 0.0f;
+            for (int w = sl * S; w < sl * S + S; w++) v += red[(w * M + row) * 16 + ep_c];
+            return v;
+        };
+        float sq = 0.0f;
+        if (ep_on && !(LEAN_KILL & 4))
+        {
+            f16 y;
+            if constexpr (PAIR)
             {
-                if (args.mat[0].bias) gv += (float)args.mat[0].bias[ep_n];
-                if (args.mat[1].bias) uv += (float)args.mat[1].bias[ep_n];
+                float gv = slot_sum(0) * rms, uv = slot_sum(1) * rms;
+                if (flags & LF_BIAS)
+                {
+                    if (args.mat[0].bias) gv += (float)args.mat[0].bias[ep_n];
+                    if (args.mat[1].bias) uv += (float)args.mat[1].bias[ep_n];
+                }
+                y = clamp_h(act_h((f16)gv, (flags & LF_GELU) != 0) * (f16)uv);
             }
-            y = clamp_h(act_h((f16)gv, (flags & LF_GELU) != 0) * (f16)uv);
+            else
+            {
+                float v = slot_sum(ep_slot) * rms;
+                if (flags & LF_BIAS) { const f16* bias = args.mat[mj].bias; if (bias) v += (float)bias[ep_n]; }
+                if (flags & LF_ACCUM) v += (float)e.c_old;
+                y = (f16)v;
+            }
+            *e.cp = y;
+            if (xp_out)
+            {
+                // chain-out: x for the next consumer = x * ITS norm weight (one rounding, saturated), in its packed order; the sum
+                // of squares is x's own
+                const float f = fmaxf(-65504.0f, fminf((float)y, 65504.0f));
+                xp_out[(size_t)row * args.hdr.ldxp + e.xp_idx] = (f16)fmaxf(-65504.0f, fminf(f * (float)e.xw_next, 65504.0f));
+                sq = f * f;
+            }
         }
-        else
+        float* const ss_out = args.hdr.ss_out;
+        if (ss_out)
         {
-            float v = slot_sum(ep_slot) * rms;
-            if (flags & LF_BIAS) { const f16* bias = args.mat[mj].bias; if (bias) v += (float)bias[ep_n]; }
-            if (flags & LF_ACCUM) v += (float)c_old;
-            y = (f16)v;
+            sq = wave_allreduce_add(sq);
+            if (lane == 0) ss_out[(size_t)row * args.hdr.wgs + u] = sq;
         }
-        *cp = y;
-        if (xp_out)
-        {
-            // chain-out: x for the next consumer = x * ITS norm weight (one rounding, saturated), in its packed order; the sum of
-            // squares is x's own
-            const float f = fmaxf(-65504.0f, fminf((float)y, 65504.0f));
-            xp_out[(size_t)row * args.hdr.ldxp + xp_idx] = (f16)fmaxf(-65504.0f, fminf(f * (float)xw_next, 65504.0f));
-            sq = f * f;
-        }
-    }
-    float* const ss_out = args.hdr.ss_out;
-    if (ss_out)
+    };
+    if constexpr (!ROWS)
     {
-        sq = wave_allreduce_add(sq);
-        if (lane == 0) ss_out[(size_t)row * args.hdr.wgs + u] = sq;
+        if (wv >= M) { LTRACE(5); block_sync_lds(); return; }
+        // what the epilogue needs from memory is requested before the barrier
+        EpIn e;
+        ep_inputs(wv, e);
+        LTRACE(5);
+        block_sync_lds();
+        LTRACE(6);
+        ep_finish(wv, e);
+    }
+    else
+    {
+        LTRACE(5);
+        block_sync_lds();
+        LTRACE(6);
+        #pragma nounroll
+        for (int row = wv; row < M; row += S * NSLOTS)
+        {
+            EpIn e;
+            ep_inputs(row, e);
+            ep_finish(row, e);
+        }
     }
     LTRACE(7);
 }
@@ -632,7 +680,7 @@ struct LeanRun { int F, bits, chunk0; u32 off, tstride; int tail_nv; u32 t_off, 
 // decoder per wave, everything in registers); the waves are dealt out to the runs in proportion to their bytes.  Fills
 // wave[0 .. S) and returns the LDS bytes of the S waves together, 0 when the matrix is not covered with S waves (more runs
 // than waves, more items than a wave's registers hold, a chunk -> group map that is not affine inside a part, ...).
-static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave* wave)
+static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave* wave, bool rows_mode = false)
 {
     const QMatDev& d = qm->dev;
     if (d.n_runs <= 0 || !qm->cg_host || !d.sc_tab || (qm->is_gptq && !d.zp_tab)) return 0;
@@ -718,7 +766,8 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
                 if (ok) shift = sh;
             }
             if (shift < 0 || c0 > 0xFFFF || c_end - c0 > 0xFFFF || g_lo > 0xFFFF || g_hi - g_lo + 1 > 0xFFFF) return 0;
-            if ((c_end - c0) * 4 > 64 * (S == 16 ? 4 : 2) || (g_hi - g_lo + 1) > 64 || M > 4) return 0;   // what the kernel's straight-line staging copies (stage_copies)
+            // what the kernel's straight-line staging copies (stage_copies); ROWS: the rows are staged by the workgroup, any length
+            if ((g_hi - g_lo + 1) > 64 || (!rows_mode && ((c_end - c0) * 4 > 256 || M > 4))) return 0;
             const bool uni = shift >= 2 && (phase & 3) == 0;                   // the four chunks of every full item share a group
             lw.w_off = r.off + (u32)i0 * 64u * (u32)r.bits; lw.w_tstride = r.tstride;
             lw.t_off = r.t_off; lw.t_tstride = r.t_tstride;
@@ -730,9 +779,9 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
             const u32 x_stride = (u32)(c_end - c0) * 32u + 8u;
             (void)norm;
             lw.x_stride = x_stride;
-            lw.off_sc = al16((u32)M * x_stride * 2u);
+            lw.off_sc = rows_mode ? 0u : al16((u32)M * x_stride * 2u);
             lw.off_zp = lw.off_sc + al16((u32)(g_hi - g_lo + 1) * 32u);
-            lds_total += al16((u32)M * x_stride * 2u) + al16((u32)(g_hi - g_lo + 1) * 32u) * (qm->is_gptq ? 2u : 1u);
+            lds_total += lw.off_sc + al16((u32)(g_hi - g_lo + 1) * 32u) * (qm->is_gptq ? 2u : 1u);
             i0 += n;
         }
         if (i0 != r.F) return 0;
@@ -741,6 +790,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
 }
 
 #define LEAN_FOR_EACH_GEOMETRY(X, OCC) X(8, 1, false, OCC) X(16, 1, false, OCC) X(8, 2, false, OCC) X(8, 2, true, OCC) X(4, 2, true, OCC)
+#define LEAN_FOR_EACH_ROWS_GEOMETRY(X) X(8, 1, false) X(16, 1, false) X(8, 2, true)
 // register budget: 6 waves per SIMD (80 registers: no spills on the common paths, three 8-wave workgroups per CU).  4 and 8
 // were built side by side during the round and measured (4 slower; 8 equal within noise once gate|up used 8-wave workgroups,
 // with spills): tools/build_variant.sh -DLEAN_OCC_DEFAULT=... rebuilds them
@@ -760,13 +810,21 @@ static void lean_attrs()
     (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LEAN_FOR_EACH_GEOMETRY(LEAN_ATTR, 6)
 #undef LEAN_ATTR
+#define LEAN_ATTR(S, NS, P) \
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, S, NS, P, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    LEAN_FOR_EACH_ROWS_GEOMETRY(LEAN_ATTR)
+#undef LEAN_ATTR
 }
 
 // 0: launched; 1: shape not covered (the caller takes the round-2 kernel).  *wgs_out = grid size = partial sums per row a
 // chain-out launch publishes.
 int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
 {
-    if (in.n_mats < 1 || in.n_mats > FLAT_MAX_MATS || in.M < 1 || in.M > LEAN_MAX_M) return 1;
+    if (in.n_mats < 1 || in.n_mats > FLAT_MAX_MATS || in.M < 1 || in.M > LEAN_MAX_ROWS) return 1;
+    static const int rows_on = []() { const char* e = getenv("EXL2_LEAN_ROWS"); return e ? atoi(e) : 1; }();
+    const bool rows_mode = in.M > LEAN_MAX_M;
+    if (rows_mode && !rows_on) return 1;
     if (in.sync_wait || in.sync_signal || in.sync_arrive) return 1;
     if (const char* e = getenv("EXL2_LEAN_DECLINE_M")) { if (atoi(e) == in.M) return 1; }      // test hook: row groups on different kernels
     const QMatrix* q0 = in.qm[0];
@@ -803,6 +861,9 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     if (in.pair && in.M == 1 && pair4) cand[n_cand++] = 4;
     cand[n_cand++] = S;
     if (!in.pair && nslots == 1 && S == 8) cand[n_cand++] = 16;        // finer split of the tile
+    if (rows_mode && (nslots != (in.pair ? 2 : 1))) return 1;          // ROWS geometries: (8, 1), (16, 1), pair (8 + 8)
+    // ROWS: the workgroup's shared copy of the M rows, in front of the waves' own (scale-row) areas
+    const u32 rows_bytes = rows_mode ? al16((u32)in.M * (u32)(K + 8) * 2u) : 0u;
     u32 slot_bytes = 0;
     bool planned = false;
     // (second round: a split that fits only with the whole LDS of a CU -- 2-4 rows of a K = 11008 matrix -- is still better
@@ -810,17 +871,17 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     for (int ci = 0; ci < 2 * n_cand && !planned; ci++)
     {
         S = cand[ci % n_cand];
-        const u32 budget = ci < n_cand ? LEAN_LDS_BUDGET * (u32)((S * nslots + 7) / 8) : 150u * 1024u;
+        const u32 budget = rows_mode ? 158u * 1024u : (ci < n_cand ? LEAN_LDS_BUDGET * (u32)((S * nslots + 7) / 8) : 150u * 1024u);
         if (in.n_mats * S > LEAN_RECORDS) continue;
         bool ok = true;
         slot_bytes = 0;
         for (int j = 0; j < in.n_mats && ok; j++)
         {
-            const u32 b = lean_plan_matrix(in.qm[j], S, in.M, in.a_mode == A_NORM_PRE, a.wave + j * S);
+            const u32 b = lean_plan_matrix(in.qm[j], S, in.M, in.a_mode == A_NORM_PRE, a.wave + j * S, rows_mode);
             if (!b) ok = false;
             if (b > slot_bytes) slot_bytes = b;
         }
-        planned = ok && (u32)nslots * slot_bytes + (u32)(S * nslots) * (u32)in.M * 64u <= budget;
+        planned = ok && rows_bytes + (u32)nslots * slot_bytes + (u32)(S * nslots) * (u32)in.M * 64u <= budget;
     }
     if (!planned) return 1;
     const int wgs = in.pair ? max_tiles : (max_tiles + nslots - 1) / nslots;
@@ -836,7 +897,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     h.a = in.a; h.xp_w = in.xp_w; h.ss = in.ss; h.xp_out = in.xp_out; h.xp_invperm = in.xp_invperm; h.ss_out = in.ss_out;
     h.eps = in.eps; h.M = in.M; h.K = K; h.lda = in.lda; h.ldxp = in.ldxp; h.npart = in.npart; h.wgs = wgs;
     h.flags = (in.a_mode == A_NORM_PRE ? LF_NORM : 0u) | (in.act_gelu ? LF_GELU : 0u) | (in.c_mode == C_ACCUM ? LF_ACCUM : 0u) | (any_bias ? LF_BIAS : 0u);
-    h.slot_bytes = slot_bytes; h.red_off = slot_bytes * (u32)nslots;
+    h.slot_bytes = slot_bytes; h.red_off = rows_bytes + slot_bytes * (u32)nslots;
     const int waves = S * nslots;
     const u32 lds = h.red_off + (u32)waves * (u32)in.M * 16u * 4u;
     lean_attrs();
@@ -859,12 +920,17 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     dim3 grid((unsigned)wgs, (unsigned)(in.pair ? 1 : in.n_mats), 1), block((unsigned)waves * 64, 1, 1);
     const bool gptq = q0->is_gptq;
     const int occ = LEAN_OCC_DEFAULT;
+#define LEAN_GO(SS, NS, P) \
+    if (rows_mode && !gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, 4, true>), grid, block, lds, stream, a); \
+    if (rows_mode && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, 4, true>), grid, block, lds, stream, a);
+    LEAN_FOR_EACH_ROWS_GEOMETRY(LEAN_GO)
+#undef LEAN_GO
 #define LEAN_GO(SS, NS, P, OCC) \
-    if (!gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a);
+    if (!rows_mode && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_GEOMETRY(LEAN_GO, LEAN_OCC_DEFAULT)
 #undef LEAN_GO
 #define LEAN_GO(SS, NS, P, OCC) \
-    if (gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC>), grid, block, lds, stream, a);
+    if (!rows_mode && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_GEOMETRY(LEAN_GO, 6)
 #undef LEAN_GO
     if (wgs_out) *wgs_out = wgs;

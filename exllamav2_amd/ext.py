@@ -585,6 +585,17 @@ class ExtC:
             self._ptr(ss_out, torch.float32, "ss_out"), C.byref(n), self._stream(x)))
         return n.value
 
+    def q_mlp_forward_chain_part(self, q_mlp, part: int, row0: int, x, xp, ss, npart: int, rows: int, next_invperm, next_norm_w,
+                                 xp_out, ss_out) -> int:
+        """one half of q_mlp_forward_chain for rows [row0, row0 + rows) (tensors are the row-group slices): part 1 = gate | up,
+        part 2 = down (returns the partial sums per row it published)"""
+        n = C.c_int(0)
+        self.lib.check(self.lib.exl2_q_mlp_forward_chain_part(
+            q_mlp, int(part), int(row0), self._ptr(x, torch.float16, "x"), self._ptr(xp, torch.float16, "xp"),
+            self._ptr(ss, torch.float32, "ss"), int(npart), int(rows), next_invperm or None, self._w_ptr(next_norm_w),
+            self._ptr(xp_out, torch.float16, "xp_out"), self._ptr(ss_out, torch.float32, "ss_out"), C.byref(n), self._stream(x)))
+        return n.value
+
     def gemm_half_q_half_chain(self, xp, ss, npart: int, eps: float, q_handle: int, c, rows: int) -> None:
         """c = rmsnorm(x) . W from xp = x * norm weight (applied by xp's producer, in W's packed order) and ss"""
         self.lib.check(self.lib.exl2_gemm_half_q_half_chain(

@@ -161,6 +161,42 @@ class ExLlamaV2:
         return out
 
 
+class _PartialSums:
+    """Host-side layout of one buffer of partial sums of squares of the chained step.  A producer launch writes its rows packed,
+    `[rows, P]` with P = the number of partials per row it published (known when the launch returns); a consumer launch reads
+    `[rows, P]` from one base pointer.  Launches of a step may group the rows differently (csrc/qgemv_lean.hip ROWS form: the rows
+    that fit in LDS depend on K), so groups are packed one behind the other and a consumer's rows must come out contiguous with one
+    P -- which they do whenever the producer groups they span published the same P."""
+
+    def __init__(self, buf: torch.Tensor, rows: int):
+        self.buf, self.rows = buf.view(-1), rows
+        self.pos, self.count = [0] * rows, [1] * rows
+        self.next = 0
+
+    def begin(self):
+        """a producer pass over all rows starts"""
+        self.next = 0
+
+    def out(self, r0: int, r1: int) -> torch.Tensor:
+        self._pending = (r0, r1, self.next)
+        return self.buf[self.next:]
+
+    def done(self, count: int):
+        r0, r1, start = self._pending
+        if start + (r1 - r0) * count > self.buf.numel():
+            raise RuntimeError("chained decode: partial sums exceed their buffer: shape not covered by the chained decode kernel")
+        for r in range(r0, r1):
+            self.pos[r], self.count[r] = start + (r - r0) * count, count
+        self.next = start + (r1 - r0) * count
+
+    def inp(self, r0: int, r1: int, what: str):
+        c = self.count[r0]
+        if any(self.count[r] != c or self.pos[r] != self.pos[r0] + (r - r0) * c for r in range(r0, r1)):
+            raise RuntimeError(f"chained decode: {what} rows {r0}..{r1 - 1} were produced with different numbers of partial sums: "
+                               f"shape not covered by the chained decode kernel")
+        return self.buf[self.pos[r0]:], c
+
+
 class GreedyGraphDecoder:
     """One greedy decode step (embedding -> all layers -> norm -> head -> argmax -> advance positions) captured as a HIP
     graph.  Procedure = test_inference.py:604-609 (forward(ids[:, -1:], cache); argmax; append) with the token feedback
@@ -221,11 +257,14 @@ class GreedyGraphDecoder:
             "ss_a": torch.zeros((self.b, 512), dtype=torch.float32, device=dev),
             "ss_b": torch.zeros((self.b, 512), dtype=torch.float32, device=dev),
         }
-        # 7-8 sequences: two groups of 4 rows on the round-3 kernel beat the round-2 kernels (2622 vs 2073 tok/s at 8); at 5-6
-        # and from 9 up they do not (profiles/r03_rowgroups.txt) -- every group streams the weights again
+        # 5-16 sequences (round 4): every q_gemm launch runs on the lean kernel, whose ROWS form stages the whole rows once per
+        # workgroup when rows x (K + 8) x 2 bytes fit in LDS (csrc/qgemv_lean.hip) -- launches with a larger K (down_proj) run as
+        # row groups, each group streaming the weights again (the later ones from the memory-side cache).  EXL2_CHAIN_ROWGROUPS=N
+        # forces groups of N rows for every launch, 0 = one group whatever the kernel underneath makes of it.
         rg = os.environ.get("EXL2_CHAIN_ROWGROUPS", "auto")
-        if (rg == "auto" and self.b in (7, 8)) or (rg not in ("auto", "0") and self.b > 4):
-            self.chain["group_rows"] = 4
+        if rg != "auto" and int(rg) > 0 and self.b > 4:
+            self.chain["group_rows"] = int(rg)
+        self.chain["group_auto"] = rg == "auto"
         # overlapped chain (csrc/chain_sync.h, EXPERIMENTAL): launches alternate between the decoder's stream and a second
         # one, each waits for its predecessor through words in memory.  5 launches per layer + the head (+ the gate's block).
         if os.environ.get("EXL2_CHAIN_OVERLAP", "0") != "0":
@@ -244,38 +283,69 @@ class GreedyGraphDecoder:
         v = m.temp_v[:b].view(b, 1, cfg.num_key_value_heads, cfg.head_dim)
         xp_a, xp_b, ss_a, ss_b = ch["xp_a"], ch["xp_b"], ch["ss_a"], ch["ss_b"]
         overlap = "flags" in ch
-        # Row groups: the round-3 kernel (csrc/qgemv_lean.hip) takes <= 4 rows per launch; 5..16 sequences run every q_gemm
-        # launch once per group of 4 rows (the second and later groups find the weights in the memory-side cache) instead of
-        # leaving it for the round-2 kernels (measured at 8 rows: tools/gpu_r3_batch.sh).  A group's (xp, ss) live in its own
-        # rows of the buffers; attention takes all rows in one launch.
-        g = ch.get("group_rows", b)
-        groups = [(r, min(r + g, b)) for r in range(0, b, g)] if (g < b and not overlap) else [(0, b)]
+        # Row groups: a launch of the lean kernel takes the rows whose staged copy fits in LDS (<= 16; <= 4 in its wave-private
+        # form); more sequences run that launch once per group of rows.  A group's (xp, ss) live in its own rows of the buffers;
+        # attention takes all rows in one launch.  Launches with different K may use different groupings: the number of partial
+        # sums of squares per row a producer published must then be the same for all its groups (checked).
+        def groups_for(K):
+            if b <= 4 or overlap:
+                return [(0, b)]
+            g = ch.get("group_rows")
+            if not g:
+                if not ch.get("group_auto", True):
+                    return [(0, b)]
+                lds = int(os.environ.get("EXL2_CHAIN_ROWS_LDS", 132 * 1024))     # rows next to ~26 KB of scale rows and partial sums
+                fit = lds // ((K + 8) * 2)
+                g = b if fit >= b else (fit if fit >= 5 else 4)
+                g = -(-b // -(-b // g))                             # equal groups: 16 rows at 6 per launch -> 6 + 5 + 5
+            return [(r, min(r + g, b)) for r in range(0, b, g)]
+
+        groups_h = groups_for(cfg.hidden_size)                    # q|k|v, gate|up, head: K = hidden
+        groups_o = groups_for(cfg.num_attention_heads * cfg.head_dim)
+        groups_d = groups_for(cfg.intermediate_size)              # down: K = intermediate
+        groups = groups_h
+        pa, pb = _PartialSums(ss_a, b), _PartialSums(ss_b, b)
+        pa.begin()
         for r0, r1 in groups:
-            ext.embed_rows_chain(m.embed_tokens, self.ids[r0:r1], x2[r0:r1], plan[0][0], plan[0][3], xp_a[r0:r1], ss_a[r0:r1])
+            ext.embed_rows_chain(m.embed_tokens, self.ids[r0:r1], x2[r0:r1], plan[0][0], plan[0][3], xp_a[r0:r1], pa.out(r0, r1))
+            pa.done(1)
         if overlap:
             sa = self.stream.cuda_stream if self.stream is not None else None
             sb = ch["stream_b"].cuda_stream if ch["stream_b"] is not None else None
             ext.chain_overlap_begin(ch["flags"], sa, sb)
         try:
-            # partial sums of squares per row a launch published: PER GROUP -- the count depends on which kernel took the launch
-            # (qgemv_lean: one per 16-column tile, qgemv_flat: one per workgroup), and a 4-row group and a 3-row group of the
-            # same matrix may be taken by different kernels (LDS budget)
-            npart = [1] * len(groups)
-            np_o = [1] * len(groups)
+            # partial sums of squares per row a launch published: the count depends on which kernel took the launch (qgemv_lean:
+            # one per 16-column tile, qgemv_flat: one per workgroup) and a 4-row group and a 3-row group of the same matrix may be
+            # taken by different kernels -- the consumer may group the rows differently, so all groups must agree
             for i, (attn, mlp) in enumerate(m.layers):
                 in_a, o_inv, in_m, nw_a, nw_m = plan[i]
-                for gi, (r0, r1) in enumerate(groups):
-                    ext.q_attn_forward_1_chain(attn.q_handle, xp_a[r0:r1], ss_a[r0:r1], npart[gi], r1 - r0, q[r0:r1], k[r0:r1], v[r0:r1])
+                for r0, r1 in groups_h:
+                    ss, cnt = pa.inp(r0, r1, "q|k|v")
+                    ext.q_attn_forward_1_chain(attn.q_handle, xp_a[r0:r1], ss, cnt, r1 - r0, q[r0:r1], k[r0:r1], v[r0:r1])
                 ao = attn.attend_chain(q, k, v, self.cache, self.cache_seqlens, self.block_table, o_inv)
                 # every producer of the residual stream publishes it times its consumer's norm weight, in that consumer's order
-                for gi, (r0, r1) in enumerate(groups):
-                    np_o[gi] = ext.q_attn_forward_2_chain(attn.q_handle, x2[r0:r1], ao[r0:r1], r1 - r0, in_m, nw_m, xp_b[r0:r1], ss_b[r0:r1])
+                pb.begin()
+                for r0, r1 in groups_o:
+                    pb.done(ext.q_attn_forward_2_chain(attn.q_handle, x2[r0:r1], ao[r0:r1], r1 - r0, in_m, nw_m, xp_b[r0:r1], pb.out(r0, r1)))
                 nxt, nxt_w = (plan[i + 1][0], plan[i + 1][3]) if i + 1 < len(plan) else (ch["head_inv"], ch["norm_head"])
-                for gi, (r0, r1) in enumerate(groups):
-                    npart[gi] = ext.q_mlp_forward_chain(mlp.q_handle, x2[r0:r1], xp_b[r0:r1], ss_b[r0:r1], np_o[gi], r1 - r0, nxt, nxt_w,
-                                                        xp_a[r0:r1], ss_a[r0:r1])
-            for gi, (r0, r1) in enumerate(groups):
-                ext.gemm_half_q_half_chain(xp_a[r0:r1], ss_a[r0:r1], npart[gi], cfg.norm_eps, m.lm_head.q_handle, self.logits[r0:r1], r1 - r0)
+                if groups_h == groups_d and os.environ.get("EXL2_CHAIN_SPLIT_MLP", "0") != "1":     # (1: test hook)
+                    pa.begin()
+                    for r0, r1 in groups_h:
+                        ss, cnt = pb.inp(r0, r1, "gate|up")
+                        pa.done(ext.q_mlp_forward_chain(mlp.q_handle, x2[r0:r1], xp_b[r0:r1], ss, cnt, r1 - r0, nxt, nxt_w,
+                                                        xp_a[r0:r1], pa.out(r0, r1)))
+                else:
+                    # the halves separately: gate | up over its groups, then down over its own
+                    for r0, r1 in groups_h:
+                        ss, cnt = pb.inp(r0, r1, "gate|up")
+                        ext.q_mlp_forward_chain_part(mlp.q_handle, 1, r0, x2[r0:r1], xp_b[r0:r1], ss, cnt, r1 - r0, None, None, None, None)
+                    pa.begin()
+                    for r0, r1 in groups_d:
+                        pa.done(ext.q_mlp_forward_chain_part(mlp.q_handle, 2, r0, x2[r0:r1], None, None, 0, r1 - r0, nxt, nxt_w,
+                                                             xp_a[r0:r1], pa.out(r0, r1)))
+            for r0, r1 in groups_h:
+                ss, cnt = pa.inp(r0, r1, "head")
+                ext.gemm_half_q_half_chain(xp_a[r0:r1], ss, cnt, cfg.norm_eps, m.lm_head.q_handle, self.logits[r0:r1], r1 - r0)
         finally:
             n_launches = ext.chain_overlap_end() if overlap else 0
         # greedy sampling + position increment behind the head: on the stream the head went to

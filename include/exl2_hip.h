@@ -230,6 +230,14 @@ int exl2_q_attn_forward_2_chain(void* handle, void* x, const void* attn_out_pack
 /* x += (act(n Wg) * (n Wu)) Wd, n from (xp, ss); publishes (xp_out, ss_out) for the next consumer */
 int exl2_q_mlp_forward_chain(void* handle, void* x, const void* xp, const float* ss, int npart, int rows,
                              const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, int* npart_out, void* stream);
+/* One half of exl2_q_mlp_forward_chain for rows [row0, row0 + rows) of a step (x / xp / ss / xp_out / ss_out point at row row0):
+   part 1 = gate | up (reads xp, ss; leaves act(gate) * up of those rows in the module's scratch), part 2 = down (+ residual, chain-out).
+   A decode step of 5..16 sequences groups its rows per launch by what fits in LDS (K = hidden for gate | up, K = intermediate for
+   down: csrc/qgemv_lean.hip ROWS form), so the two halves may be called with different row groups.  Composition replaced: QMLP::
+   forward_run_ (q_mlp.cu:153-236). */
+int exl2_q_mlp_forward_chain_part(void* handle, int part, int row0, void* x, const void* xp, const float* ss, int npart, int rows,
+                                  const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, int* npart_out,
+                                  void* stream);
 /* c = rmsnorm(x) . W from (xp, ss); the producer of xp applied the norm weight gathered through W's q_perm (exl2_gather_f16) */
 int exl2_gemm_half_q_half_chain(const void* xp, const float* ss, int npart, float eps,
                                 void* q_matrix, void* c, int rows, void* stream);

@@ -68,12 +68,57 @@ def test_chain_decode_wide_k(be, recipe):
     _decode_and_check(be, cfg, recipe, 1, steps=2, seed=5)
 
 
-@pytest.mark.parametrize("batch", [16, 8, 4])
+@pytest.mark.parametrize("batch", [16, 11, 8, 5, 4])
 def test_chain_decode_many_rows(be, batch):
-    """16 sequences: the row loop of the A_NORM_PRE prologue, 16 finalising waves (round-2 kernel); 8: two row groups of 4 on the
-    round-3 kernel (model.step_chain); 4: one launch of the round-3 kernel with four finalising waves"""
+    """4 sequences: one launch of the lean kernel's wave-private form with four finalising waves; 5..16: its ROWS form (round 4: the
+    workgroup stages the whole rows once, every finalising wave takes several rows) -- every launch of the step on the lean
+    kernel, none left to the round-2 kernel"""
     cfg = tiny_cfg(max_batch_size=16)
+    be.ext.chain_route_counts(reset=True)
     _decode_and_check(be, cfg, "4.0bpw", batch, steps=2, seed=12)
+    lean, flat = be.ext.chain_route_counts(reset=True)
+    assert lean > 0 and flat == 0, (lean, flat)
+
+
+@pytest.mark.parametrize("recipe,batch", [("3.5bpw", 16), ("2.5bpw", 7)])
+def test_chain_decode_many_rows_mixed_groupings(be, recipe, batch, monkeypatch):
+    """down_proj's K is larger than hidden: its rows x (K + 8) x 2 bytes stop fitting in LDS at fewer rows than those of q|k|v / o /
+    gate|up, so a step runs gate|up once over all rows and down over row groups (exl2_q_mlp_forward_chain_part).  Forced here on
+    a small shape by shrinking the LDS the host grants the staged rows (the grouping logic is the host's: model.step_chain)."""
+    cfg = tiny_cfg(max_batch_size=16, intermediate_size=640, num_attention_heads=4, num_key_value_heads=2)
+    import exllamav2_amd.model as M
+    calls = {"n": 0}
+    orig = be.ext.q_mlp_forward_chain_part
+    def spy(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(be.ext, "q_mlp_forward_chain_part", spy)
+    monkeypatch.setenv("EXL2_CHAIN_ROWS_LDS", str(16 * (cfg.hidden_size + 8) * 2))      # 16 rows of K = hidden fit, of K = 640 do not
+    _decode_and_check(be, cfg, recipe, batch, steps=2, seed=17)
+    assert calls["n"] > 0
+
+
+def test_llama2_70b_widths_stay_on_the_lean_kernel(be):
+    """configs[3]'s shapes (hidden 8192, intermediate 28672, 2.5 bpw: 2 / 3-bit items, 1792-row slices on 16 waves, shares of two
+    register passes) through one layer + head of the chained step over a Q4 cache: every launch must be planned by the lean kernel
+    -- a host-side limit that declines one of them silently un-chains the WHOLE decoder (it did, for one GPU call of round 4)."""
+    from exllamav2_amd.config import ExLlamaV2Config
+    cfg = ExLlamaV2Config.llama2_70b(max_seq_len=256, max_input_len=32)
+    cfg.num_hidden_layers = 1
+    cfg.vocab_size = 512
+    ck = synth_checkpoint(cfg, be.device, recipe="2.5bpw", seed=0)
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    cache = ExLlamaV2Cache_Q4(model, batch_size=1)
+    dec = GreedyGraphDecoder(model, cache, batch_size=1)
+    assert dec.chain is not None
+    be.ext.chain_route_counts(reset=True)
+    dec.reset(torch.tensor([3]), 0)
+    dec.run(1, use_graph=False)
+    lean, flat = be.ext.chain_route_counts(reset=True)
+    assert dec.chain is not None and lean == 5 and flat == 0, (dec.chain is not None, lean, flat)     # q|k|v, o, gate|up, down, head
+    tok = be.n(dec.tokens(0, 1))
+    assert 0 <= int(tok[0, 0]) < cfg.vocab_size
+    dec.free(); model.unload()
 
 
 @pytest.mark.parametrize("recipe,act_order", [("gptq-4bit-128g", False), ("gptq-4bit-32g", True)])
