@@ -53,10 +53,16 @@ def parse():
     p.add_argument("--no-ctx-window", action="store_true", help="skip the extra ctx-1920 decode window")
     p.add_argument("--cache", default="fp16", choices=["fp16", "q4"], help="KV cache type (q4: ExLlamaV2Cache_Q4)")
     p.add_argument("--no-prefill", action="store_true", help="skip the extra prefill measurement (BASELINE configs[2])")
+    p.add_argument("--no-dropin", action="store_true",
+                   help="skip the extra figure of the UNMODIFIED reference host on the drop-in (tools/dropin_decode_bench.py, child process)")
     p.add_argument("--batch", type=int, default=1, help="sequences decoded together (BASELINE configs[4]: 16)")
     p.add_argument("--parallel", default="pipeline", choices=["pipeline", "tp"],
                    help="N > 1: layer-split pipeline (default, weak scaling) or tensor parallel (column shards + all-gather, strong scaling)")
-    return p.parse_args()
+    p.add_argument("--headline-only", action="store_true", help="= --no-cpu-baseline --no-prefill --no-dropin --no-ctx-window (A/B runs)")
+    a = p.parse_args()
+    if a.headline_only:
+        a.no_cpu_baseline = a.no_prefill = a.no_dropin = a.no_ctx_window = True
+    return a
 
 
 def make_cfg(name: str, max_seq_len: int):
@@ -571,6 +577,31 @@ def cpu_baseline_in_child(args, timeout_s: int = 420):
         return {"value": None, "error": str(e)[:200]}
 
 
+def dropin_rate_in_child(timeout_s: int = 300):
+    """SURVEY.md 8(d)(i) defines the headline metric by the reference's own loop (test_inference.py:584-618: model.forward(ids[:,
+    -1:], cache) + host argmax per token).  That loop, run by the UNMODIFIED reference host code on dropin/exllamav2_ext.py ->
+    libexl2_hip.so over a synthetic 7B model directory, in a child process (tools/dropin_decode_bench.py; it writes ~3.7 GB to
+    /tmp first).  Informational beside the GreedyGraphDecoder figure: never the headline value."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "dropin_decode_bench.py"), "--tokens", "128", "--attn", "flash"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            d = json.loads(lines[-1])
+            if "value" in d:
+                return {"tokens_per_s": d["value"], "ms_per_token": d["ms_per_token"], "tokens": d["tokens"], "attention": d["attention"],
+                        "loop": "unmodified reference host (ExLlamaV2 / ExLlamaV2Cache / test_inference.py -s loop) on dropin/exllamav2_ext.py",
+                        "limiter": "per-module route: 5 launches per layer on the un-chained kernels, no whole-step graph, ~130 ctypes "
+                                   "calls per token on the host (DESIGN.md section 4)"}
+            return d
+        return {"error": f"child rc={r.returncode}: {(r.stderr or '').strip()[-200:]}"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"child exceeded {timeout_s} s"}
+    except Exception as e:
+        return {"error": str(e)[:200]}
+
+
 def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq: int = 2048, parity: bool = True):
     """BASELINE configs[2] beside the headline: test_inference.py -ps procedure (:533-579), forward(ids[8, 2048],
     preprocess_only=True) on a fresh synthetic model, all layers, the product route (row pre-pass + dequantize-into-MFMA
@@ -813,6 +844,12 @@ def finish(args, cfg, result, rank, world, n_gpus, device, dist):
                 out["prefill"] = prefill_rate(args.model, args.recipe, device, parity=not args.no_parity_check)
             except Exception as e:  # informational; never lose the headline number
                 out["prefill"] = {"error": str(e)[:200]}
+        if (not args.no_dropin and n_gpus == 1 and args.model == "llama2-7b" and args.recipe == "4.0bpw" and args.batch == 1
+                and args.cache == "fp16"):
+            d = dropin_rate_in_child()
+            if "tokens_per_s" in d:
+                d["fraction_of_headline"] = round(d["tokens_per_s"] / result["value"], 3)
+            out.setdefault("extra", {})["reference_host_on_dropin"] = d
         if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline_in_child(args)
         print(json.dumps(out))

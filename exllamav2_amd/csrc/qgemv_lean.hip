@@ -918,6 +918,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
             }
     }
     dim3 grid((unsigned)wgs, (unsigned)(in.pair ? 1 : in.n_mats), 1), block((unsigned)waves * 64, 1, 1);
+    if (getenv("EXL2_LEAN_PLAN_ONLY")) { if (wgs_out) *wgs_out = wgs; return 0; }     // test hook: the host plan without the launch (results undefined)
     const bool gptq = q0->is_gptq;
     const int occ = LEAN_OCC_DEFAULT;
 #define LEAN_GO(SS, NS, P) \

@@ -21,7 +21,13 @@ none_tensor = torch.empty((1, 1), device="meta")
 
 
 def _is_none(t) -> bool:
-    return t is None or (isinstance(t, torch.Tensor) and t.device.type == "meta")
+    return t is None or (isinstance(t, torch.Tensor) and t.is_meta)
+
+
+# (the host layer sits on the per-token path of the unmodified reference host -- ~130 calls x ~10 tensors per decoded token,
+# tools/dropin_decode_bench.py -- so the argument checks below read tensor attributes that cost no Python-level object)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 class ExtC:
@@ -41,18 +47,20 @@ class ExtC:
     # ---- helpers ----------------------------------------------------------------------------------------------------
 
     def _ptr(self, t, dtype=None, name="tensor"):
-        if _is_none(t):
+        if t is None or t.is_meta:
             return None
-        if dtype is not None and t.dtype != dtype:
+        if dtype is not None and t.dtype is not dtype:
             raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
         if not t.is_contiguous():
             raise RuntimeError(f"{name}: tensor must be contiguous")
-        if t.device.type != "cuda" and not (self.allow_cpu and t.device.type == "cpu"):
+        if not t.is_cuda and not (self.allow_cpu and t.device.type == "cpu"):
             raise RuntimeError(f"{name}: tensor must live on a HIP device (got {t.device}); there is no CPU path")
         return t.data_ptr()
 
     def _stream(self, t) -> int | None:
-        if t.device.type == "cuda":
+        if t.is_cuda:
+            if _raw_stream is not None:
+                return _raw_stream(t.get_device())
             return torch.cuda.current_stream(t.device).cuda_stream
         return None
 
@@ -758,8 +766,8 @@ def _device_scoped(fn):
     @functools.wraps(fn)
     def scoped(self, *args, **kwargs):
         for a in args:
-            if isinstance(a, torch.Tensor) and a.device.type == "cuda":
-                if a.device.index != torch.cuda.current_device():
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.get_device() != (_cur_device() if _cur_device is not None else torch.cuda.current_device()):
                     with torch.cuda.device(a.device):
                         return fn(self, *args, **kwargs)
                 break

@@ -98,11 +98,14 @@ def test_chain_decode_many_rows_mixed_groupings(be, recipe, batch, monkeypatch):
     assert calls["n"] > 0
 
 
-def test_llama2_70b_widths_stay_on_the_lean_kernel(be):
+def test_llama2_70b_widths_stay_on_the_lean_kernel(be, monkeypatch):
     """configs[3]'s shapes (hidden 8192, intermediate 28672, 2.5 bpw: 2 / 3-bit items, 1792-row slices on 16 waves, shares of two
     register passes) through one layer + head of the chained step over a Q4 cache: every launch must be planned by the lean kernel
-    -- a host-side limit that declines one of them silently un-chains the WHOLE decoder (it did, for one GPU call of round 4)."""
+    -- a host-side limit that declines one of them silently un-chains the WHOLE decoder (it did, for one GPU call of round 4).
+    Emulator: the plans only (EXL2_LEAN_PLAN_ONLY: a 0.9 G-weight layer takes minutes to emulate); GPU: the real launches."""
     from exllamav2_amd.config import ExLlamaV2Config
+    if be.is_emu:
+        monkeypatch.setenv("EXL2_LEAN_PLAN_ONLY", "1")
     cfg = ExLlamaV2Config.llama2_70b(max_seq_len=256, max_input_len=32)
     cfg.num_hidden_layers = 1
     cfg.vocab_size = 512
@@ -116,8 +119,9 @@ def test_llama2_70b_widths_stay_on_the_lean_kernel(be):
     dec.run(1, use_graph=False)
     lean, flat = be.ext.chain_route_counts(reset=True)
     assert dec.chain is not None and lean == 5 and flat == 0, (dec.chain is not None, lean, flat)     # q|k|v, o, gate|up, down, head
-    tok = be.n(dec.tokens(0, 1))
-    assert 0 <= int(tok[0, 0]) < cfg.vocab_size
+    if not be.is_emu:
+        tok = be.n(dec.tokens(0, 1))
+        assert 0 <= int(tok[0, 0]) < cfg.vocab_size
     dec.free(); model.unload()
 
 
