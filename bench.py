@@ -771,7 +771,8 @@ def main():
             extra["chain_route_launches"] = {"qgemv_lean_kernel": int(n_lean), "qgemv_flat_kernel": int(n_flat)}
         if dec.chain is not None and "flags" in dec.chain:
             # overlapped chain (EXL2_CHAIN_OVERLAP=1): waits that gave up would make the timing meaningless -- must be 0
-            extra["chain_overlap"] = {"hand_off_words_left_set": int((dec.chain["flags"][:, [0] + [32 * (1 + c) for c in range(8)]] != 0).sum()),
+            words = [0] + [32 * (1 + c) for c in range(8)] + [320 + 32 * c for c in range(8)] + [576 + 32 * c for c in range(8)]
+            extra["chain_overlap"] = {"hand_off_words_left_set": int((dec.chain["flags"][:, words] != 0).sum()),
                                       "waits_given_up": int(dec.chain["flags"][:, 2].sum()),
                                       "given_up_by_launch": {int(i): int(v) for i, v in enumerate(dec.chain["flags"][:, 2].tolist()) if v}}
         if args.model == "llama2-7b" and args.ctx == 0 and not args.no_ctx_window:

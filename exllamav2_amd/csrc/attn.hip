@@ -226,6 +226,7 @@ struct FusedArgs
     // overlapped chain (chain_sync.h / hw.h): q / k_new / v_new are read behind the wait, with agent-scope loads; the
     // workgroup that writes a group's final output arrives once (sync_total = batch * kv_heads * row_blocks per launch)
     const u32* sync_wait; u32* sync_signal; u32 sync_total;
+    u32* sync_arrive;                                   // every workgroup of the grid reports here on entry (the next launch's gate)
 };
 
 // where feature d of query row qrow = (token row) * H + head goes
@@ -290,6 +291,7 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     const int dl = lane % LPK;
 
     const bool dep = a.sync_signal != nullptr;                 // overlapped chain: producer may still be running
+    if (a.sync_arrive && tid() == 0) sync_report_entry(a.sync_arrive, (u32)((bid_z() * gdim_y() + bid_y()) * gdim_x() + bid_x()));
 
     // ---- request level 1: everything whose address does not depend on the cache length goes out TOGETHER -- the length
     // itself, the first page of the sequence (split 0 starts at key 0), the query rows, the new key / value row this stream
@@ -798,6 +800,7 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
         const int e = chain_sync_next(&cl);
         if (e) return e;
         a.sync_wait = cl.wait; a.sync_signal = cl.signal; a.sync_total = (u32)(batch * num_kv_heads * rblocks);
+        a.sync_arrive = cl.arrive;
         stream = cl.stream;
     }
 #define FUSED_CASE(HDIM_, RB_) LAUNCH((attn_fused_kernel<HDIM_, RB_>), grid, dim3(ATT_WAVES * 64), lds, stream, a)
@@ -813,7 +816,7 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
 #undef FUSED_HD
 #undef FUSED_CASE
     HIP_TRY(hipGetLastError());
-    if (overlapped) { const int e = chain_sync_done(0u); if (e) return e; }
+    if (overlapped) { const int e = chain_sync_done((u32)(grid.x * grid.y * grid.z)); if (e) return e; }
     return EXL2_OK;
 }
 

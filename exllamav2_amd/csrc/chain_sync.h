@@ -6,11 +6,12 @@
 // as soon as workgroups of launch N leave their CUs; it waits for N's signals only before it reads activations.
 //
 // Progress: launch k sits behind launch k-2 in its own (in-order) stream, so at most two launches are in flight; the older
-// one never waits on the younger, and the younger's workgroups only spin while holding CUs the older no longer needs
-// (its workgroups were all placed before k-2 ... k-1 finished).  The spin is bounded (hw.h: FLAG_SPIN_LIMIT).
-// Start of the chain: launches 0 and 1 would be released together and share the CUs between them -- launch 1 spinning on
-// CUs that launch 0 still needs.  So every workgroup of launch 0 reports on entry, and a one-wave gate kernel ahead of
-// launch 1 in the other stream lets it through only when all of launch 0 is resident.  (The first launch must be a q_gemm.)
+// one never waits on the younger.  The younger's workgroups spin while they hold their slots, so they must never hold a
+// slot the older still needs: every workgroup of every launch reports on entry (hw.h: sync_report_entry), and a one-wave
+// GATE kernel sits ahead of launch k + 1 in its stream that lets it through only when all workgroups of launch k have
+// entered (round 2 had such a gate for the first pair only and met the race it leaves: about once in 150 steps a launch
+// two ahead took the slots of an attention launch that was still waiting to be placed).  The spins are bounded
+// (hw.h: FLAG_SPIN_LIMIT): a protocol error shows as wrong numbers and a count in the block, never as a hung GPU.
 //
 // While a chain is open (exl2_chain_overlap_begin ... _end) every chained launch of THIS thread -- the chained q_gemm
 // entry points and exl2_attn_decode_fused -- takes its stream, its wait counter / target and its signal counter from here.
@@ -24,6 +25,6 @@ struct ChainLaunch { const u32* wait; u32* signal; u32* arrive; void* stream; };
 bool chain_sync_active();
 // stream / counters of the next launch; returns < 0 (error set) when the chain has run out of counters
 int chain_sync_next(ChainLaunch* out);
-// the launch took place; `arrivals` = its workgroups (first launch only: the gate on the other stream is launched with this
-// target).  Returns < 0 on error.
+// the launch took place; `arrivals` = its workgroups: the gate of the next launch (other stream) is launched with this target.
+// Returns < 0 on error.
 int chain_sync_done(u32 arrivals);

@@ -187,6 +187,13 @@ DEV void dma_buf_to_lds16(const void* base, u32 voffset_bytes, void* lds_wave_ba
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voffset_bytes, 0, 0, 0);
 }
+// the same at agent scope (sc1: served by the L2 / memory side, never by this CU's L1): what a producer that may still be running
+// wrote with agent-scope stores (overlapped chain, chain_sync.h) -- and what a previous launch wrote, at the price of an L1 bypass
+DEV void dma_buf_to_lds16_agent(const void* base, u32 voffset_bytes, void* lds_wave_base)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voffset_bytes, 0, 0, 16);
+}
 // A "fence load": an ordinary 4-byte vector load the COMPILER tracks, issued behind LDS-DMA copies.  Vector-memory operations
 // of a wave complete in issue order, so when this load's value is available the copies issued before it have landed in LDS;
 // fence_load_use() makes the compiler wait for exactly this load -- it inserts `s_waitcnt vmcnt(n)` with n = the number of
@@ -251,8 +258,14 @@ DEV u32 load_agent_u32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELA
 //     gain is the consumer's start-up (arguments, tables, weight ring) running during it.
 // Block of one launch: word 0 = arrivals counter, words 32 (1 + c) = copy c of "go" (own 128-byte lines), word 2 = waits
 // that gave up (debug).  The spin is bounded: a missing producer must show up as wrong numbers in a test, never as a hung GPU.
-#define SYNC_BLOCK_WORDS 320
+#define SYNC_BLOCK_WORDS 1024
 #define SYNC_GO_COPIES 8
+// round 4: the counters are sharded 8 ways (own 128-byte lines: words 320 + 32 c = workgroups finished, 576 + 32 c = workgroups
+// entered), workgroup `lin` uses shard lin % 8 -- a launch of 700-2000 small workgroups adding to ONE word takes ~12 ns per add,
+// i.e. longer than the launch itself.  The last arrival of a shard forwards one arrival to word 0.
+#define SYNC_SHARDS 8
+DEV u32* sync_fin_shard(u32* block, u32 c) { return block + 320 + 32 * (c & (SYNC_SHARDS - 1)); }
+DEV u32* sync_entry_shard(u32* block, u32 c) { return block + 576 + 32 * (c & (SYNC_SHARDS - 1)); }
 #define FLAG_SPIN_LIMIT (1 << 17)              // ~ 50 ms (a poll is ~0.4 us)
 DEV const u32* sync_go_word(const u32* block, int cls) { return block + 32 * (1 + (cls & (SYNC_GO_COPIES - 1))); }
 // consumer: the calling WAVE polls (one wave per workgroup; the others wait at the workgroup barrier behind it)
@@ -276,12 +289,42 @@ DEV void sync_arrive_publish(u32* own_block, u32 total, const u32* waited_block)
     store_relaxed_agent(own_block, 0u);
     if (waited_block) for (int c = 0; c < SYNC_GO_COPIES; c++) store_relaxed_agent((u32*)sync_go_word(waited_block, c), 0u);
 }
-// the gate ahead of the chain's second launch (chain_sync.h): one wave waits for `target` arrivals, then zeroes the counter
-DEV void sync_gate_wait(u32* arrived, u32 target)
+// sharded form of the same (round 4): workgroup `lin` of `total_wgs`, `per_wg` arrivals per workgroup (its finalising waves)
+DEV void sync_arrive_publish_sharded(u32* own_block, u32 lin, u32 per_wg, u32 total_wgs, const u32* waited_block)
 {
+    wait_vmcnt0();
+    if (lane_id() != 0) return;
+    const u32 c = lin & (SYNC_SHARDS - 1);
+    const u32 in_shard = ((total_wgs - c + SYNC_SHARDS - 1) / SYNC_SHARDS) * per_wg;        // arrivals of the workgroups with lin % 8 == c
+    const u32 n_shards = total_wgs < SYNC_SHARDS ? total_wgs : SYNC_SHARDS;
+    u32 old = ticket_add_agent(sync_fin_shard(own_block, c), 1u);
+    if (old + 1 != in_shard) return;
+    store_relaxed_agent(sync_fin_shard(own_block, c), 0u);
+    old = ticket_add_agent(own_block, 1u);
+    if (old + 1 != n_shards) return;
+    for (int k = 0; k < SYNC_GO_COPIES; k++) store_relaxed_agent((u32*)sync_go_word(own_block, k), 1u);
+    store_relaxed_agent(own_block, 0u);
+    if (waited_block) for (int k = 0; k < SYNC_GO_COPIES; k++) store_relaxed_agent((u32*)sync_go_word(waited_block, k), 0u);
+}
+// "this workgroup holds its slot": one lane per workgroup, on entry (the gate below counts them)
+DEV void sync_report_entry(u32* own_block, u32 lin) { (void)ticket_add_agent(sync_entry_shard(own_block, lin), 1u); }
+// the gate ahead of every launch of an overlapped chain (chain_sync.h): one wave waits until all `target` workgroups of the
+// launch's PRODUCER have entered (the consumer's workgroups spin while they hold their slots: they must not take slots the
+// producer still needs), then zeroes the counters for the next replay
+DEV void sync_gate_wait(u32* producer_block, u32 target)
+{
+    const int lane = lane_id();
     int spins = 0;
-    while (uniform((int)load_agent_u32(arrived)) < (int)target && ++spins < FLAG_SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
-    if (lane_id() == 0) store_relaxed_agent(arrived, 0u);
+    while (true)
+    {
+        u32 v = lane < SYNC_SHARDS ? load_agent_u32(sync_entry_shard(producer_block, (u32)lane)) : 0u;
+        #pragma unroll
+        for (int m = 1; m < SYNC_SHARDS; m <<= 1) v += shfl_xor_u32(v, m);
+        if (uniform((int)v) >= (int)target) break;
+        if (++spins >= FLAG_SPIN_LIMIT) { if (lane == 0) (void)ticket_add_agent(producer_block + 2, 1u); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane < SYNC_SHARDS) store_relaxed_agent(sync_entry_shard(producer_block, (u32)lane), 0u);
 }
 // agent-scope loads of what a still-running producer has written (no acquire fence: see above)
 DEV f16 load_agent_f16(const f16* p) { return __builtin_bit_cast(f16, (u16)__hip_atomic_load((const u16*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }

@@ -169,13 +169,14 @@ int chain_sync_next(ChainLaunch* out)
     const int k = g_chain.next;
     out->wait = k > 0 ? chain_block(k - 1) : nullptr;
     out->signal = chain_block(k);
-    out->arrive = k == 0 ? chain_block(g_chain.n_blocks - 1) : nullptr;            // last block: the gate's arrivals counter
+    out->arrive = chain_block(k);                    // every workgroup reports on entry (sync_report_entry): the gate below counts them
     out->stream = g_chain.stream[k & 1];
     return EXL2_OK;
 }
 
-// one wave: holds launch 1 back until every workgroup of launch 0 sits on its CU (chain_sync.h); zeroes the counter again
-KERNEL void __launch_bounds__(64) chain_gate_kernel(u32* arrived, u32 target) { sync_gate_wait(arrived, target); }
+// one wave, in the OTHER stream, behind launch k - 1 and ahead of launch k + 1: holds launch k + 1 back until every workgroup of
+// launch k has entered (chain_sync.h); zeroes the entry counters again
+KERNEL void __launch_bounds__(64) chain_gate_kernel(u32* producer_block, u32 target) { sync_gate_wait(producer_block, target); }
 // end of a chain: nobody waits for the last launch's "go" -- back to zero for the next replay (runs behind it in its stream)
 KERNEL void __launch_bounds__(64) chain_tail_kernel(u32* block)
 {
@@ -184,12 +185,10 @@ KERNEL void __launch_bounds__(64) chain_tail_kernel(u32* block)
 
 int chain_sync_done(u32 arrivals)
 {
-    if (g_chain.next == 0)
-    {
-        EXL2_REQUIRE(arrivals > 0, "chain: the first launch of an overlapped chain must be a chained q_gemm");
-        LAUNCH(chain_gate_kernel, dim3(1, 1, 1), dim3(64, 1, 1), 0, g_chain.stream[1], chain_block(g_chain.n_blocks - 1), arrivals);
-        HIP_TRY(hipGetLastError());
-    }
+    EXL2_REQUIRE(arrivals > 0, "chain: a launch of an overlapped chain must say how many workgroups it has");
+    const int k = g_chain.next;
+    LAUNCH(chain_gate_kernel, dim3(1, 1, 1), dim3(64, 1, 1), 0, g_chain.stream[(k + 1) & 1], chain_block(k), arrivals);
+    HIP_TRY(hipGetLastError());
     g_chain.next++;
     return EXL2_OK;
 }
@@ -217,13 +216,15 @@ static int flat_try(FlatIn& in, void* stream, int* wgs, const char* what)
     // round 3: the lean kernel (qgemv_lean.hip) takes what it covers (<= LEAN_MAX_M rows, serial chain); EXL2_LEAN=0 keeps
     // the round-2 kernel for A/B runs
     int rc = 1;
-    if (!overlapped && lean_enabled()) rc = qgemv_lean_launch(in, cl.stream, &n_wgs);
+    if (lean_enabled()) rc = qgemv_lean_launch(in, cl.stream, &n_wgs);
     if (rc == 0) g_route_lean++;
-    if (rc == 1) { rc = qgemv_flat_launch(in, cl.stream, &n_wgs); if (rc == 0) g_route_flat++; }
+    // (the overlapped chain's protocol -- entry reports, sharded counters -- is the lean kernel's: what it declines ends the chain)
+    if (rc == 1 && !overlapped) { rc = qgemv_flat_launch(in, cl.stream, &n_wgs); if (rc == 0) g_route_flat++; }
     if (rc > 0) EXL2_FAIL(EXL2_E_INVALID, "%s: shape not covered by the chained decode kernel", what);
     if (rc < 0) EXL2_FAIL(EXL2_E_INVALID, "%s: launch configuration rejected (%d)", what, rc);
     HIP_TRY(hipGetLastError());
-    if (overlapped) { const int e = chain_sync_done((u32)n_wgs); if (e) return e; }
+    // (the gate of the next launch counts this launch's whole grid: the lean kernel puts its matrices on blockIdx.y)
+    if (overlapped) { const int e = chain_sync_done((u32)n_wgs * (u32)(in.pair ? 1 : in.n_mats)); if (e) return e; }
     if (wgs) *wgs = n_wgs;
     return EXL2_OK;
 }

@@ -51,7 +51,9 @@
 #endif
 #if LEAN_BUF_DMA
 #define LEAN_DMA(base, off_bytes, lds) dma_buf_to_lds16(base, (u32)(off_bytes), lds)
+#define LEAN_DMA_X(base, off_bytes, lds) dma_buf_to_lds16_agent(base, (u32)(off_bytes), lds)     // activations: another launch wrote them
 #else
+#define LEAN_DMA_X(base, off_bytes, lds) dma_to_lds16((const u8*)(base) + (size_t)(off_bytes), lds)
 #define LEAN_DMA(base, off_bytes, lds) dma_to_lds16((const u8*)(base) + (size_t)(off_bytes), lds)
 #endif
 #ifndef EXL2_EMU
@@ -102,6 +104,10 @@ struct alignas(64) LeanHdr
     f16* xp_out; const u16* xp_invperm;
     float* ss_out; int ldxp, wgs;
     int ldc[FLAT_MAX_MATS];
+    // overlapped chain (chain_sync.h; flags & LF_DEP): the producer launch's block ("go" is polled before the activations are staged,
+    // they and the partial sums / residual are read at agent scope), this launch's block (every workgroup reports on entry; outputs
+    // are agent-scope stores; every finalising wave arrives, the last publishes "go"), workgroups of the grid
+    const u32* sync_wait; u32* sync_signal; u32 sync_wgs, sync_pad;
 };
 struct LeanArgs
 {
@@ -113,6 +119,7 @@ struct LeanArgs
 #define LF_GELU 8u
 #define LF_ACCUM 16u
 #define LF_BIAS 32u
+#define LF_DEP 64u
 
 // items of one bit width a wave may hold in registers (<= 25 dwords per lane in flight)
 // (S = 4: the 8-wave gate|up workgroup, built for 6 waves per SIMD = 80 registers -- a wave there holds 8 items of <= 4 bits)
@@ -305,13 +312,37 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
 #define LTRACE(i) do { } while (0)
 #endif
     LTRACE(0);
+    // overlapped chain: "this workgroup holds its slot" (before anything may leave: the next launch's gate counts the whole grid)
+    const u32 lin_wg = (u32)bid_y() * (u32)gdim_x() + (u32)bid_x();
+    u32* const sync_signal = args.hdr.sync_signal;
+    if (sync_signal && wv == 0 && lane == 0) sync_report_entry(sync_signal, lin_wg);
     const int n_tiles = (int)m2.y;
     const int tile = PAIR ? u : u * NSLOTS + slot;
-    if (!PAIR && u * NSLOTS >= n_tiles) return;                          // (matrices of one launch may have different widths)
+    if (!PAIR && u * NSLOTS >= n_tiles)                                  // (matrices of one launch may have different widths)
+    {
+        // overlapped chain: the launch's arrival count covers the whole grid -- a workgroup without a tile arrives empty-handed
+        if (sync_signal)
+        {
+            const u32 m_rows = (u32)args.hdr.M, fin = (u32)(S * NSLOTS);
+            const u32 per_wg = ROWS ? (m_rows < fin ? m_rows : fin) : m_rows;
+            if ((u32)wv < per_wg) sync_arrive_publish_sharded(sync_signal, lin_wg, per_wg, args.hdr.sync_wgs, args.hdr.sync_wait);
+        }
+        return;
+    }
     const bool active = tile < n_tiles;
     const u32 meta = active ? meta_ : 0u;
     const int n = (int)(meta & 0xFFu), bits = (int)((meta >> 8) & 0xFu), tail_nv = (int)((meta >> 12) & 0x7u);
-    const bool pipe_on = ((meta_ >> 29) & 1u) == 0;                       // (bit 29 of every record: the host's EXL2_LEAN_PIPE=0 switch)
+    const bool pipe_on = ((meta_ >> 29) & 1u) == 0;                       // (bit 29 of every record: the host's EXL2_LEAN_PIPE=0 switch;
+                                                                          //  the host also sets it for launches of an overlapped chain)
+    // overlapped chain: the producer's "go" -- one wave polls, the workgroup meets behind it; the weight requests are out by then
+    auto await_producer = [&]() {
+        const u32* const w = args.hdr.sync_wait;
+        if (sync_signal)                                                  // (uniform over the launch)
+        {
+            if (w && wv == 0) sync_wait_go(w, (int)(lin_wg & 7u));
+            block_sync_lds();
+        }
+    };
     const int t_ = active ? tile : 0;
     const u32* const wptr = (const u32*)ptr_of(m0.x, m0.y) + w0.x + (size_t)t_ * w0.y;
     const u32* const tptr = (const u32*)ptr_of(m0.z, m0.w) + w0.z + (size_t)t_ * w0.w;
@@ -381,7 +412,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                         u8* const dst = (u8*)(x_lds + (size_t)rr * x_stride);
                         #pragma unroll
                         for (int u = 0; u < LEAN_X_PIECES; u++)
-                            if (u * 64 + lane < xunits && xu0 + u * 64 + lane < oct) LEAN_DMA(row, (xu0 + u * 64 + lane) * 16, dst + u * 1024);
+                            if (u * 64 + lane < xunits && xu0 + u * 64 + lane < oct) LEAN_DMA_X(row, (xu0 + u * 64 + lane) * 16, dst + u * 1024);
                     }
                 }
             }
@@ -397,7 +428,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                     u8* const dst = smem + (size_t)rr * x_stride * 2;
                     #pragma nounroll
                     for (int pc = (wv + WAVES - (rr % WAVES)) % WAVES; pc < pieces; pc += WAVES)
-                        if (pc * 64 + lane < oct) LEAN_DMA(row, (pc * 64 + lane) * 16, dst + (size_t)pc * 1024);
+                        if (pc * 64 + lane < oct) LEAN_DMA_X(row, (pc * 64 + lane) * 16, dst + (size_t)pc * 1024);
                 }
             }
         }
@@ -439,6 +470,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         for (int q = 0; q < DA; q++) if (q < nA) load_lane_words<BITS>(wptr + (size_t)q * STEP, lane, a[q]);
         if (tail_nv) load_lane_words<BITS>(tptr, lane, bt);
         LTRACE(2);
+        if constexpr (NB == 0) await_producer();        // (the pipelined form is never taken inside an overlapped chain)
         Staged P;
         stage_copies(P, std::integral_constant<int, 1000 * BITS + 10 * NB>());
         LEAN_MARK(1000 * BITS + 10 * NB + 2);
@@ -515,6 +547,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     if (n == 0 && tail_nv == 0)
     {
         LTRACE(2);
+        await_producer();
         Staged P;
         stage_copies(P, std::integral_constant<int, 99000>());
         LTRACE(3);
@@ -574,7 +607,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
             if (xp_out && xp_invperm) e.xp_idx = (int)xp_invperm[ep_n];
             if (xp_out && args.hdr.xp_w) e.xw_next = args.hdr.xp_w[e.xp_idx];
             e.cp = args.mat[mj].c + (size_t)row * args.hdr.ldc[mj] + c_idx;
-            if (flags & LF_ACCUM) e.c_old = *e.cp;
+            if (flags & LF_ACCUM) e.c_old = (flags & LF_DEP) ? load_agent_f16(e.cp) : *e.cp;
         }
         // A_NORM_PRE: the activations were x * w (qgemv_flat.h); 1 / rms(x) multiplies the finished sum.  The partial sums of
         // squares of this row (fixed order)
@@ -582,7 +615,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         {
             const float* sp = args.hdr.ss + (size_t)row * args.hdr.npart;
             #pragma nounroll
-            for (int i = lane; i < args.hdr.npart; i += 64) e.ssq += sp[i];
+            for (int i = lane; i < args.hdr.npart; i += 64) e.ssq += (flags & LF_DEP) ? load_agent_f32(sp + i) : sp[i];
         }
     };
     // combine (fixed order) + epilogue of one row
@@ -619,13 +652,15 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                 if (flags & LF_ACCUM) v += (float)e.c_old;
                 y = (f16)v;
             }
-            *e.cp = y;
+            if (flags & LF_DEP) store_agent_f16(e.cp, y); else *e.cp = y;
             if (xp_out)
             {
                 // chain-out: x for the next consumer = x * ITS norm weight (one rounding, saturated), in its packed order; the sum
                 // of squares is x's own
                 const float f = fmaxf(-65504.0f, fminf((float)y, 65504.0f));
-                xp_out[(size_t)row * args.hdr.ldxp + e.xp_idx] = (f16)fmaxf(-65504.0f, fminf(f * (float)e.xw_next, 65504.0f));
+                const f16 xw = (f16)fmaxf(-65504.0f, fminf(f * (float)e.xw_next, 65504.0f));
+                if (flags & LF_DEP) store_agent_f16(xp_out + (size_t)row * args.hdr.ldxp + e.xp_idx, xw);
+                else xp_out[(size_t)row * args.hdr.ldxp + e.xp_idx] = xw;
                 sq = f * f;
             }
         }
@@ -633,8 +668,14 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         if (ss_out)
         {
             sq = wave_allreduce_add(sq);
-            if (lane == 0) ss_out[(size_t)row * args.hdr.wgs + u] = sq;
+            if (lane == 0) { if (flags & LF_DEP) store_agent_f32(ss_out + (size_t)row * args.hdr.wgs + u, sq); else ss_out[(size_t)row * args.hdr.wgs + u] = sq; }
         }
+    };
+    // overlapped chain: this finalising wave's outputs have completed -> it arrives; the launch's last arrival publishes "go"
+    constexpr u32 FIN_WAVES = (u32)(S * NSLOTS);
+    auto signal_done = [&]() {
+        if (sync_signal)
+            sync_arrive_publish_sharded(sync_signal, lin_wg, ROWS ? ((u32)M < FIN_WAVES ? (u32)M : FIN_WAVES) : (u32)M, args.hdr.sync_wgs, args.hdr.sync_wait);
     };
     if constexpr (!ROWS)
     {
@@ -646,6 +687,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         block_sync_lds();
         LTRACE(6);
         ep_finish(wv, e);
+        signal_done();
     }
     else
     {
@@ -659,6 +701,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
             ep_inputs(row, e);
             ep_finish(row, e);
         }
+        if (wv < M) signal_done();
     }
     LTRACE(7);
 }
@@ -825,7 +868,8 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     static const int rows_on = []() { const char* e = getenv("EXL2_LEAN_ROWS"); return e ? atoi(e) : 1; }();
     const bool rows_mode = in.M > LEAN_MAX_M;
     if (rows_mode && !rows_on) return 1;
-    if (in.sync_wait || in.sync_signal || in.sync_arrive) return 1;
+    const bool dep = in.sync_signal != nullptr;                     // a launch of an overlapped chain (chain_sync.h)
+    if (!dep && (in.sync_wait || in.sync_arrive)) return 1;
     if (const char* e = getenv("EXL2_LEAN_DECLINE_M")) { if (atoi(e) == in.M) return 1; }      // test hook: row groups on different kernels
     const QMatrix* q0 = in.qm[0];
     const int K = q0->height;
@@ -896,7 +940,14 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     }
     h.a = in.a; h.xp_w = in.xp_w; h.ss = in.ss; h.xp_out = in.xp_out; h.xp_invperm = in.xp_invperm; h.ss_out = in.ss_out;
     h.eps = in.eps; h.M = in.M; h.K = K; h.lda = in.lda; h.ldxp = in.ldxp; h.npart = in.npart; h.wgs = wgs;
-    h.flags = (in.a_mode == A_NORM_PRE ? LF_NORM : 0u) | (in.act_gelu ? LF_GELU : 0u) | (in.c_mode == C_ACCUM ? LF_ACCUM : 0u) | (any_bias ? LF_BIAS : 0u);
+    h.flags = (in.a_mode == A_NORM_PRE ? LF_NORM : 0u) | (in.act_gelu ? LF_GELU : 0u) | (in.c_mode == C_ACCUM ? LF_ACCUM : 0u) | (any_bias ? LF_BIAS : 0u)
+            | (dep ? LF_DEP : 0u);
+    if (dep)
+    {
+        h.sync_wait = in.sync_wait; h.sync_signal = in.sync_signal; h.sync_wgs = (u32)wgs * (u32)(in.pair ? 1 : in.n_mats);
+        // (no pipelined form: the staging copies wait for the producer, the weight requests must not)
+        for (int j = 0; j < in.n_mats; j++) for (int w = 0; w < S; w++) a.wave[j * S + w].meta |= 1u << 29;
+    }
     h.slot_bytes = slot_bytes; h.red_off = rows_bytes + slot_bytes * (u32)nslots;
     const int waves = S * nslots;
     const u32 lds = h.red_off + (u32)waves * (u32)in.M * 16u * 4u;

@@ -622,11 +622,11 @@ class ExtC:
         self.lib.check(self.lib.exl2_prefill_route_info(out))
         return out[0], out[1] * 32, bool(out[2]), out[3]
 
-    SYNC_BLOCK_WORDS = 320
+    SYNC_BLOCK_WORDS = 1024
 
     def chain_overlap_begin(self, flags, stream_a, stream_b) -> None:
         """csrc/chain_sync.h: until chain_overlap_end() the chained launches alternate between the two streams and carry
-        their dependency in `flags` (int32 [n, 320], one block per launch, zero at first use)."""
+        their dependency in `flags` (int32 [n, SYNC_BLOCK_WORDS], one block per launch, zero at first use)."""
         n = flags.numel() // self.SYNC_BLOCK_WORDS
         self.lib.check(self.lib.exl2_chain_overlap_begin(self._ptr(flags, torch.int32, "flags"), n, stream_a, stream_b))
 

@@ -251,6 +251,7 @@ DEV void fence_load_use(u32) { }
 DEV u64 realtime_stamp() { return 0; }
 DEV void dma_to_lds16(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
 DEV void dma_buf_to_lds16(const void* base, u32 voffset_bytes, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, (const char*)base + voffset_bytes, 16); }
+DEV void dma_buf_to_lds16_agent(const void* base, u32 voffset_bytes, void* lds_wave_base) { dma_buf_to_lds16(base, voffset_bytes, lds_wave_base); }
 DEV void dma_to_lds16_nt(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
 DEV void wait_lds_reads() { }
 DEV void wave_converge() { emu_ctx_->wave[wave_id()].bar.wait(); }
@@ -290,8 +291,11 @@ DEV void store_agent_f16(f16* p, f16 v) { *p = v; }
 DEV u32 load_agent_u32(const u32* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 // hand-off between overlapped launches (hw.h): launches run to completion one after the other here, so a consumer finds its
 // producer's "go" already published; a missing one is a bug in the host's bookkeeping -- reported, not waited for
-#define SYNC_BLOCK_WORDS 320
+#define SYNC_BLOCK_WORDS 1024
 #define SYNC_GO_COPIES 8
+#define SYNC_SHARDS 8
+DEV u32* sync_fin_shard(u32* block, u32 c) { return block + 320 + 32 * (c & (SYNC_SHARDS - 1)); }
+DEV u32* sync_entry_shard(u32* block, u32 c) { return block + 576 + 32 * (c & (SYNC_SHARDS - 1)); }
 DEV const u32* sync_go_word(const u32* block, int cls) { return block + 32 * (1 + (cls & (SYNC_GO_COPIES - 1))); }
 DEV void sync_wait_go(const u32* producer_block, int cls)
 {
@@ -310,11 +314,30 @@ DEV void sync_arrive_publish(u32* own_block, u32 total, const u32* waited_block)
     *own_block = 0u;
     if (waited_block) for (int c = 0; c < SYNC_GO_COPIES; c++) *(u32*)sync_go_word(waited_block, c) = 0u;
 }
-DEV void sync_gate_wait(u32* arrived, u32 target)
+DEV void sync_arrive_publish_sharded(u32* own_block, u32 lin, u32 per_wg, u32 total_wgs, const u32* waited_block)
+{
+    if (lane_id() != 0) return;
+    const u32 c = lin & (SYNC_SHARDS - 1);
+    const u32 in_shard = ((total_wgs - c + SYNC_SHARDS - 1) / SYNC_SHARDS) * per_wg;
+    const u32 n_shards = total_wgs < SYNC_SHARDS ? total_wgs : SYNC_SHARDS;
+    u32 old = __atomic_fetch_add(sync_fin_shard(own_block, c), 1u, __ATOMIC_SEQ_CST);
+    if (old + 1 > in_shard) { fprintf(stderr, "emu: more arrivals than the shard holds (%u of %u)\n", old + 1, in_shard); abort(); }
+    if (old + 1 != in_shard) return;
+    *sync_fin_shard(own_block, c) = 0u;
+    old = __atomic_fetch_add(own_block, 1u, __ATOMIC_SEQ_CST);
+    if (old + 1 != n_shards) return;
+    for (int k = 0; k < SYNC_GO_COPIES; k++) *(u32*)sync_go_word(own_block, k) = 1u;
+    *own_block = 0u;
+    if (waited_block) for (int k = 0; k < SYNC_GO_COPIES; k++) *(u32*)sync_go_word(waited_block, k) = 0u;
+}
+DEV void sync_report_entry(u32* own_block, u32 lin) { (void)__atomic_fetch_add(sync_entry_shard(own_block, lin), 1u, __ATOMIC_SEQ_CST); }
+DEV void sync_gate_wait(u32* producer_block, u32 target)
 {
     if (lane_id() != 0) return;                  // (lanes run one after the other here: only the lane that zeroes may look)
-    if (__atomic_load_n(arrived, __ATOMIC_SEQ_CST) < target) { fprintf(stderr, "emu: gate would wait forever (%u arrivals of %u)\n", __atomic_load_n(arrived, __ATOMIC_SEQ_CST), target); abort(); }
-    if (lane_id() == 0) *arrived = 0u;
+    u32 sum = 0;
+    for (u32 c = 0; c < SYNC_SHARDS; c++) sum += __atomic_load_n(sync_entry_shard(producer_block, c), __ATOMIC_SEQ_CST);
+    if (sum != target) { fprintf(stderr, "emu: gate would wait forever / over-count (%u entries of %u)\n", sum, target); abort(); }
+    for (u32 c = 0; c < SYNC_SHARDS; c++) *sync_entry_shard(producer_block, c) = 0u;
 }
 DEV f16 load_agent_f16(const f16* p) { return *p; }
 DEV f16x8 load_agent_f16x8(const f16* p) { return *(const f16x8*)p; }

@@ -160,12 +160,12 @@ def test_chain_tokens_equal_unchained_route(be, monkeypatch):
 
 @pytest.mark.parametrize("recipe,batch", [("4.0bpw", 1), ("3.5bpw", 3), ("gptq-4bit-128g", 2)])
 def test_overlapped_chain_equals_serial_chain(be, monkeypatch, recipe, batch):
-    """EXL2_CHAIN_OVERLAP=1 (csrc/chain_sync.h, EXPERIMENTAL, off by default): the same launches on two alternating streams,
-    dependencies through words in memory.  Same kernels, same arithmetic, same order of every sum: logits and tokens are
-    bit-identical to the one-stream chain -- on the GPU through two captured graphs (one per stream) replayed side by side
-    for several steps; the hand-off words are back to zero after every step and no wait gave up."""
+    """EXL2_CHAIN_OVERLAP=1 (csrc/chain_sync.h): the same launches of the lean kernel on two alternating streams, dependencies
+    through words in memory, a gate kernel ahead of every launch.  Same arithmetic, same order of every sum (the pipelined
+    form of the serial chain changes WHEN an item is decoded, not the order of the sums): logits and tokens are bit-identical to
+    the one-stream chain -- on the GPU through two captured graphs (one per stream) replayed side by side for several steps;
+    the hand-off words (counters, shards, entry counts, "go") are back to zero after every step and no wait gave up."""
     cfg = tiny_cfg(num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2, intermediate_size=384)
-    monkeypatch.setenv("EXL2_LEAN", "0")              # the overlapped chain exists for the round-2 kernel only: compare like with like
     outs = []
     for overlap in ("0", "1"):
         monkeypatch.setenv("EXL2_CHAIN_OVERLAP", overlap)
@@ -190,6 +190,7 @@ def test_overlapped_chain_equals_serial_chain(be, monkeypatch, recipe, batch):
                 torch.cuda.synchronize()
             flags = be.n(dec.chain["flags"])
             assert np.all(flags == 0), np.nonzero(flags)
+            assert sum(be.ext.chain_route_counts()) > 0
         dec.free(); model.unload()
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
