@@ -266,14 +266,17 @@ DEV u32 load_agent_u32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELA
 #define SYNC_SHARDS 8
 DEV u32* sync_fin_shard(u32* block, u32 c) { return block + 320 + 32 * (c & (SYNC_SHARDS - 1)); }
 DEV u32* sync_entry_shard(u32* block, u32 c) { return block + 576 + 32 * (c & (SYNC_SHARDS - 1)); }
-#define FLAG_SPIN_LIMIT (1 << 17)              // ~ 50 ms (a poll is ~0.4 us)
+#ifndef SYNC_POLL_SLEEP
+#define SYNC_POLL_SLEEP 16                     // s_sleep units (64 cycles each) between two polls: pollers next to a weight stream cost it
+#endif                                         // bandwidth (MI355X_MICROARCH.md "polling-cost"); 1 in round 2
+#define FLAG_SPIN_LIMIT (1 << 15)              // ~ 30 ms at the default sleep
 DEV const u32* sync_go_word(const u32* block, int cls) { return block + 32 * (1 + (cls & (SYNC_GO_COPIES - 1))); }
 // consumer: the calling WAVE polls (one wave per workgroup; the others wait at the workgroup barrier behind it)
 DEV void sync_wait_go(const u32* producer_block, int cls)
 {
     const u32* go = sync_go_word(producer_block, cls);
     int spins = 0;
-    while (uniform((int)load_agent_u32(go)) == 0 && ++spins < FLAG_SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+    while (uniform((int)load_agent_u32(go)) == 0 && ++spins < FLAG_SPIN_LIMIT) __builtin_amdgcn_s_sleep(SYNC_POLL_SLEEP);
     if (spins >= FLAG_SPIN_LIMIT && lane_id() == 0) (void)ticket_add_agent((u32*)producer_block + 2, 1u);
 }
 // producer: the calling wave's outputs were agent-scope stores; when they have completed it arrives; the last of `total`
@@ -322,7 +325,7 @@ DEV void sync_gate_wait(u32* producer_block, u32 target)
         for (int m = 1; m < SYNC_SHARDS; m <<= 1) v += shfl_xor_u32(v, m);
         if (uniform((int)v) >= (int)target) break;
         if (++spins >= FLAG_SPIN_LIMIT) { if (lane == 0) (void)ticket_add_agent(producer_block + 2, 1u); break; }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SYNC_POLL_SLEEP);
     }
     if (lane < SYNC_SHARDS) store_relaxed_agent(sync_entry_shard(producer_block, (u32)lane), 0u);
 }

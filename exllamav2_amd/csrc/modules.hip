@@ -169,7 +169,8 @@ int chain_sync_next(ChainLaunch* out)
     const int k = g_chain.next;
     out->wait = k > 0 ? chain_block(k - 1) : nullptr;
     out->signal = chain_block(k);
-    out->arrive = chain_block(k);                    // every workgroup reports on entry (sync_report_entry): the gate below counts them
+    static const bool gates = []() { const char* e = getenv("EXL2_CHAIN_GATES"); return !(e && e[0] == '0'); }();
+    out->arrive = gates ? chain_block(k) : nullptr;  // every workgroup reports on entry (sync_report_entry): the gate below counts them
     out->stream = g_chain.stream[k & 1];
     return EXL2_OK;
 }
@@ -187,7 +188,9 @@ int chain_sync_done(u32 arrivals)
 {
     EXL2_REQUIRE(arrivals > 0, "chain: a launch of an overlapped chain must say how many workgroups it has");
     const int k = g_chain.next;
-    LAUNCH(chain_gate_kernel, dim3(1, 1, 1), dim3(64, 1, 1), 0, g_chain.stream[(k + 1) & 1], chain_block(k), arrivals);
+    // EXL2_CHAIN_GATES=0 (measurement only): no gates -- the entry counters are then cleared by a gate-less clear kernel at the end
+    static const bool gates = []() { const char* e = getenv("EXL2_CHAIN_GATES"); return !(e && e[0] == '0'); }();
+    if (gates) LAUNCH(chain_gate_kernel, dim3(1, 1, 1), dim3(64, 1, 1), 0, g_chain.stream[(k + 1) & 1], chain_block(k), arrivals);
     HIP_TRY(hipGetLastError());
     g_chain.next++;
     return EXL2_OK;

@@ -315,7 +315,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     // overlapped chain: "this workgroup holds its slot" (before anything may leave: the next launch's gate counts the whole grid)
     const u32 lin_wg = (u32)bid_y() * (u32)gdim_x() + (u32)bid_x();
     u32* const sync_signal = args.hdr.sync_signal;
-    if (sync_signal && wv == 0 && lane == 0) sync_report_entry(sync_signal, lin_wg);
+    if (sync_signal && args.hdr.sync_pad && wv == 0 && lane == 0) sync_report_entry(sync_signal, lin_wg);     // (sync_pad: a gate counts the entries)
     const int n_tiles = (int)m2.y;
     const int tile = PAIR ? u : u * NSLOTS + slot;
     if (!PAIR && u * NSLOTS >= n_tiles)                                  // (matrices of one launch may have different widths)
@@ -360,6 +360,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         // compiler otherwise, and then the registers of EITHER instantiation's pending requests count as pending here -- the
         // compiler then waits for them (a wait that also drains the copies it does not see) before it reuses one)
         LEAN_MARK(decltype(tag)::value);
+        constexpr bool CAN_DEP = (decltype(tag)::value % 1000) / 10 == 0;     // (tag = 1000 bits + 10 NB [+ k]: the non-pipelined forms)
         const u32x4 h0 = hb[0], h1 = hb[1], h2 = hb[2];
         const u32x2 h3 = *(const u32x2*)(hb + 3);
         const u32x4 m1 = mb[1];
@@ -412,7 +413,12 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                         u8* const dst = (u8*)(x_lds + (size_t)rr * x_stride);
                         #pragma unroll
                         for (int u = 0; u < LEAN_X_PIECES; u++)
-                            if (u * 64 + lane < xunits && xu0 + u * 64 + lane < oct) LEAN_DMA_X(row, (xu0 + u * 64 + lane) * 16, dst + u * 1024);
+                        {
+                            // (a launch of an overlapped chain reads its producer's rows at agent scope; it never takes the pipelined form)
+                            const bool on = u * 64 + lane < xunits && xu0 + u * 64 + lane < oct;
+                            if (CAN_DEP && sync_signal) { if (on) LEAN_DMA_X(row, (xu0 + u * 64 + lane) * 16, dst + u * 1024); }
+                            else if (on) LEAN_DMA(row, (xu0 + u * 64 + lane) * 16, dst + u * 1024);
+                        }
                     }
                 }
             }
@@ -428,7 +434,11 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                     u8* const dst = smem + (size_t)rr * x_stride * 2;
                     #pragma nounroll
                     for (int pc = (wv + WAVES - (rr % WAVES)) % WAVES; pc < pieces; pc += WAVES)
-                        if (pc * 64 + lane < oct) LEAN_DMA_X(row, (pc * 64 + lane) * 16, dst + (size_t)pc * 1024);
+                    {
+                        const bool on = pc * 64 + lane < oct;
+                        if (CAN_DEP && sync_signal) { if (on) LEAN_DMA_X(row, (pc * 64 + lane) * 16, dst + (size_t)pc * 1024); }
+                        else if (on) LEAN_DMA(row, (pc * 64 + lane) * 16, dst + (size_t)pc * 1024);
+                    }
                 }
             }
         }
@@ -945,6 +955,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     if (dep)
     {
         h.sync_wait = in.sync_wait; h.sync_signal = in.sync_signal; h.sync_wgs = (u32)wgs * (u32)(in.pair ? 1 : in.n_mats);
+        h.sync_pad = in.sync_arrive ? 1u : 0u;
         // (no pipelined form: the staging copies wait for the producer, the weight requests must not)
         for (int j = 0; j < in.n_mats; j++) for (int w = 0; w < S; w++) a.wave[j * S + w].meta |= 1u << 29;
     }
