@@ -286,7 +286,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     DYN_SMEM(smem);
     const int lane = lane_id();
     const int wv = uniform(wave_id());
-    const int u = bid_x();
+    int u = bid_x();                                                      // the workgroup's unit (tile / tile pair); ROWS: its first one
     const int slot = wv / S, r = wv % S;
     const int mj = PAIR ? slot : bid_y();
     // ---- arguments: header, matrix block, wave record -- addresses from built-in ids only: one batch of scalar loads.
@@ -317,6 +317,10 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     u32* const sync_signal = args.hdr.sync_signal;
     if (sync_signal && args.hdr.sync_pad && wv == 0 && lane == 0) sync_report_entry(sync_signal, lin_wg);     // (sync_pad: a gate counts the entries)
     const int n_tiles = (int)m2.y;
+    // ROWS: a workgroup walks units u, u + grid, ... with ONE staged copy of the rows (the host sizes the grid to the CUs: one
+    // workgroup per CU fits anyway); every other form: one unit, one pass
+    for (bool first_unit = true;; first_unit = false)
+    {
     const int tile = PAIR ? u : u * NSLOTS + slot;
     if (!PAIR && u * NSLOTS >= n_tiles)                                  // (matrices of one launch may have different widths)
     {
@@ -424,11 +428,12 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
             }
             else
             {
-                // the whole rows, dealt out over the workgroup's waves in 1 KB pieces (piece p of row rr -> wave (p + rr) mod waves)
+                // the whole rows, dealt out over the workgroup's waves in 1 KB pieces (piece p of row rr -> wave (p + rr) mod waves);
+                // once per workgroup: its later units read the same copy
                 constexpr int WAVES = S * NSLOTS;
                 const int pieces = (oct + 63) >> 6;
                 #pragma nounroll
-                for (int rr = 0; rr < M; rr++)
+                for (int rr = 0; rr < (first_unit ? M : 0); rr++)
                 {
                     const f16* const row = in_a + (size_t)rr * lda;
                     u8* const dst = smem + (size_t)rr * x_stride * 2;
@@ -601,7 +606,8 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     // THEIR matrix is the output's): lane -> output slot lane >> 4 (pair: the one act(gate) * up output), column lane & 15.
     constexpr int N_OUT = PAIR ? 1 : NSLOTS;
     const int ep_slot = lane >> 4, ep_c = lane & 15;
-    const int ep_tile = tile + (PAIR ? 0 : ep_slot);                    // (finalising waves sit in slot 0)
+    const int ep_tile = (PAIR ? u : u * NSLOTS) + (PAIR ? 0 : ep_slot);  // (ROWS: a finalising wave may sit in any slot -- the unit's first tile, not its own)
+    const int ep_mj = PAIR ? 0 : mj;                                     // (pair: the one output goes through matrix 0's c / c_invperm)
     const bool ep_on = ep_slot < N_OUT && ep_tile < n_tiles;
     const int ep_n = ep_tile * 16 + ep_c;
     f16* const xp_out = args.hdr.xp_out;
@@ -611,12 +617,12 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         e.cp = nullptr; e.c_old = (f16)0.0f; e.xp_idx = ep_n; e.xw_next = (f16)1.0f; e.ssq = 0.0f;
         if (ep_on)
         {
-            const u16* const c_invperm = args.mat[mj].c_invperm;
+            const u16* const c_invperm = args.mat[ep_mj].c_invperm;
             const u16* const xp_invperm = args.hdr.xp_invperm;
             const int c_idx = c_invperm ? (int)c_invperm[ep_n] : ep_n;
             if (xp_out && xp_invperm) e.xp_idx = (int)xp_invperm[ep_n];
             if (xp_out && args.hdr.xp_w) e.xw_next = args.hdr.xp_w[e.xp_idx];
-            e.cp = args.mat[mj].c + (size_t)row * args.hdr.ldc[mj] + c_idx;
+            e.cp = args.mat[ep_mj].c + (size_t)row * args.hdr.ldc[ep_mj] + c_idx;
             if (flags & LF_ACCUM) e.c_old = (flags & LF_DEP) ? load_agent_f16(e.cp) : *e.cp;
         }
         // A_NORM_PRE: the activations were x * w (qgemv_flat.h); 1 / rms(x) multiplies the finished sum.  The partial sums of
@@ -658,7 +664,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
             else
             {
                 float v = slot_sum(ep_slot) * rms;
-                if (flags & LF_BIAS) { const f16* bias = args.mat[mj].bias; if (bias) v += (float)bias[ep_n]; }
+                if (flags & LF_BIAS) { const f16* bias = args.mat[ep_mj].bias; if (bias) v += (float)bias[ep_n]; }
                 if (flags & LF_ACCUM) v += (float)e.c_old;
                 y = (f16)v;
             }
@@ -714,6 +720,13 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         if (wv < M) signal_done();
     }
     LTRACE(7);
+    if constexpr (!ROWS) break;
+    else
+    {
+        u += gdim_x();
+        if (u >= args.hdr.wgs) break;                                     // (hdr.wgs = units of the launch = partial sums per row it publishes)
+    }
+    }
 }
 
 #ifdef EXL2_TRACE
@@ -843,7 +856,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
 }
 
 #define LEAN_FOR_EACH_GEOMETRY(X, OCC) X(8, 1, false, OCC) X(16, 1, false, OCC) X(8, 2, false, OCC) X(8, 2, true, OCC) X(4, 2, true, OCC)
-#define LEAN_FOR_EACH_ROWS_GEOMETRY(X) X(8, 1, false) X(16, 1, false) X(8, 2, true)
+#define LEAN_FOR_EACH_ROWS_GEOMETRY(X) X(8, 1, false) X(16, 1, false) X(8, 2, false) X(8, 2, true)
 // register budget: 6 waves per SIMD (80 registers: no spills on the common paths, three 8-wave workgroups per CU).  4 and 8
 // were built side by side during the round and measured (4 slower; 8 equal within noise once gate|up used 8-wave workgroups,
 // with spills): tools/build_variant.sh -DLEAN_OCC_DEFAULT=... rebuilds them
@@ -910,12 +923,24 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     // candidates, in order: a one-row pair tries 4 waves per tile first (8-wave workgroups: three per CU at 6 waves per SIMD, so
     // the 688 workgroups of a 7B gate|up launch are resident at once; with 16-wave workgroups a quarter of them starts when
     // the first ones have finished: profiles/r03_trace_lean_v6.txt, workgroup entry p90 9.5 us)
-    int cand[2], n_cand = 0;
+    int cand[3], n_cand = 0;
     static const int pair4 = []() { const char* e = getenv("EXL2_LEAN_PAIR4"); return e ? atoi(e) : 1; }();
     if (in.pair && in.M == 1 && pair4) cand[n_cand++] = 4;
     cand[n_cand++] = S;
     if (!in.pair && nslots == 1 && S == 8) cand[n_cand++] = 16;        // finer split of the tile
-    if (rows_mode && (nslots != (in.pair ? 2 : 1))) return 1;          // ROWS geometries: (8, 1), (16, 1), pair (8 + 8)
+    // ROWS geometries, in order: two tiles x 8 waves sharing the staged rows (16 waves per CU), one tile x 8, one tile x 16; pair (8 + 8)
+    int cand_slots[3] = {nslots, nslots, nslots};
+    if (rows_mode)
+    {
+        n_cand = 0;
+        if (in.pair) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
+        else
+        {
+            if (!(in.ss_out && (max_tiles + 1) / 2 > LEAN_MAX_PART) && max_tiles >= 2) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
+            cand[n_cand] = 8; cand_slots[n_cand++] = 1;
+            cand[n_cand] = 16; cand_slots[n_cand++] = 1;               // (K = 11008: a tile's share does not fit 8 waves' registers)
+        }
+    }
     // ROWS: the workgroup's shared copy of the M rows, in front of the waves' own (scale-row) areas
     const u32 rows_bytes = rows_mode ? al16((u32)in.M * (u32)(K + 8) * 2u) : 0u;
     u32 slot_bytes = 0;
@@ -925,6 +950,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     for (int ci = 0; ci < 2 * n_cand && !planned; ci++)
     {
         S = cand[ci % n_cand];
+        if (rows_mode) nslots = cand_slots[ci % n_cand];
         const u32 budget = rows_mode ? 158u * 1024u : (ci < n_cand ? LEAN_LDS_BUDGET * (u32)((S * nslots + 7) / 8) : 150u * 1024u);
         if (in.n_mats * S > LEAN_RECORDS) continue;
         bool ok = true;
@@ -979,7 +1005,20 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
                         ((lw.meta >> 15) & 1) ? " uni" : "");
             }
     }
-    dim3 grid((unsigned)wgs, (unsigned)(in.pair ? 1 : in.n_mats), 1), block((unsigned)waves * 64, 1, 1);
+    // ROWS: one workgroup per CU fits (the staged rows fill the LDS), so the grid is sized to the CUs and a workgroup walks its
+    // units with one staged copy; inside an overlapped chain every workgroup takes one unit (its arrival counts are per unit)
+    int grid_x = wgs;
+    if (rows_mode && !dep)
+    {
+        static int cus[EXL2_MAX_DEVICES] = {0};
+        const int dev = exl2_current_device();
+        if (!cus[dev]) { hipDeviceProp_t prop; cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
+        int cap = cus[dev] / (in.pair ? 1 : in.n_mats);
+        if (const char* e = getenv("EXL2_LEAN_ROWS_GRID")) { const int v = atoi(e); if (v > 0) cap = v; }      // (tests: force the walk on small shapes)
+        if (cap < 1) cap = 1;
+        if (grid_x > cap) grid_x = cap;
+    }
+    dim3 grid((unsigned)grid_x, (unsigned)(in.pair ? 1 : in.n_mats), 1), block((unsigned)waves * 64, 1, 1);
     if (getenv("EXL2_LEAN_PLAN_ONLY")) { if (wgs_out) *wgs_out = wgs; return 0; }     // test hook: the host plan without the launch (results undefined)
     const bool gptq = q0->is_gptq;
     const int occ = LEAN_OCC_DEFAULT;

@@ -80,6 +80,18 @@ def test_chain_decode_many_rows(be, batch):
     assert lean > 0 and flat == 0, (lean, flat)
 
 
+@pytest.mark.parametrize("batch,grid", [(16, 1), (11, 2), (6, 3)])
+def test_chain_decode_many_rows_workgroups_walk_their_units(be, batch, grid, monkeypatch):
+    """ROWS form: the grid is sized to the CUs and a workgroup takes units u, u + grid, ... with one staged copy of the rows
+    (a 7B gate|up launch: 688 tile pairs on 256 workgroups).  Small shapes never have more units than CUs, so the walk is forced."""
+    monkeypatch.setenv("EXL2_LEAN_ROWS_GRID", str(grid))
+    cfg = tiny_cfg(max_batch_size=16, intermediate_size=384, num_attention_heads=4, num_key_value_heads=2)
+    be.ext.chain_route_counts(reset=True)
+    _decode_and_check(be, cfg, "3.5bpw", batch, steps=2, seed=19)
+    lean, flat = be.ext.chain_route_counts(reset=True)
+    assert lean > 0 and flat == 0, (lean, flat)
+
+
 @pytest.mark.parametrize("recipe,batch", [("3.5bpw", 16), ("2.5bpw", 7)])
 def test_chain_decode_many_rows_mixed_groupings(be, recipe, batch, monkeypatch):
     """down_proj's K is larger than hidden: its rows x (K + 8) x 2 bytes stop fitting in LDS at fewer rows than those of q|k|v / o /
