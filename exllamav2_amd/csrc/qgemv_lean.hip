@@ -280,7 +280,10 @@ DEV const void* ptr_of(u32 lo, u32 hi) { return (const void*)global_ptr_of(lo, h
 // 16 x 4096); no pipelined form (the barrier sits between the requests and the decode anyway), every finalising wave takes
 // several rows.  Replaces the row pre-pass + K-phased kernels (qgemv_stream.hip / qgemm_prefill.hip) on the chained path
 // wherever M x (K + 8) x 2 bytes fit in LDS; larger K is served as row groups of <= 4 rows by the host (model.py).
-template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false>
+// WALK (ROWS only): the workgroup takes units u, u + grid, ... with its one staged copy of the rows (two-tile geometries: a 7B gate|up
+// launch is 688 tile pairs on 256 CUs); without it one unit per workgroup (fewer registers: the 16-wave geometry of down_proj's row
+// groups spills otherwise).
+template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false>
 KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs args)
 {
     DYN_SMEM(smem);
@@ -720,7 +723,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         if (wv < M) signal_done();
     }
     LTRACE(7);
-    if constexpr (!ROWS) break;
+    if constexpr (!(ROWS && WALK)) break;
     else
     {
         u += gdim_x();
@@ -856,7 +859,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
 }
 
 #define LEAN_FOR_EACH_GEOMETRY(X, OCC) X(8, 1, false, OCC) X(16, 1, false, OCC) X(8, 2, false, OCC) X(8, 2, true, OCC) X(4, 2, true, OCC)
-#define LEAN_FOR_EACH_ROWS_GEOMETRY(X) X(8, 1, false) X(16, 1, false) X(8, 2, false) X(8, 2, true)
+#define LEAN_FOR_EACH_ROWS_GEOMETRY(X) X(8, 1, false, false) X(16, 1, false, false) X(8, 2, false, true) X(8, 2, true, true)
 // register budget: 6 waves per SIMD (80 registers: no spills on the common paths, three 8-wave workgroups per CU).  4 and 8
 // were built side by side during the round and measured (4 slower; 8 equal within noise once gate|up used 8-wave workgroups,
 // with spills): tools/build_variant.sh -DLEAN_OCC_DEFAULT=... rebuilds them
@@ -876,9 +879,9 @@ static void lean_attrs()
     (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LEAN_FOR_EACH_GEOMETRY(LEAN_ATTR, 6)
 #undef LEAN_ATTR
-#define LEAN_ATTR(S, NS, P) \
-    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, S, NS, P, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define LEAN_ATTR(S, NS, P, W) \
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, S, NS, P, 4, true, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, 4, true, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LEAN_FOR_EACH_ROWS_GEOMETRY(LEAN_ATTR)
 #undef LEAN_ATTR
 }
@@ -936,7 +939,9 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
         if (in.pair) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
         else
         {
-            if (!(in.ss_out && (max_tiles + 1) / 2 > LEAN_MAX_PART) && max_tiles >= 2) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
+            // (up to 8 rows the staged rows leave room for two 8-wave workgroups per CU: one tile per workgroup, the whole grid
+            // resident; from 9 rows up one workgroup per CU anyway: two tiles per unit, the workgroup walks -- profiles/r04_rows_sweep*.txt)
+            if (in.M >= 9 && !(in.ss_out && (max_tiles + 1) / 2 > LEAN_MAX_PART) && max_tiles >= 2) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
             cand[n_cand] = 8; cand_slots[n_cand++] = 1;
             cand[n_cand] = 16; cand_slots[n_cand++] = 1;               // (K = 11008: a tile's share does not fit 8 waves' registers)
         }
@@ -1008,7 +1013,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     // ROWS: one workgroup per CU fits (the staged rows fill the LDS), so the grid is sized to the CUs and a workgroup walks its
     // units with one staged copy; inside an overlapped chain every workgroup takes one unit (its arrival counts are per unit)
     int grid_x = wgs;
-    if (rows_mode && !dep)
+    if (rows_mode && !dep && nslots == 2)                            // (the WALK instantiations: the two-tile geometries)
     {
         static int cus[EXL2_MAX_DEVICES] = {0};
         const int dev = exl2_current_device();
@@ -1022,9 +1027,9 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     if (getenv("EXL2_LEAN_PLAN_ONLY")) { if (wgs_out) *wgs_out = wgs; return 0; }     // test hook: the host plan without the launch (results undefined)
     const bool gptq = q0->is_gptq;
     const int occ = LEAN_OCC_DEFAULT;
-#define LEAN_GO(SS, NS, P) \
-    if (rows_mode && !gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, 4, true>), grid, block, lds, stream, a); \
-    if (rows_mode && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, 4, true>), grid, block, lds, stream, a);
+#define LEAN_GO(SS, NS, P, W) \
+    if (rows_mode && !gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, 4, true, W>), grid, block, lds, stream, a); \
+    if (rows_mode && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, 4, true, W>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_ROWS_GEOMETRY(LEAN_GO)
 #undef LEAN_GO
 #define LEAN_GO(SS, NS, P, OCC) \

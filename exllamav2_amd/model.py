@@ -297,10 +297,6 @@ class GreedyGraphDecoder:
                 lds = int(os.environ.get("EXL2_CHAIN_ROWS_LDS", 132 * 1024))     # rows next to ~26 KB of scale rows and partial sums
                 fit = lds // ((K + 8) * 2)
                 g = b if fit >= b else (fit if fit >= 5 else 4)
-                # (exactly 8 sequences: two launches of the 4-row wave-private, pipelined form beat one launch of the ROWS form --
-                # 3534 vs 3401 tok/s, profiles/r04_rows_sweep.txt; 5-7 and 9-16 sequences: the ROWS form wins by 23-43 %)
-                if b == 8 and "EXL2_CHAIN_ROWS_LDS" not in os.environ:
-                    g = 4
                 g = -(-b // -(-b // g))                             # equal groups: 16 rows at 6 per launch -> 6 + 5 + 5
             return [(r, min(r + g, b)) for r in range(0, b, g)]
 
