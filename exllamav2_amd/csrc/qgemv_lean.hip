@@ -76,7 +76,7 @@ struct alignas(64) LeanWave
 {
     u32 w_off, w_tstride;             // full items: word offset of the first one for tile 0 in qw, words between consecutive tiles
     u32 t_off, t_tstride;             // the partial item: the same in the side buffer
-    u32 meta;                         // n (0..7) | bits (8..11) | nvalid of the partial item, 0 = none (12..14) | uniform (15) | gshift (16..18) | gphase (19..28) | pipelined form off (29)
+    u32 meta;                         // n (0..7) | bits (8..11) | nvalid of the partial item, 0 = none (12..14) | uniform (15) | gshift (16..18) | gphase (19..28) | pipelined form off (29) | launch of an overlapped chain (30)
     u32 xr;                           // first chunk (0..15) | number of chunks (16..31) of the activation slice
     u32 gr;                           // first scale-table row (0..15) | number of rows (16..31)
     u32 lds_off;                      // byte offset of the wave's LDS area inside its slot's area
@@ -283,7 +283,10 @@ DEV const void* ptr_of(u32 lo, u32 hi) { return (const void*)global_ptr_of(lo, h
 // WALK (ROWS only): the workgroup takes units u, u + grid, ... with its one staged copy of the rows (two-tile geometries: a 7B gate|up
 // launch is 688 tile pairs on 256 CUs); without it one unit per workgroup (fewer registers: the 16-wave geometry of down_proj's row
 // groups spills otherwise).
-template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false>
+// DEP: a launch of the overlapped chain (chain_sync.h; EXPERIMENTAL).  A template parameter, not a run-time flag: the run-time form
+// cost the ordinary launches 2-4 % (a few scalar loads and branches on the request path and in the finalising wave's tail:
+// profiles/r04_bisect.txt).
+template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false, bool DEP = false>
 KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs args)
 {
     DYN_SMEM(smem);
@@ -316,9 +319,22 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
 #endif
     LTRACE(0);
     // overlapped chain: "this workgroup holds its slot" (before anything may leave: the next launch's gate counts the whole grid)
-    const u32 lin_wg = (u32)bid_y() * (u32)gdim_x() + (u32)bid_x();
-    u32* const sync_signal = args.hdr.sync_signal;
-    if (sync_signal && args.hdr.sync_pad && wv == 0 && lane == 0) sync_report_entry(sync_signal, lin_wg);     // (sync_pad: a gate counts the entries)
+    // (bit 30 of every wave record says so: the header's sync words sit in a cache line of their own, and a scalar load + wait
+    // in front of the weight requests costs every launch ~0.3 us -- measured: profiles/r04_states_ab.txt)
+    // The workgroup's linear index is computed only THERE too: gridDim comes from the dispatch packet -- another scalar load the
+    // requests would wait for (-4.5 % on the whole decode step when it sat here unconditionally: profiles/r04_bisect.txt).
+    // (kernel-argument loads are speculatable: without the laundered pointer the compiler hoists these two into the first batch.)
+    u32* sync_signal_ = nullptr;
+    auto lin_wg_of = [&]() -> u32 { return (u32)bid_y() * (u32)gdim_x() + (u32)bid_x(); };
+    if constexpr (DEP)
+    {
+        u32 opaque0 = 0;
+        pin_scalar(opaque0);
+        const LeanHdr* hp = (const LeanHdr*)((const u8*)&args.hdr + opaque0);
+        sync_signal_ = hp->sync_signal;
+        if (hp->sync_pad && wv == 0 && lane == 0) sync_report_entry(sync_signal_, lin_wg_of());       // (sync_pad: a gate counts the entries)
+    }
+    u32* const sync_signal = sync_signal_;
     const int n_tiles = (int)m2.y;
     // ROWS: a workgroup walks units u, u + grid, ... with ONE staged copy of the rows (the host sizes the grid to the CUs: one
     // workgroup per CU fits anyway); every other form: one unit, one pass
@@ -332,7 +348,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         {
             const u32 m_rows = (u32)args.hdr.M, fin = (u32)(S * NSLOTS);
             const u32 per_wg = ROWS ? (m_rows < fin ? m_rows : fin) : m_rows;
-            if ((u32)wv < per_wg) sync_arrive_publish_sharded(sync_signal, lin_wg, per_wg, args.hdr.sync_wgs, args.hdr.sync_wait);
+            if ((u32)wv < per_wg) sync_arrive_publish_sharded(sync_signal, lin_wg_of(), per_wg, args.hdr.sync_wgs, args.hdr.sync_wait);
         }
         return;
     }
@@ -346,7 +362,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         const u32* const w = args.hdr.sync_wait;
         if (sync_signal)                                                  // (uniform over the launch)
         {
-            if (w && wv == 0) sync_wait_go(w, (int)(lin_wg & 7u));
+            if (w && wv == 0) sync_wait_go(w, (int)(lin_wg_of() & 7u));
             block_sync_lds();
         }
     };
@@ -401,13 +417,15 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         {
             // straight-line code: <= 2 copy instructions per scale table, <= LEAN_X_PIECES per activation row (M <= 4 rows,
             // slices of <= 64 * LEAN_X_PIECES 16-byte units, <= 64 scale rows: what the host plans)
+            // (the second and later pieces sit behind a SCALAR test: a lane-wise test alone costs ~8 instructions per skipped copy, in
+            // front of the requests of the wave's last items)
             if (lane < sc_units) LEAN_DMA(st, lane * 16, sc_lds);
-            if (64 + lane < sc_units) LEAN_DMA(st, (64 + lane) * 16, sc_lds + 1024);
+            if (sc_units > 64) { if (64 + lane < sc_units) LEAN_DMA(st, (64 + lane) * 16, sc_lds + 1024); }
             if constexpr (GPTQ)
             {
                 const f16* zt = zp_tab + ((size_t)t_ * G + gw0) * 16;
                 if (lane < sc_units) LEAN_DMA(zt, lane * 16, zp_lds);
-                if (64 + lane < sc_units) LEAN_DMA(zt, (64 + lane) * 16, zp_lds + 1024);
+                if (sc_units > 64) { if (64 + lane < sc_units) LEAN_DMA(zt, (64 + lane) * 16, zp_lds + 1024); }
             }
             if constexpr (!ROWS)
             {
@@ -420,10 +438,11 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                         u8* const dst = (u8*)(x_lds + (size_t)rr * x_stride);
                         #pragma unroll
                         for (int u = 0; u < LEAN_X_PIECES; u++)
+                        if (u == 0 || u * 64 < xunits)
                         {
                             // (a launch of an overlapped chain reads its producer's rows at agent scope; it never takes the pipelined form)
                             const bool on = u * 64 + lane < xunits && xu0 + u * 64 + lane < oct;
-                            if (CAN_DEP && sync_signal) { if (on) LEAN_DMA_X(row, (xu0 + u * 64 + lane) * 16, dst + u * 1024); }
+                            if constexpr (CAN_DEP && DEP) { if (on) LEAN_DMA_X(row, (xu0 + u * 64 + lane) * 16, dst + u * 1024); }
                             else if (on) LEAN_DMA(row, (xu0 + u * 64 + lane) * 16, dst + u * 1024);
                         }
                     }
@@ -444,7 +463,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                     for (int pc = (wv + WAVES - (rr % WAVES)) % WAVES; pc < pieces; pc += WAVES)
                     {
                         const bool on = pc * 64 + lane < oct;
-                        if (CAN_DEP && sync_signal) { if (on) LEAN_DMA_X(row, (pc * 64 + lane) * 16, dst + (size_t)pc * 1024); }
+                        if constexpr (CAN_DEP && DEP) { if (on) LEAN_DMA_X(row, (pc * 64 + lane) * 16, dst + (size_t)pc * 1024); }
                         else if (on) LEAN_DMA(row, (pc * 64 + lane) * 16, dst + (size_t)pc * 1024);
                     }
                 }
@@ -626,7 +645,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
             if (xp_out && xp_invperm) e.xp_idx = (int)xp_invperm[ep_n];
             if (xp_out && args.hdr.xp_w) e.xw_next = args.hdr.xp_w[e.xp_idx];
             e.cp = args.mat[ep_mj].c + (size_t)row * args.hdr.ldc[ep_mj] + c_idx;
-            if (flags & LF_ACCUM) e.c_old = (flags & LF_DEP) ? load_agent_f16(e.cp) : *e.cp;
+            if (flags & LF_ACCUM) e.c_old = DEP ? load_agent_f16(e.cp) : *e.cp;
         }
         // A_NORM_PRE: the activations were x * w (qgemv_flat.h); 1 / rms(x) multiplies the finished sum.  The partial sums of
         // squares of this row (fixed order)
@@ -634,7 +653,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         {
             const float* sp = args.hdr.ss + (size_t)row * args.hdr.npart;
             #pragma nounroll
-            for (int i = lane; i < args.hdr.npart; i += 64) e.ssq += (flags & LF_DEP) ? load_agent_f32(sp + i) : sp[i];
+            for (int i = lane; i < args.hdr.npart; i += 64) e.ssq += DEP ? load_agent_f32(sp + i) : sp[i];
         }
     };
     // combine (fixed order) + epilogue of one row
@@ -671,14 +690,14 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                 if (flags & LF_ACCUM) v += (float)e.c_old;
                 y = (f16)v;
             }
-            if (flags & LF_DEP) store_agent_f16(e.cp, y); else *e.cp = y;
+            if constexpr (DEP) store_agent_f16(e.cp, y); else *e.cp = y;
             if (xp_out)
             {
                 // chain-out: x for the next consumer = x * ITS norm weight (one rounding, saturated), in its packed order; the sum
                 // of squares is x's own
                 const float f = fmaxf(-65504.0f, fminf((float)y, 65504.0f));
                 const f16 xw = (f16)fmaxf(-65504.0f, fminf(f * (float)e.xw_next, 65504.0f));
-                if (flags & LF_DEP) store_agent_f16(xp_out + (size_t)row * args.hdr.ldxp + e.xp_idx, xw);
+                if constexpr (DEP) store_agent_f16(xp_out + (size_t)row * args.hdr.ldxp + e.xp_idx, xw);
                 else xp_out[(size_t)row * args.hdr.ldxp + e.xp_idx] = xw;
                 sq = f * f;
             }
@@ -687,14 +706,14 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         if (ss_out)
         {
             sq = wave_allreduce_add(sq);
-            if (lane == 0) { if (flags & LF_DEP) store_agent_f32(ss_out + (size_t)row * args.hdr.wgs + u, sq); else ss_out[(size_t)row * args.hdr.wgs + u] = sq; }
+            if (lane == 0) { if constexpr (DEP) store_agent_f32(ss_out + (size_t)row * args.hdr.wgs + u, sq); else ss_out[(size_t)row * args.hdr.wgs + u] = sq; }
         }
     };
     // overlapped chain: this finalising wave's outputs have completed -> it arrives; the launch's last arrival publishes "go"
     constexpr u32 FIN_WAVES = (u32)(S * NSLOTS);
     auto signal_done = [&]() {
         if (sync_signal)
-            sync_arrive_publish_sharded(sync_signal, lin_wg, ROWS ? ((u32)M < FIN_WAVES ? (u32)M : FIN_WAVES) : (u32)M, args.hdr.sync_wgs, args.hdr.sync_wait);
+            sync_arrive_publish_sharded(sync_signal, lin_wg_of(), ROWS ? ((u32)M < FIN_WAVES ? (u32)M : FIN_WAVES) : (u32)M, args.hdr.sync_wgs, args.hdr.sync_wait);
     };
     if constexpr (!ROWS)
     {
@@ -872,11 +891,13 @@ static void lean_attrs()
     static bool attr[EXL2_MAX_DEVICES] = {false};
     if (!exl2_first_on_device(attr)) return;
 #define LEAN_ATTR(S, NS, P, OCC) \
-    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, S, NS, P, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, S, NS, P, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, S, NS, P, OCC, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LEAN_FOR_EACH_GEOMETRY(LEAN_ATTR, LEAN_OCC_DEFAULT)
 #undef LEAN_ATTR
 #define LEAN_ATTR(S, NS, P, OCC) \
-    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, OCC, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LEAN_FOR_EACH_GEOMETRY(LEAN_ATTR, 6)
 #undef LEAN_ATTR
 #define LEAN_ATTR(S, NS, P, W) \
@@ -894,8 +915,9 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     static const int rows_on = []() { const char* e = getenv("EXL2_LEAN_ROWS"); return e ? atoi(e) : 1; }();
     const bool rows_mode = in.M > LEAN_MAX_M;
     if (rows_mode && !rows_on) return 1;
-    const bool dep = in.sync_signal != nullptr;                     // a launch of an overlapped chain (chain_sync.h)
+    const bool dep = in.sync_signal != nullptr;                     // a launch of an overlapped chain (chain_sync.h): <= 4 rows only
     if (!dep && (in.sync_wait || in.sync_arrive)) return 1;
+    if (dep && rows_mode) return 1;
     if (const char* e = getenv("EXL2_LEAN_DECLINE_M")) { if (atoi(e) == in.M) return 1; }      // test hook: row groups on different kernels
     const QMatrix* q0 = in.qm[0];
     const int K = q0->height;
@@ -988,7 +1010,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
         h.sync_wait = in.sync_wait; h.sync_signal = in.sync_signal; h.sync_wgs = (u32)wgs * (u32)(in.pair ? 1 : in.n_mats);
         h.sync_pad = in.sync_arrive ? 1u : 0u;
         // (no pipelined form: the staging copies wait for the producer, the weight requests must not)
-        for (int j = 0; j < in.n_mats; j++) for (int w = 0; w < S; w++) a.wave[j * S + w].meta |= 1u << 29;
+        for (int j = 0; j < in.n_mats; j++) for (int w = 0; w < S; w++) a.wave[j * S + w].meta |= (1u << 29) | (1u << 30);
     }
     h.slot_bytes = slot_bytes; h.red_off = rows_bytes + slot_bytes * (u32)nslots;
     const int waves = S * nslots;
@@ -1033,11 +1055,13 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     LEAN_FOR_EACH_ROWS_GEOMETRY(LEAN_GO)
 #undef LEAN_GO
 #define LEAN_GO(SS, NS, P, OCC) \
-    if (!rows_mode && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a);
+    if (!rows_mode && !dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a); \
+    if (!rows_mode && dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC, false, false, true>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_GEOMETRY(LEAN_GO, LEAN_OCC_DEFAULT)
 #undef LEAN_GO
 #define LEAN_GO(SS, NS, P, OCC) \
-    if (!rows_mode && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC>), grid, block, lds, stream, a);
+    if (!rows_mode && !dep && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC>), grid, block, lds, stream, a); \
+    if (!rows_mode && dep && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC, false, false, true>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_GEOMETRY(LEAN_GO, 6)
 #undef LEAN_GO
     if (wgs_out) *wgs_out = wgs;
