@@ -414,6 +414,25 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         const int sc_units = 2 * ng;                                      // 16-byte units of the scale rows (a row = 16 halfs)
         const f16* const st = sc_tab + ((size_t)t_ * G + gw0) * 16;
         LEAN_MARK(decltype(tag)::value + 1);
+        if (!ROWS && M == 1 && xunits <= (S == 4 ? 128 : 64) && sc_units <= 64)
+        {
+            // the headline case -- one row, one copy instruction per table (two for the 4-wave geometry's 128-unit slices) -- with
+            // nothing but those in front of the requests of the wave's last items (1.5 % of the whole decode step against the
+            // general form below: profiles/r04_states_ab_final.txt)
+            if (lane < sc_units) LEAN_DMA(st, lane * 16, sc_lds);
+            if constexpr (GPTQ) { if (lane < sc_units) LEAN_DMA(zp_tab + ((size_t)t_ * G + gw0) * 16, lane * 16, zp_lds); }
+            if constexpr (CAN_DEP && DEP)
+            {
+                if (lane < xunits && xu0 + lane < oct) LEAN_DMA_X(in_a, (xu0 + lane) * 16, (u8*)x_lds);
+                if constexpr (S == 4) { if (64 + lane < xunits && xu0 + 64 + lane < oct) LEAN_DMA_X(in_a, (xu0 + 64 + lane) * 16, (u8*)x_lds + 1024); }
+            }
+            else
+            {
+                if (lane < xunits && xu0 + lane < oct) LEAN_DMA(in_a, (xu0 + lane) * 16, (u8*)x_lds);
+                if constexpr (S == 4) { if (64 + lane < xunits && xu0 + 64 + lane < oct) LEAN_DMA(in_a, (xu0 + 64 + lane) * 16, (u8*)x_lds + 1024); }
+            }
+        }
+        else
         {
             // straight-line code: <= 2 copy instructions per scale table, <= LEAN_X_PIECES per activation row (M <= 4 rows,
             // slices of <= 64 * LEAN_X_PIECES 16-byte units, <= 64 scale rows: what the host plans)
