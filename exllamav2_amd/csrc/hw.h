@@ -70,6 +70,7 @@ DEV int uniform(int x) { return (int)__builtin_amdgcn_readfirstlane((u32)x); }
 // Pin a wave-uniform value into a scalar register HERE: kernel-argument loads feeding it cannot be sunk past this point, so
 // a run of pins at the top of a kernel turns scattered single-dword argument loads into one batch of wide scalar loads.
 template <typename T> DEV void pin_scalar(T& x) { asm volatile("" : "+s"(x)); }
+template <typename T> DEV void pin_vector(T& x) { asm volatile("" : "+v"(x)); }        // the value is made HERE, in a vector register
 
 // ---- cross-lane ----------------------------------------------------------------------------------------------------
 // butterfly exchange within a wave: value held by lane (lane ^ mask).  Masks 1,2 map to DPP quad_perm, 4/8 to

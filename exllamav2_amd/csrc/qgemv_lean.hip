@@ -61,6 +61,9 @@
 #else
 #define LEAN_MARK(id) do { } while (0)
 #endif
+#ifndef LEAN_XMEM_AHEAD
+#define LEAN_XMEM_AHEAD 3             // XMEM form: items whose A operands are in registers or in flight (16 registers each)
+#endif
 #define LEAN_MAX_WAVES 16
 #define LEAN_RECORDS 48               // wave records in the argument block: matrices x waves per tile (q|k|v at 16 waves)
 #define LEAN_MAX_PASSES 4             // 16-wave geometry: a wave's share may be this many register loads (qgemv_lean_kernel, further passes)
@@ -155,8 +158,9 @@ struct LeanCtx
 // One FULL item whose four chunks share a group (group size >= 128 rows, aligned): exact (code - zero) halves -> four chained
 // MFMAs against the staged activations -> the group scale on the fp32 partial sum.  Same arithmetic as gemv_super
 // (qgemv_common.h).
-template <int BITS, bool GPTQ>
-DEV void lean_item_uniform(const LaneWords<BITS>& lw, const LeanCtx& cx, int chunk, int g, int lane, f32x4& acc)
+// PRE (the XMEM form of the kernel): the four A operands were requested from MEMORY ahead of time and arrive in `pre`.
+template <int BITS, bool GPTQ, bool PRE = false>
+DEV void lean_item_uniform(const LaneWords<BITS>& lw, const LeanCtx& cx, int chunk, int g, int lane, f32x4& acc, const f16x8* pre = nullptr)
 {
     const int c = lane & 15, j = lane >> 4;
     const int mrow = c < cx.M ? c : cx.M - 1;
@@ -173,7 +177,8 @@ DEV void lean_item_uniform(const LaneWords<BITS>& lw, const LeanCtx& cx, int chu
     for (int q = 0; q < 4; q++)
     {
         const f16x8 b = {p[4 * q].x, p[4 * q].y, p[4 * q + 1].x, p[4 * q + 1].y, p[4 * q + 2].x, p[4 * q + 2].y, p[4 * q + 3].x, p[4 * q + 3].y};
-        const f16x8 a = *(const f16x8*)(arow + q * 32);
+        f16x8 a;
+        if constexpr (PRE) a = pre[q]; else a = *(const f16x8*)(arow + q * 32);
         part = mfma_16x16x32_f16(a, b, part);
     }
     #pragma unroll
@@ -186,9 +191,9 @@ DEV void lean_item_uniform(const LaneWords<BITS>& lw, const LeanCtx& cx, int chu
 // reconstruct()'s value (q_matrix.cu:328-553) -- so the four chunks still accumulate into one fp32 chain and the item
 // needs no more registers than the uniform form (four scales on the partial sums cost 13 more, i.e. a workgroup per CU).
 #if LEAN_PRESCALE
-template <int BITS, bool GPTQ>
+template <int BITS, bool GPTQ, bool PRE = false>
 DEV void lean_item_general(const LaneWords<BITS>& lw, const LeanCtx& cx, int chunk, int cs, int g0, int gshift, int gphase, int nvalid,
-                           int lane, f32x4& acc)
+                           int lane, f32x4& acc, const f16x8* pre = nullptr)
 {
     const int c = lane & 15, j = lane >> 4;
     const int mrow = c < cx.M ? c : cx.M - 1;
@@ -216,7 +221,8 @@ DEV void lean_item_general(const LaneWords<BITS>& lw, const LeanCtx& cx, int chu
             const f16x2 s2 = h2_dup(cx.sc_lds[(g0 + ((cs + q + gphase) >> gshift)) * 16 + c]);
             const f16x2 b0 = p[4 * q] * s2, b1 = p[4 * q + 1] * s2, b2 = p[4 * q + 2] * s2, b3 = p[4 * q + 3] * s2;
             const f16x8 b = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
-            const f16x8 a = *(const f16x8*)(arow + q * 32);
+            f16x8 a;
+            if constexpr (PRE) a = pre[q]; else a = *(const f16x8*)(arow + q * 32);
             part = mfma_16x16x32_f16(a, b, part);
         }
     }
@@ -224,9 +230,9 @@ DEV void lean_item_general(const LaneWords<BITS>& lw, const LeanCtx& cx, int chu
     for (int i = 0; i < 4; i++) acc[i] += part[i];
 }
 #else
-template <int BITS, bool GPTQ>
+template <int BITS, bool GPTQ, bool PRE = false>
 DEV void lean_item_general(const LaneWords<BITS>& lw, const LeanCtx& cx, int chunk, int cs, int g0, int gshift, int gphase, int nvalid,
-                           int lane, f32x4& acc)
+                           int lane, f32x4& acc, const f16x8* pre = nullptr)
 {
     const int c = lane & 15, j = lane >> 4;
     const int mrow = c < cx.M ? c : cx.M - 1;
@@ -255,7 +261,8 @@ DEV void lean_item_general(const LaneWords<BITS>& lw, const LeanCtx& cx, int chu
         if (q < nvalid)
         {
             const f16x8 b = {p[4 * q].x, p[4 * q].y, p[4 * q + 1].x, p[4 * q + 1].y, p[4 * q + 2].x, p[4 * q + 2].y, p[4 * q + 3].x, p[4 * q + 3].y};
-            const f16x8 a = *(const f16x8*)(arow + q * 32);
+            f16x8 a;
+            if constexpr (PRE) a = pre[q]; else a = *(const f16x8*)(arow + q * 32);
             const f32x4 part = mfma_16x16x32_f16(a, b, zero4);
             #pragma unroll
             for (int i = 0; i < 4; i++) acc[i] = fmaf(s[q], part[i], acc[i]);
@@ -265,6 +272,17 @@ DEV void lean_item_general(const LaneWords<BITS>& lw, const LeanCtx& cx, int chu
 #endif
 
 DEV const void* ptr_of(u32 lo, u32 hi) { return (const void*)global_ptr_of(lo, hi); }
+
+// XMEM: the A operands of one item (4 chunks x 16 rows x 32 halfs) requested from memory -- cx.x_lds is the activations' GLOBAL
+// base there, x_stride their row stride: per chunk lane (c, j) reads the 16 bytes at row min(c, M - 1), column 32 chunk + 8 j
+DEV void lean_xmem_request(const LeanCtx& cx, int chunk, int nvalid, int lane, f16x8 (&v)[4])
+{
+    const int c = lane & 15, j = lane >> 4;
+    const int mrow = c < cx.M ? c : cx.M - 1;
+    const f16* arow = cx.x_lds + (size_t)mrow * cx.x_stride + (chunk - cx.xc0) * 32 + 8 * j;
+    #pragma unroll
+    for (int q = 0; q < 4; q++) if (q < nvalid) v[q] = *(const f16x8*)(arow + q * 32);
+}
 
 // Geometry (template): S = waves per tile (8 / 16), NSLOTS = tiles per workgroup (1 / 2), PAIR = the two tiles are tile u of
 // matrix 0 (gate) and of matrix 1 (up) and the epilogue writes act(gate) * up.  Otherwise blockIdx.y = matrix.
@@ -286,7 +304,12 @@ DEV const void* ptr_of(u32 lo, u32 hi) { return (const void*)global_ptr_of(lo, h
 // DEP: a launch of the overlapped chain (chain_sync.h; EXPERIMENTAL).  A template parameter, not a run-time flag: the run-time form
 // cost the ordinary launches 2-4 % (a few scalar loads and branches on the request path and in the finalising wave's tail:
 // profiles/r04_bisect.txt).
-template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false, bool DEP = false>
+// XMEM (5 .. 16 rows; round 4, second form): no staged activations at all -- a wave requests the A operands of its items from
+// memory (the L2 holds the M x K activations), LEAN_XMEM_AHEAD items ahead of the one it decodes, next to its weights.  For
+// launches whose rows do not fit the LDS as a whole (down_proj at K = 11008: 16 rows = 352 KB) this replaces the host's row
+// GROUPS (every group re-read all weights: three launches of 12 + 12 + 10 us) by one launch; LDS holds scale rows and the
+// partial sums only, so several workgroups share a CU again.
+template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false, bool DEP = false, bool XMEM = false>
 KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs args)
 {
     DYN_SMEM(smem);
@@ -399,13 +422,13 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         const int gw0 = (int)(gr & 0xFFFFu), ng = (int)(gr >> 16);
         // the wave's LDS area: [M rows of the activation slice][scale rows][zero-point rows]
         // (ROWS: the workgroup's shared rows come first, x_stride = K + 8; a wave's own area holds its scale rows only)
-        const int x_stride = ROWS ? K + 8 : (int)w2.w;
+        const int x_stride = ROWS ? K + 8 : XMEM ? lda : (int)w2.w;
         const u32 rows_bytes = ROWS ? (((u32)M * (u32)x_stride * 2u + 15u) & ~15u) : 0u;
         u8* const wbase = smem + rows_bytes + (size_t)slot * h3.x + w1.w;
         f16* const x_lds = (f16*)wbase;
         u8* const sc_lds = wbase + w2.y;
         u8* const zp_lds = wbase + w2.z;
-        P.wbase = wbase; P.off_sc = w2.y; P.off_zp = w2.z; P.x_stride = x_stride; P.xc0 = ROWS ? 0 : xc0; P.M = M;
+        P.wbase = wbase; P.off_sc = w2.y; P.off_zp = w2.z; P.x_stride = x_stride; P.xc0 = (ROWS || XMEM) ? 0 : xc0; P.M = M;
         // requests: scale rows, activation slice.  The common case -- one row, <= 64 units (16 bytes) of each -- is straight-line
         // code, one LDS-DMA instruction per table (the compiler's loop skeletons around run-time trip counts cost more
         // instructions per wave than the decode of an item)
@@ -414,7 +437,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         const int sc_units = 2 * ng;                                      // 16-byte units of the scale rows (a row = 16 halfs)
         const f16* const st = sc_tab + ((size_t)t_ * G + gw0) * 16;
         LEAN_MARK(decltype(tag)::value + 1);
-        if (!ROWS && M == 1 && xunits <= (S == 4 ? 128 : 64) && sc_units <= 64)
+        if (!ROWS && !XMEM && M == 1 && xunits <= (S == 4 ? 128 : 64) && sc_units <= 64)
         {
             // the headline case -- one row, one copy instruction per table (two for the 4-wave geometry's 128-unit slices) -- with
             // nothing but those in front of the requests of the wave's last items (1.5 % of the whole decode step against the
@@ -446,7 +469,8 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                 if (lane < sc_units) LEAN_DMA(zt, lane * 16, zp_lds);
                 if (sc_units > 64) { if (64 + lane < sc_units) LEAN_DMA(zt, (64 + lane) * 16, zp_lds + 1024); }
             }
-            if constexpr (!ROWS)
+            if constexpr (XMEM) { }                                     // (the activations are read from memory, item by item)
+            else if constexpr (!ROWS)
             {
                 #pragma unroll
                 for (int rr = 0; rr < 4; rr++)
@@ -501,7 +525,8 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         R.gshift = (int)((meta >> 16) & 0x7u); R.gphase = (int)((meta >> 19) & 0x3FFu);
         R.chunk0 = (int)(w2x & 0xFFFFu); R.g0 = (int)(w2x >> 16);
         R.red = (float*)(smem + h3.y);
-        R.cx.x_lds = ROWS ? (const f16*)smem : (const f16*)P.wbase;
+        if constexpr (XMEM) { const u32x4 h0 = hb[0]; R.cx.x_lds = (const f16*)ptr_of(h0.x, h0.y); }
+        else R.cx.x_lds = ROWS ? (const f16*)smem : (const f16*)P.wbase;
         R.cx.sc_lds = (const f16*)(P.wbase + P.off_sc); R.cx.zp_lds = (const f16*)(P.wbase + P.off_zp);
         R.cx.x_stride = P.x_stride; R.cx.xc0 = P.xc0; R.cx.M = P.M;
     };
@@ -522,6 +547,14 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         constexpr size_t STEP = 64 * BITS;
         LaneWords<BITS> a[DA > 0 ? DA : 1], b[NB > 0 ? NB : 1], bt;
         const int nA = n - NB;
+        u32 xvoff = 0;                                                 // XMEM: the lane's byte offset into the activations (row, 8 j)
+        if constexpr (XMEM)
+        {
+            const u32x4 h1 = hb[1], h2 = hb[2];
+            const int M_ = (int)h1.w, lda_ = (int)h2.y, c = lane & 15, j = lane >> 4;
+            xvoff = ((u32)(c < M_ ? c : M_ - 1) * (u32)lda_ + 8u * (u32)j) * 2u;
+            pin_vector(xvoff);
+        }
         #pragma unroll
         for (int q = 0; q < DA; q++) if (q < nA) load_lane_words<BITS>(wptr + (size_t)q * STEP, lane, a[q]);
         if (tail_nv) load_lane_words<BITS>(tptr, lane, bt);
@@ -541,6 +574,27 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         }
         LTRACE(3);
         rest_ctx(R, P);
+        // XMEM: a ring of XL items' A operands, the first XL requested here -- behind the weights, in front of the wait for them.
+        // EVERY request is unconditional (an item the wave does not have requests one 16-byte line, the same for all lanes):
+        // the compiler's count of the requests in flight stays exact, so item q waits for ITS operands only while those of
+        // items q + 1 .. q + XL - 1 are on their way
+        constexpr int XL = !XMEM ? 1 : (LEAN_XMEM_AHEAD < D ? LEAN_XMEM_AHEAD : D);
+        f16x8 xa[XL][4];
+        // (address = a UNIFORM base -- the activations + the item's columns, scalar arithmetic -- + the lane's byte offset `xvoff`,
+        // made in front of the weight requests: no vector instruction per request, nothing that could wait for a register)
+        auto xrequest = [&](f16x8 (&v)[4], int q) {
+            const u8* const xb = (const u8*)R.cx.x_lds + (q < n ? (size_t)(R.chunk0 + 4 * q) * 64 : 0);
+            #pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = *(const f16x8*)(xb + xvoff + (q < n ? e * 64 : 0));
+        };
+        if constexpr (XMEM)
+        {
+            LEAN_MARK(1000 * BITS + 10 * NB + 3);
+            #pragma unroll
+            for (int q = 0; q < XL; q++) xrequest(xa[q], q);
+            sched_fence();
+            LEAN_MARK(1000 * BITS + 10 * NB + 4);
+        }
         fence_load_use(fence);               // the first part, the activation slice and the scale rows have landed
         if constexpr (ROWS) { wait_vmcnt_le<0>(); block_sync_lds(); }      // every wave's share of the rows has landed
         wave_converge();
@@ -562,6 +616,23 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
             acc[0] = __builtin_bit_cast(float, xr & 0x3fffffffu) + (float)R.cx.x_lds[lane] + (float)R.cx.sc_lds[lane & 15];
         }
         else if (LEAN_KILL & 1) { }
+        else if constexpr (XMEM)
+        {
+            // a ring of LEAN_XMEM_AHEAD items' A operands.  EVERY request is unconditional (an item the wave does not have
+            // requests one 16-byte line, the same for all lanes): the compiler's count of the requests in flight stays exact, so
+            // item q waits for ITS operands only while those of items q + 1 .. q + AHEAD - 1 are on their way
+            #pragma unroll
+            for (int q = 0; q < D; q++)
+            {
+                if (q < n)
+                {
+                    if (R.uni) lean_item_uniform<BITS, GPTQ, true>(a[q], R.cx, R.chunk0 + 4 * q, R.g0 + ((4 * q + R.gphase) >> R.gshift), lane, acc, xa[q % XL]);
+                    else lean_item_general<BITS, GPTQ, true>(a[q], R.cx, R.chunk0 + 4 * q, 4 * q, R.g0, R.gshift, R.gphase, 4, lane, acc, xa[q % XL]);
+                }
+                sched_fence();
+                if (q + XL < D) { xrequest(xa[q % XL], q + XL); sched_fence(); }
+            }
+        }
         else
         {
             #pragma unroll
@@ -594,7 +665,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     auto head_bits = [&](auto bits_tag) {
         constexpr int BITS = decltype(bits_tag)::value;
         constexpr int NB = LeanTail<BITS, S>::v;
-        if constexpr (NB > 0 && !ROWS)
+        if constexpr (NB > 0 && !ROWS && !XMEM)
         {
             if (n >= NB && n <= LeanDepth<BITS, S>::v && pipe_on) { head(bits_tag, std::integral_constant<int, NB>()); return; }
         }
@@ -654,25 +725,39 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     f16* const xp_out = args.hdr.xp_out;
     struct EpIn { f16* cp; f16 c_old; int xp_idx; f16 xw_next; float ssq; };
     // what a row's epilogue needs from memory
+    // (two round trips to memory, not one per dependent load: first everything whose address is known -- the two permutation
+    // entries and the row's partial sums of squares, <= 256 of them in four independent loads per lane -- then what those address:
+    // the next consumer's norm weight and the residual.  The finalising wave runs this between its last item and the workgroup's
+    // barrier: one load + wait per loop trip was 4-7 round trips of ~0.5 us at the end of every launch)
     auto ep_inputs = [&](int row, EpIn& e) {
         e.cp = nullptr; e.c_old = (f16)0.0f; e.xp_idx = ep_n; e.xw_next = (f16)1.0f; e.ssq = 0.0f;
+        const u16* const c_invperm = ep_on ? args.mat[ep_mj].c_invperm : nullptr;
+        const u16* const xp_invperm = (ep_on && xp_out) ? args.hdr.xp_invperm : nullptr;
+        int c_idx = ep_n;
+        if (c_invperm) c_idx = (int)c_invperm[ep_n];
+        if (xp_invperm) e.xp_idx = (int)xp_invperm[ep_n];
+        // A_NORM_PRE: the activations were x * w (qgemv_flat.h); 1 / rms(x) multiplies the finished sum.  The partial sums of
+        // squares of this row (fixed order: a lane adds its entries lane, lane + 64, ... in that order)
+        float sv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* const sp = args.hdr.ss + (size_t)row * args.hdr.npart;
+        const int npart = args.hdr.npart;
+        if (flags & LF_NORM)
+        {
+            #pragma unroll
+            for (int k = 0; k < 4; k++) if (lane + 64 * k < npart) sv[k] = DEP ? load_agent_f32(sp + lane + 64 * k) : sp[lane + 64 * k];
+        }
         if (ep_on)
         {
-            const u16* const c_invperm = args.mat[ep_mj].c_invperm;
-            const u16* const xp_invperm = args.hdr.xp_invperm;
-            const int c_idx = c_invperm ? (int)c_invperm[ep_n] : ep_n;
-            if (xp_out && xp_invperm) e.xp_idx = (int)xp_invperm[ep_n];
             if (xp_out && args.hdr.xp_w) e.xw_next = args.hdr.xp_w[e.xp_idx];
             e.cp = args.mat[ep_mj].c + (size_t)row * args.hdr.ldc[ep_mj] + c_idx;
             if (flags & LF_ACCUM) e.c_old = DEP ? load_agent_f16(e.cp) : *e.cp;
         }
-        // A_NORM_PRE: the activations were x * w (qgemv_flat.h); 1 / rms(x) multiplies the finished sum.  The partial sums of
-        // squares of this row (fixed order)
         if (flags & LF_NORM)
         {
-            const float* sp = args.hdr.ss + (size_t)row * args.hdr.npart;
+            #pragma unroll
+            for (int k = 0; k < 4; k++) e.ssq += sv[k];
             #pragma nounroll
-            for (int i = lane; i < args.hdr.npart; i += 64) e.ssq += DEP ? load_agent_f32(sp + i) : sp[i];
+            for (int i = lane + 256; i < npart; i += 64) e.ssq += DEP ? load_agent_f32(sp + i) : sp[i];
         }
     };
     // combine (fixed order) + epilogue of one row
@@ -734,7 +819,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         if (sync_signal)
             sync_arrive_publish_sharded(sync_signal, lin_wg_of(), ROWS ? ((u32)M < FIN_WAVES ? (u32)M : FIN_WAVES) : (u32)M, args.hdr.sync_wgs, args.hdr.sync_wait);
     };
-    if constexpr (!ROWS)
+    if constexpr (!ROWS && !XMEM)
     {
         if (wv >= M) { LTRACE(5); block_sync_lds(); return; }
         // what the epilogue needs from memory is requested before the barrier
@@ -787,7 +872,7 @@ struct LeanRun { int F, bits, chunk0; u32 off, tstride; int tail_nv; u32 t_off, 
 // decoder per wave, everything in registers); the waves are dealt out to the runs in proportion to their bytes.  Fills
 // wave[0 .. S) and returns the LDS bytes of the S waves together, 0 when the matrix is not covered with S waves (more runs
 // than waves, more items than a wave's registers hold, a chunk -> group map that is not affine inside a part, ...).
-static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave* wave, bool rows_mode = false)
+static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave* wave, bool rows_mode = false, bool xmem = false)
 {
     const QMatDev& d = qm->dev;
     if (d.n_runs <= 0 || !qm->cg_host || !d.sc_tab || (qm->is_gptq && !d.zp_tab)) return 0;
@@ -874,7 +959,9 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
             }
             if (shift < 0 || c0 > 0xFFFF || c_end - c0 > 0xFFFF || g_lo > 0xFFFF || g_hi - g_lo + 1 > 0xFFFF) return 0;
             // what the kernel's straight-line staging copies (stage_copies); ROWS: the rows are staged by the workgroup, any length
-            if ((g_hi - g_lo + 1) > 64 || (!rows_mode && ((c_end - c0) * 4 > 256 || M > 4))) return 0;
+            // (XMEM: no staged activations -- any M <= 16, any slice; one pass only: the ring of A operands covers LeanDepth items)
+            if ((g_hi - g_lo + 1) > 64 || (!rows_mode && !xmem && ((c_end - c0) * 4 > 256 || M > 4))) return 0;
+            if (xmem && n > lean_depth(r.bits, S)) return 0;
             const bool uni = shift >= 2 && (phase & 3) == 0;                   // the four chunks of every full item share a group
             lw.w_off = r.off + (u32)i0 * 64u * (u32)r.bits; lw.w_tstride = r.tstride;
             lw.t_off = r.t_off; lw.t_tstride = r.t_tstride;
@@ -886,7 +973,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
             const u32 x_stride = (u32)(c_end - c0) * 32u + 8u;
             (void)norm;
             lw.x_stride = x_stride;
-            lw.off_sc = rows_mode ? 0u : al16((u32)M * x_stride * 2u);
+            lw.off_sc = (rows_mode || xmem) ? 0u : al16((u32)M * x_stride * 2u);
             lw.off_zp = lw.off_sc + al16((u32)(g_hi - g_lo + 1) * 32u);
             lds_total += lw.off_sc + al16((u32)(g_hi - g_lo + 1) * 32u) * (qm->is_gptq ? 2u : 1u);
             i0 += n;
@@ -898,6 +985,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
 
 #define LEAN_FOR_EACH_GEOMETRY(X, OCC) X(8, 1, false, OCC) X(16, 1, false, OCC) X(8, 2, false, OCC) X(8, 2, true, OCC) X(4, 2, true, OCC)
 #define LEAN_FOR_EACH_ROWS_GEOMETRY(X) X(8, 1, false, false) X(16, 1, false, false) X(8, 2, false, true) X(8, 2, true, true)
+#define LEAN_FOR_EACH_XMEM_GEOMETRY(X) X(8, 1, false) X(16, 1, false) X(8, 2, false) X(8, 2, true)
 // register budget: 6 waves per SIMD (80 registers: no spills on the common paths, three 8-wave workgroups per CU).  4 and 8
 // were built side by side during the round and measured (4 slower; 8 equal within noise once gate|up used 8-wave workgroups,
 // with spills): tools/build_variant.sh -DLEAN_OCC_DEFAULT=... rebuilds them
@@ -923,6 +1011,11 @@ static void lean_attrs()
     (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, S, NS, P, 4, true, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, 4, true, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LEAN_FOR_EACH_ROWS_GEOMETRY(LEAN_ATTR)
+#undef LEAN_ATTR
+#define LEAN_ATTR(S, NS, P) \
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, S, NS, P, 4, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, 4, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    LEAN_FOR_EACH_XMEM_GEOMETRY(LEAN_ATTR)
 #undef LEAN_ATTR
 }
 
@@ -967,48 +1060,73 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     // candidates, in order: a one-row pair tries 4 waves per tile first (8-wave workgroups: three per CU at 6 waves per SIMD, so
     // the 688 workgroups of a 7B gate|up launch are resident at once; with 16-wave workgroups a quarter of them starts when
     // the first ones have finished: profiles/r03_trace_lean_v6.txt, workgroup entry p90 9.5 us)
-    int cand[3], n_cand = 0;
+    int cand[3] = {0, 0, 0}, n_cand = 0;
     static const int pair4 = []() { const char* e = getenv("EXL2_LEAN_PAIR4"); return e ? atoi(e) : 1; }();
     if (in.pair && in.M == 1 && pair4) cand[n_cand++] = 4;
     cand[n_cand++] = S;
     if (!in.pair && nslots == 1 && S == 8) cand[n_cand++] = 16;        // finer split of the tile
     // ROWS geometries, in order: two tiles x 8 waves sharing the staged rows (16 waves per CU), one tile x 8, one tile x 16; pair (8 + 8)
+    // XMEM geometries (the rows do not fit / EXL2_LEAN_XMEM=2): one tile x 8, one tile x 16; pair (8 + 8)
     int cand_slots[3] = {nslots, nslots, nslots};
-    if (rows_mode)
-    {
-        n_cand = 0;
-        if (in.pair) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
-        else
-        {
-            // (up to 8 rows the staged rows leave room for two 8-wave workgroups per CU: one tile per workgroup, the whole grid
-            // resident; from 9 rows up one workgroup per CU anyway: two tiles per unit, the workgroup walks -- profiles/r04_rows_sweep*.txt)
-            if (in.M >= 9 && !(in.ss_out && (max_tiles + 1) / 2 > LEAN_MAX_PART) && max_tiles >= 2) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
-            cand[n_cand] = 8; cand_slots[n_cand++] = 1;
-            cand[n_cand] = 16; cand_slots[n_cand++] = 1;               // (K = 11008: a tile's share does not fit 8 waves' registers)
-        }
-    }
-    // ROWS: the workgroup's shared copy of the M rows, in front of the waves' own (scale-row) areas
-    const u32 rows_bytes = rows_mode ? al16((u32)in.M * (u32)(K + 8) * 2u) : 0u;
-    u32 slot_bytes = 0;
+    const int xmem_on = []() { const char* e = getenv("EXL2_LEAN_XMEM"); return e ? atoi(e) : 1; }();     // (read per launch build: tests switch it)
+    bool xmem = false;
+    u32 rows_bytes = 0, slot_bytes = 0;
     bool planned = false;
-    // (second round: a split that fits only with the whole LDS of a CU -- 2-4 rows of a K = 11008 matrix -- is still better
-    // than leaving the chain: the decoder would fall back to the module-by-module route for EVERY launch)
-    for (int ci = 0; ci < 2 * n_cand && !planned; ci++)
-    {
-        S = cand[ci % n_cand];
-        if (rows_mode) nslots = cand_slots[ci % n_cand];
-        const u32 budget = rows_mode ? 158u * 1024u : (ci < n_cand ? LEAN_LDS_BUDGET * (u32)((S * nslots + 7) / 8) : 150u * 1024u);
-        if (in.n_mats * S > LEAN_RECORDS) continue;
-        bool ok = true;
-        slot_bytes = 0;
-        for (int j = 0; j < in.n_mats && ok; j++)
+    const int nslots0 = nslots;
+    const int plain_cand[3] = {cand[0], cand[1], cand[2]};
+    const int plain_n = n_cand;
+    auto plan = [&](int form) {                                      // 0: <= 4 rows; 1: ROWS; 2: XMEM
+        n_cand = plain_n;
+        for (int i = 0; i < 3; i++) { cand[i] = plain_cand[i]; cand_slots[i] = nslots0; }
+        if (form == 1)
         {
-            const u32 b = lean_plan_matrix(in.qm[j], S, in.M, in.a_mode == A_NORM_PRE, a.wave + j * S, rows_mode);
-            if (!b) ok = false;
-            if (b > slot_bytes) slot_bytes = b;
+            n_cand = 0;
+            if (in.pair) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
+            else
+            {
+                // (up to 8 rows the staged rows leave room for two 8-wave workgroups per CU: one tile per workgroup, the whole grid
+                // resident; from 9 rows up one workgroup per CU anyway: two tiles per unit, the workgroup walks -- profiles/r04_rows_sweep*.txt)
+                if (in.M >= 9 && !(in.ss_out && (max_tiles + 1) / 2 > LEAN_MAX_PART) && max_tiles >= 2) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
+                cand[n_cand] = 8; cand_slots[n_cand++] = 1;
+                cand[n_cand] = 16; cand_slots[n_cand++] = 1;               // (K = 11008: a tile's share does not fit 8 waves' registers)
+            }
         }
-        planned = ok && rows_bytes + (u32)nslots * slot_bytes + (u32)(S * nslots) * (u32)in.M * 64u <= budget;
-    }
+        else if (form == 2)
+        {
+            n_cand = 0;
+            if (in.pair) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
+            else if (in.ss_out && max_tiles > LEAN_MAX_PART) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
+            else
+            {
+                cand[n_cand] = 8; cand_slots[n_cand++] = 1;
+                cand[n_cand] = 16; cand_slots[n_cand++] = 1;
+            }
+        }
+        // ROWS: the workgroup's shared copy of the M rows, in front of the waves' own (scale-row) areas
+        rows_bytes = form == 1 ? al16((u32)in.M * (u32)(K + 8) * 2u) : 0u;
+        // (second round: a split that fits only with the whole LDS of a CU -- 2-4 rows of a K = 11008 matrix -- is still better
+        // than leaving the chain: the decoder would fall back to the module-by-module route for EVERY launch)
+        for (int ci = 0; ci < 2 * n_cand && !planned; ci++)
+        {
+            S = cand[ci % n_cand];
+            if (form) nslots = cand_slots[ci % n_cand];
+            const u32 budget = form == 1 ? 158u * 1024u : (ci < n_cand ? LEAN_LDS_BUDGET * (u32)((S * nslots + 7) / 8) : 150u * 1024u);
+            if (in.n_mats * S > LEAN_RECORDS) continue;
+            bool ok = true;
+            slot_bytes = 0;
+            for (int j = 0; j < in.n_mats && ok; j++)
+            {
+                const u32 b = lean_plan_matrix(in.qm[j], S, in.M, in.a_mode == A_NORM_PRE, a.wave + j * S, form == 1, form == 2);
+                if (!b) ok = false;
+                if (b > slot_bytes) slot_bytes = b;
+            }
+            planned = ok && rows_bytes + (u32)nslots * slot_bytes + (u32)(S * nslots) * (u32)in.M * 64u <= budget;
+        }
+        xmem = planned && form == 2;
+    };
+    if (!rows_mode) plan(0);
+    else if (xmem_on >= 2) { plan(2); if (!planned) plan(1); }
+    else { plan(1); if (!planned && xmem_on >= 1) plan(2); }
     if (!planned) return 1;
     const int wgs = in.pair ? max_tiles : (max_tiles + nslots - 1) / nslots;
     if (in.ss_out && wgs > LEAN_MAX_PART) return 1;
@@ -1054,7 +1172,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     // ROWS: one workgroup per CU fits (the staged rows fill the LDS), so the grid is sized to the CUs and a workgroup walks its
     // units with one staged copy; inside an overlapped chain every workgroup takes one unit (its arrival counts are per unit)
     int grid_x = wgs;
-    if (rows_mode && !dep && nslots == 2)                            // (the WALK instantiations: the two-tile geometries)
+    if (rows_mode && !xmem && !dep && nslots == 2)                   // (the WALK instantiations: the two-tile geometries)
     {
         static int cus[EXL2_MAX_DEVICES] = {0};
         const int dev = exl2_current_device();
@@ -1069,9 +1187,14 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     const bool gptq = q0->is_gptq;
     const int occ = LEAN_OCC_DEFAULT;
 #define LEAN_GO(SS, NS, P, W) \
-    if (rows_mode && !gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, 4, true, W>), grid, block, lds, stream, a); \
-    if (rows_mode && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, 4, true, W>), grid, block, lds, stream, a);
+    if (rows_mode && !xmem && !gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, 4, true, W>), grid, block, lds, stream, a); \
+    if (rows_mode && !xmem && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, 4, true, W>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_ROWS_GEOMETRY(LEAN_GO)
+#undef LEAN_GO
+#define LEAN_GO(SS, NS, P) \
+    if (xmem && !gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, 4, false, false, false, true>), grid, block, lds, stream, a); \
+    if (xmem && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, 4, false, false, false, true>), grid, block, lds, stream, a);
+    LEAN_FOR_EACH_XMEM_GEOMETRY(LEAN_GO)
 #undef LEAN_GO
 #define LEAN_GO(SS, NS, P, OCC) \
     if (!rows_mode && !dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a); \

@@ -269,7 +269,10 @@ class GreedyGraphDecoder:
         # one, each waits for its predecessor through words in memory.  5 launches per layer + the head (+ the gate's block).
         if os.environ.get("EXL2_CHAIN_OVERLAP", "0") != "0":
             self.chain["flags"] = torch.zeros((5 * len(plan) + 4, ext.SYNC_BLOCK_WORDS), dtype=torch.int32, device=dev)
-            self.chain["stream_b"] = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+            # (another PRIORITY class: torch hands out streams from a pool and two of them may share a hardware queue -- the launches
+            # of the two graphs would then run one after the other and every wait of the first would spin until it gives up;
+            # queues of different priorities are never shared)
+            self.chain["stream_b"] = torch.cuda.Stream(device=dev, priority=-1) if dev.type == "cuda" else None
             if dev.type == "cuda":
                 self.chain["ev_pre"], self.chain["ev_b"] = torch.cuda.Event(), torch.cuda.Event()
             self.graph_b = None
@@ -296,7 +299,10 @@ class GreedyGraphDecoder:
                     return [(0, b)]
                 lds = int(os.environ.get("EXL2_CHAIN_ROWS_LDS", 132 * 1024))     # rows next to ~26 KB of scale rows and partial sums
                 fit = lds // ((K + 8) * 2)
-                g = b if fit >= b else (fit if fit >= 5 else 4)
+                # (rows that do not fit: the lean kernel's XMEM form reads the A operands from memory -- one launch for all rows;
+                # EXL2_LEAN_XMEM=0: its row groups of round 4's first form)
+                xmem = int(os.environ.get("EXL2_LEAN_XMEM", "1")) >= 1
+                g = b if (fit >= b or xmem) else (fit if fit >= 5 else 4)
                 g = -(-b // -(-b // g))                             # equal groups: 16 rows at 6 per launch -> 6 + 5 + 5
             return [(r, min(r + g, b)) for r in range(0, b, g)]
 

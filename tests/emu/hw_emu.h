@@ -134,6 +134,7 @@ DEV float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
 DEV float fast_rcp(float x) { return 1.0f / x; }
 
 template <typename T> DEV void pin_scalar(T&) { }
+template <typename T> DEV void pin_vector(T&) { }
 
 // ---- cross-lane ------------------------------------------------------------------------------------------------------
 template <typename T> DEV T emu_wave_read(T mine, int src_lane)
