@@ -88,6 +88,7 @@ PROTOTYPES = {
     "exl2_q_mlp_forward_chain_part": (ci, [vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, C.POINTER(ci), vp]),
     "exl2_gemm_half_q_half_chain": (ci, [vp, vp, ci, cf, vp, vp, ci, vp]),
     "exl2_embed_rows_chain": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp]),
+    "exl2_chain_set_tiled": (ci, [ci]),
     "exl2_gather_f16": (ci, [vp, vp, vp, ci, vp]),
     "exl2_chain_overlap_begin": (ci, [vp, ci, vp, vp]),
     "exl2_chain_overlap_end": (ci, [C.POINTER(ci)]),

@@ -23,6 +23,9 @@ struct ChainLaunch { const u32* wait; u32* signal; u32* arrive; void* stream; };
 
 // true while a chain is open on this thread
 bool chain_sync_active();
+// 5 .. 16 rows (round 4): the chain's (xp, ss) hand-off buffers in the MFMA-tiled layout (qgemv_flat.h: FlatIn.a_tiled) between
+// exl2_chain_set_tiled(1) and (0): every producer of the residual stream writes xp so, every consumer reads it so
+bool chain_xp_tiled();
 // stream / counters of the next launch; returns < 0 (error set) when the chain has run out of counters
 int chain_sync_next(ChainLaunch* out);
 // the launch took place; `arrivals` = its workgroups: the gate of the next launch (other stream) is launched with this target.

@@ -6,6 +6,7 @@
 // row fits in registers.
 #include "hw.h"
 #include "errors.h"
+#include "chain_sync.h"
 
 // ---- RMSNorm --------------------------------------------------------------------------------------------------------
 
@@ -268,7 +269,7 @@ KERNEL void __launch_bounds__(256) embed_rows_kernel(const f16* table, const int
 // embedding row -> x, x times the first consumer's norm weight in that consumer's packed order, and the row's sum of squares
 // (npart = 1): what the chained decode (qgemv_flat.h: A_NORM_PRE) expects from the producer of a residual stream
 KERNEL void __launch_bounds__(256) embed_rows_chain_kernel(const f16* table, const int* ids, f16* out, int hidden, int vocab,
-                                                           const u16* invperm, const f16* next_w, f16* xp, float* ss)
+                                                           const u16* invperm, const f16* next_w, f16* xp, float* ss, int tiled)
 {
     SHARED float part[4];
     const int row = bid_x();
@@ -299,7 +300,9 @@ KERNEL void __launch_bounds__(256) embed_rows_chain_kernel(const f16* table, con
         {
             const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f));
             sq = fmaf(f, f, sq);
-            xr[idx[e]] = next_w ? (f16)fmaxf(-65504.0f, fminf(f * (float)next_w[idx[e]], 65504.0f)) : v[e];
+            // (tiled: the layout the lean kernel's XMEM form reads -- qgemv_flat.h: FlatIn.a_tiled)
+            f16* const dstp = tiled ? xp + ((size_t)(idx[e] >> 3) * 16 + row) * 8 + (idx[e] & 7) : xr + idx[e];
+            *dstp = next_w ? (f16)fmaxf(-65504.0f, fminf(f * (float)next_w[idx[e]], 65504.0f)) : v[e];
         }
     }
     sq = wave_allreduce_add(sq);
@@ -389,7 +392,7 @@ int exl2_embed_rows_chain(const void* table, const int* ids, void* x, int rows, 
     EXL2_REQUIRE(!next_invperm || (((size_t)next_invperm) & 15) == 0, "embed_rows_chain: invperm must be 16-byte aligned");
     if (rows <= 0) return EXL2_OK;
     LAUNCH(embed_rows_chain_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const f16*)table, ids, (f16*)x, hidden, vocab,
-           (const u16*)next_invperm, (const f16*)next_norm_w, (f16*)xp_out, ss_out);
+           (const u16*)next_invperm, (const f16*)next_norm_w, (f16*)xp_out, ss_out, chain_xp_tiled() ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return EXL2_OK;
 }

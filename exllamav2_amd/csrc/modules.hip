@@ -159,6 +159,8 @@ struct ChainSyncState { u32* flags; int n_blocks; void* stream[2]; int next; boo
 static thread_local ChainSyncState g_chain = {nullptr, 0, {nullptr, nullptr}, 0, false};
 
 bool chain_sync_active() { return g_chain.open; }
+static int g_chain_tiled = 0;
+bool chain_xp_tiled() { return g_chain_tiled != 0; }
 
 static u32* chain_block(int k) { return g_chain.flags + (size_t)k * SYNC_BLOCK_WORDS; }
 
@@ -629,6 +631,7 @@ int exl2_q_attn_forward_1_chain(void* handle, const void* xp, const float* ss, i
     for (int i = 0; i < 3; i++) { in.qm[i] = ms[i]; in.c[i] = (f16*)cs[i]; in.ldc[i] = ms[i]->width; }
     in.n_mats = 3; in.M = rows; in.a_mode = A_NORM_PRE; in.a = (const f16*)xp; in.lda = a->hidden_size;
     in.ss = ss; in.npart = npart; in.eps = a->norm_epsilon; in.c_mode = C_STORE;
+    in.a_tiled = chain_xp_tiled() ? 1 : 0;
     FLAT_TRY(in, stream, nullptr, "q_attn_forward_1_chain");
     return EXL2_OK;
 }
@@ -647,6 +650,7 @@ int exl2_q_attn_forward_2_chain(void* handle, void* x, const void* attn_out_pack
     in.c_mode = C_ACCUM;
     in.xp_out = (f16*)xp_out; in.xp_invperm = (const u16*)next_invperm; in.xp_w = (const f16*)next_norm_w;
     in.ss_out = xp_out ? ss_out : nullptr; in.ldxp = a->hidden_size;
+    in.xp_tiled = (xp_out && chain_xp_tiled()) ? 1 : 0;
     int wgs = 0;
     FLAT_TRY(in, stream, &wgs, "q_attn_forward_2_chain");
     if (npart_out) *npart_out = wgs;
@@ -665,6 +669,13 @@ static int q_mlp_chain_part(void* handle, int part, void* x, const void* xp, con
     EXL2_REQUIRE(row0 >= 0 && row0 + rows <= m->max_rows && rows <= MAX_GEMV_ROWS, "q_mlp_forward_chain: rows %d + %d", row0, rows);
     const int hidden = m->up->height, inter = m->up->width;
     f16* const act = m->temp_a + (size_t)row0 * inter;              // SiLU(gate) * up of rows [row0, row0 + rows), down's packed order
+    // 5 .. 16 rows, both halves in this call: SiLU(gate) * up goes to down_proj in the layout the matrix cores read (qgemv_flat.h:
+    // FlatIn.a_tiled) -- down reads its A operands straight from memory then (the lean kernel's XMEM form), no staged copy, whatever K.
+    // EXL2_MLP_TILED: 0 never, 1 (default) where the rows' staged copy would not fit the LDS, 2 from 5 rows up
+    const int tiled_on = []() { const char* e = getenv("EXL2_MLP_TILED"); return e ? atoi(e) : 1; }();     // (per call: tests switch it)
+    const int xmem_env = []() { const char* e = getenv("EXL2_LEAN_XMEM"); return e ? atoi(e) : 1; }();
+    const bool tiled = part == 3 && rows > 4 && m->max_rows >= 16 && row0 == 0 && tiled_on > 0 && xmem_env > 0 && lean_enabled() && !chain_sync_active()
+                       && (tiled_on >= 2 || (size_t)rows * (size_t)(inter + 8) * 2 > 150u * 1024u);
     if (part & 1)
     {
         EXL2_REQUIRE(xp && ss, "q_mlp_forward_chain: null argument");
@@ -675,6 +686,8 @@ static int q_mlp_chain_part(void* handle, int part, void* x, const void* xp, con
         in.n_mats = 2; in.pair = 1; in.M = rows; in.a_mode = A_NORM_PRE; in.a = (const f16*)xp; in.lda = hidden;
         in.ss = ss; in.npart = npart; in.eps = m->norm_epsilon; in.c_mode = C_STORE;
         in.act_gelu = m->act_gelu ? 1 : 0;
+        in.c_tiled = tiled ? 1 : 0;
+        in.a_tiled = chain_xp_tiled() ? 1 : 0;
         FLAT_TRY(in, stream, nullptr, "q_mlp_forward_chain");
     }
     if (part & 2)
@@ -682,8 +695,10 @@ static int q_mlp_chain_part(void* handle, int part, void* x, const void* xp, con
         FlatIn in; memset(&in, 0, sizeof(in));
         in.qm[0] = m->down; in.c[0] = (f16*)x; in.ldc[0] = hidden;
         in.n_mats = 1; in.M = rows; in.a_mode = A_DIRECT; in.a = act; in.lda = inter; in.c_mode = C_ACCUM;
+        in.a_tiled = tiled ? 1 : 0;
         in.xp_out = (f16*)xp_out; in.xp_invperm = (const u16*)next_invperm; in.xp_w = (const f16*)next_norm_w;
         in.ss_out = xp_out ? ss_out : nullptr; in.ldxp = hidden;
+        in.xp_tiled = (xp_out && chain_xp_tiled()) ? 1 : 0;
         int wgs = 0;
         FLAT_TRY(in, stream, &wgs, "q_mlp_forward_chain");
         if (npart_out) *npart_out = wgs;
@@ -706,6 +721,14 @@ int exl2_q_mlp_forward_chain_part(void* handle, int part, int row0, void* x, con
     return q_mlp_chain_part(handle, part, x, xp, ss, npart, rows, row0, next_invperm, next_norm_w, xp_out, ss_out, npart_out, stream);
 }
 
+// reference: none (the reference has no chained decode); exllamav2_amd/model.py: GreedyGraphDecoder.step_chain brackets a step of
+// 5 .. 16 rows with (1) / (0)
+int exl2_chain_set_tiled(int on)
+{
+    g_chain_tiled = on ? 1 : 0;
+    return EXL2_OK;
+}
+
 int exl2_gemm_half_q_half_chain(const void* xp, const float* ss, int npart, float eps,
                                 void* q_matrix, void* c, int rows, void* stream)
 {
@@ -717,6 +740,7 @@ int exl2_gemm_half_q_half_chain(const void* xp, const float* ss, int npart, floa
     in.qm[0] = q; in.c[0] = (f16*)c; in.ldc[0] = q->width;
     in.n_mats = 1; in.M = rows; in.a_mode = A_NORM_PRE; in.a = (const f16*)xp; in.lda = q->height;
     in.ss = ss; in.npart = npart; in.eps = eps; in.c_mode = C_STORE;
+    in.a_tiled = chain_xp_tiled() ? 1 : 0;
     FLAT_TRY(in, stream, nullptr, "gemm_half_q_half_chain");
     return EXL2_OK;
 }

@@ -27,6 +27,12 @@ struct FlatIn
     // every combining wave arrives there, the last publishes "go").  Both nullable.
     const u32* sync_wait; u32* sync_signal;
     u32* sync_arrive;             // first launch of a chain: every workgroup adds 1 on entry (chain_sync.h: the gate)
+    // 5 .. 16 rows between two launches of one module (gate | up -> down, round 4): the activations in the layout the matrix
+    // cores read them in -- [K / 8][16 rows][8 halfs], element (row, k) at ((k >> 3) * 16 + row) * 8 + (k & 7): the 16 x 32
+    // A operand of one MFMA is 1 KB of consecutive memory, one fully coalesced request per wave (row-major: 16 separate
+    // 64-byte pieces).  c_tiled: this launch WRITES its (one) output so; a_tiled: it READS `a` so (lean kernel, XMEM form only).
+    int a_tiled, c_tiled;
+    int xp_tiled;                 // chain-out: xp_out is written in that layout too (16 row slots; ldxp unused)
 };
 
 // 0: launched; 1: shape not covered; < 0: error.  *wgs_out = grid size = partial sums a chain-out launch writes per row

@@ -913,7 +913,7 @@ static bool flat_any_big(const FpMatCold* cold, int n)
 // (= the number of partial sums a chain-out launch publishes per row).
 int qgemv_flat_launch(const FlatIn& in, void* stream, int* wgs_out)
 {
-    if (!flat_in_ok(in)) return 1;
+    if (!flat_in_ok(in) || in.a_tiled || in.c_tiled || in.xp_tiled) return 1;      // (the tiled layouts are the lean kernel's)
     FlatArgs args;
     memset(&args, 0, sizeof(args));
     FlatPlanAcc acc; memset(&acc, 0, sizeof(acc));

@@ -123,6 +123,9 @@ struct LeanArgs
 #define LF_ACCUM 16u
 #define LF_BIAS 32u
 #define LF_DEP 64u
+#define LF_ATILED 128u                // the activations are in the MFMA-tiled layout (qgemv_flat.h: FlatIn.a_tiled)
+#define LF_CTILED 256u                // the output is written in that layout (FlatIn.c_tiled)
+#define LF_XPTILED 512u               // chain-out: xp_out in that layout (FlatIn.xp_tiled)
 
 // items of one bit width a wave may hold in registers (<= 25 dwords per lane in flight)
 // (S = 4: the 8-wave gate|up workgroup, built for 6 waves per SIMD = 80 registers -- a wave there holds 8 items of <= 4 bits)
@@ -552,7 +555,8 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         {
             const u32x4 h1 = hb[1], h2 = hb[2];
             const int M_ = (int)h1.w, lda_ = (int)h2.y, c = lane & 15, j = lane >> 4;
-            xvoff = ((u32)(c < M_ ? c : M_ - 1) * (u32)lda_ + 8u * (u32)j) * 2u;
+            // (tiled: lane c + 16 j reads row c of 8-column block j of a chunk = bytes [16 lane, 16 lane + 16) of the chunk's 1 KB)
+            xvoff = (h2.w & LF_ATILED) ? (u32)lane * 16u : ((u32)(c < M_ ? c : M_ - 1) * (u32)lda_ + 8u * (u32)j) * 2u;
             pin_vector(xvoff);
         }
         #pragma unroll
@@ -582,10 +586,11 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         f16x8 xa[XL][4];
         // (address = a UNIFORM base -- the activations + the item's columns, scalar arithmetic -- + the lane's byte offset `xvoff`,
         // made in front of the weight requests: no vector instruction per request, nothing that could wait for a register)
+        const u32 xcs = (R.flags & LF_ATILED) ? 1024u : 64u;          // bytes between the 32-column chunks of the activations
         auto xrequest = [&](f16x8 (&v)[4], int q) {
-            const u8* const xb = (const u8*)R.cx.x_lds + (q < n ? (size_t)(R.chunk0 + 4 * q) * 64 : 0);
+            const u8* const xb = (const u8*)R.cx.x_lds + (q < n ? (size_t)(R.chunk0 + 4 * q) * xcs : 0);
             #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = *(const f16x8*)(xb + xvoff + (q < n ? e * 64 : 0));
+            for (int e = 0; e < 4; e++) v[e] = *(const f16x8*)(xb + xvoff + (q < n ? e * xcs : 0u));
         };
         if constexpr (XMEM)
         {
@@ -659,7 +664,19 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                 }
             }
         }
-        if (tail_nv) lean_item_general<BITS, GPTQ>(bt, R.cx, R.chunk0 + 4 * n, 4 * n, R.g0, R.gshift, R.gphase, tail_nv, lane, acc);
+        if constexpr (XMEM)
+        {
+            if (tail_nv)
+            {
+                const f16x8 z8 = {(f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f};
+                f16x8 xt[4] = {z8, z8, z8, z8};
+                const u8* const xb = (const u8*)R.cx.x_lds + (size_t)(R.chunk0 + 4 * n) * xcs;
+                #pragma unroll
+                for (int e = 0; e < 4; e++) if (e < tail_nv) xt[e] = *(const f16x8*)(xb + xvoff + e * xcs);
+                lean_item_general<BITS, GPTQ, true>(bt, R.cx, R.chunk0 + 4 * n, 4 * n, R.g0, R.gshift, R.gphase, tail_nv, lane, acc, xt);
+            }
+        }
+        else if (tail_nv) lean_item_general<BITS, GPTQ>(bt, R.cx, R.chunk0 + 4 * n, 4 * n, R.g0, R.gshift, R.gphase, tail_nv, lane, acc);
     };
     // a share of at least NB and at most D items takes the pipelined form
     auto head_bits = [&](auto bits_tag) {
@@ -749,7 +766,8 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         if (ep_on)
         {
             if (xp_out && args.hdr.xp_w) e.xw_next = args.hdr.xp_w[e.xp_idx];
-            e.cp = args.mat[ep_mj].c + (size_t)row * args.hdr.ldc[ep_mj] + c_idx;
+            e.cp = args.mat[ep_mj].c + ((flags & LF_CTILED) ? ((size_t)(c_idx >> 3) * 16 + row) * 8 + (c_idx & 7)
+                                                           : (size_t)row * args.hdr.ldc[ep_mj] + c_idx);
             if (flags & LF_ACCUM) e.c_old = DEP ? load_agent_f16(e.cp) : *e.cp;
         }
         if (flags & LF_NORM)
@@ -801,8 +819,10 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                 // of squares is x's own
                 const float f = fmaxf(-65504.0f, fminf((float)y, 65504.0f));
                 const f16 xw = (f16)fmaxf(-65504.0f, fminf(f * (float)e.xw_next, 65504.0f));
-                if constexpr (DEP) store_agent_f16(xp_out + (size_t)row * args.hdr.ldxp + e.xp_idx, xw);
-                else xp_out[(size_t)row * args.hdr.ldxp + e.xp_idx] = xw;
+                const size_t xo = (flags & LF_XPTILED) ? ((size_t)(e.xp_idx >> 3) * 16 + row) * 8 + (e.xp_idx & 7)
+                                                       : (size_t)row * args.hdr.ldxp + e.xp_idx;
+                if constexpr (DEP) store_agent_f16(xp_out + xo, xw);
+                else xp_out[xo] = xw;
                 sq = f * f;
             }
         }
@@ -1030,6 +1050,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     const bool dep = in.sync_signal != nullptr;                     // a launch of an overlapped chain (chain_sync.h): <= 4 rows only
     if (!dep && (in.sync_wait || in.sync_arrive)) return 1;
     if (dep && rows_mode) return 1;
+    if ((in.a_tiled || in.c_tiled || in.xp_tiled) && (dep || in.c_mode == C_ACCUM && in.c_tiled || (in.c_tiled && !in.pair && in.n_mats != 1))) return 1;
     if (const char* e = getenv("EXL2_LEAN_DECLINE_M")) { if (atoi(e) == in.M) return 1; }      // test hook: row groups on different kernels
     const QMatrix* q0 = in.qm[0];
     const int K = q0->height;
@@ -1124,7 +1145,8 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
         }
         xmem = planned && form == 2;
     };
-    if (!rows_mode) plan(0);
+    if (in.a_tiled) plan(2);                                       // (only the XMEM form reads that layout)
+    else if (!rows_mode) plan(0);
     else if (xmem_on >= 2) { plan(2); if (!planned) plan(1); }
     else { plan(1); if (!planned && xmem_on >= 1) plan(2); }
     if (!planned) return 1;
@@ -1141,7 +1163,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     h.a = in.a; h.xp_w = in.xp_w; h.ss = in.ss; h.xp_out = in.xp_out; h.xp_invperm = in.xp_invperm; h.ss_out = in.ss_out;
     h.eps = in.eps; h.M = in.M; h.K = K; h.lda = in.lda; h.ldxp = in.ldxp; h.npart = in.npart; h.wgs = wgs;
     h.flags = (in.a_mode == A_NORM_PRE ? LF_NORM : 0u) | (in.act_gelu ? LF_GELU : 0u) | (in.c_mode == C_ACCUM ? LF_ACCUM : 0u) | (any_bias ? LF_BIAS : 0u)
-            | (dep ? LF_DEP : 0u);
+            | (dep ? LF_DEP : 0u) | (in.a_tiled ? LF_ATILED : 0u) | (in.c_tiled ? LF_CTILED : 0u) | (in.xp_tiled ? LF_XPTILED : 0u);
     if (dep)
     {
         h.sync_wait = in.sync_wait; h.sync_signal = in.sync_signal; h.sync_wgs = (u32)wgs * (u32)(in.pair ? 1 : in.n_mats);
@@ -1158,7 +1180,8 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
 #endif
     if (getenv("EXL2_LEAN_TRACE"))
     {
-        fprintf(stderr, "[lean] M=%d K=%d mats=%d pair=%d S=%d slots=%d wgs=%d lds=%u mode=%d\n", in.M, K, in.n_mats, in.pair, S, nslots, wgs, lds, in.a_mode);
+        fprintf(stderr, "[lean] M=%d K=%d mats=%d pair=%d S=%d slots=%d wgs=%d lds=%u mode=%d form=%s a_tiled=%d c_tiled=%d\n", in.M, K, in.n_mats, in.pair, S, nslots, wgs, lds,
+                in.a_mode, xmem ? "xmem" : rows_mode ? "rows" : "plain", in.a_tiled, in.c_tiled);
         for (int j = 0; j < in.n_mats; j++)
             for (int w = 0; w < S; w++)
             {
@@ -1197,12 +1220,12 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     LEAN_FOR_EACH_XMEM_GEOMETRY(LEAN_GO)
 #undef LEAN_GO
 #define LEAN_GO(SS, NS, P, OCC) \
-    if (!rows_mode && !dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a); \
+    if (!rows_mode && !xmem && !dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a); \
     if (!rows_mode && dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC, false, false, true>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_GEOMETRY(LEAN_GO, LEAN_OCC_DEFAULT)
 #undef LEAN_GO
 #define LEAN_GO(SS, NS, P, OCC) \
-    if (!rows_mode && !dep && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC>), grid, block, lds, stream, a); \
+    if (!rows_mode && !xmem && !dep && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC>), grid, block, lds, stream, a); \
     if (!rows_mode && dep && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC, false, false, true>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_GEOMETRY(LEAN_GO, 6)
 #undef LEAN_GO

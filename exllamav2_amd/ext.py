@@ -635,6 +635,10 @@ class ExtC:
         self.lib.check(self.lib.exl2_chain_overlap_end(C.byref(n)))
         return n.value
 
+    def chain_set_tiled(self, on: bool) -> None:
+        """5..16 rows: the chain's xp buffers in the MFMA-tiled layout between (True) and (False) (include/exl2_hip.h)"""
+        self.lib.check(self.lib.exl2_chain_set_tiled(1 if on else 0))
+
     def embed_rows_chain(self, table, ids, x, next_invperm, next_norm_w, xp_out, ss_out) -> None:
         self.lib.check(self.lib.exl2_embed_rows_chain(
             self._ptr(table, torch.float16, "table"), self._ptr(ids, torch.int32, "ids"), self._ptr(x, torch.float16, "x"),

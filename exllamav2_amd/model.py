@@ -276,6 +276,14 @@ class GreedyGraphDecoder:
             if dev.type == "cuda":
                 self.chain["ev_pre"], self.chain["ev_b"] = torch.cuda.Event(), torch.cuda.Event()
             self.graph_b = None
+        # 5-16 sequences, second form (round 4): the hand-off buffers xp in the layout the matrix cores read ([K / 8][16 rows][8]:
+        # include/exl2_hip.h, exl2_chain_set_tiled) -- q|k|v, gate|up and the head then take the lean kernel's XMEM form (A operands
+        # straight from memory, one coalesced kilobyte each, no staged copy); o_proj keeps the ROWS form (attention writes row-major)
+        if (self.b > 4 and "flags" not in self.chain and rg == "auto" and int(os.environ.get("EXL2_LEAN_XMEM", "1")) >= 1
+                and os.environ.get("EXL2_XP_TILED", "1") != "0" and os.environ.get("EXL2_LEAN", "1") != "0"):
+            self.chain["xp_tiled"] = True
+            for name in ("xp_a", "xp_b"):
+                self.chain[name] = torch.zeros((16, cfg.hidden_size), dtype=torch.float16, device=dev)
 
     def step_chain(self):
         m, ext, cfg, ch = self.model, self.model.ext, self.model.config, self.chain
@@ -312,9 +320,16 @@ class GreedyGraphDecoder:
         groups = groups_h
         pa, pb = _PartialSums(ss_a, b), _PartialSums(ss_b, b)
         pa.begin()
-        for r0, r1 in groups:
-            ext.embed_rows_chain(m.embed_tokens, self.ids[r0:r1], x2[r0:r1], plan[0][0], plan[0][3], xp_a[r0:r1], pa.out(r0, r1))
-            pa.done(1)
+        tiled = bool(ch.get("xp_tiled")) and groups_h == groups_o == groups_d == [(0, b)]
+        if tiled:
+            ext.chain_set_tiled(True)
+        try:
+            for r0, r1 in groups:
+                ext.embed_rows_chain(m.embed_tokens, self.ids[r0:r1], x2[r0:r1], plan[0][0], plan[0][3], xp_a[r0:r1], pa.out(r0, r1))
+                pa.done(1)
+        except Exception:
+            ext.chain_set_tiled(False)
+            raise
         if overlap:
             sa = self.stream.cuda_stream if self.stream is not None else None
             sb = ch["stream_b"].cuda_stream if ch["stream_b"] is not None else None
@@ -353,6 +368,8 @@ class GreedyGraphDecoder:
                 ss, cnt = pa.inp(r0, r1, "head")
                 ext.gemm_half_q_half_chain(xp_a[r0:r1], ss, cnt, cfg.norm_eps, m.lm_head.q_handle, self.logits[r0:r1], r1 - r0)
         finally:
+            if tiled:
+                ext.chain_set_tiled(False)
             n_launches = ext.chain_overlap_end() if overlap else 0
         # greedy sampling + position increment behind the head: on the stream the head went to
         import contextlib

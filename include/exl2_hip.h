@@ -242,6 +242,16 @@ int exl2_q_mlp_forward_chain_part(void* handle, int part, int row0, void* x, con
 int exl2_gemm_half_q_half_chain(const void* xp, const float* ss, int npart, float eps,
                                 void* q_matrix, void* c, int rows, void* stream);
 /* embedding rows -> x, and published as (xp_out, ss_out with npart = 1) for the first consumer */
+/* Chained decode of 5..16 rows (round 4): between exl2_chain_set_tiled(1) and (0) the chain's hand-off buffers xp (the residual
+ * stream times its consumer's norm weight, in that consumer's order) hold the layout the matrix cores read their A operand in:
+ * [K / 8][16 row slots][8 halfs] -- element (row, k) at ((k >> 3) * 16 + row) * 8 + (k & 7); buffers of 16 x hidden halfs whatever
+ * the number of rows.  exl2_embed_rows_chain, exl2_q_attn_forward_2_chain and exl2_q_mlp_forward_chain write xp so,
+ * exl2_q_attn_forward_1_chain, exl2_q_mlp_forward_chain and exl2_gemm_half_q_half_chain read it so (the lean kernel's XMEM form:
+ * one coalesced kilobyte per 16 x 32 operand, no staged copy).  Process-wide switch, set around the launches of a step (or
+ * their capture).  No reference counterpart (the reference has no chained decode: q_attn.cu:153-345 / q_mlp.cu:153-236 run module
+ * by module). */
+int exl2_chain_set_tiled(int on);
+
 int exl2_embed_rows_chain(const void* table, const int* ids, void* x, int rows, int hidden, int vocab,
                           const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, void* stream);
 /* dst[i] = src[perm[i]] (u16 perm, nullable = copy), n elements */

@@ -68,11 +68,14 @@ def test_chain_decode_wide_k(be, recipe):
     _decode_and_check(be, cfg, recipe, 1, steps=2, seed=5)
 
 
+@pytest.mark.parametrize("xp_tiled", ["1", "0"])
 @pytest.mark.parametrize("batch", [16, 11, 8, 5, 4])
-def test_chain_decode_many_rows(be, batch):
+def test_chain_decode_many_rows(be, batch, xp_tiled, monkeypatch):
     """4 sequences: one launch of the lean kernel's wave-private form with four finalising waves; 5..16: its ROWS form (round 4: the
-    workgroup stages the whole rows once, every finalising wave takes several rows) -- every launch of the step on the lean
-    kernel, none left to the round-2 kernel"""
+    workgroup stages the whole rows once, every finalising wave takes several rows; EXL2_XP_TILED=0) or -- the default -- the
+    hand-off buffers in the matrix cores' layout and q|k|v, gate|up, down, head in the XMEM form (o_proj: ROWS).  Every launch of
+    the step on the lean kernel, none left to the round-2 kernel"""
+    monkeypatch.setenv("EXL2_XP_TILED", xp_tiled)
     cfg = tiny_cfg(max_batch_size=16)
     be.ext.chain_route_counts(reset=True)
     _decode_and_check(be, cfg, "4.0bpw", batch, steps=2, seed=12)
@@ -89,6 +92,20 @@ def test_chain_decode_many_rows_operands_from_memory(be, recipe, batch, monkeypa
     cfg = tiny_cfg(max_batch_size=16, intermediate_size=384, num_attention_heads=4, num_key_value_heads=2)
     be.ext.chain_route_counts(reset=True)
     _decode_and_check(be, cfg, recipe, batch, steps=2, seed=23)
+    lean, flat = be.ext.chain_route_counts(reset=True)
+    assert lean > 0 and flat == 0, (lean, flat)
+
+
+@pytest.mark.parametrize("recipe,batch,inter", [("4.0bpw", 16, 384), ("3.5bpw", 13, 416), ("2.5bpw", 9, 384), ("4.0bpw_plain", 5, 640),
+                                                ("gptq-4bit-128g", 16, 384)])
+def test_chain_decode_many_rows_tiled_hand_off(be, recipe, batch, inter, monkeypatch):
+    """gate | up -> down at 5 .. 16 rows in the layout the matrix cores read ([K / 8][16 rows][8 halfs]: FlatIn.c_tiled / a_tiled):
+    the pair launch's epilogue writes it, down_proj's XMEM form reads one coalesced kilobyte per A operand.  Default where the rows'
+    staged copy would not fit the LDS (7B: 16 x 11008); forced here for every step (EXL2_MLP_TILED=2).  K = 416: a partial last item."""
+    monkeypatch.setenv("EXL2_MLP_TILED", "2")
+    cfg = tiny_cfg(max_batch_size=16, intermediate_size=inter, num_attention_heads=4, num_key_value_heads=2)
+    be.ext.chain_route_counts(reset=True)
+    _decode_and_check(be, cfg, recipe, batch, steps=2, seed=29)
     lean, flat = be.ext.chain_route_counts(reset=True)
     assert lean > 0 and flat == 0, (lean, flat)
 
@@ -113,6 +130,7 @@ def test_chain_decode_many_rows_workgroups_walk_their_units(be, batch, grid, mon
     """ROWS form: the grid is sized to the CUs and a workgroup takes units u, u + grid, ... with one staged copy of the rows
     (a 7B gate|up launch: 688 tile pairs on 256 workgroups).  Small shapes never have more units than CUs, so the walk is forced."""
     monkeypatch.setenv("EXL2_LEAN_ROWS_GRID", str(grid))
+    monkeypatch.setenv("EXL2_XP_TILED", "0")                     # (the ROWS form for every launch of the step)
     cfg = tiny_cfg(max_batch_size=16, intermediate_size=384, num_attention_heads=4, num_key_value_heads=2)
     be.ext.chain_route_counts(reset=True)
     _decode_and_check(be, cfg, "3.5bpw", batch, steps=2, seed=19)
