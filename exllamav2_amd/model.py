@@ -276,11 +276,13 @@ class GreedyGraphDecoder:
             if dev.type == "cuda":
                 self.chain["ev_pre"], self.chain["ev_b"] = torch.cuda.Event(), torch.cuda.Event()
             self.graph_b = None
-        # 5-16 sequences, second form (round 4): the hand-off buffers xp in the layout the matrix cores read ([K / 8][16 rows][8]:
-        # include/exl2_hip.h, exl2_chain_set_tiled) -- q|k|v, gate|up and the head then take the lean kernel's XMEM form (A operands
-        # straight from memory, one coalesced kilobyte each, no staged copy); o_proj keeps the ROWS form (attention writes row-major)
+        # 5-16 sequences, EXL2_XP_TILED=1 (round 4, measured SLOWER than the default and therefore off: profiles/r04_xp_tiled_sweep.txt
+        # -- 7B bs = 16: 6460 vs 6652 tok/s, bs = 5: 2251 vs 2565): the hand-off buffers xp in the layout the matrix cores read
+        # ([K / 8][16 rows][8]: include/exl2_hip.h, exl2_chain_set_tiled) -- q|k|v, gate|up and the head then take the lean kernel's
+        # XMEM form (A operands straight from memory, no staged copy); o_proj keeps the ROWS form (attention writes row-major).
+        # The default keeps that layout for ONE hand-off only: gate|up -> down where down's rows do not fit the LDS (csrc/modules.hip)
         if (self.b > 4 and "flags" not in self.chain and rg == "auto" and int(os.environ.get("EXL2_LEAN_XMEM", "1")) >= 1
-                and os.environ.get("EXL2_XP_TILED", "1") != "0" and os.environ.get("EXL2_LEAN", "1") != "0"):
+                and os.environ.get("EXL2_XP_TILED", "0") != "0" and os.environ.get("EXL2_LEAN", "1") != "0"):
             self.chain["xp_tiled"] = True
             for name in ("xp_a", "xp_b"):
                 self.chain[name] = torch.zeros((16, cfg.hidden_size), dtype=torch.float16, device=dev)

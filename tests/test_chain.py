@@ -72,9 +72,9 @@ def test_chain_decode_wide_k(be, recipe):
 @pytest.mark.parametrize("batch", [16, 11, 8, 5, 4])
 def test_chain_decode_many_rows(be, batch, xp_tiled, monkeypatch):
     """4 sequences: one launch of the lean kernel's wave-private form with four finalising waves; 5..16: its ROWS form (round 4: the
-    workgroup stages the whole rows once, every finalising wave takes several rows; EXL2_XP_TILED=0) or -- the default -- the
-    hand-off buffers in the matrix cores' layout and q|k|v, gate|up, down, head in the XMEM form (o_proj: ROWS).  Every launch of
-    the step on the lean kernel, none left to the round-2 kernel"""
+    workgroup stages the whole rows once, every finalising wave takes several rows; the default) or -- EXL2_XP_TILED=1 -- the
+    hand-off buffers in the matrix cores' layout and q|k|v, gate|up, down, head in the XMEM form (o_proj: ROWS; measured slower on
+    the 7B shapes, kept as an option).  Every launch of the step on the lean kernel, none left to the round-2 kernel"""
     monkeypatch.setenv("EXL2_XP_TILED", xp_tiled)
     cfg = tiny_cfg(max_batch_size=16)
     be.ext.chain_route_counts(reset=True)
