@@ -43,6 +43,9 @@ timeout -k 10 300 python bench.py --model llama2-70b --recipe 2.5bpw --cache q4 
 timeout -k 10 300 python bench.py --model mixtral-8x7b --recipe 3.5bpw --steps 32 --warmup 4 --headline-only 2>/dev/null | tail -1 > $R/${T}_bench_mixtral_b1.json; cut -c1-200 $R/${T}_bench_mixtral_b1.json
 timeout -k 10 300 python bench.py --model mixtral-8x7b --recipe 3.5bpw --batch 16 --steps 32 --warmup 4 --headline-only 2>/dev/null | tail -1 > $R/${T}_bench_mixtral_b16.json; cut -c1-200 $R/${T}_bench_mixtral_b16.json
 timeout -k 10 200 python bench.py --batch 12 --steps 32 --warmup 4 --headline-only 2>/dev/null | tail -1 > $R/${T}_bench_b12.json; cut -c1-200 $R/${T}_bench_b12.json
+timeout -k 10 200 python bench.py --batch 5 --steps 32 --warmup 4 --headline-only 2>/dev/null | tail -1 > $R/${T}_bench_b5.json; cut -c1-200 $R/${T}_bench_b5.json
+echo "== rocprof stats (bs=16)"; (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_stats16 -o ${T}_b16 -- python $GRAFT_REPO_ROOT/bench.py --batch 16 --steps 32 --warmup 4 --headline-only --no-parity-check > /dev/null 2>&1); echo "rc=$?"
+head -7 $R/prof_stats16/${T}_b16_kernel_stats.csv | cut -c1-160; cp $R/prof_stats16/${T}_b16_kernel_stats.csv $R/${T}_b16_kernel_stats.csv; rm -rf $R/prof_stats16
 timeout -k 10 200 python tools/moe_bench.py 2>/dev/null > $R/${T}_moe_bench.jsonl; cut -c1-130 $R/${T}_moe_bench.jsonl
 timeout -k 10 300 python tools/prefill_bench.py 2>/dev/null > $R/${T}_prefill_gemm.jsonl; cut -c1-160 $R/${T}_prefill_gemm.jsonl | tail -8
 timeout -k 10 200 python tools/attn_prefill_bench.py 2>/dev/null > $R/${T}_attn_prefill_bench.jsonl; cut -c1-160 $R/${T}_attn_prefill_bench.jsonl | tail -4
