@@ -384,6 +384,54 @@ def test_gemm_chain_norm_pre(be, rows, spec_name, monkeypatch):
     be.ext.free_q_matrix(h)
 
 
+@pytest.mark.parametrize("case", ["outliers", "tiny", "saturating"])
+def test_gemm_chain_norm_pre_extreme_activations(be, case):
+    """The chained hand-off stores fp16(clamp(x * w)) and scales the finished sums by 1 / rms(x), where the reference's rms_norm
+    rounds x * (1 / rms) * w once (rms_norm.cu:33-175).  What that costs at the edges of fp16's range, against rms_norm + q_gemm:
+      * outliers: a few channels at +-3e4 (the largest residual-stream activations seen in 7B-class models are ~1e3) with norm
+        weights <= 1.5: products stay below 65504 -- the ordinary tolerance holds;
+      * tiny: a residual stream of ~1e-4 with norm weights ~0.05, products ~5e-6 = fp16 SUBNORMALS (quantised to 6e-8): the
+        reference normalises first and keeps 11 bits; here each product keeps 6-7 bits, the K-term sum averages that out -- the
+        ordinary tolerance holds (measured: 2 % of it; the outputs are ~0.05 in magnitude);
+      * saturating: an outlier whose product exceeds 65504 is CLAMPED (documented deviation: the producers saturate, they never
+        emit inf) -- the result equals the reference's for the clamped activation, which the test states explicitly."""
+    k, spec = CHAIN_SPECS["6_4_2"]
+    n = 96
+    t, ref, w, h = _mk(be, k, n, spec, 33)
+    rng = np.random.default_rng(5)
+    rows = 3
+    x = rng.standard_normal((rows, k)).astype(np.float32)
+    nw = (1 + 0.2 * rng.standard_normal(k)).astype(np.float32).clip(0.2, 1.5)
+    slack = 2.0
+    if case == "outliers":
+        x[:, rng.choice(k, 6, replace=False)] = 3e4 * rng.choice([-1.0, 1.0], (rows, 6))
+    elif case == "tiny":
+        x *= 1e-4
+        nw = (0.05 * (1 + 0.2 * rng.standard_normal(k))).astype(np.float32).clip(0.02, 0.1)
+    else:
+        x[:, 7] = 4e4
+        nw[7] = 2.5                                                     # 1e5 > 65504
+    x = x.astype(np.float16); nw = nw.astype(np.float16)
+    perm = np.argsort(t["q_invperm"]).astype(np.int64)
+    prod = (x.astype(np.float32) * nw.astype(np.float32)).clip(-65504.0, 65504.0)
+    xp = prod.astype(np.float16)[:, perm]
+    sq = x.astype(np.float32) ** 2
+    npart = 3
+    ss = np.stack([sq[:, i::npart].sum(-1) for i in range(npart)], axis=-1).astype(np.float32)
+    c = torch.zeros((rows, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half_chain(be.t(xp), be.t(ss), npart, 1e-5, h, c, rows)
+    x_eff = x.astype(np.float64)
+    if case == "saturating":
+        x_eff[:, 7] = 65504.0 / float(nw[7])                            # what the clamp makes of that activation
+    rms = 1.0 / np.sqrt((x.astype(np.float64) ** 2).mean(-1, keepdims=True) + 1e-5)
+    xn = x_eff * rms * nw.astype(np.float64)                            # (fp64: the reference rounds this to fp16 once)
+    want = xn @ ref.astype(np.float64)
+    err = np.abs(be.n(c).astype(np.float64) - want)
+    tol = slack * (half_tol(want, k) + 2.0 ** -10 * (np.abs(xn) @ np.abs(ref.astype(np.float64))) / np.sqrt(k))
+    assert np.all(err <= tol), (case, float((err / tol).max()))
+    be.ext.free_q_matrix(h)
+
+
 def test_embed_rows_chain(be):
     rng = np.random.default_rng(5)
     vocab, hidden = 50, 256
