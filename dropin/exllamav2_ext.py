@@ -19,10 +19,12 @@ from exllamav2_amd import ext_tp as _tp
 # handle doubled the weight VRAM of every drop-in user).
 # The one consumer of the ORIGINAL layout is the reference's single-process tensor-parallel loader: after load() it slices
 # q_weight by output columns (linear.py:572-576) and hands the slices to make_q_matrix_split.  Its own shuffle is column-local,
-# so its slices stay valid; the tile-major layout of libexl2_hip.so is not sliceable.  Processes that call `model.load_tp`
-# therefore opt in with EXL2_DROPIN_TP=1 BEFORE loading: make_q_matrix then re-lays out a private copy (held while the handle
-# lives) and leaves the caller's tensor as loaded.  Without the opt-in make_q_matrix_split raises instead of building
-# matrices from a re-laid-out tensor.
+# so its slices stay valid; the tile-major layout of libexl2_hip.so is not sliceable.  That loader is recognised by what it
+# passes: `model.load_tp` loads every module with `device_context = False` (model.py:449), and load() then hands make_q_matrix
+# the placeholder `none_tensor` -- a meta tensor -- as temp_dq (linear.py:144-147); every other load path passes a scratch slice.
+# For such a call make_q_matrix re-lays out a PRIVATE copy (held while the handle lives) and leaves the caller's tensor as
+# loaded, so the column slices make_q_matrix_split receives afterwards are weights.  EXL2_DROPIN_TP=1 forces the private copy for
+# every handle (a host that slices q_weight on a path of its own).
 _private_weights = {}
 
 
@@ -30,9 +32,13 @@ def _tp_opt_in():
     return _os.environ.get("EXL2_DROPIN_TP", "0") != "0"
 
 
+def _is_placeholder(t):
+    return t is None or (isinstance(t, _torch.Tensor) and t.is_meta)
+
+
 def make_q_matrix(q_weight, q_perm, q_invperm, q_scale, q_scale_max, q_groups, q_group_map, gptq_qzeros, gptq_scales,
                   gptq_g_idx, bias, temp_dq, max_dq_rows):
-    if not _tp_opt_in():
+    if not (_tp_opt_in() or _is_placeholder(temp_dq)):
         return _e.make_q_matrix(q_weight, q_perm, q_invperm, q_scale, q_scale_max, q_groups, q_group_map, gptq_qzeros,
                                 gptq_scales, gptq_g_idx, bias, temp_dq, max_dq_rows)
     own = q_weight.clone()
@@ -48,11 +54,8 @@ def free_q_matrix(handle):
 
 
 def make_q_matrix_split(*args):
-    # (its inputs are fresh contiguous column slices of the tensors load() kept: re-laid out in place)
-    if not _tp_opt_in():
-        raise RuntimeError("exllamav2_ext.make_q_matrix_split (model.load_tp): set EXL2_DROPIN_TP=1 before loading the model -- "
-                           "without it make_q_matrix re-lays q_weight out in place and column slices of it are not weights "
-                           "(dropin/exllamav2_ext.py)")
+    # (its inputs are fresh contiguous column slices of the tensors load(device_context = False) kept -- see above: re-laid out in
+    # place, they are this handle's own)
     return _e.make_q_matrix_split(*args)
 
 

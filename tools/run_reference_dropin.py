@@ -92,7 +92,8 @@ def main_tp(model_dir: str, out: str, steps: int = 4):
     1259), the MLP through tp_mlp_forward_ (mlp.py:365-399), norm / head through rms_norm_tp / gemm_half_q_half_tp, the
     exchanges through tp_broadcast / tp_gather and the pinned host buffers -- all served by exllamav2_amd/ext_tp.py.
     Split over every visible device (one on the GPU box of this build)."""
-    os.environ["EXL2_DROPIN_TP"] = "1"          # load_tp slices q_weight after load(): the drop-in must keep the loaded layout
+    # (load_tp slices q_weight after load(): the drop-in recognises that loader by the placeholder temp_dq it passes and keeps the
+    # loaded layout -- no switch needed; dropin/exllamav2_ext.py)
     from exllamav2 import ExLlamaV2, ExLlamaV2Config, ExLlamaV2Cache, ExLlamaV2Cache_TP
     from exllamav2.ext import ext_c
     assert ext_c.__name__ == "exllamav2_ext" and "dropin" in ext_c.__file__, ext_c.__file__
