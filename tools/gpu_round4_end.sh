@@ -54,7 +54,7 @@ if [ -f exllamav2_amd/libexl2_hip_trace.so ]; then timeout -k 10 200 python tool
 rocm-smi --showproductname 2>/dev/null | grep -i "card series\|gfx" | head -3 > $R/${T}_gpu.txt
 echo "== same-box A/B of the lean kernel's states (libraries differ in qgemv_lean.o only): final source, commit 549e139, round 3"
 for rep in 1 2; do
-  for v in head callb r3; do
+  for v in head callb r3; do   # (callb / r3: tools/build_state_variants.sh; skipped when not built)
     if [ $v = head ]; then E="A=1"; else E="EXL2_HIP_LIB=$GRAFT_REPO_ROOT/exllamav2_amd/libexl2_hip_$v.so"; fi
     [ $v = head ] || [ -f exllamav2_amd/libexl2_hip_$v.so ] || continue
     echo -n "$v : "; env $E timeout -k 10 200 python bench.py --steps 64 --warmup 8 --headline-only --no-parity-check 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'tok/s', d['roofline']['avg_launch_us'], 'us/launch', d['roofline']['frac'])"
