@@ -30,6 +30,8 @@
 
 #define SAMPLE_THREADS 1024
 #define SAMPLE_KMAX 500
+#define SAMPLE_KPAD 512                // >= SAMPLE_KMAX + 2, a multiple of 8
+#define SAMPLE_LIST 1024               // quick select: entries at or above the lower bound it can hold (more: the radix passes)
 
 struct SampleArgs
 {
@@ -42,6 +44,7 @@ struct SampleArgs
     // filled by the host many tokens ahead -- and the token goes where the arg-max kernel puts it (history, position increment)
     const float* randoms; const int* counter; int n_randoms;
     int* history; int* hist_pos; int hist_stride, pos_inc;
+    int quick;                        // REG: quick select in front of the radix passes (EXL2_SAMPLE_QUICK=0: A/B, tests)
 };
 
 // Row walks.  A row whose length and stride are multiples of 4 elements on a 16-byte-aligned base (every real vocabulary) is
@@ -115,15 +118,19 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
 {
     SHARED float red_v[16];
     SHARED int   red_i[16];
-    SHARED u32   hist[256];
+    SHARED u32   hist[1024];          // radix passes: 256 digits; quick select (REG): 1024 bins of key >> 20
+    SHARED u32   lst_k[SAMPLE_LIST];  // quick select: keys / indices of the entries at or above the lower bound
+    SHARED int   lst_i[SAMPLE_LIST];
     SHARED u32   scan_ge[16], scan_eq[16];
-    SHARED u32   sel[8];              // 0: prefix key, 1: need, 2: P (prefix end), 3: c, 4: slot counter
+    SHARED u32   sel[12];             // 0: prefix key, 1: need, 2: P (prefix end), 3: c, 4: slot counter, 5: entries == theta,
+                                      // 6: quick select's lower bound, 7: its list length, 8: theta found (flag)
     SHARED float raw_p[SAMPLE_KMAX];
     SHARED int   raw_i[SAMPLE_KMAX];
-    SHARED float cand_p[SAMPLE_KMAX + 2];
-    SHARED int   cand_i[SAMPLE_KMAX + 2];
-    SHARED float stk_p[SAMPLE_KMAX + 2];
-    SHARED int   stk_i[SAMPLE_KMAX + 2];
+    // (16-byte aligned, padded to whole batches of 8: the one-thread stages read them 8 entries at a time)
+    SHARED __attribute__((aligned(16))) float cand_p[SAMPLE_KPAD];
+    SHARED __attribute__((aligned(16))) int   cand_i[SAMPLE_KPAD];
+    SHARED __attribute__((aligned(16))) float stk_p[SAMPLE_KPAD];
+    SHARED __attribute__((aligned(16))) int   stk_i[SAMPLE_KPAD];
 
     const int row = bid_x(), t = tid(), V = a.vocab, K = a.top_k;
     const T* lr = (const T*)a.logits + (size_t)row * a.ld;
@@ -235,7 +242,7 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
             *(f32x4*)(ws + 4 * (size_t)q) = e;
         }
     else for (int i = t; i < V; i += SAMPLE_THREADS) ws[i] = ws[i] * isum;
-    if (t == 0) { sel[0] = 0; sel[1] = (u32)K; sel[4] = 0; }
+    if (t == 0) { sel[0] = 0; sel[1] = (u32)K; sel[4] = 0; sel[6] = 0; sel[7] = 0; sel[8] = 0; }
     block_sync();                      // (workgroup-scope: the row's probabilities are visible to every thread from here)
 
     if (K == 1)
@@ -250,125 +257,263 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
         return;
     }
 
-    // ---- 3. theta = k-th largest probability: radix select on the bit patterns (p >= 0: integer order = float order) ----
-    // A thread adds a run of equal digits with ONE LDS atomic: in the first pass nearly every entry of a row has the same top
-    // byte, and one atomic per entry would serialise 32 K adds on a single LDS word.
-    u32 prefix = 0, maskbits = 0, need = (u32)K;
-    for (int pass = 0; pass < 4; pass++)
+    // ---- 3. theta = k-th largest probability ------------------------------------------------------------------------------
+    // (a) quick select, when the row lives in registers (REG).  The K largest of the 1024 per-thread maxima are K distinct
+    // entries of the row, so the lower edge t0 of the 1 / 8-octave bin that holds the K-th largest thread maximum satisfies
+    // #(p >= t0) >= K -- and with the entries dealt to the threads quad by quad that count is seldom much more than K.  ONE
+    // histogram add per thread (1024 bins of key >> 20), a descending scan, then every entry >= t0 goes to a list in LDS, where
+    // theta, the tie counts and every candidate's rank in descending (p, index) order are found by comparing the list with
+    // itself.  7 barriers and no pass over memory, against 16 + three passes for (b); identical theta / m / candidates (both
+    // are exact selections).  A list that would overflow (flat rows, tiny vocabularies) takes (b).
+    u32 theta = 0, m = 0, eq_total = 0;
+    bool have_theta = false, placed = false;
+    if (REG && a.quick)
     {
-        const int shift = 24 - 8 * pass;
-        if (t < 256) hist[t] = 0;
+        u32 kmax = 0;
+        for_regs([&](int, float p) { const u32 key = f32_bits(p); kmax = key > kmax ? key : kmax; });
+        hist[t] = 0;
         block_sync();
-        u32 run_digit = 0, run_len = 0;
-        auto digit = [&](int, float p)
-        {
-            const u32 key = f32_bits(p);
-            if ((key & maskbits) != prefix) return;
-            const u32 d = (key >> shift) & 255;
-            if (d != run_digit && run_len) { atomic_add_u32(&hist[run_digit], run_len); run_len = 0; }
-            run_digit = d; run_len++;
-        };
-        if constexpr (REG) for_regs(digit); else for_row(ws, V, vec, digit);
-        if (run_len) atomic_add_u32(&hist[run_digit], run_len);
+        atomic_add_u32(&hist[(kmax >> 20) < 1023u ? (kmax >> 20) : 1023u], 1u);     // (p <= 1: bins 0 .. 1016; a NaN row must not leave the array)
         block_sync();
-        // the digit whose bucket holds the need-th largest key: buckets taken from 255 down, one per thread of waves 0-3, a
-        // wave scan + four wave totals (a single thread walking the 256 counters costs ~12 us per pass in LDS round trips)
-        u32 h = 0, inc = 0;
-        if (t < 256)
         {
-            h = hist[255 - t];
-            inc = wave_scan_incl(h);
+            const u32 h = hist[1023 - t];
+            const u32 inc = wave_scan_incl(h);
             if (lane_id() == 63) scan_ge[wave_id()] = inc;
-        }
-        block_sync();
-        if (t < 256)
-        {
-            u32 above = inc - h;                                   // keys in buckets with a larger digit
+            block_sync();
+            u32 above = inc - h;
             for (int w = 0; w < wave_id(); w++) above += scan_ge[w];
-            if (above < need && above + h >= need) { sel[0] = prefix | ((u32)(255 - t) << shift); sel[1] = need - above; }
+            if (above < (u32)K && above + h >= (u32)K) sel[6] = (u32)(1023 - t) << 20;
         }
         block_sync();
-        prefix = sel[0]; need = sel[1]; maskbits |= 0xFFu << shift;
-    }
-    const u32 theta = prefix;
-    const u32 m = need;                // entries equal to theta that survive
-
-    // ---- 4. which of the entries equal to theta: the last m inside the prefix ending at the k-th entry >= theta ----------
-    const int chunk = (((V + SAMPLE_THREADS - 1) / SAMPLE_THREADS) + 3) & ~3;      // contiguous share of a thread, in whole quads
-    const int c0 = min(t * chunk, V), c1 = min(c0 + chunk, V);
-    u32 n_ge = 0, n_eq = 0;
-    for_range(ws, c0, c1, vec, [&](int, float p) { const u32 key = f32_bits(p); n_ge += key >= theta; n_eq += key == theta; });
-    const u32 inc_ge = wave_scan_incl(n_ge), inc_eq = wave_scan_incl(n_eq);
-    if (lane_id() == 63) { scan_ge[wave_id()] = inc_ge; scan_eq[wave_id()] = inc_eq; }
-    block_sync();
-    u32 ge_before = inc_ge - n_ge, eq_before = inc_eq - n_eq;
-    for (int w = 0; w < wave_id(); w++) { ge_before += scan_ge[w]; eq_before += scan_eq[w]; }
-    if (ge_before < (u32)K && ge_before + n_ge >= (u32)K)
-    {
-        u32 g = ge_before, e = eq_before; bool found = false;
-        for_range(ws, c0, c1, vec, [&](int i, float p)
+        const u32 t0 = sel[6];
+        for_regs([&](int i, float p)
         {
             const u32 key = f32_bits(p);
-            g += key >= theta; e += key == theta;
-            if (!found && g == (u32)K && key >= theta) { sel[2] = (u32)i; sel[3] = e; found = true; }
-        });
-    }
-    block_sync();
-    const int P = (int)sel[2];
-    const u32 first_rank = sel[3] - m;             // 0-based rank (among the entries == theta, ascending index) of the first kept
-    {
-        u32 e = eq_before;
-        for_range(ws, c0, c1, vec, [&](int i, float p)
-        {
-            const u32 key = f32_bits(p);
-            bool take = key > theta;
-            if (key == theta) { take = (i <= P) && (e >= first_rank); e++; }
-            if (take)
+            if (key >= t0)
             {
-                const u32 slot = atomic_add_u32(&sel[4], 1u);
-                if (slot < (u32)SAMPLE_KMAX) { raw_p[slot] = p; raw_i[slot] = i; }
+                const u32 slot = atomic_add_u32(&sel[7], 1u);
+                if (slot < (u32)SAMPLE_LIST) { lst_k[slot] = key; lst_i[slot] = i; }
             }
         });
+        block_sync();
+        const u32 L = sel[7];
+        if (L <= (u32)SAMPLE_LIST && L >= (u32)K)
+        {
+            u32 my_key = 0, rank = 0; int my_i = 0;
+            if ((u32)t < L)
+            {
+                my_key = lst_k[t]; my_i = lst_i[t];
+                u32 gt = 0, eq = 0, eq_hi = 0;
+                for (u32 j = 0; j < L; j++)
+                {
+                    const u32 kj = lst_k[j];
+                    gt += kj > my_key;
+                    if (kj == my_key) { eq++; eq_hi += lst_i[j] > my_i; }
+                }
+                rank = gt + eq_hi;                                 // position in descending (p, index) order
+                if (gt < (u32)K && gt + eq >= (u32)K) { sel[0] = my_key; sel[1] = (u32)K - gt; sel[5] = eq; sel[8] = 1u; }
+            }
+            block_sync();
+            if (sel[8])
+            {
+                theta = sel[0]; m = sel[1]; eq_total = sel[5]; have_theta = true;
+                if (eq_total == m)
+                {
+                    // no tie across the k-th place: the candidates are the list's entries >= theta, already ranked
+                    if ((u32)t < L && my_key >= theta) { cand_p[rank] = __builtin_bit_cast(float, my_key); cand_i[rank] = my_i; }
+                    placed = true;
+                }
+            }
+        }
     }
-    block_sync();
-
-    // ---- 5. descending (p, index) order by rank (the pairs are distinct); position k = what top_k_cpu left there -------
-    if (t < K)
+    // (b) radix select on the bit patterns (p >= 0: integer order = float order), four 8-bit passes
+    if (!have_theta)
     {
-        const float p = raw_p[t]; const int ix = raw_i[t];
-        int rank = 0;
-        for (int j = 0; j < K; j++) { const float q = raw_p[j]; rank += (q > p) || (q == p && raw_i[j] > ix); }
-        cand_p[rank] = p; cand_i[rank] = ix;
+        // A thread adds a run of equal digits with ONE LDS atomic: in the first pass nearly every entry of a row has the same top
+        // byte, and one atomic per entry would serialise 32 K adds on a single LDS word.
+        u32 prefix = 0, maskbits = 0, need = (u32)K;
+        for (int pass = 0; pass < 4; pass++)
+        {
+            const int shift = 24 - 8 * pass;
+            if (t < 256) hist[t] = 0;
+            block_sync();
+            u32 run_digit = 0, run_len = 0;
+            auto digit = [&](int, float p)
+            {
+                const u32 key = f32_bits(p);
+                if ((key & maskbits) != prefix) return;
+                const u32 d = (key >> shift) & 255;
+                if (d != run_digit && run_len) { atomic_add_u32(&hist[run_digit], run_len); run_len = 0; }
+                run_digit = d; run_len++;
+            };
+            if constexpr (REG) for_regs(digit); else for_row(ws, V, vec, digit);
+            if (run_len) atomic_add_u32(&hist[run_digit], run_len);
+            block_sync();
+            // the digit whose bucket holds the need-th largest key: buckets taken from 255 down, one per thread of waves 0-3, a
+            // wave scan + four wave totals (a single thread walking the 256 counters costs ~12 us per pass in LDS round trips)
+            u32 h = 0, inc = 0;
+            if (t < 256)
+            {
+                h = hist[255 - t];
+                inc = wave_scan_incl(h);
+                if (lane_id() == 63) scan_ge[wave_id()] = inc;
+            }
+            block_sync();
+            if (t < 256)
+            {
+                u32 above = inc - h;                                   // keys in buckets with a larger digit
+                for (int w = 0; w < wave_id(); w++) above += scan_ge[w];
+                if (above < need && above + h >= need) { sel[0] = prefix | ((u32)(255 - t) << shift); sel[1] = need - above; sel[5] = h; }
+            }
+            block_sync();
+            prefix = sel[0]; need = sel[1]; maskbits |= 0xFFu << shift;
+        }
+        theta = prefix;
+        m = need;                          // entries equal to theta that survive
+        eq_total = sel[5];                 // entries equal to theta in the row (the last pass' bucket = all 32 bits)
+    }
+
+    if (!placed)
+    {
+        // ---- 4. which of the entries equal to theta: the last m inside the prefix ending at the k-th entry >= theta ----------
+        // (when ALL of them survive -- no tie across the k-th place, the usual case -- the set is simply every entry >= theta: one
+        // gather, from the registers where the row lives there; the index-ordered passes below run only for a real tie)
+        if (eq_total == m)
+        {
+            auto take = [&](int i, float p)
+            {
+                if (f32_bits(p) >= theta)
+                {
+                    const u32 slot = atomic_add_u32(&sel[4], 1u);
+                    if (slot < (u32)SAMPLE_KMAX) { raw_p[slot] = p; raw_i[slot] = i; }
+                }
+            };
+            if constexpr (REG) for_regs(take); else for_row(ws, V, vec, take);
+            block_sync();
+        }
+        else
+        {
+            const int chunk = (((V + SAMPLE_THREADS - 1) / SAMPLE_THREADS) + 3) & ~3;      // contiguous share of a thread, in whole quads
+            const int c0 = min(t * chunk, V), c1 = min(c0 + chunk, V);
+            u32 n_ge = 0, n_eq = 0;
+            for_range(ws, c0, c1, vec, [&](int, float p) { const u32 key = f32_bits(p); n_ge += key >= theta; n_eq += key == theta; });
+            const u32 inc_ge = wave_scan_incl(n_ge), inc_eq = wave_scan_incl(n_eq);
+            if (lane_id() == 63) { scan_ge[wave_id()] = inc_ge; scan_eq[wave_id()] = inc_eq; }
+            block_sync();
+            u32 ge_before = inc_ge - n_ge, eq_before = inc_eq - n_eq;
+            for (int w = 0; w < wave_id(); w++) { ge_before += scan_ge[w]; eq_before += scan_eq[w]; }
+            if (ge_before < (u32)K && ge_before + n_ge >= (u32)K)
+            {
+                u32 g = ge_before, e = eq_before; bool found = false;
+                for_range(ws, c0, c1, vec, [&](int i, float p)
+                {
+                    const u32 key = f32_bits(p);
+                    g += key >= theta; e += key == theta;
+                    if (!found && g == (u32)K && key >= theta) { sel[2] = (u32)i; sel[3] = e; found = true; }
+                });
+            }
+            block_sync();
+            const int P = (int)sel[2];
+            const u32 first_rank = sel[3] - m;             // 0-based rank (among the entries == theta, ascending index) of the first kept
+            {
+                u32 e = eq_before;
+                for_range(ws, c0, c1, vec, [&](int i, float p)
+                {
+                    const u32 key = f32_bits(p);
+                    bool take = key > theta;
+                    if (key == theta) { take = (i <= P) && (e >= first_rank); e++; }
+                    if (take)
+                    {
+                        const u32 slot = atomic_add_u32(&sel[4], 1u);
+                        if (slot < (u32)SAMPLE_KMAX) { raw_p[slot] = p; raw_i[slot] = i; }
+                    }
+                });
+            }
+            block_sync();
+        }
+
+        // ---- 5. descending (p, index) order by rank (the pairs are distinct); position k = what top_k_cpu left there -------
+        if (t < K)
+        {
+            const float p = raw_p[t]; const int ix = raw_i[t];
+            int rank = 0;
+            for (int j = 0; j < K; j++) { const float q = raw_p[j]; rank += (q > p) || (q == p && raw_i[j] > ix); }
+            cand_p[rank] = p; cand_i[rank] = ix;
+        }
     }
     if (t == SAMPLE_THREADS - 1) { cand_p[K] = ws[K]; cand_i[K] = K; cand_p[K + 1] = 0.0f; cand_i[K + 1] = 0; }
     block_sync();
     if (t != 0) return;
 
     // ---- 6. the reference's sequential stages on the candidate array, in place (one thread; sums in the reference's order) ----
+    // One thread, so what a pass over the array costs is LDS latency: an entry per round trip (read, wait, add) was ~0.3 us per
+    // candidate over the stages.  The passes read 8 entries per round trip into registers (two 16-byte reads) and keep the
+    // reference's order of every sum and comparison; the stack's top two values live in registers.
     int n = K;
+    auto load8 = [&](const float* arr, int i0, float (&v)[8]) {
+        const f32x4 lo = *(const f32x4*)(arr + i0), hi = *(const f32x4*)(arr + i0 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    };
+    auto load8i = [&](const int* arr, int i0, int (&v)[8]) {
+        const u32x4 lo = *(const u32x4*)(arr + i0), hi = *(const u32x4*)(arr + i0 + 4);
+        v[0] = (int)lo.x; v[1] = (int)lo.y; v[2] = (int)lo.z; v[3] = (int)lo.w; v[4] = (int)hi.x; v[5] = (int)hi.y; v[6] = (int)hi.z; v[7] = (int)hi.w;
+    };
     auto normalize = [&](int cnt)                                   // sampling.cpp:265-281
     {
         float s = 0.0f;
-        for (int i = 0; i < cnt; i++) s += cand_p[i];
+        for (int i0 = 0; i0 < cnt; i0 += 8)
+        {
+            float v[8]; load8(cand_p, i0, v);
+            #pragma unroll
+            for (int e = 0; e < 8; e++) if (i0 + e < cnt) s += v[e];
+        }
         const float is = 1.0f / s;
-        for (int i = 0; i < cnt; i++) cand_p[i] *= is;
+        for (int i0 = 0; i0 < cnt; i0 += 8)
+        {
+            float v[8]; load8(cand_p, i0, v);
+            #pragma unroll
+            for (int e = 0; e < 8; e++) if (i0 + e < cnt) v[e] *= is;          // (entries behind cnt go back as they were)
+            *(f32x4*)(cand_p + i0) = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)(cand_p + i0 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        }
     };
     normalize(n);
     if (n > 1 && a.top_p > 0.0f && a.top_p < 1.0f)                  // sampling.cpp:524-566 (heap == stack on this order)
     {
         int top = 0;                                                // the heap's content = stk[0 .. top), minimum on top
         float s = 0.0f;
-        for (int i = 0; i < n; i++)
+        float tv = 0.0f, sv = 0.0f;                                 // stk_p[top - 1] and (while sv_ok) stk_p[top - 2]
+        bool sv_ok = false;
+        for (int i0 = 0; i0 < n; i0 += 8)
         {
-            const float p = cand_p[i];
-            if (p < 1e-6f) continue;
-            if (s > a.top_p && p < stk_p[top - 1]) continue;
-            stk_p[top] = p; stk_i[top] = cand_i[i]; top++;
-            s += p;
-            while (s > a.top_p && top > 1) { s -= stk_p[top - 1]; top--; }
+            float v[8]; int vi[8];
+            load8(cand_p, i0, v); load8i(cand_i, i0, vi);
+            #pragma unroll
+            for (int e = 0; e < 8; e++)
+            {
+                if (i0 + e >= n) break;
+                const float p = v[e];
+                if (p < 1e-6f) continue;
+                if (s > a.top_p && p < tv) continue;                // (top >= 1 whenever s > 0)
+                stk_p[top] = p; stk_i[top] = vi[e];
+                sv = tv; sv_ok = top >= 1; tv = p; top++;
+                s += p;
+                while (s > a.top_p && top > 1)
+                {
+                    s -= tv; top--;
+                    tv = sv_ok ? sv : stk_p[top - 1];
+                    sv_ok = false;
+                }
+            }
         }
         // the result overwrites positions 0 .. top-1; everything behind keeps the previous stage's entries (min-p can reach one)
-        for (int i = 0; i < top; i++) { cand_p[i] = stk_p[i]; cand_i[i] = stk_i[i]; }
+        int i = 0;
+        for (; i + 8 <= top; i += 8)
+        {
+            *(f32x4*)(cand_p + i) = *(const f32x4*)(stk_p + i); *(f32x4*)(cand_p + i + 4) = *(const f32x4*)(stk_p + i + 4);
+            *(u32x4*)(cand_i + i) = *(const u32x4*)(stk_i + i); *(u32x4*)(cand_i + i + 4) = *(const u32x4*)(stk_i + i + 4);
+        }
+        for (; i < top; i++) { cand_p[i] = stk_p[i]; cand_i[i] = stk_i[i]; }
         n = top;
         normalize(n);
     }
@@ -401,13 +546,20 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     }
     const float radj = (float)((double)random * 0.9998);            // :273
     int idx = 0;
-    float accum = cand_p[0];
-    while (true)                                                    // sampling.cpp:894-906
+    float accum = 0.0f;
+    bool done = false;
+    for (int i0 = 0; i0 < n && !done; i0 += 8)                       // sampling.cpp:894-906, 8 entries per LDS round trip
     {
-        if (accum >= radj) break;
-        if (idx == n - 1) { while (idx > 0 && cand_p[idx] == 0.0f) idx--; break; }
-        idx++;
-        accum += cand_p[idx];
+        float v[8]; load8(cand_p, i0, v);
+        #pragma unroll
+        for (int e = 0; e < 8; e++)
+        {
+            if (done || i0 + e >= n) break;
+            idx = i0 + e;
+            accum = idx == 0 ? v[e] : accum + v[e];
+            if (accum >= radj) { done = true; break; }
+            if (idx == n - 1) { while (idx > 0 && cand_p[idx] == 0.0f) idx--; done = true; break; }
+        }
     }
     a.out_tokens[row] = cand_i[idx];
     a.out_probs[row] = cand_p[idx];
@@ -437,6 +589,8 @@ static int sample_launch(SampleArgs a, int logits_f32, int rows, float random, v
     if (const char* e = getenv("EXL2_SAMPLE_REG")) reg_on = atoi(e);
     const bool vec = ((a.vocab & 3) == 0) && ((a.ld & 3) == 0) && ((((size_t)a.logits) & 15) == 0) && ((((size_t)a.ws) & 15) == 0);
     const bool reg = reg_on && vec && !a.filter && a.vocab <= 4 * SAMPLE_REG_QUADS * SAMPLE_THREADS;
+    a.quick = 1;
+    if (const char* e = getenv("EXL2_SAMPLE_QUICK")) a.quick = atoi(e);
     if (logits_f32) { if (reg) LAUNCH((sample_rows_kernel<float, true>), dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a);
                       else     LAUNCH((sample_rows_kernel<float, false>), dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a); }
     else            { if (reg) LAUNCH((sample_rows_kernel<f16, true>), dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, stream, a);

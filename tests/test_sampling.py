@@ -132,7 +132,9 @@ def test_sample_rows_refuses_what_is_not_built(be):
 def test_row_in_registers_equals_memory_walks(be, monkeypatch):
     """sample_rows with the row held in registers (default where it applies: quad-aligned rows up to 32768 entries, no filter)
     against the same kernel walking memory for every stage (EXL2_SAMPLE_REG=0): tokens, probabilities and the whole workspace of
-    probabilities identical bit for bit -- fp16 and fp32 logits, 1 and 3 rows, a 32 000-entry vocabulary, tie-heavy logits."""
+    probabilities identical bit for bit -- fp16 and fp32 logits, 1 and 3 rows, a 32 000-entry vocabulary, tie-heavy logits.  Round 4:
+    the register route finds theta by a quick select (lower bound from the per-thread maxima, the entries above it compared among
+    themselves) in front of the radix passes (EXL2_SAMPLE_QUICK=0): all three routes agree bit for bit."""
     import torch
     rng = np.random.default_rng(11)
     for vocab, rows, dt, coarse in ((96, 3, np.float16, False), (4096, 1, np.float32, False), (32000, 3, np.float16, False), (2048, 2, np.float16, True)):
@@ -140,12 +142,15 @@ def test_row_in_registers_equals_memory_walks(be, monkeypatch):
         if coarse: lg = np.round(lg * 2) / 2                          # exact ties at the top-k boundary
         lg = lg.astype(dt)
         out = []
-        for reg in ("1", "0"):
+        for reg, quick in (("1", "1"), ("0", "1"), ("1", "0")):
+            # (registers + quick select: the default; memory walks + radix passes; registers + radix passes)
             monkeypatch.setenv("EXL2_SAMPLE_REG", reg)
+            monkeypatch.setenv("EXL2_SAMPLE_QUICK", quick)
             t = torch.zeros((rows,), dtype=torch.int32, device=be.device); p = torch.zeros((rows,), dtype=torch.float32, device=be.device)
             ws = be.ext.sample_rows(be.t(lg), 0.8, 50, 0.8, 0.02, 0.37, t, p)
             out.append((be.n(t).copy(), be.n(p).view(np.uint32).copy(), be.n(ws).view(np.uint32).copy()))
-        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2]), (vocab, rows)
+        for other in out[1:]:
+            assert np.array_equal(out[0][0], other[0]) and np.array_equal(out[0][1], other[1]) and np.array_equal(out[0][2], other[2]), (vocab, rows)
 
 
 def test_dropin_apply_rep_penalty_reproduces_the_executed_reference():
