@@ -81,6 +81,8 @@ DEV u32 shfl_xor_u32(u32 v, int mask) {
 }
 DEV float shfl_xor_f32(float v, int mask) { return as_f32(shfl_xor_u32(f32_bits(v), mask)); }
 DEV u32 shfl_idx_u32(u32 v, int src_lane) { return (u32)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
+// bit l = the predicate of lane l (every lane of the wave calls)
+DEV u64 wave_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 DEV float shfl_idx_f32(float v, int src_lane) { return as_f32(shfl_idx_u32(f32_bits(v), src_lane)); }
 
 // exchange with lane ^ MASK for MASK < 32 (stays inside each 32-lane half): ds_swizzle bit-mask mode, no LDS memory

@@ -151,6 +151,17 @@ template <typename T> DEV T emu_wave_read(T mine, int src_lane)
 DEV u32 shfl_xor_u32(u32 v, int mask) { return emu_wave_read(v, lane_id() ^ mask); }
 DEV float shfl_xor_f32(float v, int mask) { return emu_wave_read(v, lane_id() ^ mask); }
 DEV u32 shfl_idx_u32(u32 v, int src) { return emu_wave_read(v, src); }
+DEV u64 wave_ballot(bool pred)
+{
+    EmuWave& w = emu_ctx_->wave[wave_id()];
+    const u32 mine = pred ? 1u : 0u;
+    memcpy(w.slot[lane_id()], &mine, sizeof(mine));
+    w.bar.wait();
+    u64 m = 0;
+    for (int l = 0; l < 64; l++) { u32 v; memcpy(&v, w.slot[l], sizeof(v)); if (v) m |= 1ull << l; }
+    w.bar.wait();
+    return m;
+}
 DEV float shfl_idx_f32(float v, int src) { return emu_wave_read(v, src); }
 
 template <int MASK> DEV u32 swz_xor_u32(u32 v) { return emu_wave_read(v, lane_id() ^ MASK); }
