@@ -513,7 +513,8 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
         float s = 0.0f;
         float tv = 0.0f, sv = 0.0f;                                 // stk_p[top - 1] and (while sv_ok) stk_p[top - 2]
         bool sv_ok = false;
-        for (int i0 = 0; i0 < n; i0 += 8)
+        int rest_from = -1;
+        for (int i0 = 0; i0 < n && rest_from < 0; i0 += 8)
         {
             float v[8]; int vi[8];
             load8(cand_p, i0, v); load8i(cand_i, i0, vi);
@@ -527,7 +528,9 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
                 if (i0 + e >= n) break;
                 const float p = v[e];
                 if (p < 1e-6f) continue;
-                if (s > a.top_p && p < tv) continue;                // (top >= 1 whenever s > 0)
+                // (the array is in descending order: once an entry is skipped here every later one is too -- nothing is pushed
+                // in between, so tv stays -- and the walk ends; their scaled values are stored below)
+                if (s > a.top_p && p < tv) { rest_from = i0 + e; break; }      // (top >= 1 whenever s > 0)
                 stk_p[top] = p; stk_i[top] = vi[e];
                 sv = tv; sv_ok = top >= 1; tv = p; top++;
                 s += p;
@@ -539,6 +542,16 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
                 }
             }
         }
+        // (the batches behind the one the walk ended in: scaled like the others -- min-p's keep_threshold may read one of them)
+        if (rest_from >= 0)
+            for (int i0 = (rest_from & ~7) + 8; i0 < n; i0 += 8)
+            {
+                float v[8]; load8(cand_p, i0, v);
+                #pragma unroll
+                for (int e = 0; e < 8; e++) if (i0 + e < n) v[e] *= is1;
+                *(f32x4*)(cand_p + i0) = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)(cand_p + i0 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            }
         // the result overwrites positions 0 .. top-1, normalised on the way (normalize_cpu on the new content: its sum runs over
         // the same values in the same order); everything behind keeps the previous stage's entries (min-p can reach one)
         const float is2 = 1.0f / seq_sum(stk_p, top);
