@@ -31,6 +31,9 @@
 #define SAMPLE_THREADS 1024
 #define SAMPLE_KMAX 500
 #define SAMPLE_KPAD 512                // >= SAMPLE_KMAX + 2, a multiple of 8
+#ifndef SAMPLE_KILL
+#define SAMPLE_KILL 0                  // timing experiments (results are WRONG): 1 no candidate stages, 2 no ranking of the quick select's list
+#endif
 #define SAMPLE_LIST 1024               // quick select: entries at or above the lower bound it can hold (more: the radix passes)
 
 struct SampleArgs
@@ -119,7 +122,7 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     SHARED float red_v[16];
     SHARED int   red_i[16];
     SHARED u32   hist[1024];          // radix passes: 256 digits; quick select (REG): 1024 bins of key >> 20
-    SHARED __attribute__((aligned(16))) u32 lst_k[SAMPLE_LIST];  // quick select: keys / indices of the entries at or above the lower bound
+    SHARED u32   lst_k[SAMPLE_LIST];  // quick select: keys / indices of the entries at or above the lower bound
     SHARED int   lst_i[SAMPLE_LIST];
     SHARED u32   scan_ge[16], scan_eq[16];
     SHARED u32   sel[12];             // 0: prefix key, 1: need, 2: P (prefix end), 3: c, 4: slot counter, 5: entries == theta,
@@ -286,33 +289,15 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
         }
         block_sync();
         const u32 t0 = sel[6];
-        // (slots per WAVE: one LDS atomic for all lanes of a wave that have an entry in the same step -- ~60 returning atomics on
-        // one word cost more than the rest of the select)
-        #pragma unroll
-        for (int u = 0; u < SAMPLE_REG_QUADS; u++)
+        for_regs([&](int i, float p)
         {
-            const int q = t + u * SAMPLE_THREADS;
-            #pragma unroll
-            for (int c = 0; c < 4; c++)
+            const u32 key = f32_bits(p);
+            if (key >= t0)
             {
-                const u32 key = f32_bits(pr[u][c]);
-                const bool hit = q < nq_reg && key >= t0;
-                const u64 mask = wave_ballot(hit);
-                if (mask)
-                {
-                    const int lane = lane_id();
-                    const int leader = __builtin_ctzll(mask);
-                    u32 base = 0;
-                    if (lane == leader) base = atomic_add_u32(&sel[7], (u32)__builtin_popcountll(mask));
-                    base = shfl_idx_u32(base, leader);
-                    if (hit)
-                    {
-                        const u32 slot = base + (u32)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                        if (slot < (u32)SAMPLE_LIST) { lst_k[slot] = key; lst_i[slot] = 4 * q + c; }
-                    }
-                }
+                const u32 slot = atomic_add_u32(&sel[7], 1u);
+                if (slot < (u32)SAMPLE_LIST) { lst_k[slot] = key; lst_i[slot] = i; }
             }
-        }
+        });
         block_sync();
         const u32 L = sel[7];
         if (L <= (u32)SAMPLE_LIST && L >= (u32)K)
@@ -322,17 +307,12 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
             {
                 my_key = lst_k[t]; my_i = lst_i[t];
                 u32 gt = 0, eq = 0, eq_hi = 0;
-                for (u32 j0 = 0; j0 < L; j0 += 4)                  // four keys per LDS read (entries behind L are masked)
+                if (SAMPLE_KILL & 2) { gt = (u32)t; eq = 1; }
+                else for (u32 j = 0; j < L; j++)
                 {
-                    const u32x4 k4 = *(const u32x4*)(lst_k + j0);
-                    const u32 kk[4] = {k4.x, k4.y, k4.z, k4.w};
-                    #pragma unroll
-                    for (int e = 0; e < 4; e++)
-                    {
-                        if (j0 + e >= L) break;
-                        gt += kk[e] > my_key;
-                        if (kk[e] == my_key) { eq++; eq_hi += lst_i[j0 + e] > my_i; }
-                    }
+                    const u32 kj = lst_k[j];
+                    gt += kj > my_key;
+                    if (kj == my_key) { eq++; eq_hi += lst_i[j] > my_i; }
                 }
                 rank = gt + eq_hi;                                 // position in descending (p, index) order
                 if (gt < (u32)K && gt + eq >= (u32)K) { sel[0] = my_key; sel[1] = (u32)K - gt; sel[5] = eq; sel[8] = 1u; }
@@ -474,6 +454,7 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     // candidate over the stages.  The passes read 8 entries per round trip into registers (two 16-byte reads) and keep the
     // reference's order of every sum and comparison; the stack's top two values live in registers.
     int n = K;
+    if (SAMPLE_KILL & 1) { a.out_tokens[row] = cand_i[0]; a.out_probs[row] = cand_p[0]; return; }
     auto load8 = [&](const float* arr, int i0, float (&v)[8]) {
         const f32x4 lo = *(const f32x4*)(arr + i0), hi = *(const f32x4*)(arr + i0 + 4);
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
@@ -482,19 +463,16 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
         const u32x4 lo = *(const u32x4*)(arr + i0), hi = *(const u32x4*)(arr + i0 + 4);
         v[0] = (int)lo.x; v[1] = (int)lo.y; v[2] = (int)lo.z; v[3] = (int)lo.w; v[4] = (int)hi.x; v[5] = (int)hi.y; v[6] = (int)hi.z; v[7] = (int)hi.w;
     };
-    auto seq_sum = [&](const float* arr, int cnt) -> float         // the reference's left-to-right fp32 sum
+    auto normalize = [&](int cnt)                                   // sampling.cpp:265-281
     {
         float s = 0.0f;
         for (int i0 = 0; i0 < cnt; i0 += 8)
         {
-            float v[8]; load8(arr, i0, v);
+            float v[8]; load8(cand_p, i0, v);
             #pragma unroll
             for (int e = 0; e < 8; e++) if (i0 + e < cnt) s += v[e];
         }
-        return s;
-    };
-    auto scale_in_place = [&](int cnt, float is)
-    {
+        const float is = 1.0f / s;
         for (int i0 = 0; i0 < cnt; i0 += 8)
         {
             float v[8]; load8(cand_p, i0, v);
@@ -504,33 +482,24 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
             *(f32x4*)(cand_p + i0 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
         }
     };
-    auto normalize = [&](int cnt) { scale_in_place(cnt, 1.0f / seq_sum(cand_p, cnt)); };      // sampling.cpp:265-281
+    normalize(n);
     if (n > 1 && a.top_p > 0.0f && a.top_p < 1.0f)                  // sampling.cpp:524-566 (heap == stack on this order)
     {
-        // normalize_cpu's scaling pass rides along: an entry is scaled (and stored: a later stage may read it) as it is visited
-        const float is1 = 1.0f / seq_sum(cand_p, n);
         int top = 0;                                                // the heap's content = stk[0 .. top), minimum on top
         float s = 0.0f;
         float tv = 0.0f, sv = 0.0f;                                 // stk_p[top - 1] and (while sv_ok) stk_p[top - 2]
         bool sv_ok = false;
-        int rest_from = -1;
-        for (int i0 = 0; i0 < n && rest_from < 0; i0 += 8)
+        for (int i0 = 0; i0 < n; i0 += 8)
         {
             float v[8]; int vi[8];
             load8(cand_p, i0, v); load8i(cand_i, i0, vi);
-            #pragma unroll
-            for (int e = 0; e < 8; e++) if (i0 + e < n) v[e] *= is1;
-            *(f32x4*)(cand_p + i0) = (f32x4){v[0], v[1], v[2], v[3]};
-            *(f32x4*)(cand_p + i0 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
             #pragma unroll
             for (int e = 0; e < 8; e++)
             {
                 if (i0 + e >= n) break;
                 const float p = v[e];
                 if (p < 1e-6f) continue;
-                // (the array is in descending order: once an entry is skipped here every later one is too -- nothing is pushed
-                // in between, so tv stays -- and the walk ends; their scaled values are stored below)
-                if (s > a.top_p && p < tv) { rest_from = i0 + e; break; }      // (top >= 1 whenever s > 0)
+                if (s > a.top_p && p < tv) continue;                // (top >= 1 whenever s > 0)
                 stk_p[top] = p; stk_i[top] = vi[e];
                 sv = tv; sv_ok = top >= 1; tv = p; top++;
                 s += p;
@@ -542,32 +511,17 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
                 }
             }
         }
-        // (the batches behind the one the walk ended in: scaled like the others -- min-p's keep_threshold may read one of them)
-        if (rest_from >= 0)
-            for (int i0 = (rest_from & ~7) + 8; i0 < n; i0 += 8)
-            {
-                float v[8]; load8(cand_p, i0, v);
-                #pragma unroll
-                for (int e = 0; e < 8; e++) if (i0 + e < n) v[e] *= is1;
-                *(f32x4*)(cand_p + i0) = (f32x4){v[0], v[1], v[2], v[3]};
-                *(f32x4*)(cand_p + i0 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-            }
-        // the result overwrites positions 0 .. top-1, normalised on the way (normalize_cpu on the new content: its sum runs over
-        // the same values in the same order); everything behind keeps the previous stage's entries (min-p can reach one)
-        const float is2 = 1.0f / seq_sum(stk_p, top);
+        // the result overwrites positions 0 .. top-1; everything behind keeps the previous stage's entries (min-p can reach one)
         int i = 0;
         for (; i + 8 <= top; i += 8)
         {
-            float v[8]; load8(stk_p, i, v);
-            #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] *= is2;
-            *(f32x4*)(cand_p + i) = (f32x4){v[0], v[1], v[2], v[3]}; *(f32x4*)(cand_p + i + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            *(f32x4*)(cand_p + i) = *(const f32x4*)(stk_p + i); *(f32x4*)(cand_p + i + 4) = *(const f32x4*)(stk_p + i + 4);
             *(u32x4*)(cand_i + i) = *(const u32x4*)(stk_i + i); *(u32x4*)(cand_i + i + 4) = *(const u32x4*)(stk_i + i + 4);
         }
-        for (; i < top; i++) { cand_p[i] = stk_p[i] * is2; cand_i[i] = stk_i[i]; }
+        for (; i < top; i++) { cand_p[i] = stk_p[i]; cand_i[i] = stk_i[i]; }
         n = top;
+        normalize(n);
     }
-    else normalize(n);
     if (n > 1 && a.min_p > 0.0f && a.min_p < 1.0f)                  // sampling.cpp:620-640 + keep_threshold :569-592
     {
         float topv = cand_p[0];
