@@ -224,6 +224,8 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     float esum = 0.0f;
     for (int w = 0; w < 16; w++) esum += red_v[w];
     const float isum = 1.0f / esum;
+    u32 kmax = 0;                                                   // the thread's largest probability (bit pattern): quick select
+    auto kmax_of = [&](float p) { const u32 key = f32_bits(p); kmax = key > kmax ? key : kmax; };
     if constexpr (REG)
     {
         #pragma unroll
@@ -242,9 +244,10 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
         {
             f32x4 e = *(const f32x4*)(ws + 4 * (size_t)q);
             e.x *= isum; e.y *= isum; e.z *= isum; e.w *= isum;
+            kmax_of(e.x); kmax_of(e.y); kmax_of(e.z); kmax_of(e.w);
             *(f32x4*)(ws + 4 * (size_t)q) = e;
         }
-    else for (int i = t; i < V; i += SAMPLE_THREADS) ws[i] = ws[i] * isum;
+    else for (int i = t; i < V; i += SAMPLE_THREADS) { const float p = ws[i] * isum; kmax_of(p); ws[i] = p; }
     if (t == 0) { sel[0] = 0; sel[1] = (u32)K; sel[4] = 0; sel[6] = 0; sel[7] = 0; sel[8] = 0; }
     block_sync();                      // (workgroup-scope: the row's probabilities are visible to every thread from here)
 
@@ -261,19 +264,19 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     }
 
     // ---- 3. theta = k-th largest probability ------------------------------------------------------------------------------
-    // (a) quick select, when the row lives in registers (REG).  The K largest of the 1024 per-thread maxima are K distinct
+    // (a) quick select.  The K largest of the 1024 per-thread maxima are K distinct
     // entries of the row, so the lower edge t0 of the 1 / 8-octave bin that holds the K-th largest thread maximum satisfies
     // #(p >= t0) >= K -- and with the entries dealt to the threads quad by quad that count is seldom much more than K.  ONE
     // histogram add per thread (1024 bins of key >> 20), a descending scan, then every entry >= t0 goes to a list in LDS, where
     // theta, the tie counts and every candidate's rank in descending (p, index) order are found by comparing the list with
-    // itself.  7 barriers and no pass over memory, against 16 + three passes for (b); identical theta / m / candidates (both
-    // are exact selections).  A list that would overflow (flat rows, tiny vocabularies) takes (b).
+    // itself.  7 barriers and no pass over memory (one where the row does not live in registers), against 16 barriers + three
+    // passes (seven) for (b); identical theta / m / candidates (both are exact selections).  A list that would overflow (flat
+    // rows, tiny vocabularies) takes (b).
     u32 theta = 0, m = 0, eq_total = 0;
     bool have_theta = false, placed = false;
-    if (REG && a.quick)
+    if (a.quick)
     {
-        u32 kmax = 0;
-        for_regs([&](int, float p) { const u32 key = f32_bits(p); kmax = key > kmax ? key : kmax; });
+        if constexpr (REG) for_regs([&](int, float p) { kmax_of(p); });
         hist[t] = 0;
         block_sync();
         atomic_add_u32(&hist[(kmax >> 20) < 1023u ? (kmax >> 20) : 1023u], 1u);     // (p <= 1: bins 0 .. 1016; a NaN row must not leave the array)
@@ -289,7 +292,7 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
         }
         block_sync();
         const u32 t0 = sel[6];
-        for_regs([&](int i, float p)
+        auto to_list = [&](int i, float p)
         {
             const u32 key = f32_bits(p);
             if (key >= t0)
@@ -297,7 +300,8 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
                 const u32 slot = atomic_add_u32(&sel[7], 1u);
                 if (slot < (u32)SAMPLE_LIST) { lst_k[slot] = key; lst_i[slot] = i; }
             }
-        });
+        };
+        if constexpr (REG) for_regs(to_list); else for_row(ws, V, vec, to_list);      // (memory route: ONE pass over the row)
         block_sync();
         const u32 L = sel[7];
         if (L <= (u32)SAMPLE_LIST && L >= (u32)K)

@@ -142,8 +142,8 @@ def test_row_in_registers_equals_memory_walks(be, monkeypatch):
         if coarse: lg = np.round(lg * 2) / 2                          # exact ties at the top-k boundary
         lg = lg.astype(dt)
         out = []
-        for reg, quick in (("1", "1"), ("0", "1"), ("1", "0")):
-            # (registers + quick select: the default; memory walks + radix passes; registers + radix passes)
+        for reg, quick in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+            # (registers / memory walks x quick select / radix passes: the default is the first, round 3's kernel the last)
             monkeypatch.setenv("EXL2_SAMPLE_REG", reg)
             monkeypatch.setenv("EXL2_SAMPLE_QUICK", quick)
             t = torch.zeros((rows,), dtype=torch.int32, device=be.device); p = torch.zeros((rows,), dtype=torch.float32, device=be.device)
