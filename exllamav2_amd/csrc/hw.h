@@ -81,6 +81,9 @@ DEV u32 shfl_xor_u32(u32 v, int mask) {
 }
 DEV float shfl_xor_f32(float v, int mask) { return as_f32(shfl_xor_u32(f32_bits(v), mask)); }
 DEV u32 shfl_idx_u32(u32 v, int src_lane) { return (u32)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
+// the lanes of a wave meet (LDS operations of one wave execute in order: what a lane wrote before is visible to every lane behind
+// this point; no instruction -- the compiler must not move LDS accesses across it)
+DEV void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // bit l = the predicate of lane l (every lane of the wave calls)
 DEV u64 wave_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 DEV float shfl_idx_f32(float v, int src_lane) { return as_f32(shfl_idx_u32(f32_bits(v), src_lane)); }

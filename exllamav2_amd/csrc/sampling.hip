@@ -249,6 +249,7 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
         }
     else for (int i = t; i < V; i += SAMPLE_THREADS) { const float p = ws[i] * isum; kmax_of(p); ws[i] = p; }
     if (t == 0) { sel[0] = 0; sel[1] = (u32)K; sel[4] = 0; sel[6] = 0; sel[7] = 0; sel[8] = 0; }
+    hist[t] = 0;                       // (the quick select's bins: zeroed in front of THIS barrier, one barrier less there)
     block_sync();                      // (workgroup-scope: the row's probabilities are visible to every thread from here)
 
     if (K == 1)
@@ -277,8 +278,6 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     if (a.quick)
     {
         if constexpr (REG) for_regs([&](int, float p) { kmax_of(p); });
-        hist[t] = 0;
-        block_sync();
         atomic_add_u32(&hist[(kmax >> 20) < 1023u ? (kmax >> 20) : 1023u], 1u);     // (p <= 1: bins 0 .. 1016; a NaN row must not leave the array)
         block_sync();
         {
@@ -451,14 +450,17 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
     }
     if (t == SAMPLE_THREADS - 1) { cand_p[K] = ws[K]; cand_i[K] = K; cand_p[K + 1] = 0.0f; cand_i[K + 1] = 0; }
     block_sync();
-    if (t != 0) return;
+    if (wave_id() != 0) return;
+    // (wave 0 stays: lane 0 runs the reference's sequential sums and walks, the element-wise passes between them use all 64 lanes)
+    const int lane = lane_id();
+    const bool lead = lane == 0;
 
     // ---- 6. the reference's sequential stages on the candidate array, in place (one thread; sums in the reference's order) ----
     // One thread, so what a pass over the array costs is LDS latency: an entry per round trip (read, wait, add) was ~0.3 us per
     // candidate over the stages.  The passes read 8 entries per round trip into registers (two 16-byte reads) and keep the
     // reference's order of every sum and comparison; the stack's top two values live in registers.
     int n = K;
-    if (SAMPLE_KILL & 1) { a.out_tokens[row] = cand_i[0]; a.out_probs[row] = cand_p[0]; return; }
+    if (SAMPLE_KILL & 1) { if (lead) { a.out_tokens[row] = cand_i[0]; a.out_probs[row] = cand_p[0]; } return; }
     auto load8 = [&](const float* arr, int i0, float (&v)[8]) {
         const f32x4 lo = *(const f32x4*)(arr + i0), hi = *(const f32x4*)(arr + i0 + 4);
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
@@ -467,29 +469,30 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
         const u32x4 lo = *(const u32x4*)(arr + i0), hi = *(const u32x4*)(arr + i0 + 4);
         v[0] = (int)lo.x; v[1] = (int)lo.y; v[2] = (int)lo.z; v[3] = (int)lo.w; v[4] = (int)hi.x; v[5] = (int)hi.y; v[6] = (int)hi.z; v[7] = (int)hi.w;
     };
-    auto normalize = [&](int cnt)                                   // sampling.cpp:265-281
+    auto normalize = [&](int cnt)                                   // sampling.cpp:265-281 (cnt: the same in every lane)
     {
-        float s = 0.0f;
-        for (int i0 = 0; i0 < cnt; i0 += 8)
+        float is = 0.0f;
+        if (lead)
         {
-            float v[8]; load8(cand_p, i0, v);
-            #pragma unroll
-            for (int e = 0; e < 8; e++) if (i0 + e < cnt) s += v[e];
+            float s = 0.0f;
+            for (int i0 = 0; i0 < cnt; i0 += 8)
+            {
+                float v[8]; load8(cand_p, i0, v);
+                #pragma unroll
+                for (int e = 0; e < 8; e++) if (i0 + e < cnt) s += v[e];
+            }
+            is = 1.0f / s;
         }
-        const float is = 1.0f / s;
-        for (int i0 = 0; i0 < cnt; i0 += 8)
-        {
-            float v[8]; load8(cand_p, i0, v);
-            #pragma unroll
-            for (int e = 0; e < 8; e++) if (i0 + e < cnt) v[e] *= is;          // (entries behind cnt go back as they were)
-            *(f32x4*)(cand_p + i0) = (f32x4){v[0], v[1], v[2], v[3]};
-            *(f32x4*)(cand_p + i0 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-        }
+        is = shfl_idx_f32(is, 0);
+        for (int i = lane; i < cnt; i += 64) cand_p[i] *= is;
+        wave_sync();
     };
     normalize(n);
     if (n > 1 && a.top_p > 0.0f && a.top_p < 1.0f)                  // sampling.cpp:524-566 (heap == stack on this order)
     {
         int top = 0;                                                // the heap's content = stk[0 .. top), minimum on top
+        if (lead)
+        {
         float s = 0.0f;
         float tv = 0.0f, sv = 0.0f;                                 // stk_p[top - 1] and (while sv_ok) stk_p[top - 2]
         bool sv_ok = false;
@@ -515,19 +518,19 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
                 }
             }
         }
-        // the result overwrites positions 0 .. top-1; everything behind keeps the previous stage's entries (min-p can reach one)
-        int i = 0;
-        for (; i + 8 <= top; i += 8)
-        {
-            *(f32x4*)(cand_p + i) = *(const f32x4*)(stk_p + i); *(f32x4*)(cand_p + i + 4) = *(const f32x4*)(stk_p + i + 4);
-            *(u32x4*)(cand_i + i) = *(const u32x4*)(stk_i + i); *(u32x4*)(cand_i + i + 4) = *(const u32x4*)(stk_i + i + 4);
         }
-        for (; i < top; i++) { cand_p[i] = stk_p[i]; cand_i[i] = stk_i[i]; }
+        top = (int)shfl_idx_u32((u32)top, 0);
+        wave_sync();
+        // the result overwrites positions 0 .. top-1; everything behind keeps the previous stage's entries (min-p can reach one)
+        for (int i = lane; i < top; i += 64) { cand_p[i] = stk_p[i]; cand_i[i] = stk_i[i]; }
+        wave_sync();
         n = top;
         normalize(n);
     }
     if (n > 1 && a.min_p > 0.0f && a.min_p < 1.0f)                  // sampling.cpp:620-640 + keep_threshold :569-592
     {
+        if (lead)
+        {
         float topv = cand_p[0];
         for (int i = 1; i < n; i++) if (cand_p[i] > topv) topv = cand_p[i];
         const float thr = topv * a.min_p;
@@ -544,8 +547,12 @@ KERNEL void __launch_bounds__(SAMPLE_THREADS) sample_rows_kernel(SampleArgs a)
             j--;
         }
         n = i;
+        }
+        n = (int)shfl_idx_u32((u32)n, 0);
+        wave_sync();
         normalize(n);
     }
+    if (!lead) return;
     float random = a.randoms ? a.randoms[(unsigned)a.counter[0] % (unsigned)a.n_randoms] : a.random;
     for (int r = 0; r < row; r++)                                   // ext_sampling.cpp:286-296, once per earlier row
     {

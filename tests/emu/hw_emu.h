@@ -151,6 +151,7 @@ template <typename T> DEV T emu_wave_read(T mine, int src_lane)
 DEV u32 shfl_xor_u32(u32 v, int mask) { return emu_wave_read(v, lane_id() ^ mask); }
 DEV float shfl_xor_f32(float v, int mask) { return emu_wave_read(v, lane_id() ^ mask); }
 DEV u32 shfl_idx_u32(u32 v, int src) { return emu_wave_read(v, src); }
+DEV void wave_sync() { EmuWave& w = emu_ctx_->wave[wave_id()]; w.bar.wait(); }
 DEV u64 wave_ballot(bool pred)
 {
     EmuWave& w = emu_ctx_->wave[wave_id()];
