@@ -58,6 +58,8 @@ def parse():
     p.add_argument("--batch", type=int, default=1, help="sequences decoded together (BASELINE configs[4]: 16)")
     p.add_argument("--parallel", default="pipeline", choices=["pipeline", "tp"],
                    help="N > 1: layer-split pipeline (default, weak scaling) or tensor parallel (column shards + all-gather, strong scaling)")
+    p.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps (each after --warmup untimed steps from the same "
+                                                           "cache position); the MEDIAN window is the reported value")
     p.add_argument("--headline-only", action="store_true", help="= --no-cpu-baseline --no-prefill --no-dropin --no-ctx-window (A/B runs)")
     a = p.parse_args()
     if a.headline_only:
@@ -192,7 +194,7 @@ def oracle_for_parity(cfg, ck, layers: int = 2):
     return OracleModel(ocfg, keep)
 
 
-def parity_check(model, oracle, device, n_decode: int = 6, cache_type: str = "fp16"):
+def parity_check(model, oracle, device, n_decode: int = 6, cache_type: str = "fp16", batch: int = 1):
     """Before anything is timed, on the first layers + head of the very checkpoint the bench times: a 4-token prompt through
     `model.forward` (the prefill route), then `n_decode` greedy steps through **GreedyGraphDecoder -- the captured chain the
     timed region replays** (same kernels, same graph mechanism; `route` in the result says which decode route it took).
@@ -204,7 +206,10 @@ def parity_check(model, oracle, device, n_decode: int = 6, cache_type: str = "fp
     cache_type "q4" (configs[3]): the check runs THROUGH an ExLlamaV2Cache_Q4 -- the cache type the timed region uses -- against
     OracleModel.forward(q4_cache=True) (the reference's cache.py:472-556 semantics); after every step the oracle adopts the
     device's codes (a 4-bit quantizer is discontinuous: oracle/model.py:q4_adopt) and the fraction of codes that differed from
-    the oracle's own is bounded."""
+    the oracle's own is bounded.
+
+    `batch` = the number of sequences the timed region decodes together (configs[4]: 16 -- a sparse-MoE layer then takes its
+    grouped-expert route, a dense one the kernels' many-row forms): the check decodes that many DIFFERENT sequences together."""
     import numpy as np
     import torch
     from exllamav2_amd import ExLlamaV2Cache, GreedyGraphDecoder
@@ -217,10 +222,10 @@ def parity_check(model, oracle, device, n_decode: int = 6, cache_type: str = "fp
     try:
         if q4:
             from exllamav2_amd.cache import ExLlamaV2Cache_Q4
-            cache = ExLlamaV2Cache_Q4(model, batch_size=1, max_seq_len=256)
+            cache = ExLlamaV2Cache_Q4(model, batch_size=batch, max_seq_len=256)
             cache.key_scales, cache.value_scales = cache.key_scales[:layers], cache.value_scales[:layers]
         else:
-            cache = ExLlamaV2Cache(model, batch_size=1, max_seq_len=256)
+            cache = ExLlamaV2Cache(model, batch_size=batch, max_seq_len=256)
         cache.key_states, cache.value_states = cache.key_states[:layers], cache.value_states[:layers]
 
         def follow_codes(n_tokens, what):
@@ -234,51 +239,67 @@ def parity_check(model, oracle, device, n_decode: int = 6, cache_type: str = "fp
                 worst_flip = max(worst_flip, f)
                 if f > 0.01:
                     raise SystemExit(f"[bench] parity check FAILED at {what}: {f:.4f} of the Q4 cache codes of layer {layer} differ from the oracle's")
-        ids = np.array([[1, 15043, 3186, 29892]]) % model.config.vocab_size
-        oracle.reset(1)
+        ids = (np.array([[1, 15043, 3186, 29892]]) + 977 * np.arange(batch)[:, None]) % model.config.vocab_size    # a row per sequence
+        oracle.reset(batch)
         worst, checked, tok_checked = 0.0, 0, 0
 
+        near_tie = 0
+
         def compare(got, want, what):
-            nonlocal worst, checked
-            err = np.abs(got - want)
-            tol = 0.03 + np.abs(want) * 2.0 ** -8
-            worst = max(worst, float((err / tol).max()))
-            checked += want.size
+            """rows whose expert selection in the oracle was a near tie (sparse-MoE models; oracle/model.py: router_margin) are
+            not compared -- top-k is discontinuous, a router logit one fp16 ulp off selects another expert there -- and counted"""
+            nonlocal worst, checked, near_tie
+            ok = oracle.router_margin > 2e-3
+            near_tie += int((~ok).sum())
+            err = np.abs(got - want)[ok]
+            tol = (0.03 + np.abs(want) * 2.0 ** -8)[ok]
+            if err.size:
+                worst = max(worst, float((err / tol).max()))
+            checked += err.size
             if not np.all(err <= tol):
                 raise SystemExit(f"[bench] parity check FAILED at {what}: max |logit - oracle| = {err.max():.4f}")
+            return ok
 
         want = oracle.forward(ids, q4_cache=q4)[:, -1]
         got = model.forward(torch.from_numpy(ids), cache).float().cpu().numpy()[:, -1].astype(np.float64)
         compare(got, want, "the prompt")
         follow_codes(ids.shape[1], "the prompt")
-        tok = int(want[0].argmax())
-        dec = GreedyGraphDecoder(model, cache, batch_size=1).capture()
+        tok = want.argmax(-1).astype(np.int64)                   # [batch]
+        dec = GreedyGraphDecoder(model, cache, batch_size=batch).capture()
         route = "chain (qgemv chain kernels, one HIP graph per step)" if dec.chain is not None else "module by module"
-        dec.reset(torch.tensor([tok]), ids.shape[1])
+        dec.reset(torch.from_numpy(tok), ids.shape[1])
         for step in range(n_decode):
             dec.run(1)
             torch.cuda.synchronize()
-            want = oracle.forward(np.array([[tok]]), q4_cache=q4)[:, -1]
+            want = oracle.forward(tok[:, None], q4_cache=q4)[:, -1]
             got = dec.logits.float().cpu().numpy()[:, :model.config.vocab_size].astype(np.float64)
-            compare(got, want, f"decode step {step}")
+            ok = compare(got, want, f"decode step {step}")
             follow_codes(ids.shape[1] + step + 1, f"decode step {step}")
-            dev_tok = int(dec.tokens(ids.shape[1] + step, 1).cpu().numpy()[0, 0])
-            top2 = np.sort(want[0])[-2:]
-            if top2[1] - top2[0] > 0.12:
+            dev_tok = dec.tokens(ids.shape[1] + step, 1).cpu().numpy()[:, 0].astype(np.int64)
+            top2 = np.sort(want, axis=-1)[:, -2:]
+            conf = ((top2[:, 1] - top2[:, 0]) > 0.12) & ok
+            if conf[0]:
                 tok_checked += 1
-                if dev_tok != int(want[0].argmax()):
-                    raise SystemExit(f"[bench] parity check FAILED at decode step {step}: greedy token {dev_tok} != oracle {int(want[0].argmax())}")
+            bad = np.nonzero(conf & (dev_tok != want.argmax(-1)))[0]
+            if len(bad):
+                r = int(bad[0])
+                raise SystemExit(f"[bench] parity check FAILED at decode step {step}, sequence {r}: greedy token {int(dev_tok[r])} != "
+                                 f"oracle {int(want[r].argmax())}")
             tok = dev_tok                                    # follow the device: each step is checked alone
         if tok_checked < 3:
             raise SystemExit(f"[bench] parity check FAILED: only {tok_checked} of {n_decode} steps had a confident oracle margin")
+        if near_tie * 10 > batch * (1 + n_decode):
+            raise SystemExit(f"[bench] parity check FAILED: {near_tie} of {batch * (1 + n_decode)} rows skipped as router near-ties")
         del cache
     finally:
         if dec is not None:
             dec.free()
         model.layers = full
-    res = {"layers": layers, "steps": 1 + n_decode, "decode_route": route, "cache": cache_type, "logits_checked": checked,
+    res = {"layers": layers, "sequences": batch, "steps": 1 + n_decode, "decode_route": route, "cache": cache_type, "logits_checked": checked,
            "worst_err_over_tol": round(worst, 3), "confident_tokens_equal": tok_checked,
            "tolerance": "0.03 + |x| * 2^-8 (fp16, tests/test_model.py)"}
+    if getattr(model.config, "num_experts", 0):
+        res["rows_skipped_router_near_tie"] = near_tie
     if q4:
         res["q4_codes_differing_from_oracle_max_frac"] = round(worst_flip, 5)
         res["oracle"] = "OracleModel.forward(q4_cache=True): cache.py:472-556 semantics, following the device's codes step by step"
@@ -346,6 +367,23 @@ def pmc_traffic_gb(launches_per_step, kernel_prefix: str):
     except Exception:
         pass
     return None, None
+
+
+def profile_frac(alg_bytes_per_launch: float):
+    """roofline.frac_profile: the same fraction from the COMMITTED rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/rNN_kernel_stats.csv, newest round): launch-weighted average duration of the qgemv_* kernels there.  The run's own
+    `frac` (HIP events, this box) and this figure (rocprofv3, the builder's box) side by side make the two boxes visible."""
+    import csv
+    try:
+        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_kernel_stats.csv") and f[1:3].isdigit() and f[3] == "_")
+        if not files:
+            return None, None
+        rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", files[-1]))) if "qgemv_" in r["Name"]]
+        calls = sum(int(r["Calls"]) for r in rows)
+        avg_s = sum(float(r["TotalDurationNs"]) for r in rows) / calls * 1e-9
+        return round(alg_bytes_per_launch / avg_s / 1e9 / HBM_PEAK_GBS, 4), f"profiles/{files[-1]} ({avg_s * 1e6:.2f} us per launch)"
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(cfg, recipe: str, seed: int = 0):
@@ -666,6 +704,28 @@ def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq:
     return out
 
 
+def spawn_ranks(n: int) -> None:
+    """Re-executes this command under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` on 127.0.0.1 (one rank per
+    GPU over RCCL), after checking that n GPUs are there; the child's exit code is ours.  Fails loudly -- exit code 2 and one line
+    on stderr -- when fewer than n devices are visible."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"[bench] --gpus {n}: only {have} GPU(s) visible on this node -- not running (a line with n_gpus < {n} would be "
+              f"mistaken for the {n}-GPU figure)", file=sys.stderr)
+        raise SystemExit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC only on this driver (RCCL peer buffers)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env, cwd=ROOT))
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -674,14 +734,27 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.gpus < 1:
+        raise SystemExit("[bench] --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` (the driver's N = 1 form with a larger N): start the N ranks ourselves, one per GPU, exactly as
+        # the driver's own launcher line does -- never fall through to a one-GPU run that would print an n_gpus = 1 line
+        return spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a figure "
+                         f"for a GPU count that was not asked for")
+    visible = torch.cuda.device_count()
+    if visible < int(os.environ.get("LOCAL_WORLD_SIZE", world)) or local_rank >= visible:
+        raise SystemExit(f"[bench] rank {rank}: {visible} GPU(s) visible, local rank {local_rank} of "
+                         f"{os.environ.get('LOCAL_WORLD_SIZE', world)} needs its own -- one process per GPU, no sharing")
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"[bench] communicator has {dist.get_world_size()} ranks, --gpus {args.gpus}")
     n_gpus = world
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
@@ -716,13 +789,14 @@ def main():
     else:
         t_load = time.perf_counter()
         ck = synth_checkpoint(cfg, device, recipe=args.recipe, seed=0)
-        do_parity = not args.no_parity_check and not getattr(cfg, "num_experts", 0)
-        oracle = oracle_for_parity(cfg, ck) if do_parity else None        # checker; before load() re-lays q_weight out
+        do_parity = not args.no_parity_check
+        moe = bool(getattr(cfg, "num_experts", 0))           # (a sparse-MoE layer = 3 x num_experts matrices to reconstruct on the host: one layer)
+        oracle = oracle_for_parity(cfg, ck, layers=1 if moe else 2) if do_parity else None    # checker; before load() re-lays q_weight out
         t_load = time.perf_counter()
         model = ExLlamaV2(cfg, device=device).load(ck)
         torch.cuda.synchronize()
         t_load = time.perf_counter() - t_load
-        parity = parity_check(model, oracle, device, cache_type=args.cache) if do_parity else None
+        parity = parity_check(model, oracle, device, cache_type=args.cache, batch=args.batch) if do_parity else None
         del oracle
         if args.cache == "q4":
             from exllamav2_amd.cache import ExLlamaV2Cache_Q4
@@ -740,20 +814,28 @@ def main():
             dec.reset(torch.tensor([1] * args.batch), 0)
             dec.run(64, use_graph=not args.no_graph)
             torch.cuda.synchronize()
-        dec.reset(torch.tensor([1] * args.batch), args.ctx)     # KV of the first `ctx` positions = resident (zeros)
-        dec.run(args.warmup, use_graph=not args.no_graph)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dec.run(args.steps, use_graph=not args.no_graph)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        # `--windows` identical timed windows (default 5), each = W untimed warm-up steps then EXACTLY K timed steps between two
+        # device synchronisations, from the same cache position; the reported value is the MEDIAN window (20 steps are 28 ms of
+        # work: one window is inside box noise), every window's rate is printed beside it
+        window_dt = []
+        for _ in range(max(1, args.windows)):
+            dec.reset(torch.tensor([1] * args.batch), args.ctx)     # KV of the first `ctx` positions = resident (zeros)
+            dec.run(args.warmup, use_graph=not args.no_graph)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dec.run(args.steps, use_graph=not args.no_graph)
+            torch.cuda.synchronize()
+            window_dt.append(time.perf_counter() - t0)
+        dt = sorted(window_dt)[len(window_dt) // 2]
+        windows = {"n": len(window_dt), "tokens_per_s": [round(args.batch * args.steps / d, 1) for d in window_dt],
+                   "reported": "median", "spread_pct": round(100.0 * (max(window_dt) - min(window_dt)) / dt, 2)}
         toks = dec.tokens(args.ctx + args.warmup, args.steps)
         assert int(dec.cache_seqlens[0]) == args.ctx + args.warmup + args.steps
         assert int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab_size
 
         if getattr(cfg, "num_experts", 0) or args.batch != 1:
             # MoE / batched runs: headline rate only (the q_gemm roofline figure is defined on configs[1])
-            result = {"value": args.batch * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load}
+            result = {"value": args.batch * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load, "windows": windows}
             if parity is not None: result["parity_check"] = parity
             dec.free()
             return finish(args, cfg, result, rank, world, n_gpus, device, dist)
@@ -766,6 +848,7 @@ def main():
         chained = getattr(dec, "chain", None) is not None
         kname = ("qgemv_lean_kernel<false" if n_lean >= n_flat else "qgemv_flat_kernel<false") if chained else "qgemv_stream_kernel<false, 4"
         traffic_gb, traffic_src = pmc_traffic_gb(launches, kname) if (args.model == "llama2-7b" and args.recipe == "4.0bpw") else (None, None)
+        fp_frac, fp_src = profile_frac(gemv_bytes / launches) if (args.model == "llama2-7b" and args.recipe == "4.0bpw") else (None, None)
         extra = {}
         if chained:
             extra["chain_route_launches"] = {"qgemv_lean_kernel": int(n_lean), "qgemv_flat_kernel": int(n_flat)}
@@ -783,7 +866,7 @@ def main():
             dec.run(64, use_graph=not args.no_graph); torch.cuda.synchronize()
             extra["ctx1920_tokens_per_s"] = round(64 / (time.perf_counter() - t1), 2)
         result = {
-            "value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load,
+            "value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load, "windows": windows,
             "weight_bytes_per_rank": [int(model.weight_bytes())],
             "roofline": {
                 "bound": "hbm", "kernel": (kname.split("<")[0] if chained else "qgemv_stream_kernel<false, MB>") + " (all q_gemm launches of a decode step: fused q|k|v, o, fused gate|up, down per layer + head)",
@@ -793,6 +876,7 @@ def main():
                 "algorithmic_bytes_per_launch": round(gemv_bytes / launches),
                 "traffic_per_step_GB": traffic_gb, "bytes_per_step": gemv_bytes, "launches_per_step": launches,
                 "avg_launch_us": round(gemv_ms * 1e3 / launches, 2),
+                "frac_profile": fp_frac, "frac_profile_source": fp_src,
                 "step_frac_of_weight_roofline": round((gemv_bytes + kv_bytes) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             },
         }
@@ -837,7 +921,7 @@ def finish(args, cfg, result, rank, world, n_gpus, device, dist):
                        "parallelism": "single GPU" if n_gpus == 1 else
                                       result.get("parallelism", f"layer-split pipeline x{n_gpus}, {n_gpus} sequences in flight")},
         }
-        for k in ("roofline", "load_s", "weight_bytes_per_rank", "per_gpu_weight_roofline_frac", "sequences_in_flight", "ranks",
+        for k in ("roofline", "windows", "load_s", "weight_bytes_per_rank", "per_gpu_weight_roofline_frac", "sequences_in_flight", "ranks",
                   "strong_scaling_tp", "parity_check", "extra"):
             if k in result: out[k] = result[k]
         if not args.no_prefill and n_gpus == 1 and args.model == "llama2-7b" and args.batch == 1:

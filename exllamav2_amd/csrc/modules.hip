@@ -159,7 +159,7 @@ struct ChainSyncState { u32* flags; int n_blocks; void* stream[2]; int next; boo
 static thread_local ChainSyncState g_chain = {nullptr, 0, {nullptr, nullptr}, 0, false};
 
 bool chain_sync_active() { return g_chain.open; }
-static int g_chain_tiled = 0;
+static thread_local int g_chain_tiled = 0;      // per host thread, like g_chain: one decoder per thread may switch its layout
 bool chain_xp_tiled() { return g_chain_tiled != 0; }
 
 static u32* chain_block(int k) { return g_chain.flags + (size_t)k * SYNC_BLOCK_WORDS; }
@@ -674,8 +674,23 @@ static int q_mlp_chain_part(void* handle, int part, void* x, const void* xp, con
     // EXL2_MLP_TILED: 0 never, 1 (default) where the rows' staged copy would not fit the LDS, 2 from 5 rows up
     const int tiled_on = []() { const char* e = getenv("EXL2_MLP_TILED"); return e ? atoi(e) : 1; }();     // (per call: tests switch it)
     const int xmem_env = []() { const char* e = getenv("EXL2_LEAN_XMEM"); return e ? atoi(e) : 1; }();
-    const bool tiled = part == 3 && rows > 4 && m->max_rows >= 16 && row0 == 0 && tiled_on > 0 && xmem_env > 0 && lean_enabled() && !chain_sync_active()
-                       && (tiled_on >= 2 || (size_t)rows * (size_t)(inter + 8) * 2 > 150u * 1024u);
+    bool tiled = part == 3 && rows > 4 && m->max_rows >= 16 && row0 == 0 && tiled_on > 0 && xmem_env > 0 && lean_enabled() && !chain_sync_active()
+                 && (tiled_on >= 2 || (size_t)rows * (size_t)(inter + 8) * 2 > 150u * 1024u);
+    if (tiled)
+    {
+        // the tiled hand-off exists in the lean kernel's XMEM form only (one register pass: K up to ~12 k at 4 bits on 16 waves),
+        // and the flat kernel reads no tiled layout: ask for down_proj's plan BEFORE gate | up writes temp_a that way
+        // (rows >= M of a tiled buffer stay unwritten: MFMA rows are independent, nothing reads them)
+        FlatIn probe; memset(&probe, 0, sizeof(probe));
+        probe.qm[0] = m->down; probe.c[0] = (f16*)x; probe.ldc[0] = hidden;
+        probe.n_mats = 1; probe.M = rows; probe.a_mode = A_DIRECT; probe.a = act; probe.lda = inter; probe.c_mode = C_ACCUM;
+        probe.a_tiled = 1; probe.plan_only = 1;
+        probe.xp_out = (f16*)xp_out; probe.xp_invperm = (const u16*)next_invperm; probe.xp_w = (const f16*)next_norm_w;
+        probe.ss_out = xp_out ? ss_out : nullptr; probe.ldxp = hidden;
+        probe.xp_tiled = (xp_out && chain_xp_tiled()) ? 1 : 0;
+        int w = 0;
+        if (qgemv_lean_launch(probe, stream, &w) != 0) tiled = false;
+    }
     if (part & 1)
     {
         EXL2_REQUIRE(xp && ss, "q_mlp_forward_chain: null argument");
@@ -688,7 +703,7 @@ static int q_mlp_chain_part(void* handle, int part, void* x, const void* xp, con
         in.act_gelu = m->act_gelu ? 1 : 0;
         in.c_tiled = tiled ? 1 : 0;
         in.a_tiled = chain_xp_tiled() ? 1 : 0;
-        FLAT_TRY(in, stream, nullptr, "q_mlp_forward_chain");
+        FLAT_TRY(in, stream, nullptr, "q_mlp_forward_chain (gate|up)");
     }
     if (part & 2)
     {
@@ -700,7 +715,7 @@ static int q_mlp_chain_part(void* handle, int part, void* x, const void* xp, con
         in.ss_out = xp_out ? ss_out : nullptr; in.ldxp = hidden;
         in.xp_tiled = (xp_out && chain_xp_tiled()) ? 1 : 0;
         int wgs = 0;
-        FLAT_TRY(in, stream, &wgs, "q_mlp_forward_chain");
+        FLAT_TRY(in, stream, &wgs, "q_mlp_forward_chain (down)");
         if (npart_out) *npart_out = wgs;
     }
     return EXL2_OK;

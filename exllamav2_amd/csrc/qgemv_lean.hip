@@ -1206,29 +1206,39 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
         if (grid_x > cap) grid_x = cap;
     }
     dim3 grid((unsigned)grid_x, (unsigned)(in.pair ? 1 : in.n_mats), 1), block((unsigned)waves * 64, 1, 1);
+    if (in.plan_only) { if (wgs_out) *wgs_out = wgs; return 0; }                      // a caller asking whether this shape is taken (modules.hip)
     if (getenv("EXL2_LEAN_PLAN_ONLY")) { if (wgs_out) *wgs_out = wgs; return 0; }     // test hook: the host plan without the launch (results undefined)
+    int launched = 0;                                                                  // a plan no instantiation below matches must not pass for a launch
     const bool gptq = q0->is_gptq;
     const int occ = LEAN_OCC_DEFAULT;
+#define LEAN_LAUNCH(...) do { launched++; LAUNCH(__VA_ARGS__); } while (0)
 #define LEAN_GO(SS, NS, P, W) \
-    if (rows_mode && !xmem && !gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, 4, true, W>), grid, block, lds, stream, a); \
-    if (rows_mode && !xmem && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, 4, true, W>), grid, block, lds, stream, a);
+    if (rows_mode && !xmem && !gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<false, SS, NS, P, 4, true, W>), grid, block, lds, stream, a); \
+    if (rows_mode && !xmem && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<true, SS, NS, P, 4, true, W>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_ROWS_GEOMETRY(LEAN_GO)
 #undef LEAN_GO
 #define LEAN_GO(SS, NS, P) \
-    if (xmem && !gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, 4, false, false, false, true>), grid, block, lds, stream, a); \
-    if (xmem && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, 4, false, false, false, true>), grid, block, lds, stream, a);
+    if (xmem && !gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<false, SS, NS, P, 4, false, false, false, true>), grid, block, lds, stream, a); \
+    if (xmem && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<true, SS, NS, P, 4, false, false, false, true>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_XMEM_GEOMETRY(LEAN_GO)
 #undef LEAN_GO
 #define LEAN_GO(SS, NS, P, OCC) \
-    if (!rows_mode && !xmem && !dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a); \
-    if (!rows_mode && dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC, false, false, true>), grid, block, lds, stream, a);
+    if (!rows_mode && !xmem && !dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a); \
+    if (!rows_mode && dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC, false, false, true>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_GEOMETRY(LEAN_GO, LEAN_OCC_DEFAULT)
 #undef LEAN_GO
 #define LEAN_GO(SS, NS, P, OCC) \
-    if (!rows_mode && !xmem && !dep && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC>), grid, block, lds, stream, a); \
-    if (!rows_mode && dep && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC, false, false, true>), grid, block, lds, stream, a);
+    if (!rows_mode && !xmem && !dep && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC>), grid, block, lds, stream, a); \
+    if (!rows_mode && dep && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC, false, false, true>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_GEOMETRY(LEAN_GO, 6)
 #undef LEAN_GO
+#undef LEAN_LAUNCH
+    if (launched != 1)
+    {
+        fprintf(stderr, "[exl2] qgemv_lean_launch: plan (S=%d slots=%d pair=%d rows=%d xmem=%d dep=%d gptq=%d) matched %d instantiations\n",
+                S, nslots, in.pair, (int)rows_mode, (int)xmem, (int)dep, (int)gptq, launched);
+        return launched ? -3 : 1;                   // nothing launched: declined (the caller's fallback runs); two: a dispatch bug
+    }
     if (wgs_out) *wgs_out = wgs;
     return 0;
 }

@@ -301,9 +301,10 @@ class GreedyGraphDecoder:
         # attention takes all rows in one launch.  Launches with different K may use different groupings: the number of partial
         # sums of squares per row a producer published must then be the same for all its groups (checked).
         def groups_for(K):
-            if b <= 4 or overlap:
+            g = ch.get("group_override", {}).get(K)            # what a declined launch of this K was regrouped to (_launch_step)
+            if overlap or (b <= 4 and not g):
                 return [(0, b)]
-            g = ch.get("group_rows")
+            g = g or ch.get("group_rows")
             if not g:
                 if not ch.get("group_auto", True):
                     return [(0, b)]
@@ -415,12 +416,20 @@ class GreedyGraphDecoder:
         self._launch_step()
 
     def _launch_step(self):
-        if self.chain is not None:
+        while self.chain is not None:
             try:
                 return self.step_chain()
             except RuntimeError as e:
                 if "not covered" not in str(e):
                     raise
+                # the optimistic grouping (all rows in one launch: the lean kernel's wave-private / ROWS / XMEM forms) is a guess
+                # about what the kernel's host plan accepts -- XMEM is one register pass (K <= ~12 k at 4 bits), the wave-private
+                # form stages rows x K-slice per wave: down_proj of a Mixtral / Llama-3 width (K = 14336) declines 5+ rows, of a
+                # 70B (K = 28672) 3+.  Before giving up the WHOLE chain, regroup the launch kind that declined: row groups of
+                # 4, then 2, then 1.  (a step that failed half-way is simply redone: it starts from the embedding and re-appends
+                # the same cache row)
+                if not self._overlapped() and self._regroup(str(e)):
+                    continue
                 if self._overlapped():
                     # the experimental overlapped mode never falls back silently: a run that asked for it and did not get it
                     # must not be mistaken for a measurement of it
@@ -435,6 +444,20 @@ class GreedyGraphDecoder:
         ext.rms_norm(self.x.view(self.b, -1), m.norm.weight, self.xn.view(self.b, -1), cfg.norm_eps)
         ext.gemm_half_q_half(self.xn.view(self.b, -1), m.lm_head.q_handle, self.logits)
         self._select_token()
+
+    def _regroup(self, msg: str) -> bool:
+        """a chained launch was declined ("<entry point>: shape not covered"): smaller row groups for launches of its K"""
+        cfg = self.model.config
+        if "(down)" in msg: K = cfg.intermediate_size
+        elif "q_attn_forward_2" in msg: K = cfg.num_attention_heads * cfg.head_dim
+        else: K = cfg.hidden_size
+        ov = self.chain.setdefault("group_override", {})
+        cur = ov.get(K) or self.b
+        for g in (4, 2, 1):
+            if g < cur:
+                ov[K] = g
+                return True
+        return False
 
     def _on_stream(self):
         import contextlib

@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 from .cache import ExLlamaV2Cache, ExLlamaV2Cache_Q4, PAGE_SIZE
+from .comm import ring_exchange
 from .model import ExLlamaV2
 from .synth import synth_checkpoint
 
@@ -227,17 +228,14 @@ class PipelineStage:
         (RCCL: wait() is a stream wait; gloo: it blocks the host).  depth 2 on a GPU: issued on the hand-off stream behind
         an event of this tick's compute -- the compute stream does not wait; the next use of pair p (two ticks on) does."""
         nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
-        ops = [dist.P2POp(dist.isend, self.msg_out_buf[p], nxt), dist.P2POp(dist.irecv, self.msg_in_buf[p], prv)]
         if self.comm_stream is None:
             with self._on_stream():
-                for r in dist.batch_isend_irecv(ops):
-                    r.wait()
+                ring_exchange(self.msg_out_buf[p], self.msg_in_buf[p], nxt, prv)
             return
         self.ev_compute[p].record(self.stream)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self.ev_compute[p])      # msg_out[p] produced, msg_in[p] consumed
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
+            ring_exchange(self.msg_out_buf[p], self.msg_in_buf[p], nxt, prv)
             self.ev_comm[p].record(self.comm_stream)
 
     def free(self):
@@ -303,11 +301,12 @@ def run_layer_split_bench(cfg, args, rank: int, world: int, device, ext=None):
     run_pipeline(stage, None, args.steps, t0=base)
     sync()
     dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    tdev = "cpu" if dist.get_backend() == "gloo" else device      # (bookkeeping scalars: host tensors on gloo)
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=tdev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
     # self-check for a driver-run scaling line: every rank reports what it holds
-    wb = torch.tensor([float(stage.model.weight_bytes())], dtype=torch.float64, device=device)
+    wb = torch.tensor([float(stage.model.weight_bytes())], dtype=torch.float64, device=tdev)
     gathered = [torch.zeros_like(wb) for _ in range(world)]
     dist.all_gather(gathered, wb)
     per_rank = [int(g.item()) for g in gathered]

@@ -85,7 +85,7 @@ GPTQ_RECIPES = {"gptq-4bit-128g": 128, "gptq-4bit-32g": 32}     # BASELINE confi
 
 
 def synth_linear_gptq(k: int, n: int, group_size: int, device, gen: torch.Generator, sigma: float = 0.02,
-                      act_order: bool = False) -> dict:
+                      act_order: bool = False, g_idx: torch.Tensor | None = None) -> dict:
     """GPTQ tensor set (module.py:125-130): qweight int32 [K/8, N] (8 nibbles along K per word), qzeros
     int32 [G, N/8] (stored nibble = zero - 1), scales fp16 [G, N], g_idx int32 [K] (shuffled = act-order)."""
     assert k % group_size == 0 and k % 8 == 0 and n % 8 == 0
@@ -99,7 +99,9 @@ def synth_linear_gptq(k: int, n: int, group_size: int, device, gen: torch.Genera
         "scales": (sc * (0.5 + torch.rand(g, n, device=dev, generator=gen))).half(),
     }
     gi = torch.arange(k, device=dev, dtype=torch.int32) // group_size
-    if act_order:
+    if g_idx is not None:                                   # projections of one input share their act-order (same Hessian)
+        gi = g_idx.clone()
+    elif act_order:
         gi = gi[torch.randperm(k, device=dev, generator=gen)]
     w["g_idx"] = gi.contiguous()
     return w
@@ -175,7 +177,9 @@ def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_ord
     if recipe in GPTQ_RECIPES:
         gs = GPTQ_RECIPES[recipe]
         rec = {k: gs for k in RECIPES["4.0bpw"]}
-        make_ = lambda k, n, r, dev, gen, sigma, act, ip=None: synth_linear_gptq(k, n, r, dev, gen, sigma, act)
+        # (`ip`: the tensor set whose act-order this one shares -- GPTQ with desc_act sorts by diag(H), and q/k/v, gate/up see
+        # the same inputs, hence the same H and the same g_idx: AutoGPTQ / the reference's loader module.py:125-130 alike)
+        make_ = lambda k, n, r, dev, gen, sigma, act, ip=None: synth_linear_gptq(k, n, r, dev, gen, sigma, act, g_idx=ip)
     else:
         rec = RECIPES[recipe]
         make_ = lambda k, n, r, dev, gen, sigma, act, ip=None: synth_linear(k, n, r, dev, gen, sigma, act, invperm=ip)
@@ -195,7 +199,8 @@ def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_ord
         gen = gen_for(i + 1)
         p = f"model.layers.{i}"
         ck[f"{p}.self_attn.q_proj"] = make(h, qd, rec["q_proj"], device, gen, s_attn, act_order)
-        ip = ck[f"{p}.self_attn.q_proj"].get("q_invperm") if (shared_perm and act_order) else None
+        shared_of = lambda w: w.get("q_invperm") if "q_invperm" in w else w.get("g_idx")
+        ip = shared_of(ck[f"{p}.self_attn.q_proj"]) if (shared_perm and act_order) else None
         ck[f"{p}.self_attn.k_proj"] = make(h, kvd, rec["k_proj"], device, gen, s_attn, act_order, ip)
         ck[f"{p}.self_attn.v_proj"] = make(h, kvd, rec["v_proj"], device, gen, s_attn, act_order, ip)
         ck[f"{p}.self_attn.o_proj"] = make(qd, h, rec["o_proj"], device, gen, 0.5 / math.sqrt(qd), act_order)
@@ -205,13 +210,13 @@ def synth_checkpoint(cfg, device, recipe: str = "4.0bpw", seed: int = 0, act_ord
             for e in range(cfg.num_experts):
                 q = f"{p}.block_sparse_moe.experts.{e}"
                 ck[f"{q}.w1"] = make(h, inter, rec["gate_proj"], device, gen, s_attn, act_order, ip)
-                if shared_perm and act_order and ip is None: ip = ck[f"{q}.w1"].get("q_invperm")
+                if shared_perm and act_order and ip is None: ip = shared_of(ck[f"{q}.w1"])
                 ck[f"{q}.w3"] = make(h, inter, rec["up_proj"], device, gen, s_attn, act_order, ip)
                 ck[f"{q}.w2"] = make(inter, h, rec["down_proj"], device, gen, 0.5 / math.sqrt(inter), False)
             ck[f"{p}.block_sparse_moe.gate"] = (torch.randn(cfg.num_experts, h, device=device, generator=gen) * s_attn).half()
         else:
             ck[f"{p}.mlp.up_proj"] = make(h, inter, rec["up_proj"], device, gen, s_attn, act_order)
-            ip = ck[f"{p}.mlp.up_proj"].get("q_invperm") if (shared_perm and act_order) else None
+            ip = shared_of(ck[f"{p}.mlp.up_proj"]) if (shared_perm and act_order) else None
             ck[f"{p}.mlp.gate_proj"] = make(h, inter, rec["gate_proj"], device, gen, s_attn, act_order, ip)
             # the reference folds down_proj's act-order into gate/up at load -> identity perm here
             # (down_act_order=True keeps down_proj's own permutation, as on disk: the reference's loader does the folding)

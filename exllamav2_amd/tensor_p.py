@@ -29,6 +29,7 @@ import torch
 import torch.distributed as dist
 
 from .attn import ExLlamaV2Attention
+from .comm import all_gather
 from .linear import ExLlamaV2Linear
 from .model import ExLlamaV2
 from .rmsnorm import ExLlamaV2RMSNorm
@@ -95,7 +96,7 @@ class TPContext:
         if w == 1:
             return local
         buf = self._gather[:w * rows * nl].view(w, rows, nl)
-        dist.all_gather(list(buf.unbind(0)), local.contiguous(), group=self.group)
+        all_gather(list(buf.unbind(0)), local.contiguous(), group=self.group)
         if rows == 1:
             return buf.view(1, w * nl)
         full = self._full[:rows * w * nl].view(rows, w, nl)
@@ -349,12 +350,13 @@ def run_tp_bench(cfg, args, rank: int, world: int, device, ext=None):
     dec.run(args.steps)
     sync()
     dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    tdev = "cpu" if dist.get_backend() == "gloo" else device      # (bookkeeping scalars: host tensors on gloo)
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=tdev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
     toks = dec.tokens(args.ctx + args.warmup, args.steps)
     assert int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab_size
-    wb = torch.tensor([float(model.weight_bytes())], dtype=torch.float64, device=device)
+    wb = torch.tensor([float(model.weight_bytes())], dtype=torch.float64, device=tdev)
     gathered = [torch.zeros_like(wb) for _ in range(world)]
     dist.all_gather(gathered, wb)
     return {"value": args.batch * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "load_s": t_load,

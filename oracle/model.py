@@ -124,12 +124,43 @@ class OracleModel:
             st[side + "_scales"][layer][:, :n_tokens * d // 32] = gs.astype(F16)
         return diff / max(total, 1)
 
+    def moe_mlp(self, x, n, p: str):
+        """ExLlamaV2MoEMLP.forward_torch (moe_mlp.py:255-323): router logits = fp16 linear on the normed rows; softmax in fp32,
+        top-k, renormalise, round to fp16 (oracle.modules.moe_route); per selected expert silu(w1 n) * (w3 n) -> w2, times the
+        routing weight, summed over the experts in index order (index_add_ into a zero fp16 tensor: one fp16 rounding per
+        expert contribution), plus the residual."""
+        c = self.cfg
+        gate = self.w[p + ".block_sparse_moe.gate"]
+        raw = (n.astype(np.float32) @ gate.astype(np.float32).T).astype(F16)
+        wts, mask = OM.moe_route(raw, c.num_experts_per_token)
+        # how close the selection was (checker's bookkeeping, not part of the restated arithmetic): probability gap between the
+        # last selected and the first rejected expert per row.  top-k is discontinuous: a path whose router logit is one fp16
+        # ulp off may legitimately select another expert where this gap is ~ 1e-3, and a comparison must skip such rows.
+        pr = raw.astype(np.float32)
+        pr = np.exp(pr - pr.max(-1, keepdims=True)); pr /= pr.sum(-1, keepdims=True)
+        srt = -np.sort(-pr, axis=-1)
+        k = c.num_experts_per_token
+        self.router_margin = np.minimum(self.router_margin, srt[:, k - 1] - srt[:, k]) if k < srt.shape[1] else self.router_margin
+        out = np.zeros(x.shape, dtype=F16)
+        for e in range(c.num_experts):
+            sel = np.nonzero(mask[:, e])[0]
+            if len(sel) == 0:
+                continue
+            q = f"{p}.block_sparse_moe.experts.{e}"
+            g = self.linear(n[sel], q + ".w1").astype(F16)
+            u = self.linear(n[sel], q + ".w3").astype(F16)
+            d = self.linear(OM.silu_mul(g, u), q + ".w2").astype(F16)
+            d = (d.astype(np.float32) * wts[sel, e].astype(np.float32)[:, None]).astype(F16)
+            out[sel] = (out[sel].astype(np.float32) + d.astype(np.float32)).astype(F16)
+        return (out.astype(np.float32) + x.astype(np.float32)).astype(F16)
+
     def forward(self, ids: np.ndarray, q4_cache: bool = False) -> np.ndarray:
         """ids int [b, q_len] -> logits float64 [b, q_len, vocab] (before the final fp16 rounding)."""
         c = self.cfg
         b, s = ids.shape
         past = self.seq_len
         x = self.w["model.embed_tokens"][ids.reshape(-1)].reshape(b * s, c.hidden_size).astype(F16)
+        self.router_margin = np.full((b * s,), np.inf)       # sparse-MoE layers: min over layers, per row (see moe_mlp)
         for i in range(c.num_hidden_layers):
             p = f"model.layers.{i}"
             n = OM.rms_norm(x, self.w[p + ".input_layernorm"], c.norm_eps)
@@ -158,11 +189,15 @@ class OracleModel:
             a = a.reshape(b * s, c.num_attention_heads * c.head_dim)
             x = (x.astype(np.float64) + self.linear(a, p + ".self_attn.o_proj")).astype(F16)
             n = OM.rms_norm(x, self.w[p + ".post_attention_layernorm"], c.norm_eps)
+            if (p + ".block_sparse_moe.gate") in self.w:
+                x = self.moe_mlp(x, n, p)
+                continue
             g = self.linear(n, p + ".mlp.gate_proj").astype(F16)
             u = self.linear(n, p + ".mlp.up_proj").astype(F16)
             y = OM.silu_mul(g, u)
             x = (x.astype(np.float64) + self.linear(y, p + ".mlp.down_proj")).astype(F16)
         self.seq_len = past + s
+        self.router_margin = self.router_margin.reshape(b, s).min(axis=1)      # per sequence of this call
         n = OM.rms_norm(x, self.w["model.norm"], c.norm_eps)
         logits = self.linear(n, "lm_head")[:, :c.vocab_size]
         return logits.reshape(b, s, c.vocab_size)

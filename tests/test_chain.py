@@ -184,11 +184,48 @@ def test_llama2_70b_widths_stay_on_the_lean_kernel(be, monkeypatch):
     dec.free(); model.unload()
 
 
-@pytest.mark.parametrize("recipe,act_order", [("gptq-4bit-128g", False), ("gptq-4bit-32g", True)])
-def test_chain_decode_gptq(be, recipe, act_order):
+@pytest.mark.parametrize("hidden,inter,heads,kv,recipe,batch", [(4096, 14336, 32, 8, "4.0bpw", 8), (4096, 14336, 32, 8, "4.0bpw", 16),
+                                                                (8192, 28672, 64, 8, "2.5bpw", 8)])
+def test_many_rows_at_wide_intermediate_stay_chained(be, monkeypatch, hidden, inter, heads, kv, recipe, batch):
+    """Llama-3-8B / Mistral / Mixtral-dense widths (intermediate 14336) and 70B widths (28672) at 6..16 sequences: down_proj's K is
+    beyond the lean kernel's one-pass XMEM form, so the optimistic "all rows in one launch" grouping is declined for that launch
+    -- the decoder must regroup (down_proj in row groups of 4) and stay on the chained route, never silently un-chain the whole
+    step (round-4 advisor finding).  Emulator: host plans only; GPU: the real launches, tokens in range."""
+    from exllamav2_amd.config import ExLlamaV2Config
+    if be.is_emu:
+        monkeypatch.setenv("EXL2_LEAN_PLAN_ONLY", "1")
+    cfg = ExLlamaV2Config(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=1, num_attention_heads=heads,
+                          num_key_value_heads=kv, head_dim=128, vocab_size=512, max_seq_len=256, max_input_len=16, max_batch_size=16)
+    ck = synth_checkpoint(cfg, be.device, recipe=recipe, seed=0)
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    cache = ExLlamaV2Cache(model, batch_size=batch)
+    dec = GreedyGraphDecoder(model, cache, batch_size=batch)
+    assert dec.chain is not None
+    be.ext.chain_route_counts(reset=True)
+    dec.reset(torch.arange(3, 3 + batch), 0)
+    dec.run(1, use_graph=False)
+    lean, flat = be.ext.chain_route_counts(reset=True)
+    assert dec.chain is not None, "the decoder left the chained route"
+    g = dec.chain.get("group_override", {}).get(inter)
+    assert g in (1, 2, 4) and set(dec.chain["group_override"]) == {inter}   # down_proj regrouped, the other launches kept all rows
+    assert flat == 0 and lean >= 5, (lean, flat)
+    be.ext.chain_route_counts(reset=True)
+    dec.run(1, use_graph=False)                                           # a settled step: q|k|v, o, gate|up, down x groups, head
+    lean, flat = be.ext.chain_route_counts(reset=True)
+    assert (lean, flat) == (4 + -(-batch // g), 0), (lean, flat)
+    if not be.is_emu:
+        tok = be.n(dec.tokens(0, 2))
+        assert tok.min() >= 0 and tok.max() < cfg.vocab_size
+    dec.free(); model.unload()
+
+
+@pytest.mark.parametrize("recipe,act_order,shared", [("gptq-4bit-128g", False, True), ("gptq-4bit-32g", True, True),
+                                                     ("gptq-4bit-32g", True, False)])
+def test_chain_decode_gptq(be, recipe, act_order, shared):
     cfg = tiny_cfg(num_attention_heads=4, num_key_value_heads=2, intermediate_size=384)
-    # GPTQ act-order permutations are derived per matrix from g_idx: synthetic ones differ between q/k/v -> unchained
-    _decode_and_check(be, cfg, recipe, 2, seed=13, act_order=act_order, expect_chain=not act_order)
+    # GPTQ act-order (desc_act) permutations are derived per matrix from g_idx: q/k/v (gate/up) of a real checkpoint share it
+    # (same inputs, same Hessian) -> chained; three different shuffles (format-legal) -> the module-by-module route
+    _decode_and_check(be, cfg, recipe, 2, seed=13, act_order=act_order, expect_chain=shared or not act_order, shared_perm=shared)
 
 
 def test_distinct_permutations_fall_back(be):

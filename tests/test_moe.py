@@ -123,3 +123,92 @@ def test_moe_model_forward(be):
     assert model.weight_bytes() == dense + experts // 4 * 2 + moe.gate.numel() * 2
     model.unload()
 
+
+
+@pytest.mark.parametrize("batch", [1, 3, 16])
+def test_moe_model_equals_oracle(be, batch):
+    """A Mixtral-style model (8 experts, top 2, 3.5 bpw mixed widths) against OracleModel's restatement of the reference's torch
+    route (moe_mlp.py:255-323): prompt logits through model.forward, then decode steps of `batch` different sequences through the
+    graph decoder (batch 16 = BASELINE configs[4]'s row count: the grouped-expert launches).  Sequences whose expert selection
+    was a near tie in the oracle are skipped (top-k is discontinuous) -- and must be few."""
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.synth import synth_checkpoint
+    from exllamav2_amd.model import ExLlamaV2, GreedyGraphDecoder
+    from exllamav2_amd.cache import ExLlamaV2Cache
+    from oracle.model import OracleModel
+    cfg = ExLlamaV2Config(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                          num_key_value_heads=1, head_dim=64, vocab_size=96, max_seq_len=256, max_input_len=32,
+                          max_batch_size=16, num_experts=8, num_experts_per_token=2, arch="mixtral")
+    ck = synth_checkpoint(cfg, be.device, recipe="3.5bpw", seed=11)
+    oracle = OracleModel(cfg, ck)
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    cache = ExLlamaV2Cache(model, batch_size=batch, max_seq_len=256)
+    ids = (np.array([[5, 17, 42, 7]]) + 13 * np.arange(batch)[:, None]) % cfg.vocab_size
+    oracle.reset(batch)
+    skipped, compared = 0, 0
+
+    def compare(got, want):
+        nonlocal skipped, compared
+        ok = oracle.router_margin > 2e-3
+        skipped += int((~ok).sum()); compared += int(ok.sum())
+        err, tol = np.abs(got - want)[ok], (0.03 + np.abs(want) * 2.0 ** -8)[ok]
+        assert np.all(err <= tol), float((err / tol).max())
+
+    want = oracle.forward(ids)[:, -1]
+    compare(be.n(model.forward(torch.from_numpy(ids), cache)).astype(np.float64)[:, -1], want)
+    tok = want.argmax(-1).astype(np.int64)
+    dec = GreedyGraphDecoder(model, cache, batch_size=batch)
+    if not be.is_emu:
+        dec.capture()
+    dec.reset(torch.from_numpy(tok), ids.shape[1])
+    for step in range(4):
+        dec.run(1, use_graph=not be.is_emu)
+        want = oracle.forward(tok[:, None])[:, -1]
+        compare(be.n(dec.logits).astype(np.float64)[:, :cfg.vocab_size], want)
+        tok = be.n(dec.tokens(ids.shape[1] + step, 1))[:, 0].astype(np.int64)
+    assert compared >= 4 * batch and skipped * 5 <= compared, (compared, skipped)
+    dec.free()
+    model.unload()
+
+
+@pytest.mark.gpu
+def test_moe_layer_mixtral_widths():
+    """BASELINE configs[4] at its real widths: ONE Mixtral-8x7B sparse-MoE block (hidden 4096, intermediate 14336, 8 experts,
+    top 2, the 3.5 bpw recipe's mixed 4/3-bit matrices), rows 1 / 4 / 16 (single launches per expert, the <= 4-row fused form,
+    the grouped-expert route) against OracleModel.moe_mlp (moe_mlp.py:255-323 semantics).  ~1 minute of host time for the 24
+    reconstructs."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import dataclasses
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.synth import synth_checkpoint
+    from exllamav2_amd.model import ExLlamaV2
+    from oracle.model import OracleModel
+    from oracle import modules as OMod
+    cfg = dataclasses.replace(ExLlamaV2Config.mixtral_8x7b(max_seq_len=256, max_input_len=16, max_batch_size=16),
+                              num_hidden_layers=1, vocab_size=512)
+    ck = synth_checkpoint(cfg, "cuda:0", recipe="3.5bpw", seed=3)
+    oracle = OracleModel(cfg, ck)
+    model = ExLlamaV2(cfg, device="cuda:0").load(ck)
+    moe = model.layers[0][1]
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for rows in (1, 4, 16):
+        x = rng.standard_normal((rows, cfg.hidden_size)).astype(F16)
+        n = OMod.rms_norm(x, oracle.w["model.layers.0.post_attention_layernorm"], cfg.norm_eps)
+        oracle.router_margin = np.full((rows,), np.inf)
+        want = oracle.moe_mlp(x, n, "model.layers.0").astype(np.float64)
+        ok = oracle.router_margin > 2e-3
+        xt = torch.from_numpy(x).to("cuda:0").view(rows, 1, -1).contiguous()
+        moe.forward(xt)
+        torch.cuda.synchronize()
+        got = xt.view(rows, -1).float().cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(got))
+        err, tol = np.abs(got - want)[ok], (np.abs(want) * 2.0 ** -8 + 8e-3)[ok]
+        assert ok.sum() >= max(1, rows - 2), "too many router near-ties"
+        assert np.all(err <= tol), (rows, float(err.max()), float((err / tol).max()))
+        # the update itself (not only the residual passed through): the MoE output has a visible magnitude
+        assert np.abs(want - x.astype(np.float64)).mean() > 0.02
+        worst = max(worst, float((err / tol).max()))
+    print(f"mixtral-width MoE block: worst error / tolerance = {worst:.3f}")
+    model.unload()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds the stand-alone probes for gfx950 (hipcc cross-compiles without a GPU).  The binaries are git-ignored but travel to
 # the GPU box with the gpurun snapshot: run this in the build container before a GPU call that uses them
-# (tools/gpu_round3_first.sh does).
+# (tools/gpu_run.sh STAGES=probes runs them).
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
