@@ -166,7 +166,7 @@ def test_moe_model_equals_oracle(be, batch):
         want = oracle.forward(tok[:, None])[:, -1]
         compare(be.n(dec.logits).astype(np.float64)[:, :cfg.vocab_size], want)
         tok = be.n(dec.tokens(ids.shape[1] + step, 1))[:, 0].astype(np.int64)
-    assert compared >= 4 * batch and skipped * 5 <= compared, (compared, skipped)
+    assert compared >= 4 * batch and skipped <= max(1, compared // 5), (compared, skipped)
     dec.free()
     model.unload()
 
