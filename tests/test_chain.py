@@ -421,6 +421,32 @@ def test_gemm_chain_norm_pre(be, rows, spec_name, monkeypatch):
     be.ext.free_q_matrix(h)
 
 
+@pytest.mark.parametrize("rows", [1, 4])
+def test_lean_kernel_identity_rows_equal_reconstruct(be, rows):
+    """The reference's own parity relation (tests/test_gemv.py:136-165: gemm(I) == reconstruct()) on the CHAINED decode kernel,
+    bit for bit: one-hot activation rows through exl2_gemm_half_q_half_chain with sum(x^2) = K and eps = 0 (the epilogue's
+    1 / rms factor is exactly 1) must return the rows of reconstruct(): 5-bit and 4-bit sections, one scale per item (g128: the scale
+    on the fp32 partial sum) and a scale per chunk (g32 / g64: on the weights).  (Written for round 5's raw 4-bit feed experiment,
+    profiles/r05_raw4_experiment.txt, which it passed; kept because the chained kernel had no such test.)"""
+    k, n = 1024, 96
+    spec = [(5, 128, 128), (4, 128, 512), (4, 32, 256), (4, 64, 128)]
+    t, ref, w, h = _mk(be, k, n, spec, 77)
+    perm = np.argsort(t["q_invperm"]).astype(np.int64)                 # packed row i holds input feature perm[i]
+    eye = np.eye(k, dtype=np.float16)
+    ss = np.full((rows, 1), float(k), dtype=np.float32)
+    picks = range(0, k, rows) if not be.is_emu else list(range(0, 160, rows)) + list(range(k - 416, k, 7 * rows))
+    for r0 in picks:
+        idx = [(r0 + i) % k for i in range(rows)]
+        c = torch.zeros((rows, n), dtype=torch.float16, device=be.device)
+        be.ext.gemm_half_q_half_chain(be.t(eye[idx]), be.t(ss), 1, 0.0, h, c, rows)
+        got = be.n(c)
+        want = ref[perm[idx]]
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (r0, np.abs(got.astype(np.float32) - want.astype(np.float32)).max())
+    lean, flat = be.ext.chain_route_counts(reset=True)
+    assert flat == 0 and lean > 0
+    be.ext.free_q_matrix(h)
+
+
 @pytest.mark.parametrize("case", ["outliers", "tiny", "saturating"])
 def test_gemm_chain_norm_pre_extreme_activations(be, case):
     """The chained hand-off stores fp16(clamp(x * w)) and scales the finished sums by 1 / rms(x), where the reference's rms_norm

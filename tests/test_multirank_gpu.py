@@ -115,7 +115,7 @@ def test_tensor_parallel_two_ranks_real_library(tmp_path):
     from exllamav2_amd.synth import synth_checkpoint
     from oracle.model import OracleModel
     cfg = _cfg()
-    oracle = OracleModel(cfg, synth_checkpoint(cfg, "cpu", seed=9))
+    oracle = OracleModel(cfg, synth_checkpoint(cfg, "cuda:0", seed=9))      # (the device generator's stream, like the ranks')
     oracle.reset(1)
     want = oracle.forward(np.array([PROMPT]))
     assert np.abs(l0.astype(np.float64) - want).max() < LOGIT_TOL
