@@ -293,7 +293,7 @@ int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
     // per-expert launch loop below (3 launches per expert: q_mlp.cu:318-402 has the same shape, moe_mlp.py:255-323 a
     // Python loop above 4 rows).
     if (m->group_ok && rows <= MAX_GEMV_ROWS && 2 * MAX_GEMV_ROWS <= m->max_rows && (long long)E * rows <= m->max_rows &&
-        (long long)E * rows * hidden <= (long long)m->max_rows * inter && !getenv("EXL2_MOE_SERIAL"))
+        (long long)E * rows * hidden <= (long long)m->max_rows * inter && !getenv("EXL2_MOE_SERIAL") && !getenv("EXL2_MOE_NO_GROUP"))
     {
         if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: grouped rows=%d experts=%d\n", rows, E);
         f16* xg = m->temp_state + (size_t)MAX_GEMV_ROWS * hidden;           // normalised rows in the experts' packed order
@@ -330,6 +330,54 @@ int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
             // (the gate|up launch wrote only temp_a: the serial route below recomputes everything)
         }
         else if (rc < 0) EXL2_FAIL(EXL2_E_INVALID, "q_moe_mlp_forward_: grouped gate|up launch rejected (%d)", rc);
+    }
+    // ---- batched route (round 5; rows <= 16 the grouped launch declined: Mixtral's 16 x 14336 down_proj rows do not fit its LDS):
+    // the experts on the streaming / phased kernels like the serial loop below, but (1) gate and up read the rows gathered ONCE into
+    // the experts' shared packed order (no row pre-pass per launch: it was 8 of the 18 stage_rows launches of a Mixtral layer, 7.3 us
+    // each -- profiles/r05g_mixtral_b16_kernel_stats.csv), (2) two experts' gate | up and four experts' down per launch
+    // (MAX_FUSED_MATS jobs: 6 launches + 2 pre-passes instead of 16 + 16), (3) every expert's SiLU(gate) * up and weighted down
+    // output in its own rows of the scratch, summed by moe_combine_kernel (fp32, expert order) instead of 8 read-modify-writes of x.
+    if (m->group_ok && rows <= MAX_GEMV_ROWS && (long long)E * rows <= m->max_rows && (E & 3) == 0 &&
+        (long long)E * rows * ((long long)inter + hidden) <= (long long)m->max_rows * inter &&
+        (long long)(MAX_GEMV_ROWS + rows) * hidden <= (long long)m->max_rows * hidden && !getenv("EXL2_MOE_SERIAL") && !getenv("EXL2_MOE_UNBATCHED"))
+    {
+        if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: batched rows=%d experts=%d\n", rows, E);
+        f16* xg = m->temp_state + (size_t)MAX_GEMV_ROWS * hidden;           // normalised rows in the experts' packed order
+        LAUNCH(gather_rows_f16_kernel, dim3((unsigned)((hidden + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
+               (const f16*)m->temp_state, (const u16*)m->w1[0]->q_perm, xg, hidden);
+        f16* const dout = m->temp_b + (size_t)E * rows * inter;              // [E][rows][hidden] weighted down outputs
+        for (int e0 = 0; e0 < E; e0 += 2)
+        {
+            GemvJob jobs[4];
+            for (int i = 0; i < 4; i++)
+            {
+                const int e = e0 + (i >> 1);
+                f16* const out = ((i & 1) ? m->temp_b : m->temp_a) + (size_t)e * rows * inter;
+                fill_job(jobs[i], (i & 1) ? m->w3[e] : m->w1[e], xg, out, A_PLAIN, C_STORE);
+                jobs[i].m.perm = nullptr;                                    // (the rows ARE in packed order)
+                jobs[i].r_weights = m->temp_logits + e; jobs[i].r_stride = E; jobs[i].mul_r_weights = 0;
+                if (m->w2[e]->dev.perm && m->w2[e]->q_invperm) jobs[i].c_invperm = m->w2[e]->q_invperm;
+            }
+            LAUNCH_JOBS(jobs, 4, rows, m->w1[e0]->is_gptq, stream, "q_moe_mlp_forward_");
+        }
+        for (int e0 = 0; e0 < E; e0 += 4)
+        {
+            GemvJob jobs[4];
+            for (int i = 0; i < 4; i++)
+            {
+                const int e = e0 + i;
+                fill_job(jobs[i], m->w2[e], m->temp_a + (size_t)e * rows * inter, dout + (size_t)e * rows * hidden,
+                         m->act_gelu ? A_GELU_MUL : A_SILU_MUL, C_STORE);
+                jobs[i].a2 = m->temp_b + (size_t)e * rows * inter;
+                jobs[i].r_weights = m->temp_logits + e; jobs[i].r_stride = E; jobs[i].mul_r_weights = 1;
+                if (m->w2[e]->dev.perm && m->w2[e]->q_invperm) jobs[i].m.perm = nullptr;
+            }
+            LAUNCH_JOBS(jobs, 4, rows, m->w2[e0]->is_gptq, stream, "q_moe_mlp_forward_");
+        }
+        LAUNCH(moe_combine_kernel, dim3((unsigned)((hidden / 8 + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
+               x, (const f16*)dout, (const f16*)m->temp_logits, rows, hidden, E);
+        HIP_TRY(hipGetLastError());
+        return EXL2_OK;
     }
     for (int r0 = 0; r0 < rows; r0 += MAX_GEMV_ROWS)
     {

@@ -28,15 +28,23 @@ def test_moe_route(be, experts, topk):
     assert np.allclose(got.astype(np.float32).sum(-1), 1.0, atol=2e-3)
 
 
+@pytest.mark.parametrize("route", ["default", "batched"])
 @pytest.mark.parametrize("shared_perm", [True, False])
 @pytest.mark.parametrize("rows", [1, 3, 16, 21])
-def test_moe_mlp_forward(be, rows, shared_perm):
+def test_moe_mlp_forward(be, rows, shared_perm, route, monkeypatch):
     """Every expert's kernels see all rows; rows not routed to it are skipped, launches with no routed row exit.
     rows = 16 is BASELINE config 5's decode batch (the reference falls back to a torch loop above 4 rows).
     shared_perm: every expert's w1 / w3 carry ONE act-order permutation, as the quantizer writes them
     (conversion/quantize.py:190-192) -> the grouped route (all experts in one launch per projection stage) for rows <= 16;
     per-matrix permutations (format-legal, never produced) -> the per-expert launch loop."""
     from tests.util import exl2_to_torch
+    if route == "batched":
+        # round 5: what a Mixtral layer takes at 5..16 rows (the grouped launch declines its 16 x 14336 down_proj rows): experts on the
+        # streaming / phased kernels, rows gathered once, 2 (gate | up) / 4 (down) experts per launch, outputs summed by the combine
+        if not shared_perm or rows > 16:
+            pytest.skip("the batched route needs the experts' shared permutation and <= 16 rows")
+        monkeypatch.setenv("EXL2_MOE_NO_GROUP", "1")
+        monkeypatch.setenv("EXL2_DEBUG_ROUTE", "1")
     rng = np.random.default_rng(31)
     E, topk, hidden, inter = 8, 2, 128, 256
     spec_up = [(5, 32, 32), (4, 32, hidden - 32)]
