@@ -29,6 +29,9 @@ int exl2_rope_qk(void* x_q, void* x_k, const void* sin, const void* cos, int bat
 int exl2_act_mul(void* x, const void* y, int rows, int width, int act_gelu,
                  const void* r_weights, int r_weights_stride, void* stream);
 int exl2_moe_route(const void* x, const void* gate, void* logits, int rows, int hidden, int num_experts, int topk, void* stream);
+// (library-internal, moe.hip: not part of include/exl2_hip.h -- the boundary is q_moe_mlp_forward_)
+int exl2_moe_front(const void* x, const void* norm_w, const void* gate, const void* perm, void* xn, void* xg, void* logits,
+                   int rows, int hidden, int num_experts, int topk, float eps, void* stream);
 }
 
 static void fill_job(GemvJob& j, const QMatrix* qm, const f16* a, f16* c, int a_mode, int c_mode)
@@ -285,9 +288,29 @@ int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
     EXL2_REQUIRE(rows <= m->max_rows, "q_moe_mlp_forward_: %d rows exceed max_rows %d", rows, m->max_rows);
     const int E = m->num_experts, hidden = m->hidden;
     f16* x = (f16*)x_;
-    { const int rc = exl2_rms_norm(x, m->layernorm, m->temp_state, m->norm_epsilon, rows, hidden, 0, 0, 0, stream); if (rc) return rc; }
-    { const int rc = exl2_moe_route(m->temp_state, m->gate, m->temp_logits, rows, hidden, E, m->num_experts_per_token, stream); if (rc) return rc; }
     const int inter = m->w1[0]->width;
+    // decode-sized row counts whose experts share their act-order: norm + router + top-k + gather in ONE launch (moe.hip:
+    // moe_front_kernel, bit-identical to the four kernels it replaces); otherwise the separate kernels
+    bool have_xg = false;
+    f16* const xg = m->temp_state + (size_t)MAX_GEMV_ROWS * hidden;       // normalised rows in the experts' packed order
+    const bool xg_room = m->group_ok && rows <= MAX_GEMV_ROWS && 2 * MAX_GEMV_ROWS <= m->max_rows;
+    int front = 1;
+    if (xg_room && !getenv("EXL2_MOE_UNFUSED_FRONT"))
+        front = exl2_moe_front(x, m->layernorm, m->gate, m->w1[0]->q_perm, m->temp_state, xg, m->temp_logits, rows, hidden, E,
+                               m->num_experts_per_token, m->norm_epsilon, stream);
+    if (front < 0) return front;
+    if (front == 0) have_xg = true;
+    else
+    {
+        { const int rc = exl2_rms_norm(x, m->layernorm, m->temp_state, m->norm_epsilon, rows, hidden, 0, 0, 0, stream); if (rc) return rc; }
+        { const int rc = exl2_moe_route(m->temp_state, m->gate, m->temp_logits, rows, hidden, E, m->num_experts_per_token, stream); if (rc) return rc; }
+    }
+    auto make_xg = [&]() {
+        if (!have_xg)
+            LAUNCH(gather_rows_f16_kernel, dim3((unsigned)((hidden + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
+                   (const f16*)m->temp_state, (const u16*)m->w1[0]->q_perm, xg, hidden);
+        have_xg = true;
+    };
     // ---- grouped route (rows <= 16): all experts' gate|up in ONE launch (SiLU * up in the epilogue, written in each down
     // projection's packed order), all experts' down in ONE launch (weighted partial outputs), one combine.  Replaces the
     // per-expert launch loop below (3 launches per expert: q_mlp.cu:318-402 has the same shape, moe_mlp.py:255-323 a
@@ -296,9 +319,7 @@ int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
         (long long)E * rows * hidden <= (long long)m->max_rows * inter && !getenv("EXL2_MOE_SERIAL") && !getenv("EXL2_MOE_NO_GROUP"))
     {
         if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: grouped rows=%d experts=%d\n", rows, E);
-        f16* xg = m->temp_state + (size_t)MAX_GEMV_ROWS * hidden;           // normalised rows in the experts' packed order
-        LAUNCH(gather_rows_f16_kernel, dim3((unsigned)((hidden + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
-               (const f16*)m->temp_state, (const u16*)m->w1[0]->q_perm, xg, hidden);
+        make_xg();
         FlatIn ins[MOE_MAX_EXPERTS];
         for (int e = 0; e < E; e++)
         {
@@ -342,9 +363,7 @@ int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
         (long long)(MAX_GEMV_ROWS + rows) * hidden <= (long long)m->max_rows * hidden && !getenv("EXL2_MOE_SERIAL") && !getenv("EXL2_MOE_UNBATCHED"))
     {
         if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: batched rows=%d experts=%d\n", rows, E);
-        f16* xg = m->temp_state + (size_t)MAX_GEMV_ROWS * hidden;           // normalised rows in the experts' packed order
-        LAUNCH(gather_rows_f16_kernel, dim3((unsigned)((hidden + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
-               (const f16*)m->temp_state, (const u16*)m->w1[0]->q_perm, xg, hidden);
+        make_xg();
         f16* const dout = m->temp_b + (size_t)E * rows * inter;              // [E][rows][hidden] weighted down outputs
         for (int e0 = 0; e0 < E; e0 += 2)
         {

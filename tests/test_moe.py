@@ -220,3 +220,29 @@ def test_moe_layer_mixtral_widths():
         worst = max(worst, float((err / tol).max()))
     print(f"mixtral-width MoE block: worst error / tolerance = {worst:.3f}")
     model.unload()
+
+
+@pytest.mark.parametrize("rows", [1, 4, 16])
+def test_moe_fused_front_is_bit_identical(be, rows, monkeypatch):
+    """Round 5: norm + router logits + top-k + row gather in ONE launch (csrc/moe.hip: moe_front_kernel) keeps the arithmetic and
+    the summation order of the four kernels it replaces -- same routing weights, same block output, bit for bit
+    (EXL2_MOE_UNFUSED_FRONT=1 = the separate kernels)."""
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.synth import synth_checkpoint
+    from exllamav2_amd.model import ExLlamaV2
+    cfg = ExLlamaV2Config(hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=4,
+                          num_key_value_heads=2, head_dim=64, vocab_size=96, max_seq_len=256, max_input_len=32,
+                          max_batch_size=16, num_experts=8, num_experts_per_token=2, arch="mixtral")
+    ck = synth_checkpoint(cfg, be.device, recipe="3.5bpw", seed=21)
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    moe = model.layers[0][1]
+    x = torch.from_numpy(np.random.default_rng(rows).standard_normal((rows, 1, cfg.hidden_size)).astype(np.float16)).to(be.device)
+    outs = []
+    for unfused in ("0", "1"):
+        if unfused == "1": monkeypatch.setenv("EXL2_MOE_UNFUSED_FRONT", "1")
+        y = x.clone()
+        moe.forward(y)
+        outs.append((be.n(y).copy(), be.n(moe.temp_logits[:rows]).copy()))
+    assert np.array_equal(outs[0][1].view(np.uint16), outs[1][1].view(np.uint16))      # routing weights
+    assert np.array_equal(outs[0][0].view(np.uint16), outs[1][0].view(np.uint16))      # block output
+    model.unload()
