@@ -11,13 +11,36 @@ from exllamav2_amd.synth import synth_linear
 MFMA_PEAK_F16 = 2500.0          # dense TFLOP/s, MI355X_MICROARCH.md
 
 
-def _time(fn, reps):
-    fn(); torch.cuda.synchronize()
+def _time_once(fn):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)
+
+
+def _interleaved(fns: dict, rounds: int, ramp_s: float = 1.0):
+    """{name: [ms, ...]}: every variant once per round, `rounds` rounds, after a clock ramp on the first one -- a variant is never
+    timed as a block of its own (round 4's file had the SAME kernel at 973 and 1031 TFLOP/s: run order and clock state, not code).
+    The figure to quote is the MEDIAN; min is the clock's best case."""
+    first = next(iter(fns.values()))
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < ramp_s:
+        first()
+    torch.cuda.synchronize()
+    for fn in fns.values():
+        fn()
+    torch.cuda.synchronize()
+    out = {k: [] for k in fns}
+    for _ in range(rounds):
+        for k, fn in fns.items():
+            out[k].append(_time_once(fn))
+    return out
+
+
+def _stat(ms_list, flops):
+    ms = sorted(ms_list)
+    med, best = ms[len(ms) // 2], ms[0]
+    return {"ms": round(med, 4), "ms_min": round(best, 4), "TFLOPs": round(flops / med / 1e9, 1), "TFLOPs_best": round(flops / best / 1e9, 1),
+            "frac_mfma_peak": round(flops / med / 1e9 / MFMA_PEAK_F16, 4), "reps": len(ms)}
 
 
 # kernel selection of csrc/qgemm_prefill.hip's host driver (read per call): the shipped choice, each tile height of the
@@ -27,30 +50,42 @@ VARIANTS = {"auto": {}, "tile256_mt8": {"EXL2_PREFILL_MT": "8"}, "tile256_mt4": 
             "decode_in_gemm": {"EXL2_PREFILL_WPRE_MIN_ROWS": "0"}}       # round 3: >= 2048 rows decode the weights once per call (auto)
 
 
-def bench_linear(k, n, m, recipe, reps=5, variants=("auto", "tile256_mt8", "tile256_mt4", "tile128")):
+def bench_linear(k, n, m, recipe, reps=20, variants=("auto", "tile256_mt8", "tile256_mt4", "tile128")):
     gen = torch.Generator(device="cuda"); gen.manual_seed(0)
     w = synth_linear(k, n, recipe, "cuda", gen)
     h = ext.make_q_matrix_from_dict(w, none_tensor)
     a = torch.randn((m, k), device="cuda", dtype=torch.float16)
     c = torch.empty((m, n), device="cuda", dtype=torch.float16)
-    out = {"k": k, "n": n, "m": m, "recipe": str(recipe)}
+    wd = torch.empty((k, n), device="cuda", dtype=torch.float16)
+    out = {"k": k, "n": n, "m": m, "recipe": str(recipe), "timing": f"interleaved rounds, {reps} per variant, median (and min)"}
+    flops = 2.0 * m * k * n
+    keys = ("EXL2_PREFILL_MT", "EXL2_PREFILL_MFMA_MIN_ROWS", "EXL2_PREFILL_WPRE_MIN_ROWS")
+
+    def variant(name):
+        def run():
+            for key in keys: os.environ.pop(key, None)
+            os.environ.update(VARIANTS[name])                # (the host driver reads its switches per call)
+            ext.gemm_half_q_half(a, h, c)
+        return run
+
+    def lib():
+        # the reference's method for M > 32: reconstruct + fp16 library GEMM (q_gemm.cu:243-263), here torch.matmul = hipBLASLt
+        ext.reconstruct(h, wd); torch.matmul(a, wd, out=c)
+
+    fns = {name: variant(name) for name in variants}
+    fns["reconstruct_plus_hipblaslt"] = lib
+    times = _interleaved(fns, reps)
+    for key in keys: os.environ.pop(key, None)
     ref = None
     for name in variants:
-        for key in ("EXL2_PREFILL_MT", "EXL2_PREFILL_MFMA_MIN_ROWS", "EXL2_PREFILL_WPRE_MIN_ROWS"): os.environ.pop(key, None)
-        os.environ.update(VARIANTS[name])
-        ms = _time(lambda: ext.gemm_half_q_half(a, h, c), reps)
-        out[name] = {"ms": round(ms, 4), "TFLOPs": round(2.0 * m * k * n / ms / 1e9, 1),
-                     "frac_mfma_peak": round(2.0 * m * k * n / ms / 1e9 / MFMA_PEAK_F16, 4)}
+        out[name] = _stat(times[name], flops)
+        fns[name](); torch.cuda.synchronize()
         if ref is None: ref = c.clone()
         else: out[name]["max_abs_diff_vs_auto"] = float((c.float() - ref.float()).abs().max())
-    for key in ("EXL2_PREFILL_MT", "EXL2_PREFILL_MFMA_MIN_ROWS", "EXL2_PREFILL_WPRE_MIN_ROWS"): os.environ.pop(key, None)
-    # the reference's method for M > 32: reconstruct + fp16 library GEMM (q_gemm.cu:243-263), here torch.matmul = hipBLASLt
-    wd = torch.empty((k, n), device="cuda", dtype=torch.float16)
-    def lib():
-        ext.reconstruct(h, wd); torch.matmul(a, wd, out=c)
-    ms_ref = _time(lib, reps)
-    out["reconstruct_plus_hipblaslt"] = {"ms": round(ms_ref, 4), "TFLOPs": round(2.0 * m * k * n / ms_ref / 1e9, 1)}
-    out["auto_speedup_vs_reconstruct_gemm"] = round(ms_ref / out[variants[0]]["ms"], 3)
+    for key in keys: os.environ.pop(key, None)
+    out["reconstruct_plus_hipblaslt"] = _stat(times["reconstruct_plus_hipblaslt"], flops)
+    lib(); torch.cuda.synchronize()
+    out["auto_speedup_vs_reconstruct_gemm"] = round(out["reconstruct_plus_hipblaslt"]["ms"] / out[variants[0]]["ms"], 3)
     out["max_abs_diff_lib_vs_auto"] = float((c.float() - ref.float()).abs().max())
     ext.free_q_matrix(h)
     return out
@@ -85,7 +120,7 @@ if __name__ == "__main__":
     ap.add_argument("--model", action="store_true")
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--variants", default="auto,tile256_mt8,tile256_mt4,tile128", help="kernel selections to time (first = the baseline)")
-    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=20)
     args = ap.parse_args()
     if args.model:
         print(json.dumps(bench_model(layers=args.layers or None)), flush=True)
