@@ -43,6 +43,9 @@
 #ifndef LEAN_KILL
 #define LEAN_KILL 0                   // instruction-count / timing experiments (results are WRONG): 1 no decode (the loads vanish too), 4 no epilogue, 8 loads kept, decode = xor
 #endif
+#ifndef LEAN_REPEAT
+#define LEAN_REPEAT 0                 // timing experiment (results are WRONG): > 0 = the decode of a wave's share runs that many times
+#endif
 #ifndef LEAN_LOWBITS
 #define LEAN_LOWBITS 1                // 0: no 2 / 3-bit register stream (code-size experiment; such segments would be wrong)
 #endif
@@ -640,6 +643,15 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         }
         else
         {
+#if LEAN_REPEAT
+            // timing experiment (results are WRONG: every sum is taken LEAN_REPEAT times): the decode of the wave's share runs again
+            // on the same registers -- the further passes find their code in the instruction cache and their data landed, so what they
+            // add is the decode's pure execution time (profiles/r05_repeat_experiment.txt)
+            u32 reps_ = LEAN_REPEAT; pin_scalar(reps_);
+            #pragma nounroll
+            for (u32 rep_ = 0; rep_ < reps_; rep_++)
+            {
+#endif
             #pragma unroll
             for (int q = 0; q < DA; q++) if (q < nA) item(a[q], q);
             if constexpr (NB > 0)
@@ -647,6 +659,9 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                 #pragma unroll
                 for (int q = 0; q < NB; q++) item(b[q], nA + q);
             }
+#if LEAN_REPEAT
+            }
+#endif
         }
         // more items than the wave's registers hold (K = 28672 split over 16 waves: 14-15 items of 3 bits): further passes of D
         // items, each its own round trip -- only the 16-wave geometry, the last one the host tries, plans such shares

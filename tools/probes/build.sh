@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-for p in chain_probe fork_probe mall_probe persist_probe tr_probe kernarg_probe; do
+for p in chain_probe fork_probe mall_probe persist_probe tr_probe kernarg_probe ifetch_probe; do
     if [ ! -x $p ] || [ $p.hip -nt $p ]; then $HIPCC --offload-arch=gfx950 -O3 $p.hip -o $p && echo "built $p"; fi
 done
 # kernel-argument preload on / off: the same source with and without the backend option
