@@ -60,20 +60,79 @@ def make_q_matrix_split(*args):
 
 
 reconstruct = _e.reconstruct
-gemm_half_q_half = _e.gemm_half_q_half
 make_group_map = _e.make_group_map
-rms_norm = _e.rms_norm
-rms_norm_ = _e.rms_norm_
-rope_ = _e.rope_
 fp16_to_q_kv = _e.fp16_to_q_kv
 q_to_fp16_kv = _e.q_to_fp16_kv
 make_q_attn = _e.make_q_attn
-free_q_attn = _e.free_q_attn
-q_attn_forward_1 = _e.q_attn_forward_1
-q_attn_forward_2 = _e.q_attn_forward_2
 make_q_mlp = _e.make_q_mlp
-free_q_mlp = _e.free_q_mlp
-q_mlp_forward_ = _e.q_mlp_forward_
+
+
+# ---- the per-token calls: compiled binding + the module chain behind the boundary (dropin/_exl2_fast.cpp) --------------------
+# `_exl2_fast.so` is built next to this file by __graft_entry__.build() (exllamav2_amd/build.py: build_fast).  It binds
+# q_attn_forward_1 / q_attn_forward_2 / q_mlp_forward_ (and the decode case of flash_attn_func, dropin/flash_attn) with pybind11
+# straight over the C ABI -- what the reference's own extension is (ext_bindings.cpp) -- and chains consecutive modules through the
+# library's fast decode kernels.  EXL2_DROPIN_FAST=0 keeps every call on the ctypes route of exllamav2_amd/ext.py (same library,
+# module by module); a missing .so does the same with a warning, never silently.
+def _load_fast():
+    if _os.environ.get("EXL2_DROPIN_FAST", "1") == "0":
+        return None
+    import importlib.machinery, importlib.util, warnings
+    path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "_exl2_fast.so")
+    try:
+        if not _os.path.exists(path):
+            raise ImportError(path + " is not built (python -c 'import __graft_entry__ as g; g.build()')")
+        loader = importlib.machinery.ExtensionFileLoader("_exl2_fast", path)
+        mod = importlib.util.module_from_spec(importlib.util.spec_from_loader("_exl2_fast", loader))
+        loader.exec_module(mod)
+        from exllamav2_amd import _lib
+        mod.init(_lib.HIP_LIB_PATH, False)
+        return mod
+    except Exception as e:                                        # noqa: BLE001 -- reported, and the ctypes route is the same library
+        warnings.warn(f"exllamav2_ext drop-in: compiled binding unavailable ({e}); per-token calls take the ctypes route", RuntimeWarning)
+        return None
+
+
+_fast = _load_fast()
+
+if _fast is not None:
+    q_attn_forward_1 = _fast.q_attn_forward_1
+    q_attn_forward_2 = _fast.q_attn_forward_2
+    q_mlp_forward_ = _fast.q_mlp_forward_
+
+    def free_q_attn(handle):
+        _fast.forget_module(handle)
+        _e.free_q_attn(handle)
+
+    def free_q_mlp(handle):
+        _fast.forget_module(handle)
+        _e.free_q_mlp(handle)
+
+    # entry points of the ctypes half that write activations through raw pointers: a hand-off published for that address is stale
+    def gemm_half_q_half(a, b, c, force_cuda=False):
+        _fast.note_write(c)
+        return _e.gemm_half_q_half(a, b, c, force_cuda)
+
+    def rms_norm(x, w, y, epsilon):
+        _fast.note_write(y)
+        return _e.rms_norm(x, w, y, epsilon)
+
+    def rms_norm_(x, w, epsilon):
+        _fast.note_write(x)
+        return _e.rms_norm_(x, w, epsilon)
+
+    def rope_(x, sin, cos, past_len, num_heads, head_dim, offsets, neox_style):
+        _fast.note_write(x)
+        return _e.rope_(x, sin, cos, past_len, num_heads, head_dim, offsets, neox_style)
+else:
+    q_attn_forward_1 = _e.q_attn_forward_1
+    q_attn_forward_2 = _e.q_attn_forward_2
+    q_mlp_forward_ = _e.q_mlp_forward_
+    free_q_attn = _e.free_q_attn
+    free_q_mlp = _e.free_q_mlp
+    gemm_half_q_half = _e.gemm_half_q_half
+    rms_norm = _e.rms_norm
+    rms_norm_ = _e.rms_norm_
+    rope_ = _e.rope_
 
 
 def set_flash_attn_func():          # ext_qattn.cpp:256-259 is a no-op in the reference too

@@ -23,10 +23,25 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
         raise NotImplementedError("flash_attn shim: sliding window / softcap are not built (SURVEY.md 8a row a15)")
     if isinstance(cache_seqlens, int):
         cache_seqlens = torch.full((q.shape[0],), cache_seqlens, dtype=torch.int32, device=q.device)
+    # decode-sized steps of the dynamic generator: append + attention + merge in ONE launch through the compiled binding (which also
+    # leaves the act-ordered copy q_attn_forward_2's chained launch reads); everything else takes the general route
+    fast = _fast()
+    if fast is not None and k is not None and v is not None and block_table is not None and causal and q.shape[1] <= 8:
+        out = fast.flash_attn_kvcache_decode(q, k_cache, v_cache, k, v, cache_seqlens, block_table,
+                                             float(q.shape[-1] ** -0.5 if softmax_scale is None else softmax_scale))
+        if out is not None:
+            return out
     return _e.flash_attn_with_kvcache(q, k_cache, v_cache, k, v, cache_seqlens, block_table, causal, softmax_scale)
 
 
 _scratch = {}
+
+
+def _fast():
+    """the compiled half of the drop-in, when `exllamav2_ext` (dropin/exllamav2_ext.py) has loaded it"""
+    import sys
+    m = sys.modules.get("exllamav2_ext")
+    return getattr(m, "_fast", None) if m is not None else None
 
 
 def _split_scratch(q):
@@ -68,6 +83,14 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, wi
     if not q.is_contiguous():
         q = q.contiguous()
     kf, vf = _whole_rows(k), _whole_rows(v)
+    # a decode step of one sequence (attn.py:1088-1091 "direct": its K / V rows are in the cache already): ONE launch of
+    # csrc/attn.hip through the compiled binding, which also leaves the act-ordered copy q_attn_forward_2's chained launch reads
+    # (dropin/_exl2_fast.cpp).  Anything else -- or a shape that kernel does not cover -- takes the general route below.
+    fast = _fast()
+    if fast is not None and b == 1 and s <= 16:
+        out = fast.flash_attn_decode(q, kf, vf, float(hd ** -0.5 if softmax_scale is None else softmax_scale))
+        if out is not None:
+            return out
     out = torch.empty_like(q)
     if not (s > 16 and _e.flash_prefill(q, kf, vf, out, None, None, n - s, s, softmax_scale, True)):
         _e.paged_attn(q, kf, vf, out, None, None, n - s, s, softmax_scale, True, 0, _split_scratch(q))

@@ -63,6 +63,8 @@ PROTOTYPES = {
     "exl2_rope_kv_append": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, vp]),
     "exl2_attn_decode_fused": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, ci,
                                     vp, cll, vp, ci, vp, vp]),
+    "exl2_attn_decode_fused_dual": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, ci,
+                                    vp, cll, vp, ci, vp, vp, vp]),
     "exl2_paged_attn_q4": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, vp, cll, vp, vp]),
     # fused modules
     "exl2_make_q_attn": (ci, [C.POINTER(vp), vp, vp, ci, ci, cf, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci,
@@ -83,12 +85,14 @@ PROTOTYPES = {
     "exl2_q_mlp_chain_info": (ci, [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp)]),
     "exl2_q_matrix_perm_info": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
     "exl2_q_attn_forward_1_chain": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, vp]),
+    "exl2_q_attn_forward_1_chain_rope": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
     "exl2_q_attn_forward_2_chain": (ci, [vp, vp, vp, ci, vp, vp, vp, vp, C.POINTER(ci), vp]),
     "exl2_q_mlp_forward_chain": (ci, [vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, C.POINTER(ci), vp]),
     "exl2_q_mlp_forward_chain_part": (ci, [vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, C.POINTER(ci), vp]),
     "exl2_gemm_half_q_half_chain": (ci, [vp, vp, ci, cf, vp, vp, ci, vp]),
     "exl2_embed_rows_chain": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp]),
     "exl2_chain_set_tiled": (ci, [ci]),
+    "exl2_publish_rows": (ci, [vp, ci, ci, vp, vp, vp, vp, vp]),
     "exl2_gather_f16": (ci, [vp, vp, vp, ci, vp]),
     "exl2_chain_overlap_begin": (ci, [vp, ci, vp, vp]),
     "exl2_chain_overlap_end": (ci, [C.POINTER(ci)]),

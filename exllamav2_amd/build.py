@@ -57,3 +57,27 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+
+
+# ---- the compiled half of the drop-in (dropin/_exl2_fast.cpp): pybind11 over the C ABI ---------------------------------------
+FAST_SRC = os.path.join(os.path.dirname(HERE), "dropin", "_exl2_fast.cpp")
+FAST_OUT = os.path.join(os.path.dirname(HERE), "dropin", "_exl2_fast.so")
+
+
+def build_fast(force: bool = False, verbose: bool = False) -> str:
+    """g++ on one host-only source (no device code: it dlopens libexl2_hip.so); in-tree like the library, so it travels to the GPU box."""
+    if not force and os.path.exists(FAST_OUT) and os.path.getmtime(FAST_OUT) >= os.path.getmtime(FAST_SRC):
+        return FAST_OUT
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", FAST_SRC, "-o", FAST_OUT, "-DTORCH_EXTENSION_NAME=_exl2_fast",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+           "-I/opt/rocm/include", "-I" + sysconfig.get_paths()["include"]] + ["-I" + i for i in ce.include_paths()] + \
+          ["-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_python", "-ldl", "-Wl,-rpath," + libdir]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return FAST_OUT

@@ -219,6 +219,7 @@ struct FusedArgs
     const int* cache_seqlens; const int* block_table;
     f16* out; float* part_o; float* part_ml; u32* counters;
     const u16* out_invperm;                             // nullable: feature n of a token row is stored at out[row, out_invperm[n]]
+    f16* out_nat;                                       // nullable: a second copy of the output in natural order (exl2_attn_decode_fused_dual)
     int b, s, H, KVH;                                   // (the consumer's packed order, i.e. o_proj's act-order: qgemv_flat.hip)
     int page_size, page_shift, pages_per_seq;
     int past_const, nsplit, rope, keys_per_split_min;
@@ -501,6 +502,7 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
             const size_t oi = (a.out_invperm && idx == tid()) ? (qrow / a.H) * ((size_t)a.H * HDIM) + (size_t)out_pre : fused_out_index<HDIM>(a, qrow, d);
             if (a.sync_signal) store_agent_f16(a.out + oi, y);
             else a.out[oi] = y;
+            if (a.out_nat) a.out_nat[qrow * HDIM + d] = y;
         }
         else
         {
@@ -548,6 +550,7 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
         const f16 y = (f16)(L > 0.0f ? O / L : 0.0f);
         if (a.sync_signal) store_agent_f16(a.out + fused_out_index<HDIM>(a, qrow, d), y);
         else a.out[fused_out_index<HDIM>(a, qrow, d)] = y;
+        if (a.out_nat) a.out_nat[qrow * HDIM + d] = y;
     }
     if (tid() == 0) store_relaxed_agent(counter, 0u);
     signal_done();
@@ -737,12 +740,12 @@ int exl2_paged_attn(const void* q, const void* k_cache, const void* v_cache, voi
 // One-launch decode-step attention (see attn_fused_kernel).  Returns 1 (nothing launched) when the shape is outside what
 // the fused kernel covers -- the caller then uses exl2_rope_kv_append + exl2_paged_attn.  q / k_new are NOT modified.
 // `counters`: >= batch * kv_heads * row_blocks zeroed u32, left zeroed.  Positions: past = past_const + cache_seqlens[b].
-int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, void* k_cache, void* v_cache, void* out,
+static int attn_decode_fused_impl(const void* q, const void* k_new, const void* v_new, void* k_cache, void* v_cache, void* out,
                            const void* sin, const void* cos, const int* cache_seqlens, const int* block_table,
                            int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
                            int page_size, int pages_per_seq, int past_const, float softmax_scale,
                            int rope_style, int sincos_size, int nsplit, void* scratch, long long scratch_bytes,
-                           void* counters, int n_counters, const void* out_invperm, void* stream)
+                           void* counters, int n_counters, const void* out_invperm, void* out_natural, void* stream)
 {
     EXL2_REQUIRE(q && k_new && v_new && k_cache && v_cache && out, "attn_decode_fused: null argument");
     EXL2_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "attn_decode_fused: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
@@ -766,6 +769,7 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
     a.sin = (const f16*)sin; a.cos = (const f16*)cos;
     a.cache_seqlens = cache_seqlens; a.block_table = block_table; a.counters = (u32*)counters;
     a.out_invperm = (const u16*)out_invperm;
+    a.out_nat = out_invperm ? (f16*)out_natural : nullptr;      // (without a permutation `out` IS the natural-order copy)
     a.b = batch; a.s = q_len; a.H = num_heads; a.KVH = num_kv_heads;
     a.page_size = page_size; a.pages_per_seq = pages_per_seq; a.page_shift = ilog2_exact(page_size);
     EXL2_REQUIRE(!block_table || a.page_shift >= 0, "attn_decode_fused: page_size %d must be a power of two", page_size);
@@ -818,6 +822,36 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
     HIP_TRY(hipGetLastError());
     if (overlapped) { const int e = chain_sync_done((u32)(grid.x * grid.y * grid.z)); if (e) return e; }
     return EXL2_OK;
+}
+
+int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, void* k_cache, void* v_cache, void* out,
+                           const void* sin, const void* cos, const int* cache_seqlens, const int* block_table,
+                           int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                           int page_size, int pages_per_seq, int past_const, float softmax_scale,
+                           int rope_style, int sincos_size, int nsplit, void* scratch, long long scratch_bytes,
+                           void* counters, int n_counters, const void* out_invperm, void* stream)
+{
+    return attn_decode_fused_impl(q, k_new, v_new, k_cache, v_cache, out, sin, cos, cache_seqlens, block_table, batch, q_len, num_heads,
+                                  num_kv_heads, head_dim, page_size, pages_per_seq, past_const, softmax_scale, rope_style, sincos_size,
+                                  nsplit, scratch, scratch_bytes, counters, n_counters, out_invperm, nullptr, stream);
+}
+
+// The same launch with TWO copies of the output: `out` through out_invperm (o_proj's packed order, what exl2_q_attn_forward_2_chain
+// reads) and `out_natural` in flash-attn's order -- the tensor the reference host receives from flash_attn_func (attn.py:960-977)
+// and hands to q_attn_forward_2 (attn.py:1195-1203): the module chain behind the operator boundary (dropin/_exl2_fast.cpp) recognises
+// that tensor and reads the packed copy instead.
+int exl2_attn_decode_fused_dual(const void* q, const void* k_new, const void* v_new, void* k_cache, void* v_cache, void* out,
+                                const void* sin, const void* cos, const int* cache_seqlens, const int* block_table,
+                                int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                                int page_size, int pages_per_seq, int past_const, float softmax_scale,
+                                int rope_style, int sincos_size, int nsplit, void* scratch, long long scratch_bytes,
+                                void* counters, int n_counters, const void* out_invperm, void* out_natural, void* stream)
+{
+    EXL2_REQUIRE(!out_invperm || out_natural, "attn_decode_fused_dual: out_natural missing");
+    return attn_decode_fused_impl(q, k_new, v_new, k_cache, v_cache, out_invperm ? out : (out_natural ? out_natural : out), sin, cos,
+                                  cache_seqlens, block_table, batch, q_len, num_heads,
+                                  num_kv_heads, head_dim, page_size, pages_per_seq, past_const, softmax_scale, rope_style, sincos_size,
+                                  nsplit, scratch, scratch_bytes, counters, n_counters, out_invperm, out_natural, stream);
 }
 
 // RoPE on q and k_new in place (rope.cu numerics) and, when caches are given, append of the rotated k_new and of v_new at

@@ -273,16 +273,16 @@ KERNEL void __launch_bounds__(256) embed_rows_chain_kernel(const f16* table, con
 {
     SHARED float part[4];
     const int row = bid_x();
-    int id = ids[row];
+    int id = ids ? ids[row] : row;                       // (no ids: row r of `table` -- exl2_publish_rows)
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     const f16x8* src = (const f16x8*)(table + (size_t)id * hidden);
-    f16x8* dst = (f16x8*)(out + (size_t)row * hidden);
+    f16x8* dst = out ? (f16x8*)(out + (size_t)row * hidden) : nullptr;
     f16* xr = xp + (size_t)row * hidden;
     float sq = 0.0f;
     for (int i = tid(); i < (hidden >> 3); i += 256)
     {
         const f16x8 v = src[i];
-        dst[i] = v;
+        if (dst) dst[i] = v;
         u32 idx[8];
         if (invperm)
         {
@@ -392,6 +392,22 @@ int exl2_embed_rows_chain(const void* table, const int* ids, void* x, int rows, 
     EXL2_REQUIRE(!next_invperm || (((size_t)next_invperm) & 15) == 0, "embed_rows_chain: invperm must be 16-byte aligned");
     if (rows <= 0) return EXL2_OK;
     LAUNCH(embed_rows_chain_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const f16*)table, ids, (f16*)x, hidden, vocab,
+           (const u16*)next_invperm, (const f16*)next_norm_w, (f16*)xp_out, ss_out, chain_xp_tiled() ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
+}
+
+// The hand-off a chained producer would have left, made from rows that are already in memory: xp_out = x * next_norm_w in the
+// consumer's packed order, ss_out[row] = sum of squares (npart = 1).  What the module chain behind the operator boundary
+// (dropin/_exl2_fast.cpp) runs when a module's input did not come from the module it expected.
+int exl2_publish_rows(const void* x, int rows, int hidden, const void* next_invperm, const void* next_norm_w,
+                      void* xp_out, float* ss_out, void* stream)
+{
+    EXL2_REQUIRE(x && xp_out && ss_out, "publish_rows: null argument");
+    EXL2_REQUIRE(hidden % 8 == 0, "publish_rows: hidden %d must be a multiple of 8", hidden);
+    EXL2_REQUIRE(!next_invperm || (((size_t)next_invperm) & 15) == 0, "publish_rows: invperm must be 16-byte aligned");
+    if (rows <= 0) return EXL2_OK;
+    LAUNCH(embed_rows_chain_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const f16*)x, (const int*)nullptr, (f16*)nullptr, hidden, rows,
            (const u16*)next_invperm, (const f16*)next_norm_w, (f16*)xp_out, ss_out, chain_xp_tiled() ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return EXL2_OK;

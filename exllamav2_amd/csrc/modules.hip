@@ -703,6 +703,23 @@ int exl2_q_attn_forward_1_chain(void* handle, const void* xp, const float* ss, i
     return EXL2_OK;
 }
 
+// q_attn_forward_1's full contract (ext_qattn.cpp:115-159: projections of the normalised rows, then RoPE on q and k in place) from a
+// published hand-off: what the module chain behind the operator boundary (dropin/_exl2_fast.cpp) calls -- the reference host reads the
+// rotated q / k (k straight in its cache rows, attn.py:1088-1091), so the rotation cannot be left to the attention launch here.
+int exl2_q_attn_forward_1_chain_rope(void* handle, const void* xp, const float* ss, int npart, int batch_size, int q_len, int past_len,
+                                     const int* past_lens, void* temp_q, void* temp_k, void* temp_v, const void* sin, const void* cos,
+                                     void* stream)
+{
+    EXL2_REQUIRE(handle, "q_attn_forward_1_chain_rope: null handle");
+    QAttn* a = (QAttn*)handle;
+    const int rc = exl2_q_attn_forward_1_chain(handle, xp, ss, npart, batch_size * q_len, temp_q, temp_k, temp_v, stream);
+    if (rc != EXL2_OK || batch_size * q_len <= 0 || a->rope_style == 0) return rc;
+    EXL2_REQUIRE(sin && cos, "q_attn_forward_1_chain_rope: sin/cos tables missing");
+    return exl2_rope_qk(temp_q, temp_k, sin, cos, batch_size, q_len * a->num_heads, q_len * a->num_kv_heads,
+                        a->head_dim, a->num_heads, a->num_kv_heads, past_len, past_lens, a->rope_style == 2,
+                        a->sincos_size, stream);
+}
+
 int exl2_q_attn_forward_2_chain(void* handle, void* x, const void* attn_out_packed, int rows, const void* next_invperm,
                                 const void* next_norm_w, void* xp_out, float* ss_out, int* npart_out, void* stream)
 {

@@ -156,6 +156,16 @@ int exl2_attn_decode_fused(const void* q, const void* k_new, const void* v_new, 
                            void* counters, int n_counters, const void* out_invperm, void* stream);
 /* out_invperm (nullable, u16 [num_heads * head_dim]): feature n of a token's output row is stored at column out_invperm[n]
    -- o_proj's packed (act-order) K order, so that exl2_q_attn_forward_2_chain copies its input without a gather. */
+/* The same launch leaving TWO copies of the output: `out` through out_invperm and `out_natural` in flash-attn's order -- the
+   tensor flash_attn_func returns to the reference host (attn.py:960-977), which hands it to q_attn_forward_2 (attn.py:1195-1203);
+   the module chain behind the operator boundary (dropin/_exl2_fast.cpp) recognises that tensor and reads the packed copy.
+   out_invperm == NULL: one natural-order copy, in out_natural (or `out` when that is NULL too). */
+int exl2_attn_decode_fused_dual(const void* q, const void* k_new, const void* v_new, void* k_cache, void* v_cache, void* out,
+                                const void* sin, const void* cos, const int* cache_seqlens, const int* block_table,
+                                int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                                int page_size, int pages_per_seq, int past_const, float softmax_scale,
+                                int rope_style, int sincos_size, int nsplit, void* scratch, long long scratch_bytes,
+                                void* counters, int n_counters, const void* out_invperm, void* out_natural, void* stream);
 
 /* Decode attention straight from the Q4 KV cache (ExLlamaV2Cache_Q4, cache.py:409-606; format cache_q.cuh:4-185): replaces
    q_to_fp16_kv of the whole live range (cache.py:472-514) + attention over the fp16 temp.  k_new / v_new (nullable, fp16
@@ -222,6 +232,10 @@ int exl2_q_matrix_perm_info(void* q_matrix, const void** perm, const void** invp
 /* q, k, v = proj(rmsnorm(x)) from (xp, ss); no RoPE (the attention launch rotates) */
 int exl2_q_attn_forward_1_chain(void* handle, const void* xp, const float* ss, int npart, int rows,
                                 void* temp_q, void* temp_k, void* temp_v, void* stream);
+/* the same + RoPE(q, k) in place: q_attn_forward_1's whole contract (ext_qattn.cpp:115-159) from a published hand-off */
+int exl2_q_attn_forward_1_chain_rope(void* handle, const void* xp, const float* ss, int npart, int batch_size, int q_len, int past_len,
+                                     const int* past_lens, void* temp_q, void* temp_k, void* temp_v, const void* sin, const void* cos,
+                                     void* stream);
 /* x += attn_out . Wo with attn_out already in o_proj's packed order (exl2_attn_decode_fused out_invperm); publishes
    (xp_out, ss_out) for the next consumer through next_invperm (nullable = identity); *npart_out = partials per row
    (ss_out: room for 512 floats per row) */
@@ -254,6 +268,12 @@ int exl2_chain_set_tiled(int on);
 
 int exl2_embed_rows_chain(const void* table, const int* ids, void* x, int rows, int hidden, int vocab,
                           const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, void* stream);
+/* The hand-off a chained producer would have left, made from rows x [rows, hidden] that are already in memory: xp_out = x *
+   next_norm_w in the consumer's packed order, ss_out[row] = sum of squares of row (npart = 1).  Run by the module chain behind
+   the operator boundary when q_attn_forward_1 (ext_qattn.cpp:115-159) / q_mlp_forward_ (ext_qmlp.cpp:87-118) receive a residual
+   stream the previous module did not publish for them (first token, a host that touched x in between). */
+int exl2_publish_rows(const void* x, int rows, int hidden, const void* next_invperm, const void* next_norm_w,
+                      void* xp_out, float* ss_out, void* stream);
 /* dst[i] = src[perm[i]] (u16 perm, nullable = copy), n elements */
 int exl2_gather_f16(const void* src, const void* perm, void* dst, int n, void* stream);
 /* Overlapped chain (csrc/chain_sync.h; no reference counterpart -- the reference serialises every launch of a decode step on

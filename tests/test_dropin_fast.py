@@ -1,0 +1,287 @@
+"""The compiled half of the drop-in (dropin/_exl2_fast.cpp): the reference host's per-token operator calls -- q_attn_forward_1,
+flash_attn_func, q_attn_forward_2 (attn.py:1128-1203), q_mlp_forward_ (mlp.py:318-366) -- and the module chain it runs BEHIND that
+boundary (round-4 review, item 4: "put the fast path behind the boundary").
+
+The test plays the reference's decode loop at the operator level, in the reference's "direct" mode (attn.py:1088-1091: K / V
+projections written straight into the cache rows, then `flash_attn_func(q, cache[:past + 1], ...)`), and checks
+  * logits against the numpy oracle (the same bar as tests/test_model.py),
+  * the chained route against the un-chained one,
+  * that the chain is actually taken from the second token on, and that it is NOT taken -- with unchanged results -- when the host
+    touches the residual stream between two modules (torch's version counter), hands over a different tensor, or swaps the order.
+Runs on the CPU emulation build of the same kernels here and on libexl2_hip.so under -m gpu.
+"""
+import importlib.machinery
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from exllamav2_amd.config import ExLlamaV2Config
+from exllamav2_amd.ext import none_tensor
+from exllamav2_amd.model import ExLlamaV2
+from exllamav2_amd.synth import synth_checkpoint
+from oracle.model import OracleModel
+from tests.conftest import ROOT, build_emu_if_needed
+from tests.test_model import check_logits
+
+
+def load_fast(be):
+    from exllamav2_amd import _lib, build
+    path = build.build_fast()
+    loader = importlib.machinery.ExtensionFileLoader("_exl2_fast", path)
+    spec = importlib.util.spec_from_loader("_exl2_fast", loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    mod.init(build_emu_if_needed() if be.is_emu else _lib.HIP_LIB_PATH, be.is_emu)
+    return mod
+
+
+def cfg_small(**kw):
+    d = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2,
+             head_dim=64, vocab_size=160, max_seq_len=64, max_input_len=16)
+    d.update(kw)
+    return ExLlamaV2Config(**d)
+
+
+class Host:
+    """the reference host's decode loop (model.py:936-1054 -> attn.py:1017-1203, mlp.py:318-366), batch 1, direct cache writes"""
+
+    def __init__(self, be, fast, cfg, seed=0, recipe="4.0bpw"):
+        self.be, self.fast, self.cfg = be, fast, cfg
+        ck = synth_checkpoint(cfg, be.device, recipe=recipe, seed=seed)
+        self.oracle = OracleModel(cfg, ck)
+        self.model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+        kv = cfg.num_key_value_heads * cfg.head_dim
+        self.K = [torch.zeros((1, cfg.max_seq_len, kv), dtype=torch.float16, device=be.device) for _ in self.model.layers]
+        self.V = [torch.zeros_like(k) for k in self.K]
+        self.past = 0
+        self.between = None            # hook(layer, where, x) -> x: what a host might do between two module calls
+
+    def reset(self):
+        self.past = 0
+        self.oracle.reset(1)
+        for t in self.K + self.V:
+            t.zero_()
+
+    def step(self, token: int):
+        cfg, m, f = self.cfg, self.model, self.fast
+        H, KVH, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        x = m.embed_tokens[torch.tensor([token], device=m.device)].view(1, 1, cfg.hidden_size).contiguous()
+        past = self.past
+        for li, (attn, mlp) in enumerate(m.layers):
+            q = torch.empty((1, 1, H * hd), dtype=torch.float16, device=m.device)
+            k = self.K[li][:1, past:past + 1, :]
+            v = self.V[li][:1, past:past + 1, :]
+            f.q_attn_forward_1(attn.q_handle, x, 1, 1, past, none_tensor, q, k, v, m.sin, m.cos, [], none_tensor)
+            out = f.flash_attn_decode(q.view(1, 1, H, hd), self.K[li][:1, :past + 1].view(1, past + 1, KVH, hd),
+                                      self.V[li][:1, :past + 1].view(1, past + 1, KVH, hd), hd ** -0.5)
+            assert out is not None
+            f.q_attn_forward_2(attn.q_handle, x, out.reshape(1, 1, H * hd), 1, 1, [], none_tensor)
+            if self.between: x = self.between(li, "attn->mlp", x)
+            f.q_mlp_forward_(mlp.q_handle, x, [], none_tensor)
+            if self.between: x = self.between(li, "mlp->attn", x)
+        self.past += 1
+        xn = m.norm.forward(x)
+        return m.lm_head.forward(xn)[..., :cfg.vocab_size]
+
+    def run(self, tokens):
+        self.reset()
+        return [self.be.n(self.step(t)) for t in tokens]
+
+    def check_against_oracle(self, tokens, logits):
+        self.oracle.reset(1)
+        for t, got in zip(tokens, logits):
+            check_logits(got.reshape(1, 1, -1), self.oracle.forward(np.array([[t]]))[:, -1:])
+
+    def close(self):
+        for attn, mlp in self.model.layers:
+            self.fast.forget_module(attn.q_handle); self.fast.forget_module(mlp.q_handle)
+        self.model.unload()
+
+
+TOKENS = [3, 17, 5, 101, 42]
+
+
+@pytest.mark.parametrize("recipe", ["4.0bpw", "2.5bpw"])
+def test_module_chain_behind_the_boundary_equals_oracle_and_plain_route(be, recipe):
+    fast = load_fast(be)
+    cfg = cfg_small()
+    host = Host(be, fast, cfg, recipe=recipe)
+    L = cfg.num_hidden_layers
+    fast.set_chain(True); fast.stats(True)
+    chained = host.run(TOKENS)
+    st = fast.stats(True)
+    host.check_against_oracle(TOKENS, chained)
+    # token 0 learns the order (every module publishes its own hand-off: 2 L); afterwards only the first module of a token does
+    # (its x is a new tensor) -- and every q_attn_forward_2 ran on the packed copy of flash_attn_func's output
+    n = len(TOKENS)
+    assert st["published"] == 2 * L + (n - 1), st
+    assert st["chained"] == (n - 1) * (2 * L - 1) + n * L, st
+    assert st["plain"] == 0 and st["attn_fast"] == n * L, st
+    fast.set_chain(False); fast.stats(True)
+    plain = host.run(TOKENS)
+    st = fast.stats(True)
+    assert st["chained"] == 0 and st["published"] == 0 and st["plain"] == 3 * L * n, st
+    host.check_against_oracle(TOKENS, plain)
+    for a, b in zip(chained, plain):                             # two kernels, the same arithmetic: fp16 rounding apart
+        assert np.all(np.abs(a.astype(np.float64) - b) <= 0.03 + np.abs(b) * 2.0 ** -8)
+    fast.set_chain(True)
+    host.close()
+
+
+def test_a_host_that_touches_the_residual_stream_is_not_served_a_stale_hand_off(be):
+    fast = load_fast(be)
+    cfg = cfg_small(num_hidden_layers=2)
+    host = Host(be, fast, cfg, seed=3)
+    fast.set_chain(True)
+    base = host.run(TOKENS)
+    host.check_against_oracle(TOKENS, base)
+
+    # (a) an in-place torch operation between attention and MLP that CHANGES x: the version counter moves, the MLP must start
+    #     from the new values.  Reference result: the same hook on the un-chained route.
+    def scale_in_place(li, where, x):
+        if where == "attn->mlp" and li == 1:
+            x.mul_(0.5)
+        return x
+    host.between = scale_in_place
+    fast.stats(True)
+    got = host.run(TOKENS)
+    st = fast.stats(True)
+    fast.set_chain(False)
+    want = host.run(TOKENS)
+    fast.set_chain(True)
+    for a, b in zip(got, want):
+        assert np.all(np.abs(a.astype(np.float64) - b) <= 0.03 + np.abs(b) * 2.0 ** -8)
+    assert not np.allclose(got[-1], base[-1], atol=1e-3), "the hook must matter for this test to mean anything"
+    assert st["published"] > 2 * cfg.num_hidden_layers + len(TOKENS) - 1, st       # layer 1's MLP published for itself every token
+
+    # (b) a host that replaces x by a copy (another tensor, same values): nothing stale can be used, results unchanged
+    def copy_out(li, where, x):
+        return x.clone() if where == "mlp->attn" else x
+    host.between = copy_out
+    got = host.run(TOKENS)
+    for a, b in zip(got, base):
+        assert np.all(np.abs(a.astype(np.float64) - b) <= 0.03 + np.abs(b) * 2.0 ** -8)
+
+    # (c) note_write: a raw-pointer write the binding is told about (the Python half's rms_norm_, gemm_half_q_half, ...)
+    def raw_write(li, where, x):
+        if where == "attn->mlp" and li == 0:
+            x.view(torch.int16).bitwise_xor_(0)              # (a torch op: bumps the version as well -- belt and braces)
+            fast.note_write(x)
+        return x
+    host.between = raw_write
+    got = host.run(TOKENS)
+    for a, b in zip(got, base):
+        assert np.all(np.abs(a.astype(np.float64) - b) <= 0.03 + np.abs(b) * 2.0 ** -8)
+    host.between = None
+    host.close()
+
+
+def test_rows_beyond_the_chain_and_prefill_shapes_take_the_plain_route(be):
+    fast = load_fast(be)
+    cfg = cfg_small(num_hidden_layers=1)
+    host = Host(be, fast, cfg, seed=5)
+    m = host.model
+    attn, mlp = m.layers[0]
+    H, KVH, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    rows = 6
+    fast.stats(True)
+    x = (torch.randn((1, rows, cfg.hidden_size), device=m.device) * 0.5).half()
+    x0 = x.clone()
+    q = torch.empty((1, rows, H * hd), dtype=torch.float16, device=m.device)
+    k = torch.empty((1, rows, KVH * hd), dtype=torch.float16, device=m.device)
+    v = torch.empty_like(k)
+    fast.q_attn_forward_1(attn.q_handle, x, 1, rows, 0, none_tensor, q, k, v, m.sin, m.cos, [], none_tensor)
+    q2, k2, v2 = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    be.ext.q_attn_forward_1(attn.q_handle, x0, 1, rows, 0, none_tensor, q2, k2, v2, m.sin, m.cos)
+    assert torch.equal(q, q2) and torch.equal(k, k2) and torch.equal(v, v2)
+    fast.q_mlp_forward_(mlp.q_handle, x, [], none_tensor)
+    be.ext.q_mlp_forward_(mlp.q_handle, x0)
+    assert torch.equal(x, x0)
+    st = fast.stats(True)
+    assert st["plain"] == 2 and st["chained"] == 0 and st["published"] == 0, st
+    # a call shape flash_attn_decode does not take is handed back (None), never approximated
+    assert fast.flash_attn_decode(q.view(1, rows, H, hd)[:, :, :, :32], k.view(1, rows, KVH, hd), v.view(1, rows, KVH, hd), 0.125) is None
+    host.close()
+
+
+def test_paged_mode_decode_of_two_sequences_chains_too(be):
+    """the dynamic generator's call pattern (attn.py:466-638 forward_paged): q_attn_forward_1 with per-sequence positions, then
+    flash_attn_with_kvcache(q, k_cache, v_cache, k, v, cache_seqlens, block_table), q_attn_forward_2, q_mlp_forward_ -- batch 2"""
+    fast = load_fast(be)
+    cfg = cfg_small(num_hidden_layers=2)
+    host = Host(be, fast, cfg, seed=7)
+    m = host.model
+    H, KVH, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    b = 2
+    toks = np.array([[3, 9], [17, 4], [5, 88], [101, 2]])              # [step, sequence]
+
+    def run():
+        Kc = [torch.zeros((b, 256, KVH, hd), dtype=torch.float16, device=m.device) for _ in m.layers]
+        Vc = [torch.zeros_like(k) for k in Kc]
+        table = torch.arange(b, dtype=torch.int32, device=m.device).view(b, 1)
+        lens = torch.zeros((b,), dtype=torch.int32, device=m.device)
+        outs = []
+        for step in toks:
+            x = m.embed_tokens[torch.tensor(step, device=m.device)].view(b, 1, cfg.hidden_size).contiguous()
+            for li, (attn, mlp) in enumerate(m.layers):
+                q = torch.empty((b, 1, H, hd), dtype=torch.float16, device=m.device)
+                k = torch.empty((b, 1, KVH, hd), dtype=torch.float16, device=m.device)
+                v = torch.empty_like(k)
+                fast.q_attn_forward_1(attn.q_handle, x, b, 1, 0, lens, q, k, v, m.sin, m.cos, [], none_tensor)
+                out = fast.flash_attn_kvcache_decode(q, Kc[li], Vc[li], k, v, lens, table, hd ** -0.5)
+                assert out is not None
+                fast.q_attn_forward_2(attn.q_handle, x, out.view(b, 1, H * hd), b, 1, [], none_tensor)
+                fast.q_mlp_forward_(mlp.q_handle, x, [], none_tensor)
+            lens = lens + 1
+            outs.append(be.n(m.lm_head.forward(m.norm.forward(x))[..., :cfg.vocab_size]))
+        return outs
+
+    fast.set_chain(True); fast.stats(True)
+    chained = run()
+    st = fast.stats(True)
+    L, n = cfg.num_hidden_layers, len(toks)
+    assert st["published"] == 2 * L + (n - 1) and st["chained"] == (n - 1) * (2 * L - 1) + n * L and st["plain"] == 0, st
+    host.oracle.reset(b)
+    for step, got in zip(toks, chained):
+        check_logits(got, host.oracle.forward(step[:, None])[:, -1:])
+    fast.set_chain(False)
+    plain = run()
+    fast.set_chain(True)
+    for a, c in zip(chained, plain):
+        assert np.all(np.abs(a.astype(np.float64) - c) <= 0.03 + np.abs(c) * 2.0 ** -8)
+    host.close()
+
+
+def test_inference_mode_tensors_and_the_self_check(be):
+    """The reference decorates its forward with torch.inference_mode() (model.py:764): such tensors have no version counter
+    (`_version` raises).  The chain must still run -- and EXL2_MODULE_CHAIN_VERIFY's self-check (every hand-off re-derived from x on
+    entry, compared bit for bit) must pass on the reference's call pattern and catch a host that rewrites x behind its back."""
+    fast = load_fast(be)
+    cfg = cfg_small(num_hidden_layers=2)
+    host = Host(be, fast, cfg, seed=11)
+    fast.set_chain(True)
+    base = host.run(TOKENS)
+    fast.set_verify(True); fast.stats(True)
+    with torch.inference_mode():
+        got = host.run(TOKENS)
+    st = fast.stats(True)
+    L, n = cfg.num_hidden_layers, len(TOKENS)
+    # (the order is known from the first run: only the first module of every token publishes for itself)
+    assert st["chained"] == n * (2 * L - 1) + n * L and st["verified"] == n * (2 * L - 1) and st["published"] == n, st
+    for a, b in zip(got, base):
+        assert np.array_equal(a, b)
+
+    def rewrite(li, where, x):
+        if where == "attn->mlp" and li == 1:
+            x.mul_(0.5)                                          # in place, invisible without a version counter
+        return x
+    host.between = rewrite
+    with torch.inference_mode():
+        with pytest.raises(RuntimeError, match="residual tensor changed between two module calls"):
+            host.run(TOKENS)
+    host.between = None
+    fast.set_verify(False)
+    host.close()

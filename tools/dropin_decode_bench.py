@@ -70,6 +70,8 @@ def main():
         sample = torch.argmax(logits[0, -1]).cpu().unsqueeze(0).unsqueeze(0)
         ids = torch.cat((ids, sample), dim=-1)
     torch.cuda.synchronize()
+    fast = getattr(ext_c, "_fast", None)
+    if fast is not None: fast.stats(True)
     prof = None
     if args.profile:
         import cProfile
@@ -88,6 +90,8 @@ def main():
     print(json.dumps({"metric": "decode tokens/s, unmodified reference host on the drop-in (test_inference.py -s loop)",
                       "value": round(args.tokens / dt, 2), "unit": "tokens/s", "ms_per_token": round(dt / args.tokens * 1e3, 3),
                       "tokens": args.tokens, "layers": args.layers, "recipe": args.recipe, "attention": "reference _attn_flash -> dropin/flash_attn.flash_attn_func (csrc/attn.hip)" if args.attn == "flash" else "reference _attn_torch (matmul branch)",
+                      "binding": ("compiled (dropin/_exl2_fast.so); per timed token: " + json.dumps({k: (round(v / args.tokens, 2) if isinstance(v, int) and not isinstance(v, bool) and k != "max_rows" and k != "known_successors" else v)
+                                                                                                          for k, v in fast.stats().items()})) if fast is not None else "ctypes (exllamav2_amd/ext.py)",
                       "write_dir_s": round(t_write, 1), "load_s": round(t_load, 1), "last_tokens": ids[0, -4:].tolist()}))
 
 
