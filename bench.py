@@ -630,8 +630,10 @@ def dropin_rate_in_child(timeout_s: int = 300):
             if "value" in d:
                 return {"tokens_per_s": d["value"], "ms_per_token": d["ms_per_token"], "tokens": d["tokens"], "attention": d["attention"],
                         "loop": "unmodified reference host (ExLlamaV2 / ExLlamaV2Cache / test_inference.py -s loop) on dropin/exllamav2_ext.py",
-                        "limiter": "per-module route: 5 launches per layer on the un-chained kernels, no whole-step graph, ~130 ctypes "
-                                   "calls per token on the host (DESIGN.md section 4)"}
+                        "binding": d.get("binding"),
+                        "route": "compiled binding + module chain behind the operator boundary (dropin/_exl2_fast.cpp): the lean decode "
+                                 "kernels, 6 launches per layer (q|k|v, RoPE, attention, o, gate|up, down), eager launches from the "
+                                 "reference's Python loop; no whole-step graph (DESIGN.md section 3.5)"}
             return d
         return {"error": f"child rc={r.returncode}: {(r.stderr or '').strip()[-200:]}"}
     except subprocess.TimeoutExpired:

@@ -19,8 +19,16 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     if rotary_cos is not None or rotary_sin is not None or cache_batch_idx is not None or cache_leftpad is not None \
             or alibi_slopes is not None or return_softmax_lse:
         raise NotImplementedError("flash_attn shim: only the arguments exllamav2 passes are supported")
-    if tuple(window_size) != (-1, -1) or softcap:
-        raise NotImplementedError("flash_attn shim: sliding window / softcap are not built (SURVEY.md 8a row a15)")
+    if softcap:
+        raise NotImplementedError("flash_attn shim: softcap is not built (SURVEY.md 8a row a15)")
+    # sliding window (attn.py:590-594 passes (W, W) for Mistral-family checkpoints): a window that cannot clip -- every key a query
+    # may see lies within W positions of it -- is plain causal attention; that is decided from HOST-side sizes (the table's capacity),
+    # never by reading cache_seqlens back.  A window that could clip is refused, not approximated.
+    if tuple(window_size) != (-1, -1):
+        capacity = (block_table.shape[1] * k_cache.shape[1]) if block_table is not None else k_cache.shape[1]
+        if window_size[0] < 0 or capacity - 1 > window_size[0]:
+            raise NotImplementedError(f"flash_attn shim: sliding window {tuple(window_size)} over a cache of {capacity} positions would clip; "
+                                      "windowed attention is not built (SURVEY.md 8a row a15)")
     if isinstance(cache_seqlens, int):
         cache_seqlens = torch.full((q.shape[0],), cache_seqlens, dtype=torch.int32, device=q.device)
     # decode-sized steps of the dynamic generator: append + attention + merge in ONE launch through the compiled binding (which also
@@ -74,10 +82,13 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, wi
     rows) instead of the ~8 torch launches per layer of the reference's own `_attn_torch` fallback."""
     if dropout_p or alibi_slopes is not None or return_attn_probs:
         raise NotImplementedError("flash_attn shim: only the arguments exllamav2 passes are supported")
-    if tuple(window_size) != (-1, -1) or softcap:
-        raise NotImplementedError("flash_attn shim: sliding window / softcap are not built (SURVEY.md 8a row a15)")
+    if softcap:
+        raise NotImplementedError("flash_attn shim: softcap is not built (SURVEY.md 8a row a15)")
     b, s, nh, hd = q.shape
     n = k.shape[1]
+    if tuple(window_size) != (-1, -1) and (window_size[0] < 0 or n - 1 > window_size[0]):     # (see flash_attn_with_kvcache)
+        raise NotImplementedError(f"flash_attn shim: sliding window {tuple(window_size)} over {n} keys would clip; windowed attention "
+                                  "is not built (SURVEY.md 8a row a15)")
     if not causal and s > 1:
         raise NotImplementedError("flash_attn shim: the kernels are causal (bottom-right aligned), like every call of the reference")
     if not q.is_contiguous():

@@ -785,6 +785,9 @@ static int attn_decode_fused_impl(const void* q, const void* k_new, const void* 
         nsplit = (int)(((gqa_small ? 1024 : 512) + base - 1) / base);
         if (nsplit > (gqa_small ? 64 : 16)) nsplit = gqa_small ? 64 : 16;
         if (nsplit < 1) nsplit = 1;
+        // (measurement switch: an upper bound on the grid's splits -- what do the workgroups of unused splits cost a short-context launch?)
+        static const int cap = []() { const char* e = getenv("EXL2_ATT_NSPLIT_MAX"); return e ? atoi(e) : 0; }();
+        if (cap >= 1 && nsplit > cap) nsplit = cap;
     }
     long long need = exl2_paged_attn_scratch_bytes(batch * q_len * num_heads, head_dim, nsplit);
     while (nsplit > 1 && (need > scratch_bytes || !scratch)) { nsplit /= 2; need = exl2_paged_attn_scratch_bytes(batch * q_len * num_heads, head_dim, nsplit); }
