@@ -101,7 +101,7 @@ void* stream_of(const at::Tensor& t) { return t.is_cuda() ? (void*)c10::hip::get
 // every hand-off from x on entry and compares (a debugging aid: it synchronises); EXL2_MODULE_CHAIN=0 turns the chain off.
 int64_t version_of(const at::Tensor& t) { return t.is_inference() ? -2 : (int64_t)t._version(); }
 
-struct ModInfo { bool attn, capable; cvp in_invperm, o_invperm, norm_w; };
+struct ModInfo { bool attn, capable; cvp in_invperm, o_invperm, norm_w; int rows_ok = 16; };      // rows_ok: largest call the chained kernels took so far declined nothing up to
 struct Identity
 {
     at::Tensor keep;                    // holds the storage: the address below cannot be handed to another tensor meanwhile
@@ -114,7 +114,7 @@ struct DevBuf { at::Tensor xp[2], ss[2], vxp, vss, packed, scratch, counters; in
 
 struct State
 {
-    bool on = true, verify = false; int max_rows = 4;
+    bool on = true, verify = false; int max_rows = 16;
     std::unordered_map<void*, ModInfo> info;
     std::unordered_map<void*, void*> succ;
     std::unordered_map<int, DevBuf> bufs;
@@ -125,13 +125,13 @@ struct State
     // attention: the module whose q_attn_forward_1 ran last, its q tensor; the output flash_attn_func returned and its packed copy
     void* cur_attn = nullptr; void* cur_q = nullptr; int cur_rows = 0;
     void* packed_for = nullptr; Identity attn_out; cvp packed_ptr = nullptr;
-    long long n_chained = 0, n_published = 0, n_plain = 0, n_attn_fast = 0, n_verified = 0;
+    long long n_chained = 0, n_published = 0, n_plain = 0, n_attn_fast = 0, n_verified = 0, n_declined = 0;
 } S;
 
 void drop_pending() { S.consumer = nullptr; S.pub_x.clear(); }
 void drop_all() { drop_pending(); S.finisher = nullptr; S.fin_x.clear(); S.cur_attn = nullptr; S.cur_q = nullptr; S.packed_for = nullptr; S.attn_out.clear(); S.packed_ptr = nullptr; }
 
-const ModInfo& info_of(void* h, bool attn)
+ModInfo& info_of(void* h, bool attn)
 {
     auto it = S.info.find(h);
     if (it != S.info.end()) return it->second;
@@ -221,7 +221,7 @@ bool chain_rows(int rows) { return S.on && rows >= 1 && rows <= S.max_rows; }
 void init(const std::string& path, bool cpu_ok)
 {
     if (dll) { dlclose(dll); dll = nullptr; }
-    dll = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    dll = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);      // (LOCAL: a process may hold the emulation twin and the product library side by side -- the test-suite does)
     if (!dll) throw std::runtime_error(std::string("_exl2_fast: cannot load ") + path + ": " + dlerror() + " (there is no CPU fallback)");
     allow_cpu = cpu_ok;
     bind(api.last_error, "exl2_last_error");
@@ -239,7 +239,7 @@ void init(const std::string& path, bool cpu_ok)
     S = State();
     if (const char* e = getenv("EXL2_MODULE_CHAIN")) S.on = atoi(e) != 0;
     if (const char* e = getenv("EXL2_MODULE_CHAIN_VERIFY")) S.verify = atoi(e) != 0;
-    if (const char* e = getenv("EXL2_MODULE_CHAIN_ROWS")) { const int v = atoi(e); if (v >= 1 && v <= 4) S.max_rows = v; }
+    if (const char* e = getenv("EXL2_MODULE_CHAIN_ROWS")) { const int v = atoi(e); if (v >= 1 && v <= 16) S.max_rows = v; }
 }
 
 void q_attn_forward_1(uintptr_t handle, const at::Tensor& x, int batch_size, int q_len, int past_len, const at::Tensor& past_lens,
@@ -257,14 +257,16 @@ void q_attn_forward_1(uintptr_t handle, const at::Tensor& x, int batch_size, int
     S.cur_attn = nullptr; S.cur_q = nullptr; S.packed_for = nullptr;
     if (chain_rows(rows))
     {
-        const ModInfo& mi = info_of(h, true);
-        if (mi.capable)
+        ModInfo& mi = info_of(h, true);
+        if (mi.capable && rows <= mi.rows_ok)
         {
             const HandOff ho = enter(h, mi, x, rows, hidden, stream);
-            check(api.q_attn_forward_1_chain_rope(h, ho.xp, ho.ss, ho.npart, batch_size, q_len, past_len, i32_ptr(past_lens, "past_lens"),
-                                                  q, k, v, any_ptr(sin), any_ptr(cos), stream));
-            S.cur_attn = h; S.cur_q = q; S.cur_rows = rows;
-            return;
+            const int rc = api.q_attn_forward_1_chain_rope(h, ho.xp, ho.ss, ho.npart, batch_size, q_len, past_len, i32_ptr(past_lens, "past_lens"),
+                                                           q, k, v, any_ptr(sin), any_ptr(cos), stream);
+            if (rc == 0) { S.cur_attn = h; S.cur_q = q; S.cur_rows = rows; return; }
+            // a shape the chained kernels do not cover at this row count: nothing was launched (include/exl2_hip.h) -- the plain entry
+            // point takes this call and every later one of this size
+            mi.rows_ok = rows - 1; S.n_declined++;
         }
     }
     drop_all();
@@ -382,10 +384,13 @@ void q_attn_forward_2(uintptr_t handle, const at::Tensor& x, const at::Tensor& a
         int npart = 0;
         const int rc = api.q_attn_forward_2_chain(h, xq, S.packed_ptr, rows, p.invperm, p.norm_w, p.xp, p.ss, &npart, stream);
         S.packed_for = nullptr; S.attn_out.clear();
-        check(rc);
-        S.n_chained++;
-        finished(h, x, rows, stream, p, npart);
-        return;
+        if (rc == 0)
+        {
+            S.n_chained++;
+            finished(h, x, rows, stream, p, npart);
+            return;
+        }
+        info_of(h, true).rows_ok = rows - 1; S.n_declined++;       // (nothing was launched: the plain entry point below takes the call)
     }
     S.packed_for = nullptr; S.attn_out.clear();
     S.n_plain++;
@@ -406,15 +411,17 @@ void q_mlp_forward_(uintptr_t handle, const at::Tensor& x, const py::object& lor
     const int rows = (int)(x.numel() / hidden);
     if (chain_rows(rows))
     {
-        const ModInfo& mi = info_of(h, false);
-        if (mi.capable)
+        ModInfo& mi = info_of(h, false);
+        if (mi.capable && rows <= mi.rows_ok)
         {
             const HandOff ho = enter(h, mi, x, rows, hidden, stream);
             const Publish p = successor(h, x, hidden);
             int npart = 0;
-            check(api.q_mlp_forward_chain(h, xq, ho.xp, ho.ss, ho.npart, rows, p.invperm, p.norm_w, p.xp, p.ss, &npart, stream));
-            finished(h, x, rows, stream, p, npart);
-            return;
+            const int rc = api.q_mlp_forward_chain(h, xq, ho.xp, ho.ss, ho.npart, rows, p.invperm, p.norm_w, p.xp, p.ss, &npart, stream);
+            if (rc == 0) { finished(h, x, rows, stream, p, npart); return; }
+            // declined (e.g. a down_proj too deep for one register pass at this row count): at most gate | up ran, into the module's
+            // scratch -- x is untouched, the plain entry point recomputes the block
+            mi.rows_ok = rows - 1; S.n_declined++;
         }
     }
     drop_all();
@@ -445,13 +452,14 @@ py::dict stats(bool reset)
 {
     py::dict d;
     d["chained"] = S.n_chained; d["published"] = S.n_published; d["plain"] = S.n_plain; d["attn_fast"] = S.n_attn_fast;
-    d["verified"] = S.n_verified; d["on"] = S.on; d["max_rows"] = S.max_rows; d["known_successors"] = (long long)S.succ.size();
-    if (reset) { S.n_chained = S.n_published = S.n_plain = S.n_attn_fast = S.n_verified = 0; }
+    d["verified"] = S.n_verified; d["declined"] = S.n_declined; d["on"] = S.on; d["max_rows"] = S.max_rows; d["known_successors"] = (long long)S.succ.size();
+    if (reset) { S.n_chained = S.n_published = S.n_plain = S.n_attn_fast = S.n_verified = S.n_declined = 0; }
     return d;
 }
 
 void set_chain(bool on) { S.on = on; drop_all(); }
 void set_verify(bool on) { S.verify = on; }
+void set_max_rows(int n) { if (n >= 1 && n <= 16) S.max_rows = n; drop_all(); }
 void reset() { drop_all(); S.succ.clear(); S.info.clear(); S.bufs.clear(); }
 
 }  // namespace
@@ -470,5 +478,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("stats", &stats, py::arg("reset") = false);
     m.def("set_chain", &set_chain);
     m.def("set_verify", &set_verify);
+    m.def("set_max_rows", &set_max_rows);
     m.def("reset", &reset);
 }

@@ -187,6 +187,7 @@ def test_rows_beyond_the_chain_and_prefill_shapes_take_the_plain_route(be):
     attn, mlp = m.layers[0]
     H, KVH, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     rows = 6
+    fast.set_max_rows(4)                                        # (EXL2_MODULE_CHAIN_ROWS: the largest call the chain takes; default 16)
     fast.stats(True)
     x = (torch.randn((1, rows, cfg.hidden_size), device=m.device) * 0.5).half()
     x0 = x.clone()
@@ -204,6 +205,80 @@ def test_rows_beyond_the_chain_and_prefill_shapes_take_the_plain_route(be):
     assert st["plain"] == 2 and st["chained"] == 0 and st["published"] == 0, st
     # a call shape flash_attn_decode does not take is handed back (None), never approximated
     assert fast.flash_attn_decode(q.view(1, rows, H, hd)[:, :, :, :32], k.view(1, rows, KVH, hd), v.view(1, rows, KVH, hd), 0.125) is None
+    fast.set_max_rows(16)
+    host.close()
+
+
+@pytest.mark.parametrize("b", [6, 16])
+def test_paged_mode_with_more_sequences_than_the_pipelined_form_takes(be, b):
+    """5..16 rows per call: the chained kernels' ROWS / XMEM forms behind the same module calls (the dynamic generator with many jobs)"""
+    fast = load_fast(be)
+    cfg = cfg_small(num_hidden_layers=2, max_input_len=16)
+    host = Host(be, fast, cfg, seed=13)
+    m = host.model
+    H, KVH, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    rng = np.random.default_rng(b)
+    toks = rng.integers(0, cfg.vocab_size, size=(3, b))
+
+    def run():
+        Kc = [torch.zeros((b, 256, KVH, hd), dtype=torch.float16, device=m.device) for _ in m.layers]
+        Vc = [torch.zeros_like(k) for k in Kc]
+        table = torch.arange(b, dtype=torch.int32, device=m.device).view(b, 1)
+        lens = torch.zeros((b,), dtype=torch.int32, device=m.device)
+        outs = []
+        for step in toks:
+            x = m.embed_tokens[torch.tensor(step, device=m.device)].view(b, 1, cfg.hidden_size).contiguous()
+            for li, (attn, mlp) in enumerate(m.layers):
+                q = torch.empty((b, 1, H, hd), dtype=torch.float16, device=m.device)
+                k = torch.empty((b, 1, KVH, hd), dtype=torch.float16, device=m.device)
+                v = torch.empty_like(k)
+                fast.q_attn_forward_1(attn.q_handle, x, b, 1, 0, lens, q, k, v, m.sin, m.cos, [], none_tensor)
+                out = fast.flash_attn_kvcache_decode(q, Kc[li], Vc[li], k, v, lens, table, hd ** -0.5)
+                assert out is not None
+                fast.q_attn_forward_2(attn.q_handle, x, out.view(b, 1, H * hd), b, 1, [], none_tensor)
+                fast.q_mlp_forward_(mlp.q_handle, x, [], none_tensor)
+            lens = lens + 1
+            outs.append(be.n(m.lm_head.forward(m.norm.forward(x))[..., :cfg.vocab_size]))
+        return outs
+
+    fast.set_chain(True); fast.stats(True)
+    chained = run()
+    st = fast.stats(True)
+    L, n = cfg.num_hidden_layers, len(toks)
+    assert st["declined"] == 0 and st["plain"] == 0 and st["chained"] == (n - 1) * (2 * L - 1) + n * L, st
+    host.oracle.reset(b)
+    for step, got in zip(toks, chained):
+        check_logits(got, host.oracle.forward(step[:, None])[:, -1:])
+    host.close()
+
+
+def test_a_prompt_chunk_of_a_few_rows_chains_as_well(be):
+    """q_len > 1 at batch 1 (a short prompt, a speculative-decoding verification step): rows = q_len, causal among the new keys"""
+    fast = load_fast(be)
+    cfg = cfg_small(num_hidden_layers=2)
+    host = Host(be, fast, cfg, seed=17)
+    m = host.model
+    H, KVH, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    ids = np.array([[3, 17, 5, 101, 42, 9]])
+    host.reset()
+    s = ids.shape[1]
+    fast.set_chain(True); fast.stats(True)
+    for rep in range(2):                                         # (second pass: the module order is known, the chain is taken)
+        x = m.embed_tokens[torch.tensor(ids[0], device=m.device)].view(1, s, cfg.hidden_size).contiguous()
+        for li, (attn, mlp) in enumerate(m.layers):
+            q = torch.empty((1, s, H * hd), dtype=torch.float16, device=m.device)
+            k = host.K[li][:1, 0:s, :]
+            v = host.V[li][:1, 0:s, :]
+            fast.q_attn_forward_1(attn.q_handle, x, 1, s, 0, none_tensor, q, k, v, m.sin, m.cos, [], none_tensor)
+            out = fast.flash_attn_decode(q.view(1, s, H, hd), host.K[li][:1, :s].view(1, s, KVH, hd), host.V[li][:1, :s].view(1, s, KVH, hd), hd ** -0.5)
+            assert out is not None
+            fast.q_attn_forward_2(attn.q_handle, x, out.reshape(1, s, H * hd), 1, s, [], none_tensor)
+            fast.q_mlp_forward_(mlp.q_handle, x, [], none_tensor)
+        logits = be.n(m.lm_head.forward(m.norm.forward(x))[..., :cfg.vocab_size])
+        host.oracle.reset(1)
+        check_logits(logits, host.oracle.forward(ids))
+    st = fast.stats(True)
+    assert st["declined"] == 0 and st["plain"] == 0 and st["chained"] >= 2 * cfg.num_hidden_layers, st
     host.close()
 
 
