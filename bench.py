@@ -812,7 +812,8 @@ def main():
         # stretch is part of set-up, the W warm-up steps below are still run and not timed
         dec.reset(torch.tensor([1] * args.batch), 0)
         t_ramp = time.perf_counter()
-        while time.perf_counter() - t_ramp < 4.0:
+        # (EXL2_BENCH_RAMP_S: the counter pass of tools/gpu_run.sh sets 0 -- every graph replay is serialised kernel by kernel there)
+        while time.perf_counter() - t_ramp < float(os.environ.get("EXL2_BENCH_RAMP_S", "4.0")):
             dec.reset(torch.tensor([1] * args.batch), 0)
             dec.run(64, use_graph=not args.no_graph)
             torch.cuda.synchronize()

@@ -42,7 +42,7 @@ if has pmc; then
   for mode in graph nograph; do
     flag=""; [ $mode = nograph ] && flag="--no-graph"
     echo "== rocprofv3 --pmc FETCH_SIZE ($mode)"
-    (cd /tmp && timeout -k 10 ${PMC_TIMEOUT:-240} rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/prof_pmc -o $T -- python $ROOT/bench.py --steps 8 --warmup 2 --windows 1 --headline-only $flag --no-parity-check > $R/${T}_rocprof_pmc_$mode.log 2>&1); rc=$?; echo "rc=$rc"
+    (cd /tmp && EXL2_BENCH_RAMP_S=0 timeout -k 10 ${PMC_TIMEOUT:-240} rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/prof_pmc -o $T -- python $ROOT/bench.py --steps ${PMC_STEPS:-4} --warmup 1 --windows 1 --headline-only $flag --no-parity-check > $R/${T}_rocprof_pmc_$mode.log 2>&1); rc=$?; echo "rc=$rc"
     python - $mode $T <<'PY'
 import csv, glob, collections, json, sys
 mode, tag = sys.argv[1], sys.argv[2]
