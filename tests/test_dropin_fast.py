@@ -104,7 +104,7 @@ class Host:
 TOKENS = [3, 17, 5, 101, 42]
 
 
-@pytest.mark.parametrize("recipe", ["4.0bpw", "2.5bpw"])
+@pytest.mark.parametrize("recipe", ["4.0bpw", "2.5bpw", "gptq-4bit-128g"])
 def test_module_chain_behind_the_boundary_equals_oracle_and_plain_route(be, recipe):
     fast = load_fast(be)
     cfg = cfg_small()
