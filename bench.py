@@ -356,7 +356,11 @@ def pmc_traffic_gb(launches_per_step, kernel_prefix: str):
     wide coalesced reads, MI355X_MICROARCH.md section HBM).  Counters cannot be read from inside this process, so the
     figure is labelled with the file it comes from.  (None, None) when no profile of this kernel is committed."""
     try:
-        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
+        # the round's own pass of THIS command only (rNN_pmc_summary[_graph|_nograph].json), newest round first, the pass over the
+        # replayed graph before the one over eager launches
+        import re
+        files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d\d_pmc_summary(_graph|_nograph)?\.json", f)),
+                       key=lambda f: (f[:3], {"_graph": 2, "": 1, "_nograph": 0}[re.fullmatch(r"r\d\d_pmc_summary(_graph|_nograph)?\.json", f).group(1) or ""]))
         for f in reversed(files):
             d = json.load(open(os.path.join(ROOT, "profiles", f)))
             # every instantiation of the kernel (geometries of one template), weighted by its launches
@@ -375,7 +379,8 @@ def profile_frac(alg_bytes_per_launch: float):
     `frac` (HIP events, this box) and this figure (rocprofv3, the builder's box) side by side make the two boxes visible."""
     import csv
     try:
-        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_kernel_stats.csv") and f[1:3].isdigit() and f[3] == "_")
+        import re
+        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d\d_kernel_stats\.csv", f))   # (the headline loop's pass only)
         if not files:
             return None, None
         rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", files[-1]))) if "qgemv_" in r["Name"]]

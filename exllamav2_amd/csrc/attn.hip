@@ -13,6 +13,7 @@
 #include "hw.h"
 #include "errors.h"
 #include "chain_sync.h"
+#include "attn_merge.h"
 #include <string.h>
 
 #define ATT_WAVES 4
@@ -187,16 +188,7 @@ KERNEL void __launch_bounds__(256) attn_combine_kernel(const AttnArgs a, int hd)
     const size_t qrow = bid_x();
     for (int d = tid(); d < hd; d += nthreads())
     {
-        float M = NEG_BIG;
-        for (int s2 = 0; s2 < a.nsplit; s2++) M = fmaxf(M, a.part_ml[(qrow * a.nsplit + s2) * 2]);
-        float L = 0.0f, O = 0.0f;
-        for (int s2 = 0; s2 < a.nsplit; s2++)
-        {
-            const float w = fast_exp(a.part_ml[(qrow * a.nsplit + s2) * 2] - M);
-            L += a.part_ml[(qrow * a.nsplit + s2) * 2 + 1] * w;
-            O += a.part_o[(qrow * a.nsplit + s2) * hd + d] * w;
-        }
-        a.out[qrow * hd + d] = (f16)(L > 0.0f ? O / L : 0.0f);
+        a.out[qrow * hd + d] = (f16)merge_split_partials<false>(a.part_o, a.part_ml, qrow, a.nsplit, a.nsplit, hd, d);
     }
 }
 
@@ -223,6 +215,7 @@ struct FusedArgs
     int b, s, H, KVH;                                   // (the consumer's packed order, i.e. o_proj's act-order: qgemv_flat.hip)
     int page_size, page_shift, pages_per_seq;
     int past_const, nsplit, rope, keys_per_split_min;
+    int split_short_cap, keys_per_split_long;           // two-slope split count (fused_active_splits); keys_per_split_long = 0: one slope
     float scale;
     // overlapped chain (chain_sync.h / hw.h): q / k_new / v_new are read behind the wait, with agent-scope loads; the
     // workgroup that writes a group's final output arrives once (sync_total = batch * kv_heads * row_blocks per launch)
@@ -231,6 +224,23 @@ struct FusedArgs
 };
 
 // where feature d of query row qrow = (token row) * H + head goes
+// Number of splits a launch of `total` keys uses (the grid holds a.nsplit of them; the rest leave at entry).  One slope: a split per
+// keys_per_split_min keys.  Two slopes (few KV heads -- grouped-query models; round 5, profiles/r05m_attn_sweep2_merge.jsonl): a split
+// per keys_per_split_min keys up to split_short_cap, beyond that a split per keys_per_split_long keys -- short contexts want many short
+// slices early (the launch is latency-bound), long ones few enough that the slices stay long (each split pays its own start-up and the
+// merge reads every partial).
+DEV int fused_active_splits(const FusedArgs& a, int total)
+{
+    int eff = (total + a.keys_per_split_min - 1) / a.keys_per_split_min;
+    if (a.keys_per_split_long > 0)
+    {
+        if (eff > a.split_short_cap) eff = a.split_short_cap;
+        const int e2 = (total + a.keys_per_split_long - 1) / a.keys_per_split_long;
+        if (e2 > eff) eff = e2;
+    }
+    return eff < 1 ? 1 : (eff > a.nsplit ? a.nsplit : eff);
+}
+
 template <int HDIM> DEV size_t fused_out_index(const FusedArgs& a, size_t qrow, int d)
 {
     if (!a.out_invperm) return qrow * HDIM + d;
@@ -308,8 +318,7 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     {
         // overlapped chain: q / k_new / v_new are read behind the wait; workgroups of unused splits leave before it
         const int total_e = a.past_const + (p_raw > 0 ? p_raw : 0) + a.s;
-        const int eff_e = (total_e + a.keys_per_split_min - 1) / a.keys_per_split_min;
-        if (split >= (eff_e < 1 ? 1 : (eff_e > a.nsplit ? a.nsplit : eff_e))) return;
+        if (split >= fused_active_splits(a, total_e)) return;
         if (wv == 0) sync_wait_go(a.sync_wait, kh + split);
         block_sync();
     }
@@ -340,8 +349,7 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
 
     const int past = a.past_const + (p_raw > 0 ? p_raw : 0);
     const int total = past + a.s;
-    int eff = (total + a.keys_per_split_min - 1) / a.keys_per_split_min;
-    eff = eff < 1 ? 1 : (eff > a.nsplit ? a.nsplit : eff);
+    const int eff = fused_active_splits(a, total);
     if (split >= eff) return;
     int kps = (total + eff - 1) / eff;
     kps = (kps + 15) & ~15;
@@ -538,16 +546,7 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
         const int rr = r0 + r;
         const int j = rr / G, g = rr - j * G;
         const size_t qrow = ((size_t)b * a.s + j) * a.H + kh * G + g;
-        float M = NEG_BIG;
-        for (int s2 = 0; s2 < eff; s2++) M = fmaxf(M, load_agent_f32(a.part_ml + (qrow * a.nsplit + s2) * 2));
-        float L = 0.0f, O = 0.0f;
-        for (int s2 = 0; s2 < eff; s2++)
-        {
-            const float w = fast_exp(load_agent_f32(a.part_ml + (qrow * a.nsplit + s2) * 2) - M);
-            L += load_agent_f32(a.part_ml + (qrow * a.nsplit + s2) * 2 + 1) * w;
-            O += load_agent_f32(a.part_o + (qrow * a.nsplit + s2) * HDIM + d) * w;
-        }
-        const f16 y = (f16)(L > 0.0f ? O / L : 0.0f);
+        const f16 y = (f16)merge_split_partials<true>(a.part_o, a.part_ml, qrow, a.nsplit, eff, HDIM, d);
         if (a.sync_signal) store_agent_f16(a.out + fused_out_index<HDIM>(a, qrow, d), y);
         else a.out[fused_out_index<HDIM>(a, qrow, d)] = y;
         if (a.out_nat) a.out_nat[qrow * HDIM + d] = y;
@@ -776,18 +775,25 @@ static int attn_decode_fused_impl(const void* q, const void* k_new, const void* 
     a.past_const = past_const; a.rope = rope_style != 0; a.scale = softmax_scale;
     {
         // keys one workgroup takes before the step is split over several (a split costs the partial-result hand-off)
-        static const int kps = []() { const char* e = getenv("EXL2_ATT_KPS"); const int v = e ? atoi(e) : 0; return v >= 16 ? v : ATT_KPS_DEFAULT; }();
-        a.keys_per_split_min = kps;
+        // (read per call: tools/attn_bench.py sweeps it inside one process)
+        const char* e = getenv("EXL2_ATT_KPS"); const int v = e ? atoi(e) : 0;
+        a.keys_per_split_min = v >= 16 ? v : ATT_KPS_DEFAULT;
+        // few KV heads: two slopes -- a split per 64 keys up to 16 splits, then one per 256 keys (measured: see fused_active_splits)
+        if (v < 16 && gqa_small && !getenv("EXL2_ATT_ONE_SLOPE")) { a.keys_per_split_min = 64; a.split_short_cap = 16; a.keys_per_split_long = 256; }
     }
     if (nsplit <= 0)
     {
         const long long base = (long long)num_kv_heads * batch * rblocks;
-        nsplit = (int)(((gqa_small ? 1024 : 512) + base - 1) / base);
-        if (nsplit > (gqa_small ? 64 : 16)) nsplit = gqa_small ? 64 : 16;
+        // (few KV heads: 4-row workgroups hold 66 KB of LDS, two per CU -- a grid beyond ~768 of them makes the workgroups of unused splits
+        // queue in front of the working ones: 48 splits x 2 row blocks x 8 KV heads measured better than 64 x 2 x 8 at every context)
+        // (many KV heads: up to 32 splits since round 5 -- with the batched merge 32 slices beat 16 from ~4000 keys on by 5-10 %)
+        nsplit = (int)(((gqa_small ? 768 : 1024) + base - 1) / base);
+        if (nsplit > (gqa_small ? 64 : 32)) nsplit = gqa_small ? 64 : 32;
         if (nsplit < 1) nsplit = 1;
-        // (measurement switch: an upper bound on the grid's splits -- what do the workgroups of unused splits cost a short-context launch?)
-        static const int cap = []() { const char* e = getenv("EXL2_ATT_NSPLIT_MAX"); return e ? atoi(e) : 0; }();
-        if (cap >= 1 && nsplit > cap) nsplit = cap;
+        // (measurement switch, read per call: the grid's number of splits -- below the policy's figure: what do the workgroups of unused
+        // splits cost a short-context launch?  above it, up to 64: more, shorter key slices at a long context)
+        const char* e = getenv("EXL2_ATT_NSPLIT_MAX"); const int cap = e ? atoi(e) : 0;
+        if (cap >= 1) { const long long fill = (long long)(4096 + base - 1) / base; nsplit = cap < 64 ? cap : 64; if (nsplit > fill) nsplit = (int)fill; if (nsplit < 1) nsplit = 1; }
     }
     long long need = exl2_paged_attn_scratch_bytes(batch * q_len * num_heads, head_dim, nsplit);
     while (nsplit > 1 && (need > scratch_bytes || !scratch)) { nsplit /= 2; need = exl2_paged_attn_scratch_bytes(batch * q_len * num_heads, head_dim, nsplit); }

@@ -14,6 +14,7 @@
 // x to fp16 element by element; this path keeps fp32 sums -- same values within that rounding.)
 #include "hw.h"
 #include "errors.h"
+#include "attn_merge.h"
 #include <string.h>
 
 #define AQ_WAVES 4
@@ -410,16 +411,7 @@ KERNEL void __launch_bounds__(256) attn_q4_combine_kernel(const AttnQ4Args a, in
     if (eff == 1) return;                                   // the single split stored the result itself
     for (int d = tid(); d < hd; d += nthreads())
     {
-        float M = AQ_NEG_BIG;
-        for (int s2 = 0; s2 < eff; s2++) M = fmaxf(M, a.part_ml[(qrow * a.nsplit + s2) * 2]);
-        float L = 0.0f, O = 0.0f;
-        for (int s2 = 0; s2 < eff; s2++)
-        {
-            const float w = fast_exp(a.part_ml[(qrow * a.nsplit + s2) * 2] - M);
-            L += a.part_ml[(qrow * a.nsplit + s2) * 2 + 1] * w;
-            O += a.part_o[(qrow * a.nsplit + s2) * hd + d] * w;
-        }
-        a.out[q4_out_index(a, qrow, hd, d)] = (f16)(L > 0.0f ? O / L : 0.0f);
+        a.out[q4_out_index(a, qrow, hd, d)] = (f16)merge_split_partials<false>(a.part_o, a.part_ml, qrow, a.nsplit, eff, hd, d);
     }
 }
 

@@ -278,6 +278,35 @@ def test_attention_fused_decode_step(be, hd, nh, kvh, s, rope):
         assert int(be.n(counters).sum()) == 0
 
 
+@pytest.mark.parametrize("nh,kvh,ctx", [(8, 1, 5000), (4, 4, 3000), (8, 2, 1300)])
+def test_attention_fused_long_context_many_splits(be, nh, kvh, ctx):
+    """Contexts long enough for the second slope of the split policy (few KV heads: 16 splits of 64 keys, then a split per 256 keys) and
+    for the batched merge of more than 8 partials (csrc/attn_merge.h): one sequence, one new token, no rotation, against the oracle."""
+    rng = np.random.default_rng(ctx)
+    hd, ps = 128, 256
+    pages = (ctx + ps) // ps + 1
+    table = rng.permutation(pages).astype(np.int32).reshape(1, pages)
+    kc = (rng.standard_normal((pages, ps, kvh, hd)) * 0.5).astype(F16)
+    vc = rng.standard_normal((pages, ps, kvh, hd)).astype(F16)
+    q = rng.standard_normal((1, 1, nh, hd)).astype(F16)
+    kn = (rng.standard_normal((1, 1, kvh, hd)) * 0.5).astype(F16)
+    vn = rng.standard_normal((1, 1, kvh, hd)).astype(F16)
+    seqlens = np.array([ctx], dtype=np.int32)
+    kc_ref, vc_ref = kc.copy(), vc.copy()
+    want = OM.paged_attention(q, kn, vn, kc_ref, vc_ref, seqlens, table)
+    scratch = torch.zeros((be.ext.paged_attn_scratch_bytes(nh, hd, 64) // 4 + 1,), dtype=torch.float32, device=be.device)
+    counters = torch.zeros((64,), dtype=torch.int32, device=be.device)
+    kct, vct = be.t(kc), be.t(vc)
+    for _ in range(2):                                           # twice: the tickets of the first launch must have been left zeroed
+        out = torch.zeros((1, 1, nh, hd), dtype=torch.float16, device=be.device)
+        assert be.ext.attn_decode_fused(be.t(q), be.t(kn), be.t(vn), kct, vct, out, None, None, be.t(seqlens), be.t(table), 0, 0,
+                                        scratch, counters)
+        got = be.n(out)
+        assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want))
+        assert int(be.n(counters).sum()) == 0
+    assert np.array_equal(be.n(kct).view(np.uint16), kc_ref.view(np.uint16))
+
+
 def test_attention_fused_contiguous_and_fallback(be):
     rng = np.random.default_rng(17)
     b, T, past, hd, nh, kvh, s = 2, 512, 300, 128, 4, 2, 2
