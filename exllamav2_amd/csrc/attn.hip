@@ -15,9 +15,11 @@
 #include "chain_sync.h"
 #include "attn_merge.h"
 #include <string.h>
+#include <type_traits>
 
 #define ATT_WAVES 4
 #define ATT_UNROLL 4
+#define ATT_MAX_PAGES 2048               // page ids of one split's key range kept in LDS (attn_fused_kernel): 8 KB, 512 K keys at 256 per page
 #ifndef ATT_KPS_DEFAULT
 #define ATT_KPS_DEFAULT 128
 #endif
@@ -358,14 +360,24 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     #pragma unroll
     for (int r = 0; r < RB; r++) limit[r] += past;
 
+    // Page ids of the split's key range live in LDS (round 5).  Before, every key step looked its page up in memory and the compiler's
+    // wait for that look-up -- `s_waitcnt vmcnt(0)` -- also drained the K / V rows already requested: the steps of a batch went out one
+    // round trip after the other instead of together.  ONE look-up path only: with a memory look-up kept as a run-time alternative the
+    // compiler waits for it on the LDS path too.  A split inside the sequence's first page (every short-context launch) takes the entry
+    // that was requested speculatively at level 1: no further dependent load, one barrier.  (The host refuses tables wider than
+    // ATT_MAX_PAGES: exl2_attn_decode_fused returns 1, the caller takes the three-launch route.)
+    int* const pg_lds = (int*)(smem + (size_t)NSTREAM * RB * ROWF * 4 + 16);
+    const int pg0 = a.block_table ? (k_start >> a.page_shift) : 0;
+    if (a.block_table)
+    {
+        const int npg = (((k_end > k_start ? k_end : k_start + 1) - 1) >> a.page_shift) - pg0 + 1;
+        if (spec && npg == 1 && pg0 == 0) { if (tid() == 0) pg_lds[0] = tab_spec; }
+        else for (int i = tid(); i < npg; i += nthreads()) pg_lds[i] = a.block_table[(size_t)b * a.pages_per_seq + pg0 + i];
+        block_sync();
+    }
     auto slot_of = [&](const int kp) -> size_t
     {
-        if (a.block_table)
-        {
-            const int pg = kp >> a.page_shift;
-            const int page = (spec && pg == 0) ? tab_spec : a.block_table[(size_t)b * a.pages_per_seq + pg];
-            return (size_t)page * a.page_size + (kp & (a.page_size - 1));
-        }
+        if (a.block_table) return (size_t)pg_lds[(kp >> a.page_shift) - pg0] * a.page_size + (kp & (a.page_size - 1));
         return (size_t)b * a.page_size + kp;
     };
     const size_t row_stride = (size_t)a.KVH * HDIM;
@@ -375,21 +387,33 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
 
     // ---- request level 2: what needs the length -- the first batch of cached keys, the rotary rows of the queries and of
     // the new key -- again together, before anything is used
-    f16x8 kf[UNR], vf[UNR];
+    // Two half-batches (round 5): while one is used the other is in flight.  EVERY request is unconditional -- a position beyond the
+    // split's cached keys reads the split's first row (a cache hit; its score is masked) -- so that the compiler's count of the loads in
+    // flight stays exact and the wait in front of a half-batch is `vmcnt(loads of the other half)`, not `vmcnt(0)`.
+    constexpr int HB = UNR / 2;
+    f16x8 kfa[HB], vfa[HB], kfb[HB], vfb[HB];
     const int base_first = k_start + wv * KPW;
-    auto request_batch = [&](const int base0)
+    auto request_half = [&](f16x8 (&kf)[HB], f16x8 (&vf)[HB], const int base0)
     {
+        // (all cache slots first, then all rows: whatever the page look-up waits for, it waits ONCE per half-batch, in front of its
+        // loads, not between them)
+        size_t slot[HB];
         #pragma unroll
-        for (int u = 0; u < UNR; u++)
+        for (int u = 0; u < HB; u++)
         {
             const int kpos = base0 + u * STEP + group;
-            const int kp = kpos < k_old_end ? kpos : k_start;       // keep the address valid, mask the score
-            const size_t off = slot_of(kp) * row_stride + (size_t)kh * HDIM + dl * 8;
+            slot[u] = slot_of(kpos < k_old_end ? kpos : k_start);   // keep the address valid, mask the score
+        }
+        #pragma unroll
+        for (int u = 0; u < HB; u++)
+        {
+            const size_t off = slot[u] * row_stride + (size_t)kh * HDIM + dl * 8;
             kf[u] = ld_nt((const f16x8*)(a.k_cache + off));
             vf[u] = ld_nt((const f16x8*)(a.v_cache + off));
         }
     };
-    if (base_first < k_old_end) request_batch(base_first);
+    const bool any_old = base_first < k_old_end;
+    if (any_old) { request_half(kfa, vfa, base_first); request_half(kfb, vfb, base_first + HB * STEP); }
     const bool pre_new = k_start <= past;                       // the stream's first new key is row j0 of this step
     if (a.rope)
     {
@@ -437,16 +461,24 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     };
     // keys already in the cache: the K/V rows of UNR steps are requested together (one round trip per batch instead of one
     // per step); the first batch is already in flight
+#define ATTEND_HALF(KF, VF, BASE) \
+    _Pragma("unroll") \
+    for (int u = 0; u < HB; u++) \
+    { \
+        const int kpos_ = (BASE) + u * STEP + group; \
+        if ((BASE) + u * STEP < k_old_end) attend(KF[u], VF[u], kpos_, kpos_ < k_old_end); \
+    }
     for (int base0 = base_first; base0 < k_old_end; base0 += UNR * STEP)
     {
-        if (base0 != base_first) request_batch(base0);
-        #pragma unroll
-        for (int u = 0; u < UNR; u++)
-        {
-            const int kpos = base0 + u * STEP + group;
-            if (base0 + u * STEP < k_old_end) attend(kf[u], vf[u], kpos, kpos < k_old_end);
-        }
+        // half A is used with half B in flight; A is re-requested (next batch) before B is used
+        ATTEND_HALF(kfa, vfa, base0)
+        if (base0 + HB * STEP >= k_old_end) break;
+        request_half(kfa, vfa, base0 + UNR * STEP);
+        ATTEND_HALF(kfb, vfb, base0 + HB * STEP)
+        if (base0 + UNR * STEP >= k_old_end) break;
+        request_half(kfb, vfb, base0 + UNR * STEP + HB * STEP);
     }
+#undef ATTEND_HALF
     // keys of this step: rotate, use, append (the stream's first one was requested and rotated above)
     const int base_new = max(k_start, past) + wv * KPW;
     for (int base = base_new; base < k_end; base += ATT_WAVES * KPW)
@@ -755,6 +787,7 @@ static int attn_decode_fused_impl(const void* q, const void* k_new, const void* 
     const int G = num_heads / num_kv_heads;
     const int R = q_len * G;
     if (R > 32) return 1;
+    if (block_table && pages_per_seq > ATT_MAX_PAGES) return 1;      // (the kernel keeps a split's page ids in LDS)
     // few KV heads (GQA): prefer more, lighter workgroups -- 4 query rows each (the KV stream is small and re-read per
     // row block) and up to 64 splits; with many KV heads 8 rows share one pass over the keys
     const bool gqa_small = (long long)num_kv_heads * batch < 64;
@@ -805,7 +838,7 @@ static int attn_decode_fused_impl(const void* q, const void* k_new, const void* 
     }
     dim3 grid((unsigned)num_kv_heads, (unsigned)nsplit, (unsigned)(batch * rblocks));
     const int lpk = head_dim / 8, kpw = 64 / lpk;
-    const size_t lds = (size_t)ATT_WAVES * kpw * rb * (head_dim + 2) * 4 + 16;
+    const size_t lds = (size_t)ATT_WAVES * kpw * rb * (head_dim + 2) * 4 + 16 + (size_t)ATT_MAX_PAGES * 4;
     const bool overlapped = chain_sync_active();
     if (overlapped)
     {
