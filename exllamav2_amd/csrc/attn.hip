@@ -279,7 +279,10 @@ template <int LPK> DEV f16x8 rope_neox_frag(f16x8 x, const f16* sin, const f16* 
     return rope_neox_apply<LPK>(x, cs, sn, dl);
 }
 
-template <int HDIM, int RB>
+// DEP: a launch of the overlapped chain (chain_sync.h; experimental) -- a TEMPLATE parameter since round 5, like the lean kernel's: as
+// run-time tests the polling loop and the agent-scope alternatives of every level-1 load sat in the ordinary launch's code, and the
+// compiler drained the first request (`vmcnt(0)`) in front of them: one round trip at the head of every launch.
+template <int HDIM, int RB, bool DEP = false>
 KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs a)
 {
     DYN_SMEM(smem);
@@ -303,23 +306,28 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     const int group = lane / LPK;
     const int dl = lane % LPK;
 
-    const bool dep = a.sync_signal != nullptr;                 // overlapped chain: producer may still be running
-    if (a.sync_arrive && tid() == 0) sync_report_entry(a.sync_arrive, (u32)((bid_z() * gdim_y() + bid_y()) * gdim_x() + bid_x()));
+    constexpr bool dep = DEP;                                  // overlapped chain: producer may still be running
+    if constexpr (DEP) if (a.sync_arrive && tid() == 0) sync_report_entry(a.sync_arrive, (u32)((bid_z() * gdim_y() + bid_y()) * gdim_x() + bid_x()));
 
     // ---- request level 1: everything whose address does not depend on the cache length goes out TOGETHER -- the length
     // itself, the first page of the sequence (split 0 starts at key 0), the query rows, the new key / value row this stream
     // takes first, the output position of the element this thread finalises.  (One dependent round trip each before:
     // length -> page -> keys -> new key -> rotary rows -> output position, 6.9 us per launch at 64 keys;
     // profiles/r03_kernel_stats.csv.)
-    int p_raw = 0;
-    if (a.cache_seqlens) p_raw = a.cache_seqlens[b];
+    // (UNCONDITIONAL loads from an address that is valid either way: behind `if (ptr) v = *ptr` the compiler waits for the load where the
+    // two paths meet -- `s_waitcnt vmcnt(0)` right behind the request, in front of every other level-1 request: one whole round trip
+    // at the head of every launch, found in the gfx950 code in round 5)
+    // (a non-temporal load = a VECTOR load the scheduler hoists with the other level-1 requests: as an ordinary load of a uniform
+    // address the compiler made it a scalar load and sank it behind the wait for the vector loads -- a dependent level of its own
+    // again; as a volatile load it is waited for on the spot)
+    const int p_ld = ld_nt(a.cache_seqlens ? a.cache_seqlens + b : (const int*)a.q);
     const bool spec = a.block_table != nullptr && split == 0;
-    int tab_spec = 0;
-    if (spec) tab_spec = a.block_table[(size_t)b * a.pages_per_seq];
-    if (a.sync_wait)
+    const int tab_spec = ld_nt(spec ? a.block_table + (size_t)b * a.pages_per_seq : (const int*)a.q);
+    if constexpr (DEP) if (a.sync_wait)
     {
         // overlapped chain: q / k_new / v_new are read behind the wait; workgroups of unused splits leave before it
-        const int total_e = a.past_const + (p_raw > 0 ? p_raw : 0) + a.s;
+        const int p_raw_e = a.cache_seqlens ? p_ld : 0;
+        const int total_e = a.past_const + (p_raw_e > 0 ? p_raw_e : 0) + a.s;
         if (split >= fused_active_splits(a, total_e)) return;
         if (wv == 0) sync_wait_go(a.sync_wait, kh + split);
         block_sync();
@@ -349,7 +357,12 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
         out_pre = (int)a.out_invperm[(kh * G + g) * HDIM + d];
     }
 
-    const int past = a.past_const + (p_raw > 0 ? p_raw : 0);
+    const int p_raw = a.cache_seqlens ? p_ld : 0;
+    // (tab_spec tied to the length through an opaque zero: needed HERE, so its request cannot be sunk -- as a scalar load -- into the
+    // block-table branch behind the wait for the level-1 vector loads)
+    u32 opaque_zero = 0;
+    pin_scalar(opaque_zero);
+    const int past = a.past_const + (p_raw > 0 ? p_raw : 0) + (int)((u32)tab_spec & opaque_zero);
     const int total = past + a.s;
     const int eff = fused_active_splits(a, total);
     if (split >= eff) return;
@@ -540,7 +553,7 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
         {
             const f16 y = (f16)(L > 0.0f ? O / L : 0.0f);
             const size_t oi = (a.out_invperm && idx == tid()) ? (qrow / a.H) * ((size_t)a.H * HDIM) + (size_t)out_pre : fused_out_index<HDIM>(a, qrow, d);
-            if (a.sync_signal) store_agent_f16(a.out + oi, y);
+            if (DEP && a.sync_signal) store_agent_f16(a.out + oi, y);
             else a.out[oi] = y;
             if (a.out_nat) a.out_nat[qrow * HDIM + d] = y;
         }
@@ -558,7 +571,7 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     }
     // (overlapped chain: the outputs above / below are agent-scope stores; one signal once the workgroup's have completed)
     auto signal_done = [&]() {
-        if (!a.sync_signal) return;
+        if (!DEP || !a.sync_signal) return;
         wait_vmcnt0();
         block_sync();
         if (wv == 0) sync_arrive_publish(a.sync_signal, a.sync_total, a.sync_wait);
@@ -579,7 +592,7 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
         const int j = rr / G, g = rr - j * G;
         const size_t qrow = ((size_t)b * a.s + j) * a.H + kh * G + g;
         const f16 y = (f16)merge_split_partials<true>(a.part_o, a.part_ml, qrow, a.nsplit, eff, HDIM, d);
-        if (a.sync_signal) store_agent_f16(a.out + fused_out_index<HDIM>(a, qrow, d), y);
+        if (DEP && a.sync_signal) store_agent_f16(a.out + fused_out_index<HDIM>(a, qrow, d), y);
         else a.out[fused_out_index<HDIM>(a, qrow, d)] = y;
         if (a.out_nat) a.out_nat[qrow * HDIM + d] = y;
     }
@@ -849,11 +862,14 @@ static int attn_decode_fused_impl(const void* q, const void* k_new, const void* 
         a.sync_arrive = cl.arrive;
         stream = cl.stream;
     }
-#define FUSED_CASE(HDIM_, RB_) LAUNCH((attn_fused_kernel<HDIM_, RB_>), grid, dim3(ATT_WAVES * 64), lds, stream, a)
+#define FUSED_CASE(HDIM_, RB_) do { if (overlapped) LAUNCH((attn_fused_kernel<HDIM_, RB_, true>), grid, dim3(ATT_WAVES * 64), lds, stream, a); \
+                                    else LAUNCH((attn_fused_kernel<HDIM_, RB_, false>), grid, dim3(ATT_WAVES * 64), lds, stream, a); } while (0)
 #define FUSED_HD(HDIM_) \
     do { static bool attr_done[EXL2_MAX_DEVICES] = {false}; \
-         if (exl2_first_on_device(attr_done)) { (void)hipFuncSetAttribute((const void*)attn_fused_kernel<HDIM_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                           (void)hipFuncSetAttribute((const void*)attn_fused_kernel<HDIM_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
+         if (exl2_first_on_device(attr_done)) { (void)hipFuncSetAttribute((const void*)attn_fused_kernel<HDIM_, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                           (void)hipFuncSetAttribute((const void*)attn_fused_kernel<HDIM_, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                           (void)hipFuncSetAttribute((const void*)attn_fused_kernel<HDIM_, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                           (void)hipFuncSetAttribute((const void*)attn_fused_kernel<HDIM_, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
          switch (rb) { case 1: FUSED_CASE(HDIM_, 1); break; case 2: FUSED_CASE(HDIM_, 2); break; \
                        case 4: FUSED_CASE(HDIM_, 4); break; default: FUSED_CASE(HDIM_, 8); break; } } while (0)
     if (head_dim == 64) FUSED_HD(64);
