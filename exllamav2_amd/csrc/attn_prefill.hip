@@ -70,7 +70,13 @@ KERNEL void __launch_bounds__(FP_WAVES * 64) flash_prefill_kernel(const FlashArg
     const int n_tiles = (kend + FP_BK - 1) / FP_BK;
     const size_t row_stride = (size_t)a.KVH * HDIM;
 
-    auto slot_of = [&](int kp) -> size_t {
+    // Cache slot of a tile's first key: ONE page look-up per tile, made two tiles ahead (round 5).  A tile of FP_BK keys never straddles
+    // a page (page sizes are powers of two >= FP_BK, checked by the host), so its rows are base + row.  Before, every 16-byte piece of
+    // a tile looked its page up itself behind `if (block_table)`: a dependent load per piece, and the compiler's wait for it --
+    // `s_waitcnt vmcnt(0)` where the two paths meet, executed with or without a table -- drained the pieces already requested: a tile's
+    // eight row loads left in four dependent round trips instead of together, and the kernel waited ~6 us per tile for ~0.4 us of MFMAs.
+    auto tile_base = [&](int tile) -> size_t {
+        const int kp = tile * FP_BK;
         if (a.block_table)
             return (size_t)a.block_table[(size_t)b * a.pages_per_seq + (kp >> a.page_shift)] * a.page_size + (kp & (a.page_size - 1));
         return (size_t)b * a.page_size + kp;
@@ -95,20 +101,18 @@ KERNEL void __launch_bounds__(FP_WAVES * 64) flash_prefill_kernel(const FlashArg
 
     // tile loads: thread -> 16-byte pieces c = t + 256 i; piece c = (key row c / (HDIM / 8), feature octet c % (HDIM / 8))
     f16x8 kreg[CPT], vreg[CPT];
-    auto fetch = [&](int tile) {
+    static_assert(CHUNKS % (FP_WAVES * 64) == 0, "a tile is a whole number of 16-byte pieces per thread");
+    auto fetch = [&](int tile, size_t base) {
+        // (every request unconditional, all of a tile's 2 CPT loads back to back)
+        const int last = total - 1 - tile * FP_BK;                           // rows beyond the sequence re-read its last key (masked below)
         #pragma unroll
         for (int i = 0; i < CPT; i++)
         {
             const int c = t + i * FP_WAVES * 64;
-            if (c < CHUNKS)
-            {
-                const int row = c / (HDIM / 8), oct = c % (HDIM / 8);
-                int kp = tile * FP_BK + row;
-                if (kp >= total) kp = total - 1;                              // keep the address valid; masked below
-                const size_t off = slot_of(kp) * row_stride + (size_t)kh * HDIM + oct * 8;
-                kreg[i] = *(const f16x8*)(a.k_cache + off);
-                vreg[i] = *(const f16x8*)(a.v_cache + off);
-            }
+            const int row = c / (HDIM / 8), oct = c % (HDIM / 8);
+            const size_t off = (base + (size_t)(row < last ? row : last)) * row_stride + (size_t)kh * HDIM + oct * 8;
+            kreg[i] = *(const f16x8*)(a.k_cache + off);
+            vreg[i] = *(const f16x8*)(a.v_cache + off);
         }
     };
     auto stage = [&]() {
@@ -116,35 +120,50 @@ KERNEL void __launch_bounds__(FP_WAVES * 64) flash_prefill_kernel(const FlashArg
         for (int i = 0; i < CPT; i++)
         {
             const int c = t + i * FP_WAVES * 64;
-            if (c < CHUNKS)
-            {
-                const int row = c / (HDIM / 8), oct = c % (HDIM / 8);
-                *(f16x8*)(k_lds + row * KSTR + oct * 8) = kreg[i];
-                *(f16x8*)(v_lds + row * VSTR + oct * 8) = vreg[i];
-            }
+            const int row = c / (HDIM / 8), oct = c % (HDIM / 8);
+            *(f16x8*)(k_lds + row * KSTR + oct * 8) = kreg[i];
+            *(f16x8*)(v_lds + row * VSTR + oct * 8) = vreg[i];
         }
     };
 
-    if (n_tiles > 0) fetch(0);
+    // (the look-up runs two tiles ahead of the tile in use, the rows one tile ahead; a tile index past the end looks tile 0 up again)
+    size_t base_next = n_tiles > 1 ? tile_base(1) : 0;
+    if (n_tiles > 0) fetch(0, tile_base(0));
     for (int tile = 0; tile < n_tiles; tile++)
     {
         block_sync();                                                         // everybody is done with the previous tile
         stage();
         block_sync();
-        if (tile + 1 < n_tiles) fetch(tile + 1);                              // in flight during the MFMAs below
+        if (tile + 1 < n_tiles)
+        {
+            fetch(tile + 1, base_next);                                       // in flight during the MFMAs below
+            base_next = tile_base(tile + 2 < n_tiles ? tile + 2 : 0);
+        }
         const int k0 = tile * FP_BK;
         if (k0 > wave_kmax) continue;                                         // fully masked for this wave's rows
 
         // S^T: FP_BK / 16 blocks of 16 keys
         constexpr int NBLK = FP_BK / 16;
         f32x4 st[NBLK];
+        // (the KK fragments of a 16-key block are read together and the next block's are in flight during this block's MFMAs: the
+        // compiler had placed every `ds_read_b128` right in front of its MFMA with `lgkmcnt(0)` between them -- one exposed LDS round
+        // trip per 16-cycle MFMA)
+        f16x8 ka[2][KK];
+        #pragma unroll
+        for (int kk = 0; kk < KK; kk++) ka[0][kk] = *(const f16x8*)(k_lds + qi * KSTR + 8 * g + 32 * kk);
         #pragma unroll
         for (int blk = 0; blk < NBLK; blk++)
         {
+            if (blk + 1 < NBLK)
+            {
+                #pragma unroll
+                for (int kk = 0; kk < KK; kk++) ka[(blk + 1) & 1][kk] = *(const f16x8*)(k_lds + (16 * (blk + 1) + qi) * KSTR + 8 * g + 32 * kk);
+            }
+            sched_fence();
             st[blk] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            const f16* kp = k_lds + (16 * blk + qi) * KSTR + 8 * g;
             #pragma unroll
-            for (int kk = 0; kk < KK; kk++) st[blk] = mfma_16x16x32_f16(*(const f16x8*)(kp + 32 * kk), qb[kk], st[blk]);
+            for (int kk = 0; kk < KK; kk++) st[blk] = mfma_16x16x32_f16(ka[blk & 1][kk], qb[kk], st[blk]);
+            sched_fence();
         }
         // mask + online softmax for column qi (lane holds keys k0 + 16 blk + 4 g + r)
         float sc[4 * NBLK];
@@ -231,7 +250,7 @@ int exl2_flash_prefill(const void* q, const void* k_cache, const void* v_cache, 
     a.cache_seqlens = cache_seqlens; a.block_table = block_table;
     a.b = batch; a.s = q_len; a.H = num_heads; a.KVH = num_kv_heads;
     a.page_size = page_size; a.pages_per_seq = pages_per_seq; a.page_shift = fp_ilog2_exact(page_size);
-    EXL2_REQUIRE(!block_table || a.page_shift >= 0, "flash_prefill: page_size %d must be a power of two", page_size);
+    EXL2_REQUIRE(!block_table || (a.page_shift >= 0 && page_size >= FP_BK), "flash_prefill: page_size %d must be a power of two >= %d", page_size, FP_BK);
     a.len_const = len_const; a.len_offset = len_offset; a.scale = softmax_scale; a.causal = causal;
     dim3 grid((unsigned)((q_len + FP_BQ - 1) / FP_BQ), (unsigned)num_heads, (unsigned)batch);
     const size_t lds = ((size_t)FP_BK * (head_dim + 8) + (size_t)FP_BK * (head_dim + 16)) * sizeof(f16);
