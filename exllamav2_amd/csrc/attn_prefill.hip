@@ -31,6 +31,12 @@
 #define FP_BK 64
 #endif
 #define FP_WAVES 4
+#ifndef FP_OCC
+#define FP_OCC 4                   // waves per SIMD the register allocation is held to (= workgroups of 4 waves per CU; 128 registers, 4 x 36 KB of LDS)
+#endif
+#ifndef FP_QK_BATCH
+#define FP_QK_BATCH 0              // 1: S^T fragments of a 16-key block read together, the next block in flight -- needs 146 registers (3 waves per SIMD): measured slower than 4 waves without it
+#endif
 #define FP_NEG_BIG (-1.0e30f)
 
 struct FlashArgs
@@ -46,7 +52,7 @@ struct FlashArgs
 
 
 template <int HDIM>
-KERNEL void __launch_bounds__(FP_WAVES * 64) flash_prefill_kernel(const FlashArgs a)
+KERNEL void __launch_bounds__(FP_WAVES * 64, FP_OCC) flash_prefill_kernel(const FlashArgs a)
 {
     DYN_SMEM(smem);
     constexpr int KSTR = HDIM + 8;                 // halfs per K row (272-byte rows at hd 128: conflict-free 16-byte reads)
@@ -148,6 +154,7 @@ KERNEL void __launch_bounds__(FP_WAVES * 64) flash_prefill_kernel(const FlashArg
         // (the KK fragments of a 16-key block are read together and the next block's are in flight during this block's MFMAs: the
         // compiler had placed every `ds_read_b128` right in front of its MFMA with `lgkmcnt(0)` between them -- one exposed LDS round
         // trip per 16-cycle MFMA)
+#if FP_QK_BATCH
         f16x8 ka[2][KK];
         #pragma unroll
         for (int kk = 0; kk < KK; kk++) ka[0][kk] = *(const f16x8*)(k_lds + qi * KSTR + 8 * g + 32 * kk);
@@ -165,6 +172,16 @@ KERNEL void __launch_bounds__(FP_WAVES * 64) flash_prefill_kernel(const FlashArg
             for (int kk = 0; kk < KK; kk++) st[blk] = mfma_16x16x32_f16(ka[blk & 1][kk], qb[kk], st[blk]);
             sched_fence();
         }
+#else
+        #pragma unroll
+        for (int blk = 0; blk < NBLK; blk++)
+        {
+            st[blk] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            const f16* kp = k_lds + (16 * blk + qi) * KSTR + 8 * g;
+            #pragma unroll
+            for (int kk = 0; kk < KK; kk++) st[blk] = mfma_16x16x32_f16(*(const f16x8*)(kp + 32 * kk), qb[kk], st[blk]);
+        }
+#endif
         // mask + online softmax for column qi (lane holds keys k0 + 16 blk + 4 g + r)
         float sc[4 * NBLK];
         float m_loc = FP_NEG_BIG;
