@@ -26,16 +26,20 @@
 #include "errors.h"
 #include <string.h>
 
-#define FP_BQ 64
+#ifndef FP_RPW
+#define FP_RPW 2                   // 16-row query blocks per wave: every K / V fragment read from LDS feeds FP_RPW MFMAs
+#endif
+#define FP_WAVES_C 4
+#define FP_BQ (FP_WAVES_C * 16 * FP_RPW)
 #ifndef FP_BK
 #define FP_BK 64
 #endif
 #define FP_WAVES 4
 #ifndef FP_OCC
-#define FP_OCC 4                   // waves per SIMD the register allocation is held to (= workgroups of 4 waves per CU; 128 registers, 4 x 36 KB of LDS)
+#define FP_OCC (FP_RPW == 1 ? 4 : 2)   // waves per SIMD the register allocation is held to (= workgroups of 4 waves per CU)
 #endif
 #ifndef FP_QK_BATCH
-#define FP_QK_BATCH 0              // 1: S^T fragments of a 16-key block read together, the next block in flight -- needs 146 registers (3 waves per SIMD): measured slower than 4 waves without it
+#define FP_QK_BATCH 0              // (round-5 experiment, RPW = 1 only, measured slower: DESIGN.md 3.5)
 #endif
 #define FP_NEG_BIG (-1.0e30f)
 
@@ -88,22 +92,33 @@ KERNEL void __launch_bounds__(FP_WAVES * 64, FP_OCC) flash_prefill_kernel(const 
         return (size_t)b * a.page_size + kp;
     };
 
-    // this wave's 16 query rows as the B operand of S^T = K Q^T: lane (qi, g) holds Q[row qi][32 kk + 8 g .. + 8]
-    const int qrow = q0 + wv * 16 + qi;
-    const int qrow_c = qrow < a.s ? qrow : a.s - 1;
-    f16x8 qb[KK];
+    // this wave's RPW x 16 query rows as B operands of S^T = K Q^T: lane (qi, g) holds Q[row 16 n + qi][32 kk + 8 g .. + 8] of block n.
+    // RPW = 2 (round 5): every K / V fragment read from LDS feeds TWO MFMAs -- at 16 rows per wave the kernel was bound by LDS bandwidth
+    // (a wave re-read the whole 32 KB K + V tile for 16 query rows: 640 KB per CU and tile round against 128 B per cycle)
+    constexpr int RPW = FP_RPW;
+    int qrow[RPW], qpos[RPW];
+    f16x8 qb[RPW][KK];
+    #pragma unroll
+    for (int n = 0; n < RPW; n++)
     {
+        qrow[n] = q0 + (wv * RPW + n) * 16 + qi;
+        const int qrow_c = qrow[n] < a.s ? qrow[n] : a.s - 1;
         const f16* qp = a.q + (((size_t)b * a.s + qrow_c) * a.H + h) * HDIM + 8 * g;
         #pragma unroll
-        for (int kk = 0; kk < KK; kk++) qb[kk] = *(const f16x8*)(qp + 32 * kk);
+        for (int kk = 0; kk < KK; kk++) qb[n][kk] = *(const f16x8*)(qp + 32 * kk);
+        qpos[n] = qpos0 + qrow[n];                                            // last key this query may see (causal)
     }
-    const int qpos = qpos0 + qrow;                                            // last key this query may see (causal)
-    const int wave_kmax = a.causal ? qpos0 + q0 + wv * 16 + 15 : total - 1;   // nothing beyond it matters to this wave
+    const int wave_kmax = a.causal ? qpos0 + q0 + (wv * RPW + RPW) * 16 - 1 : total - 1;   // nothing beyond it matters to this wave
 
-    f32x4 ot[DB];
+    f32x4 ot[RPW][DB];
+    float m_run[RPW], l_run[RPW];
     #pragma unroll
-    for (int d = 0; d < DB; d++) ot[d] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    float m_run = FP_NEG_BIG, l_run = 0.0f;
+    for (int n = 0; n < RPW; n++)
+    {
+        #pragma unroll
+        for (int d = 0; d < DB; d++) ot[n][d] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        m_run[n] = FP_NEG_BIG; l_run[n] = 0.0f;
+    }
 
     // tile loads: thread -> 16-byte pieces c = t + 256 i; piece c = (key row c / (HDIM / 8), feature octet c % (HDIM / 8))
     f16x8 kreg[CPT], vreg[CPT];
@@ -148,100 +163,93 @@ KERNEL void __launch_bounds__(FP_WAVES * 64, FP_OCC) flash_prefill_kernel(const 
         const int k0 = tile * FP_BK;
         if (k0 > wave_kmax) continue;                                         // fully masked for this wave's rows
 
-        // S^T: FP_BK / 16 blocks of 16 keys
+        // S^T: FP_BK / 16 blocks of 16 keys; one LDS read of a K fragment per RPW MFMAs
         constexpr int NBLK = FP_BK / 16;
-        f32x4 st[NBLK];
-        // (the KK fragments of a 16-key block are read together and the next block's are in flight during this block's MFMAs: the
-        // compiler had placed every `ds_read_b128` right in front of its MFMA with `lgkmcnt(0)` between them -- one exposed LDS round
-        // trip per 16-cycle MFMA)
-#if FP_QK_BATCH
-        f16x8 ka[2][KK];
-        #pragma unroll
-        for (int kk = 0; kk < KK; kk++) ka[0][kk] = *(const f16x8*)(k_lds + qi * KSTR + 8 * g + 32 * kk);
+        f32x4 st[RPW][NBLK];
         #pragma unroll
         for (int blk = 0; blk < NBLK; blk++)
         {
-            if (blk + 1 < NBLK)
-            {
-                #pragma unroll
-                for (int kk = 0; kk < KK; kk++) ka[(blk + 1) & 1][kk] = *(const f16x8*)(k_lds + (16 * (blk + 1) + qi) * KSTR + 8 * g + 32 * kk);
-            }
-            sched_fence();
-            st[blk] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             #pragma unroll
-            for (int kk = 0; kk < KK; kk++) st[blk] = mfma_16x16x32_f16(ka[blk & 1][kk], qb[kk], st[blk]);
-            sched_fence();
-        }
-#else
-        #pragma unroll
-        for (int blk = 0; blk < NBLK; blk++)
-        {
-            st[blk] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int n = 0; n < RPW; n++) st[n][blk] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             const f16* kp = k_lds + (16 * blk + qi) * KSTR + 8 * g;
             #pragma unroll
-            for (int kk = 0; kk < KK; kk++) st[blk] = mfma_16x16x32_f16(*(const f16x8*)(kp + 32 * kk), qb[kk], st[blk]);
-        }
-#endif
-        // mask + online softmax for column qi (lane holds keys k0 + 16 blk + 4 g + r)
-        float sc[4 * NBLK];
-        float m_loc = FP_NEG_BIG;
-        #pragma unroll
-        for (int blk = 0; blk < NBLK; blk++)
-            #pragma unroll
-            for (int r = 0; r < 4; r++)
+            for (int kk = 0; kk < KK; kk++)
             {
-                const int kpos = k0 + 16 * blk + 4 * g + r;
-                const bool valid = kpos < total && (!a.causal || kpos <= qpos);
-                const float v = valid ? st[blk][r] * a.scale : FP_NEG_BIG;
-                sc[blk * 4 + r] = v;
-                m_loc = fmaxf(m_loc, v);
+                const f16x8 kf = *(const f16x8*)(kp + 32 * kk);
+                #pragma unroll
+                for (int n = 0; n < RPW; n++) st[n][blk] = mfma_16x16x32_f16(kf, qb[n][kk], st[n][blk]);
             }
-        m_loc = fmaxf(m_loc, shfl_xor_f32(m_loc, 16));
-        m_loc = fmaxf(m_loc, shfl_xor_f32(m_loc, 32));
-        const float m_new = fmaxf(m_run, m_loc);
-        const float alpha = fast_exp(m_run - m_new);
-        float p_sum = 0.0f;
-        f16x8 pb[NBLK / 2];                          // B operands: 32 keys each = {block 2n keys 4g..4g+3, block 2n+1 keys 4g..4g+3}
-        #pragma unroll
-        for (int e = 0; e < 4 * NBLK; e++)
-        {
-            const float p = sc[e] > 0.5f * FP_NEG_BIG ? fast_exp(sc[e] - m_new) : 0.0f;
-            p_sum += p;
-            pb[e / 8][e % 8] = (f16)p;
         }
-        p_sum += shfl_xor_f32(p_sum, 16);
-        p_sum += shfl_xor_f32(p_sum, 32);
-        l_run = l_run * alpha + p_sum;
-        m_run = m_new;
+        // mask + online softmax for column qi of each query block (lane holds keys k0 + 16 blk + 4 g + r)
+        f16x8 pb[RPW][NBLK / 2];                     // B operands: 32 keys each = {block 2n keys 4g..4g+3, block 2n+1 keys 4g..4g+3}
+        float alpha[RPW];
+        #pragma unroll
+        for (int n = 0; n < RPW; n++)
+        {
+            float sc[4 * NBLK];
+            float m_loc = FP_NEG_BIG;
+            #pragma unroll
+            for (int blk = 0; blk < NBLK; blk++)
+                #pragma unroll
+                for (int r = 0; r < 4; r++)
+                {
+                    const int kpos = k0 + 16 * blk + 4 * g + r;
+                    const bool valid = kpos < total && (!a.causal || kpos <= qpos[n]);
+                    const float v = valid ? st[n][blk][r] * a.scale : FP_NEG_BIG;
+                    sc[blk * 4 + r] = v;
+                    m_loc = fmaxf(m_loc, v);
+                }
+            m_loc = fmaxf(m_loc, shfl_xor_f32(m_loc, 16));
+            m_loc = fmaxf(m_loc, shfl_xor_f32(m_loc, 32));
+            const float m_new = fmaxf(m_run[n], m_loc);
+            alpha[n] = fast_exp(m_run[n] - m_new);
+            float p_sum = 0.0f;
+            #pragma unroll
+            for (int e = 0; e < 4 * NBLK; e++)
+            {
+                const float p = sc[e] > 0.5f * FP_NEG_BIG ? fast_exp(sc[e] - m_new) : 0.0f;
+                p_sum += p;
+                pb[n][e / 8][e % 8] = (f16)p;
+            }
+            p_sum += shfl_xor_f32(p_sum, 16);
+            p_sum += shfl_xor_f32(p_sum, 32);
+            l_run[n] = l_run[n] * alpha[n] + p_sum;
+            m_run[n] = m_new;
+        }
         // O^T = alpha O^T + V^T P^T: A = V^T rows (feature 16 db + qi), keys {4g..4g+3, 16+4g..16+4g+3} -- transposing reads:
-        // this lane points at key row 4 g + qi / 4, features 16 db + 4 (qi % 4) .. + 3 and receives column qi of the block
+        // this lane points at key row 4 g + qi / 4, features 16 db + 4 (qi % 4) .. + 3 and receives column qi of the block;
+        // one pair of reads per RPW MFMAs
         const f16* vbase = v_lds + (4 * g + (qi >> 2)) * VSTR + 4 * (qi & 3);
         #pragma unroll
         for (int d = 0; d < DB; d++)
         {
-            f32x4 acc = ot[d];
-            acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
             #pragma unroll
-            for (int n = 0; n < NBLK / 2; n++)
+            for (int n = 0; n < RPW; n++) { ot[n][d][0] *= alpha[n]; ot[n][d][1] *= alpha[n]; ot[n][d][2] *= alpha[n]; ot[n][d][3] *= alpha[n]; }
+            #pragma unroll
+            for (int m2 = 0; m2 < NBLK / 2; m2++)
             {
-                const f16x4 lo = lds_read_tr16_b64(vbase + (32 * n) * VSTR + 16 * d), hi = lds_read_tr16_b64(vbase + (32 * n + 16) * VSTR + 16 * d);
+                const f16x4 lo = lds_read_tr16_b64(vbase + (32 * m2) * VSTR + 16 * d), hi = lds_read_tr16_b64(vbase + (32 * m2 + 16) * VSTR + 16 * d);
                 const f16x8 va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                acc = mfma_16x16x32_f16(va, pb[n], acc);
+                #pragma unroll
+                for (int n = 0; n < RPW; n++) ot[n][d] = mfma_16x16x32_f16(va, pb[n][m2], ot[n][d]);
             }
-            ot[d] = acc;
         }
     }
 
     // O^T[feature 16 d + 4 g + r][query qi] / l -> out[query][feature]: 4 consecutive features per lane
-    if (qrow < a.s)
+    #pragma unroll
+    for (int n = 0; n < RPW; n++)
     {
-        const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
-        f16* op = a.out + (((size_t)b * a.s + qrow) * a.H + h) * HDIM + 4 * g;
-        #pragma unroll
-        for (int d = 0; d < DB; d++)
+        if (qrow[n] < a.s)
         {
-            const f16x4 y = {(f16)(ot[d][0] * inv), (f16)(ot[d][1] * inv), (f16)(ot[d][2] * inv), (f16)(ot[d][3] * inv)};
-            *(f16x4*)(op + 16 * d) = y;
+            const float inv = l_run[n] > 0.0f ? 1.0f / l_run[n] : 0.0f;
+            f16* op = a.out + (((size_t)b * a.s + qrow[n]) * a.H + h) * HDIM + 4 * g;
+            #pragma unroll
+            for (int d = 0; d < DB; d++)
+            {
+                const f16x4 y = {(f16)(ot[n][d][0] * inv), (f16)(ot[n][d][1] * inv), (f16)(ot[n][d][2] * inv), (f16)(ot[n][d][3] * inv)};
+                *(f16x4*)(op + 16 * d) = y;
+            }
         }
     }
 }
