@@ -193,6 +193,14 @@ DEV void dma_buf_to_lds16(const void* base, u32 voffset_bytes, void* lds_wave_ba
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voffset_bytes, 0, 0, 0);
 }
+// the same with the wave-uniform part of the address in a SCALAR register (soffset): a copy whose per-lane offsets never change --
+// a GEMM's stage fill -- then costs no vector instruction and no vector register beyond the one offset it keeps for the whole loop
+// (qgemm_mfma.hip: the global_load_lds form made a 64-bit per-lane address per copy, `v_lshl_add_u64` x 11 per K step)
+DEV void dma_buf_to_lds16_so(const void* base, u32 voffset_bytes, u32 soffset_bytes, void* lds_wave_base)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voffset_bytes, (int)soffset_bytes, 0, 0);
+}
 // the same at agent scope (sc1: served by the L2 / memory side, never by this CU's L1): what a producer that may still be running
 // wrote with agent-scope stores (overlapped chain, chain_sync.h) -- and what a previous launch wrote, at the price of an L1 bypass
 DEV void dma_buf_to_lds16_agent(const void* base, u32 voffset_bytes, void* lds_wave_base)

@@ -145,30 +145,67 @@ DEV void decode_half_sw(int bits, const TileRaw& R, u8* w_stage, int wv, int lan
 }
 
 // `nv` (0..2) chunks of 32 K rows from one stage: MT x 4 MFMAs per chunk
-template <int MT>
+template <int MT, bool PIPE = false>
 DEV void multiply_stage(const u8* x_stage, const u8* w_stage, int nv, int wm, int wn, int lane, f32x4 (&acc)[MT][4])
 {
     const int i16 = lane & 15, j4 = lane >> 4, sw = (lane >> 1) & 7;
     if (MF_KILL & 4) return;
+    if constexpr (!PIPE)
+    {
+        // (the kernels that decode inside the K loop have no registers to spare: fragments of one chunk at a time)
+        #pragma unroll
+        for (int kq = 0; kq < 2; kq++)
+        {
+            if (kq < nv)
+            {
+                f16x8 wf[4];
+                #pragma unroll
+                for (int nt = 0; nt < 4; nt++)
+                    wf[nt] = *(const f16x8*)(w_stage + ((size_t)(((wn * 4 + nt) * 2 + kq) * 64 + lane)) * 16);
+                const u8* xr = x_stage + (size_t)(wm * MT * 16 + i16) * 128 + (((4 * kq + j4) ^ sw) * 16);
+                #pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                {
+                    const f16x8 xf = *(const f16x8*)(xr + mt * 16 * 128);
+                    #pragma unroll
+                    for (int nt = 0; nt < 4; nt++) acc[mt][nt] = mfma_16x16x32_f16(wf[nt], xf, acc[mt][nt]);
+                }
+            }
+            MF_FENCE();
+        }
+        return;
+    }
+    // Round 5 (PIPE: the kernels whose weights were decoded by the pre-pass): the NEXT fragments are on their way while the current ones are multiplied -- the X fragment of row tile mt + 1 behind the
+    // four MFMAs of row tile mt, the four W fragments of chunk 1 behind chunk 0's first row tiles.  Before, the compiler had every pair
+    // of `ds_read_b128` directly in front of its eight MFMAs with `lgkmcnt(0)` between them (an exposed LDS round trip per 128 cycles
+    // of MFMA: 61 % matrix-core busy at best); the 24 registers this needs were freed by the buffer-form stage fills (222 instead
+    // of 256 + spills).
+    auto w_frag = [&](int kq, int nt) -> f16x8 { return *(const f16x8*)(w_stage + ((size_t)(((wn * 4 + nt) * 2 + kq) * 64 + lane)) * 16); };
+    auto x_frag = [&](int kq, int mt) -> f16x8 { return *(const f16x8*)(x_stage + (size_t)(wm * MT * 16 + i16 + mt * 16) * 128 + (((4 * kq + j4) ^ sw) * 16)); };
+    if (nv <= 0) return;
+    f16x8 wf[2][4], xf[2];
+    #pragma unroll
+    for (int nt = 0; nt < 4; nt++) wf[0][nt] = w_frag(0, nt);
+    xf[0] = x_frag(0, 0);
     #pragma unroll
     for (int kq = 0; kq < 2; kq++)
     {
         if (kq < nv)
         {
-            f16x8 wf[4];
-            #pragma unroll
-            for (int nt = 0; nt < 4; nt++)
-                wf[nt] = *(const f16x8*)(w_stage + ((size_t)(((wn * 4 + nt) * 2 + kq) * 64 + lane)) * 16);
-            const u8* xr = x_stage + (size_t)(wm * MT * 16 + i16) * 128 + (((4 * kq + j4) ^ sw) * 16);
+            const bool next_chunk = kq == 0 && nv > 1;
             #pragma unroll
             for (int mt = 0; mt < MT; mt++)
             {
-                const f16x8 xf = *(const f16x8*)(xr + mt * 16 * 128);
+                // requests first: the next X fragment, and -- spread over the first row tiles -- the next chunk's W fragments
+                if (mt + 1 < MT) xf[(mt + 1) & 1] = x_frag(kq, mt + 1);
+                else if (next_chunk) xf[(mt + 1) & 1] = x_frag(1, 0);
+                if (kq == 0 && mt < 4 && next_chunk) wf[1][mt] = w_frag(1, mt);
+                MF_FENCE();
                 #pragma unroll
-                for (int nt = 0; nt < 4; nt++) acc[mt][nt] = mfma_16x16x32_f16(wf[nt], xf, acc[mt][nt]);
+                for (int nt = 0; nt < 4; nt++) acc[mt][nt] = mfma_16x16x32_f16(wf[kq][nt], xf[mt & 1], acc[mt][nt]);
+                MF_FENCE();
             }
         }
-        MF_FENCE();             // fragments of one chunk at a time
     }
 }
 
@@ -178,8 +215,9 @@ struct MfCtx
     const QMatDev* m;
     u8* x_st[2]; u8* w_st[2];
     const u16* cg_lds;
-    const f16* x_base;          // first row of this wave's first X piece (packed K order, row stride K)
-    u32 x_off0, x_off1;         // the lane's offset (halves) inside an even / odd piece
+    const f16* x_base;          // the staged activations (packed K order, row stride K): base of the buffer descriptor
+    u32 x_wave;                 // byte offset of this wave's first X piece (wave-uniform)
+    u32 x_off0, x_off1;         // the lane's BYTE offset inside an even / odd piece
     int x_u0;                   // the unit the lane holds in even pieces (odd pieces: ^ 4)
     int tile[2];
     int K, lane, wv, wm, wn;
@@ -195,8 +233,9 @@ DEV void issue_x(const MfCtx& x, int k0, int nv, u8* stage)
     for (int i = 0; i < PIECES; i++)
     {
         const int u = (i & 1) ? (x.x_u0 ^ 4) : x.x_u0;
-        const f16* src = x.x_base + (size_t)(i * 8) * x.K + k0 + ((i & 1) ? x.x_off1 : x.x_off0);
-        if (u < 4 * nv) dma_to_lds16(src, stage + (size_t)(x.wv * PIECES + i) * 1024);
+        // (buffer form: the lane's offset is one of two registers kept for the whole kernel, everything else is scalar)
+        if (u < 4 * nv) dma_buf_to_lds16_so(x.x_base, (i & 1) ? x.x_off1 : x.x_off0, x.x_wave + (u32)((i * 8) * x.K + k0) * 2u,
+                                            stage + (size_t)(x.wv * PIECES + i) * 1024);
     }
 }
 
@@ -248,17 +287,18 @@ DEV void run_section(const MfCtx& x, int bits, const u32* base, u32 tile_stride,
 // scale tables in the K loop.
 
 // this wave's eighth of one K step's decoded weights -> stage
-DEV void issue_w(const u8* slot, u8* stage, int wv, int lane)
+DEV void issue_w(const u8* wfrag, u32 slot_off, u8* stage, int wv, int lane)
 {
     #pragma unroll
-    for (int i = 0; i < 4; i++) dma_to_lds16(slot + (size_t)((wv * 4 + i) * 64 + lane) * 16, stage + (size_t)(wv * 4 + i) * 1024);
+    for (int i = 0; i < 4; i++) dma_buf_to_lds16_so(wfrag, (u32)lane * 16u, slot_off + (u32)((wv * 4 + i) * 1024), stage + (size_t)(wv * 4 + i) * 1024);
 }
 
 template <int MT>
-DEV void run_section_pre(const MfCtx& x, const u8* slots, int F, int k_base, int nvl, f32x4 (&acc)[MT][4])
+DEV void run_section_pre(const MfCtx& x, const u8* wfrag, u32 slots, int F, int k_base, int nvl, f32x4 (&acc)[MT][4])
 {
+    // (slots = byte offset of the section's first W stage image inside the call's scratch: base + scalar offset + lane * 16)
     issue_x<MT>(x, k_base, F == 1 ? min(2, nvl) : 2, x.x_st[0]);
-    issue_w(slots, x.w_st[0], x.wv, x.lane);
+    issue_w(wfrag, slots, x.w_st[0], x.wv, x.lane);
     for (int s = 0; s < F; s++)
     {
         const int k0 = k_base + s * SUPER_ROWS;
@@ -266,22 +306,22 @@ DEV void run_section_pre(const MfCtx& x, const u8* slots, int F, int k_base, int
         const int nv0 = min(2, nvalid), nv1 = nvalid - nv0;
         const bool more = s + 1 < F;
         const int nvalid_next = (s + 1 == F - 1) ? nvl : 4;
-        const u8* const sl = slots + (size_t)(2 * s) * MF_W_STAGE;
+        const u32 sl = slots + (u32)(2 * s) * (u32)MF_W_STAGE;
         // K step 0: multiply stage 0; stage 1 <- the second half of this super-chunk
         wait_vmcnt_le<0>();
         block_sync();
         issue_x<MT>(x, k0 + 64, nv1, x.x_st[1]);
-        issue_w(sl + MF_W_STAGE, x.w_st[1], x.wv, x.lane);
-        multiply_stage<MT>(x.x_st[0], x.w_st[0], nv0, x.wm, x.wn, x.lane, acc);
+        issue_w(wfrag, sl + (u32)MF_W_STAGE, x.w_st[1], x.wv, x.lane);
+        multiply_stage<MT, true>(x.x_st[0], x.w_st[0], nv0, x.wm, x.wn, x.lane, acc);
         // K step 1: multiply stage 1; stage 0 <- the first half of the next super-chunk
         wait_vmcnt_le<0>();
         block_sync();
         if (more)
         {
             issue_x<MT>(x, k0 + SUPER_ROWS, min(2, nvalid_next), x.x_st[0]);
-            issue_w(sl + 2 * MF_W_STAGE, x.w_st[0], x.wv, x.lane);
+            issue_w(wfrag, sl + 2u * (u32)MF_W_STAGE, x.w_st[0], x.wv, x.lane);
         }
-        multiply_stage<MT>(x.x_st[1], x.w_st[1], nv1, x.wm, x.wn, x.lane, acc);
+        multiply_stage<MT, true>(x.x_st[1], x.w_st[1], nv1, x.wm, x.wn, x.lane, acc);
     }
 }
 
@@ -376,9 +416,10 @@ KERNEL void __launch_bounds__(MF_THREADS, 2) qgemm_mfma_kernel(const PrefillArgs
     {
         const int x_pos = lane & 7, x_r8 = lane >> 3;
         x.x_u0 = x_pos ^ (lane >> 4);
-        x.x_off0 = (u32)(x_r8 * K + x.x_u0 * 8);
-        x.x_off1 = (u32)(x_r8 * K + (x.x_u0 ^ 4) * 8);
-        x.x_base = args.a + (size_t)(m0 + wv * PIECES * 8) * K;
+        x.x_off0 = (u32)(x_r8 * K + x.x_u0 * 8) * 2u;
+        x.x_off1 = (u32)(x_r8 * K + (x.x_u0 ^ 4) * 8) * 2u;
+        x.x_base = args.a;
+        x.x_wave = (u32)((size_t)(m0 + wv * PIECES * 8) * K * 2);              // (the host keeps rows x K x 2 below 2 GB: run_prefill)
     }
     #pragma unroll
     for (int i = 0; i < 2; i++) x.tile[i] = min((n0 >> 4) + 2 * wv + i, n_tiles - 1);   // partial last block column: computed, never stored
@@ -412,7 +453,7 @@ KERNEL void __launch_bounds__(MF_THREADS, 2) qgemm_mfma_kernel(const PrefillArgs
         if (F <= 0) continue;
         if constexpr (WPRE)
         {
-            run_section_pre<MT>(x, args.wfrag + ((size_t)vn * args.wfrag_steps + step0) * MF_W_STAGE, F, k_base, nvl, acc);
+            run_section_pre<MT>(x, args.wfrag, (u32)(((size_t)vn * args.wfrag_steps + step0) * MF_W_STAGE), F, k_base, nvl, acc);
             step0 += 2 * F;
         }
         else run_section<GPTQ, MT>(x, bits, base, tile_stride, F, k_base, nvl, acc);

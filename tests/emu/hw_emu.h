@@ -265,6 +265,7 @@ DEV u64 realtime_stamp() { return 0; }
 DEV void dma_to_lds16(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
 DEV void dma_buf_to_lds16(const void* base, u32 voffset_bytes, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, (const char*)base + voffset_bytes, 16); }
 DEV void dma_buf_to_lds16_agent(const void* base, u32 voffset_bytes, void* lds_wave_base) { dma_buf_to_lds16(base, voffset_bytes, lds_wave_base); }
+DEV void dma_buf_to_lds16_so(const void* base, u32 voffset_bytes, u32 soffset_bytes, void* lds_wave_base) { dma_buf_to_lds16(base, voffset_bytes + soffset_bytes, lds_wave_base); }
 DEV void dma_to_lds16_nt(const void* g_lane_ptr, void* lds_wave_base) { memcpy((char*)lds_wave_base + lane_id() * 16, g_lane_ptr, 16); }
 DEV void wait_lds_reads() { }
 DEV void wave_converge() { emu_ctx_->wave[wave_id()].bar.wait(); }
