@@ -70,6 +70,16 @@
 #define LEAN_MAX_WAVES 16
 #define LEAN_RECORDS 48               // wave records in the argument block: matrices x waves per tile (q|k|v at 16 waves)
 #define LEAN_MAX_PASSES 4             // 16-wave geometry: a wave's share may be this many register loads (qgemv_lean_kernel, further passes)
+#ifndef LEAN_S8_PASSES
+#define LEAN_S8_PASSES 2              // 8-wave geometry, launches of several matrices (q|k|v): register loads a share may take (1 = round-4 behaviour)
+#endif
+#ifndef LEAN_S8_PASS_BITS
+#define LEAN_S8_PASS_BITS 4           // ... for items of at most this many bits; also the widest items decoded as a RING in either geometry (wider decoders + a full
+                                      // ring of requests do not fit 80 registers: spills, and the 5-bit pipelined region of the 16-wave kernel lost its counted wait)
+#endif
+#ifndef LEAN_PASS_RING
+#define LEAN_PASS_RING 1              // shares of several register loads: item q of the NEXT load is requested as soon as item q of this one is decoded
+#endif
 #define LEAN_MAX_PART 512             // partial sums of squares per row a chain-out launch may publish (hidden 8192 = 512 tiles; the
                                       // host's ss buffers are [rows, 512]; the round-2 kernel reads at most 256 and declines more)
 #define LEAN_LDS_BUDGET (40u * 1024u)  // per 8 waves: four 8-wave / two 16-wave workgroups stay resident on a CU
@@ -551,6 +561,8 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         constexpr int D = LeanDepth<BITS, S>::v;
         constexpr int DA = D - NB;
         constexpr size_t STEP = 64 * BITS;
+        constexpr bool PASSES = !XMEM && (S == 16 || (S == 8 && NSLOTS == 1 && !PAIR && !ROWS && LEAN_S8_PASSES > 1 && BITS <= LEAN_S8_PASS_BITS));   // (what lean_plan_matrix plans)
+        constexpr bool RING = PASSES && LEAN_PASS_RING && BITS <= LEAN_S8_PASS_BITS;      // (wider items: a whole load at a time, the round-4 loop)
         LaneWords<BITS> a[DA > 0 ? DA : 1], b[NB > 0 ? NB : 1], bt;
         const int nA = n - NB;
         u32 xvoff = 0;                                                 // XMEM: the lane's byte offset into the activations (row, 8 j)
@@ -612,6 +624,48 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
             else lean_item_general<BITS, GPTQ>(w, R.cx, R.chunk0 + 4 * q, 4 * q, R.g0, R.gshift, R.gphase, 4, lane, acc);
             sched_fence();
         };
+        // (shares of several register loads; returns true when it took the share)
+        auto ring_passes = [&](auto on_tag) -> bool {
+            if constexpr (decltype(on_tag)::value)
+            {
+                if (n <= D) return false;
+
+                // more items than the wave's registers hold (K = 28672 split over 16 waves: 14-15 items of 3 bits; the v part of a
+                // 70B q|k|v launch on 8 waves: 9 of 3 bits): the registers are a ring -- as soon as item q of one register load is
+                // decoded, item q of the NEXT one is requested into the same registers, so a later load's round trip runs under the
+                // decode of the current one (round 4 requested a whole load, waited for all of it, decoded it: one exposed round trip
+                // per pass).  EVERY request is unconditional -- indices past the end are clamped to the last item, a line that is in
+                // flight anyway -- in the first load's straight-line code and in the loop body alike, same order: the compiler's
+                // count of the requests in flight is exact on both edges into the loop (tests/test_lean_isa.py).
+                const u32* const lastp = wptr + (size_t)(n - 1) * STEP;
+                // (a request past the end is lane 0's words of the last item for every lane: one 16-byte line, not another 64 x 4 BITS bytes)
+                auto request = [&](LaneWords<BITS>& w, int q) { load_lane_words<BITS>(q < n ? wptr + (size_t)q * STEP : lastp, q < n ? lane : 0, w); };
+                #pragma unroll
+                for (int q = 0; q < D; q++) { item(a[q], q); request(a[q], D + q); }
+                // (the second load in straight-line code as well: around a loop the register allocator leaves copies of the
+                // 3-bit items' register triples on the back edge, and a copy waits for ITS load -- vmcnt(0) once per trip, which
+                // is the exposed round trip again; 15 three-bit items on 16 waves, 9 on 8 waves end here)
+                #pragma unroll
+                for (int q = 0; q < D; q++)
+                {
+                    if (D + q < n) item(a[q], D + q);
+                    if constexpr (S == 16) request(a[q], 2 * D + q);
+                }
+                // (8 waves: two loads at most, lean_plan_matrix)
+                #pragma nounroll
+                for (int q0 = 2 * D; S == 16 && q0 < n; q0 += D)
+                {
+                    #pragma unroll
+                    for (int q = 0; q < D; q++)
+                    {
+                        if (q0 + q < n) item(a[q], q0 + q);
+                        request(a[q], q0 + D + q);
+                    }
+                }
+                return true;
+            }
+            else return false;
+        };
         if (LEAN_KILL & 8)
         {
             // timing experiment: the loads stay, the decode is an xor (what does the launch cost without the decode's VALU work?)
@@ -641,6 +695,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                 if (q + XL < D) { xrequest(xa[q % XL], q + XL); sched_fence(); }
             }
         }
+        else if (ring_passes(std::integral_constant<bool, RING && NB == 0>())) { }
         else
         {
 #if LEAN_REPEAT
@@ -665,7 +720,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         }
         // more items than the wave's registers hold (K = 28672 split over 16 waves: 14-15 items of 3 bits): further passes of D
         // items, each its own round trip -- only the 16-wave geometry, the last one the host tries, plans such shares
-        if constexpr (S == 16 && NB == 0)
+        if constexpr (PASSES && NB == 0 && !RING)
         {
             if (!(LEAN_KILL & 9))
             {
@@ -907,8 +962,9 @@ struct LeanRun { int F, bits, chunk0; u32 off, tstride; int tail_nv; u32 t_off, 
 // decoder per wave, everything in registers); the waves are dealt out to the runs in proportion to their bytes.  Fills
 // wave[0 .. S) and returns the LDS bytes of the S waves together, 0 when the matrix is not covered with S waves (more runs
 // than waves, more items than a wave's registers hold, a chunk -> group map that is not affine inside a part, ...).
-static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave* wave, bool rows_mode = false, bool xmem = false)
+static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave* wave, bool rows_mode = false, bool xmem = false, int passes = 0)
 {
+    if (passes <= 0) passes = S == 16 ? LEAN_MAX_PASSES : 1;            // register loads a wave's share may take (S = 8: items of <= LEAN_S8_PASS_BITS bits only)
     const QMatDev& d = qm->dev;
     if (d.n_runs <= 0 || !qm->cg_host || !d.sc_tab || (qm->is_gptq && !d.zp_tab)) return 0;
     // QRun list (K order): a full run, optionally followed by its partial super-chunk -> logical runs
@@ -971,7 +1027,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
             const int n = (r.F - i0 + (nw[i] - k) - 1) / (nw[i] - k);        // even split, larger parts first
             const bool last = k == nw[i] - 1;
             const int tail_nv = last ? r.tail_nv : 0;
-            if (n > lean_depth(r.bits, S) * (S == 16 ? LEAN_MAX_PASSES : 1) || n > 255) return 0;
+            if (n > lean_depth(r.bits, S) * ((S == 16 || r.bits <= LEAN_S8_PASS_BITS) ? passes : 1) || n > 255) return 0;
             LeanWave& lw = wave[w];
             lw.lds_off = lds_total;
             const int c0 = r.chunk0 + 4 * i0;
@@ -1099,7 +1155,13 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     int cand[3] = {0, 0, 0}, n_cand = 0;
     static const int pair4 = []() { const char* e = getenv("EXL2_LEAN_PAIR4"); return e ? atoi(e) : 1; }();
     if (in.pair && in.M == 1 && pair4) cand[n_cand++] = 4;
+    int cand_passes[3] = {0, 0, 0};                                    // (0 = the geometry's default: lean_plan_matrix)
     cand[n_cand++] = S;
+    // several matrices in one launch (q|k|v) whose shares 8 waves cannot hold in ONE register load: two loads on 8 waves before 16
+    // waves -- a 16-wave workgroup is alone on its CU (80 registers x 4 waves per SIMD), so the 640 tiles of a 70B q|k|v launch ran
+    // as three rounds of 256; 8-wave workgroups are three per CU and all resident at once
+    static const int s8_passes = []() { const char* e = getenv("EXL2_LEAN_S8_PASSES"); const int v = e ? atoi(e) : LEAN_S8_PASSES; return v < 1 ? 1 : (v > LEAN_S8_PASSES ? LEAN_S8_PASSES : v); }();
+    if (!in.pair && nslots == 1 && S == 8 && in.n_mats >= 2 && s8_passes > 1 && !rows_mode && !in.a_tiled) { cand_passes[n_cand] = s8_passes; cand[n_cand++] = 8; }
     if (!in.pair && nslots == 1 && S == 8) cand[n_cand++] = 16;        // finer split of the tile
     // ROWS geometries, in order: two tiles x 8 waves sharing the staged rows (16 waves per CU), one tile x 8, one tile x 16; pair (8 + 8)
     // XMEM geometries (the rows do not fit / EXL2_LEAN_XMEM=2): one tile x 8, one tile x 16; pair (8 + 8)
@@ -1110,10 +1172,11 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     bool planned = false;
     const int nslots0 = nslots;
     const int plain_cand[3] = {cand[0], cand[1], cand[2]};
+    const int plain_passes[3] = {cand_passes[0], cand_passes[1], cand_passes[2]};
     const int plain_n = n_cand;
     auto plan = [&](int form) {                                      // 0: <= 4 rows; 1: ROWS; 2: XMEM
         n_cand = plain_n;
-        for (int i = 0; i < 3; i++) { cand[i] = plain_cand[i]; cand_slots[i] = nslots0; }
+        for (int i = 0; i < 3; i++) { cand[i] = plain_cand[i]; cand_slots[i] = nslots0; cand_passes[i] = form ? 0 : plain_passes[i]; }
         if (form == 1)
         {
             n_cand = 0;
@@ -1152,7 +1215,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
             slot_bytes = 0;
             for (int j = 0; j < in.n_mats && ok; j++)
             {
-                const u32 b = lean_plan_matrix(in.qm[j], S, in.M, in.a_mode == A_NORM_PRE, a.wave + j * S, form == 1, form == 2);
+                const u32 b = lean_plan_matrix(in.qm[j], S, in.M, in.a_mode == A_NORM_PRE, a.wave + j * S, form == 1, form == 2, cand_passes[ci % n_cand]);
                 if (!b) ok = false;
                 if (b > slot_bytes) slot_bytes = b;
             }

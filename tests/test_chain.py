@@ -5,6 +5,8 @@ What the chain replaces is a COMPOSITION of reference kernels (q_attn.cu:153-345
 rope / act_mul -> q_gemm -> residual): its results must equal the oracle's within the same fp16 tolerance as the
 unchained route (tests/test_model.py), step by step, for every bit-width mix, for GPTQ, for several rows.
 """
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -419,6 +421,68 @@ def test_gemm_chain_norm_pre(be, rows, spec_name, monkeypatch):
     slack = 2 * max(1.0, (k / 1024.0) ** 0.5)
     assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= slack * half_tol(want, k))
     be.ext.free_q_matrix(h)
+
+
+# shares of SEVERAL register loads (qgemv_lean.hip: ring_passes): 16 waves x 9 three-bit items (two loads of 8), 16 x 13 two-bit items
+# (two loads of 10), 16 x 14 four-bit items (three loads of 6) + a partial item behind the last full one
+DEEP_SPECS = {
+    "k18432_3b": (18432, [(3, 32, 18432)]),
+    "k26624_2b": (26624, [(2, 64, 26624)]),
+    "k28768_4b_3b": (28768, [(4, 128, 28672), (3, 32, 96)]),
+}
+
+
+@pytest.mark.parametrize("spec_name", list(DEEP_SPECS))
+@pytest.mark.parametrize("rows", [1, 3])
+def test_gemm_chain_shares_of_several_register_loads(be, rows, spec_name, capfd, monkeypatch):
+    """A wave's share beyond its registers (70B down_proj: K = 28672 on 16 waves) is decoded as a RING: item q of the next register
+    load is requested as soon as item q of the current one is decoded.  Numerics against the oracle for 2, 3 and 4-bit shares of
+    two and three loads, one and three rows; the plan is checked to be the multi-load one (a wave with more items than LeanDepth)."""
+    k, spec = DEEP_SPECS[spec_name]
+    if rows * k * 2 > 140 * 1024:
+        pytest.skip("rows x K beyond one workgroup's LDS: the decoder serves such launches as smaller row groups")
+    n = 32
+    t, ref, w, h = _mk(be, k, n, spec, 5)
+    rng = np.random.default_rng(rows + 40)
+    x = (rng.standard_normal((rows, k)) * 2).astype(np.float16)
+    nw = (1 + 0.1 * rng.standard_normal(k)).astype(np.float16)
+    perm = np.argsort(t["q_invperm"]).astype(np.int64)
+    xp = (x.astype(np.float32) * nw.astype(np.float32)).astype(np.float16)[:, perm]
+    ss = (x.astype(np.float32) ** 2).sum(-1, keepdims=True).astype(np.float32)
+    c = torch.zeros((rows, n), dtype=torch.float16, device=be.device)
+    monkeypatch.setenv("EXL2_LEAN_TRACE", "1")
+    be.ext.gemm_half_q_half_chain(be.t(xp), be.t(ss), 1, 1e-5, h, c, rows)
+    monkeypatch.delenv("EXL2_LEAN_TRACE")
+    err = capfd.readouterr().err
+    assert " S=16 " in err, err[:400]
+    depth = {2: 10, 3: 8, 4: 6}
+    shares = [(int(m.group(1)), int(m.group(2))) for m in re.finditer(r"; (\d+) x (\d+)b", err)]
+    assert any(cnt > depth[bits] for cnt, bits in shares), shares
+    want = OX.gemm_ref(OM.rms_norm(x, nw, 1e-5), ref, exact=True)
+    slack = 2 * max(1.0, (k / 1024.0) ** 0.5)
+    assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= slack * half_tol(want, k))
+    lean, flat = be.ext.chain_route_counts(reset=True)
+    assert flat == 0 and lean > 0
+    be.ext.free_q_matrix(h)
+
+
+def test_qkv_launch_takes_two_register_loads_on_eight_waves(be, capfd, monkeypatch):
+    """hidden 8192 at 2.5 bpw (configs[3]'s q|k|v): v_proj's 3 / 4-bit items do not fit ONE register load of 8 waves (capacity 60 of
+    64 items), and the launch's three matrices share one geometry.  Round 4 took 16 waves for all three -- a 16-wave workgroup is alone
+    on its CU, 640 tiles ran as three rounds; now 8 waves with a second (ring) load for the waves that need it, three workgroups per
+    CU.  Plan checked from the host's trace, numerics through the chained decode against the oracle."""
+    cfg = tiny_cfg(hidden_size=8192, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                   head_dim=128)
+    monkeypatch.setenv("EXL2_LEAN_TRACE", "1")
+    _decode_and_check(be, cfg, "2.5bpw", 1, steps=2, seed=5)
+    monkeypatch.delenv("EXL2_LEAN_TRACE")
+    err = capfd.readouterr().err
+    blocks = err.split("[lean] M=")
+    qkv = [b for b in blocks if b.startswith("1 K=8192 mats=3 ")]
+    assert qkv and all(" S=8 " in b.split("\n")[0] for b in qkv), [b.split("\n")[0] for b in blocks][:8]
+    depth = {2: 10, 3: 8, 4: 6}
+    shares = [(int(m.group(1)), int(m.group(2))) for m in re.finditer(r"; (\d+) x (\d+)b", qkv[0])]
+    assert any(cnt > depth.get(bits, 99) for cnt, bits in shares), shares
 
 
 @pytest.mark.parametrize("rows", [1, 4])

@@ -95,3 +95,38 @@ def test_no_global_load_lds_in_the_lean_kernel(tmp_path):
         body = s[m.end():s.index(".Lfunc_end", m.end())]
         assert "global_load_lds" not in body, m.group(1)
         assert "buffer_load_dwordx4" in body and " lds" in body
+
+
+def test_ring_loads_keep_a_whole_register_load_in_flight(tmp_path):
+    """Shares of several register loads (qgemv_lean.hip: ring_passes; 2 / 3 / 4-bit items).  The first two loads are straight-line
+    code: item q of the second load is requested right behind the decode of item q of the first, and decoded behind a wait that
+    leaves the younger requests in flight.  Read off the instruction stream per bit width (the ring's requests are the only
+    non-temporal loads of D consecutive items that are followed by counted waits):
+      * 8 waves, one tile (two loads at most, no third request): D requests, then the waits D - 1, D - 2, ... 0;
+      * 16 waves (up to four loads): D requests, then D times (wait D - 1, request) -- never a vmcnt(0) between them.
+    A vmcnt(0) in front of the second load's first item is the round-4 behaviour: one exposed round trip per load."""
+    s = _asm(tmp_path)
+
+    def events(name):
+        m = re.search(r"^" + name + r":", s, re.M)
+        body = s[m.end():s.index(".Lfunc_end", m.end())].splitlines()
+        ev = []
+        for line in body:
+            t = line.strip()
+            ld = re.match(r"global_load_dword(x\d)? ", t)
+            if ld and " nt" in t:
+                ev.append("L" + (ld.group(1) or "x1")[1:])
+            elif t.startswith("s_waitcnt") and "vmcnt" in t:
+                ev.append("W" + re.search(r"vmcnt\((\d+)\)", t).group(1))
+        return " ".join(ev)
+
+    e8 = events("_Z17qgemv_lean_kernelILb0ELi8ELi1ELb0ELi6ELb0ELb0ELb0ELb0EEv8LeanArgs")
+    e16 = events("_Z17qgemv_lean_kernelILb0ELi16ELi1ELb0ELi6ELb0ELb0ELb0ELb0EEv8LeanArgs")
+    for width, depth in (("4", 6), ("2", 10), ("3", 8)):
+        req = " ".join(["L" + width] * depth)
+        down = " ".join("W%d" % i for i in range(depth - 1, -1, -1))
+        assert req + " " + down in e8, (width, e8)
+        ring = " ".join(["W%d L%s" % (depth - 1, width)] * (depth - 1))
+        assert req + " " + ring in e16, (width, e16)
+    e82 = events("_Z17qgemv_lean_kernelILb0ELi8ELi2ELb1ELi6ELb0ELb0ELb0ELb0EEv8LeanArgs")           # the pair geometry: no such shares
+    assert " ".join(["W9 L2"] * 3) not in e82 and " ".join(["L2"] * 10) + " W9 W8 W7" not in e82
