@@ -22,6 +22,9 @@ class ExLlamaV2Attention:
         self.q_handle = None
         self.fused_decode = os.environ.get("EXL2_ATTN_FUSED", "1") != "0"       # A/B switch for measurements
         self.q4_fused = os.environ.get("EXL2_Q4_FUSED", "1") != "0"
+        # Q4 decode steps in two launches (RoPE + pack of the new rows; attention with the split merge inside) instead of four
+        # (EXL2_Q4_LAUNCHES=4: the round-4 sequence rope_kv_append -> fp16_to_q_kv -> paged_attn_q4 -> its combine launch)
+        self.q4_two_launches = os.environ.get("EXL2_Q4_LAUNCHES", "2") != "4"
 
     def load(self, ck: dict):
         cfg, m = self.model.config, self.model
@@ -95,15 +98,18 @@ class ExLlamaV2Attention:
             sl, bt, past = None, None, past_len
         if q4_direct:
             # new K/V -> (rotated) into the fp16 staging rows -> quantised into the cache -> attention over codes
-            ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, past if not paged else 0,
-                               sl if paged else none_tensor, bt if paged else none_tensor, cfg.rope_style)
-            if paged:
-                cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
-            else:
-                cache.store_kv_state(self.layer_idx, b, past_len, q_len)
             kq, ks, vq, vs = cache.q4_views(self.layer_idx, paged)
+            two = getattr(self, "q4_two_launches", False)
+            if not (two and ext.rope_quant_append_q4(q, k, v, kq, ks, vq, vs, m.sin, m.cos, past if not paged else 0,
+                                                     sl if paged else none_tensor, bt if paged else none_tensor, cfg.rope_style)):
+                ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, past if not paged else 0,
+                                   sl if paged else none_tensor, bt if paged else none_tensor, cfg.rope_style)
+                if paged:
+                    cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
+                else:
+                    cache.store_kv_state(self.layer_idx, b, past_len, q_len)
             ok = ext.paged_attn_q4(q, kq, ks, vq, vs, attn_out, sl, bt, len_const=past, len_offset=q_len,
-                                   scratch=m.attn_scratch, k_new=k, v_new=v)
+                                   scratch=m.attn_scratch, k_new=k, v_new=v, counters=m.attn_counters if two else None)
             if not ok:
                 raise RuntimeError("ExLlamaV2Attention: fused Q4 attention rejected a shape it was selected for")
         else:
@@ -131,8 +137,8 @@ class ExLlamaV2Attention:
 
     def attend_chain(self, q, k, v, cache, cache_seqlens, block_table, out_invperm):
         """Decode attention of the chained step (model.GreedyGraphDecoder), output written in o_proj's packed order.  Paged
-        FP16 cache: the one-launch kernel.  Paged Q4 cache: RoPE + staging of the new rows, their quantisation into the cache,
-        attention straight from the codes (csrc/attn_q4.hip) -- the three launches of _attend's q4_direct route.  Raises when
+        FP16 cache: the one-launch kernel.  Paged Q4 cache: RoPE + Q4 pack of the new rows (csrc/cache_q.hip: rope_quant_q4_kernel),
+        attention straight from the codes with the split merge inside (csrc/attn_q4.hip) -- the two launches of _attend's q4_direct route.  Raises when
         the shape needs another path (the decoder then un-chains)."""
         cfg, m, ext = self.model.config, self.model, self.ext
         b, q_len = q.shape[0], q.shape[1]
@@ -140,12 +146,15 @@ class ExLlamaV2Attention:
             if not self.q4_chain_capable(cache):
                 raise RuntimeError("attend_chain: shape not covered by the Q4 attention kernel")
             attn_out = m.temp_attn[:b * q_len].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
-            kc, vc = cache.paged_view(self.layer_idx)
-            ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, 0, cache_seqlens, block_table, cfg.rope_style)
-            cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
             kq, ks, vq, vs = cache.q4_views(self.layer_idx, True)
+            two = getattr(self, "q4_two_launches", False)
+            if not (two and ext.rope_quant_append_q4(q, k, v, kq, ks, vq, vs, m.sin, m.cos, 0, cache_seqlens, block_table, cfg.rope_style)):
+                kc, vc = cache.paged_view(self.layer_idx)
+                ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, 0, cache_seqlens, block_table, cfg.rope_style)
+                cache.store_kv_state(self.layer_idx, b, 0, q_len, 256, cache_seqlens, block_table)
             if not ext.paged_attn_q4(q, kq, ks, vq, vs, attn_out, cache_seqlens, block_table, len_const=0, len_offset=q_len,
-                                     scratch=m.attn_scratch, k_new=k, v_new=v, out_invperm=out_invperm):
+                                     scratch=m.attn_scratch, k_new=k, v_new=v, out_invperm=out_invperm,
+                                     counters=m.attn_counters if two else None):
                 raise RuntimeError("attend_chain: shape not covered by the Q4 attention kernel")
             return attn_out
         kc, vc = cache.paged_view(self.layer_idx)

@@ -30,6 +30,7 @@ struct AttnQ4Args
     const f16* k_new; const f16* v_new;          // nullable: [b, s, KVH, hd] fp16 (k rotated): keys >= total - s come from here
     const int* cache_seqlens; const int* block_table;
     f16* out; float* part_o; float* part_ml;
+    u32* counters;                // nullable: [b, KVH, row blocks] zeroed tickets -- the last split of a row block to finish merges (no combine launch)
     const u16* out_invperm;       // nullable: feature n of a token row is stored at out[row, out_invperm[n]] (the consumer's packed order)
     int b, s, H, KVH;
     int page_size, page_shift, pages_per_seq;
@@ -390,6 +391,16 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
         {
             a.out[q4_out_index(a, qrow, HDIM, e)] = (f16)(L > 0.0f ? acc / L : 0.0f);
         }
+        else if (a.counters)
+        {
+            // (agent-scope stores, read back with agent-scope loads by the merging workgroup: attn.hip's hand-off)
+            store_agent_f32(a.part_o + (qrow * a.nsplit + split) * HDIM + e, acc);
+            if (e == 0)
+            {
+                store_agent_f32(a.part_ml + (qrow * a.nsplit + split) * 2 + 0, M);
+                store_agent_f32(a.part_ml + (qrow * a.nsplit + split) * 2 + 1, L);
+            }
+        }
         else
         {
             a.part_o[(qrow * a.nsplit + split) * HDIM + e] = acc;
@@ -400,6 +411,23 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
             }
         }
     }
+    if (eff == 1 || !a.counters) return;
+    // hand-off: the last split of this (sequence, kv head, row block) to arrive merges all of them
+    u32* ticket_lds = (u32*)(mg + RB * ROWF);
+    wait_vmcnt0();
+    block_sync();
+    u32* counter = a.counters + ((size_t)b * a.KVH + kh) * rblocks + rblk;
+    if (tid() == 0) *ticket_lds = ticket_add_agent(counter, 1u);
+    block_sync();
+    if (*ticket_lds != (u32)(eff - 1)) return;
+    for (int idx = tid(); idx < nrows * HDIM; idx += nthreads())
+    {
+        const int r = idx / HDIM, d = idx - r * HDIM;
+        const int rr = r0 + r, j = rr / G, g = rr - j * G;
+        const size_t qrow = ((size_t)b * a.s + j) * a.H + kh * G + g;
+        a.out[q4_out_index(a, qrow, HDIM, d)] = (f16)merge_split_partials<true>(a.part_o, a.part_ml, qrow, a.nsplit, eff, HDIM, d);
+    }
+    if (tid() == 0) store_relaxed_agent(counter, 0u);
 }
 
 KERNEL void __launch_bounds__(256) attn_q4_combine_kernel(const AttnQ4Args a, int hd)
@@ -421,7 +449,7 @@ template <int HDIM>
 static void launch_q4(const AttnQ4Args& a, int rb, dim3 grid, void* stream)
 {
     const int lpk = HDIM / 16, kpw = 64 / lpk;
-    size_t lds = ((size_t)AQ_WAVES * kpw * rb + rb) * (HDIM + 2) * 4;
+    size_t lds = ((size_t)AQ_WAVES * kpw * rb + rb) * (HDIM + 2) * 4 + 16;      // (+ the ticket)
     const size_t pro = (size_t)rb * HDIM * 4 + (size_t)rb * HDIM * 2 + AQ_MAX_PAGES * 4;     // prologue: rotated + raw rows + pages
     if (lds < pro) lds = pro;
     static bool attr_done[EXL2_MAX_DEVICES] = {false};
@@ -438,19 +466,17 @@ static void launch_q4(const AttnQ4Args& a, int rb, dim3 grid, void* stream)
     }
 }
 
-extern "C" {
-
 // Attention over a Q4 KV cache.  k_new / v_new == NULL: the cache holds all `total` keys.  Otherwise the last q_len keys
 // (the step's own, k_new already rotated) are taken from these fp16 tensors -- the reference attends over the step's K/V
 // before quantising them (cache.py:517-556 runs after attention) -- and only keys < total - q_len come from the codes.
 // Same addressing / length conventions as exl2_paged_attn; codes [.., KVH, hd/2] uint8, scales [.., KVH, hd/32] fp16.
 // Returns 1 without launching for shapes it does not cover (caller unpacks with exl2_q_to_fp16_kv + exl2_paged_attn).
-int exl2_paged_attn_q4(const void* q, const void* k_codes, const void* k_scales, const void* v_codes, const void* v_scales,
+static int paged_attn_q4_impl(const void* q, const void* k_codes, const void* k_scales, const void* v_codes, const void* v_scales,
                        const void* k_new, const void* v_new, void* out, const int* cache_seqlens, const int* block_table,
                        int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
                        int page_size, int pages_per_seq, int len_const, int len_offset,
                        float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
-                       const void* out_invperm, void* stream)
+                       const void* out_invperm, void* counters, int n_counters, void* stream)
 {
     EXL2_REQUIRE(q && k_codes && k_scales && v_codes && v_scales && out, "paged_attn_q4: null argument");
     EXL2_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged_attn_q4: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
@@ -489,15 +515,47 @@ int exl2_paged_attn_q4(const void* q, const void* k_codes, const void* k_scales,
         a.part_o = (float*)scratch;
         a.part_ml = a.part_o + (size_t)batch * q_len * num_heads * nsplit * head_dim;
     }
+    // tickets given: the last split of a row block merges inside the launch (the combine launch cost ~5 us per layer whether or not
+    // the length needed more than one split)
+    if (nsplit > 1 && counters && (long long)n_counters >= (long long)batch * num_kv_heads * rblocks) a.counters = (u32*)counters;
     dim3 grid((unsigned)num_kv_heads, (unsigned)nsplit, (unsigned)(batch * rblocks));
     if (head_dim == 64) launch_q4<64>(a, rb, grid, stream);
     else if (head_dim == 128) launch_q4<128>(a, rb, grid, stream);
     else launch_q4<256>(a, rb, grid, stream);
-    if (nsplit > 1)
+    if (nsplit > 1 && !a.counters)
         LAUNCH(attn_q4_combine_kernel, dim3((unsigned)(batch * q_len * num_heads)), dim3(head_dim < 256 ? head_dim : 256), 0,
                stream, a, head_dim);
     HIP_TRY(hipGetLastError());
     return EXL2_OK;
+}
+
+extern "C" {
+
+int exl2_paged_attn_q4(const void* q, const void* k_codes, const void* k_scales, const void* v_codes, const void* v_scales,
+                       const void* k_new, const void* v_new, void* out, const int* cache_seqlens, const int* block_table,
+                       int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                       int page_size, int pages_per_seq, int len_const, int len_offset,
+                       float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
+                       const void* out_invperm, void* stream)
+{
+    return paged_attn_q4_impl(q, k_codes, k_scales, v_codes, v_scales, k_new, v_new, out, cache_seqlens, block_table, batch, q_len,
+                              num_heads, num_kv_heads, head_dim, page_size, pages_per_seq, len_const, len_offset, softmax_scale, causal,
+                              nsplit, scratch, scratch_bytes, out_invperm, nullptr, 0, stream);
+}
+
+// The same with `counters`: n_counters >= batch * num_kv_heads * ceil(q_len * (H / KVH) / 4) u32 tickets, ZERO before the first
+// call (every launch leaves them zero): the split partials are merged by the last split to finish, inside the launch -- one launch
+// instead of two.  (exl2_attn_decode_fused's counters serve: same indexing, never used by both at once on a stream.)
+int exl2_paged_attn_q4_merged(const void* q, const void* k_codes, const void* k_scales, const void* v_codes, const void* v_scales,
+                              const void* k_new, const void* v_new, void* out, const int* cache_seqlens, const int* block_table,
+                              int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                              int page_size, int pages_per_seq, int len_const, int len_offset,
+                              float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
+                              const void* out_invperm, void* counters, int n_counters, void* stream)
+{
+    return paged_attn_q4_impl(q, k_codes, k_scales, v_codes, v_scales, k_new, v_new, out, cache_seqlens, block_table, batch, q_len,
+                              num_heads, num_kv_heads, head_dim, page_size, pages_per_seq, len_const, len_offset, softmax_scale, causal,
+                              nsplit, scratch, scratch_bytes, out_invperm, counters, n_counters, stream);
 }
 
 }  // extern "C"

@@ -32,11 +32,21 @@ DEV int rint_clamp(f16 v, int hi)
     return q > hi ? hi : q;
 }
 
-// pack one 512-element block; t = thread in block (0..255)
+// pack one 512-element block; t = thread in block (0..255).  Everything below the load works on 32-lane halves of a wave (64
+// consecutive elements), so ONE wave with t = lane packs any 128-element piece whose offset is a multiple of 128 (q_pack_lane's
+// other caller: rope_quant_q4_kernel, one wave per head row of 128)
+template <int WBITS>
+DEV void q_pack_lane(int t, f16x2 w, u8* out, f16* scales, size_t block_offset);
+
 template <int WBITS>
 DEV void fp16_to_q_block(int t, const f16* in, u8* out, f16* scales, size_t block_offset)
 {
-    f16x2 w = ((const f16x2*)(in + block_offset))[t];
+    q_pack_lane<WBITS>(t, ((const f16x2*)(in + block_offset))[t], out, scales, block_offset);
+}
+
+template <int WBITS>
+DEV void q_pack_lane(int t, f16x2 w, u8* out, f16* scales, size_t block_offset)
+{
     w = wht32(w, t);
 
     f16 am = hmax(habs(w.x), habs(w.y));
@@ -164,6 +174,94 @@ KERNEL void __launch_bounds__(256) kv_codec_paged_kernel(const QKVArgs a)
         codec_block<DIR>(a, kv, (size_t)j);
 }
 
+// ---- RoPE on q / new k + Q4 pack of the new k, v rows straight from registers (decode steps over a Q4 cache) --------------------
+//
+// What the Q4 decode path ran per layer before: rope_append_kernel (attn.hip: rotate q and k in place, copy rotated k and v into the
+// cache's fp16 staging pages) and kv_codec_paged_kernel<0> (read the staging pages back, pack) -- two launches of ~5 us for a few
+// KB.  Here one wave per (token, head row): q rows are rotated in place; k rows are rotated in place (the attention kernel attends
+// over the step's own keys in fp16, attn_q4.hip) and packed from the registers that hold them; v rows are packed.  Same fp16
+// arithmetic in the same order as the two kernels it replaces (rope.cu numerics as restated in rope_append_kernel; q_pack_lane is
+// the codec's own function): codes and scales are bit-identical (tests/test_ops.py).  head_dim 128, full rotary only.
+struct RopeQ4Args
+{
+    f16* q; f16* k_new; const f16* v_new;       // [b, s, H|KVH, 128]
+    u8* k_codes; f16* k_scales; u8* v_codes; f16* v_scales;
+    const f16* sin; const f16* cos;             // [max_seq, 128]
+    const int* past_lens; const int* block_table;
+    int b, s, H, KVH;
+    int past_len, neox, rope;
+    int page_size, page_shift, pages_per_seq;
+};
+
+KERNEL void __launch_bounds__(64) rope_quant_q4_kernel(const RopeQ4Args a)
+{
+    constexpr int HDIM = 128;
+    const int slot = bid_x();                   // < H: q ; < H + KVH: k ; else v
+    const int j = bid_y();
+    const int b = bid_z();
+    const int t = tid();
+    int past = a.past_len;
+    if (past == -1) { past = a.past_lens[b]; past = past > 0 ? past : 0; }
+    else if (a.past_lens) past += a.past_lens[b];
+    const int pos = past + j;
+    const bool is_q = slot < a.H, is_v = slot >= a.H + a.KVH;
+    const int h = is_q ? slot : (is_v ? slot - a.H - a.KVH : slot - a.H);
+    size_t tok = 0;
+    if (!is_q)
+    {
+        if (a.block_table)
+            tok = (size_t)a.block_table[(size_t)b * a.pages_per_seq + (pos >> a.page_shift)] * a.page_size + (pos & (a.page_size - 1));
+        else
+            tok = (size_t)b * a.page_size + pos;
+    }
+    const size_t cache_off = (tok * a.KVH + h) * HDIM;            // element offset of this head row in the cache
+    if (is_v)
+    {
+        const f16x2 w = ((const f16x2*)(a.v_new + (((size_t)b * a.s + j) * a.KVH + h) * HDIM))[t];
+        q_pack_lane<4>(t, w, a.v_codes, a.v_scales, cache_off);
+        return;
+    }
+    f16* x = is_q ? a.q + (((size_t)b * a.s + j) * a.H + h) * HDIM : a.k_new + (((size_t)b * a.s + j) * a.KVH + h) * HDIM;
+    f16x2 w = ((const f16x2*)x)[t];
+    if (a.rope)
+    {
+        const int srow = pos > 0 ? pos : 0;
+        const f16* sr = a.sin + (size_t)srow * HDIM;
+        const f16* cr = a.cos + (size_t)srow * HDIM;
+        if (a.neox)
+        {
+            // pairs (c, c + 64): lane t holds elements 2 t, 2 t + 1 -> its partners sit in lane t ^ 32
+            const f16x2 p = as_h2(shfl_xor_u32(as_u32(w), 32));
+            const int c = 2 * (t & 31);
+            const f16x2 cs = *(const f16x2*)(cr + c), sn = *(const f16x2*)(sr + c);
+            if (t < 32)
+            {
+                // l = own, r = partner:  l' = fma(l, cos, r * (-sin))
+                w.x = h_fma(w.x, cs.x, p.x * (-sn.x));
+                w.y = h_fma(w.y, cs.y, p.y * (-sn.y));
+            }
+            else
+            {
+                // r = own, l = partner:  r' = fma(r, cos, l * sin)
+                w.x = h_fma(w.x, cs.x, p.x * sn.x);
+                w.y = h_fma(w.y, cs.y, p.y * sn.y);
+            }
+        }
+        else
+        {
+            const int c0 = 2 * t;
+            const f16x2 cs = *(const f16x2*)(cr + c0), sn = *(const f16x2*)(sr + c0);
+            const f16 r0 = h_fma(w.y, -sn.x, w.x * cs.x);
+            const f16 r1 = h_fma(w.x, sn.y, w.y * cs.y);
+            w.x = r0; w.y = r1;
+        }
+        ((f16x2*)x)[t] = w;
+    }
+    if (!is_q) q_pack_lane<4>(t, w, a.k_codes, a.k_scales, cache_off);
+}
+
+static int ilog2_exact_cq(int x) { int s = 0; while ((1 << s) < x) s++; return (1 << s) == x ? s : -1; }
+
 static int wbits_pair(int wbits, int* k, int* v)
 {
     if (wbits == 4) { *k = 4; *v = 4; return 0; }
@@ -244,6 +342,34 @@ int exl2_q_to_fp16_kv(const void* k_in, void* k_out, const void* k_scales, const
     EXL2_REQUIRE(k_in && k_out && k_scales, "q_to_fp16_kv: null argument");
     return kv_codec<1>(k_in, k_out, (void*)k_scales, v_in, v_out, (void*)v_scales, batch_size, dim, seq_stride_tokens,
                        offset, width, page_size, cache_seqlens, block_table, pages_per_seq, wbits, stream);
+}
+
+// RoPE on q and k_new in place + Q4 pack of the rotated k_new and of v_new into the cache at positions past_len (+ past_lens[b]) + j
+// through the block table (exl2_rope_kv_append's conventions; block_table == NULL: row b of a [batch, page_size = max_seq_len] cache).
+// One launch for exl2_rope_kv_append + exl2_fp16_to_q_kv (paged, wbits 4) of a decode step.  Returns 1 without launching for shapes
+// it does not cover (head_dim != 128, partial rotary): the caller takes the two entry points it replaces.
+int exl2_rope_quant_append_q4(void* q, void* k_new, const void* v_new, void* k_codes, void* k_scales, void* v_codes, void* v_scales,
+                              const void* sin, const void* cos, int batch, int q_len, int num_heads, int num_kv_heads,
+                              int head_dim, int past_len, const int* past_lens, const int* block_table,
+                              int page_size, int pages_per_seq, int rope_style, int sincos_size, void* stream)
+{
+    EXL2_REQUIRE(q && k_new && v_new && k_codes && k_scales && v_codes && v_scales, "rope_quant_append_q4: null argument");
+    EXL2_REQUIRE(rope_style == 0 || (sin && cos), "rope_quant_append_q4: sin/cos tables missing");
+    EXL2_REQUIRE(past_len != -1 || past_lens, "rope_quant_append_q4: past_len == -1 needs past_lens");
+    if (batch <= 0 || q_len <= 0) return EXL2_OK;
+    if (head_dim != 128 || (rope_style != 0 && sincos_size > 0 && sincos_size != head_dim)) return 1;
+    RopeQ4Args a;
+    memset(&a, 0, sizeof(a));
+    a.q = (f16*)q; a.k_new = (f16*)k_new; a.v_new = (const f16*)v_new;
+    a.k_codes = (u8*)k_codes; a.k_scales = (f16*)k_scales; a.v_codes = (u8*)v_codes; a.v_scales = (f16*)v_scales;
+    a.sin = (const f16*)sin; a.cos = (const f16*)cos; a.past_lens = past_lens; a.block_table = block_table;
+    a.b = batch; a.s = q_len; a.H = num_heads; a.KVH = num_kv_heads;
+    a.past_len = past_len; a.neox = rope_style == 2; a.rope = rope_style != 0;      // ROPE_STYLE_* q_attn.cuh:13-15
+    a.page_size = page_size; a.pages_per_seq = pages_per_seq; a.page_shift = ilog2_exact_cq(page_size);
+    EXL2_REQUIRE(!block_table || a.page_shift >= 0, "rope_quant_append_q4: page_size must be a power of two");
+    LAUNCH(rope_quant_q4_kernel, dim3((unsigned)(num_heads + 2 * num_kv_heads), (unsigned)q_len, (unsigned)batch), dim3(64), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
 }
 
 }  // extern "C"

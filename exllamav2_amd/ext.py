@@ -390,24 +390,45 @@ class ExtC:
 
     def paged_attn_q4(self, q, k_codes, k_scales, v_codes, v_scales, out, cache_seqlens, block_table, len_const: int = 0,
                       len_offset: int = 0, softmax_scale: float | None = None, causal: bool = True, nsplit: int = 0,
-                      scratch=None, k_new=None, v_new=None, out_invperm: int | None = None) -> bool:
+                      scratch=None, k_new=None, v_new=None, out_invperm: int | None = None, counters=None) -> bool:
         """Attention over Q4 codes + scales ([b | pages, T | page_size, KVH, hd/2] uint8, [.., KVH, hd/32] fp16) without
         unpacking them; False when the shape needs the unpack route.  out_invperm (device pointer, u16 [H * hd]): output in
-        o_proj's packed order (chained decode)."""
+        o_proj's packed order (chained decode).  counters (zeroed int32 tickets, left zeroed): the split partials are merged inside
+        the launch instead of by a second one."""
         b, s, nh, hd = q.shape
         kvh = k_codes.shape[2]
         page_size = k_codes.shape[1]
         pps = 0 if _is_none(block_table) else block_table.shape[1]
         scale = hd ** -0.5 if softmax_scale is None else softmax_scale
         sb = 0 if scratch is None else scratch.numel() * scratch.element_size()
-        rc = self.lib.check(self.lib.exl2_paged_attn_q4(
-            self._ptr(q, torch.float16, "q"), self._ptr(k_codes, torch.uint8, "k_codes"),
-            self._ptr(k_scales, torch.float16, "k_scales"), self._ptr(v_codes, torch.uint8, "v_codes"),
-            self._ptr(v_scales, torch.float16, "v_scales"), self._ptr(k_new, torch.float16, "k_new"),
-            self._ptr(v_new, torch.float16, "v_new"), self._ptr(out, torch.float16, "out"),
-            self._ptr(cache_seqlens, torch.int32, "cache_seqlens"), self._ptr(block_table, torch.int32, "block_table"),
-            b, s, nh, kvh, hd, page_size, pps, int(len_const), int(len_offset), float(scale), int(causal), int(nsplit),
-            self._ptr(scratch), sb, out_invperm or None, self._stream(q)))
+        args = (self._ptr(q, torch.float16, "q"), self._ptr(k_codes, torch.uint8, "k_codes"),
+                self._ptr(k_scales, torch.float16, "k_scales"), self._ptr(v_codes, torch.uint8, "v_codes"),
+                self._ptr(v_scales, torch.float16, "v_scales"), self._ptr(k_new, torch.float16, "k_new"),
+                self._ptr(v_new, torch.float16, "v_new"), self._ptr(out, torch.float16, "out"),
+                self._ptr(cache_seqlens, torch.int32, "cache_seqlens"), self._ptr(block_table, torch.int32, "block_table"),
+                b, s, nh, kvh, hd, page_size, pps, int(len_const), int(len_offset), float(scale), int(causal), int(nsplit),
+                self._ptr(scratch), sb, out_invperm or None)
+        if counters is not None:
+            rc = self.lib.check(self.lib.exl2_paged_attn_q4_merged(*args, self._ptr(counters, torch.int32, "counters"), counters.numel(),
+                                                                   self._stream(q)))
+        else:
+            rc = self.lib.check(self.lib.exl2_paged_attn_q4(*args, self._stream(q)))
+        return rc == 0
+
+    def rope_quant_append_q4(self, q, k_new, v_new, k_codes, k_scales, v_codes, v_scales, sin, cos, past_len: int, past_lens,
+                             block_table, rope_style: int, sincos_size: int = 0) -> bool:
+        """RoPE(q, k_new) in place + Q4 pack of the rotated k_new and of v_new into codes / scales at past_len (+ past_lens[b]) + j
+        through the block table: one launch for rope_kv_append + fp16_to_q_kv of a decode step.  False: shape not covered."""
+        b, s, nh, hd = q.shape
+        kvh = k_new.shape[2]
+        page_size = k_codes.shape[1]
+        pps = 0 if _is_none(block_table) else block_table.shape[1]
+        rc = self.lib.check(self.lib.exl2_rope_quant_append_q4(
+            self._ptr(q, torch.float16, "q"), self._ptr(k_new, torch.float16, "k_new"), self._ptr(v_new, torch.float16, "v_new"),
+            self._ptr(k_codes, torch.uint8, "k_codes"), self._ptr(k_scales, torch.float16, "k_scales"),
+            self._ptr(v_codes, torch.uint8, "v_codes"), self._ptr(v_scales, torch.float16, "v_scales"),
+            self._ptr(sin), self._ptr(cos), b, s, nh, kvh, hd, int(past_len), self._ptr(past_lens), self._ptr(block_table),
+            page_size, pps, int(rope_style), int(sincos_size), self._stream(q)))
         return rc == 0
 
     def rope_kv_append(self, q, k_new, v_new, k_cache, v_cache, sin, cos, past_len: int, past_lens, block_table,

@@ -178,6 +178,24 @@ int exl2_paged_attn_q4(const void* q, const void* k_codes, const void* k_scales,
                        float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
                        const void* out_invperm, void* stream);
 /* (out_invperm: nullable, as in exl2_attn_decode_fused -- the chained decode step over a Q4 cache) */
+/* The same with tickets: counters = zeroed u32[n_counters >= batch * num_kv_heads * ceil(q_len * (H / KVH) / 4)], left zeroed (the
+   buffer of exl2_attn_decode_fused serves).  The split partials are merged by the last split to finish, inside the launch: one
+   launch instead of attention + combine. */
+int exl2_paged_attn_q4_merged(const void* q, const void* k_codes, const void* k_scales, const void* v_codes, const void* v_scales,
+                              const void* k_new, const void* v_new, void* out, const int* cache_seqlens, const int* block_table,
+                              int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                              int page_size, int pages_per_seq, int len_const, int len_offset,
+                              float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
+                              const void* out_invperm, void* counters, int n_counters, void* stream);
+/* RoPE(q, k_new) in place + Q4 pack of the rotated k_new and of v_new into the cache's codes / scales at device-side positions:
+   ONE launch for what a decode step over a Q4 cache otherwise does with exl2_rope_kv_append (into the fp16 staging pages) +
+   exl2_fp16_to_q_kv (paged, wbits 4; ext_cache.cpp:80-173 / cache.cu:143-195) -- same fp16 arithmetic, bit-identical codes and
+   scales.  Conventions of exl2_rope_kv_append; codes [pages | batch, page_size, KVH, hd / 2] u8, scales [.., KVH, hd / 32] fp16.
+   Returns 1 without launching for shapes it does not cover (head_dim != 128, partial rotary). */
+int exl2_rope_quant_append_q4(void* q, void* k_new, const void* v_new, void* k_codes, void* k_scales, void* v_codes, void* v_scales,
+                              const void* sin, const void* cos, int batch, int q_len, int num_heads, int num_kv_heads,
+                              int head_dim, int past_len, const int* past_lens, const int* block_table,
+                              int page_size, int pages_per_seq, int rope_style, int sincos_size, void* stream);
 
 /* ---- fused modules --------------------------------------------------------------------------------------------------- */
 

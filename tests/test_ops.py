@@ -407,6 +407,41 @@ def test_attention_from_q4_cache_with_fp16_new_tokens(be, hd, nh, kvh, s):
         assert np.all(err <= _attn_tol(want) + 2e-3), (nsplit, float(err.max()))
 
 
+@pytest.mark.parametrize("hd,nh,kvh,s", [(128, 8, 2, 1), (128, 16, 2, 1), (64, 4, 4, 3)])
+def test_attention_from_q4_cache_merges_its_splits_in_the_launch(be, hd, nh, kvh, s):
+    """exl2_paged_attn_q4_merged: with tickets the last split of a (sequence, kv head, row block) to finish merges the partials
+    inside the launch -- bit-identical to the two-launch form (same merge function), tickets left at zero, also when a sequence is
+    short enough for ONE split while the grid was sized for many (HIP graph: the grid is fixed, the lengths are not)."""
+    rng = np.random.default_rng(47)
+    b, T = 3, 2048
+    total = np.array([1500, 40, 700], dtype=np.int32)
+    kf = rng.standard_normal((b, T, kvh, hd)).astype(F16); vf = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    kq, ks = OM.q4_pack(kf.reshape(-1)); vq, vs = OM.q4_pack(vf.reshape(-1))
+    kn = rng.standard_normal((b, s, kvh, hd)).astype(F16); vn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    scratch = torch.zeros((be.ext.paged_attn_scratch_bytes(b * s * nh, hd, 16) // 4 + 1,), dtype=torch.float32, device=be.device)
+    counters = torch.zeros((256,), dtype=torch.int32, device=be.device)
+    args = (be.t(q), be.t(kq.reshape(b, T, kvh, hd // 2)), be.t(ks.reshape(b, T, kvh, hd // 32)),
+            be.t(vq.reshape(b, T, kvh, hd // 2)), be.t(vs.reshape(b, T, kvh, hd // 32)))
+    for nsplit in (1, 4, 7):
+        outs = []
+        for cnt in (None, counters):
+            out = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+            assert be.ext.paged_attn_q4(*args, out, be.t(total - s), None, len_const=0, len_offset=s, nsplit=nsplit, scratch=scratch,
+                                        k_new=be.t(kn), v_new=be.t(vn), counters=cnt)
+            outs.append(be.n(out))
+        assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16)), nsplit
+        assert int(be.n(counters).astype(np.int64).sum()) == 0
+    # too few tickets: the two-launch form runs (same result as without any)
+    res = []
+    for cnt in (None, counters[:1]):
+        out = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+        assert be.ext.paged_attn_q4(*args, out, be.t(total - s), None, len_const=0, len_offset=s, nsplit=4, scratch=scratch,
+                                    k_new=be.t(kn), v_new=be.t(vn), counters=cnt)
+        res.append(be.n(out))
+    assert np.array_equal(res[0].view(np.uint16), res[1].view(np.uint16))
+
+
 @pytest.mark.parametrize("hd,nh,kvh,s,paged", [(128, 4, 4, 1, True), (64, 8, 8, 1, False), (128, 8, 2, 2, True)])
 def test_attention_from_q4_cache_in_consumer_order(be, hd, nh, kvh, s, paged):
     """exl2_paged_attn_q4(out_invperm=...): the chained decode step's form -- feature n of a token row lands at
@@ -505,6 +540,71 @@ def test_rope_kv_append(be, neox):
             pg = table[i, pos // ps]
             assert np.array_equal(kcn[pg, pos % ps].view(np.uint16), k_want[i, j].view(np.uint16))
             assert np.array_equal(vcn[pg, pos % ps].view(np.uint16), vn[i, j].view(np.uint16))
+
+
+@pytest.mark.parametrize("neox", [True, False])
+@pytest.mark.parametrize("paged", [True, False])
+def test_rope_quant_append_q4(be, neox, paged):
+    """exl2_rope_quant_append_q4: RoPE on q / new k in place + Q4 pack of the rotated k and of v at device-side positions in ONE launch.
+    Checkers: the oracle's rope_ (bit-exact, like rope_kv_append) and the oracle's q4_pack of the rotated rows (codes and scales
+    bit-exact: cache_q.cuh numerics); rows the step did not touch stay untouched.  Then the same through the two entry points it
+    replaces (rope_kv_append into fp16 staging pages + fp16_to_q_kv): identical bytes."""
+    rng = np.random.default_rng(9)
+    pages, ps, kvh, hd, nh = 4, 256, 4, 128, 8
+    b, s = 2, 3
+    past = np.array([10, 254], dtype=np.int32)                # the second sequence crosses a page boundary
+    table = np.array([[2, 0], [1, 3]], dtype=np.int32)
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    kn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    vn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    sin, cos = OM.rope_tables(1024, hd, neox=neox)
+    if paged:
+        shape, T = (pages, ps), ps
+        slot = lambda i, pos: (table[i, pos // ps], pos % ps)
+    else:
+        shape, T = (b, 2 * ps), 2 * ps
+        slot = lambda i, pos: (i, pos)
+    mk = lambda last, dt: torch.full(shape + (kvh, last), 7 if dt == torch.uint8 else 0.5, dtype=dt, device=be.device)
+    kq, vq = mk(hd // 2, torch.uint8), mk(hd // 2, torch.uint8)
+    ks, vs = mk(hd // 32, torch.float16), mk(hd // 32, torch.float16)
+    qt, kt = be.t(q), be.t(kn)
+    style = 2 if neox else 1
+    assert be.ext.rope_quant_append_q4(qt, kt, be.t(vn), kq, ks, vq, vs, be.t(sin), be.t(cos), 0, be.t(past),
+                                       be.t(table) if paged else None, style)
+    q_want = OM.rope_(q, sin, cos, past, neox=neox)
+    k_want = OM.rope_(kn, sin, cos, past, neox=neox)
+    assert np.array_equal(be.n(qt).view(np.uint16), q_want.view(np.uint16))
+    assert np.array_equal(be.n(kt).view(np.uint16), k_want.view(np.uint16))
+    got = [be.n(x) for x in (kq, ks, vq, vs)]
+    touched = np.zeros(shape, dtype=bool)
+    for i in range(b):
+        for j in range(s):
+            a0, a1 = slot(i, past[i] + j)
+            touched[a0, a1] = True
+            for rows, codes, scales in ((k_want[i, j], got[0], got[1]), (vn[i, j], got[2], got[3])):
+                c_want, s_want = OM.q4_pack(rows.reshape(-1))
+                assert np.array_equal(codes[a0, a1].reshape(-1), c_want)
+                assert np.array_equal(scales[a0, a1].reshape(-1).view(np.uint16), s_want.view(np.uint16))
+    assert np.all(got[0][~touched] == 7) and np.all(got[2][~touched] == 7) and np.all(got[1][~touched] == F16(0.5))
+    # the two launches it replaces leave the same bytes
+    kc = torch.zeros(shape + (kvh, hd), dtype=torch.float16, device=be.device)
+    vc = torch.zeros_like(kc)
+    kq2, vq2, ks2, vs2 = mk(hd // 2, torch.uint8), mk(hd // 2, torch.uint8), mk(hd // 32, torch.float16), mk(hd // 32, torch.float16)
+    q2, k2 = be.t(q), be.t(kn)
+    if paged:
+        be.ext.rope_kv_append(q2, k2, be.t(vn), kc, vc, be.t(sin), be.t(cos), 0, be.t(past), be.t(table), style)
+        be.ext.fp16_to_q_kv(kc, kq2, ks2, vc, vq2, vs2, b, 0, s, ps, be.t(past), be.t(table), 4)
+        assert np.array_equal(be.n(q2).view(np.uint16), be.n(qt).view(np.uint16))
+        for new, old in zip(got, (kq2, ks2, vq2, vs2)):
+            o = be.n(old)
+            assert np.array_equal(new[touched].view(np.uint8), o[touched].view(np.uint8))
+    # shapes it does not cover are declined, not approximated
+    q64 = torch.zeros((1, 1, 2, 64), dtype=torch.float16, device=be.device)
+    k64 = torch.zeros((1, 1, 2, 64), dtype=torch.float16, device=be.device)
+    c64 = torch.zeros((1, 256, 2, 32), dtype=torch.uint8, device=be.device)
+    s64 = torch.zeros((1, 256, 2, 2), dtype=torch.float16, device=be.device)
+    sin64, cos64 = OM.rope_tables(16, 64, neox=True)
+    assert not be.ext.rope_quant_append_q4(q64, k64, k64, c64, s64, c64, s64, be.t(sin64), be.t(cos64), 3, None, None, 2)
 
 
 def test_decode_utilities(be):
