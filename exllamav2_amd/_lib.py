@@ -67,6 +67,7 @@ PROTOTYPES = {
                                     vp, cll, vp, ci, vp, vp, vp]),
     "exl2_paged_attn_q4": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, vp, cll, vp, vp]),
     "exl2_paged_attn_q4_merged": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, vp, cll, vp, vp, ci, vp]),
+    "exl2_attn_q4_decode_fused": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, ci, vp, cll, vp, ci, vp, vp]),
     "exl2_rope_quant_append_q4": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, vp]),
     # fused modules
     "exl2_make_q_attn": (ci, [C.POINTER(vp), vp, vp, ci, ci, cf, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci,

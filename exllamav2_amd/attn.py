@@ -23,8 +23,10 @@ class ExLlamaV2Attention:
         self.fused_decode = os.environ.get("EXL2_ATTN_FUSED", "1") != "0"       # A/B switch for measurements
         self.q4_fused = os.environ.get("EXL2_Q4_FUSED", "1") != "0"
         # Q4 decode steps in two launches (RoPE + pack of the new rows; attention with the split merge inside) instead of four
-        # (EXL2_Q4_LAUNCHES=4: the round-4 sequence rope_kv_append -> fp16_to_q_kv -> paged_attn_q4 -> its combine launch)
-        self.q4_two_launches = os.environ.get("EXL2_Q4_LAUNCHES", "2") != "4"
+        # (EXL2_Q4_LAUNCHES=4: the round-4 sequence rope_kv_append -> fp16_to_q_kv -> paged_attn_q4 -> its combine launch) ...
+        self.q4_two_launches = os.environ.get("EXL2_Q4_LAUNCHES", "1") != "4"
+        # ... or ONE (RoPE + pack + attention + merge: csrc/attn_q4.hip, the FUSED form; head_dim 128) -- EXL2_Q4_LAUNCHES=2 keeps two
+        self.q4_one_launch = os.environ.get("EXL2_Q4_LAUNCHES", "1") == "1"
 
     def load(self, ck: dict):
         cfg, m = self.model.config, self.model
@@ -100,6 +102,9 @@ class ExLlamaV2Attention:
             # new K/V -> (rotated) into the fp16 staging rows -> quantised into the cache -> attention over codes
             kq, ks, vq, vs = cache.q4_views(self.layer_idx, paged)
             two = getattr(self, "q4_two_launches", False)
+            if getattr(self, "q4_one_launch", False) and ext.attn_q4_decode_fused(
+                    q, k, v, kq, ks, vq, vs, attn_out, m.sin, m.cos, sl, bt, past, cfg.rope_style, m.attn_scratch, m.attn_counters):
+                return attn_out
             if not (two and ext.rope_quant_append_q4(q, k, v, kq, ks, vq, vs, m.sin, m.cos, past if not paged else 0,
                                                      sl if paged else none_tensor, bt if paged else none_tensor, cfg.rope_style)):
                 ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, past if not paged else 0,
@@ -148,6 +153,10 @@ class ExLlamaV2Attention:
             attn_out = m.temp_attn[:b * q_len].view(b, q_len, cfg.num_attention_heads, cfg.head_dim)
             kq, ks, vq, vs = cache.q4_views(self.layer_idx, True)
             two = getattr(self, "q4_two_launches", False)
+            if getattr(self, "q4_one_launch", False) and ext.attn_q4_decode_fused(
+                    q, k, v, kq, ks, vq, vs, attn_out, m.sin, m.cos, cache_seqlens, block_table, 0, cfg.rope_style, m.attn_scratch,
+                    m.attn_counters, out_invperm=out_invperm):
+                return attn_out
             if not (two and ext.rope_quant_append_q4(q, k, v, kq, ks, vq, vs, m.sin, m.cos, 0, cache_seqlens, block_table, cfg.rope_style)):
                 kc, vc = cache.paged_view(self.layer_idx)
                 ext.rope_kv_append(q, k, v, kc, vc, m.sin, m.cos, 0, cache_seqlens, block_table, cfg.rope_style)

@@ -15,6 +15,7 @@
 #include "hw.h"
 #include "errors.h"
 #include "attn_merge.h"
+#include "cache_q_pack.h"
 #include <string.h>
 
 #define AQ_WAVES 4
@@ -30,6 +31,9 @@ struct AttnQ4Args
     const f16* k_new; const f16* v_new;          // nullable: [b, s, KVH, hd] fp16 (k rotated): keys >= total - s come from here
     const int* cache_seqlens; const int* block_table;
     f16* out; float* part_o; float* part_ml;
+    // FUSED form (template parameter; head_dim 128): q and k_new arrive UNROTATED -- the launch applies RoPE to them on the way in
+    // (positions total - s + j) and packs the rotated k_new and v_new into the codes: the whole decode step in one launch
+    const f16* sin; const f16* cos; int rope, neox;
     u32* counters;                // nullable: [b, KVH, row blocks] zeroed tickets -- the last split of a row block to finish merges (no combine launch)
     const u16* out_invperm;       // nullable: feature n of a token row is stored at out[row, out_invperm[n]] (the consumer's packed order)
     int b, s, H, KVH;
@@ -53,9 +57,36 @@ DEV int q4_eff_splits(int total, int nsplit)
     return e < 1 ? 1 : (e > nsplit ? nsplit : e);
 }
 
-template <int HDIM, int RB>
+// RoPE on 8 consecutive elements [c, c + 8) of a head row (`own`), `partner` = the elements 64 columns away (NeoX; unused for GPT-J):
+// rope_append_kernel's fp16 operations (attn.hip), element by element
+DEV f16x8 rope8_128(f16x8 own, f16x8 partner, int c, const f16* sr, const f16* cr, bool neox)
+{
+    f16x8 y;
+    if (neox)
+    {
+        const int c0 = c & 63;
+        const f16x8 cs = *(const f16x8*)(cr + c0), sn = *(const f16x8*)(sr + c0);
+        #pragma unroll
+        for (int e = 0; e < 8; e++)
+            y[e] = c < 64 ? h_fma(own[e], cs[e], partner[e] * (-sn[e])) : h_fma(own[e], cs[e], partner[e] * sn[e]);
+    }
+    else
+    {
+        const f16x8 cs = *(const f16x8*)(cr + c), sn = *(const f16x8*)(sr + c);
+        #pragma unroll
+        for (int e = 0; e < 8; e += 2)
+        {
+            y[e] = h_fma(own[e + 1], -sn[e], own[e] * cs[e]);
+            y[e + 1] = h_fma(own[e], sn[e + 1], own[e + 1] * cs[e + 1]);
+        }
+    }
+    return y;
+}
+
+template <int HDIM, int RB, bool FUSED = false>
 KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4Args a)
 {
+    static_assert(!FUSED || HDIM == 128, "the one-launch form is built for head_dim 128");
     DYN_SMEM(smem);
     constexpr int LPK = HDIM / 16;              // lanes per key: 16 elements (8 code bytes) each
     constexpr int KPW = 64 / LPK;
@@ -86,6 +117,34 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
     const int k_start = split * kps;
     const int k_end = min(total, k_start + kps);
 
+    if constexpr (FUSED)
+    {
+        // ---- the step's own rows into the cache: one workgroup per (sequence, kv head), one wave per row (k rotated first).  Nobody
+        // in this launch reads what is written here: the codes serve keys < total - s, the step's own keys are attended in fp16
+        if (split == 0 && rblk == 0)
+        {
+            for (int task = wv; task < 2 * a.s; task += AQ_WAVES)
+            {
+                const int j = task >> 1;
+                const bool is_v = task & 1;
+                const int pos = total - a.s + j;
+                size_t tok;
+                if (a.block_table) tok = (size_t)a.block_table[(size_t)b * a.pages_per_seq + (pos >> a.page_shift)] * a.page_size + (pos & (a.page_size - 1));
+                else tok = (size_t)b * a.page_size + pos;
+                const size_t cache_off = (tok * a.KVH + kh) * HDIM;
+                const size_t src = (((size_t)b * a.s + j) * a.KVH + kh) * HDIM;
+                if (is_v) q_pack_lane<4>(lane, ((const f16x2*)(a.v_new + src))[lane], (u8*)a.v_codes, (f16*)a.v_scales, cache_off);
+                else
+                {
+                    f16x2 w = ((const f16x2*)(a.k_new + src))[lane];
+                    const int srow = pos > 0 ? pos : 0;
+                    if (a.rope) w = rope_lane_pair128(w, lane, a.sin + (size_t)srow * HDIM, a.cos + (size_t)srow * HDIM, a.neox != 0);
+                    q_pack_lane<4>(lane, w, (u8*)a.k_codes, (f16*)a.k_scales, cache_off);
+                }
+            }
+        }
+    }
+
     // ---- block-table entries of this split and the raw query rows into LDS ------------------------------------------------
     float* qh_lds = (float*)smem;                                       // [RB][HDIM] rotated rows
     f16* qraw_lds = (f16*)(qh_lds + RB * HDIM);                         // [RB][HDIM] raw rows
@@ -101,7 +160,18 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
     {
         const int r = idx / (HDIM / 8), o8 = idx - r * (HDIM / 8);
         const int rr = r0 + r, j = rr / G, g = rr - j * G;
-        ((f16x8*)qraw_lds)[idx] = *(const f16x8*)(a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM + o8 * 8);
+        const f16* qrow_p = a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM;
+        f16x8 qv = *(const f16x8*)(qrow_p + o8 * 8);
+        if constexpr (FUSED)
+        {
+            if (a.rope)
+            {
+                const int pos = total - a.s + j, srow = pos > 0 ? pos : 0;
+                const f16x8 qpart = *(const f16x8*)(qrow_p + ((o8 * 8) ^ 64));
+                qv = rope8_128(qv, qpart, o8 * 8, a.sin + (size_t)srow * HDIM, a.cos + (size_t)srow * HDIM, a.neox != 0);
+            }
+        }
+        ((f16x8*)qraw_lds)[idx] = qv;
     }
     block_sync();
     // ---- rotate the query rows: qh[64 g + 2 t + comp] = sum_t' H[t, t'] q[64 g + 2 t' + comp], H[t,t'] = (-1)^popc(t & t')
@@ -287,6 +357,28 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
             kn[i] = (f16x2){a.k_new[src + 2 * i], a.k_new[src + 2 * i + 1]};
             w[2 * i] = (float)a.v_new[src + 2 * i]; w[2 * i + 1] = (float)a.v_new[src + 2 * i + 1];
         }
+        if constexpr (FUSED)
+        {
+            if (a.rope)
+            {
+                // the lane's 16 elements [16 u, 16 u + 16) of the UNROTATED row, their NeoX partners 64 columns away
+                const int srow = kp > 0 ? kp : 0;
+                const f16* sr = a.sin + (size_t)srow * HDIM;
+                const f16* cr = a.cos + (size_t)srow * HDIM;
+                const size_t psrc = src - 16 * u + ((16 * u) ^ 64);
+                #pragma unroll
+                for (int hblk = 0; hblk < 2; hblk++)
+                {
+                    f16x8 own, part;
+                    #pragma unroll
+                    for (int e = 0; e < 8; e++) own[e] = e & 1 ? kn[4 * hblk + e / 2].y : kn[4 * hblk + e / 2].x;
+                    part = *(const f16x8*)(a.k_new + psrc + 8 * hblk);
+                    const f16x8 y = rope8_128(own, part, 16 * u + 8 * hblk, sr, cr, a.neox != 0);
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) kn[4 * hblk + e] = (f16x2){y[2 * e], y[2 * e + 1]};
+                }
+            }
+        }
         // rotate v into the accumulation domain: H over the pair index t = 8 (u & 3) + i, per component
         #pragma unroll
         for (int mbit = 1; mbit < 8; mbit <<= 1)
@@ -446,8 +538,9 @@ KERNEL void __launch_bounds__(256) attn_q4_combine_kernel(const AttnQ4Args a, in
 static int ilog2_exact_q4(int x) { int s = 0; while ((1 << s) < x) s++; return (1 << s) == x ? s : -1; }
 
 template <int HDIM>
-static void launch_q4(const AttnQ4Args& a, int rb, dim3 grid, void* stream)
+static void launch_q4(const AttnQ4Args& a, int rb, dim3 grid, void* stream, bool fused = false)
 {
+    static bool attr_done_fused[EXL2_MAX_DEVICES] = {false};
     const int lpk = HDIM / 16, kpw = 64 / lpk;
     size_t lds = ((size_t)AQ_WAVES * kpw * rb + rb) * (HDIM + 2) * 4 + 16;      // (+ the ticket)
     const size_t pro = (size_t)rb * HDIM * 4 + (size_t)rb * HDIM * 2 + AQ_MAX_PAGES * 4;     // prologue: rotated + raw rows + pages
@@ -457,6 +550,24 @@ static void launch_q4(const AttnQ4Args& a, int rb, dim3 grid, void* stream)
     {
         (void)hipFuncSetAttribute((const void*)attn_q4_decode_kernel<HDIM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)attn_q4_decode_kernel<HDIM, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if constexpr (HDIM == 128)
+    {
+        if (fused)
+        {
+            if (exl2_first_on_device(attr_done_fused))
+            {
+                (void)hipFuncSetAttribute((const void*)attn_q4_decode_kernel<HDIM, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)attn_q4_decode_kernel<HDIM, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
+            switch (rb)
+            {
+                case 1: LAUNCH((attn_q4_decode_kernel<HDIM, 1, true>), grid, dim3(AQ_WAVES * 64), lds, stream, a); break;
+                case 2: LAUNCH((attn_q4_decode_kernel<HDIM, 2, true>), grid, dim3(AQ_WAVES * 64), lds, stream, a); break;
+                default: LAUNCH((attn_q4_decode_kernel<HDIM, 4, true>), grid, dim3(AQ_WAVES * 64), lds, stream, a); break;
+            }
+            return;
+        }
     }
     switch (rb)
     {
@@ -476,12 +587,15 @@ static int paged_attn_q4_impl(const void* q, const void* k_codes, const void* k_
                        int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
                        int page_size, int pages_per_seq, int len_const, int len_offset,
                        float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
-                       const void* out_invperm, void* counters, int n_counters, void* stream)
+                       const void* out_invperm, void* counters, int n_counters, void* stream,
+                       const void* sin = nullptr, const void* cos = nullptr, int rope_style = -1, int sincos_size = 0)
 {
+    const bool fused = rope_style >= 0;                     // the one-launch form: RoPE + pack of the step's rows inside this launch
     EXL2_REQUIRE(q && k_codes && k_scales && v_codes && v_scales && out, "paged_attn_q4: null argument");
     EXL2_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged_attn_q4: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
     if (batch <= 0 || q_len <= 0) return EXL2_OK;
     if (!(head_dim == 64 || head_dim == 128 || head_dim == 256)) return 1;
+    if (fused && (head_dim != 128 || !k_new || !v_new || (rope_style != 0 && (!sin || !cos || (sincos_size > 0 && sincos_size != head_dim))))) return 1;
     const int G = num_heads / num_kv_heads;
     const int R = q_len * G;
     if (R > 64) return 1;
@@ -496,6 +610,7 @@ static int paged_attn_q4_impl(const void* q, const void* k_codes, const void* k_
     a.page_size = page_size; a.pages_per_seq = pages_per_seq; a.page_shift = ilog2_exact_q4(page_size);
     EXL2_REQUIRE(!block_table || a.page_shift >= 0, "paged_attn_q4: page_size %d must be a power of two", page_size);
     a.len_const = len_const; a.len_offset = len_offset; a.causal = causal; a.scale = softmax_scale;
+    if (fused) { a.sin = (const f16*)sin; a.cos = (const f16*)cos; a.rope = rope_style != 0; a.neox = rope_style == 2; }      // ROPE_STYLE_* q_attn.cuh:13-15
     const int rb = R >= 4 ? 4 : (R >= 2 ? 2 : 1);
     const int rblocks = (R + rb - 1) / rb;
     if (nsplit <= 0)
@@ -520,7 +635,7 @@ static int paged_attn_q4_impl(const void* q, const void* k_codes, const void* k_
     if (nsplit > 1 && counters && (long long)n_counters >= (long long)batch * num_kv_heads * rblocks) a.counters = (u32*)counters;
     dim3 grid((unsigned)num_kv_heads, (unsigned)nsplit, (unsigned)(batch * rblocks));
     if (head_dim == 64) launch_q4<64>(a, rb, grid, stream);
-    else if (head_dim == 128) launch_q4<128>(a, rb, grid, stream);
+    else if (head_dim == 128) launch_q4<128>(a, rb, grid, stream, fused);
     else launch_q4<256>(a, rb, grid, stream);
     if (nsplit > 1 && !a.counters)
         LAUNCH(attn_q4_combine_kernel, dim3((unsigned)(batch * q_len * num_heads)), dim3(head_dim < 256 ? head_dim : 256), 0,
@@ -556,6 +671,25 @@ int exl2_paged_attn_q4_merged(const void* q, const void* k_codes, const void* k_
     return paged_attn_q4_impl(q, k_codes, k_scales, v_codes, v_scales, k_new, v_new, out, cache_seqlens, block_table, batch, q_len,
                               num_heads, num_kv_heads, head_dim, page_size, pages_per_seq, len_const, len_offset, softmax_scale, causal,
                               nsplit, scratch, scratch_bytes, out_invperm, counters, n_counters, stream);
+}
+
+// The whole decode step over a Q4 cache in ONE launch: RoPE on q and k_new (NOT modified in memory: rotated on the way into the
+// kernel), Q4 pack of the rotated k_new and of v_new into the codes / scales at positions past + j (past = cache_seqlens[b], or
+// past_const without cache_seqlens), attention over the codes for keys below `past` and over the step's own rows in fp16, split
+// merge by ticket == exl2_rope_kv_append + exl2_fp16_to_q_kv + exl2_paged_attn_q4 (+ its combine launch).  Returns 1 without
+// launching for shapes it does not cover (head_dim != 128, partial rotary, > 64 query rows per kv head): the caller takes
+// exl2_rope_quant_append_q4 + exl2_paged_attn_q4_merged.
+int exl2_attn_q4_decode_fused(const void* q, const void* k_new, const void* v_new, void* k_codes, void* k_scales, void* v_codes,
+                              void* v_scales, void* out, const void* sin, const void* cos, const int* cache_seqlens,
+                              const int* block_table, int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                              int page_size, int pages_per_seq, int past_const, float softmax_scale, int rope_style, int sincos_size,
+                              int nsplit, void* scratch, long long scratch_bytes, void* counters, int n_counters,
+                              const void* out_invperm, void* stream)
+{
+    EXL2_REQUIRE(rope_style >= 0 && rope_style <= 2, "attn_q4_decode_fused: rope_style %d", rope_style);
+    return paged_attn_q4_impl(q, k_codes, k_scales, v_codes, v_scales, k_new, v_new, out, cache_seqlens, block_table, batch, q_len,
+                              num_heads, num_kv_heads, head_dim, page_size, pages_per_seq, past_const, q_len, softmax_scale, 1,
+                              nsplit, scratch, scratch_bytes, out_invperm, counters, n_counters, stream, sin, cos, rope_style, sincos_size);
 }
 
 }  // extern "C"

@@ -8,73 +8,15 @@
 // reproducible bit for bit by the oracle.
 #include "hw.h"
 #include "errors.h"
+#include "cache_q_pack.h"
 #include <string.h>
 
 #define QBLOCK 512
-
-DEV f16x2 wht32(f16x2 w, int t)
-{
-    u32 wi = as_u32(w);
-    #define WHT_STEP(M) { const u32 p = swz_xor_u32<M>(wi); if (t & M) wi ^= 0x80008000u; wi = as_u32(as_h2(wi) + as_h2(p)); }
-    WHT_STEP(1) WHT_STEP(2) WHT_STEP(4) WHT_STEP(8) WHT_STEP(16)
-    #undef WHT_STEP
-    return as_h2(wi);
-}
-
-DEV f16 hmax(f16 a, f16 b) { return a > b ? a : b; }
-DEV f16 habs(f16 a) { return as_h((u16)(as_u16(a) & 0x7FFF)); }
-
-DEV int rint_clamp(f16 v, int hi)
-{
-    const float f = (float)v;
-    int q = (f != f) ? 0 : (int)rintf(f);          // __half2int_rn(NaN) == 0
-    q = q < 0 ? 0 : q;
-    return q > hi ? hi : q;
-}
-
-// pack one 512-element block; t = thread in block (0..255).  Everything below the load works on 32-lane halves of a wave (64
-// consecutive elements), so ONE wave with t = lane packs any 128-element piece whose offset is a multiple of 128 (q_pack_lane's
-// other caller: rope_quant_q4_kernel, one wave per head row of 128)
-template <int WBITS>
-DEV void q_pack_lane(int t, f16x2 w, u8* out, f16* scales, size_t block_offset);
 
 template <int WBITS>
 DEV void fp16_to_q_block(int t, const f16* in, u8* out, f16* scales, size_t block_offset)
 {
     q_pack_lane<WBITS>(t, ((const f16x2*)(in + block_offset))[t], out, scales, block_offset);
-}
-
-template <int WBITS>
-DEV void q_pack_lane(int t, f16x2 w, u8* out, f16* scales, size_t block_offset)
-{
-    w = wht32(w, t);
-
-    f16 am = hmax(habs(w.x), habs(w.y));
-    am = hmax(am, as_h((u16)swz_xor_u32<8>((u32)as_u16(am))));
-    am = hmax(am, as_h((u16)swz_xor_u32<4>((u32)as_u16(am))));
-    am = hmax(am, as_h((u16)swz_xor_u32<2>((u32)as_u16(am))));
-    am = hmax(am, as_h((u16)swz_xor_u32<1>((u32)as_u16(am))));
-    const f16x2 am2 = h2_dup(am);
-
-    if constexpr (WBITS == 4)
-    {
-        f16x2 n = h2_div_rn(w, am2);
-        n = h2_fma(n, h2_dup((f16)8.0f), h2_dup((f16)8.0f));
-        u32 q = (u32)rint_clamp(n.x, 15) | ((u32)rint_clamp(n.y, 15) << 4);
-        q |= shfl_idx_u32(q, lane_id() + 1) << 8;          // lanes t % 2 == 0 now hold 2 bytes
-        q |= shfl_idx_u32(q, lane_id() + 2) << 16;         // lanes t % 4 == 0 hold 4 bytes
-        if ((t & 3) == 0) ((u32*)(out + block_offset / 2))[t >> 2] = q;
-        if ((t & 15) == 0) scales[block_offset / 32 + (t >> 4)] = am * (f16)0.125f;
-    }
-    else
-    {
-        f16x2 n = h2_div_rn(w, am2);
-        n = h2_fma(n, h2_dup((f16)128.0f), h2_dup((f16)128.0f));
-        u32 q = (u32)rint_clamp(n.x, 255) | ((u32)rint_clamp(n.y, 255) << 8);
-        q |= shfl_idx_u32(q, lane_id() + 1) << 16;
-        if ((t & 1) == 0) ((u32*)(out + block_offset))[t >> 1] = q;
-        if ((t & 15) == 0) scales[block_offset / 32 + (t >> 4)] = am * (f16)0.0078125f;
-    }
 }
 
 template <int WBITS>
@@ -228,33 +170,7 @@ KERNEL void __launch_bounds__(64) rope_quant_q4_kernel(const RopeQ4Args a)
         const int srow = pos > 0 ? pos : 0;
         const f16* sr = a.sin + (size_t)srow * HDIM;
         const f16* cr = a.cos + (size_t)srow * HDIM;
-        if (a.neox)
-        {
-            // pairs (c, c + 64): lane t holds elements 2 t, 2 t + 1 -> its partners sit in lane t ^ 32
-            const f16x2 p = as_h2(shfl_xor_u32(as_u32(w), 32));
-            const int c = 2 * (t & 31);
-            const f16x2 cs = *(const f16x2*)(cr + c), sn = *(const f16x2*)(sr + c);
-            if (t < 32)
-            {
-                // l = own, r = partner:  l' = fma(l, cos, r * (-sin))
-                w.x = h_fma(w.x, cs.x, p.x * (-sn.x));
-                w.y = h_fma(w.y, cs.y, p.y * (-sn.y));
-            }
-            else
-            {
-                // r = own, l = partner:  r' = fma(r, cos, l * sin)
-                w.x = h_fma(w.x, cs.x, p.x * sn.x);
-                w.y = h_fma(w.y, cs.y, p.y * sn.y);
-            }
-        }
-        else
-        {
-            const int c0 = 2 * t;
-            const f16x2 cs = *(const f16x2*)(cr + c0), sn = *(const f16x2*)(sr + c0);
-            const f16 r0 = h_fma(w.y, -sn.x, w.x * cs.x);
-            const f16 r1 = h_fma(w.x, sn.y, w.y * cs.y);
-            w.x = r0; w.y = r1;
-        }
+        w = rope_lane_pair128(w, t, sr, cr, a.neox != 0);
         ((f16x2*)x)[t] = w;
     }
     if (!is_q) q_pack_lane<4>(t, w, a.k_codes, a.k_scales, cache_off);

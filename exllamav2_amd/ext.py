@@ -415,6 +415,28 @@ class ExtC:
             rc = self.lib.check(self.lib.exl2_paged_attn_q4(*args, self._stream(q)))
         return rc == 0
 
+    def attn_q4_decode_fused(self, q, k_new, v_new, k_codes, k_scales, v_codes, v_scales, out, sin, cos, cache_seqlens, block_table,
+                             past_const: int, rope_style: int, scratch, counters, softmax_scale: float | None = None, nsplit: int = 0,
+                             out_invperm: int | None = None, sincos_size: int = 0) -> bool:
+        """One launch for a decode step over a Q4 cache: RoPE(q, k_new) on the way in (the tensors are NOT modified), Q4 pack of the
+        new rows, attention over codes + the step's own fp16 rows, split merge.  False: shape not covered."""
+        b, s, nh, hd = q.shape
+        kvh = k_new.shape[2]
+        page_size = k_codes.shape[1]
+        pps = 0 if _is_none(block_table) else block_table.shape[1]
+        scale = hd ** -0.5 if softmax_scale is None else softmax_scale
+        sb = 0 if scratch is None else scratch.numel() * scratch.element_size()
+        rc = self.lib.check(self.lib.exl2_attn_q4_decode_fused(
+            self._ptr(q, torch.float16, "q"), self._ptr(k_new, torch.float16, "k_new"), self._ptr(v_new, torch.float16, "v_new"),
+            self._ptr(k_codes, torch.uint8, "k_codes"), self._ptr(k_scales, torch.float16, "k_scales"),
+            self._ptr(v_codes, torch.uint8, "v_codes"), self._ptr(v_scales, torch.float16, "v_scales"),
+            self._ptr(out, torch.float16, "out"), self._ptr(sin), self._ptr(cos),
+            self._ptr(cache_seqlens, torch.int32, "cache_seqlens"), self._ptr(block_table, torch.int32, "block_table"),
+            b, s, nh, kvh, hd, page_size, pps, int(past_const), float(scale), int(rope_style), int(sincos_size), int(nsplit),
+            self._ptr(scratch), sb, self._ptr(counters, torch.int32, "counters"), counters.numel(), out_invperm or None,
+            self._stream(q)))
+        return rc == 0
+
     def rope_quant_append_q4(self, q, k_new, v_new, k_codes, k_scales, v_codes, v_scales, sin, cos, past_len: int, past_lens,
                              block_table, rope_style: int, sincos_size: int = 0) -> bool:
         """RoPE(q, k_new) in place + Q4 pack of the rotated k_new and of v_new into codes / scales at past_len (+ past_lens[b]) + j

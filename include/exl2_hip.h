@@ -187,6 +187,18 @@ int exl2_paged_attn_q4_merged(const void* q, const void* k_codes, const void* k_
                               int page_size, int pages_per_seq, int len_const, int len_offset,
                               float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
                               const void* out_invperm, void* counters, int n_counters, void* stream);
+/* The whole decode step over a Q4 cache in ONE launch: RoPE on q / k_new on the way into the kernel (q and k_new are NOT modified),
+   Q4 pack of the rotated k_new and of v_new at positions past + j (past = cache_seqlens[b], or past_const without cache_seqlens),
+   attention over the codes (keys < past) and the step's own rows in fp16, split merge by ticket.  Replaces exl2_rope_kv_append +
+   exl2_fp16_to_q_kv + exl2_paged_attn_q4 of a decode step (cache.py:517-556 + attn.py:602-613 over ExLlamaV2Cache_Q4).  counters:
+   zeroed u32[n_counters >= batch * num_kv_heads * ceil(q_len * (H / KVH) / 4)], left zeroed.  Returns 1 without launching for
+   shapes it does not cover (head_dim != 128, partial rotary): use exl2_rope_quant_append_q4 + exl2_paged_attn_q4_merged. */
+int exl2_attn_q4_decode_fused(const void* q, const void* k_new, const void* v_new, void* k_codes, void* k_scales, void* v_codes,
+                              void* v_scales, void* out, const void* sin, const void* cos, const int* cache_seqlens,
+                              const int* block_table, int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                              int page_size, int pages_per_seq, int past_const, float softmax_scale, int rope_style, int sincos_size,
+                              int nsplit, void* scratch, long long scratch_bytes, void* counters, int n_counters,
+                              const void* out_invperm, void* stream);
 /* RoPE(q, k_new) in place + Q4 pack of the rotated k_new and of v_new into the cache's codes / scales at device-side positions:
    ONE launch for what a decode step over a Q4 cache otherwise does with exl2_rope_kv_append (into the fp16 staging pages) +
    exl2_fp16_to_q_kv (paged, wbits 4; ext_cache.cpp:80-173 / cache.cu:143-195) -- same fp16 arithmetic, bit-identical codes and

@@ -301,17 +301,35 @@ def test_overlapped_chain_equals_serial_chain(be, monkeypatch, recipe, batch):
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("hd,launches", [(64, "1"), (128, "1"), (128, "2"), (128, "4")])
 @pytest.mark.parametrize("recipe,batch", [("4.0bpw", 1), ("2.5bpw", 2)])
-def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch):
+def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch, hd, launches):
     """Q4 KV cache (configs[3]) on the chained route: q|k|v from the chain, RoPE + quantised append, attention straight from
     the codes with the output in o_proj's packed order (attn_q4.hip out_invperm), o / gate|up / down chained -- and the same
     steps on the module-by-module route.  Checker: OracleModel.forward(q4_cache=True), the reference's ExLlamaV2Cache_Q4
     semantics (cache.py:472-556: earlier tokens read back dequantized, the step's own K/V in fp16, touched blocks quantized
     after attention) -- BOTH routes at the model tolerance step by step, tokens where the oracle is confident, and the codes
     each route wrote against the oracle's codes."""
-    cfg = tiny_cfg(num_attention_heads=8, num_key_value_heads=8, head_dim=64, hidden_size=512, intermediate_size=512,
+    # head_dim 128: the decode step's attention side is ONE launch (csrc/attn_q4.hip FUSED form; EXL2_Q4_LAUNCHES=2: RoPE + pack, then
+    # attention; =4: the round-4 sequence) -- head_dim 64 is outside the one / two-launch forms and takes the four-launch sequence
+    cfg = tiny_cfg(num_attention_heads=512 // hd, num_key_value_heads=512 // hd, head_dim=hd, hidden_size=512, intermediate_size=512,
                    num_hidden_layers=2)
     steps = 6
+    monkeypatch.setenv("EXL2_Q4_LAUNCHES", launches)
+    taken = {"one": 0, "two": 0}
+    one_launch, two_launch = be.ext.attn_q4_decode_fused, be.ext.rope_quant_append_q4
+
+    def spy_one(*a, **k):
+        ok = one_launch(*a, **k)
+        taken["one"] += int(ok)
+        return ok
+
+    def spy_two(*a, **k):
+        ok = two_launch(*a, **k)
+        taken["two"] += int(ok)
+        return ok
+    monkeypatch.setattr(be.ext, "attn_q4_decode_fused", spy_one)
+    monkeypatch.setattr(be.ext, "rope_quant_append_q4", spy_two)
     for chain in ("1", "0"):
         monkeypatch.setenv("EXL2_CHAIN", chain)
         ck = synth_checkpoint(cfg, be.device, recipe=recipe, seed=16)
@@ -349,6 +367,7 @@ def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch):
         n_chain = sum(be.ext.chain_route_counts())
         assert (n_chain > 0) == (chain == "1")                      # chained launches ran / did not run
         dec.free(); model.unload()
+    assert (taken["one"] > 0) == (hd == 128 and launches == "1") and (taken["two"] > 0) == (hd == 128 and launches == "2"), taken
 
 
 def test_row_groups_taken_by_different_kernels(be, monkeypatch):

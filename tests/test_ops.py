@@ -607,6 +607,68 @@ def test_rope_quant_append_q4(be, neox, paged):
     assert not be.ext.rope_quant_append_q4(q64, k64, k64, c64, s64, c64, s64, be.t(sin64), be.t(cos64), 3, None, None, 2)
 
 
+@pytest.mark.parametrize("nh,kvh,s,paged,neox", [(8, 2, 1, True, True), (8, 4, 3, True, False), (16, 2, 2, False, True), (4, 4, 1, False, True)])
+def test_attention_q4_decode_step_in_one_launch(be, nh, kvh, s, paged, neox):
+    """exl2_attn_q4_decode_fused: RoPE + Q4 pack of the step's rows + attention over codes and the step's own fp16 rows + split merge in
+    ONE launch, against the two launches it replaces (rope_quant_append_q4, itself checked against the oracle above, + paged_attn_q4 with
+    tickets): attention output, codes and scales bit-identical; q and k_new are left unrotated; tickets left at zero.  Sequences of 1
+    and of many splits in one call."""
+    rng = np.random.default_rng(53 + nh + s)
+    hd, ps, b = 128, 256, 3
+    past = np.array([700, 3, 255], dtype=np.int32)
+    pages_per_seq = 4
+    T = ps * pages_per_seq
+    table = rng.permutation(b * pages_per_seq).astype(np.int32).reshape(b, pages_per_seq)
+    shape = (b * pages_per_seq, ps) if paged else (b, T)
+    kf = rng.standard_normal(shape + (kvh, hd)).astype(F16); vf = rng.standard_normal(shape + (kvh, hd)).astype(F16)
+    kq0, ks0 = OM.q4_pack(kf.reshape(-1)); vq0, vs0 = OM.q4_pack(vf.reshape(-1))
+    mkc = lambda x: be.t(x.reshape(shape + (kvh, hd // 2)).copy())
+    mks = lambda x: be.t(x.reshape(shape + (kvh, hd // 32)).copy())
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    kn = rng.standard_normal((b, s, kvh, hd)).astype(F16); vn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    sin, cos = OM.rope_tables(2048, hd, neox=neox)
+    style = 2 if neox else 1
+    scratch = torch.zeros((be.ext.paged_attn_scratch_bytes(b * s * nh, hd, 16) // 4 + 1,), dtype=torch.float32, device=be.device)
+    counters = torch.zeros((256,), dtype=torch.int32, device=be.device)
+    sl, bt = be.t(past), (be.t(table) if paged else None)
+    for nsplit in (1, 4):
+        # two launches
+        c2 = [mkc(kq0), mks(ks0), mkc(vq0), mks(vs0)]
+        q2, k2 = be.t(q), be.t(kn)
+        assert be.ext.rope_quant_append_q4(q2, k2, be.t(vn), *c2, be.t(sin), be.t(cos), 0, sl, bt, style)
+        out2 = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+        assert be.ext.paged_attn_q4(q2, *c2, out2, sl, bt, len_const=0, len_offset=s, nsplit=nsplit, scratch=scratch,
+                                    k_new=k2, v_new=be.t(vn), counters=counters)
+        # one launch
+        c1 = [mkc(kq0), mks(ks0), mkc(vq0), mks(vs0)]
+        q1, k1 = be.t(q), be.t(kn)
+        out1 = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+        assert be.ext.attn_q4_decode_fused(q1, k1, be.t(vn), *c1, out1, be.t(sin), be.t(cos), sl, bt, 0, style, scratch, counters,
+                                           nsplit=nsplit)
+        assert np.array_equal(be.n(q1).view(np.uint16), q.view(np.uint16)) and np.array_equal(be.n(k1).view(np.uint16), kn.view(np.uint16))
+        assert np.array_equal(be.n(out1).view(np.uint16), be.n(out2).view(np.uint16)), nsplit
+        for x1, x2 in zip(c1, c2):
+            assert np.array_equal(be.n(x1).view(np.uint8), be.n(x2).view(np.uint8))
+        assert int(be.n(counters).astype(np.int64).sum()) == 0
+    # the oracle, end to end: attention over the unpacked old keys + the rotated new rows
+    k_un = OM.q4_unpack(kq0, ks0).reshape(shape + (kvh, hd)); v_un = OM.q4_unpack(vq0, vs0).reshape(shape + (kvh, hd))
+    q_rot = OM.rope_(q, sin, cos, past, neox=neox); k_rot = OM.rope_(kn, sin, cos, past, neox=neox)
+    got = be.n(out1)
+    for i in range(b):
+        if paged:
+            ko = np.concatenate([k_un[table[i, pg]] for pg in range(pages_per_seq)])[:past[i]]
+            vo = np.concatenate([v_un[table[i, pg]] for pg in range(pages_per_seq)])[:past[i]]
+        else:
+            ko, vo = k_un[i, :past[i]], v_un[i, :past[i]]
+        want = OM.attention(q_rot[i:i + 1], np.concatenate([ko, k_rot[i]])[None], np.concatenate([vo, vn[i]])[None])[0]
+        err = np.abs(got[i].astype(np.float32) - want.astype(np.float32))
+        assert np.all(err <= _attn_tol(want) + 2e-3), (i, float(err.max()))
+    # shapes it does not cover are declined
+    assert not be.ext.attn_q4_decode_fused(be.t(q[..., :64].copy()), be.t(kn[..., :64].copy()), be.t(vn[..., :64].copy()),
+                                           *[x[..., :x.shape[-1] // 2].contiguous() for x in c1], torch.zeros((b, s, nh, 64), dtype=torch.float16, device=be.device),
+                                           be.t(sin[:, :64].copy()), be.t(cos[:, :64].copy()), sl, bt, 0, style, scratch, counters)
+
+
 def test_decode_utilities(be):
     rng = np.random.default_rng(8)
     table = rng.standard_normal((50, 64)).astype(F16)
