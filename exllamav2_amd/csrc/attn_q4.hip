@@ -17,6 +17,7 @@
 #include "attn_merge.h"
 #include "cache_q_pack.h"
 #include <string.h>
+#include <stdlib.h>
 
 #define AQ_WAVES 4
 #define AQ_UNROLL 4
@@ -34,6 +35,7 @@ struct AttnQ4Args
     // FUSED form (template parameter; head_dim 128): q and k_new arrive UNROTATED -- the launch applies RoPE to them on the way in
     // (positions total - s + j) and packs the rotated k_new and v_new into the codes: the whole decode step in one launch
     const f16* sin; const f16* cos; int rope, neox;
+    int pack_first;               // A/B switch (EXL2_Q4_PACK_FIRST=1): the step's rows are packed by split 0 in front of its attention (first form)
     u32* counters;                // nullable: [b, KVH, row blocks] zeroed tickets -- the last split of a row block to finish merges (no combine launch)
     const u16* out_invperm;       // nullable: feature n of a token row is stored at out[row, out_invperm[n]] (the consumer's packed order)
     int b, s, H, KVH;
@@ -111,17 +113,14 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
     const int total = (a.cache_seqlens ? a.cache_seqlens[b] : a.len_const) + a.len_offset;
     // the grid is fixed (HIP graph) but the sequence length is not: use as many splits as the length deserves
     const int eff = q4_eff_splits(total, a.nsplit);
-    if (split >= eff) return;
-    int kps = (total + eff - 1) / eff;
-    kps = (kps + 15) & ~15;
-    const int k_start = split * kps;
-    const int k_end = min(total, k_start + kps);
-
     if constexpr (FUSED)
     {
         // ---- the step's own rows into the cache: one workgroup per (sequence, kv head), one wave per row (k rotated first).  Nobody
-        // in this launch reads what is written here: the codes serve keys < total - s, the step's own keys are attended in fp16
-        if (split == 0 && rblk == 0)
+        // in this launch reads what is written here: the codes serve keys < total - s, the step's own keys are attended in fp16.
+        // The grid is sized for long sequences (HIP graph), so unless the sequence uses every split there is a workgroup with
+        // nothing to attend over -- the first idle split packs, beside the attention instead of in front of it; else split 0.
+        const int pack_split = (eff < a.nsplit && !a.pack_first) ? eff : 0;
+        if (split == pack_split && rblk == 0)
         {
             for (int task = wv; task < 2 * a.s; task += AQ_WAVES)
             {
@@ -144,6 +143,11 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
             }
         }
     }
+    if (split >= eff) return;
+    int kps = (total + eff - 1) / eff;
+    kps = (kps + 15) & ~15;
+    const int k_start = split * kps;
+    const int k_end = min(total, k_start + kps);
 
     // ---- block-table entries of this split and the raw query rows into LDS ------------------------------------------------
     float* qh_lds = (float*)smem;                                       // [RB][HDIM] rotated rows
@@ -611,6 +615,7 @@ static int paged_attn_q4_impl(const void* q, const void* k_codes, const void* k_
     EXL2_REQUIRE(!block_table || a.page_shift >= 0, "paged_attn_q4: page_size %d must be a power of two", page_size);
     a.len_const = len_const; a.len_offset = len_offset; a.causal = causal; a.scale = softmax_scale;
     if (fused) { a.sin = (const f16*)sin; a.cos = (const f16*)cos; a.rope = rope_style != 0; a.neox = rope_style == 2; }      // ROPE_STYLE_* q_attn.cuh:13-15
+    if (fused) { const char* e = getenv("EXL2_Q4_PACK_FIRST"); a.pack_first = (e && atoi(e)) ? 1 : 0; }
     const int rb = R >= 4 ? 4 : (R >= 2 ? 2 : 1);
     const int rblocks = (R + rb - 1) / rb;
     if (nsplit <= 0)
