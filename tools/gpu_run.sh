@@ -6,7 +6,7 @@
 # STAGES (any subset, in this order):
 #   smoke      __graft_entry__.smoke()
 #   tests      pytest -m gpu            (TESTS="tests/test_x.py -k expr" narrows it; default: all of tests/)
-#   bench      bench.py with default flags + with the driver's flags (--gpus 1 --steps 20 --warmup 5)
+#   bench      bench.py with default flags + with the driver's flags (--gpus 1 --steps 20 --warmup 5); bench_default / bench_driver: one of them
 #   stats      rocprofv3 --kernel-trace --stats of the headline decode loop  -> ${TAG}_kernel_stats.csv
 #   pmc        rocprofv3 --pmc FETCH_SIZE (own pass, kernel-trace only) over the headline loop, graph replay first and eager
 #              launches if that does not finish -> ${TAG}_pmc_summary.json
@@ -28,8 +28,10 @@ if has tests; then
   echo "== pytest -m gpu ${TESTS:-tests}"
   timeout -k 10 ${TESTS_TIMEOUT:-1200} python -m pytest ${TESTS:-tests} -m gpu -q --timeout 600 -x > $R/${T}_pytest_gpu.log 2>&1; echo "rc=$?"; tail -${TESTS_TAIL:-4} $R/${T}_pytest_gpu.log
 fi
-if has bench; then
+if has bench || has bench_default; then
   echo "== bench (default flags)"; timeout -k 10 900 python bench.py > $R/${T}_bench.json 2> $R/${T}_bench.err; echo "rc=$?"; cut -c1-1800 $R/${T}_bench.json; tail -3 $R/${T}_bench.err
+fi
+if has bench || has bench_driver; then
   echo "== bench (the driver's flags)"; timeout -k 10 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/${T}_bench_driver_flags.json 2>/dev/null; cut -c1-400 $R/${T}_bench_driver_flags.json
 fi
 if has stats; then
