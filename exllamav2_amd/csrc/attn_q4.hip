@@ -616,7 +616,16 @@ static int paged_attn_q4_impl(const void* q, const void* k_codes, const void* k_
     a.len_const = len_const; a.len_offset = len_offset; a.causal = causal; a.scale = softmax_scale;
     if (fused) { a.sin = (const f16*)sin; a.cos = (const f16*)cos; a.rope = rope_style != 0; a.neox = rope_style == 2; }      // ROPE_STYLE_* q_attn.cuh:13-15
     if (fused) { const char* e = getenv("EXL2_Q4_PACK_FIRST"); a.pack_first = (e && atoi(e)) ? 1 : 0; }
-    const int rb = R >= 4 ? 4 : (R >= 2 ? 2 : 1);
+    // Query rows per workgroup.  Four rows share one pass over the keys -- but a workgroup's own dependent chain (rotate the rows,
+    // fill registers, merge 32 streams per row, rotate back) grows with its rows, and up to a few thousand keys that chain is the
+    // launch: the 70B shape (8 rows per kv head) measures 91.1 / 92.8 / 94.2 tok/s at 4 / 2 / 1 rows per workgroup with an empty
+    // cache and 87.5 / 88.6 / 89.3 with 1920 tokens cached (profiles/r05y_ab_q4_rb*.txt).  The length is device-side (HIP graph),
+    // the CAPACITY of the sequence is not: one row per workgroup while the sequence cannot exceed 4096 keys, four beyond
+    // (unmeasured there: eight passes over the keys against two).  EXL2_Q4_RB=1|2|4 overrides.
+    const long long capacity = block_table ? (long long)pages_per_seq * page_size : (long long)page_size;
+    int rb = R >= 4 ? 4 : (R >= 2 ? 2 : 1);
+    if (capacity <= 4096) rb = 1;
+    if (const char* e = getenv("EXL2_Q4_RB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) rb = v < R ? v : (R >= 4 ? 4 : (R >= 2 ? 2 : 1)); }
     const int rblocks = (R + rb - 1) / rb;
     if (nsplit <= 0)
     {
@@ -663,7 +672,7 @@ int exl2_paged_attn_q4(const void* q, const void* k_codes, const void* k_scales,
                               nsplit, scratch, scratch_bytes, out_invperm, nullptr, 0, stream);
 }
 
-// The same with `counters`: n_counters >= batch * num_kv_heads * ceil(q_len * (H / KVH) / 4) u32 tickets, ZERO before the first
+// The same with `counters`: n_counters >= batch * q_len * num_heads (one per query row always suffices; fewer than the launch needs: the combine launch runs instead) u32 tickets, ZERO before the first
 // call (every launch leaves them zero): the split partials are merged by the last split to finish, inside the launch -- one launch
 // instead of two.  (exl2_attn_decode_fused's counters serve: same indexing, never used by both at once on a stream.)
 int exl2_paged_attn_q4_merged(const void* q, const void* k_codes, const void* k_scales, const void* v_codes, const void* v_scales,

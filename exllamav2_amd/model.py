@@ -48,7 +48,7 @@ class ExLlamaV2:
         self.temp_attn = torch.empty((r, cfg.num_attention_heads * cfg.head_dim), dtype=torch.float16, device=dev)
         sb = self.ext.paged_attn_scratch_bytes(min(r, 64) * cfg.num_attention_heads, cfg.head_dim, 64)
         self.attn_scratch = torch.empty((sb // 4 + 16,), dtype=torch.float32, device=dev)
-        self.attn_counters = torch.zeros((4096,), dtype=torch.int32, device=dev)     # split hand-off tickets (attn.hip)
+        self.attn_counters = torch.zeros((16384,), dtype=torch.int32, device=dev)     # split hand-off tickets (attn.hip)
         self._dq = None                                   # reconstruct target of ExLlamaV2Linear.forward(force_recons=True)
         self.sin, self.cos = rope_tables(cfg, dev)
         self.modules = []

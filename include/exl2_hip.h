@@ -178,7 +178,7 @@ int exl2_paged_attn_q4(const void* q, const void* k_codes, const void* k_scales,
                        float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
                        const void* out_invperm, void* stream);
 /* (out_invperm: nullable, as in exl2_attn_decode_fused -- the chained decode step over a Q4 cache) */
-/* The same with tickets: counters = zeroed u32[n_counters >= batch * num_kv_heads * ceil(q_len * (H / KVH) / 4)], left zeroed (the
+/* The same with tickets: counters = zeroed u32[n_counters >= batch * q_len * num_heads (one per query row always suffices; fewer than the launch needs: the combine launch runs instead)], left zeroed (the
    buffer of exl2_attn_decode_fused serves).  The split partials are merged by the last split to finish, inside the launch: one
    launch instead of attention + combine. */
 int exl2_paged_attn_q4_merged(const void* q, const void* k_codes, const void* k_scales, const void* v_codes, const void* v_scales,
@@ -191,7 +191,7 @@ int exl2_paged_attn_q4_merged(const void* q, const void* k_codes, const void* k_
    Q4 pack of the rotated k_new and of v_new at positions past + j (past = cache_seqlens[b], or past_const without cache_seqlens),
    attention over the codes (keys < past) and the step's own rows in fp16, split merge by ticket.  Replaces exl2_rope_kv_append +
    exl2_fp16_to_q_kv + exl2_paged_attn_q4 of a decode step (cache.py:517-556 + attn.py:602-613 over ExLlamaV2Cache_Q4).  counters:
-   zeroed u32[n_counters >= batch * num_kv_heads * ceil(q_len * (H / KVH) / 4)], left zeroed.  Returns 1 without launching for
+   zeroed u32[n_counters >= batch * q_len * num_heads (one per query row always suffices; fewer than the launch needs: the combine launch runs instead)], left zeroed.  Returns 1 without launching for
    shapes it does not cover (head_dim != 128, partial rotary): use exl2_rope_quant_append_q4 + exl2_paged_attn_q4_merged. */
 int exl2_attn_q4_decode_fused(const void* q, const void* k_new, const void* v_new, void* k_codes, void* k_scales, void* v_codes,
                               void* v_scales, void* out, const void* sin, const void* cos, const int* cache_seqlens,

@@ -408,10 +408,11 @@ def test_attention_from_q4_cache_with_fp16_new_tokens(be, hd, nh, kvh, s):
 
 
 @pytest.mark.parametrize("hd,nh,kvh,s", [(128, 8, 2, 1), (128, 16, 2, 1), (64, 4, 4, 3)])
-def test_attention_from_q4_cache_merges_its_splits_in_the_launch(be, hd, nh, kvh, s):
+def test_attention_from_q4_cache_merges_its_splits_in_the_launch(be, hd, nh, kvh, s, monkeypatch):
     """exl2_paged_attn_q4_merged: with tickets the last split of a (sequence, kv head, row block) to finish merges the partials
     inside the launch -- bit-identical to the two-launch form (same merge function), tickets left at zero, also when a sequence is
     short enough for ONE split while the grid was sized for many (HIP graph: the grid is fixed, the lengths are not)."""
+    monkeypatch.setenv("EXL2_Q4_RB", "4")                              # (several rows per workgroup and ticket: the long-capacity form)
     rng = np.random.default_rng(47)
     b, T = 3, 2048
     total = np.array([1500, 40, 700], dtype=np.int32)
@@ -607,12 +608,17 @@ def test_rope_quant_append_q4(be, neox, paged):
     assert not be.ext.rope_quant_append_q4(q64, k64, k64, c64, s64, c64, s64, be.t(sin64), be.t(cos64), 3, None, None, 2)
 
 
+@pytest.mark.parametrize("rows_per_wg", ["", "4", "2"])
 @pytest.mark.parametrize("nh,kvh,s,paged,neox", [(8, 2, 1, True, True), (8, 4, 3, True, False), (16, 2, 2, False, True), (4, 4, 1, False, True)])
-def test_attention_q4_decode_step_in_one_launch(be, nh, kvh, s, paged, neox):
+def test_attention_q4_decode_step_in_one_launch(be, nh, kvh, s, paged, neox, rows_per_wg, monkeypatch):
     """exl2_attn_q4_decode_fused: RoPE + Q4 pack of the step's rows + attention over codes and the step's own fp16 rows + split merge in
     ONE launch, against the two launches it replaces (rope_quant_append_q4, itself checked against the oracle above, + paged_attn_q4 with
     tickets): attention output, codes and scales bit-identical; q and k_new are left unrotated; tickets left at zero.  Sequences of 1
     and of many splits in one call."""
+    # (query rows per workgroup: by default ONE while the sequence's capacity is <= 4096 keys -- every table here --, else up to four;
+    # EXL2_Q4_RB forces the other instantiations)
+    if rows_per_wg:
+        monkeypatch.setenv("EXL2_Q4_RB", rows_per_wg)
     rng = np.random.default_rng(53 + nh + s)
     hd, ps, b = 128, 256, 3
     past = np.array([700, 3, 255], dtype=np.int32)
