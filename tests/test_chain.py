@@ -301,8 +301,8 @@ def test_overlapped_chain_equals_serial_chain(be, monkeypatch, recipe, batch):
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("hd,launches", [(64, "1"), (128, "1"), (128, "2"), (128, "4")])
-@pytest.mark.parametrize("recipe,batch", [("4.0bpw", 1), ("2.5bpw", 2)])
+@pytest.mark.parametrize("recipe,batch,hd,launches", [("4.0bpw", 1, 64, "1"), ("2.5bpw", 2, 64, "1"), ("4.0bpw", 1, 128, "1"),
+                                                      ("2.5bpw", 2, 128, "1"), ("4.0bpw", 1, 128, "2"), ("2.5bpw", 2, 128, "4")])
 def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch, hd, launches):
     """Q4 KV cache (configs[3]) on the chained route: q|k|v from the chain, RoPE + quantised append, attention straight from
     the codes with the output in o_proj's packed order (attn_q4.hip out_invperm), o / gate|up / down chained -- and the same
