@@ -485,6 +485,42 @@ def test_gemm_chain_shares_of_several_register_loads(be, rows, spec_name, capfd,
     be.ext.free_q_matrix(h)
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_gemm_chain_random_bit_mixes_and_depths(be, seed):
+    """Seeded random matrices through exl2_gemm_half_q_half_chain: K from 2048 to ~20 k, one to three bit-width sections in the
+    quantizer's order (descending), group sizes 32 / 64 / 128, one to four rows -- so that the host plan meets shares of one, two and
+    three register loads on 8 and on 16 waves, partial items at section ends, uniform and per-chunk scales.  Checker: the oracle's
+    reconstruct-then-matmul on rmsnorm(x).  What the plan does not cover must raise (never a silent wrong launch)."""
+    if not be.is_emu:
+        pytest.skip("seeded sweep written after the round's last GPU call: emulator only (the GPU suite holds the fixed shapes of this path)")
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([2048, 4096, 8192, 11008, 14336, 18432])) + 32 * int(rng.integers(0, 3))
+    widths = sorted(rng.choice([8, 6, 5, 4, 3, 2], size=int(rng.integers(1, 4)), replace=False).tolist(), reverse=True)
+    cuts = sorted(rng.choice(np.arange(1, k // 32), size=len(widths) - 1, replace=False).tolist()) if len(widths) > 1 else []
+    edges = [0] + [32 * c for c in cuts] + [k]
+    spec = [(int(b), int(rng.choice([32, 64, 128])), edges[i + 1] - edges[i]) for i, b in enumerate(widths)]
+    rows = int(rng.integers(1, 5))
+    n = 32
+    t, ref, w, h = _mk(be, k, n, spec, 300 + seed)
+    x = (rng.standard_normal((rows, k)) * 2).astype(np.float16)
+    nw = (1 + 0.1 * rng.standard_normal(k)).astype(np.float16)
+    perm = np.argsort(t["q_invperm"]).astype(np.int64)
+    xp = (x.astype(np.float32) * nw.astype(np.float32)).astype(np.float16)[:, perm]
+    ss = (x.astype(np.float32) ** 2).sum(-1, keepdims=True).astype(np.float32)
+    c = torch.zeros((rows, n), dtype=torch.float16, device=be.device)
+    try:
+        be.ext.gemm_half_q_half_chain(be.t(xp), be.t(ss), 1, 1e-5, h, c, rows)
+    except RuntimeError as e:
+        assert "not covered" in str(e), (spec, rows, str(e))
+        be.ext.free_q_matrix(h)
+        pytest.skip(f"plan declined (loudly): K={k} {spec} rows={rows}")
+    want = OX.gemm_ref(OM.rms_norm(x, nw, 1e-5), ref, exact=True)
+    slack = 2 * max(1.0, (k / 1024.0) ** 0.5)
+    bad = np.abs(be.n(c).astype(np.float64) - want) > slack * half_tol(want, k)
+    assert not bad.any(), (k, spec, rows, int(bad.sum()))
+    be.ext.free_q_matrix(h)
+
+
 def test_qkv_launch_takes_two_register_loads_on_eight_waves(be, capfd, monkeypatch):
     """hidden 8192 at 2.5 bpw (configs[3]'s q|k|v): v_proj's 3 / 4-bit items do not fit ONE register load of 8 waves (capacity 60 of
     64 items), and the launch's three matrices share one geometry.  Round 4 took 16 waves for all three -- a 16-wave workgroup is alone

@@ -675,6 +675,69 @@ def test_attention_q4_decode_step_in_one_launch(be, nh, kvh, s, paged, neox, row
                                            be.t(sin[:, :64].copy()), be.t(cos[:, :64].copy()), sl, bt, 0, style, scratch, counters)
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_attention_q4_decode_step_random_shapes(be, seed, monkeypatch):
+    """Seeded random shapes for the one-launch Q4 decode step (exl2_attn_q4_decode_fused): batch 1-4, 1-8 new tokens, 1-8 query heads per
+    kv head, paged or contiguous, lengths from empty to several splits, either RoPE style, every row blocking (1 / 2 / 4 query rows per
+    workgroup), split counts 1-8.  Checkers: the two launches it replaces (bit-identical output, codes, scales) and the oracle's
+    attention over the unpacked old keys + the rotated new rows."""
+    if not be.is_emu:
+        pytest.skip("seeded sweep written after the round's last GPU call: emulator only (the GPU suite holds the fixed shapes of this path)")
+    rng = np.random.default_rng(7000 + seed)
+    hd, ps = 128, 256
+    b = int(rng.integers(1, 5)); s = int(rng.integers(1, 9))
+    kvh = int(rng.choice([1, 2, 4])); g = int(rng.choice([1, 2, 4, 8])); nh = kvh * g
+    if s * g > 64:
+        g = max(1, 64 // s // 1); g = 1 << (g.bit_length() - 1); nh = kvh * g
+    paged = bool(rng.integers(0, 2)); neox = bool(rng.integers(0, 2))
+    pages_per_seq = int(rng.integers(2, 6))
+    T = ps * pages_per_seq
+    past = np.array([int(rng.choice([0, 1, 30, 255, 256, 300, T - s])) for _ in range(b)], dtype=np.int32)
+    past = np.minimum(past, T - s).astype(np.int32)
+    monkeypatch.setenv("EXL2_Q4_RB", str(int(rng.choice([1, 2, 4]))))
+    nsplit = int(rng.choice([1, 2, 3, 8]))
+    table = rng.permutation(b * pages_per_seq).astype(np.int32).reshape(b, pages_per_seq)
+    shape = (b * pages_per_seq, ps) if paged else (b, T)
+    kf = rng.standard_normal(shape + (kvh, hd)).astype(F16); vf = rng.standard_normal(shape + (kvh, hd)).astype(F16)
+    kq0, ks0 = OM.q4_pack(kf.reshape(-1)); vq0, vs0 = OM.q4_pack(vf.reshape(-1))
+    mkc = lambda x: be.t(x.reshape(shape + (kvh, hd // 2)).copy())
+    mks = lambda x: be.t(x.reshape(shape + (kvh, hd // 32)).copy())
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    kn = rng.standard_normal((b, s, kvh, hd)).astype(F16); vn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    sin, cos = OM.rope_tables(T + 8, hd, neox=neox)
+    style = 2 if neox else 1
+    scratch = torch.zeros((be.ext.paged_attn_scratch_bytes(b * s * nh, hd, 16) // 4 + 1,), dtype=torch.float32, device=be.device)
+    counters = torch.zeros((b * s * nh + 8,), dtype=torch.int32, device=be.device)
+    sl, bt = be.t(past), (be.t(table) if paged else None)
+    c2 = [mkc(kq0), mks(ks0), mkc(vq0), mks(vs0)]
+    q2, k2 = be.t(q), be.t(kn)
+    assert be.ext.rope_quant_append_q4(q2, k2, be.t(vn), *c2, be.t(sin), be.t(cos), 0, sl, bt, style)
+    out2 = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+    assert be.ext.paged_attn_q4(q2, *c2, out2, sl, bt, len_const=0, len_offset=s, nsplit=nsplit, scratch=scratch,
+                                k_new=k2, v_new=be.t(vn), counters=counters)
+    c1 = [mkc(kq0), mks(ks0), mkc(vq0), mks(vs0)]
+    out1 = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+    assert be.ext.attn_q4_decode_fused(be.t(q), be.t(kn), be.t(vn), *c1, out1, be.t(sin), be.t(cos), sl, bt, 0, style, scratch, counters,
+                                       nsplit=nsplit)
+    what = (b, s, nh, kvh, paged, neox, past.tolist(), nsplit)
+    assert np.array_equal(be.n(out1).view(np.uint16), be.n(out2).view(np.uint16)), what
+    for x1, x2 in zip(c1, c2):
+        assert np.array_equal(be.n(x1).view(np.uint8), be.n(x2).view(np.uint8)), what
+    assert int(be.n(counters).astype(np.int64).sum()) == 0
+    k_un = OM.q4_unpack(kq0, ks0).reshape(shape + (kvh, hd)); v_un = OM.q4_unpack(vq0, vs0).reshape(shape + (kvh, hd))
+    q_rot = OM.rope_(q, sin, cos, past, neox=neox); k_rot = OM.rope_(kn, sin, cos, past, neox=neox)
+    got = be.n(out1)
+    for i in range(b):
+        if paged:
+            ko = np.concatenate([k_un[table[i, pg]] for pg in range(pages_per_seq)])[:past[i]]
+            vo = np.concatenate([v_un[table[i, pg]] for pg in range(pages_per_seq)])[:past[i]]
+        else:
+            ko, vo = k_un[i, :past[i]], v_un[i, :past[i]]
+        want = OM.attention(q_rot[i:i + 1], np.concatenate([ko, k_rot[i]])[None], np.concatenate([vo, vn[i]])[None])[0]
+        err = np.abs(got[i].astype(np.float32) - want.astype(np.float32))
+        assert np.all(err <= _attn_tol(want) + 2e-3), (what, i, float(err.max()))
+
+
 def test_decode_utilities(be):
     rng = np.random.default_rng(8)
     table = rng.standard_normal((50, 64)).astype(F16)
