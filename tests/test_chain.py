@@ -5,6 +5,7 @@ What the chain replaces is a COMPOSITION of reference kernels (q_attn.cu:153-345
 rope / act_mul -> q_gemm -> residual): its results must equal the oracle's within the same fp16 tolerance as the
 unchained route (tests/test_model.py), step by step, for every bit-width mix, for GPTQ, for several rows.
 """
+import os
 import re
 
 import numpy as np
@@ -485,7 +486,7 @@ def test_gemm_chain_shares_of_several_register_loads(be, rows, spec_name, capfd,
     be.ext.free_q_matrix(h)
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "12")))))       # (more seeds: a longer hunt, by hand)
 def test_gemm_chain_random_bit_mixes_and_depths(be, seed):
     """Seeded random matrices through exl2_gemm_half_q_half_chain: K from 2048 to ~20 k, one to three bit-width sections in the
     quantizer's order (descending), group sizes 32 / 64 / 128, one to four rows -- so that the host plan meets shares of one, two and

@@ -1,4 +1,6 @@
 """RMSNorm, RoPE, act*mul, Q-cache codec, attention, RoPE+append, decode utilities -- against the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -675,7 +677,7 @@ def test_attention_q4_decode_step_in_one_launch(be, nh, kvh, s, paged, neox, row
                                            be.t(sin[:, :64].copy()), be.t(cos[:, :64].copy()), sl, bt, 0, style, scratch, counters)
 
 
-@pytest.mark.parametrize("seed", list(range(8)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "8")))))        # (more seeds: a longer hunt, by hand)
 def test_attention_q4_decode_step_random_shapes(be, seed, monkeypatch):
     """Seeded random shapes for the one-launch Q4 decode step (exl2_attn_q4_decode_fused): batch 1-4, 1-8 new tokens, 1-8 query heads per
     kv head, paged or contiguous, lengths from empty to several splits, either RoPE style, every row blocking (1 / 2 / 4 query rows per
