@@ -280,6 +280,52 @@ def test_attention_fused_decode_step(be, hd, nh, kvh, s, rope):
         assert int(be.n(counters).sum()) == 0
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "8")))))        # (more seeds: a longer hunt, by hand)
+def test_attention_fused_decode_step_random_shapes(be, seed, monkeypatch):
+    """Seeded random shapes for the one-launch FP16 decode step (attn_decode_fused): batch 1-4, 1-4 new tokens, 1-8 query heads per kv
+    head, head_dim 64 / 128, lengths from empty to several pages (page boundaries, the last slot of the table), split policy left to
+    the library or forced (EXL2_ATT_KPS / EXL2_ATT_NSPLIT_MAX are read per launch), NeoX RoPE or none.  Checker: the oracle's paged
+    attention with the append; the caches must hold exactly the rotated new rows afterwards."""
+    if not be.is_emu:
+        pytest.skip("seeded sweep written after the round's last GPU call: emulator only (the GPU suite holds the fixed shapes of this path)")
+    rng = np.random.default_rng(9000 + seed)
+    ps = 256
+    hd = int(rng.choice([64, 128])); b = int(rng.integers(1, 5)); s = int(rng.integers(1, 5))
+    kvh = int(rng.choice([1, 2, 4])); g = int(rng.choice([1, 2, 4, 8])); nh = kvh * g
+    rope = bool(rng.integers(0, 2))
+    pages_per_seq = int(rng.integers(1, 7))
+    T = ps * pages_per_seq
+    pages = b * pages_per_seq + 1
+    table = rng.permutation(pages)[:b * pages_per_seq].astype(np.int32).reshape(b, pages_per_seq)
+    seqlens = np.array([min(int(rng.choice([0, 1, 17, 255, 256, 257, 511, 700, 1290, T - s])), T - s) for _ in range(b)], dtype=np.int32)
+    if rng.integers(0, 2):
+        monkeypatch.setenv("EXL2_ATT_KPS", str(int(rng.choice([16, 64, 256]))))
+    if rng.integers(0, 2):
+        monkeypatch.setenv("EXL2_ATT_NSPLIT_MAX", str(int(rng.choice([1, 2, 5, 16]))))
+    sin, cos = OM.rope_tables(T + 8, hd, neox=True)
+    kc = (rng.standard_normal((pages, ps, kvh, hd)) * 0.5).astype(F16); vc = rng.standard_normal((pages, ps, kvh, hd)).astype(F16)
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    kn = (rng.standard_normal((b, s, kvh, hd)) * 0.5).astype(F16); vn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    q_r = OM.rope_(q, sin, cos, seqlens, neox=True) if rope else q
+    k_r = OM.rope_(kn, sin, cos, seqlens, neox=True) if rope else kn
+    kc_ref, vc_ref = kc.copy(), vc.copy()
+    want = OM.paged_attention(q_r, k_r, vn, kc_ref, vc_ref, seqlens, table)
+    scratch = torch.zeros((be.ext.paged_attn_scratch_bytes(b * s * nh, hd, 64) // 4 + 1,), dtype=torch.float32, device=be.device)
+    counters = torch.zeros((b * s * nh + 64,), dtype=torch.int32, device=be.device)
+    kct, vct = be.t(kc), be.t(vc)
+    out = torch.zeros((b, s, nh, hd), dtype=torch.float16, device=be.device)
+    what = (hd, b, s, nh, kvh, rope, seqlens.tolist(), pages_per_seq)
+    ok = be.ext.attn_decode_fused(be.t(q), be.t(kn), be.t(vn), kct, vct, out, be.t(sin), be.t(cos), be.t(seqlens), be.t(table),
+                                  0, 2 if rope else 0, scratch, counters)
+    if not ok:
+        pytest.skip(f"shape declined by the one-launch kernel (the caller takes the three-launch variant): {what}")
+    assert np.array_equal(be.n(kct).view(np.uint16), kc_ref.view(np.uint16)), what
+    assert np.array_equal(be.n(vct).view(np.uint16), vc_ref.view(np.uint16)), what
+    err = np.abs(be.n(out).astype(np.float32) - want.astype(np.float32))
+    assert np.all(err <= _attn_tol(want)), (what, float(err.max()))
+    assert int(be.n(counters).astype(np.int64).sum()) == 0
+
+
 @pytest.mark.parametrize("nh,kvh,ctx", [(8, 1, 5000), (4, 4, 3000), (8, 2, 1300)])
 def test_attention_fused_long_context_many_splits(be, nh, kvh, ctx):
     """Contexts long enough for the second slope of the split policy (few KV heads: 16 splits of 64 keys, then a split per 256 keys) and
