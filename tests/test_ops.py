@@ -219,6 +219,42 @@ def test_flash_prefill_paged(be):
     assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want))
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
+def test_flash_prefill_random_shapes(be, seed):
+    """Seeded random shapes for the MFMA flash-prefill kernel (round 5: two 16-row query blocks per wave, one page look-up per key
+    tile made two tiles ahead): 17-300 query rows, 0-600 cached tokens, GQA 1-8, head_dim 64 / 128, paged (lengths on the device,
+    ragged last query / key tiles, page boundaries inside a key tile's range) or contiguous.  Checker: the fp64 oracle."""
+    if not be.is_emu:
+        pytest.skip("seeded sweep written after the round's last GPU call: emulator only (the GPU suite holds the fixed shapes of this path)")
+    rng = np.random.default_rng(11000 + seed)
+    ps = 256
+    hd = int(rng.choice([64, 128])); b = int(rng.integers(1, 4)); s = int(rng.choice([17, 40, 64, 65, 128, 129, 200, 300]))
+    kvh = int(rng.choice([1, 2])); g = int(rng.choice([1, 2, 4, 8])); nh = kvh * g
+    paged = bool(rng.integers(0, 2))
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    out = torch.full((b, s, nh, hd), 77.0, dtype=torch.float16, device=be.device)
+    if paged:
+        seqlens = np.array([int(rng.choice([0, 1, 31, 200, 250, 256, 480, 600])) for _ in range(b)], dtype=np.int32)
+        pages_per_seq = int((seqlens.max() + s + ps - 1) // ps) + int(rng.integers(0, 2))
+        pages = b * pages_per_seq + 1
+        table = rng.permutation(pages)[:b * pages_per_seq].astype(np.int32).reshape(b, pages_per_seq)
+        kc = rng.standard_normal((pages, ps, kvh, hd)).astype(F16); vc = rng.standard_normal((pages, ps, kvh, hd)).astype(F16)
+        what = (hd, b, s, nh, kvh, "paged", seqlens.tolist(), pages_per_seq)
+        if not be.ext.flash_prefill(be.t(q), be.t(kc), be.t(vc), out, be.t(seqlens), be.t(table), len_const=0, len_offset=s):
+            pytest.skip(f"declined: {what}")
+        want = OM.paged_attention(q, None, None, kc, vc, seqlens + s, table)
+    else:
+        past = int(rng.choice([0, 1, 33, 200, 511]))
+        T = past + s + int(rng.integers(0, 40))
+        k = rng.standard_normal((b, T, kvh, hd)).astype(F16); v = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+        what = (hd, b, s, nh, kvh, "contiguous", past, T)
+        if not be.ext.flash_prefill(be.t(q), be.t(k), be.t(v), out, None, None, len_const=past, len_offset=s):
+            pytest.skip(f"declined: {what}")
+        want = OM.attention(q, k[:, :past + s], v[:, :past + s])
+    err = np.abs(be.n(out).astype(np.float32) - want.astype(np.float32))
+    assert np.all(err <= _attn_tol(want)), (what, float(err.max()))
+
+
 def test_attention_paged_with_append(be):
     """flash_attn_with_kvcache contract (attn.py:602-613): append new k/v at cache_seqlens through the block table,
     attend bottom-right causal."""
