@@ -3,6 +3,8 @@
 Parity method = the reference's own (tests/test_gemv.py:136-165): kernel vs reconstruct+matmul on identity and randn
 inputs, for every bit width, mixed sections, partial super-chunks, act-order on/off, GPTQ with and without g_idx.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -103,6 +105,44 @@ def test_prefill_vs_oracle(be, m):
     be.ext.gemm_half_q_half(be.t(a), h, c)
     want = OX.gemm_ref(a, ref, bias=t["bias"], exact=True)
     assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= half_tol(want, k))
+    be.ext.free_q_matrix(h)
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
+def test_gemm_random_rows_shapes_and_bit_mixes(be, seed, monkeypatch):
+    """Seeded random (rows, K, N, bit-width sections, group sizes, act-order, bias) through exl2_gemm_half_q_half: every row-count
+    route -- the decode kernels (<= 16 rows), the 17-128-row prefill kernel, the 256-column MFMA kernel with the weights decoded
+    inside the GEMM or once per call (forced at random: its natural threshold is beyond what the emulator runs in seconds) --
+    against the oracle's reconstruct-then-matmul; one-hot rows must return rows of reconstruct() bit for bit."""
+    if not be.is_emu:
+        pytest.skip("seeded sweep written after the round's last GPU call: emulator only (the GPU suite holds the fixed shapes of this path)")
+    rng = np.random.default_rng(13000 + seed)
+    k = 32 * int(rng.integers(4, 49))
+    n = 32 * int(rng.choice([1, 2, 3, 8, 9]))
+    widths = sorted(rng.choice([8, 6, 5, 4, 3, 2], size=int(rng.integers(1, 4)), replace=False).tolist(), reverse=True)
+    cuts = sorted(rng.choice(np.arange(1, k // 32), size=len(widths) - 1, replace=False).tolist()) if len(widths) > 1 else []
+    edges = [0] + [32 * c for c in cuts] + [k]
+    spec = [(int(b), int(rng.choice([32, 64, 128])), edges[i + 1] - edges[i]) for i, b in enumerate(widths)]
+    m = int(rng.choice([1, 3, 4, 5, 11, 16, 17, 40, 128, 129, 200, 300, 520]))
+    if m >= 129 and rng.integers(0, 2):
+        monkeypatch.setenv("EXL2_PREFILL_MT", str(int(rng.choice([4, 8]))))
+        monkeypatch.setenv("EXL2_PREFILL_WPRE_MIN_ROWS", str(int(rng.integers(0, 2))))
+    bias = bool(rng.integers(0, 2))
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=400 + seed, act_order=bool(rng.integers(0, 2)), bias=bias)
+    a = rng.standard_normal((m, k)).astype(np.float16)
+    hot = rng.choice(m, size=min(m, 8), replace=False)
+    hot_k = rng.integers(0, k, size=len(hot))
+    if not bias:
+        a[hot] = 0
+        a[hot, hot_k] = 1.0
+    c = torch.zeros((m, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    got = be.n(c)
+    what = (m, k, n, spec, bias)
+    if not bias:
+        assert np.array_equal(got[hot].view(np.uint16), ref[hot_k].view(np.uint16)), what
+    want = OX.gemm_ref(a, ref, bias=t["bias"] if bias else None, exact=True)
+    assert np.all(np.abs(got.astype(np.float64) - want) <= half_tol(want, k)), what
     be.ext.free_q_matrix(h)
 
 
