@@ -108,14 +108,13 @@ def test_prefill_vs_oracle(be, m):
     be.ext.free_q_matrix(h)
 
 
+@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
 def test_gemm_random_rows_shapes_and_bit_mixes(be, seed, monkeypatch):
     """Seeded random (rows, K, N, bit-width sections, group sizes, act-order, bias) through exl2_gemm_half_q_half: every row-count
     route -- the decode kernels (<= 16 rows), the 17-128-row prefill kernel, the 256-column MFMA kernel with the weights decoded
     inside the GEMM or once per call (forced at random: its natural threshold is beyond what the emulator runs in seconds) --
     against the oracle's reconstruct-then-matmul; one-hot rows must return rows of reconstruct() bit for bit."""
-    if not be.is_emu:
-        pytest.skip("seeded sweep written after the round's last GPU call: emulator only (the GPU suite holds the fixed shapes of this path)")
     rng = np.random.default_rng(13000 + seed)
     k = 32 * int(rng.integers(4, 49))
     n = 32 * int(rng.choice([1, 2, 3, 8, 9]))
