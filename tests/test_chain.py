@@ -504,6 +504,7 @@ def test_gemm_chain_shares_of_several_register_loads(be, rows, spec_name, capfd,
     xp = (x.astype(np.float32) * nw.astype(np.float32)).astype(np.float16)[:, perm]
     ss = (x.astype(np.float32) ** 2).sum(-1, keepdims=True).astype(np.float32)
     c = torch.zeros((rows, n), dtype=torch.float16, device=be.device)
+    be.ext.chain_route_counts(reset=True)                              # (process-wide: not the launches of whatever ran before)
     monkeypatch.setenv("EXL2_LEAN_TRACE", "1")
     be.ext.gemm_half_q_half_chain(be.t(xp), be.t(ss), 1, 1e-5, h, c, rows)
     monkeypatch.delenv("EXL2_LEAN_TRACE")
@@ -584,6 +585,7 @@ def test_lean_kernel_identity_rows_equal_reconstruct(be, rows):
     k, n = 1024, 96
     spec = [(5, 128, 128), (4, 128, 512), (4, 32, 256), (4, 64, 128)]
     t, ref, w, h = _mk(be, k, n, spec, 77)
+    be.ext.chain_route_counts(reset=True)                              # (a process-wide counter: other tests' launches are not this test's)
     perm = np.argsort(t["q_invperm"]).astype(np.int64)                 # packed row i holds input feature perm[i]
     eye = np.eye(k, dtype=np.float16)
     ss = np.full((rows, 1), float(k), dtype=np.float32)
