@@ -141,9 +141,11 @@ def test_a_host_that_touches_the_residual_stream_is_not_served_a_stale_hand_off(
 
     # (a) an in-place torch operation between attention and MLP that CHANGES x: the version counter moves, the MLP must start
     #     from the new values.  Reference result: the same hook on the un-chained route.
+    #     (NOT a uniform scale: RMSNorm is scale-invariant, a stale hand-off of a uniformly scaled row normalises to the same values
+    #     and would go unnoticed -- every second feature is halved)
     def scale_in_place(li, where, x):
         if where == "attn->mlp" and li == 1:
-            x.mul_(0.5)
+            x[..., ::2].mul_(0.5)
         return x
     host.between = scale_in_place
     fast.stats(True)
@@ -385,7 +387,7 @@ def test_hosts_that_do_random_things_between_module_calls(be, seed):
             script[key] = str(rng.choice(acts))
         a = script[key]
         if a == "scale":
-            x.mul_(0.75)
+            x[..., ::2].mul_(0.5)                                  # (not uniform: RMSNorm would hide a stale hand-off of a uniform scale)
         elif a == "touch":
             x.add_(0)
         elif a == "clone":
@@ -409,6 +411,24 @@ def test_hosts_that_do_random_things_between_module_calls(be, seed):
     assert st["chained"] > 0, st
     for i, (a, b) in enumerate(zip(chained, plain)):
         err = np.abs(a.astype(np.float64) - b)
-        assert np.all(err <= 2 * (0.03 + np.abs(b) * 2.0 ** -8)), (i, float(err.max()), sorted(set(script.values())))
+        # (6 x the model tolerance: the two routes round to fp16 at different points, and over random models single tokens sit up to
+        # ~3 x apart for that reason alone -- seed 94 of this sweep, no hook involved: each route is within 0.5 x of the oracle that
+        # rounds where it rounds, tests/test_chain.py::test_chain_decode_random_models.  A stale hand-off is a 25 % error or another
+        # token's row: orders of magnitude beyond this)
+        assert np.all(err <= 6 * (0.03 + np.abs(b) * 2.0 ** -8)), (i, float(err.max()), sorted(set(script.values())))
+    # the threshold does see a stale hand-off: a write that moves neither the version counter nor calls note_write (against the
+    # binding's contract) is served the old hand-off on the chained route and not on the plain one
+    if seed == 0:
+        def sneaky(li, where, x):
+            if where == "attn->mlp" and li == 0 and host.past == 2:
+                x.data[..., ::2].mul_(0.5)
+            return x
+        host.between = sneaky
+        a = host.run(tokens)
+        fast.set_chain(False)
+        b = host.run(tokens)
+        fast.set_chain(True)
+        worst = max(float((np.abs(u.astype(np.float64) - v) / (0.03 + np.abs(v) * 2.0 ** -8)).max()) for u, v in zip(a[2:], b[2:]))
+        assert worst > 6, worst
     host.between = None
     host.close()
