@@ -336,6 +336,64 @@ def test_overlapped_chain_equals_serial_chain(be, monkeypatch, recipe, batch):
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
+def _q4_chain_case(be, monkeypatch, cfg, recipe, batch, steps, ck_seed=16, slack=1.0, rows_ok=None):
+    """both routes (chained, module by module) over an ExLlamaV2Cache_Q4 against OracleModel.forward(q4_cache=True), step by step:
+    logits, tokens where the oracle is confident, the codes each route wrote"""
+    for chain in ("1", "0"):
+        monkeypatch.setenv("EXL2_CHAIN", chain)
+        ck = synth_checkpoint(cfg, be.device, recipe=recipe, seed=ck_seed)
+        oracle = OracleModel(cfg, ck)
+        # (both before load(): it re-lays the checkpoint's tensors out in place)
+        cond = (OracleModel(cfg, ck), OracleModel(cfg, ck, rounding="chain")) if rows_ok is not None else None
+        model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+        cache = ExLlamaV2Cache_Q4(model, batch_size=batch)
+        dec = GreedyGraphDecoder(model, cache, batch_size=batch)
+        assert (dec.chain is not None) == (chain == "1")
+        be.ext.chain_route_counts(reset=True)
+        if not be.is_emu:
+            dec.capture()
+        first = np.random.default_rng(ck_seed).integers(0, cfg.vocab_size, size=(batch,)) if ck_seed != 16 else np.array([3, 50][:batch])
+        dec.reset(torch.from_numpy(first), 0)
+        oracle.reset(batch)
+        if cond is not None:                                            # (see test_q4_cache_random_models: rows nothing can be said about)
+            cond[0].reset(batch); cond[1].reset(batch)
+        tok = first.copy()
+        n_conf = 0
+        for i in range(steps):
+            dec.run(1, use_graph=not be.is_emu)
+            want = oracle.forward(tok[:, None], q4_cache=True)[:, -1]
+            got = be.n(dec.logits)[:, :cfg.vocab_size]
+            if cond is not None:
+                w_a, w_b = cond[0].forward(tok[:, None])[:, -1], cond[1].forward(tok[:, None])[:, -1]
+                rows_ok = rows_ok & (np.abs(w_a - w_b) <= 0.5 * (0.03 + np.abs(w_a) * 2.0 ** -8)).all(axis=-1)      # (once lost, a sequence stays out)
+            if slack == 1.0:
+                check_logits(got[:, None], want[:, None])              # the model tolerance of the FP16-cache tests, not a multiple
+            else:
+                err = np.abs(got.astype(np.float64) - want)
+                ok = err <= slack * (0.03 + np.abs(want) * 2.0 ** -8)
+                if rows_ok is not None:
+                    ok[~rows_ok] = True
+                assert np.all(ok), (chain, i, float((err / (0.03 + np.abs(want) * 2.0 ** -8)).max()))
+            g = be.n(dec.tokens(i, 1))[:, 0]
+            conf = confident(want)
+            if rows_ok is not None:
+                conf = conf & rows_ok
+            assert np.array_equal(g[conf], want.argmax(-1)[conf])
+            n_conf += int(conf.sum())
+            tok = g.copy()                                              # follow the device's tokens ...
+            # ... and its cache codes: the oracle quantized ITS K/V of this step; the route's K/V are the same up to fp16
+            # ulps, so all but a few codes at rounding boundaries must agree (everything written so far is compared, i.e.
+            # also that nothing outside the step's blocks was touched) -- then the oracle continues from the device's codes
+            for layer in range(cfg.num_hidden_layers):
+                flipped = oracle.q4_adopt(layer, be.n(cache.key_states[layer]), be.n(cache.key_scales[layer]),
+                                          be.n(cache.value_states[layer]), be.n(cache.value_scales[layer]), i + 1)
+                assert flipped < slack * (0.01 / (i + 1) + 0.002), (chain, i, layer, flipped)
+        assert n_conf >= 1 or slack != 1.0
+        n_chain = sum(be.ext.chain_route_counts())
+        assert (n_chain > 0) == (chain == "1")                      # chained launches ran / did not run
+        dec.free(); model.unload()
+
+
 @pytest.mark.parametrize("recipe,batch,hd,launches", [("4.0bpw", 1, 64, "1"), ("2.5bpw", 2, 64, "1"), ("4.0bpw", 1, 128, "1"),
                                                       ("2.5bpw", 2, 128, "1"), ("4.0bpw", 1, 128, "2"), ("2.5bpw", 2, 128, "4")])
 def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch, hd, launches):
@@ -365,44 +423,29 @@ def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch, hd, launc
         return ok
     monkeypatch.setattr(be.ext, "attn_q4_decode_fused", spy_one)
     monkeypatch.setattr(be.ext, "rope_quant_append_q4", spy_two)
-    for chain in ("1", "0"):
-        monkeypatch.setenv("EXL2_CHAIN", chain)
-        ck = synth_checkpoint(cfg, be.device, recipe=recipe, seed=16)
-        oracle = OracleModel(cfg, ck)
-        model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
-        cache = ExLlamaV2Cache_Q4(model, batch_size=batch)
-        dec = GreedyGraphDecoder(model, cache, batch_size=batch)
-        assert (dec.chain is not None) == (chain == "1")
-        be.ext.chain_route_counts(reset=True)
-        if not be.is_emu:
-            dec.capture()
-        first = np.array([3, 50][:batch])
-        dec.reset(torch.from_numpy(first), 0)
-        oracle.reset(batch)
-        tok = first.copy()
-        n_conf = 0
-        for i in range(steps):
-            dec.run(1, use_graph=not be.is_emu)
-            want = oracle.forward(tok[:, None], q4_cache=True)[:, -1]
-            got = be.n(dec.logits)[:, :cfg.vocab_size]
-            check_logits(got[:, None], want[:, None])                  # the model tolerance of the FP16-cache tests, not a multiple
-            g = be.n(dec.tokens(i, 1))[:, 0]
-            conf = confident(want)
-            assert np.array_equal(g[conf], want.argmax(-1)[conf])
-            n_conf += int(conf.sum())
-            tok = g.copy()                                              # follow the device's tokens ...
-            # ... and its cache codes: the oracle quantized ITS K/V of this step; the route's K/V are the same up to fp16
-            # ulps, so all but a few codes at rounding boundaries must agree (everything written so far is compared, i.e.
-            # also that nothing outside the step's blocks was touched) -- then the oracle continues from the device's codes
-            for layer in range(cfg.num_hidden_layers):
-                flipped = oracle.q4_adopt(layer, be.n(cache.key_states[layer]), be.n(cache.key_scales[layer]),
-                                          be.n(cache.value_states[layer]), be.n(cache.value_scales[layer]), i + 1)
-                assert flipped < 0.01 / (i + 1) + 0.002, (chain, i, layer, flipped)
-        assert n_conf >= 1
-        n_chain = sum(be.ext.chain_route_counts())
-        assert (n_chain > 0) == (chain == "1")                      # chained launches ran / did not run
-        dec.free(); model.unload()
+    _q4_chain_case(be, monkeypatch, cfg, recipe, batch, steps)
     assert (taken["one"] > 0) == (hd == 128 and launches == "1") and (taken["two"] > 0) == (hd == 128 and launches == "2"), taken
+
+
+@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "4")))))        # (more seeds: a longer hunt, by hand)
+def test_q4_cache_random_models(be, monkeypatch, seed):
+    """Seeded random small models over the Q4 cache, head_dim 128 (the one-launch decode step; on odd seeds the two-launch form):
+    4 / 8 kv heads, 1-8 query heads per kv head, 1-4 sequences, every EXL2 recipe, both routes.  3 x the model tolerance and 3 x the
+    code-flip allowance: the oracle rounds where the reference's composition rounds (test_chain_decode_random_models)."""
+    rng = np.random.default_rng(29000 + seed)
+    kvh = int(rng.choice([4, 8])); g = int(rng.choice([1, 2, 4, 8]))   # (kv width a multiple of the codec's 512-element block: the direct route)
+    cfg = tiny_cfg(num_attention_heads=kvh * g, num_key_value_heads=kvh, head_dim=128, hidden_size=128 * int(rng.integers(1, 7)),
+                   intermediate_size=128 * int(rng.integers(1, 7)), num_hidden_layers=int(rng.integers(1, 3)))
+    monkeypatch.setenv("EXL2_Q4_LAUNCHES", "2" if seed & 1 else "1")
+    recipe, batch = str(rng.choice(["4.0bpw", "3.5bpw", "2.5bpw"])), int(rng.integers(1, 5))
+    # Rows a comparison means nothing for: random weights now and then give a row whose residual stream nearly cancels, and the next
+    # RMSNorm multiplies every rounding difference -- e.g. seed 20 of this sweep, hidden 640, two layers, token 77: the two admissible
+    # roundings of the ORACLE sit 11.6 x the tolerance apart in its logits (its neighbours in the batch: 0.05), the chained route
+    # 8.8 x from the reference rounding and the module-by-module route 1.7 x, on the FP16 cache alike.  Such rows are
+    # found by exactly that -- the oracle in both roundings (FP16 cache), step by step on the device's tokens -- and left out of the
+    # logit / token checks from then on (they still run, their codes are still compared).
+    _q4_chain_case(be, monkeypatch, cfg, recipe, batch, steps=4, ck_seed=700 + seed, slack=3.0, rows_ok=np.ones((batch,), dtype=bool))
 
 
 def test_row_groups_taken_by_different_kernels(be, monkeypatch):
