@@ -1,6 +1,8 @@
 """MoE expert path: router (softmax -> top-k -> renormalise) and the fused q_moe_mlp_forward_
 against a composition of oracle pieces (oracle.modules.moe_route / rms_norm / silu_mul + reconstructed experts).
 Reference semantics: QMoEMLP::forward_ (cuda/q_mlp.cu:318-402), routing arithmetic cuda/q_mlp_softmax.cuh."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -28,27 +30,12 @@ def test_moe_route(be, experts, topk):
     assert np.allclose(got.astype(np.float32).sum(-1), 1.0, atol=2e-3)
 
 
-@pytest.mark.parametrize("route", ["default", "batched"])
-@pytest.mark.parametrize("shared_perm", [True, False])
-@pytest.mark.parametrize("rows", [1, 3, 16, 21])
-def test_moe_mlp_forward(be, rows, shared_perm, route, monkeypatch):
-    """Every expert's kernels see all rows; rows not routed to it are skipped, launches with no routed row exit.
-    rows = 16 is BASELINE config 5's decode batch (the reference falls back to a torch loop above 4 rows).
-    shared_perm: every expert's w1 / w3 carry ONE act-order permutation, as the quantizer writes them
-    (conversion/quantize.py:190-192) -> the grouped route (all experts in one launch per projection stage) for rows <= 16;
-    per-matrix permutations (format-legal, never produced) -> the per-expert launch loop."""
+def _moe_case(be, rows, shared_perm, E=8, topk=2, hidden=128, inter=256, seed=31, spec_up=None, spec_dn=None, gate_scale=0.3):
+    """one sparse-MoE block (q_moe_mlp_forward_) against the oracle's composition: routing mask, weighted expert sum into the residual"""
     from tests.util import exl2_to_torch
-    if route == "batched":
-        # round 5: what a Mixtral layer takes at 5..16 rows (the grouped launch declines its 16 x 14336 down_proj rows): experts on the
-        # streaming / phased kernels, rows gathered once, 2 (gate | up) / 4 (down) experts per launch, outputs summed by the combine
-        if not shared_perm or rows > 16:
-            pytest.skip("the batched route needs the experts' shared permutation and <= 16 rows")
-        monkeypatch.setenv("EXL2_MOE_NO_GROUP", "1")
-        monkeypatch.setenv("EXL2_DEBUG_ROUTE", "1")
-    rng = np.random.default_rng(31)
-    E, topk, hidden, inter = 8, 2, 128, 256
-    spec_up = [(5, 32, 32), (4, 32, hidden - 32)]
-    spec_dn = [(5, 32, 64), (4, 64, inter - 64)]
+    rng = np.random.default_rng(seed)
+    spec_up = spec_up or [(5, 32, 32), (4, 32, hidden - 32)]
+    spec_dn = spec_dn or [(5, 32, 64), (4, 64, inter - 64)]
     keep, handles, refs = [], {"w1": [], "w2": [], "w3": []}, {"w1": [], "w2": [], "w3": []}
     shared = rng.permutation(hidden).astype(np.int32)
     for e in range(E):
@@ -61,7 +48,7 @@ def test_moe_mlp_forward(be, rows, shared_perm, route, monkeypatch):
             h = be.ext.make_q_matrix_from_dict(w, None)
             keep.append(w); handles[name].append(h); refs[name].append(ref)
     norm_w = (1.0 + 0.1 * rng.standard_normal(hidden)).astype(F16)
-    gate = (rng.standard_normal((E, hidden)) * 0.3).astype(F16)
+    gate = (rng.standard_normal((E, hidden)) * gate_scale).astype(F16)
     x = rng.standard_normal((rows, hidden)).astype(F16)
 
     max_rows = 128                                        # room for the grouped route's per-expert scratch (E * rows rows)
@@ -82,7 +69,14 @@ def test_moe_mlp_forward(be, rows, shared_perm, route, monkeypatch):
     xn = OM.rms_norm(x, norm_w, 1e-5)
     raw = (xn.astype(np.float32) @ gate.astype(np.float32).T).astype(F16)
     wts, mask = OM.moe_route(raw, topk)
-    assert np.array_equal(be.n(tl)[:rows] != 0, mask)
+    chosen = be.n(tl)[:rows] != 0
+    # rows whose k-th and (k + 1)-th router logits are within a few fp16 steps of each other may legitimately go to either expert (the
+    # device sums the router's dot product in another order than the oracle): they are not compared (bench.py's parity check does the same)
+    srt = np.sort(raw.astype(np.float32), axis=-1)[:, ::-1]
+    clear = np.ones((rows,), dtype=bool) if topk >= E else (srt[:, topk - 1] - srt[:, topk]) > 4 * np.maximum(np.abs(srt[:, topk - 1]), 1.0) * 2.0 ** -10
+    # (a peaked router's second / third weights underflow to 0 in fp16: "nonzero" then marks fewer experts than were chosen)
+    tiny = wts.astype(np.float32) < 1e-4
+    assert not np.any((chosen & ~mask)[clear]) and np.array_equal((chosen | tiny)[clear], (mask | tiny)[clear])
     want = x.astype(np.float64).copy()
     acc16 = x.copy()
     for e in range(E):
@@ -94,10 +88,30 @@ def test_moe_mlp_forward(be, rows, shared_perm, route, monkeypatch):
         d = OX.gemm_ref(a, refs["w2"][e], exact=True)
         want[sel] += d * wts[sel, e].astype(np.float64)[:, None]
     tol = np.abs(want) * 2.0 ** -8 + 6e-3                   # E sequential fp16 accumulations into the residual
-    assert np.all(np.abs(got - want) <= tol), float(np.abs(got - want).max())
+    assert np.all((np.abs(got - want) <= tol)[clear]), float(np.abs(got - want)[clear].max())
+    assert np.all(np.isfinite(got))
     be.ext.free_q_moe_mlp(moe)
     for hs in handles.values():
         for h in hs: be.ext.free_q_matrix(h)
+
+@pytest.mark.parametrize("route", ["default", "batched"])
+@pytest.mark.parametrize("shared_perm", [True, False])
+@pytest.mark.parametrize("rows", [1, 3, 16, 21])
+def test_moe_mlp_forward(be, rows, shared_perm, route, monkeypatch):
+    """Every expert's kernels see all rows; rows not routed to it are skipped, launches with no routed row exit.
+    rows = 16 is BASELINE config 5's decode batch (the reference falls back to a torch loop above 4 rows).
+    shared_perm: every expert's w1 / w3 carry ONE act-order permutation, as the quantizer writes them
+    (conversion/quantize.py:190-192) -> the grouped route (all experts in one launch per projection stage) for rows <= 16;
+    per-matrix permutations (format-legal, never produced) -> the per-expert launch loop."""
+    if route == "batched":
+        # round 5: what a Mixtral layer takes at 5..16 rows (the grouped launch declines its 16 x 14336 down_proj rows): experts on the
+        # streaming / phased kernels, rows gathered once, 2 (gate | up) / 4 (down) experts per launch, outputs summed by the combine
+        if not shared_perm or rows > 16:
+            pytest.skip("the batched route needs the experts' shared permutation and <= 16 rows")
+        monkeypatch.setenv("EXL2_MOE_NO_GROUP", "1")
+        monkeypatch.setenv("EXL2_DEBUG_ROUTE", "1")
+    _moe_case(be, rows, shared_perm)
+
 
 
 def test_moe_model_forward(be):
@@ -246,3 +260,25 @@ def test_moe_fused_front_is_bit_identical(be, rows, monkeypatch):
     assert np.array_equal(outs[0][1].view(np.uint16), outs[1][1].view(np.uint16))      # routing weights
     assert np.array_equal(outs[0][0].view(np.uint16), outs[1][0].view(np.uint16))      # block output
     model.unload()
+
+
+@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
+def test_moe_mlp_forward_random_shapes(be, seed, monkeypatch):
+    """Seeded random sparse-MoE blocks: 4 / 8 experts, top-1..3, 1-24 rows, hidden / intermediate sizes off the powers of two, 4 / 3 / 2-bit
+    sections, routers from near-uniform to peaked (experts without a row, every row to one expert), the grouped route / the batched
+    expert launches / the per-expert loop."""
+    rng = np.random.default_rng(31000 + seed)
+    E = int(rng.choice([4, 8])); topk = int(rng.integers(1, 4))
+    hidden = 64 * int(rng.integers(2, 7)); inter = 64 * int(rng.integers(2, 9))
+    rows = int(rng.choice([1, 2, 4, 5, 8, 13, 16, 17, 24]))
+    b1, b2 = sorted(rng.choice([5, 4, 3, 2], size=2, replace=False).tolist(), reverse=True)
+    cut_u = 32 * int(rng.integers(1, hidden // 32)); cut_d = 32 * int(rng.integers(1, inter // 32))
+    spec_up = [(b1, 32, cut_u), (b2, int(rng.choice([32, 64])), hidden - cut_u)]
+    spec_dn = [(b1, 32, cut_d), (b2, int(rng.choice([32, 64])), inter - cut_d)]
+    route = str(rng.choice(["default", "batched", "loop"]))
+    shared = route != "loop"
+    if route == "batched" and rows <= 16:
+        monkeypatch.setenv("EXL2_MOE_NO_GROUP", "1")
+    _moe_case(be, rows, shared, E=E, topk=topk, hidden=hidden, inter=inter, seed=32000 + seed, spec_up=spec_up, spec_dn=spec_dn,
+              gate_scale=float(rng.choice([0.02, 0.3, 3.0])))
