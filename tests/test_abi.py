@@ -112,3 +112,61 @@ def test_flash_attn_shim_window_that_cannot_clip_is_causal_attention_and_one_tha
     # a window of 4096 over 9 keys cannot clip: the call goes on to the kernels (which refuse CPU tensors -- there is no CPU path)
     with pytest.raises(RuntimeError, match="no CPU path|HIP device"):
         mod.flash_attn_func(q, k, k, causal=True, window_size=(4096, 4096))
+
+
+@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
+def test_flash_attn_shim_random_calls(be, seed):
+    """The flash-attn stand-in as the reference calls it (attn.py:960-977 / 602-613), seeded random shapes: `flash_attn_func` with k / v
+    handed over as VIEWS of a longer cache (batch stride = max_seq_len: the shim recovers the whole rows), 1-40 query rows (decode-shaped
+    and prefill-shaped kernels), GQA 1-8, head_dim 64 / 128, a window that cannot clip; `flash_attn_with_kvcache` with the append through
+    a shuffled block table.  Checker: the oracle's attention; the appended rows must sit in the cache afterwards."""
+    import importlib.util
+    import numpy as np
+    import torch
+    from oracle import modules as OM
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(f"flash_attn_shim_r{seed}", os.path.join(root, "dropin", "flash_attn", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod._e = be.ext                                                  # (the emulation build's binding here, libexl2_hip.so's under -m gpu)
+    rng = np.random.default_rng(43000 + seed)
+    F16 = np.float16
+    hd = int(rng.choice([64, 128])); kvh = int(rng.choice([1, 2, 4])); g = int(rng.choice([1, 2, 4, 8])); nh = kvh * g
+    b = int(rng.integers(1, 4)); s = int(rng.choice([1, 2, 5, 16, 17, 40])); past = int(rng.choice([0, 3, 100, 255, 300]))
+    if s * g > 64 and s <= 16:
+        s = 1
+    max_seq = past + s + int(rng.integers(0, 50))
+
+    def tol(want):
+        return 4e-3 + np.abs(want) * 2.0 ** -7
+
+    q = rng.standard_normal((b, s, nh, hd)).astype(F16)
+    kc = (rng.standard_normal((b, max_seq, kvh, hd)) * 0.5).astype(F16); vc = rng.standard_normal((b, max_seq, kvh, hd)).astype(F16)
+    kt, vt = be.t(kc), be.t(vc)
+    window = (-1, -1) if rng.integers(0, 2) else (8192, 8192)
+    out = mod.flash_attn_func(be.t(q), kt[:, :past + s], vt[:, :past + s], causal=True, window_size=window)
+    want = OM.attention(q, kc[:, :past + s], vc[:, :past + s])
+    err = np.abs(be.n(out).astype(np.float32) - want.astype(np.float32))
+    assert np.all(err <= tol(want)), ("flash_attn_func", b, s, nh, kvh, hd, past, float(err.max()))
+    # paged, with the append
+    ps = 256
+    s2 = int(rng.integers(1, 9))
+    if s2 * g > 64:
+        s2 = 1
+    pages_per_seq = int(rng.integers(1, 4))
+    pages = b * pages_per_seq + 1
+    table = rng.permutation(pages)[:b * pages_per_seq].astype(np.int32).reshape(b, pages_per_seq)
+    cap = ps * pages_per_seq
+    seqlens = np.array([min(int(rng.choice([0, 5, 250, 255, 256, 400, cap - s2])), cap - s2) for _ in range(b)], dtype=np.int32)
+    kp = (rng.standard_normal((pages, ps, kvh, hd)) * 0.5).astype(F16); vp = rng.standard_normal((pages, ps, kvh, hd)).astype(F16)
+    q2 = rng.standard_normal((b, s2, nh, hd)).astype(F16)
+    kn = (rng.standard_normal((b, s2, kvh, hd)) * 0.5).astype(F16); vn = rng.standard_normal((b, s2, kvh, hd)).astype(F16)
+    kp_ref, vp_ref = kp.copy(), vp.copy()
+    want2 = OM.paged_attention(q2, kn, vn, kp_ref, vp_ref, seqlens, table)
+    kpt, vpt = be.t(kp), be.t(vp)
+    out2 = mod.flash_attn_with_kvcache(be.t(q2), kpt, vpt, k=be.t(kn), v=be.t(vn), cache_seqlens=be.t(seqlens), block_table=be.t(table),
+                                       causal=True, window_size=(-1, -1) if rng.integers(0, 2) else (4096, 4096))
+    assert np.array_equal(be.n(kpt).view(np.uint16), kp_ref.view(np.uint16)) and np.array_equal(be.n(vpt).view(np.uint16), vp_ref.view(np.uint16))
+    err2 = np.abs(be.n(out2).astype(np.float32) - want2.astype(np.float32))
+    assert np.all(err2 <= tol(want2)), ("flash_attn_with_kvcache", b, s2, nh, kvh, hd, seqlens.tolist(), float(err2.max()))
