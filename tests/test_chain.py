@@ -69,7 +69,7 @@ def test_chain_decode_equals_oracle(be, recipe, batch):
 
 @pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "4")))))        # (more seeds: a longer hunt, by hand)
-def test_chain_decode_random_models(be, seed):
+def test_chain_decode_random_models(be, seed, monkeypatch):
     """Seeded random small models through the chained decoder against the oracle, step by step: hidden / intermediate sizes that are
     not powers of two, 1-8 query heads per kv head, head_dim 64 / 128, every recipe (EXL2 2.5-4.0 bpw mixes, GPTQ), 1-16 sequences
     (<= 4 rows: the one-row forms; more: ROWS / XMEM forms and row groups), FP16 cache.
@@ -94,6 +94,9 @@ def test_chain_decode_random_models(be, seed):
     act_order = not recipe.startswith("gptq") or bool(rng.integers(0, 2))
     _decode_and_check(be, cfg, recipe, batch, steps=2, seed=600 + seed, act_order=act_order, expect_chain=True, rounding="chain")
     _decode_and_check(be, cfg, recipe, batch, steps=2, seed=600 + seed, act_order=act_order, expect_chain=True, logit_slack=3.0)
+    # ... and the module-by-module route (the kernels behind the plain operator calls) on the same model
+    monkeypatch.setenv("EXL2_CHAIN", "0")
+    _decode_and_check(be, cfg, recipe, batch, steps=2, seed=600 + seed, act_order=act_order, expect_chain=False, logit_slack=3.0)
 
 
 @pytest.mark.parametrize("recipe", ["4.0bpw", "3.5bpw"])
