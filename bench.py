@@ -691,7 +691,7 @@ def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq:
                      "linear_TFLOPs": round(flops / best / 1e12, 1)}
     # roofline of the dominant prefill kernel (qgemm_mfma_kernel, csrc/qgemm_mfma.hip): the largest linear of a layer alone, the
     # same 16384-row pass the forward above makes, timed with HIP events on the launch stream; dense fp16 MFMA peak 2.5 PFLOP/s
-    # (MI355X_MICROARCH.md).  MFMA-busy counters of the same kernel: profiles/r03_pmc_prefill_summary.json (61 %; round 2: 35 %).
+    # (MI355X_MICROARCH.md).  MFMA-busy counters of the CURRENT kernel source: profiles/r06_pmc_prefill_summary.json (58.8 %; the round-3 source: 61 %).
     try:
         lin = model.layers[0][1].gate_proj
         rows = batch * seq
@@ -709,7 +709,7 @@ def prefill_rate(model_name: str, recipe: str, device: str, batch: int = 8, seq:
         out["roofline"] = {"bound": "mfma", "kernel": "qgemm_mfma_kernel (gate_proj %d x %d at %d rows: row pre-pass + GEMM launches of one call)" % (lin.in_features, lin.out_features, rows),
                            "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                            "frac": round(fl / (ms * 1e-3) / 2.5e15, 4), "traffic": None, "flops_per_call": fl, "avg_call_us": round(ms * 1e3, 1),
-                           "pmc_source": "profiles/r03_pmc_prefill_summary.json (SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) = 61 % for this kernel at 16384 rows)"}
+                           "pmc_source": "profiles/r06_pmc_prefill_summary.json (round-6 pass over the current source: SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) = 58.8 % for the 256-row instantiation at 16384 rows, 56.0 % for the 128-row one; waves parked 35 %, issue-stalled 47 %, LDS bank conflicts 0)"}
         del x, y
     except Exception as e:  # informational
         out["roofline"] = {"error": str(e)[:200]}

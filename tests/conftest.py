@@ -23,8 +23,6 @@ EMU_LIB = os.path.join(ROOT, "tests", "emu", "libexl2_emu.so")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
-    config.addinivalue_line("markers", "hip_unverified: the hip variant is skipped unless EXL2_RUN_UNVERIFIED=1 (test added after "
-                                       "the round's last GPU call; it runs on the emulation backend)")
 
 
 def _emu_sources():
@@ -80,10 +78,6 @@ _backends = {}
 @pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
 def be(request):
     name = request.param
-    if name == "hip" and request.node.get_closest_marker("hip_unverified") and os.environ.get("EXL2_RUN_UNVERIFIED", "0") != "1":
-        # written after the round's GPU budget was spent: green on the emulation backend (same kernel sources), never yet
-        # run on the GPU.  EXL2_RUN_UNVERIFIED=1 runs them; the marker comes off once they have passed on an MI355X.
-        pytest.skip("not yet run on a GPU (EXL2_RUN_UNVERIFIED=1 to run)")
     if name not in _backends:
         _backends[name] = Backend(name)
     return _backends[name]

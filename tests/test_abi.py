@@ -114,7 +114,6 @@ def test_flash_attn_shim_window_that_cannot_clip_is_causal_attention_and_one_tha
         mod.flash_attn_func(q, k, k, causal=True, window_size=(4096, 4096))
 
 
-@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
 def test_flash_attn_shim_random_calls(be, seed):
     """The flash-attn stand-in as the reference calls it (attn.py:960-977 / 602-613), seeded random shapes: `flash_attn_func` with k / v

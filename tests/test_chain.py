@@ -67,7 +67,6 @@ def test_chain_decode_equals_oracle(be, recipe, batch):
     _decode_and_check(be, cfg, recipe, batch, seed=11)
 
 
-@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "4")))))        # (more seeds: a longer hunt, by hand)
 def test_chain_decode_random_models(be, seed, monkeypatch):
     """Seeded random small models through the chained decoder against the oracle, step by step: hidden / intermediate sizes that are
@@ -430,7 +429,6 @@ def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch, hd, launc
     assert (taken["one"] > 0) == (hd == 128 and launches == "1") and (taken["two"] > 0) == (hd == 128 and launches == "2"), taken
 
 
-@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "4")))))        # (more seeds: a longer hunt, by hand)
 def test_q4_cache_random_models(be, monkeypatch, seed):
     """Seeded random small models over the Q4 cache, head_dim 128 (the one-launch decode step; on odd seeds the two-launch form):
@@ -567,7 +565,6 @@ def test_gemm_chain_shares_of_several_register_loads(be, rows, spec_name, capfd,
     be.ext.free_q_matrix(h)
 
 
-@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "12")))))       # (more seeds: a longer hunt, by hand)
 def test_gemm_chain_random_bit_mixes_and_depths(be, seed):
     """Seeded random matrices through exl2_gemm_half_q_half_chain: K from 2048 to ~20 k, one to three bit-width sections in the

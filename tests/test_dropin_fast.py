@@ -364,7 +364,6 @@ def test_inference_mode_tensors_and_the_self_check(be):
     host.close()
 
 
-@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))
 def test_hosts_that_do_random_things_between_module_calls(be, seed):
     """Fuzz of the module chain's identity rules: between any two module calls of any token a host may do nothing, change x in place

@@ -262,7 +262,6 @@ def test_moe_fused_front_is_bit_identical(be, rows, monkeypatch):
     model.unload()
 
 
-@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
 def test_moe_mlp_forward_random_shapes(be, seed, monkeypatch):
     """Seeded random sparse-MoE blocks: 4 / 8 experts, top-1..3, 1-24 rows, hidden / intermediate sizes off the powers of two, 4 / 3 / 2-bit

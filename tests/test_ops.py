@@ -103,7 +103,6 @@ def test_q4_cache_contiguous_roundtrip(be):
     assert err.max() < 0.6 and err.mean() < 0.12
 
 
-@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
 def test_kv_codec_random_ranges(be, seed):
     """Seeded random contiguous pack / unpack calls of the Q4 / Q8 cache codec: kv widths 128-1024 (so that a 512-element block holds
@@ -150,7 +149,6 @@ def test_kv_codec_random_ranges(be, seed):
             assert np.array_equal(o[i, lo:hi].view(np.uint16), want.view(np.uint16))
 
 
-@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
 def test_kv_codec_random_paged_appends(be, seed):
     """Seeded random PAGED appends of the Q4 / Q8 codec (cache.cu:143-195): 1-3 sequences at random lengths (page starts, page ends,
@@ -310,7 +308,6 @@ def test_flash_prefill_paged(be):
     assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want))
 
 
-@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
 def test_flash_prefill_random_shapes(be, seed):
     """Seeded random shapes for the MFMA flash-prefill kernel (round 5: two 16-row query blocks per wave, one page look-up per key
@@ -406,7 +403,6 @@ def test_attention_fused_decode_step(be, hd, nh, kvh, s, rope):
         assert int(be.n(counters).sum()) == 0
 
 
-@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "8")))))        # (more seeds: a longer hunt, by hand)
 def test_attention_fused_decode_step_random_shapes(be, seed, monkeypatch):
     """Seeded random shapes for the one-launch FP16 decode step (attn_decode_fused): batch 1-4, 1-4 new tokens, 1-8 query heads per kv
@@ -848,7 +844,6 @@ def test_attention_q4_decode_step_in_one_launch(be, nh, kvh, s, paged, neox, row
                                            be.t(sin[:, :64].copy()), be.t(cos[:, :64].copy()), sl, bt, 0, style, scratch, counters)
 
 
-@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "8")))))        # (more seeds: a longer hunt, by hand)
 def test_attention_q4_decode_step_random_shapes(be, seed, monkeypatch):
     """Seeded random shapes for the one-launch Q4 decode step (exl2_attn_q4_decode_fused): batch 1-4, 1-8 new tokens, 1-8 query heads per

@@ -108,7 +108,6 @@ def test_prefill_vs_oracle(be, m):
     be.ext.free_q_matrix(h)
 
 
-@pytest.mark.hip_unverified            # (seeded sweep written after the round's last GPU call: green on the emulation build, EXL2_RUN_UNVERIFIED=1 runs it on a GPU)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
 def test_gemm_random_rows_shapes_and_bit_mixes(be, seed, monkeypatch):
     """Seeded random (rows, K, N, bit-width sections, group sizes, act-order, bias) through exl2_gemm_half_q_half: every row-count

@@ -15,7 +15,8 @@
 #   trace      in-kernel timeline of the chained decode kernel (needs tools/build_trace.sh's library)
 #   ab         same-box A/B: VARIANTS="name=ENV1=v,ENV2=v ..." (name `head` = no env); libraries built by tools/build_variant.sh are
 #              selected with EXL2_HIP_LIB=...; REPS (default 2) rounds, interleaved; AB_FLAGS = extra bench flags
-#   probes     every built binary under tools/probes/*_probe
+#   probes     every built binary under tools/probes/*_probe (PROBES="a_probe b_probe" narrows it)
+#   pfpmc      rocprofv3 --pmc over tools/prefill_bench.py (MFMA busy, LDS, wait states: two passes) -> ${TAG}_pmc_prefill_summary.json
 mkdir -p gpurun_out; export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; R=$ROOT/gpurun_out; T=${TAG:-r05}
 STAGES=${STAGES:-"smoke tests bench"}
@@ -26,7 +27,7 @@ line() { timeout -k 10 ${2:-300} python bench.py $1 2>$R/${T}_last.err | tail -1
 if has smoke; then echo "== smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $R/${T}_smoke.log 2>&1; echo "rc=$?"; tail -1 $R/${T}_smoke.log; fi
 if has tests; then
   echo "== pytest -m gpu ${TESTS:-tests}"
-  timeout -k 10 ${TESTS_TIMEOUT:-1200} python -m pytest ${TESTS:-tests} -m gpu -q --timeout 600 -x > $R/${T}_pytest_gpu.log 2>&1; echo "rc=$?"; tail -${TESTS_TAIL:-4} $R/${T}_pytest_gpu.log
+  timeout -k 10 ${TESTS_TIMEOUT:-1200} python -m pytest ${TESTS:-tests} -m gpu -q --timeout 600 ${TESTS_X--x} > $R/${T}_pytest_gpu.log 2>&1; echo "rc=$?"; tail -${TESTS_TAIL:-4} $R/${T}_pytest_gpu.log
 fi
 if has bench || has bench_default; then
   echo "== bench (default flags)"; timeout -k 10 900 python bench.py > $R/${T}_bench.json 2> $R/${T}_bench.err; echo "rc=$?"; cut -c1-1800 $R/${T}_bench.json; tail -3 $R/${T}_bench.err
@@ -100,8 +101,43 @@ print(d['value'], 'tok/s', d.get('windows', {}).get('tokens_per_s'), r.get('avg_
     done
   done 2>&1 | tee $R/${T}_ab_${AB_NAME:-variants}.txt
 fi
+if has pfpmc; then
+  echo "== rocprofv3 --pmc over the prefill GEMM (two passes)"
+  (cd /tmp && timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/prof_pmc_pf -o a -- python $ROOT/tools/prefill_bench.py --quick --variants auto --reps 2 > $R/${T}_pmc_pf_a.log 2>&1); echo "rc=$?"
+  (cd /tmp && timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $R/prof_pmc_pf2 -o b -- python $ROOT/tools/prefill_bench.py --quick --variants auto --reps 2 > $R/${T}_pmc_pf_b.log 2>&1); echo "rc=$?"
+  python - $T <<'PY'
+import csv, glob, collections, json, sys
+tag = sys.argv[1]
+out = {}
+for d in ("prof_pmc_pf", "prof_pmc_pf2"):
+    for f in glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "qgemm_mfma" in r["Kernel_Name"] or "wfrag" in r["Kernel_Name"] or "qgemm_prefill" in r["Kernel_Name"]:
+                agg[(r["Kernel_Name"][:60], r["Counter_Name"], r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
+        for (k, c, g), v in sorted(agg.items()):
+            out[f"{c}:{k}:grid{g}"] = {"launches": len(v), "avg": sum(v) / len(v)}
+json.dump(out, open(f"gpurun_out/{tag}_pmc_prefill_summary.json", "w"), indent=1)
+by = collections.defaultdict(dict)
+for key, v in out.items():
+    c, k, g = key.split(":", 2)[0], key.split(":", 2)[1], key.rsplit(":", 1)[1]
+    by[(k, g)][c] = v["avg"]
+lines = []
+for (k, g), d in by.items():
+    if "SQ_BUSY_CU_CYCLES" in d:
+        line = f"{k} {g}: "
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in d: line += "MFMA busy %.1f%%  " % (100 * d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * d["SQ_BUSY_CU_CYCLES"]))
+        if "SQ_LDS_IDX_ACTIVE" in d: line += "LDS idx active / CU busy %.2f  bank conflict cycles / active %.3f  " % (d["SQ_LDS_IDX_ACTIVE"] / d["SQ_BUSY_CU_CYCLES"], d.get("SQ_LDS_BANK_CONFLICT", 0) / max(1, d["SQ_LDS_IDX_ACTIVE"]))
+        if "SQ_WAIT_ANY" in d: line += "wave wait %.0f%% (inst-any wait %.0f%%, LDS-inst wait %.0f%%) active LDS %.0f%% VALU %.0f%%" % (100 * d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], 100 * d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], 100 * d["SQ_WAIT_INST_LDS"] / d["SQ_WAVE_CYCLES"], 100 * d["SQ_ACTIVE_INST_LDS"] / d["SQ_WAVE_CYCLES"], 100 * d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"])
+        lines.append(line)
+open(f"gpurun_out/{tag}_pmc_prefill_lines.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+PY
+  rm -rf $R/prof_pmc_pf $R/prof_pmc_pf2
+fi
 if has probes; then
-  for p in tools/probes/*_probe; do [ -x $p ] && { echo "== $p"; timeout -k 10 120 $p 2>&1 | tee $R/${T}_$(basename $p).txt | tail -${PROBE_TAIL:-12}; }; done
+  plist="tools/probes/*_probe"; [ -n "$PROBES" ] && plist=$(for q in $PROBES; do echo tools/probes/$q; done)
+  for p in $plist; do [ -x $p ] && { echo "== $p"; timeout -k 10 120 $p 2>&1 | tee $R/${T}_$(basename $p).txt | tail -${PROBE_TAIL:-12}; }; done
 fi
 rocm-smi --showproductname 2>/dev/null | grep -i "card series\|gfx" | head -3 > $R/${T}_gpu.txt
 echo "== done"
