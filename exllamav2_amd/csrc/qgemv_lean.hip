@@ -49,6 +49,10 @@
 #ifndef LEAN_LOWBITS
 #define LEAN_LOWBITS 1                // 0: no 2 / 3-bit register stream (code-size experiment; such segments would be wrong)
 #endif
+#ifndef LEAN_RAW2
+#define LEAN_RAW2 1                   // 4-bit items: the matrix cores get the UN-subtracted codes (half2 1024 + q / 64 + q: one v_and_or_b32 per pair, no
+#endif                                // v_pk_add / v_pk_fma) and the constant part leaves through a second MFMA per chunk against a constant B fragment
+                                      // -(1024 + z) / -(64 + z): 20 vector instructions per item instead of 50, no pre-pass (round 6; A/B in profiles/r06_raw2_ab.txt)
 #ifndef LEAN_BUF_DMA
 #define LEAN_BUF_DMA 1                // the wave-private staging copies in the buffer form (hw.h: dma_buf_to_lds16): counted waits stay exact
 #endif
@@ -175,6 +179,31 @@ struct LeanCtx
 // MFMAs against the staged activations -> the group scale on the fp32 partial sum.  Same arithmetic as gemv_super
 // (qgemv_common.h).
 // PRE (the XMEM form of the kernel): the four A operands were requested from MEMORY ahead of time and arrive in `pre`.
+#if LEAN_RAW2
+// B fragment of one 32-row chunk straight from its packed dword: pairs (e = 0, 1) and (e = 4, 5) as 1024 + q, (2, 3) and (6, 7) as 64 + q
+// (the nibble sits where the half's unit bit is: 0x6400 = 1024, ulp 1; 0x5400 = 64, ulp 1 / 16).  Plain C so that the compiler sees
+// the VALU write in front of the MFMA (an inline-asm and_or feeding an MFMA hides the hazard: profiles/r05_raw4_experiment.txt).
+DEV f16x8 raw4_b(u32 x, u32 m_lo, u32 m_hi, u32 k_lo, u32 k_hi)
+{
+    const u32 y = x >> 8;
+    const u32x4 bw = {(x & m_lo) | k_lo, (x & m_hi) | k_hi, (y & m_lo) | k_lo, (y & m_hi) | k_hi};
+    return __builtin_bit_cast(f16x8, bw);
+}
+// the constant B fragment that takes the bias back out: -(1024 + z) where the code was fed as 1024 + q, -(64 + z) where as 64 + q
+DEV f16x8 raw4_negc(f16 z)
+{
+    const f16 a = -((f16)1024.0f + z), b = -((f16)64.0f + z);
+    return (f16x8){a, a, b, b, a, a, b, b};
+}
+struct Raw4K { u32 m_lo, m_hi, k_lo, k_hi; };
+DEV Raw4K raw4_consts()
+{
+    Raw4K k = {0x000F000Fu, 0x00F000F0u, 0x64006400u, 0x54005400u};
+    pin_scalar(k.m_lo); pin_scalar(k.m_hi); pin_vector(k.k_lo); pin_vector(k.k_hi);
+    return k;
+}
+#endif
+
 template <int BITS, bool GPTQ, bool PRE = false>
 DEV void lean_item_uniform(const LaneWords<BITS>& lw, const LeanCtx& cx, int chunk, int g, int lane, f32x4& acc, const f16x8* pre = nullptr)
 {
@@ -182,6 +211,28 @@ DEV void lean_item_uniform(const LaneWords<BITS>& lw, const LeanCtx& cx, int chu
     const int mrow = c < cx.M ? c : cx.M - 1;
     const f16* arow = cx.x_lds + mrow * cx.x_stride + (chunk - cx.xc0) * 32 + 8 * j;
     const float s = (float)cx.sc_lds[g * 16 + c];
+#if LEAN_RAW2
+    if constexpr (BITS == 4)
+    {
+        const Raw4K k = raw4_consts();
+        f16 z = (f16)8.0f;
+        if constexpr (GPTQ) z = cx.zp_lds[g * 16 + c];
+        const f16x8 negc = raw4_negc(z);
+        f32x4 part = {0.0f, 0.0f, 0.0f, 0.0f};
+        #pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const f16x8 b = raw4_b(lw.w[q], k.m_lo, k.m_hi, k.k_lo, k.k_hi);
+            f16x8 a;
+            if constexpr (PRE) a = pre[q]; else a = *(const f16x8*)(arow + q * 32);
+            part = mfma_16x16x32_f16(a, b, part);
+            part = mfma_16x16x32_f16(a, negc, part);
+        }
+        #pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = fmaf(s, part[i], acc[i]);
+        return;
+    }
+#endif
     ZC zc[4];
     if constexpr (GPTQ) zc[0] = make_zc(cx.zp_lds[g * 16 + c]);
     else zc[0] = make_zc((f16)(float)(1 << (BITS - 1)));
@@ -214,6 +265,34 @@ DEV void lean_item_general(const LaneWords<BITS>& lw, const LeanCtx& cx, int chu
     const int c = lane & 15, j = lane >> 4;
     const int mrow = c < cx.M ? c : cx.M - 1;
     const f16* arow = cx.x_lds + mrow * cx.x_stride + (chunk - cx.xc0) * 32 + 8 * j;
+#if LEAN_RAW2
+    if constexpr (BITS == 4)
+    {
+        // a scale per chunk: each chunk's two MFMAs start from zero and the scale goes onto the fp32 sums (the same value
+        // reconstruct() rounds to for a one-hot row: fp16 scale x small integer is exact in fp32)
+        const Raw4K k = raw4_consts();
+        #pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            if (q < nvalid)
+            {
+                const int gi = (g0 + ((cs + q + gphase) >> gshift)) * 16 + c;
+                f16 z = (f16)8.0f;
+                if constexpr (GPTQ) z = cx.zp_lds[gi];
+                const float sq = (float)cx.sc_lds[gi];
+                const f16x8 b = raw4_b(lw.w[q], k.m_lo, k.m_hi, k.k_lo, k.k_hi);
+                f16x8 a;
+                if constexpr (PRE) a = pre[q]; else a = *(const f16x8*)(arow + q * 32);
+                f32x4 part = {0.0f, 0.0f, 0.0f, 0.0f};
+                part = mfma_16x16x32_f16(a, b, part);
+                part = mfma_16x16x32_f16(a, raw4_negc(z), part);
+                #pragma unroll
+                for (int i = 0; i < 4; i++) acc[i] = fmaf(sq, part[i], acc[i]);
+            }
+        }
+        return;
+    }
+#endif
     ZC zc[4];
     if constexpr (GPTQ)
     {
