@@ -38,6 +38,8 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
+#include <mutex>
 
 namespace {
 
@@ -115,6 +117,12 @@ struct DevBuf { at::Tensor xp[2], ss[2], vxp, vss, packed, scratch, counters; in
 struct State
 {
     bool on = true, verify = false; int max_rows = 16;
+    // self-check sampling (default ON): the first `verify_first` uses of every consumer's published hand-off and every `verify_every`-th one
+    // after that are re-derived from x and compared; a mismatch blocks that edge for good (the module then makes its own hand-off)
+    int verify_first = 8, verify_every = 256;
+    std::unordered_map<void*, long long> edge_uses;
+    std::unordered_set<void*> blocked;
+    long long n_mismatch = 0; bool warned = false;
     std::unordered_map<void*, ModInfo> info;
     std::unordered_map<void*, void*> succ;
     std::unordered_map<int, DevBuf> bufs;
@@ -127,6 +135,9 @@ struct State
     void* packed_for = nullptr; Identity attn_out; cvp packed_ptr = nullptr;
     long long n_chained = 0, n_published = 0, n_plain = 0, n_attn_fast = 0, n_verified = 0, n_declined = 0;
 } S;
+// one host thread at a time inside the binding (the GIL serialises Python callers already; this also covers callers that release it)
+std::recursive_mutex g_mu;
+#define LOCKED std::lock_guard<std::recursive_mutex> lock_(g_mu)
 
 void drop_pending() { S.consumer = nullptr; S.pub_x.clear(); }
 void drop_all() { drop_pending(); S.finisher = nullptr; S.fin_x.clear(); S.cur_attn = nullptr; S.cur_q = nullptr; S.packed_for = nullptr; S.attn_out.clear(); S.packed_ptr = nullptr; }
@@ -170,14 +181,25 @@ HandOff enter(void* h, const ModInfo& mi, const at::Tensor& x, int rows, int hid
     {
         ho.xp = b.xp[S.pub_buf].data_ptr(); ho.ss = (const float*)b.ss[S.pub_buf].data_ptr(); ho.npart = S.pub_npart;
         S.n_chained++;
-        if (S.verify)
+        const long long uses = S.edge_uses[h]++;
+        if (S.verify || uses < S.verify_first || (S.verify_every > 0 && uses % S.verify_every == 0))
         {
             // what this module would have published from x itself must be what its predecessor left (same fp32 product, same rounding)
             check(api.publish_rows(x.data_ptr(), rows, hidden, mi.in_invperm, mi.norm_w, b.vxp.data_ptr(), (float*)b.vss.data_ptr(), stream));
-            if (!at::equal(b.vxp.narrow(0, 0, rows), b.xp[S.pub_buf].narrow(0, 0, rows)))
-                throw std::runtime_error("_exl2_fast: EXL2_MODULE_CHAIN_VERIFY: the residual tensor changed between two module calls "
-                                         "(the published hand-off no longer matches it)");
             S.n_verified++;
+            if (!at::equal(b.vxp.narrow(0, 0, rows), b.xp[S.pub_buf].narrow(0, 0, rows)))
+            {
+                if (S.verify)
+                    throw std::runtime_error("_exl2_fast: EXL2_MODULE_CHAIN_VERIFY: the residual tensor changed between two module calls "
+                                             "(the published hand-off no longer matches it)");
+                // somebody wrote x between two module calls without the binding seeing it (a raw-pointer write without
+                // note_write, or an in-place torch op on a tensor without a version counter): this edge is never chained again, and this
+                // call starts from the hand-off just re-derived from x
+                S.n_mismatch++; S.blocked.insert(h);
+                if (!S.warned) { S.warned = true; fprintf(stderr, "[exl2] module chain: a residual tensor changed between two module calls; that hand-off is disabled (EXL2_MODULE_CHAIN_VERIFY=1 raises instead)\n"); }
+                ho.xp = b.vxp.data_ptr(); ho.ss = (const float*)b.vss.data_ptr(); ho.npart = 1;
+                S.n_chained--; S.n_published++;
+            }
         }
     }
     else
@@ -200,7 +222,7 @@ Publish successor(void* h, const at::Tensor& x, int hidden)
     auto it = S.succ.find(h);
     if (it == S.succ.end()) return p;
     auto in = S.info.find(it->second);
-    if (in == S.info.end() || !in->second.capable) return p;
+    if (in == S.info.end() || !in->second.capable || S.blocked.count(it->second)) return p;
     DevBuf& b = bufs_for(x, hidden);
     p.next = it->second; p.invperm = in->second.in_invperm; p.norm_w = in->second.norm_w;
     p.buf = S.next_buf; S.next_buf ^= 1;
@@ -239,6 +261,8 @@ void init(const std::string& path, bool cpu_ok)
     S = State();
     if (const char* e = getenv("EXL2_MODULE_CHAIN")) S.on = atoi(e) != 0;
     if (const char* e = getenv("EXL2_MODULE_CHAIN_VERIFY")) S.verify = atoi(e) != 0;
+    if (const char* e = getenv("EXL2_MODULE_CHAIN_VERIFY_FIRST")) S.verify_first = atoi(e) < 0 ? 0 : atoi(e);
+    if (const char* e = getenv("EXL2_MODULE_CHAIN_VERIFY_EVERY")) S.verify_every = atoi(e) < 0 ? 0 : atoi(e);
     if (const char* e = getenv("EXL2_MODULE_CHAIN_ROWS")) { const int v = atoi(e); if (v >= 1 && v <= 16) S.max_rows = v; }
 }
 
@@ -246,6 +270,7 @@ void q_attn_forward_1(uintptr_t handle, const at::Tensor& x, int batch_size, int
                       const at::Tensor& q_temp, const at::Tensor& k_temp, const at::Tensor& v_temp, const at::Tensor& sin,
                       const at::Tensor& cos, const py::object& loras, const py::object& loras_temp)
 {
+    LOCKED;
     if (!loras.is_none() && py::len(loras) > 0) throw std::runtime_error("q_attn_forward_1: LoRA is out of scope of this build");
     void* h = (void*)handle;
     c10::OptionalDeviceGuard guard; if (x.is_cuda()) guard.reset_device(x.device());
@@ -279,6 +304,7 @@ void q_attn_forward_1(uintptr_t handle, const at::Tensor& x, int batch_size, int
 // that shape (the Python shim then takes the general route).
 py::object flash_attn_decode(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v, double softmax_scale)
 {
+    LOCKED;
     if (q.dim() != 4 || k.dim() != 4 || v.dim() != 4 || q.size(0) != 1 || k.size(0) != 1 || !q.is_contiguous() || !k.is_contiguous() || !v.is_contiguous()
         || q.scalar_type() != at::kHalf || k.scalar_type() != at::kHalf || v.scalar_type() != at::kHalf)
         return py::none();
@@ -326,6 +352,7 @@ py::object flash_attn_decode(const at::Tensor& q, const at::Tensor& k, const at:
 py::object flash_attn_kvcache_decode(const at::Tensor& q, const at::Tensor& k_cache, const at::Tensor& v_cache, const at::Tensor& k,
                                      const at::Tensor& v, const at::Tensor& cache_seqlens, const at::Tensor& block_table, double softmax_scale)
 {
+    LOCKED;
     for (const at::Tensor* t : {&q, &k_cache, &v_cache, &k, &v})
         if (!t->defined() || t->dim() != 4 || !t->is_contiguous() || t->scalar_type() != at::kHalf) return py::none();
     if (!cache_seqlens.defined() || !block_table.defined() || cache_seqlens.scalar_type() != at::kInt || block_table.scalar_type() != at::kInt
@@ -371,6 +398,7 @@ py::object flash_attn_kvcache_decode(const at::Tensor& q, const at::Tensor& k_ca
 void q_attn_forward_2(uintptr_t handle, const at::Tensor& x, const at::Tensor& attn_output, int batch_size, int q_len,
                       const py::object& loras, const py::object& loras_temp)
 {
+    LOCKED;
     if (!loras.is_none() && py::len(loras) > 0) throw std::runtime_error("q_attn_forward_2: LoRA is out of scope of this build");
     void* h = (void*)handle;
     c10::OptionalDeviceGuard guard; if (x.is_cuda()) guard.reset_device(x.device());
@@ -402,6 +430,7 @@ void q_attn_forward_2(uintptr_t handle, const at::Tensor& x, const at::Tensor& a
 
 void q_mlp_forward_(uintptr_t handle, const at::Tensor& x, const py::object& loras, const py::object& loras_temp)
 {
+    LOCKED;
     if (!loras.is_none() && py::len(loras) > 0) throw std::runtime_error("q_mlp_forward_: LoRA is out of scope of this build");
     void* h = (void*)handle;
     c10::OptionalDeviceGuard guard; if (x.is_cuda()) guard.reset_device(x.device());
@@ -433,6 +462,7 @@ void q_mlp_forward_(uintptr_t handle, const at::Tensor& x, const py::object& lor
 // that address is stale
 void note_write(const at::Tensor& t)
 {
+    LOCKED;
     if (!t.defined() || t.is_meta()) return;
     void* p = t.data_ptr();
     if (p == S.pub_x.ptr) drop_pending();
@@ -442,25 +472,29 @@ void note_write(const at::Tensor& t)
 
 void forget_module(uintptr_t handle)
 {
+    LOCKED;
     void* h = (void*)handle;
-    S.info.erase(h); S.succ.erase(h);
+    S.info.erase(h); S.succ.erase(h); S.edge_uses.erase(h); S.blocked.erase(h);
     for (auto it = S.succ.begin(); it != S.succ.end();) { if (it->second == h) it = S.succ.erase(it); else ++it; }
     drop_all();
 }
 
 py::dict stats(bool reset)
 {
+    LOCKED;
     py::dict d;
     d["chained"] = S.n_chained; d["published"] = S.n_published; d["plain"] = S.n_plain; d["attn_fast"] = S.n_attn_fast;
     d["verified"] = S.n_verified; d["declined"] = S.n_declined; d["on"] = S.on; d["max_rows"] = S.max_rows; d["known_successors"] = (long long)S.succ.size();
-    if (reset) { S.n_chained = S.n_published = S.n_plain = S.n_attn_fast = S.n_verified = S.n_declined = 0; }
+    d["verify_mismatch"] = S.n_mismatch; d["blocked_edges"] = (long long)S.blocked.size(); d["verify_first"] = S.verify_first; d["verify_every"] = S.verify_every;
+    if (reset) { S.n_chained = S.n_published = S.n_plain = S.n_attn_fast = S.n_verified = S.n_declined = S.n_mismatch = 0; }
     return d;
 }
 
 void set_chain(bool on) { S.on = on; drop_all(); }
 void set_verify(bool on) { S.verify = on; }
+void set_verify_sampling(int first, int every) { S.verify_first = first < 0 ? 0 : first; S.verify_every = every < 0 ? 0 : every; }
 void set_max_rows(int n) { if (n >= 1 && n <= 16) S.max_rows = n; drop_all(); }
-void reset() { drop_all(); S.succ.clear(); S.info.clear(); S.bufs.clear(); }
+void reset() { drop_all(); S.succ.clear(); S.info.clear(); S.bufs.clear(); S.edge_uses.clear(); S.blocked.clear(); S.warned = false; }
 
 }  // namespace
 
@@ -478,6 +512,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("stats", &stats, py::arg("reset") = false);
     m.def("set_chain", &set_chain);
     m.def("set_verify", &set_verify);
+    m.def("set_verify_sampling", &set_verify_sampling, py::arg("first"), py::arg("every"));
     m.def("set_max_rows", &set_max_rows);
     m.def("reset", &reset);
 }

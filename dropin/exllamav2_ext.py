@@ -123,6 +123,10 @@ if _fast is not None:
     def rope_(x, sin, cos, past_len, num_heads, head_dim, offsets, neox_style):
         _fast.note_write(x)
         return _e.rope_(x, sin, cos, past_len, num_heads, head_dim, offsets, neox_style)
+
+    def q_moe_mlp_forward_(q_moe_mlp, x):
+        _fast.note_write(x)
+        return _e.q_moe_mlp_forward_(q_moe_mlp, x)
 else:
     q_attn_forward_1 = _e.q_attn_forward_1
     q_attn_forward_2 = _e.q_attn_forward_2
@@ -133,6 +137,7 @@ else:
     rms_norm = _e.rms_norm
     rms_norm_ = _e.rms_norm_
     rope_ = _e.rope_
+    q_moe_mlp_forward_ = _e.q_moe_mlp_forward_
 
 
 def set_flash_attn_func():          # ext_qattn.cpp:256-259 is a no-op in the reference too
@@ -169,7 +174,6 @@ tp_attn_forward_ = _tp.tp_attn_forward_
 tp_attn_forward_paged_ = _tp.tp_attn_forward_paged_
 make_q_moe_mlp = _e.make_q_moe_mlp
 free_q_moe_mlp = _e.free_q_moe_mlp
-q_moe_mlp_forward_ = _e.q_moe_mlp_forward_
 fp16_to_fp8 = _e.fp16_to_fp8
 fp8_to_fp16 = _e.fp8_to_fp16
 cache_rotate = _e.cache_rotate

@@ -364,6 +364,38 @@ def test_inference_mode_tensors_and_the_self_check(be):
     host.close()
 
 
+def test_inference_mode_host_that_rewrites_the_residual_is_caught_by_the_default_sampling(be):
+    """Round-5 advisor finding: under torch.inference_mode() (the reference's forward, model.py:764) tensors carry no version counter,
+    so an in-place write between two module calls is invisible to the identity test.  The binding's DEFAULT self-check sampling
+    (first 8 uses of every learned hand-off, then every 256th) re-derives the hand-off from x and compares: a host that rewrites x
+    between attention and MLP of layer 1 on every token is caught at the first use, that edge is blocked for good, and the results
+    equal the un-chained route's for the same host."""
+    fast = load_fast(be)
+    fast.reset(); fast.set_verify(False); fast.set_verify_sampling(8, 256)
+    cfg = cfg_small(num_hidden_layers=2)
+    host = Host(be, fast, cfg, seed=13)
+
+    def rewrite(li, where, x):
+        if where == "attn->mlp" and li == 1:
+            x[..., ::2].mul_(0.5)                                # in place, invisible without a version counter
+        return x
+    host.between = rewrite
+    fast.set_chain(True); fast.stats(True)
+    with torch.inference_mode():
+        chained = host.run(TOKENS)
+    st = fast.stats(True)
+    fast.set_chain(False)
+    with torch.inference_mode():
+        plain = host.run(TOKENS)
+    fast.set_chain(True)
+    assert st["verify_mismatch"] == 1 and st["blocked_edges"] == 1 and st["chained"] > 0, st
+    for a, b in zip(chained, plain):
+        err = np.abs(a.astype(np.float64) - b)
+        assert np.all(err <= 6 * (0.03 + np.abs(b) * 2.0 ** -8)), float(err.max())
+    host.between = None
+    host.close()
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))
 def test_hosts_that_do_random_things_between_module_calls(be, seed):
     """Fuzz of the module chain's identity rules: between any two module calls of any token a host may do nothing, change x in place
@@ -415,19 +447,29 @@ def test_hosts_that_do_random_things_between_module_calls(be, seed):
         # rounds where it rounds, tests/test_chain.py::test_chain_decode_random_models.  A stale hand-off is a 25 % error or another
         # token's row: orders of magnitude beyond this)
         assert np.all(err <= 6 * (0.03 + np.abs(b) * 2.0 ** -8)), (i, float(err.max()), sorted(set(script.values())))
-    # the threshold does see a stale hand-off: a write that moves neither the version counter nor calls note_write (against the
-    # binding's contract) is served the old hand-off on the chained route and not on the plain one
+    # a write that moves neither the version counter nor calls note_write (against the binding's contract):
     if seed == 0:
         def sneaky(li, where, x):
             if where == "attn->mlp" and li == 0 and host.past == 2:
                 x.data[..., ::2].mul_(0.5)
             return x
         host.between = sneaky
-        a = host.run(tokens)
-        fast.set_chain(False)
-        b = host.run(tokens)
-        fast.set_chain(True)
-        worst = max(float((np.abs(u.astype(np.float64) - v) / (0.03 + np.abs(v) * 2.0 ** -8)).max()) for u, v in zip(a[2:], b[2:]))
-        assert worst > 6, worst
+
+        def worst_gap():
+            a = host.run(tokens)
+            fast.set_chain(False)
+            b = host.run(tokens)
+            fast.set_chain(True)
+            return max(float((np.abs(u.astype(np.float64) - v) / (0.03 + np.abs(v) * 2.0 ** -8)).max()) for u, v in zip(a[2:], b[2:]))
+        # (a) with the self-check sampling switched off it is served the old hand-off on the chained route and not on the plain one --
+        # the threshold above does see a stale hand-off
+        fast.reset(); fast.set_verify_sampling(0, 0)
+        assert worst_gap() > 6
+        # (b) with the DEFAULT sampling (the first 8 uses of every hand-off are re-derived from x and compared) it is caught on the spot:
+        # that call starts from the re-derived hand-off, the edge is never chained again, the results are the plain route's
+        fast.reset(); fast.set_verify_sampling(8, 256); fast.stats(True)
+        assert worst_gap() <= 6
+        st2 = fast.stats(True)
+        assert st2["verify_mismatch"] >= 1 and st2["blocked_edges"] >= 1, st2
     host.between = None
     host.close()
