@@ -60,6 +60,16 @@ def _decode_and_check(be, cfg, recipe, batch, steps=3, seed=0, act_order=True, e
     model.unload()
 
 
+def reference_yardstick() -> float:
+    """worst distance (in units of the model tolerance) of the reference's own kernel composition from the float64 oracle over the
+    128 random models of test_chain_decode_random_models -- measured by execution: tests/golden/reference_model_yardstick.json"""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_model_yardstick.json")) as f:
+        y = json.load(f)["random_models"]
+    assert y["n"] >= 128 and 1.0 <= y["worst"] < 8.0, y["worst"]
+    return float(y["worst"])
+
+
 @pytest.mark.parametrize("recipe", ["4.0bpw", "3.5bpw", "2.5bpw"])
 @pytest.mark.parametrize("batch", [1, 3])
 def test_chain_decode_equals_oracle(be, recipe, batch):
@@ -73,14 +83,16 @@ def test_chain_decode_random_models(be, seed, monkeypatch):
     not powers of two, 1-8 query heads per kv head, head_dim 64 / 128, every recipe (EXL2 2.5-4.0 bpw mixes, GPTQ), 1-16 sequences
     (<= 4 rows: the one-row forms; more: ROWS / XMEM forms and row groups), FP16 cache.
 
-    Two oracles.  OracleModel(rounding="chain") rounds to fp16 where the chained kernels round: the decoder must meet it at the MODEL
-    tolerance.  OracleModel() rounds where the reference's kernel composition rounds (the normalised row, gate and up before the
-    activation): 3 x the tolerance.  Why: over 128 such models (3 steps, <= 4 sequences) the worst |error| / tolerance against the
-    reference-rounding oracle has median 0.14 chained and 0.12 module by module, with a tail on BOTH routes -- 4 / 128 models above 1.0
-    (worst 2.03) chained, 2 / 128 (worst 1.62) module by module: single rows where attention over two keys amplifies one-ulp differences
-    in q and k.  For one of them (hidden 1024, GPTQ, two layers) the two oracles differ from EACH OTHER by 1.24 x the tolerance in that
-    logit and the device sits 0.18 x from the one that rounds where it rounds.  The chained kernel's weights are bit-exact on every K
-    index of such matrices (one-hot hunt over 12 random specs)."""
+    The bar is MEASURED, not asserted (round-5 review, item 5): tests/golden/reference_model_yardstick.json holds, for the same 128
+    model specs / weights / first tokens, how far the reference's OWN decode kernels -- gemm_half_q_half_kernel, rms_norm_kernel,
+    act_mul_kernel, rope, executed on the host and composed as q_attn.cu / q_mlp.cu compose them (oracle/ref_kernel_model.py;
+    generator: tests/golden/make_golden_model_yardstick.py) -- sit from this same float64 oracle in units of the model tolerance
+    0.03 + |x| 2^-8: median 0.32, 10 of 128 above 1.0, worst 4.09 (single rows where attention over one or two keys amplifies
+    one-ulp differences in q and k).  The device must be no farther from the reference-rounding oracle than the reference's own
+    kernels were at their worst; over the same 128 models it measures median 0.14, 4 above 1.0, worst 2.03 chained (0.12 / 2 /
+    1.62 module by module).  OracleModel(rounding="chain") -- fp16 roundings where OUR kernels have them -- stays as a diagnostic at
+    1 x the tolerance: it tells a rounding-point difference from a defect, it is not the bar."""
+    bar = reference_yardstick()
     rng = np.random.default_rng(17000 + seed)
     hd = int(rng.choice([64, 128]))
     kvh = int(rng.choice([1, 2, 4])); g = int(rng.choice([1, 2, 4, 8]))
@@ -92,10 +104,10 @@ def test_chain_decode_random_models(be, seed, monkeypatch):
                    num_key_value_heads=kvh, head_dim=hd, max_batch_size=16)
     act_order = not recipe.startswith("gptq") or bool(rng.integers(0, 2))
     _decode_and_check(be, cfg, recipe, batch, steps=2, seed=600 + seed, act_order=act_order, expect_chain=True, rounding="chain")
-    _decode_and_check(be, cfg, recipe, batch, steps=2, seed=600 + seed, act_order=act_order, expect_chain=True, logit_slack=3.0)
+    _decode_and_check(be, cfg, recipe, batch, steps=2, seed=600 + seed, act_order=act_order, expect_chain=True, logit_slack=bar)
     # ... and the module-by-module route (the kernels behind the plain operator calls) on the same model
     monkeypatch.setenv("EXL2_CHAIN", "0")
-    _decode_and_check(be, cfg, recipe, batch, steps=2, seed=600 + seed, act_order=act_order, expect_chain=False, logit_slack=3.0)
+    _decode_and_check(be, cfg, recipe, batch, steps=2, seed=600 + seed, act_order=act_order, expect_chain=False, logit_slack=bar)
 
 
 @pytest.mark.parametrize("recipe", ["4.0bpw", "3.5bpw"])
@@ -432,8 +444,9 @@ def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch, hd, launc
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "4")))))        # (more seeds: a longer hunt, by hand)
 def test_q4_cache_random_models(be, monkeypatch, seed):
     """Seeded random small models over the Q4 cache, head_dim 128 (the one-launch decode step; on odd seeds the two-launch form):
-    4 / 8 kv heads, 1-8 query heads per kv head, 1-4 sequences, every EXL2 recipe, both routes.  3 x the model tolerance and 3 x the
-    code-flip allowance: the oracle rounds where the reference's composition rounds (test_chain_decode_random_models)."""
+    4 / 8 kv heads, 1-8 query heads per kv head, 1-4 sequences, every EXL2 recipe, both routes.  The bar is the measured one of
+    test_chain_decode_random_models (how far the reference's own kernels sit from this oracle at their worst over 128 random models,
+    FP16 cache: 4.09 x the model tolerance -- a Q4 cache only adds a quantizer on top); the code-flip allowance scales with it."""
     rng = np.random.default_rng(29000 + seed)
     kvh = int(rng.choice([4, 8])); g = int(rng.choice([1, 2, 4, 8]))   # (kv width a multiple of the codec's 512-element block: the direct route)
     cfg = tiny_cfg(num_attention_heads=kvh * g, num_key_value_heads=kvh, head_dim=128, hidden_size=128 * int(rng.integers(1, 7)),
@@ -446,7 +459,7 @@ def test_q4_cache_random_models(be, monkeypatch, seed):
     # 8.8 x from the reference rounding and the module-by-module route 1.7 x, on the FP16 cache alike.  Such rows are
     # found by exactly that -- the oracle in both roundings (FP16 cache), step by step on the device's tokens -- and left out of the
     # logit / token checks from then on (they still run, their codes are still compared).
-    _q4_chain_case(be, monkeypatch, cfg, recipe, batch, steps=4, ck_seed=700 + seed, slack=3.0, rows_ok=np.ones((batch,), dtype=bool))
+    _q4_chain_case(be, monkeypatch, cfg, recipe, batch, steps=4, ck_seed=700 + seed, slack=reference_yardstick(), rows_ok=np.ones((batch,), dtype=bool))
 
 
 def test_row_groups_taken_by_different_kernels(be, monkeypatch):

@@ -433,3 +433,25 @@ def test_fixture_fp8_codec_and_cache_rotate_equal_oracle():
         lib = G.load()
         assert np.array_equal(G.reference_fp8(lib, 1)[0], fx["fp8_1_codes"])
         assert np.array_equal(G.digest(G.reference_rotate(lib, 1)), fx["rotate_1_sha"])
+
+
+# ---- the model-level yardstick: the reference's own kernel composition against the float64 oracle ---------------------------------------
+
+def test_model_yardstick_fixture_is_what_the_reference_kernels_measure_here():
+    """tests/golden/reference_model_yardstick.json (the bar of tests/test_chain.py::test_chain_decode_random_models) re-measured by
+    execution for three of its seeds -- one of them the worst of the 128 -- wherever oracle/_ref is built: the reference's
+    gemm_half_q_half_kernel / rms_norm_kernel / act_mul_kernel / rope composed into a forward (oracle/ref_kernel_model.py)."""
+    import json
+    from oracle import ref_kernel_model as RK
+    with open(os.path.join(ROOT, "tests", "golden", "reference_model_yardstick.json")) as f:
+        fx = json.load(f)["random_models"]
+    assert fx["n"] == 128 and fx["worst"] == max(max(v["ratio_bk32"], v["ratio_bk64"]) for v in fx["per_seed"].values())
+    if not RK.available():
+        pytest.skip("oracle/_ref not built here")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_model_yardstick as Y
+    worst_seed = max(fx["per_seed"], key=lambda k: max(fx["per_seed"][k]["ratio_bk32"], fx["per_seed"][k]["ratio_bk64"]))
+    for seed in (3, 98, int(worst_seed)):
+        got = Y.one_seed(seed)
+        want = fx["per_seed"][str(seed)]
+        assert got == want, (seed, got, want)
