@@ -2,7 +2,9 @@
 2.5.7`; attn.py:602-613 calls `flash_attn_with_kvcache` in paged mode, attn.py:960-977 `flash_attn_func` otherwise) run on
 MI355X without flash-attn, on top of libexl2_hip.so (`exl2_rope_kv_append`, `exl2_paged_attn`, `exl2_flash_prefill`:
 csrc/attn.hip, csrc/attn_prefill.hip).  Only the call shapes the reference uses are accepted; anything else raises instead of
-silently computing something different."""
+silently computing something different.  window_size (left part) and softcap -- the two keyword arguments the reference adds for
+Mistral / Gemma-type checkpoints (attn.py:590-600) -- are served by the general kernels (`exl2_paged_attn_ex`, `exl2_flash_prefill_ex`:
+a window that clips, a score cap); a window that cannot clip and no cap keep the one-launch decode route."""
 import torch
 
 from exllamav2_amd.ext import ext_c as _e
@@ -19,21 +21,25 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     if rotary_cos is not None or rotary_sin is not None or cache_batch_idx is not None or cache_leftpad is not None \
             or alibi_slopes is not None or return_softmax_lse:
         raise NotImplementedError("flash_attn shim: only the arguments exllamav2 passes are supported")
-    if softcap:
-        raise NotImplementedError("flash_attn shim: softcap is not built (SURVEY.md 8a row a15)")
-    # sliding window (attn.py:590-594 passes (W, W) for Mistral-family checkpoints): a window that cannot clip -- every key a query
-    # may see lies within W positions of it -- is plain causal attention; that is decided from HOST-side sizes (the table's capacity),
-    # never by reading cache_seqlens back.  A window that could clip is refused, not approximated.
-    if tuple(window_size) != (-1, -1):
+    # sliding window (attn.py:590-594 passes (W, W) for Mistral-family checkpoints; causal attention makes the right part moot): a
+    # window that cannot clip -- every key a query may see lies within W positions of it, decided from HOST-side sizes (the table's
+    # capacity), never by reading cache_seqlens back -- is plain causal attention and keeps the fast route; one that may clip goes to
+    # the general kernels with window_left = W
+    window_left = -1
+    if tuple(window_size) != (-1, -1) and window_size[0] >= 0:
         capacity = (block_table.shape[1] * k_cache.shape[1]) if block_table is not None else k_cache.shape[1]
-        if window_size[0] < 0 or capacity - 1 > window_size[0]:
-            raise NotImplementedError(f"flash_attn shim: sliding window {tuple(window_size)} over a cache of {capacity} positions would clip; "
-                                      "windowed attention is not built (SURVEY.md 8a row a15)")
+        if capacity - 1 > window_size[0]:
+            if not causal:
+                raise NotImplementedError("flash_attn shim: a sliding window without causal attention is not a call the reference makes")
+            window_left = int(window_size[0])
     if isinstance(cache_seqlens, int):
         cache_seqlens = torch.full((q.shape[0],), cache_seqlens, dtype=torch.int32, device=q.device)
     # decode-sized steps of the dynamic generator: append + attention + merge in ONE launch through the compiled binding (which also
     # leaves the act-ordered copy q_attn_forward_2's chained launch reads); everything else takes the general route
     fast = _fast()
+    if window_left >= 0 or softcap:
+        return _e.flash_attn_with_kvcache(q, k_cache, v_cache, k, v, cache_seqlens, block_table, causal, softmax_scale, None,
+                                          window_left, float(softcap or 0.0))
     if fast is not None and k is not None and v is not None and block_table is not None and causal and q.shape[1] <= 8:
         out = fast.flash_attn_kvcache_decode(q, k_cache, v_cache, k, v, cache_seqlens, block_table,
                                              float(q.shape[-1] ** -0.5 if softmax_scale is None else softmax_scale))
@@ -82,13 +88,13 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, wi
     rows) instead of the ~8 torch launches per layer of the reference's own `_attn_torch` fallback."""
     if dropout_p or alibi_slopes is not None or return_attn_probs:
         raise NotImplementedError("flash_attn shim: only the arguments exllamav2 passes are supported")
-    if softcap:
-        raise NotImplementedError("flash_attn shim: softcap is not built (SURVEY.md 8a row a15)")
     b, s, nh, hd = q.shape
     n = k.shape[1]
-    if tuple(window_size) != (-1, -1) and (window_size[0] < 0 or n - 1 > window_size[0]):     # (see flash_attn_with_kvcache)
-        raise NotImplementedError(f"flash_attn shim: sliding window {tuple(window_size)} over {n} keys would clip; windowed attention "
-                                  "is not built (SURVEY.md 8a row a15)")
+    window_left = -1
+    if tuple(window_size) != (-1, -1) and window_size[0] >= 0 and n - 1 > window_size[0]:     # (see flash_attn_with_kvcache)
+        if not causal:
+            raise NotImplementedError("flash_attn shim: a sliding window without causal attention is not a call the reference makes")
+        window_left = int(window_size[0])
     if not causal and s > 1:
         raise NotImplementedError("flash_attn shim: the kernels are causal (bottom-right aligned), like every call of the reference")
     if not q.is_contiguous():
@@ -98,13 +104,13 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, wi
     # csrc/attn.hip through the compiled binding, which also leaves the act-ordered copy q_attn_forward_2's chained launch reads
     # (dropin/_exl2_fast.cpp).  Anything else -- or a shape that kernel does not cover -- takes the general route below.
     fast = _fast()
-    if fast is not None and b == 1 and s <= 16:
+    if fast is not None and b == 1 and s <= 16 and window_left < 0 and not softcap:
         out = fast.flash_attn_decode(q, kf, vf, float(hd ** -0.5 if softmax_scale is None else softmax_scale))
         if out is not None:
             return out
     out = torch.empty_like(q)
-    if not (s > 16 and _e.flash_prefill(q, kf, vf, out, None, None, n - s, s, softmax_scale, True)):
-        _e.paged_attn(q, kf, vf, out, None, None, n - s, s, softmax_scale, True, 0, _split_scratch(q))
+    if not (s > 16 and _e.flash_prefill(q, kf, vf, out, None, None, n - s, s, softmax_scale, True, window_left, float(softcap or 0.0))):
+        _e.paged_attn(q, kf, vf, out, None, None, n - s, s, softmax_scale, True, 0, _split_scratch(q), window_left, float(softcap or 0.0))
     return out
 
 

@@ -9,13 +9,12 @@ def fwd_kvcache(q, k_cache, v_cache, k, v, cache_seqlens, rotary_cos, rotary_sin
                 block_table, alibi_slopes, out, softmax_scale, causal, window_left, window_right, softcap,
                 rotary_interleaved, num_splits):
     """Argument order of flash-attn 2.5.7+'s C++ entry as the reference calls it.  Returns [out, softmax_lse(None)]."""
-    if softcap:
-        raise NotImplementedError("flash_attn_2_cuda.fwd_kvcache shim: softcap is not built")
-    # (a window that cannot clip is accepted, one that could is refused: dropin/flash_attn/__init__.py)
+    # (a window that cannot clip keeps the one-launch route, one that may clip and softcap take the general kernels:
+    # dropin/flash_attn/__init__.py)
     window = (-1, -1) if (window_left < 0 and window_right in (-1, 0)) else (window_left, window_right)
     o = _fa(q, k_cache, v_cache, k=k, v=v, rotary_cos=rotary_cos, rotary_sin=rotary_sin, cache_seqlens=cache_seqlens,
             cache_batch_idx=cache_batch_idx, cache_leftpad=cache_leftpad, block_table=block_table,
-            softmax_scale=softmax_scale, causal=causal, window_size=window, alibi_slopes=alibi_slopes)
+            softmax_scale=softmax_scale, causal=causal, window_size=window, softcap=softcap or 0.0, alibi_slopes=alibi_slopes)
     if out is not None:
         out.copy_(o)
         o = out

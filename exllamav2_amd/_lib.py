@@ -60,6 +60,8 @@ PROTOTYPES = {
     "exl2_paged_attn_scratch_bytes": (cll, [ci, ci, ci]),
     "exl2_flash_prefill": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
     "exl2_paged_attn": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, vp, cll, vp]),
+    "exl2_paged_attn_ex": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, vp, cll, ci, cf, vp]),
+    "exl2_flash_prefill_ex": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, cf, vp]),
     "exl2_rope_kv_append": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, vp]),
     "exl2_attn_decode_fused": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci, ci, ci,
                                     vp, cll, vp, ci, vp, vp]),

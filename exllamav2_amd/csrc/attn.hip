@@ -40,6 +40,9 @@ struct AttnArgs
     int len_const, len_offset;    // total keys = (cache_seqlens ? cache_seqlens[b] : len_const) + len_offset
     int nsplit, causal;
     float scale;
+    // flash-attn's window_size = (window_left, .) and softcap (attn.py:590-600: Mistral / Gemma-type checkpoints): query at absolute
+    // position p sees keys [p - window_left, p] (window_left < 0: no window); scores = softcap * tanh(q.k * scale / softcap) (0: off)
+    int window_left; float softcap;
 };
 
 template <int LPK> DEV float group_allreduce_add(float v)
@@ -89,6 +92,17 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_decode_kernel(const AttnArgs 
         qf[r] = *(const f16x8*)(a.q + (((size_t)b * a.s + j) * a.H + kh * G + g) * HDIM + dl * 8);
         limit[r] = a.causal ? (total - a.s + j + 1) : total;
     }
+    // sliding window: row r sees keys >= lo[r]; keys below every row's bound are not even read (the split starts behind them)
+    int lo[RB], lo_min = 0x7fffffff;
+    #pragma unroll
+    for (int r = 0; r < RB; r++)
+    {
+        const int rr = r0 + (r < nrows ? r : 0);
+        const int pos = total - a.s + rr / G;                 // the query's absolute position
+        lo[r] = a.window_left >= 0 ? max(0, pos - a.window_left) : 0;
+        lo_min = min(lo_min, lo[r]);
+    }
+    const float cap = a.softcap, inv_cap = cap > 0.0f ? 1.0f / cap : 0.0f;
 
     float m[RB], l[RB], o[RB][8];
     #pragma unroll
@@ -100,7 +114,8 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_decode_kernel(const AttnArgs 
     }
 
     const size_t row_stride = (size_t)a.KVH * HDIM;          // elements between consecutive token slots
-    for (int base = k_start + wv * KPW; base < k_end; base += ATT_WAVES * KPW)
+    const int k_first = max(k_start, lo_min & ~(KPW - 1));   // (aligned down: the waves' key groups stay where they were)
+    for (int base = k_first + wv * KPW; base < k_end; base += ATT_WAVES * KPW)
     {
         const int kpos = base + group;
         const bool in_range = kpos < k_end;
@@ -125,8 +140,9 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_decode_kernel(const AttnArgs 
                 for (int e = 0; e < 4; e++)
                     d = dot2_f32_f16((f16x2){qf[r][2 * e], qf[r][2 * e + 1]}, (f16x2){kf[2 * e], kf[2 * e + 1]}, d);
                 d = group_allreduce_add<LPK>(d);
-                const float sc = d * a.scale;
-                const bool valid = in_range && kpos < limit[r];
+                float sc = d * a.scale;
+                if (cap > 0.0f) sc = cap * tanhf(sc * inv_cap);
+                const bool valid = in_range && kpos < limit[r] && kpos >= lo[r];
                 const float m_new = valid ? fmaxf(m[r], sc) : m[r];
                 const float alpha = fast_exp(m[r] - m_new);
                 const float p = valid ? fast_exp(sc - m_new) : 0.0f;
@@ -384,8 +400,10 @@ KERNEL void __launch_bounds__(ATT_WAVES * 64) attn_fused_kernel(const FusedArgs 
     if (a.block_table)
     {
         const int npg = (((k_end > k_start ? k_end : k_start + 1) - 1) >> a.page_shift) - pg0 + 1;
+        // (an EMPTY split -- k_start >= total once eff is clamped and kps rounded up -- may sit one page past the row: the index is clamped,
+        // the entry is never used; round-5 advisor finding)
         if (spec && npg == 1 && pg0 == 0) { if (tid() == 0) pg_lds[0] = tab_spec; }
-        else for (int i = tid(); i < npg; i += nthreads()) pg_lds[i] = a.block_table[(size_t)b * a.pages_per_seq + pg0 + i];
+        else for (int i = tid(); i < npg; i += nthreads()) pg_lds[i] = a.block_table[(size_t)b * a.pages_per_seq + min(pg0 + i, a.pages_per_seq - 1)];
         block_sync();
     }
     auto slot_of = [&](const int kp) -> size_t
@@ -730,13 +748,33 @@ long long exl2_paged_attn_scratch_bytes(int rows, int head_dim, int nsplit)
 // [b, page_size, KVH, hd]) fp16 KV cache that already holds all keys.  Keys per sequence = (cache_seqlens ?
 // cache_seqlens[i] : len_const) + len_offset; query token j attends keys [0, total - q_len + j + 1) when causal.
 // nsplit <= 0 picks a split count from the grid size.
+// window_left >= 0: flash-attn's sliding window (a query at absolute position p sees keys [p - window_left, p]); softcap > 0: scores =
+// softcap * tanh(q.k * scale / softcap) -- the two keyword arguments the reference passes for Mistral / Gemma-type checkpoints
+// (attn.py:590-600).
+int exl2_paged_attn_ex(const void* q, const void* k_cache, const void* v_cache, void* out,
+                       const int* cache_seqlens, const int* block_table,
+                       int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                       int page_size, int pages_per_seq, int len_const, int len_offset,
+                       float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
+                       int window_left, float softcap, void* stream);
 int exl2_paged_attn(const void* q, const void* k_cache, const void* v_cache, void* out,
                     const int* cache_seqlens, const int* block_table,
                     int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
                     int page_size, int pages_per_seq, int len_const, int len_offset,
                     float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes, void* stream)
 {
+    return exl2_paged_attn_ex(q, k_cache, v_cache, out, cache_seqlens, block_table, batch, q_len, num_heads, num_kv_heads, head_dim, page_size,
+                              pages_per_seq, len_const, len_offset, softmax_scale, causal, nsplit, scratch, scratch_bytes, -1, 0.0f, stream);
+}
+int exl2_paged_attn_ex(const void* q, const void* k_cache, const void* v_cache, void* out,
+                       const int* cache_seqlens, const int* block_table,
+                       int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                       int page_size, int pages_per_seq, int len_const, int len_offset,
+                       float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
+                       int window_left, float softcap, void* stream)
+{
     EXL2_REQUIRE(q && k_cache && v_cache && out, "paged_attn: null argument");
+    EXL2_REQUIRE(window_left < 0 || causal, "paged_attn: a sliding window needs causal attention");
     EXL2_REQUIRE(head_dim == 64 || head_dim == 128 || head_dim == 256, "paged_attn: head_dim %d unsupported (64/128/256)", head_dim);
     EXL2_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged_attn: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
     if (batch <= 0 || q_len <= 0) return EXL2_OK;
@@ -749,6 +787,7 @@ int exl2_paged_attn(const void* q, const void* k_cache, const void* v_cache, voi
     a.page_shift = ilog2_exact(page_size);
     EXL2_REQUIRE(!block_table || a.page_shift >= 0, "paged_attn: page_size %d must be a power of two", page_size);
     a.len_const = len_const; a.len_offset = len_offset; a.causal = causal; a.scale = softmax_scale;
+    a.window_left = window_left; a.softcap = softcap > 0.0f ? softcap : 0.0f;
 
     const int G = num_heads / num_kv_heads;
     const int R = q_len * G;

@@ -52,6 +52,7 @@ struct FlashArgs
     int len_const, len_offset;
     float scale;
     int causal;
+    int window_left; float softcap;     // flash-attn's window_size[0] (< 0: none) and softcap (0: off): csrc/attn.hip AttnArgs
 };
 
 
@@ -148,9 +149,12 @@ KERNEL void __launch_bounds__(FP_WAVES * 64, FP_OCC) flash_prefill_kernel(const 
     };
 
     // (the look-up runs two tiles ahead of the tile in use, the rows one tile ahead; a tile index past the end looks tile 0 up again)
-    size_t base_next = n_tiles > 1 ? tile_base(1) : 0;
-    if (n_tiles > 0) fetch(0, tile_base(0));
-    for (int tile = 0; tile < n_tiles; tile++)
+    // sliding window: every row of this workgroup sits at position >= qpos0 + q0, so no row sees a key below that minus the window
+    const int tile_lo = a.window_left >= 0 ? max(0, qpos0 + q0 - a.window_left) / FP_BK : 0;
+    const float cap = a.softcap, inv_cap = cap > 0.0f ? 1.0f / cap : 0.0f;
+    size_t base_next = n_tiles > tile_lo + 1 ? tile_base(tile_lo + 1) : 0;
+    if (n_tiles > tile_lo) fetch(tile_lo, tile_base(tile_lo));
+    for (int tile = tile_lo; tile < n_tiles; tile++)
     {
         block_sync();                                                         // everybody is done with the previous tile
         stage();
@@ -194,8 +198,10 @@ KERNEL void __launch_bounds__(FP_WAVES * 64, FP_OCC) flash_prefill_kernel(const 
                 for (int r = 0; r < 4; r++)
                 {
                     const int kpos = k0 + 16 * blk + 4 * g + r;
-                    const bool valid = kpos < total && (!a.causal || kpos <= qpos[n]);
-                    const float v = valid ? st[n][blk][r] * a.scale : FP_NEG_BIG;
+                    const bool valid = kpos < total && (!a.causal || kpos <= qpos[n]) && (a.window_left < 0 || kpos >= qpos[n] - a.window_left);
+                    float sv = st[n][blk][r] * a.scale;
+                    if (cap > 0.0f) sv = cap * tanhf(sv * inv_cap);
+                    const float v = valid ? sv : FP_NEG_BIG;
                     sc[blk * 4 + r] = v;
                     m_loc = fmaxf(m_loc, v);
                 }
@@ -260,11 +266,25 @@ extern "C" {
 
 // Prefill-shaped attention over the FP16 cache (see the header of this file).  Returns 1 (nothing launched) for a head_dim
 // outside {64, 128, 256}: the caller then uses exl2_paged_attn.
+int exl2_flash_prefill_ex(const void* q, const void* k_cache, const void* v_cache, void* out, const int* cache_seqlens,
+                          const int* block_table, int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                          int page_size, int pages_per_seq, int len_const, int len_offset, float softmax_scale, int causal,
+                          int window_left, float softcap, void* stream);
 int exl2_flash_prefill(const void* q, const void* k_cache, const void* v_cache, void* out, const int* cache_seqlens,
                        const int* block_table, int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
                        int page_size, int pages_per_seq, int len_const, int len_offset, float softmax_scale, int causal,
                        void* stream)
 {
+    return exl2_flash_prefill_ex(q, k_cache, v_cache, out, cache_seqlens, block_table, batch, q_len, num_heads, num_kv_heads, head_dim, page_size,
+                                 pages_per_seq, len_const, len_offset, softmax_scale, causal, -1, 0.0f, stream);
+}
+// the same with flash-attn's sliding window and softcap (exl2_paged_attn_ex, csrc/attn.hip)
+int exl2_flash_prefill_ex(const void* q, const void* k_cache, const void* v_cache, void* out, const int* cache_seqlens,
+                          const int* block_table, int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                          int page_size, int pages_per_seq, int len_const, int len_offset, float softmax_scale, int causal,
+                          int window_left, float softcap, void* stream)
+{
+    EXL2_REQUIRE(window_left < 0 || causal, "flash_prefill: a sliding window needs causal attention");
     EXL2_REQUIRE(q && k_cache && v_cache && out, "flash_prefill: null argument");
     EXL2_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "flash_prefill: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
     if (batch <= 0 || q_len <= 0) return EXL2_OK;
@@ -275,8 +295,10 @@ int exl2_flash_prefill(const void* q, const void* k_cache, const void* v_cache, 
     a.cache_seqlens = cache_seqlens; a.block_table = block_table;
     a.b = batch; a.s = q_len; a.H = num_heads; a.KVH = num_kv_heads;
     a.page_size = page_size; a.pages_per_seq = pages_per_seq; a.page_shift = fp_ilog2_exact(page_size);
-    EXL2_REQUIRE(!block_table || (a.page_shift >= 0 && page_size >= FP_BK), "flash_prefill: page_size %d must be a power of two >= %d", page_size, FP_BK);
+    EXL2_REQUIRE(!block_table || a.page_shift >= 0, "flash_prefill: page_size %d must be a power of two", page_size);
+    if (block_table && page_size < FP_BK) return 1;            // (a tile of FP_BK keys must not straddle a page: not covered, the caller takes exl2_paged_attn)
     a.len_const = len_const; a.len_offset = len_offset; a.scale = softmax_scale; a.causal = causal;
+    a.window_left = window_left; a.softcap = softcap > 0.0f ? softcap : 0.0f;
     dim3 grid((unsigned)((q_len + FP_BQ - 1) / FP_BQ), (unsigned)num_heads, (unsigned)batch);
     const size_t lds = ((size_t)FP_BK * (head_dim + 8) + (size_t)FP_BK * (head_dim + 16)) * sizeof(f16);
     {

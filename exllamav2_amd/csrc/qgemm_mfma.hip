@@ -560,6 +560,7 @@ int qgemm_mfma_launch(const PrefillArgs& p, bool gptq, void* stream)
             const size_t bytes = (size_t)nb_n * (size_t)(2 * supers) * MF_W_STAGE;
             size_t cap = (size_t)1 << 30;
             if (const char* e = getenv("EXL2_PREFILL_WPRE_MAX_BYTES")) cap = (size_t)strtoull(e, nullptr, 10);
+            if (cap >= ((size_t)1 << 31)) cap = ((size_t)1 << 31) - 1;      // (the W stages are filled by buffer loads: a 2 GB window)
             const bool fits = bytes <= cap && prefill_scratch(bytes, stream, 1, &buf) == EXL2_OK;
             if (!fits) { exl2_set_error("%s", ""); buf = nullptr; }
             if (buf)

@@ -641,7 +641,12 @@ int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stre
     for (int i = 0; i < n_jobs; i++) if (jobs[i].m.K > k_max) k_max = jobs[i].m.K;
     int mfma_min_rows = PF_MFMA_MIN_ROWS;
     if (const char* e = getenv("EXL2_PREFILL_MFMA_MIN_ROWS")) mfma_min_rows = atoi(e);      // tests / A-B runs (0 = never)
-    const int chunk = M < PF_ROW_CHUNK ? M : PF_ROW_CHUNK;
+    int chunk = M < PF_ROW_CHUNK ? M : PF_ROW_CHUNK;
+    // qgemm_mfma.hip fills its stages with BUFFER loads (u32 byte offsets into a 2 GB window over the staged rows): a chunk's
+    // (rows + 256) x K x 2 bytes must stay below 2^31, or out-of-range pieces would read zeros silently (round-5 advisor finding;
+    // K > ~64.5 k at the default chunk).  The chunk shrinks instead of the route changing.
+    while ((size_t)(chunk + 256) * (size_t)k_max * 2 >= ((size_t)1 << 31) && chunk > 256) chunk = (chunk / 2 + 255) & ~255;
+    EXL2_REQUIRE((size_t)(chunk + 256) * (size_t)k_max * 2 < ((size_t)1 << 31), "prefill: K = %d is too wide for the staged-row window", k_max);
     f16* stage = nullptr;
     // + 256 rows: qgemm_mfma.hip reads whole row blocks (rows >= M hold stale values, feed only rows that are never stored)
     { const int rc = stage_scratch((size_t)(chunk + 256) * k_max * 2, stream, &stage); if (rc) return rc; }

@@ -53,6 +53,9 @@
 #define LEAN_RAW2 1                   // 4-bit items: the matrix cores get the UN-subtracted codes (half2 1024 + q / 64 + q: one v_and_or_b32 per pair, no
 #endif                                // v_pk_add / v_pk_fma) and the constant part leaves through a second MFMA per chunk against a constant B fragment
                                       // -(1024 + z) / -(64 + z): 20 vector instructions per item instead of 50, no pre-pass (round 6; A/B in profiles/r06_raw2_ab.txt)
+#ifndef LEAN_ITEM_FENCE
+#define LEAN_ITEM_FENCE 1             // a scheduling fence behind every item's decode (register pressure); 0: the compiler may interleave items (A/B experiment)
+#endif
 #ifndef LEAN_BUF_DMA
 #define LEAN_BUF_DMA 1                // the wave-private staging copies in the buffer form (hw.h: dma_buf_to_lds16): counted waits stay exact
 #endif
@@ -701,7 +704,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         auto item = [&](const LaneWords<BITS>& w, int q) {
             if (R.uni) lean_item_uniform<BITS, GPTQ>(w, R.cx, R.chunk0 + 4 * q, R.g0 + ((4 * q + R.gphase) >> R.gshift), lane, acc);
             else lean_item_general<BITS, GPTQ>(w, R.cx, R.chunk0 + 4 * q, 4 * q, R.g0, R.gshift, R.gphase, 4, lane, acc);
-            sched_fence();
+            if (LEAN_ITEM_FENCE) sched_fence();
         };
         // (shares of several register loads; returns true when it took the share)
         auto ring_passes = [&](auto on_tag) -> bool {

@@ -357,35 +357,38 @@ class ExtC:
         return int(self.lib.exl2_paged_attn_scratch_bytes(rows, head_dim, nsplit))
 
     def paged_attn(self, q, k_cache, v_cache, out, cache_seqlens, block_table, len_const: int = 0, len_offset: int = 0,
-                   softmax_scale: float | None = None, causal: bool = True, nsplit: int = 0, scratch=None) -> None:
-        """q [b, s, H, hd]; caches [pages, page_size, KVH, hd] (block_table [b, pages]) or [b, T, KVH, hd] (no table)."""
+                   softmax_scale: float | None = None, causal: bool = True, nsplit: int = 0, scratch=None,
+                   window_left: int = -1, softcap: float = 0.0) -> None:
+        """q [b, s, H, hd]; caches [pages, page_size, KVH, hd] (block_table [b, pages]) or [b, T, KVH, hd] (no table).
+        window_left / softcap: flash-attn's window_size[0] and softcap (attn.py:590-600); -1 / 0 = off."""
         b, s, nh, hd = q.shape
         kvh = k_cache.shape[2]
         page_size = k_cache.shape[1]
         pps = 0 if _is_none(block_table) else block_table.shape[1]
         scale = hd ** -0.5 if softmax_scale is None else softmax_scale
         sb = 0 if scratch is None else scratch.numel() * scratch.element_size()
-        self.lib.check(self.lib.exl2_paged_attn(
+        self.lib.check(self.lib.exl2_paged_attn_ex(
             self._ptr(q, torch.float16, "q"), self._ptr(k_cache, torch.float16, "k_cache"),
             self._ptr(v_cache, torch.float16, "v_cache"), self._ptr(out, torch.float16, "out"),
             self._ptr(cache_seqlens, torch.int32, "cache_seqlens"), self._ptr(block_table, torch.int32, "block_table"),
             b, s, nh, kvh, hd, page_size, pps, int(len_const), int(len_offset), float(scale), int(causal), int(nsplit),
-            self._ptr(scratch), sb, self._stream(q)))
+            self._ptr(scratch), sb, int(window_left), float(softcap or 0.0), self._stream(q)))
 
     def flash_prefill(self, q, k_cache, v_cache, out, cache_seqlens, block_table, len_const: int = 0, len_offset: int = 0,
-                      softmax_scale: float | None = None, causal: bool = True) -> bool:
+                      softmax_scale: float | None = None, causal: bool = True, window_left: int = -1, softcap: float = 0.0) -> bool:
         """csrc/attn_prefill.hip: paged_attn's contract for many query rows (MFMA flash attention).  False when the head
-        size is outside {64, 128, 256} (nothing launched)."""
+        size is outside {64, 128, 256} or the pages are shorter than a 64-key tile (nothing launched)."""
         b, s, nh, hd = q.shape
         kvh = k_cache.shape[2]
         page_size = k_cache.shape[1]
         pps = 0 if _is_none(block_table) else block_table.shape[1]
         scale = hd ** -0.5 if softmax_scale is None else softmax_scale
-        rc = self.lib.check(self.lib.exl2_flash_prefill(
+        rc = self.lib.check(self.lib.exl2_flash_prefill_ex(
             self._ptr(q, torch.float16, "q"), self._ptr(k_cache, torch.float16, "k_cache"),
             self._ptr(v_cache, torch.float16, "v_cache"), self._ptr(out, torch.float16, "out"),
             self._ptr(cache_seqlens, torch.int32, "cache_seqlens"), self._ptr(block_table, torch.int32, "block_table"),
-            b, s, nh, kvh, hd, page_size, pps, int(len_const), int(len_offset), float(scale), int(causal), self._stream(q)))
+            b, s, nh, kvh, hd, page_size, pps, int(len_const), int(len_offset), float(scale), int(causal), int(window_left),
+            float(softcap or 0.0), self._stream(q)))
         return rc == 0
 
     def paged_attn_q4(self, q, k_codes, k_scales, v_codes, v_scales, out, cache_seqlens, block_table, len_const: int = 0,
@@ -488,18 +491,17 @@ class ExtC:
         return rc == 0
 
     def flash_attn_with_kvcache(self, q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, block_table=None,
-                                causal: bool = True, softmax_scale: float | None = None, scratch=None):
-        """Drop-in for flash_attn.flash_attn_with_kvcache as the reference calls it (attn.py:602-613)."""
+                                causal: bool = True, softmax_scale: float | None = None, scratch=None,
+                                window_left: int = -1, softcap: float = 0.0):
+        """Drop-in for flash_attn.flash_attn_with_kvcache as the reference calls it (attn.py:602-613; window_size[0] / softcap: :590-600)."""
         out = torch.empty_like(q)
         s = q.shape[1]
+        off = s if k is not None else 0
         if k is not None:
             self.rope_kv_append(q, k, v, k_cache, v_cache, none_tensor, none_tensor, 0, cache_seqlens, block_table, 0)
-            # many query rows (prefill chunks): MFMA flash attention; decode-shaped: the split-KV kernel
-            if not (s > 16 and self.flash_prefill(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, s, softmax_scale, causal)):
-                self.paged_attn(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, s, softmax_scale, causal, 0, scratch)
-        else:
-            if not (s > 16 and self.flash_prefill(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, 0, softmax_scale, causal)):
-                self.paged_attn(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, 0, softmax_scale, causal, 0, scratch)
+        # many query rows (prefill chunks): MFMA flash attention; decode-shaped: the split-KV kernel
+        if not (s > 16 and self.flash_prefill(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, off, softmax_scale, causal, window_left, softcap)):
+            self.paged_attn(q, k_cache, v_cache, out, cache_seqlens, block_table, 0, off, softmax_scale, causal, 0, scratch, window_left, softcap)
         return out
 
     # ---- fused modules (ext_qattn.cpp, ext_qmlp.cpp) -------------------------------------------------------------------

@@ -130,6 +130,15 @@ int exl2_paged_attn(const void* q, const void* k_cache, const void* v_cache, voi
                     int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
                     int page_size, int pages_per_seq, int len_const, int len_offset,
                     float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes, void* stream);
+/* the same with the two keyword arguments the reference passes to flash-attn for Mistral / Gemma-type checkpoints (attn.py:590-600):
+   window_left >= 0 = flash-attn's window_size[0] (a query at absolute position p sees keys [p - window_left, p]; < 0: no window; needs
+   causal), softcap > 0: scores = softcap * tanh(q.k * scale / softcap) (0: off).  Replaces attn.py:905-933's softcap_ + window slicing. */
+int exl2_paged_attn_ex(const void* q, const void* k_cache, const void* v_cache, void* out,
+                       const int* cache_seqlens, const int* block_table,
+                       int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                       int page_size, int pages_per_seq, int len_const, int len_offset,
+                       float softmax_scale, int causal, int nsplit, void* scratch, long long scratch_bytes,
+                       int window_left, float softcap, void* stream);
 /* the same contract for prefill-shaped steps (many query rows per sequence): MFMA flash attention, csrc/attn_prefill.hip
    (replaces _attn_torch's SDPA / matmul route, attn.py:869-937, and flash_attn_func, attn.py:960-977).  Returns 1 (nothing
    launched) for a head_dim outside {64, 128, 256}. */
@@ -138,6 +147,13 @@ int exl2_flash_prefill(const void* q, const void* k_cache, const void* v_cache, 
                        int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
                        int page_size, int pages_per_seq, int len_const, int len_offset,
                        float softmax_scale, int causal, void* stream);
+/* ... with the sliding window and softcap of exl2_paged_attn_ex; returns 1 (nothing launched) also for a paged cache whose pages are
+   shorter than one 64-key tile */
+int exl2_flash_prefill_ex(const void* q, const void* k_cache, const void* v_cache, void* out,
+                          const int* cache_seqlens, const int* block_table,
+                          int batch, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                          int page_size, int pages_per_seq, int len_const, int len_offset,
+                          float softmax_scale, int causal, int window_left, float softcap, void* stream);
 /* RoPE(q, k_new) in place + append of k_new / v_new into the (paged) cache at device-side positions */
 int exl2_rope_kv_append(void* q, void* k_new, const void* v_new, void* k_cache, void* v_cache,
                         const void* sin, const void* cos, int batch, int q_len, int num_heads, int num_kv_heads,

@@ -113,8 +113,14 @@ def silu_mul(gate: np.ndarray, up: np.ndarray) -> np.ndarray:
 # attention (attn.py:905-933 semantics, fp32 softmax like SDPA / flash-attn)
 # ----------------------------------------------------------------------------------------------------------------------
 
-def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, scale: float | None = None) -> np.ndarray:
-    """q [b, sq, H, hd], k/v [b, sk, KVH, hd] fp16, causal bottom-right aligned, GQA by head repetition."""
+def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, scale: float | None = None, window_left: int = -1,
+              softcap: float = 0.0) -> np.ndarray:
+    """q [b, sq, H, hd], k/v [b, sk, KVH, hd] fp16, causal bottom-right aligned, GQA by head repetition.
+    softcap (attn.py:919-920 -> ext_c.softcap_, applied to the SCALED scores before the mask; flash-attn's `softcap` keyword,
+    attn.py:596-600): s = softcap * tanh(s / softcap).  window_left (flash-attn's window_size[0], attn.py:590-594): the query at
+    absolute position p sees keys [p - window_left, p] -- for a decode step that is the reference's own torch route up to its
+    off-by-one (attn.py:924-926 keeps the last `sliding_window` keys = window_left + 1 of them with window_left = W - 1; the
+    flash-attn call it prefers passes (W, W))."""
     b, sq, nh, hd = q.shape
     sk, kvh = k.shape[1], k.shape[2]
     g = nh // kvh
@@ -124,9 +130,13 @@ def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, scale: float | None =
         for hi in range(nh):
             kh = hi // g
             s = (q[bi, :, hi, :].astype(F64) @ k[bi, :, kh, :].astype(F64).T) * scale      # [sq, sk]
+            if softcap:
+                s = softcap * np.tanh(s / softcap)
             qi = np.arange(sq)[:, None]
             ki = np.arange(sk)[None, :]
             s = np.where(ki <= qi + (sk - sq), s, -np.inf)
+            if window_left >= 0:
+                s = np.where(ki >= qi + (sk - sq) - window_left, s, -np.inf)
             s = s - s.max(axis=-1, keepdims=True)
             p = np.exp(s)
             p = p / p.sum(axis=-1, keepdims=True)

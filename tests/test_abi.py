@@ -95,8 +95,10 @@ def test_unmodified_reference_imports_on_top_of_the_dropin():
     assert json.loads(out.stdout.strip().splitlines()[-1]) == []
 
 
-def test_flash_attn_shim_window_that_cannot_clip_is_causal_attention_and_one_that_could_is_refused():
-    """attn.py:590-594: Mistral-family checkpoints pass window_size = (W, W).  The shim decides from host-side sizes only."""
+def test_flash_attn_shim_window_and_softcap_reach_the_kernels():
+    """attn.py:590-600: Mistral / Gemma-family checkpoints pass window_size = (W, W) / softcap.  The shim decides from host-side sizes
+    only whether a window can clip; round 6: a clipping window and a cap go to the general kernels (tests/test_ops.py::
+    test_flash_attn_shim_window_and_softcap checks the numbers) -- which refuse CPU tensors: there is no CPU path."""
     import importlib.util, sys, types
     import torch
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -105,10 +107,12 @@ def test_flash_attn_shim_window_that_cannot_clip_is_causal_attention_and_one_tha
     spec.loader.exec_module(mod)
     q = torch.zeros((1, 1, 2, 64), dtype=torch.float16)
     k = torch.zeros((1, 9, 1, 64), dtype=torch.float16)
-    with pytest.raises(NotImplementedError, match="would clip"):
+    with pytest.raises(RuntimeError, match="no CPU path|HIP device"):
         mod.flash_attn_func(q, k, k, causal=True, window_size=(4, 4))
-    with pytest.raises(NotImplementedError, match="softcap"):
+    with pytest.raises(RuntimeError, match="no CPU path|HIP device"):
         mod.flash_attn_func(q, k, k, causal=True, softcap=30.0)
+    with pytest.raises(NotImplementedError, match="without causal"):
+        mod.flash_attn_func(q, k, k, causal=False, window_size=(4, 4))
     # a window of 4096 over 9 keys cannot clip: the call goes on to the kernels (which refuse CPU tensors -- there is no CPU path)
     with pytest.raises(RuntimeError, match="no CPU path|HIP device"):
         mod.flash_attn_func(q, k, k, causal=True, window_size=(4096, 4096))

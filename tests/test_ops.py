@@ -258,6 +258,79 @@ def test_attention_contiguous(be, hd, nh, kvh, s):
         assert np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want)), nsplit
 
 
+@pytest.mark.parametrize("hd,nh,kvh,s,past,window,cap", [(128, 4, 4, 1, 70, 16, 0.0), (128, 8, 2, 1, 70, 5, 3.0), (64, 4, 1, 3, 90, 33, 0.0),
+                                                         (128, 2, 1, 5, 60, -1, 4.0), (128, 4, 2, 70, 100, 40, 0.0), (64, 4, 2, 130, 7, 64, 3.0),
+                                                         (128, 2, 2, 200, 0, 17, 0.0), (256, 2, 1, 40, 30, -1, 2.0)])
+def test_attention_sliding_window_and_softcap(be, hd, nh, kvh, s, past, window, cap):
+    """flash-attn's window_size[0] and softcap (the keyword arguments the reference adds for Mistral / Gemma-type checkpoints,
+    attn.py:590-600) on the general kernels: decode-shaped (exl2_paged_attn_ex, one and several splits, splits that lie wholly in
+    front of the window) and prefill-shaped (exl2_flash_prefill_ex: key tiles in front of a workgroup's window are not even fetched,
+    rows whose first visible key sits mid-tile).  Checker: the fp64 oracle with the same two arguments (oracle/modules.py:attention)."""
+    rng = np.random.default_rng(hd + s + past)
+    b, T = 2, past + s + 9
+    q = (2.0 * rng.standard_normal((b, s, nh, hd))).astype(F16)           # (scores large enough for the cap to bite)
+    k = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    v = rng.standard_normal((b, T, kvh, hd)).astype(F16)
+    total = past + s
+    want = OM.attention(q, k[:, :total], v[:, :total], window_left=window, softcap=cap)
+    plain = OM.attention(q, k[:, :total], v[:, :total])
+    assert np.abs(want.astype(np.float32) - plain.astype(np.float32)).max() > 0.05          # (the arguments do something in every case)
+    if s <= 16:
+        for nsplit in (1, 3, 7):
+            out = torch.full((b, s, nh, hd), 77.0, dtype=torch.float16, device=be.device)
+            scratch = torch.zeros((be.ext.paged_attn_scratch_bytes(b * s * nh, hd, nsplit) // 4 + 1,), dtype=torch.float32, device=be.device)
+            be.ext.paged_attn(be.t(q), be.t(k), be.t(v), out, None, None, len_const=past, len_offset=s, nsplit=nsplit, scratch=scratch,
+                              window_left=window, softcap=cap)
+            err = np.abs(be.n(out).astype(np.float32) - want.astype(np.float32))
+            assert np.all(err <= _attn_tol(want)), (nsplit, float(err.max()))
+    else:
+        out = torch.full((b, s, nh, hd), 77.0, dtype=torch.float16, device=be.device)
+        assert be.ext.flash_prefill(be.t(q), be.t(k), be.t(v), out, None, None, len_const=past, len_offset=s, window_left=window, softcap=cap)
+        err = np.abs(be.n(out).astype(np.float32) - want.astype(np.float32))
+        assert np.all(err <= _attn_tol(want)), float(err.max())
+
+
+def test_flash_attn_shim_window_and_softcap(be):
+    """The flash-attn stand-in (dropin/flash_attn) with the reference's keyword arguments: a window that clips and a score cap reach the
+    general kernels (round 5 raised); a window that cannot clip keeps the plain route.  Paged call with append + the non-paged call."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("flash_attn_shim_ws", os.path.join(root, "dropin", "flash_attn", "__init__.py"))
+    FA = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(FA)
+    FA._e = be.ext                                                    # (the emulation build's binding here, libexl2_hip.so's under -m gpu)
+    rng = np.random.default_rng(77)
+    hd, nh, kvh, ps = 128, 4, 2, 256
+    # paged decode step, 300 cached tokens, window 64, cap 3
+    b, s = 2, 1
+    seqlens = np.array([300, 270], dtype=np.int32)
+    table = np.array([[1, 3], [2, 0]], dtype=np.int32)
+    kc = rng.standard_normal((4, ps, kvh, hd)).astype(F16); vc = rng.standard_normal((4, ps, kvh, hd)).astype(F16)
+    q = (2.0 * rng.standard_normal((b, s, nh, hd))).astype(F16)
+    kn = rng.standard_normal((b, s, kvh, hd)).astype(F16); vn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
+    kct, vct = be.t(kc), be.t(vc)
+    got = FA.flash_attn_with_kvcache(be.t(q), kct, vct, k=be.t(kn), v=be.t(vn), cache_seqlens=be.t(seqlens), block_table=be.t(table),
+                                     causal=True, window_size=(64, 64), softcap=3.0)
+    for i in range(b):
+        n = int(seqlens[i])
+        kk = np.concatenate([kc[table[i]].reshape(-1, kvh, hd)[:n], kn[i]], 0)[None]
+        vv = np.concatenate([vc[table[i]].reshape(-1, kvh, hd)[:n], vn[i]], 0)[None]
+        want = OM.attention(q[i:i + 1], kk, vv, window_left=64, softcap=3.0)
+        err = np.abs(be.n(got)[i:i + 1].astype(np.float32) - want.astype(np.float32))
+        assert np.all(err <= _attn_tol(want)), (i, float(err.max()))
+    # non-paged prompt of 90 rows over 40 cached, window 32
+    s, past = 90, 40
+    q = rng.standard_normal((1, s, nh, hd)).astype(F16)
+    k = rng.standard_normal((1, past + s, kvh, hd)).astype(F16); v = rng.standard_normal((1, past + s, kvh, hd)).astype(F16)
+    got = FA.flash_attn_func(be.t(q), be.t(k), be.t(v), causal=True, window_size=(32, 32))
+    want = OM.attention(q, k, v, window_left=32)
+    assert np.all(np.abs(be.n(got).astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want))
+    # a window that cannot clip is plain causal attention
+    got = FA.flash_attn_func(be.t(q), be.t(k), be.t(v), causal=True, window_size=(4096, 4096))
+    want = OM.attention(q, k, v)
+    assert np.all(np.abs(be.n(got).astype(np.float32) - want.astype(np.float32)) <= _attn_tol(want))
+
+
 @pytest.mark.parametrize("hd,nh,kvh,s,past", [(128, 4, 2, 70, 0), (128, 2, 2, 64, 37), (64, 4, 1, 33, 5), (256, 2, 1, 20, 0),
                                               (128, 4, 4, 130, 3)])
 def test_flash_prefill_contiguous(be, hd, nh, kvh, s, past):
