@@ -382,6 +382,10 @@ DEV u64 cycle_stamp() { return __builtin_amdgcn_s_memtime(); }
 // constant 100 MHz counter shared by all XCDs (10 ns ticks): timelines across workgroups in the EXL2_TRACE build
 DEV u64 realtime_stamp() { return __builtin_amdgcn_s_memrealtime(); }
 
+// a numbered comment in the generated code: keeps identical code sequences of two template instantiations apart (tail merging would
+// join their pending-register sets, qgemv_lean.hip) and gives tests/test_lean_isa.py its landmarks
+#define ASM_MARK(id) asm volatile("; lean mark %0" :: "n"(id))
+
 // scheduling fence: keeps the compiler from interleaving the decode of consecutive super-chunks (register pressure)
 DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

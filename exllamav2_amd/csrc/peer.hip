@@ -18,16 +18,11 @@ int exl2_memcpy_2d_async(void* dst, long long dpitch, const void* src, long long
     EXL2_REQUIRE(dst && src && dpitch >= width_bytes && spitch >= width_bytes && width_bytes >= 0 && height >= 0,
                  "memcpy_2d_async: bad argument");
     if (width_bytes == 0 || height == 0) return EXL2_OK;
-#ifdef EXL2_EMU
-    (void)stream;
-    for (long long r = 0; r < height; r++) memcpy((char*)dst + r * dpitch, (const char*)src + r * spitch, (size_t)width_bytes);
-#else
     if (dpitch == width_bytes && spitch == width_bytes)
         HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(width_bytes * height), hipMemcpyDefault, (hipStream_t)stream));
     else
         HIP_TRY(hipMemcpy2DAsync(dst, (size_t)dpitch, src, (size_t)spitch, (size_t)width_bytes, (size_t)height, hipMemcpyDefault,
                                  (hipStream_t)stream));
-#endif
     return EXL2_OK;
 }
 
@@ -36,9 +31,6 @@ int exl2_memcpy_2d_async(void* dst, long long dpitch, const void* src, long long
 int exl2_enable_peer_access(const int* devices, int n)
 {
     EXL2_REQUIRE(n >= 0 && (n == 0 || devices), "enable_peer_access: bad argument");
-#ifdef EXL2_EMU
-    return 0;
-#else
     int prev = 0, unreachable = 0;
     HIP_TRY(hipGetDevice(&prev));
     for (int i = 0; i < n; i++)
@@ -57,7 +49,6 @@ int exl2_enable_peer_access(const int* devices, int n)
     }
     HIP_TRY(hipSetDevice(prev));
     return unreachable;
-#endif
 }
 
 }

@@ -66,11 +66,7 @@
 #define LEAN_DMA_X(base, off_bytes, lds) dma_to_lds16((const u8*)(base) + (size_t)(off_bytes), lds)
 #define LEAN_DMA(base, off_bytes, lds) dma_to_lds16((const u8*)(base) + (size_t)(off_bytes), lds)
 #endif
-#ifndef EXL2_EMU
-#define LEAN_MARK(id) asm volatile("; lean mark %0" :: "n"(id))
-#else
-#define LEAN_MARK(id) do { } while (0)
-#endif
+#define LEAN_MARK(id) ASM_MARK(id)     // (hw.h: a numbered comment in the gfx950 code; the emulation twin's hw_emu.h makes it nothing)
 #ifndef LEAN_XMEM_AHEAD
 #define LEAN_XMEM_AHEAD 3             // XMEM form: items whose A operands are in registers or in flight (16 registers each)
 #endif
@@ -385,11 +381,7 @@ DEV void lean_xmem_request(const LeanCtx& cx, int chunk, int nvalid, int lane, f
 // Geometry (template): S = waves per tile (8 / 16), NSLOTS = tiles per workgroup (1 / 2), PAIR = the two tiles are tile u of
 // matrix 0 (gate) and of matrix 1 (up) and the epilogue writes act(gate) * up.  Otherwise blockIdx.y = matrix.
 // OCC = waves per SIMD the register allocation leaves room for.
-#ifndef EXL2_EMU
 #define LEAN_BOUNDS(T, OCC) __launch_bounds__(T, OCC)
-#else
-#define LEAN_BOUNDS(T, OCC)
-#endif
 // ROWS (5 .. 16 rows; round 4): the M x K activations no longer fit as wave-private slices next to each other, so the
 // workgroup stages the WHOLE rows once, cooperatively (every wave copies a share; one barrier), into an area all its tiles
 // read: the pair geometry's gate and up tiles -- and their 16 waves -- share one copy.  One workgroup per CU then (128 KB at

@@ -41,6 +41,7 @@ typedef u32      u32x4 __attribute__((ext_vector_type(4)));
 #define KERNEL static
 #define NOINLINE_DEV inline
 #define __launch_bounds__(...)
+#define ASM_MARK(id) do { } while (0)      // (hw.h: a numbered comment in the gfx950 code)
 #define WAVE 64
 
 using std::min;
@@ -371,7 +372,7 @@ DEV void* global_ptr_of(u32 lo, u32 hi) { return (void*)(((u64)hi << 32) | lo); 
 typedef int hipError_t;
 typedef void* hipStream_t;
 enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
-enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyHostToHost = 0 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyHostToHost = 0, hipMemcpyDefault = 4 };
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 struct hipDeviceProp_t { int multiProcessorCount; };
 
@@ -383,6 +384,14 @@ DEV hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d,
 DEV hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 DEV hipError_t hipDeviceSynchronize() { return hipSuccess; }
 DEV hipError_t hipGetLastError() { return hipSuccess; }
+DEV hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, int, hipStream_t)
+{
+    for (size_t r = 0; r < h; r++) memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
+    return hipSuccess;
+}
+static const hipError_t hipErrorPeerAccessAlreadyEnabled = (hipError_t)704;
+DEV hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
+DEV hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 DEV hipError_t hipSetDevice(int) { return hipSuccess; }
 DEV hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 DEV hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
