@@ -42,3 +42,14 @@ def all_gather(pieces: list, local: torch.Tensor, group=None):
     dist.all_gather(h, local.cpu(), group=group)
     for p, s in zip(pieces, h):
         p.copy_(s)
+
+
+def all_reduce_sum(t: torch.Tensor, group=None):
+    """t <- sum over the ranks of t, in place (fp32 payload: the partial sums of a row-parallel linear, tensor_p.py)."""
+    if not host_staged(t, group):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return
+    torch.cuda.current_stream(t.device).synchronize()
+    h = t.cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+    t.copy_(h)

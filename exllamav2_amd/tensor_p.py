@@ -29,7 +29,9 @@ import torch
 import torch.distributed as dist
 
 from .attn import ExLlamaV2Attention
-from .comm import all_gather
+import os
+
+from .comm import all_gather, all_reduce_sum
 from .linear import ExLlamaV2Linear
 from .model import ExLlamaV2
 from .rmsnorm import ExLlamaV2RMSNorm
@@ -53,6 +55,66 @@ def tp_split_columns(w: dict, a: int, b: int) -> dict:
     if "bias" in w:
         s["bias"] = w["bias"][a:b].contiguous()
     return s
+
+
+def _remap_4bit_columns(packed: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """int32 [rows, cols / 8], eight 4-bit values per word along the columns (q_scale): new[:, c] = old[:, index[c]]
+    (tensor_remap_4bit, ext_stloader.cpp:186-219)."""
+    rows, words = packed.shape
+    sh = torch.arange(8, device=packed.device, dtype=torch.int64) * 4
+    v = ((packed.to(torch.int64) & 0xFFFFFFFF).unsqueeze(-1) >> sh) & 0xF                 # [rows, words, 8]
+    v = v.reshape(rows, words * 8)[:, index.long()].reshape(rows, words, 8)
+    w = (v << sh).sum(-1)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+
+
+def tp_fold_down_perm(gate_w: dict, up_w: dict, down_w: dict):
+    """What ExLlamaV2MLP.load does on one device (mlp.py:162, linear.py:147-160): down_proj's act-order permutation
+    is folded into the OUTPUT columns of gate / up (new column c = old column q_perm[c]), after which down_proj's packed K rows are
+    simply rows 0 .. K-1 of its input -- the one EXL2 matrix of a layer that CAN be cut along K.  Returns (gate', up', down') with
+    down' carrying an identity permutation.  The caller's dicts are left alone."""
+    perm = down_w["q_perm"].long()
+    def cols(w):
+        o = dict(w)
+        o["q_weight"] = w["q_weight"][:, perm].contiguous()
+        o["q_scale"] = _remap_4bit_columns(w["q_scale"], perm)
+        if "bias" in w: o["bias"] = w["bias"][perm].contiguous()
+        return o
+    d = dict(down_w)
+    ident = torch.arange(perm.shape[0], device=perm.device, dtype=down_w["q_perm"].dtype)
+    d["q_perm"], d["q_invperm"] = ident, ident.clone()
+    return cols(gate_w), cols(up_w), d
+
+
+def tp_split_rows(w: dict, ka: int, kb: int):
+    """Packed K rows [ka, kb) of an EXL2 tensor set whose permutation is the identity (tp_fold_down_perm): the groups that cover
+    exactly that range -- their words of q_weight, their rows of q_scale / q_scale_max, q_groups rebased.  None when the range does
+    not fall on group boundaries (the caller keeps the column split)."""
+    qg = w["q_groups"].cpu().tolist()
+    groups = len(qg) // 2
+    total_words = w["q_weight"].shape[0]
+    k, ga, gb, wa, wb = 0, None, None, None, None
+    for g in range(groups):
+        bits, off = qg[2 * g], qg[2 * g + 1]
+        nxt = qg[2 * g + 3] if g + 1 < groups else total_words
+        rows = (nxt - off) * 32 // bits
+        if k == ka: ga, wa = g, off
+        k += rows
+        if k == kb: gb, wb = g + 1, nxt
+    if ga is None or gb is None or gb <= ga:
+        return None
+    new_groups = []
+    for g in range(ga, gb):
+        new_groups += [qg[2 * g], qg[2 * g + 1] - wa]
+    n = kb - ka
+    ident = torch.arange(n, device=w["q_weight"].device, dtype=w["q_perm"].dtype)
+    return {
+        "q_weight": w["q_weight"][wa:wb].contiguous(),
+        "q_scale": w["q_scale"][ga:gb].contiguous(),
+        "q_scale_max": w["q_scale_max"][ga:gb].clone(),
+        "q_groups": torch.tensor(new_groups, dtype=w["q_groups"].dtype, device=w["q_groups"].device),
+        "q_perm": ident, "q_invperm": ident.clone(),
+    }                                                       # (bias: added once, by the caller, after the reduction)
 
 
 def tp_ranges(total: int, world: int, unit: int):
@@ -153,7 +215,16 @@ class TPAttention(ExLlamaV2Attention):
 
 
 class TPMLP:
-    """mlp.py:363-451 (`forward_tp`): gate / up column shards -> act * mul -> gather -> down column shard -> gather."""
+    """mlp.py:363-451 (`forward_tp`): gate / up column shards -> act * mul -> down.  Two forms of the second half:
+
+    * row-parallel down_proj (round 6; default where the tensors allow it): down_proj's act-order permutation is folded into the
+      columns of gate / up at load (what mlp.py:162 / linear.py:147-160 do on one device), gate / up are cut along those PERMUTED
+      columns, down_proj along its packed K rows [r I/N, (r+1) I/N) -- every rank multiplies ITS slice of silu(gate) * up by ITS rows
+      of down_proj and ONE all-reduce of [rows, hidden] partial sums (fp32 on the wire) replaces the all-gather of the intermediate
+      rows AND the all-gather of the outputs: three collectives per layer instead of four, and the 2 x intermediate / N values per
+      row never travel.  (o_proj cannot take this: its permutation mixes the heads.)
+    * column shards + two all-gathers (the reference's plan; kept for GPTQ tensors, a range that does not fall on group
+      boundaries, EXL2_TP_ROW_DOWN=0)."""
 
     def __init__(self, model, key: str, layer_idx: int):
         ctx, full = model.tp, model.full_config
@@ -163,10 +234,30 @@ class TPMLP:
         self.up_proj = TPLinear(self.ext, key + ".mlp.up_proj", h, inter, ctx.id_split, model)
         self.down_proj = TPLinear(self.ext, key + ".mlp.down_proj", inter, h, ctx.rs_split, model)
         self.post_attention_layernorm = None
+        self.row_down = False
+        self.down_bias = None
 
     def load(self, ck: dict):
-        for lin in (self.gate_proj, self.up_proj, self.down_proj):
-            lin.load(ck[lin.key])
+        from .ext import none_tensor
+        ctx = self.model.tp
+        gw, uw, dw = ck[self.gate_proj.key], ck[self.up_proj.key], ck[self.down_proj.key]
+        rows = None
+        if ctx.world > 1 and os.environ.get("EXL2_TP_ROW_DOWN", "1") != "0" and all("q_weight" in w for w in (gw, uw, dw)):
+            g2, u2, d2 = tp_fold_down_perm(gw, uw, dw)
+            rows = tp_split_rows(d2, *ctx.id_split)
+        if rows is not None:
+            self.row_down = True
+            self.gate_proj.load(g2); self.up_proj.load(u2)                       # column shards of the permuted columns
+            a, b = ctx.id_split
+            lin = self.down_proj
+            lin.in_features, lin.out_features, lin.padding = b - a, self.model.full_config.hidden_size, 0
+            lin.col_range = (0, lin.out_features)
+            lin.q_tensors = rows
+            lin.q_handle = self.ext.make_q_matrix_from_dict(rows, none_tensor, key=lin.key)
+            self.down_bias = dw.get("bias")
+        else:
+            for lin in (self.gate_proj, self.up_proj, self.down_proj):
+                lin.load(ck[lin.key])
         self.post_attention_layernorm = ck[self.key + ".post_attention_layernorm"]
         return self
 
@@ -184,6 +275,12 @@ class TPMLP:
         g = self.gate_proj.forward(xn)
         u = self.up_proj.forward(xn)
         ext.act_mul_(g, u)                                                       # silu(g) * u in place on g
+        if self.row_down:
+            part = self.down_proj.forward(g).float()                             # this rank's K rows: partial sums [rows, hidden]
+            all_reduce_sum(part, group=tp.group)
+            if self.down_bias is not None: part += self.down_bias.float()
+            x2.add_(part.half())
+            return hidden_states
         a = tp.all_gather_columns(g)
         x2.add_(tp.all_gather_columns(self.down_proj.forward(a)))
         return hidden_states
