@@ -256,7 +256,7 @@ def parity_check(model, oracle, device, n_decode: int = 6, cache_type: str = "fp
             # value: a row whose logits reach 46 (sequence 2 of the --batch >= 3 prompts on the 7B synthetic weights) shows +-0.25 on
             # logits of any size -- the chained and the module-by-module route deviate from the oracle in OPPOSITE directions there
             # (0.23 / 0.28, i.e. 0.5-0.6 % of the row's scale; 0.51 apart: tools/debug/batch_parity_debug.py,
-            # profiles/r05q_batch_parity_debug.txt).  Hence the third term: 2^-7 of what the row's largest |logit| exceeds 8 by -- rows
+            # profiles/history/r05q_batch_parity_debug.txt).  Hence the third term: 2^-7 of what the row's largest |logit| exceeds 8 by -- rows
             # inside the range the bar of tests/test_model.py was set on (|logit| <= 8: every other row of every configuration) keep it.
             # MEASURED yardstick for that term (round 6; tests/golden/reference_model_yardstick.json: "outlier_rows_7b", made by
             # tests/golden/make_golden_model_yardstick.py --outlier): the reference's OWN decode kernels (gemm_half_q_half_kernel +

@@ -4,7 +4,7 @@
 // (ext_bindings.cpp:27-138: tensors in, raw pointers + current stream down).  Two things live here:
 //
 //   1. The binding itself: no ctypes, no per-argument Python (round 4 measured ~130 ctypes calls and ~35 k Python-level pointer
-//      look-ups per 64 tokens under the reference's loop: profiles/r04_dropin_host_profile.txt).
+//      look-ups per 64 tokens under the reference's loop: profiles/history/r04_dropin_host_profile.txt).
 //
 //   2. The MODULE CHAIN behind the operator boundary (round-4 review, item 4).  The library's fast decode route is "chained": a
 //      producer leaves the residual stream as (xp, ss) = (x times the consumer's RMSNorm weight in the consumer's act-order, partial

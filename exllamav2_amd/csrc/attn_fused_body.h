@@ -58,7 +58,7 @@ struct FusedArgs
 
 // where feature d of query row qrow = (token row) * H + head goes
 // Number of splits a launch of `total` keys uses (the grid holds a.nsplit of them; the rest leave at entry).  One slope: a split per
-// keys_per_split_min keys.  Two slopes (few KV heads -- grouped-query models; round 5, profiles/r05m_attn_sweep2_merge.jsonl): a split
+// keys_per_split_min keys.  Two slopes (few KV heads -- grouped-query models; round 5, profiles/history/r05m_attn_sweep2_merge.jsonl): a split
 // per keys_per_split_min keys up to split_short_cap, beyond that a split per keys_per_split_long keys -- short contexts want many short
 // slices early (the launch is latency-bound), long ones few enough that the slices stay long (each split pays its own start-up and the
 // merge reads every partial).
@@ -143,7 +143,7 @@ DEV void attn_fused_body(const FusedArgs& a, const int kh, const int split, cons
     // itself, the first page of the sequence (split 0 starts at key 0), the query rows, the new key / value row this stream
     // takes first, the output position of the element this thread finalises.  (One dependent round trip each before:
     // length -> page -> keys -> new key -> rotary rows -> output position, 6.9 us per launch at 64 keys;
-    // profiles/r03_kernel_stats.csv.)
+    // profiles/history/r03_kernel_stats.csv.)
     // (UNCONDITIONAL loads from an address that is valid either way: behind `if (ptr) v = *ptr` the compiler waits for the load where the
     // two paths meet -- `s_waitcnt vmcnt(0)` right behind the request, in front of every other level-1 request: one whole round trip
     // at the head of every launch, found in the gfx950 code in round 5)

@@ -5,7 +5,7 @@
 // TIME and folded with the online-softmax update: ceil(eff / 8) round trips.  Rounds 1-4 ran `for s: M = max(M, load)` and then
 // `for s: three loads, accumulate` -- one load-and-wait per loop trip (the gfx950 code had `s_waitcnt vmcnt(0)` inside both loops)
 // = 2 eff dependent round trips of ~0.6 us: a 64-split launch of a grouped-query model spent ~75 of its 80 us in the merge
-// (profiles/r05l_attn_sweep2.jsonl).  AGENT: the partials were written by other workgroups of the SAME launch (agent-scope loads;
+// (profiles/history/r05l_attn_sweep2.jsonl).  AGENT: the partials were written by other workgroups of the SAME launch (agent-scope loads;
 // hw.h explains why no fence).
 template <bool AGENT>
 DEV float merge_split_partials(const float* part_o, const float* part_ml, size_t qrow, int nsplit, int eff, int hd, int d)

@@ -52,12 +52,14 @@ struct FlashArgs
     int len_const, len_offset;
     float scale;
     int causal;
-    int window_left; float softcap;     // flash-attn's window_size[0] (< 0: none) and softcap (0: off): csrc/attn.hip AttnArgs
 };
+struct FlashWS { int window_left; float softcap; };     // flash-attn's window_size[0] (< 0: none) and softcap (0: off): csrc/attn.hip AttnArgs
 
 
-template <int HDIM>
-KERNEL void __launch_bounds__(FP_WAVES * 64, FP_OCC) flash_prefill_kernel(const FlashArgs a)
+// WS: the instantiation with flash-attn's sliding window / softcap (a template parameter, not run-time tests: as run-time tests they cost
+// the plain kernel 30 scalar spills and 30 % of its speed -- 0.83 -> 1.09 ms at 8 x 2048 x 32 heads, round 6)
+template <int HDIM, bool WS = false>
+KERNEL void __launch_bounds__(FP_WAVES * 64, FP_OCC) flash_prefill_kernel(const FlashArgs a, const FlashWS ws)
 {
     DYN_SMEM(smem);
     constexpr int KSTR = HDIM + 8;                 // halfs per K row (272-byte rows at hd 128: conflict-free 16-byte reads)
@@ -150,11 +152,22 @@ KERNEL void __launch_bounds__(FP_WAVES * 64, FP_OCC) flash_prefill_kernel(const 
 
     // (the look-up runs two tiles ahead of the tile in use, the rows one tile ahead; a tile index past the end looks tile 0 up again)
     // sliding window: every row of this workgroup sits at position >= qpos0 + q0, so no row sees a key below that minus the window
-    const int tile_lo = a.window_left >= 0 ? max(0, qpos0 + q0 - a.window_left) / FP_BK : 0;
-    const float cap = a.softcap, inv_cap = cap > 0.0f ? 1.0f / cap : 0.0f;
-    size_t base_next = n_tiles > tile_lo + 1 ? tile_base(tile_lo + 1) : 0;
-    if (n_tiles > tile_lo) fetch(tile_lo, tile_base(tile_lo));
-    for (int tile = tile_lo; tile < n_tiles; tile++)
+    int tile_lo = 0;
+    float cap = 0.0f, inv_cap = 0.0f;
+    size_t base_next;
+    if constexpr (WS)
+    {
+        tile_lo = ws.window_left >= 0 ? max(0, qpos0 + q0 - ws.window_left) / FP_BK : 0;
+        cap = ws.softcap; inv_cap = cap > 0.0f ? 1.0f / cap : 0.0f;
+        base_next = n_tiles > tile_lo + 1 ? tile_base(tile_lo + 1) : 0;
+        if (n_tiles > tile_lo) fetch(tile_lo, tile_base(tile_lo));
+    }
+    else
+    {
+        base_next = n_tiles > 1 ? tile_base(1) : 0;
+        if (n_tiles > 0) fetch(0, tile_base(0));
+    }
+    for (int tile = WS ? tile_lo : 0; tile < n_tiles; tile++)
     {
         block_sync();                                                         // everybody is done with the previous tile
         stage();
@@ -198,10 +211,19 @@ KERNEL void __launch_bounds__(FP_WAVES * 64, FP_OCC) flash_prefill_kernel(const 
                 for (int r = 0; r < 4; r++)
                 {
                     const int kpos = k0 + 16 * blk + 4 * g + r;
-                    const bool valid = kpos < total && (!a.causal || kpos <= qpos[n]) && (a.window_left < 0 || kpos >= qpos[n] - a.window_left);
-                    float sv = st[n][blk][r] * a.scale;
-                    if (cap > 0.0f) sv = cap * tanhf(sv * inv_cap);
-                    const float v = valid ? sv : FP_NEG_BIG;
+                    float v;
+                    if constexpr (WS)
+                    {
+                        const bool valid = kpos < total && (!a.causal || kpos <= qpos[n]) && (ws.window_left < 0 || kpos >= qpos[n] - ws.window_left);
+                        float sv = st[n][blk][r] * a.scale;
+                        if (cap > 0.0f) sv = cap * tanhf(sv * inv_cap);
+                        v = valid ? sv : FP_NEG_BIG;
+                    }
+                    else
+                    {
+                        const bool valid = kpos < total && (!a.causal || kpos <= qpos[n]);
+                        v = valid ? st[n][blk][r] * a.scale : FP_NEG_BIG;
+                    }
                     sc[blk * 4 + r] = v;
                     m_loc = fmaxf(m_loc, v);
                 }
@@ -298,7 +320,7 @@ int exl2_flash_prefill_ex(const void* q, const void* k_cache, const void* v_cach
     EXL2_REQUIRE(!block_table || a.page_shift >= 0, "flash_prefill: page_size %d must be a power of two", page_size);
     if (block_table && page_size < FP_BK) return 1;            // (a tile of FP_BK keys must not straddle a page: not covered, the caller takes exl2_paged_attn)
     a.len_const = len_const; a.len_offset = len_offset; a.scale = softmax_scale; a.causal = causal;
-    a.window_left = window_left; a.softcap = softcap > 0.0f ? softcap : 0.0f;
+    FlashWS w; w.window_left = window_left; w.softcap = softcap > 0.0f ? softcap : 0.0f;
     dim3 grid((unsigned)((q_len + FP_BQ - 1) / FP_BQ), (unsigned)num_heads, (unsigned)batch);
     const size_t lds = ((size_t)FP_BK * (head_dim + 8) + (size_t)FP_BK * (head_dim + 16)) * sizeof(f16);
     {
@@ -309,13 +331,23 @@ int exl2_flash_prefill_ex(const void* q, const void* k_cache, const void* v_cach
             (void)hipFuncSetAttribute((const void*)flash_prefill_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)flash_prefill_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)flash_prefill_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)flash_prefill_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)flash_prefill_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)flash_prefill_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
     }
+    const bool ws = w.window_left >= 0 || w.softcap > 0.0f;
     switch (head_dim)
     {
-        case 64:  LAUNCH(flash_prefill_kernel<64>, grid, dim3(FP_WAVES * 64), lds, stream, a); break;
-        case 128: LAUNCH(flash_prefill_kernel<128>, grid, dim3(FP_WAVES * 64), lds, stream, a); break;
-        default:  LAUNCH(flash_prefill_kernel<256>, grid, dim3(FP_WAVES * 64), lds, stream, a); break;
+        case 64:  if (ws) LAUNCH((flash_prefill_kernel<64, true>), grid, dim3(FP_WAVES * 64), lds, stream, a, w);
+                  else LAUNCH((flash_prefill_kernel<64, false>), grid, dim3(FP_WAVES * 64), lds, stream, a, w);
+                  break;
+        case 128: if (ws) LAUNCH((flash_prefill_kernel<128, true>), grid, dim3(FP_WAVES * 64), lds, stream, a, w);
+                  else LAUNCH((flash_prefill_kernel<128, false>), grid, dim3(FP_WAVES * 64), lds, stream, a, w);
+                  break;
+        default:  if (ws) LAUNCH((flash_prefill_kernel<256, true>), grid, dim3(FP_WAVES * 64), lds, stream, a, w);
+                  else LAUNCH((flash_prefill_kernel<256, false>), grid, dim3(FP_WAVES * 64), lds, stream, a, w);
+                  break;
     }
     HIP_TRY(hipGetLastError());
     return EXL2_OK;

@@ -619,7 +619,7 @@ static int paged_attn_q4_impl(const void* q, const void* k_codes, const void* k_
     // Query rows per workgroup.  Four rows share one pass over the keys -- but a workgroup's own dependent chain (rotate the rows,
     // fill registers, merge 32 streams per row, rotate back) grows with its rows, and up to a few thousand keys that chain is the
     // launch: the 70B shape (8 rows per kv head) measures 91.1 / 92.8 / 94.2 tok/s at 4 / 2 / 1 rows per workgroup with an empty
-    // cache and 87.5 / 88.6 / 89.3 with 1920 tokens cached (profiles/r05y_ab_q4_rb*.txt).  The length is device-side (HIP graph),
+    // cache and 87.5 / 88.6 / 89.3 with 1920 tokens cached (profiles/history/r05y_ab_q4_rb*.txt).  The length is device-side (HIP graph),
     // the CAPACITY of the sequence is not: one row per workgroup while the sequence cannot exceed 4096 keys, four beyond
     // (unmeasured there: eight passes over the keys against two).  EXL2_Q4_RB=1|2|4 overrides.
     const long long capacity = block_table ? (long long)pages_per_seq * page_size : (long long)page_size;

@@ -355,7 +355,7 @@ int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
     // ---- batched route (round 5; rows <= 16 the grouped launch declined: Mixtral's 16 x 14336 down_proj rows do not fit its LDS):
     // the experts on the streaming / phased kernels like the serial loop below, but (1) gate and up read the rows gathered ONCE into
     // the experts' shared packed order (no row pre-pass per launch: it was 8 of the 18 stage_rows launches of a Mixtral layer, 7.3 us
-    // each -- profiles/r05g_mixtral_b16_kernel_stats.csv), (2) two experts' gate | up and four experts' down per launch
+    // each -- profiles/history/r05g_mixtral_b16_kernel_stats.csv), (2) two experts' gate | up and four experts' down per launch
     // (MAX_FUSED_MATS jobs: 6 launches + 2 pre-passes instead of 16 + 16), (3) every expert's SiLU(gate) * up and weighted down
     // output in its own rows of the scratch, summed by moe_combine_kernel (fp32, expert order) instead of 8 read-modify-writes of x.
     if (m->group_ok && rows <= MAX_GEMV_ROWS && (long long)E * rows <= m->max_rows && (E & 3) == 0 &&

@@ -73,7 +73,7 @@ KERNEL void __launch_bounds__(64) moe_topk_kernel(f16* x, int rows, int topk)
 
 // Round 5: the front of a sparse-MoE block in ONE launch for decode-sized row counts -- rms_norm_kernel (elementwise.hip), the two
 // kernels above and the row gather into the experts' packed order were four launches of 4.7-4.8 us each per layer
-// (profiles/r05_mixtral_b16_before_kernel_stats.csv: 19 us of a 124 us Mixtral layer at one row).  One workgroup per row; the SAME
+// (profiles/history/r05_mixtral_b16_before_kernel_stats.csv: 19 us of a 124 us Mixtral layer at one row).  One workgroup per row; the SAME
 // arithmetic in the same order as those kernels (sum of squares per thread -> wave -> four partials; logits per thread over the
 // normalised fp16 row -> wave -> four partials; the top-k on one thread), so the routing is bit-identical to the unfused route.
 // xn: the normalised row (natural order); xg: the same row gathered through `perm` (nullable = no packed copy).

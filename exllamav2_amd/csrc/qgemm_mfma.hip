@@ -37,7 +37,7 @@
 #define MF_BN 256
 #ifndef MF_WPRE_MIN_ROWS
 #define MF_WPRE_MIN_ROWS 129             // rows from which the weights are decoded once per call (wfrag_kernel): every call this file
-                                        // serves -- it wins from 192 rows up (profiles/r03_prefill_wpre_threshold.txt)
+                                        // serves -- it wins from 192 rows up (profiles/history/r03_prefill_wpre_threshold.txt)
 #endif
 #define MF_THREADS 512
 #define MF_W_STAGE 32768                        // 16 tiles x 2 chunks x 64 lanes x 16 bytes
@@ -282,7 +282,7 @@ DEV void run_section(const MfCtx& x, int bits, const u32* base, u32 tile_stride,
 // ---- many rows: weights decoded ONCE per call (wfrag_kernel below) instead of once per workgroup ------------------------------
 // With 16384 rows a column block's weights are decoded by 64 workgroups, and the decode is what a K step waits for: the kernel
 // with the decode compiled out runs 31 % faster, with the multiply compiled out it still takes half the time
-// (profiles/r03_prefill_kill.txt).  The pre-pass writes every K step's W stage image (32 KB: [16 tiles][2 chunks][64 lanes][16 B])
+// (profiles/history/r03_prefill_kill.txt).  The pre-pass writes every K step's W stage image (32 KB: [16 tiles][2 chunks][64 lanes][16 B])
 // to a scratch buffer; the GEMM then fills its W stages by LDS-DMA like its X stages -- no decode, no packed words, no
 // scale tables in the K loop.
 

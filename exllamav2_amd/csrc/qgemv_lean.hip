@@ -6,7 +6,7 @@
 // kernel remains the route for what this one declines (> LEAN_MAX_M rows, grouped MoE launches, shares too big for the
 // register stream).
 //
-// Why another shape (profiles/r02_trace_flat.txt, profiles/r03_lean_probe.txt, profiles/r03_trace_lean_v2.txt): the round-2
+// Why another shape (profiles/r02_trace_flat.txt, profiles/history/r03_lean_probe.txt, profiles/history/r03_trace_lean_v2.txt): the round-2
 // kernel is ONE 1024-thread workgroup per CU whose 16 waves share a scalar unit, plan their split on the device
 // (1.3-1.6 us), copy tables workgroup-wide and meet at a barrier before the first weight is decoded (4.5-7.8 us into a
 // 9-16 us launch).  A skeleton with the real decode but none of that runs the four launches of a layer in 26.9 us
@@ -181,7 +181,7 @@ struct LeanCtx
 #if LEAN_RAW2
 // B fragment of one 32-row chunk straight from its packed dword: pairs (e = 0, 1) and (e = 4, 5) as 1024 + q, (2, 3) and (6, 7) as 64 + q
 // (the nibble sits where the half's unit bit is: 0x6400 = 1024, ulp 1; 0x5400 = 64, ulp 1 / 16).  Plain C so that the compiler sees
-// the VALU write in front of the MFMA (an inline-asm and_or feeding an MFMA hides the hazard: profiles/r05_raw4_experiment.txt).
+// the VALU write in front of the MFMA (an inline-asm and_or feeding an MFMA hides the hazard: profiles/history/r05_raw4_experiment.txt).
 DEV f16x8 raw4_b(u32 x, u32 m_lo, u32 m_hi, u32 k_lo, u32 k_hi)
 {
     const u32 y = x >> 8;
@@ -393,7 +393,7 @@ DEV void lean_xmem_request(const LeanCtx& cx, int chunk, int nvalid, int lane, f
 // groups spills otherwise).
 // DEP: a launch of the overlapped chain (chain_sync.h; EXPERIMENTAL).  A template parameter, not a run-time flag: the run-time form
 // cost the ordinary launches 2-4 % (a few scalar loads and branches on the request path and in the finalising wave's tail:
-// profiles/r04_bisect.txt).
+// profiles/history/r04_bisect.txt).
 // XMEM (5 .. 16 rows; round 4, second form): no staged activations at all -- a wave requests the A operands of its items from
 // memory (the L2 holds the M x K activations), LEAN_XMEM_AHEAD items ahead of the one it decodes, next to its weights.  For
 // launches whose rows do not fit the LDS as a whole (down_proj at K = 11008: 16 rows = 352 KB) this replaces the host's row
@@ -411,7 +411,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     // ---- arguments: header, matrix block, wave record -- addresses from built-in ids only: one batch of scalar loads.
     // What the weight requests need (matrix pointers, the record's run) is unpacked first; everything else is unpacked AFTER
     // the requests have been issued: the waves of a CU share one scalar unit, so every scalar instruction ahead of the
-    // requests delays the requests of all of them (profiles/r03_trace_lean_v4.txt: 1-3 us before this ordering).
+    // requests delays the requests of all of them (profiles/history/r03_trace_lean_v4.txt: 1-3 us before this ordering).
     const u32x4* hb = (const u32x4*)&args.hdr;
     const u32x4* mb = (const u32x4*)&args.mat[mj];
     const u32x4* wb = (const u32x4*)&args.wave[mj * S + r];
@@ -433,9 +433,9 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     LTRACE(0);
     // overlapped chain: "this workgroup holds its slot" (before anything may leave: the next launch's gate counts the whole grid)
     // (bit 30 of every wave record says so: the header's sync words sit in a cache line of their own, and a scalar load + wait
-    // in front of the weight requests costs every launch ~0.3 us -- measured: profiles/r04_states_ab.txt)
+    // in front of the weight requests costs every launch ~0.3 us -- measured: profiles/history/r04_states_ab.txt)
     // The workgroup's linear index is computed only THERE too: gridDim comes from the dispatch packet -- another scalar load the
-    // requests would wait for (-4.5 % on the whole decode step when it sat here unconditionally: profiles/r04_bisect.txt).
+    // requests would wait for (-4.5 % on the whole decode step when it sat here unconditionally: profiles/history/r04_bisect.txt).
     // (kernel-argument loads are speculatable: without the laundered pointer the compiler hoists these two into the first batch.)
     u32* sync_signal_ = nullptr;
     auto lin_wg_of = [&]() -> u32 { return (u32)bid_y() * (u32)gdim_x() + (u32)bid_x(); };
@@ -531,7 +531,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         {
             // the headline case -- one row, one copy instruction per table (two for the 4-wave geometry's 128-unit slices) -- with
             // nothing but those in front of the requests of the wave's last items (1.5 % of the whole decode step against the
-            // general form below: profiles/r04_states_ab_final.txt)
+            // general form below: profiles/history/r04_states_ab_final.txt)
             if (lane < sc_units) LEAN_DMA(st, lane * 16, sc_lds);
             if constexpr (GPTQ) { if (lane < sc_units) LEAN_DMA(zp_tab + ((size_t)t_ * G + gw0) * 16, lane * 16, zp_lds); }
             if constexpr (CAN_DEP && DEP)
@@ -775,7 +775,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
 #if LEAN_REPEAT
             // timing experiment (results are WRONG: every sum is taken LEAN_REPEAT times): the decode of the wave's share runs again
             // on the same registers -- the further passes find their code in the instruction cache and their data landed, so what they
-            // add is the decode's pure execution time (profiles/r05_repeat_experiment.txt)
+            // add is the decode's pure execution time (profiles/history/r05_repeat_experiment.txt)
             u32 reps_ = LEAN_REPEAT; pin_scalar(reps_);
             #pragma nounroll
             for (u32 rep_ = 0; rep_ < reps_; rep_++)
@@ -1225,7 +1225,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     if (const char* e = getenv("EXL2_LEAN_S16")) { if (atoi(e) && nslots == 1 && in.n_mats <= 2) S = 16; }
     // candidates, in order: a one-row pair tries 4 waves per tile first (8-wave workgroups: three per CU at 6 waves per SIMD, so
     // the 688 workgroups of a 7B gate|up launch are resident at once; with 16-wave workgroups a quarter of them starts when
-    // the first ones have finished: profiles/r03_trace_lean_v6.txt, workgroup entry p90 9.5 us)
+    // the first ones have finished: profiles/history/r03_trace_lean_v6.txt, workgroup entry p90 9.5 us)
     int cand[3] = {0, 0, 0}, n_cand = 0;
     static const int pair4 = []() { const char* e = getenv("EXL2_LEAN_PAIR4"); return e ? atoi(e) : 1; }();
     if (in.pair && in.M == 1 && pair4) cand[n_cand++] = 4;
@@ -1258,7 +1258,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
             else
             {
                 // (up to 8 rows the staged rows leave room for two 8-wave workgroups per CU: one tile per workgroup, the whole grid
-                // resident; from 9 rows up one workgroup per CU anyway: two tiles per unit, the workgroup walks -- profiles/r04_rows_sweep*.txt)
+                // resident; from 9 rows up one workgroup per CU anyway: two tiles per unit, the workgroup walks -- profiles/history/r04_rows_sweep*.txt)
                 if (in.M >= 9 && !(in.ss_out && (max_tiles + 1) / 2 > LEAN_MAX_PART) && max_tiles >= 2) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
                 cand[n_cand] = 8; cand_slots[n_cand++] = 1;
                 cand[n_cand] = 16; cand_slots[n_cand++] = 1;               // (K = 11008: a tile's share does not fit 8 waves' registers)

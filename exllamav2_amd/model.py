@@ -276,7 +276,7 @@ class GreedyGraphDecoder:
             if dev.type == "cuda":
                 self.chain["ev_pre"], self.chain["ev_b"] = torch.cuda.Event(), torch.cuda.Event()
             self.graph_b = None
-        # 5-16 sequences, EXL2_XP_TILED=1 (round 4, measured SLOWER than the default and therefore off: profiles/r04_xp_tiled_sweep.txt
+        # 5-16 sequences, EXL2_XP_TILED=1 (round 4, measured SLOWER than the default and therefore off: profiles/history/r04_xp_tiled_sweep.txt
         # -- 7B bs = 16: 6460 vs 6652 tok/s, bs = 5: 2251 vs 2565): the hand-off buffers xp in the layout the matrix cores read
         # ([K / 8][16 rows][8]: include/exl2_hip.h, exl2_chain_set_tiled) -- q|k|v, gate|up and the head then take the lean kernel's
         # XMEM form (A operands straight from memory, no staged copy); o_proj keeps the ROWS form (attention writes row-major).

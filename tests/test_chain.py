@@ -637,7 +637,7 @@ def test_lean_kernel_identity_rows_equal_reconstruct(be, rows):
     bit for bit: one-hot activation rows through exl2_gemm_half_q_half_chain with sum(x^2) = K and eps = 0 (the epilogue's
     1 / rms factor is exactly 1) must return the rows of reconstruct(): 5-bit and 4-bit sections, one scale per item (g128: the scale
     on the fp32 partial sum) and a scale per chunk (g32 / g64: on the weights).  (Written for round 5's raw 4-bit feed experiment,
-    profiles/r05_raw4_experiment.txt, which it passed; kept because the chained kernel had no such test.)"""
+    profiles/history/r05_raw4_experiment.txt, which it passed; kept because the chained kernel had no such test.)"""
     k, n = 1024, 96
     spec = [(5, 128, 128), (4, 128, 512), (4, 32, 256), (4, 64, 128)]
     t, ref, w, h = _mk(be, k, n, spec, 77)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of SOURCE STATES of the lean decode kernel (profiles/r04_states_ab*.txt): builds exllamav2_amd/libexl2_hip_<name>.so =
+# Same-box A/B of SOURCE STATES of the lean decode kernel (profiles/history/r04_states_ab*.txt): builds exllamav2_amd/libexl2_hip_<name>.so =
 # the current library with qgemv_lean.o compiled from another commit's csrc/qgemv_lean.hip (against the current headers), so that
 # the libraries differ in that one object only.  EXL2_HIP_LIB=<path> makes exllamav2_amd/_lib.py load one of them.
 # usage: tools/build_state_variants.sh [name:commit ...]      default: callb:549e139 (pipelined form, before ROWS / overlap support)

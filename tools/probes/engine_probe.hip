@@ -61,7 +61,7 @@ DEV void lds_write_u32(lds_vu32* p, u32 v) { *p = v; }
 // copies with immediate offsets 0 / 1 / 2 / 3 KB -- the immediate advances the memory address AND the LDS address)
 #define FILL 16
 // THIN: what the loader does while its CU gathers (0 nothing, 1 one fill in flight, 2 pause); GW: consumers that sweep
-// RAW: the raw 4-bit feed (profiles/r05_raw4_experiment.txt): the matrix cores get the un-subtracted codes (1024 + q / 64 + q), the
+// RAW: the raw 4-bit feed (profiles/history/r05_raw4_experiment.txt): the matrix cores get the un-subtracted codes (1024 + q / 64 + q), the
 // constant part enters as the C operand from a per-item correction table made ONCE per phase and CU from the gathered vector
 // TB > 0: the tight consumer -- a consumer takes TURNS of TB consecutive items of one tile (turn t of the phase -> consumer t % NC), reads a
 // turn's operands together, and publishes the end of its last finished turn (the loader frees the prefix below the minimum)
@@ -440,7 +440,7 @@ __global__ void init_kernel(u32* w, u64 cu_words, u32 items)
     }
 }
 
-// the launches baseline of the same content: lean_probe.hip (26.9 us per layer), production 35.8 us (profiles/r05_kernel_stats.csv)
+// the launches baseline of the same content: lean_probe.hip (26.9 us per layer), production 35.8 us (profiles/history/r05_kernel_stats.csv)
 typedef void (*EngFn)(const EngArgs);
 struct Variant { const char* name; EngFn fn; int nc, rd; };
 #define V(NC, RD, D, DEC, HO) {"NC" #NC " RD" #RD " D" #D " dec" #DEC " ho" #HO, engine_kernel<NC, RD, D, DEC, HO>, NC, RD}

@@ -1,4 +1,4 @@
-// What does COLD CODE cost a short launch on gfx950?  (round 5; output: profiles/r05_ifetch_probe.txt)
+// What does COLD CODE cost a short launch on gfx950?  (round 5; output: profiles/history/r05_ifetch_probe.txt)
 //
 // The chained decode kernel (csrc/qgemv_lean.hip) is straight-line code by design: 140-190 KB per instantiation, of which one
 // wave walks ~6-8 KB once.  Its in-kernel timeline shows ~10 cycles per instruction and wave where the instruction mix explains
