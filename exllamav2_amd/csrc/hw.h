@@ -258,6 +258,20 @@ DEV u32 ticket_add_agent(u32* p, u32 v) { return __hip_atomic_fetch_add(p, v, __
 DEV float load_agent_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // write-through store at agent scope (sc1): visible to the other XCDs without flushing the whole L2 (buffer_wbl2)
 DEV void store_agent_f32(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a lane's four accumulators as two 8-byte agent-scope accesses (16-byte atomics do not exist; the halves are independent values)
+DEV void store_agent_f32x4(f32x4* p, f32x4 v)
+{
+    struct Pair { u64 a, b; } w = __builtin_bit_cast(Pair, v);
+    __hip_atomic_store((u64*)p, w.a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((u64*)p + 1, w.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEV f32x4 load_agent_f32x4(const f32x4* p)
+{
+    struct Pair { u64 a, b; } w;
+    w.a = __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w.b = __hip_atomic_load((const u64*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_bit_cast(f32x4, w);
+}
 DEV void store_relaxed_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void store_agent_f16(f16* p, f16 v) { __hip_atomic_store((u16*)p, as_u16(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV u32 load_agent_u32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

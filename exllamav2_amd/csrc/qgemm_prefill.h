@@ -1,5 +1,5 @@
-// qgemm_prefill.h -- what the two prefill-shaped q_gemm kernels (qgemm_prefill.hip: 128 x 128 tiles, B decoded in registers;
-// qgemm_mfma.hip: 256 x 256 tiles, B decoded once per workgroup into LDS) share with their host driver.
+// qgemm_prefill.h -- what the prefill-shaped q_gemm kernels (qgemm_skinny.hip: 17 .. 128 rows, weight-stream bound; qgemm_mfma.hip:
+// 256 x 256 tiles, B decoded once per call; qgemm_prefill.hip: the generic 128 x 128 kernel + the row pre-pass) share with their host driver.
 #pragma once
 #include "qgemv_common.h"
 
@@ -18,6 +18,9 @@ struct PrefillArgs
 // qgemm_prefill.hip: per (device, stream) scratch that lives until exl2_release_scratch; kind 0 = staged activation rows,
 // 1 = decoded weight fragments (two buffers of one call must not alias)
 int prefill_scratch(size_t bytes, void* stream, int kind, f16** out);
+
+// qgemm_skinny.hip (17 .. 128 rows): 0 = launched, 1 = does not apply (generic 128 x 128 kernel), < 0 = error (message set)
+int qgemm_skinny_launch(const PrefillArgs& p, bool gptq, void* stream);
 
 // qgemm_mfma.hip: 0 = launched, < 0 = error (message set)
 int qgemm_mfma_launch(const PrefillArgs& p, bool gptq, void* stream);

@@ -681,6 +681,16 @@ int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stre
                 if (rc) return rc;
                 continue;
             }
+            {
+                // 17 .. 128 rows: the weight-stream-bound kernel (qgemm_skinny.hip); EXL2_PREFILL_SKINNY=0: the generic kernel (A/B runs, tests)
+                const char* e = getenv("EXL2_PREFILL_SKINNY");
+                if (rows <= 128 && !(e && !atoi(e)))
+                {
+                    const int rc = qgemm_skinny_launch(p, gptq, stream);
+                    if (rc < 0) return rc;
+                    if (rc == 0) continue;
+                }
+            }
             dim3 grid((unsigned)((j.m.N + PF_BN - 1) / PF_BN), (unsigned)((rows + PF_BM - 1) / PF_BM), 1);
             const size_t lds = PF_LDS_BYTES(j.m.K, j.m.G);
             if (gptq) LAUNCH((qgemm_prefill_kernel<true>), grid, dim3(PF_THREADS), lds, stream, p);

@@ -301,6 +301,8 @@ DEV void fence_acquire_agent() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 DEV u32 ticket_add_agent(u32* p, u32 v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 DEV float load_agent_f32(const float* p) { return *(const volatile float*)p; }
 DEV void store_agent_f32(float* p, float v) { *(volatile float*)p = v; }
+DEV void store_agent_f32x4(f32x4* p, f32x4 v) { *p = v; }
+DEV f32x4 load_agent_f32x4(const f32x4* p) { return *p; }
 DEV void store_relaxed_agent(u32* p, u32 v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 DEV void store_agent_f16(f16* p, f16 v) { *p = v; }
 DEV u32 load_agent_u32(const u32* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }

@@ -438,15 +438,34 @@ def test_hosts_that_do_random_things_between_module_calls(be, seed):
         fast.set_verify(False)
     fast.set_chain(False)
     plain = host.run(tokens)                                       # (the script is fixed by now: the same actions at the same places)
+    # the yardstick of the comparison below, measured on the SAME host and route: one ulp on the residual stream at the first hook of
+    # every token.  Some of these random models are chaotic (residual rms > 100 after a "scale", attention a hard arg-max: round-6
+    # seed 10 on the MI355X, profiles/r06o_fuzz_seed10_trace.txt -- both routes bit-clean hand-offs, 10 % apart after layer 2's
+    # attention); where one ulp already moves the logits by more than the model tolerance, two correct routes need not agree and the
+    # token is left out (the self-check of the odd seeds still covers it bit for bit).
+    def one_ulp(li, where, x):
+        x = between(li, where, x)
+        if li == 0 and where == "attn->mlp":
+            x = x.clone()
+            x.view(torch.int16).bitwise_xor_(1)
+        return x
+    host.between = one_ulp
+    nudged = host.run(tokens)
+    host.between = between
     fast.set_chain(True)
     assert st["chained"] > 0, st
-    for i, (a, b) in enumerate(zip(chained, plain)):
+    compared = 0
+    for i, (a, b, c) in enumerate(zip(chained, plain, nudged)):
+        tol = 0.03 + np.abs(b) * 2.0 ** -8
+        if np.any(np.abs(c.astype(np.float64) - b) > tol): continue
+        compared += 1
         err = np.abs(a.astype(np.float64) - b)
         # (6 x the model tolerance between the two ROUTES: each route is held to the measured yardstick against the oracle -- the
         # reference's own kernels sit up to 4.09 x from it over 128 random models, tests/golden/reference_model_yardstick.json --
         # so two admissible routes may sit up to twice that apart; 6 is inside that.  A stale hand-off is a 25 % error or another
         # token's row: orders of magnitude beyond this)
-        assert np.all(err <= 6 * (0.03 + np.abs(b) * 2.0 ** -8)), (i, float(err.max()), sorted(set(script.values())))
+        assert np.all(err <= 6 * tol), (i, float(err.max()), sorted(set(script.values())))
+    assert compared >= 2, compared
     # a write that moves neither the version counter nor calls note_write (against the binding's contract):
     if seed == 0:
         def sneaky(li, where, x):

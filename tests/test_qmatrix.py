@@ -108,6 +108,44 @@ def test_prefill_vs_oracle(be, m):
     be.ext.free_q_matrix(h)
 
 
+@pytest.mark.parametrize("name", ["mixed_5_4", "mixed_all", "b4_g128"])
+@pytest.mark.parametrize("m", [17, 64, 128])
+def test_skinny_kernel_split_k(be, name, m, monkeypatch):
+    """Round 6: 17-128 rows run on qgemm_skinny_kernel (weight-stream bound: 128 columns x all rows x a slice of K per workgroup).
+    EXL2_SKINNY_SPLITK forces the number of K splits here (the host picks it from the grid otherwise): partial tiles leave as
+    agent-scope stores, the last split to arrive adds them in split order.  Same bar against the oracle for every split count and
+    for the generic 128 x 128 kernel (EXL2_PREFILL_SKINNY=0); two runs are bit-identical (fixed order); identity rows return
+    reconstruct() bit for bit; the ticket reset (a second call on the same scratch) works."""
+    k, n, spec = SPECS[name]
+    t, ref, w, h = make_exl2(be, k, n, spec, seed=21, bias=True)
+    rng = np.random.default_rng(22)
+    a = rng.standard_normal((m, k)).astype(np.float16)
+    want = OX.gemm_ref(a, ref, bias=t["bias"], exact=True)
+    outs = {}
+    for ks in ("generic", "1", "2", "3", "5"):
+        if ks == "generic": monkeypatch.setenv("EXL2_PREFILL_SKINNY", "0")
+        else:
+            monkeypatch.delenv("EXL2_PREFILL_SKINNY", raising=False)
+            monkeypatch.setenv("EXL2_SKINNY_SPLITK", ks)
+        for rep in range(2):
+            c = torch.full((m, n), 7.0, dtype=torch.float16, device=be.device)
+            be.ext.gemm_half_q_half(be.t(a), h, c)
+            got = be.n(c).copy()
+            assert np.all(np.abs(got.astype(np.float64) - want) <= half_tol(want, k)), (ks, rep)
+            if rep: assert np.array_equal(got, outs[ks])
+            outs[ks] = got
+    # identity rows: every output has ONE non-zero term, whatever the split
+    eye = np.zeros((m, k), dtype=np.float16)
+    rows = rng.choice(k, size=m, replace=False)
+    eye[np.arange(m), rows] = 1.0
+    monkeypatch.setenv("EXL2_SKINNY_SPLITK", "3")
+    c = torch.zeros((m, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(eye), h, c)
+    bias = t["bias"].astype(np.float32) if t.get("bias") is not None else 0.0
+    assert np.array_equal(be.n(c), (ref[rows].astype(np.float32) + bias).astype(np.float16))
+    be.ext.free_q_matrix(h)
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
 def test_gemm_random_rows_shapes_and_bit_mixes(be, seed, monkeypatch):
     """Seeded random (rows, K, N, bit-width sections, group sizes, act-order, bias) through exl2_gemm_half_q_half: every row-count

@@ -141,3 +141,9 @@ if has probes; then
 fi
 rocm-smi --showproductname 2>/dev/null | grep -i "card series\|gfx" | head -3 > $R/${T}_gpu.txt
 echo "== done"
+if has skinny; then
+  echo "== 17-128-row q_gemm by kernel time (tools/skinny_bench.py)"
+  (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $R/prof_skb -o skb -- python $ROOT/tools/skinny_bench.py > $R/${T}_skinny_meta.json 2>$R/${T}_skinny.err); echo "rc=$?"
+  f=$(find $R/prof_skb -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/skinny_bench.py --parse $f $R/${T}_skinny_meta.json | tee $R/${T}_skinny_bench.jsonl
+  rm -rf $R/prof_skb
+fi
