@@ -20,7 +20,7 @@ struct PrefillArgs
 int prefill_scratch(size_t bytes, void* stream, int kind, f16** out);
 
 // qgemm_skinny.hip (17 .. 128 rows): 0 = launched, 1 = does not apply (generic 128 x 128 kernel), < 0 = error (message set)
-int qgemm_skinny_launch(const PrefillArgs& p, bool gptq, void* stream);
+int qgemm_skinny_launch(const PrefillArgs* p, int n, bool gptq, void* stream);     // n <= 3 matrices over the same staged rows
 
 // qgemm_mfma.hip: 0 = launched, < 0 = error (message set)
 int qgemm_mfma_launch(const PrefillArgs& p, bool gptq, void* stream);

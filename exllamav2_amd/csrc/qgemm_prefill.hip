@@ -543,6 +543,8 @@ int prefill_scratch(size_t bytes, void* stream, int kind, f16** out)
                 EXL2_FAIL(EXL2_E_OOM, "HIP out of memory (prefill staging scratch: %zu bytes)", bytes);
             }
         }
+        // kind 2 (qgemm_skinny.hip's split-K scratch) starts with 64 KB of arrival tickets that must read zero (the kernel leaves them so)
+        if (kind == 2) HIP_TRY(hipMemsetAsync(fresh, 0, (size_t)1 << 16, (hipStream_t)stream));
         if (slot->buf) slot->retired.push_back(slot->buf);      // stays allocated until exl2_release_scratch (see above)
         slot->buf = fresh;
         slot->bytes = want;
@@ -682,13 +684,31 @@ int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stre
                 continue;
             }
             {
-                // 17 .. 128 rows: the weight-stream-bound kernel (qgemm_skinny.hip); EXL2_PREFILL_SKINNY=0: the generic kernel (A/B runs, tests)
+                // 17 .. 128 rows: the weight-stream-bound kernel (qgemm_skinny.hip), the following jobs over the SAME staged rows
+                // (q | k | v, gate | up) in the same launch; EXL2_PREFILL_SKINNY=0: the generic kernel (A/B runs, tests)
                 const char* e = getenv("EXL2_PREFILL_SKINNY");
                 if (rows <= 128 && !(e && !atoi(e)))
                 {
-                    const int rc = qgemm_skinny_launch(p, gptq, stream);
+                    PrefillArgs pas[3];
+                    int n = 1;
+                    pas[0] = p;
+                    while (n < 3 && i + n < n_jobs && !getenv("EXL2_SKINNY_UNFUSED"))
+                    {
+                        const GemvJob& q = jobs[i + n];
+                        const GemvJob& pr = jobs[i + n - 1];
+                        const bool same = q.rows_as_prev && pr.a == q.a && pr.a2 == q.a2 && pr.lda == q.lda && pr.m.K == q.m.K &&
+                                          pr.a_mode == q.a_mode && pr.norm_w == q.norm_w && pr.norm_eps == q.norm_eps;
+                        if (!same) break;
+                        PrefillArgs& pq = pas[n];
+                        memset(&pq, 0, sizeof(pq));
+                        pq.m = q.m; pq.a = stage; pq.c = q.c + (size_t)r0 * q.ldc; pq.ldc = q.ldc; pq.c_invperm = q.c_invperm;
+                        pq.M = rows; pq.c_mode = q.c_mode;
+                        n++;
+                    }
+                    int rc = qgemm_skinny_launch(pas, n, gptq, stream);
+                    if (rc == 1 && n > 1) { n = 1; rc = qgemm_skinny_launch(pas, 1, gptq, stream); }
                     if (rc < 0) return rc;
-                    if (rc == 0) continue;
+                    if (rc == 0) { i += n - 1; continue; }
                 }
             }
             dim3 grid((unsigned)((j.m.N + PF_BN - 1) / PF_BN), (unsigned)((rows + PF_BM - 1) / PF_BM), 1);

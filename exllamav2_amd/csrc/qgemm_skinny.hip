@@ -277,13 +277,14 @@ DEV void sk_tail_step(const SkCtx& x, u8* smem, const u32* base, u32 tile_stride
     block_sync();
 }
 
+#define SK_MAX_JOBS 3        // matrices of one launch: q | k | v, gate | up multiply the same staged rows (GemvJob::rows_as_prev)
+struct SkinnyJob { QMatDev m; f16* c; const u16* c_invperm; int ldc, c_mode; };
 struct SkinnyArgs
 {
-    QMatDev m;
+    SkinnyJob job[SK_MAX_JOBS];
+    int group0[SK_MAX_JOBS + 1];   // first column group (blockIdx.x) of every matrix
     const f16* a;           // [M, K] in packed K order, row stride K (stage_rows_kernel's output)
-    f16* c; int ldc;
-    const u16* c_invperm;
-    int M, c_mode;
+    int M;
     int ks;                 // K splits (gridDim.y)
     f32x4* part;            // [column group][split][wave][row block][tile][lane] partial accumulators (ks > 1)
     u32* tickets;           // [column group], zero between launches
@@ -295,10 +296,12 @@ template <bool GPTQ, int RB>
 KERNEL void __launch_bounds__(SK_THREADS, RB == 8 ? 1 : 2) qgemm_skinny_kernel(const SkinnyArgs args)
 {
     DYN_SMEM(smem);
-    const QMatDev& m = args.m;
+    const int jb = (bid_x() >= args.group0[1] ? 1 : 0) + (bid_x() >= args.group0[2] ? 1 : 0);
+    const SkinnyJob& job = args.job[jb];
+    const QMatDev& m = job.m;
     const int t = tid(), lane = lane_id(), wv = uniform(wave_id());
     const int KS = args.ks, z = bid_y();
-    const int n0 = bid_x() * SK_BN;
+    const int n0 = (bid_x() - args.group0[jb]) * SK_BN;
     const int i16 = lane & 15, j4 = lane >> 4;
 
     SK_STAMP(0);
@@ -405,14 +408,14 @@ KERNEL void __launch_bounds__(SK_THREADS, RB == 8 ? 1 : 2) qgemm_skinny_kernel(c
     }
     SK_STAMP(5);
     // ---- epilogue: D fragment lane (c = l & 15, j) holds rows 4 j .. 4 j + 3 of column c ---------------------------------------------
-    if (SK_SKIP(x, 16)) { if (acc[0][0][0] == 123.456f) args.c[0] = (f16)1.0f; return; }
+    if (SK_SKIP(x, 16)) { if (acc[0][0][0] == 123.456f) job.c[0] = (f16)1.0f; return; }
     #pragma unroll
     for (int ct = 0; ct < SK_CT; ct++)
     {
         const int n = n0 + (wv * SK_CT + ct) * 16 + i16;
         if (n >= m.N) continue;
         const float bias = m.bias ? (float)m.bias[n] : 0.0f;
-        const int nn = args.c_invperm ? (int)args.c_invperm[n] : n;
+        const int nn = job.c_invperm ? (int)job.c_invperm[n] : n;
         #pragma unroll
         for (int rb = 0; rb < RB; rb++)
         {
@@ -422,9 +425,9 @@ KERNEL void __launch_bounds__(SK_THREADS, RB == 8 ? 1 : 2) qgemm_skinny_kernel(c
                 const int row = rb * 16 + j4 * 4 + e;
                 if (row < args.M)
                 {
-                    f16* cp = args.c + (size_t)row * args.ldc + nn;
+                    f16* cp = job.c + (size_t)row * job.ldc + nn;
                     float v = acc[rb][ct][e] + bias;
-                    if (args.c_mode == C_ACCUM) v += (float)*cp;
+                    if (job.c_mode == C_ACCUM) v += (float)*cp;
                     *cp = (f16)v;
                 }
             }
@@ -446,50 +449,56 @@ static int sk_launch_rb(const SkinnyArgs& p, dim3 grid, size_t lds, void* stream
     return EXL2_OK;
 }
 
-// 0 = launched, 1 = does not apply (the caller takes the generic kernel), < 0 = error
-int qgemm_skinny_launch(const PrefillArgs& pa, bool gptq, void* stream)
+// n (1 .. SK_MAX_JOBS) matrices over the SAME staged rows in one launch.  0 = launched, 1 = does not apply (the caller takes the generic
+// kernel, one matrix at a time), < 0 = error
+int qgemm_skinny_launch(const PrefillArgs* pas, int n, bool gptq, void* stream)
 {
-    const QMatDev& m = pa.m;
-    if (m.n_runs <= 0 || pa.M < 1 || pa.M > 128) return 1;
-    if ((size_t)128 * (size_t)m.K * 2 >= ((size_t)1 << 31)) return 1;             // the row copies address a 2 GB buffer window
-    const int rb = (pa.M + 15) / 16, RBT = rb <= 2 ? 2 : rb <= 4 ? 4 : rb <= 6 ? 6 : 8;
-    int full_items = 0;
-    for (int ri = 0; ri < m.n_runs; ri++) if (m.runs[ri].nvalid_last == 4) full_items += (int)m.runs[ri].n_super;
-    const int groups = (m.N + SK_BN - 1) / SK_BN;
+    if (n < 1 || n > SK_MAX_JOBS) return 1;
+    const int M = pas[0].M, K = pas[0].m.K;
+    if (M < 1 || M > 128) return 1;
+    if ((size_t)128 * (size_t)K * 2 >= ((size_t)1 << 31)) return 1;               // the row copies address a 2 GB buffer window
+    const int rb = (M + 15) / 16, RBT = rb <= 2 ? 2 : rb <= 4 ? 4 : rb <= 6 ? 6 : 8;
+    SkinnyArgs p;
+    memset(&p, 0, sizeof(p));
+    int groups = 0, min_items = 0x7fffffff;
+    for (int i = 0; i < n; i++)
+    {
+        const QMatDev& m = pas[i].m;
+        if (m.n_runs <= 0 || m.K != K || pas[i].M != M || pas[i].a != pas[0].a) return 1;
+        int full_items = 0;
+        for (int ri = 0; ri < m.n_runs; ri++) if (m.runs[ri].nvalid_last == 4) full_items += (int)m.runs[ri].n_super;
+        if (full_items < min_items) min_items = full_items;
+        p.job[i].m = m; p.job[i].c = pas[i].c; p.job[i].ldc = pas[i].ldc; p.job[i].c_invperm = pas[i].c_invperm; p.job[i].c_mode = pas[i].c_mode;
+        p.group0[i] = groups;
+        groups += (m.N + SK_BN - 1) / SK_BN;
+    }
+    for (int i = n; i <= SK_MAX_JOBS; i++) p.group0[i] = i == n ? groups : 0x7fffffff;
+    for (int i = n + 1; i <= SK_MAX_JOBS; i++) p.group0[i] = 0x7fffffff;
     // K splits: as many as fit the chip in ONE round (2 workgroups per CU; RB = 8: one, its stages fill the LDS -- a workgroup
     // that has to wait for a slot doubles the launch), >= 3 items per split
     int ks = (RBT == 8 ? 256 : 512) / groups;
     if (ks > 16) ks = 16;
-    if (ks > full_items / 3) ks = full_items / 3;
-    if (const char* e = getenv("EXL2_SKINNY_SPLITK")) { const int v = atoi(e); if (v >= 1) ks = v > 32 ? 32 : v; if (ks > full_items) ks = full_items; }
+    if (ks > min_items / 3) ks = min_items / 3;
+    if (const char* e = getenv("EXL2_SKINNY_SPLITK")) { const int v = atoi(e); if (v >= 1) ks = v > 32 ? 32 : v; if (ks > min_items) ks = min_items; }
     if (ks < 1) ks = 1;
-    const size_t lds = SK_LDS_BYTES(RBT, m.K >> 5);
+    const size_t lds = SK_LDS_BYTES(RBT, K >> 5);
     if (lds > 160 * 1024) return 1;
-
-    SkinnyArgs p;
-    memset(&p, 0, sizeof(p));
 #ifdef SK_DBG
     if (const char* e = getenv("EXL2_SKINNY_DBG")) p.dbg = atoi(e);
     if (const char* e = getenv("EXL2_SKINNY_TRACE_PTR")) p.trace = (u64*)strtoull(e, nullptr, 0);
 #endif
-    p.m = m; p.a = pa.a; p.c = pa.c; p.ldc = pa.ldc; p.c_invperm = pa.c_invperm; p.M = pa.M; p.c_mode = pa.c_mode; p.ks = ks;
+    p.a = pas[0].a; p.M = M; p.ks = ks;
     if (ks > 1)
     {
         const size_t part_bytes = (size_t)groups * ks * SK_WAVES * RBT * SK_CT * 64 * sizeof(f32x4);
         const size_t tick_bytes = (size_t)1 << 16;
         EXL2_REQUIRE((size_t)groups * 4 <= tick_bytes, "q_gemm: too many column groups for the split-K tickets");
         f16* buf = nullptr;
-        const int rc = prefill_scratch(tick_bytes + part_bytes, stream, 2, &buf); if (rc) return rc;
-        {
-            static std::mutex mu; static std::vector<void*> zeroed;                 // ticket areas already cleared (the kernel leaves them zero)
-            std::lock_guard<std::mutex> lock(mu);
-            bool seen = false; for (void* q : zeroed) if (q == (void*)buf) seen = true;
-            if (!seen) { HIP_TRY(hipMemsetAsync(buf, 0, tick_bytes, (hipStream_t)stream)); zeroed.push_back((void*)buf); }
-        }
+        const int rc = prefill_scratch(tick_bytes + part_bytes, stream, 2, &buf); if (rc) return rc;      // (tickets zeroed at allocation)
         p.tickets = (u32*)buf; p.part = (f32x4*)((u8*)buf + tick_bytes);
     }
     const dim3 grid((unsigned)groups, (unsigned)ks, 1);
-    if (getenv("EXL2_SKINNY_DEBUG")) fprintf(stderr, "[skinny] M %d K %d N %d RB %d grid %d x %d lds %zu items %d\n", pa.M, m.K, m.N, RBT, groups, ks, lds, full_items);
+    if (getenv("EXL2_SKINNY_DEBUG")) fprintf(stderr, "[skinny] M %d K %d matrices %d RB %d grid %d x %d lds %zu items %d\n", M, K, n, RBT, groups, ks, lds, min_items);
     if (gptq)
         switch (RBT)
         {

@@ -80,13 +80,16 @@ def test_chunked_prefill_equals_oracle(be):
     model.unload()
 
 
-@pytest.mark.parametrize("kernel", ["tile128", "tile256"])
+@pytest.mark.parametrize("kernel", ["skinny", "skinny_unfused", "tile128", "tile256"])
 def test_prefill_sized_forward_equals_oracle(be, kernel, monkeypatch):
     """rows > 16 through the module handles (q_attn_forward_1 / _2, q_mlp_forward_): row pre-pass + dequantize-into-MFMA GEMM,
-    once with the 128 x 128 register-decode kernel (qgemm_prefill.hip) and once with the 256-column LDS-decode kernel
-    (qgemm_mfma.hip) forced for every row count; attention is the MFMA flash-prefill kernel (attn_prefill.hip); then one
-    decode step on the cache they filled.  No torch GEMM / SDPA anywhere on this route."""
-    monkeypatch.setenv("EXL2_PREFILL_MFMA_MIN_ROWS", "0" if kernel == "tile128" else "17")
+    with the 17-128-row kernel (qgemm_skinny.hip; q | k | v and gate | up in ONE launch each, or one launch per matrix), the generic
+    128 x 128 register-decode kernel (qgemm_prefill.hip) and the 256-column LDS-decode kernel (qgemm_mfma.hip) forced for every row
+    count; attention is the MFMA flash-prefill kernel (attn_prefill.hip); then one decode step on the cache they filled.  No torch
+    GEMM / SDPA anywhere on this route."""
+    monkeypatch.setenv("EXL2_PREFILL_MFMA_MIN_ROWS", "17" if kernel == "tile256" else "0")
+    if kernel == "tile128": monkeypatch.setenv("EXL2_PREFILL_SKINNY", "0")
+    if kernel == "skinny_unfused": monkeypatch.setenv("EXL2_SKINNY_UNFUSED", "1")
     cfg = tiny_cfg(max_input_len=128, max_seq_len=256, num_hidden_layers=1)
     model, oracle = build(be, cfg, seed=3)
     cache = ExLlamaV2Cache(model, batch_size=1)
@@ -102,6 +105,33 @@ def test_prefill_sized_forward_equals_oracle(be, kernel, monkeypatch):
     nxt = np.array([[5]])
     logits = model.forward(torch.from_numpy(nxt), cache)
     check_logits(be.n(logits), oracle.forward(nxt)[:, -1:])
+    model.unload()
+
+
+@pytest.mark.parametrize("recipe", ["4.0bpw", "2.5bpw", "gptq-4bit-128g"])
+@pytest.mark.parametrize("batch", [17, 40])
+def test_batch_decode_of_17_to_128_sequences_equals_oracle(be, recipe, batch):
+    """More than 16 sequences decoding together (round 6): every module GEMM has 17-128 rows and runs on qgemm_skinny_kernel
+    (q | k | v and gate | up fused per launch, K split over workgroups, deterministic ticket reduction); logits against the oracle
+    on every step, and a second run of the same steps is bit-identical."""
+    cfg = tiny_cfg(num_hidden_layers=2, hidden_size=256, intermediate_size=384, max_input_len=64)
+    model, oracle = build(be, cfg, recipe=recipe, seed=8)
+    rng = np.random.default_rng(8)
+    ids0 = rng.integers(0, cfg.vocab_size, size=(batch, 1))
+    runs = []
+    for rep in range(2):
+        cache = ExLlamaV2Cache(model, batch_size=batch)
+        oracle.reset(batch)
+        ids, outs = ids0, []
+        for _ in range(3):
+            logits = be.n(model.forward(torch.from_numpy(ids), cache))
+            want = oracle.forward(ids)
+            check_logits(logits, want)
+            outs.append(logits.copy())
+            ids = np.argmax(want[:, -1], axis=-1)[:, None]
+        runs.append(outs)
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
     model.unload()
 
 
