@@ -424,9 +424,11 @@ struct RowStageArgs
 {
     const f16* a; const f16* a2; const f16* norm_w; const u16* perm; f16* out;
     int K, lda, mode; float eps;
+    int parts;               // stage_rows_kernel, few rows: blockIdx.y = which slice of the OUTPUT row this workgroup writes (every
+                             // workgroup of a row transforms the whole row -- a few KB from the L2 -- so that rows x parts fill the chip)
 };
 
-DEV void stage_rows_body(const RowStageArgs& s, char* smem)
+DEV void stage_rows_body(const RowStageArgs& s, char* smem, int slice = 0, int slices = 1)
 {
     const int r = bid_x();
     const int t = tid(), nt = nthreads(), lane = lane_id(), wv = wave_id(), nw = nt >> 6;
@@ -478,7 +480,8 @@ DEV void stage_rows_body(const RowStageArgs& s, char* smem)
     }
     block_sync();
     f16* out = s.out + (size_t)r * s.K;
-    for (int i = t; i < oct; i += nt)
+    const int o_lo = (int)((long long)oct * slice / slices), o_hi = (int)((long long)oct * (slice + 1) / slices);
+    for (int i = o_lo + t; i < o_hi; i += nt)
     {
         f16x8 v;
         if (s.perm)
@@ -495,7 +498,8 @@ DEV void stage_rows_body(const RowStageArgs& s, char* smem)
 KERNEL void __launch_bounds__(256) stage_rows_kernel(const RowStageArgs s)
 {
     DYN_SMEM(smem);
-    stage_rows_body(s, (char*)smem);
+    if (s.parts > 1) stage_rows_body(s, (char*)smem, bid_y(), s.parts);
+    else stage_rows_body(s, (char*)smem);
 }
 
 // the same for the matrices of a fused launch (blockIdx.y = matrix): one launch ahead of the phased decode kernel
@@ -670,7 +674,11 @@ int qgemm_prefill_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stre
                 memset(&s, 0, sizeof(s));
                 s.a = j.a + (size_t)r0 * j.lda; s.a2 = j.a2 ? j.a2 + (size_t)r0 * j.lda : nullptr;
                 s.norm_w = j.norm_w; s.perm = j.m.perm; s.out = stage; s.K = j.m.K; s.lda = j.lda; s.mode = j.a_mode; s.eps = j.norm_eps;
-                LAUNCH(stage_rows_kernel, dim3((unsigned)rows), dim3(256), (size_t)j.m.K * 2 + 64, stream, s);
+                // few rows: rows x parts workgroups ~ one per CU (a 32-row pre-pass on 32 CUs took 6.8 us, 20 % of a 32-sequence decode layer)
+                s.parts = rows >= 128 ? 1 : (256 / rows > 16 ? 16 : 256 / rows);
+                if (getenv("EXL2_STAGE_PARTS")) s.parts = atoi(getenv("EXL2_STAGE_PARTS"));
+                if (s.parts < 1) s.parts = 1;
+                LAUNCH(stage_rows_kernel, dim3((unsigned)rows, (unsigned)s.parts, 1), dim3(256), (size_t)j.m.K * 2 + 64, stream, s);
             }
 
             PrefillArgs p;
