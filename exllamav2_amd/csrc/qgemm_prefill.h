@@ -1,5 +1,5 @@
 // qgemm_prefill.h -- what the prefill-shaped q_gemm kernels (qgemm_skinny.hip: 17 .. 128 rows, weight-stream bound; qgemm_mfma.hip:
-// 256 x 256 tiles, B decoded once per call; qgemm_prefill.hip: the generic 128 x 128 kernel + the row pre-pass) share with their host driver.
+// 256 x 256 tiles, B decoded once per call; qgemm_prefill.hip: the row pre-pass) share with their host driver.
 #pragma once
 #include "qgemv_common.h"
 
@@ -19,7 +19,7 @@ struct PrefillArgs
 // 1 = decoded weight fragments (two buffers of one call must not alias)
 int prefill_scratch(size_t bytes, void* stream, int kind, f16** out);
 
-// qgemm_skinny.hip (17 .. 128 rows): 0 = launched, 1 = does not apply (generic 128 x 128 kernel), < 0 = error (message set)
+// qgemm_skinny.hip (17 .. 128 rows): 0 = launched, 1 = does not apply (the many-row kernel takes the call), < 0 = error (message set)
 int qgemm_skinny_launch(const PrefillArgs* p, int n, bool gptq, void* stream);     // n <= 3 matrices over the same staged rows
 
 // qgemm_mfma.hip: 0 = launched, < 0 = error (message set)

@@ -2,8 +2,8 @@
 //
 // Replaces, for these row counts, the reference's reconstruct_kernel + library Hgemm (cuda/q_gemm.cu:243-263: the whole fp16 [K, N]
 // matrix written to HBM and read back for a product that needs K N / 2 bytes of weights) and this library's own round-1 kernel
-// (qgemm_prefill.hip: 128 x 128 tiles, ONE K step in flight, a barrier-synchronised global round trip per step = 3-4 us x K / 128
-// steps: 137 us for a 7B gate_proj at 64 rows, on 86 of 256 CUs).
+// (128 x 128 tiles, ONE K step in flight, a barrier-synchronised global round trip per step = 3-4 us x K / 128 steps: 137 us for a 7B
+// gate_proj at 64 rows, on 86 of 256 CUs; removed in round 6, git history).
 //
 // The product is bound by the weight stream (64 rows: 256 FLOP per weight byte, the chip's ridge is ~310), so the kernel is built like
 // the decode kernels -- many small workgroups, every request far ahead of its use -- and not like a GEMM:
@@ -277,6 +277,31 @@ DEV void sk_tail_step(const SkCtx& x, u8* smem, const u32* base, u32 tile_stride
     block_sync();
 }
 
+// one contiguous stream of items per 16-column tile: a bit-width section (QRun, kernel arguments) or, for matrices with more sections
+// than the argument block holds (n_runs = 0), a descriptor (QDesc, device memory); its last item may be partial (`tail_nv` chunks)
+struct SkSegment { const u32* base; u32 tile_stride; int n_full, k_base, bits, tail_nv; };
+DEV SkSegment sk_segment(const QMatDev& m, int i)
+{
+    SkSegment g;
+    int n_super, nvl, in_tail; u32 base_word;
+    if (m.n_runs > 0)
+    {
+        const QRun& r = m.runs[i];
+        n_super = uniform((int)r.n_super); nvl = uniform((int)r.nvalid_last); in_tail = uniform((int)r.in_tail); base_word = uniform(r.base_word);
+        g.tile_stride = uniform(r.tile_stride); g.k_base = uniform((int)r.k_base); g.bits = uniform((int)r.bits);
+    }
+    else
+    {
+        const QDesc* d = m.desc + i;
+        n_super = uniform((int)d->n_super); nvl = uniform((int)d->nvalid_last); in_tail = uniform((int)d->in_tail); base_word = uniform(d->base_word);
+        g.tile_stride = uniform(d->tile_stride); g.k_base = uniform((int)d->k_base); g.bits = uniform((int)d->bits);
+    }
+    g.base = (in_tail ? m.tail : m.qw) + base_word;
+    g.n_full = nvl == 4 ? n_super : n_super - 1;
+    g.tail_nv = nvl == 4 ? 0 : nvl;
+    return g;
+}
+
 #define SK_MAX_JOBS 3        // matrices of one launch: q | k | v, gate | up multiply the same staged rows (GemvJob::rows_as_prev)
 struct SkinnyJob { QMatDev m; f16* c; const u16* c_invperm; int ldc, c_mode; };
 struct SkinnyArgs
@@ -317,8 +342,9 @@ KERNEL void __launch_bounds__(SK_THREADS, RB == 8 ? 1 : 2) qgemm_skinny_kernel(c
     }
 
     // this split's share: full items [it_lo, it_hi) counted over the sections in K order; partial last items go to the last split
+    const int n_seg = m.n_runs > 0 ? m.n_runs : m.n_desc;
     int total = 0;
-    for (int ri = 0; ri < m.n_runs; ri++) if (m.runs[ri].nvalid_last == 4) total += (int)m.runs[ri].n_super;
+    for (int si = 0; si < n_seg; si++) total += sk_segment(m, si).n_full;
     const int it_lo = (int)((long long)total * z / KS), it_hi = (int)((long long)total * (z + 1) / KS);
     {
         u16* cg = (u16*)(smem + SK_NST(RB) * SK_STAGE_BYTES(RB));
@@ -335,40 +361,41 @@ KERNEL void __launch_bounds__(SK_THREADS, RB == 8 ? 1 : 2) qgemm_skinny_kernel(c
         for (int ct = 0; ct < SK_CT; ct++) acc[rb][ct] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
     int pos = 0;
-    for (int ri = 0; ri < m.n_runs; ri++)
+    for (int si = 0; si < n_seg; si++)
     {
-        const QRun& run = m.runs[ri];
-        const int bits = uniform((int)run.bits);
-        const u32* base = (uniform((int)run.in_tail) ? m.tail : m.qw) + uniform(run.base_word);
-        const u32 tile_stride = uniform(run.tile_stride);
-        int F = uniform((int)run.n_super), k_base = uniform((int)run.k_base);
-        const int nvl = uniform((int)run.nvalid_last);
-        if (nvl == 4)
+        const SkSegment sg = sk_segment(m, si);
+        const int bits = GPTQ ? 4 : sg.bits;
+        if (sg.n_full > 0)
         {
-            const int f0 = max(it_lo - pos, 0), f1 = min(it_hi - pos, F);
-            pos += F;
-            if (f1 <= f0) continue;
-            base += (size_t)f0 * (size_t)(64 * (GPTQ ? 4 : bits)); k_base += f0 * SUPER_ROWS; F = f1 - f0;
-            switch (GPTQ ? 4 : bits)
+            const int f0 = max(it_lo - pos, 0), f1 = min(it_hi - pos, sg.n_full);
+            pos += sg.n_full;
+            if (f1 > f0)
             {
-                case 4: sk_run_stream<4, GPTQ, RB>(x, smem, base, tile_stride, F, k_base, acc); break;
-                case 8: if constexpr (!GPTQ) sk_run_stream<8, false, RB>(x, smem, base, tile_stride, F, k_base, acc); break;
-                case 6: if constexpr (!GPTQ) sk_run_stream<6, false, RB>(x, smem, base, tile_stride, F, k_base, acc); break;
-                case 5: if constexpr (!GPTQ) sk_run_stream<5, false, RB>(x, smem, base, tile_stride, F, k_base, acc); break;
-                case 3: if constexpr (!GPTQ) sk_run_stream<3, false, RB>(x, smem, base, tile_stride, F, k_base, acc); break;
-                default: if constexpr (!GPTQ) sk_run_stream<2, false, RB>(x, smem, base, tile_stride, F, k_base, acc); break;
+                const u32* base = sg.base + (size_t)f0 * (size_t)(64 * bits);
+                const int k_base = sg.k_base + f0 * SUPER_ROWS, F = f1 - f0;
+                switch (bits)
+                {
+                    case 4: sk_run_stream<4, GPTQ, RB>(x, smem, base, sg.tile_stride, F, k_base, acc); break;
+                    case 8: if constexpr (!GPTQ) sk_run_stream<8, false, RB>(x, smem, base, sg.tile_stride, F, k_base, acc); break;
+                    case 6: if constexpr (!GPTQ) sk_run_stream<6, false, RB>(x, smem, base, sg.tile_stride, F, k_base, acc); break;
+                    case 5: if constexpr (!GPTQ) sk_run_stream<5, false, RB>(x, smem, base, sg.tile_stride, F, k_base, acc); break;
+                    case 3: if constexpr (!GPTQ) sk_run_stream<3, false, RB>(x, smem, base, sg.tile_stride, F, k_base, acc); break;
+                    default: if constexpr (!GPTQ) sk_run_stream<2, false, RB>(x, smem, base, sg.tile_stride, F, k_base, acc); break;
+                }
             }
         }
-        else if (z == KS - 1)
+        if (sg.tail_nv > 0 && z == KS - 1)
         {
-            switch (GPTQ ? 4 : bits)
+            const u32* base = sg.base + (size_t)sg.n_full * (size_t)(64 * bits);
+            const int k0 = sg.k_base + sg.n_full * SUPER_ROWS, nvl = sg.tail_nv;
+            switch (bits)
             {
-                case 4: sk_tail_step<4, GPTQ, RB>(x, smem, base, tile_stride, k_base, nvl, acc); break;
-                case 8: if constexpr (!GPTQ) sk_tail_step<8, false, RB>(x, smem, base, tile_stride, k_base, nvl, acc); break;
-                case 6: if constexpr (!GPTQ) sk_tail_step<6, false, RB>(x, smem, base, tile_stride, k_base, nvl, acc); break;
-                case 5: if constexpr (!GPTQ) sk_tail_step<5, false, RB>(x, smem, base, tile_stride, k_base, nvl, acc); break;
-                case 3: if constexpr (!GPTQ) sk_tail_step<3, false, RB>(x, smem, base, tile_stride, k_base, nvl, acc); break;
-                default: if constexpr (!GPTQ) sk_tail_step<2, false, RB>(x, smem, base, tile_stride, k_base, nvl, acc); break;
+                case 4: sk_tail_step<4, GPTQ, RB>(x, smem, base, sg.tile_stride, k0, nvl, acc); break;
+                case 8: if constexpr (!GPTQ) sk_tail_step<8, false, RB>(x, smem, base, sg.tile_stride, k0, nvl, acc); break;
+                case 6: if constexpr (!GPTQ) sk_tail_step<6, false, RB>(x, smem, base, sg.tile_stride, k0, nvl, acc); break;
+                case 5: if constexpr (!GPTQ) sk_tail_step<5, false, RB>(x, smem, base, sg.tile_stride, k0, nvl, acc); break;
+                case 3: if constexpr (!GPTQ) sk_tail_step<3, false, RB>(x, smem, base, sg.tile_stride, k0, nvl, acc); break;
+                default: if constexpr (!GPTQ) sk_tail_step<2, false, RB>(x, smem, base, sg.tile_stride, k0, nvl, acc); break;
             }
         }
     }
@@ -464,11 +491,14 @@ int qgemm_skinny_launch(const PrefillArgs* pas, int n, bool gptq, void* stream)
     for (int i = 0; i < n; i++)
     {
         const QMatDev& m = pas[i].m;
-        if (m.n_runs <= 0 || m.K != K || pas[i].M != M || pas[i].a != pas[0].a) return 1;
+        if (m.K != K || pas[i].M != M || pas[i].a != pas[0].a) return 1;
         int full_items = 0;
         for (int ri = 0; ri < m.n_runs; ri++) if (m.runs[ri].nvalid_last == 4) full_items += (int)m.runs[ri].n_super;
+        if (m.n_runs <= 0) full_items = (K >> 7) - m.n_desc > 0 ? (K >> 7) - m.n_desc : 0;       // (descriptors live on the device: a lower bound)
         if (full_items < min_items) min_items = full_items;
-        p.job[i].m = m; p.job[i].c = pas[i].c; p.job[i].ldc = pas[i].ldc; p.job[i].c_invperm = pas[i].c_invperm; p.job[i].c_mode = pas[i].c_mode;
+        p.job[i].m = m;
+        if (getenv("EXL2_SKINNY_FORCE_DESC")) p.job[i].m.n_runs = 0;      // tests: walk the descriptors (what a matrix with > MAX_RUNS sections takes)
+        p.job[i].c = pas[i].c; p.job[i].ldc = pas[i].ldc; p.job[i].c_invperm = pas[i].c_invperm; p.job[i].c_mode = pas[i].c_mode;
         p.group0[i] = groups;
         groups += (m.N + SK_BN - 1) / SK_BN;
     }

@@ -80,15 +80,13 @@ def test_chunked_prefill_equals_oracle(be):
     model.unload()
 
 
-@pytest.mark.parametrize("kernel", ["skinny", "skinny_unfused", "tile128", "tile256"])
+@pytest.mark.parametrize("kernel", ["skinny", "skinny_unfused", "tile256"])
 def test_prefill_sized_forward_equals_oracle(be, kernel, monkeypatch):
     """rows > 16 through the module handles (q_attn_forward_1 / _2, q_mlp_forward_): row pre-pass + dequantize-into-MFMA GEMM,
-    with the 17-128-row kernel (qgemm_skinny.hip; q | k | v and gate | up in ONE launch each, or one launch per matrix), the generic
-    128 x 128 register-decode kernel (qgemm_prefill.hip) and the 256-column LDS-decode kernel (qgemm_mfma.hip) forced for every row
-    count; attention is the MFMA flash-prefill kernel (attn_prefill.hip); then one decode step on the cache they filled.  No torch
-    GEMM / SDPA anywhere on this route."""
-    monkeypatch.setenv("EXL2_PREFILL_MFMA_MIN_ROWS", "17" if kernel == "tile256" else "0")
-    if kernel == "tile128": monkeypatch.setenv("EXL2_PREFILL_SKINNY", "0")
+    with the 17-128-row kernel (qgemm_skinny.hip; q | k | v and gate | up in ONE launch each, or one launch per matrix) and with the
+    256-column LDS-decode kernel (qgemm_mfma.hip) forced for every row count; attention is the MFMA flash-prefill kernel
+    (attn_prefill.hip); then one decode step on the cache they filled.  No torch GEMM / SDPA anywhere on this route."""
+    if kernel == "tile256": monkeypatch.setenv("EXL2_PREFILL_MFMA_MIN_ROWS", "17")
     if kernel == "skinny_unfused": monkeypatch.setenv("EXL2_SKINNY_UNFUSED", "1")
     cfg = tiny_cfg(max_input_len=128, max_seq_len=256, num_hidden_layers=1)
     model, oracle = build(be, cfg, seed=3)

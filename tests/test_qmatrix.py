@@ -113,20 +113,17 @@ def test_prefill_vs_oracle(be, m):
 def test_skinny_kernel_split_k(be, name, m, monkeypatch):
     """Round 6: 17-128 rows run on qgemm_skinny_kernel (weight-stream bound: 128 columns x all rows x a slice of K per workgroup).
     EXL2_SKINNY_SPLITK forces the number of K splits here (the host picks it from the grid otherwise): partial tiles leave as
-    agent-scope stores, the last split to arrive adds them in split order.  Same bar against the oracle for every split count and
-    for the generic 128 x 128 kernel (EXL2_PREFILL_SKINNY=0); two runs are bit-identical (fixed order); identity rows return
-    reconstruct() bit for bit; the ticket reset (a second call on the same scratch) works."""
+    agent-scope stores, the last split to arrive adds them in split order.  Same bar against the oracle for every split count; two
+    runs are bit-identical (fixed order); identity rows return reconstruct() bit for bit; the ticket reset (a second call on the
+    same scratch) works."""
     k, n, spec = SPECS[name]
     t, ref, w, h = make_exl2(be, k, n, spec, seed=21, bias=True)
     rng = np.random.default_rng(22)
     a = rng.standard_normal((m, k)).astype(np.float16)
     want = OX.gemm_ref(a, ref, bias=t["bias"], exact=True)
     outs = {}
-    for ks in ("generic", "1", "2", "3", "5"):
-        if ks == "generic": monkeypatch.setenv("EXL2_PREFILL_SKINNY", "0")
-        else:
-            monkeypatch.delenv("EXL2_PREFILL_SKINNY", raising=False)
-            monkeypatch.setenv("EXL2_SKINNY_SPLITK", ks)
+    for ks in ("1", "2", "3", "5"):
+        monkeypatch.setenv("EXL2_SKINNY_SPLITK", ks)
         for rep in range(2):
             c = torch.full((m, n), 7.0, dtype=torch.float16, device=be.device)
             be.ext.gemm_half_q_half(be.t(a), h, c)
@@ -134,6 +131,12 @@ def test_skinny_kernel_split_k(be, name, m, monkeypatch):
             assert np.all(np.abs(got.astype(np.float64) - want) <= half_tol(want, k)), (ks, rep)
             if rep: assert np.array_equal(got, outs[ks])
             outs[ks] = got
+    # a matrix with more bit-width sections than the kernel arguments hold walks its descriptors in device memory instead: forced here
+    monkeypatch.setenv("EXL2_SKINNY_FORCE_DESC", "1")
+    c = torch.full((m, n), 7.0, dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half(be.t(a), h, c)
+    assert np.array_equal(be.n(c), outs["5"])
+    monkeypatch.delenv("EXL2_SKINNY_FORCE_DESC")
     # identity rows: every output has ONE non-zero term, whatever the split
     eye = np.zeros((m, k), dtype=np.float16)
     rows = rng.choice(k, size=m, replace=False)

@@ -43,17 +43,16 @@ def _stat(ms_list, flops):
             "frac_mfma_peak": round(flops / med / 1e9 / MFMA_PEAK_F16, 4), "reps": len(ms)}
 
 
-# kernel selection of csrc/qgemm_prefill.hip's host driver (read per call): the shipped choice, each tile height of the
-# 256-column LDS-decode kernel (qgemm_mfma.hip), and the 128 x 128 register-decode kernel (qgemm_prefill.hip)
+# kernel selection of csrc/qgemm_prefill.hip's host driver (read per call): the shipped choice and each tile height of the
+# 256-column LDS-decode kernel (qgemm_mfma.hip)
 VARIANTS = {"auto": {}, "tile256_mt8": {"EXL2_PREFILL_MT": "8"}, "tile256_mt4": {"EXL2_PREFILL_MT": "4"},
-            "tile128": {"EXL2_PREFILL_MFMA_MIN_ROWS": "0"},
             "decode_in_gemm": {"EXL2_PREFILL_WPRE_MIN_ROWS": "0"},       # round 3: >= 2048 rows decode the weights once per call (auto)
-            # round 6, 17-128 rows (qgemm_skinny.hip): the generic 128 x 128 kernel instead, forced K splits
-            "generic": {"EXL2_PREFILL_SKINNY": "0"}, "nosplit": {"EXL2_SKINNY_SPLITK": "1"}, "split2": {"EXL2_SKINNY_SPLITK": "2"},
+            # round 6, 17-128 rows (qgemm_skinny.hip): forced K splits
+            "nosplit": {"EXL2_SKINNY_SPLITK": "1"}, "split2": {"EXL2_SKINNY_SPLITK": "2"},
             "split4": {"EXL2_SKINNY_SPLITK": "4"}, "split8": {"EXL2_SKINNY_SPLITK": "8"}, "split16": {"EXL2_SKINNY_SPLITK": "16"}}
 
 
-def bench_linear(k, n, m, recipe, reps=20, variants=("auto", "tile256_mt8", "tile256_mt4", "tile128")):
+def bench_linear(k, n, m, recipe, reps=20, variants=("auto", "tile256_mt8", "tile256_mt4")):
     gen = torch.Generator(device="cuda"); gen.manual_seed(0)
     w = synth_linear(k, n, recipe, "cuda", gen)
     h = ext.make_q_matrix_from_dict(w, none_tensor)
@@ -62,7 +61,7 @@ def bench_linear(k, n, m, recipe, reps=20, variants=("auto", "tile256_mt8", "til
     wd = torch.empty((k, n), device="cuda", dtype=torch.float16)
     out = {"k": k, "n": n, "m": m, "recipe": str(recipe), "timing": f"interleaved rounds, {reps} per variant, median (and min)"}
     flops = 2.0 * m * k * n
-    keys = ("EXL2_PREFILL_MT", "EXL2_PREFILL_MFMA_MIN_ROWS", "EXL2_PREFILL_WPRE_MIN_ROWS", "EXL2_PREFILL_SKINNY", "EXL2_SKINNY_SPLITK")
+    keys = ("EXL2_PREFILL_MT", "EXL2_PREFILL_MFMA_MIN_ROWS", "EXL2_PREFILL_WPRE_MIN_ROWS", "EXL2_SKINNY_SPLITK")
 
     def variant(name):
         def run():
@@ -122,7 +121,7 @@ if __name__ == "__main__":
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--model", action="store_true")
     ap.add_argument("--layers", type=int, default=0)
-    ap.add_argument("--variants", default="auto,tile256_mt8,tile256_mt4,tile128", help="kernel selections to time (first = the baseline)")
+    ap.add_argument("--variants", default="auto,tile256_mt8,tile256_mt4", help="kernel selections to time (first = the baseline)")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--small", action="store_true", help="the 17-128-row kernel: the three 7B linears at 32 / 64 / 128 rows, K split off / auto / forced")
     args = ap.parse_args()
@@ -135,6 +134,6 @@ if __name__ == "__main__":
     if args.quick: cases = cases[1:2] + cases[3:4]
     if args.small:
         cases = [(k, n, m, rec) for m in (32, 64, 128) for (k, n, _, rec) in cases[:3]]
-        if args.variants == ap.get_default("variants"): args.variants = "auto,generic,nosplit,split2,split4,split8,split16"
+        if args.variants == ap.get_default("variants"): args.variants = "auto,nosplit,split2,split4,split8,split16"
     for k, n, m, rec in cases:
         print(json.dumps(bench_linear(k, n, m, rec, reps=args.reps, variants=tuple(args.variants.split(",")))), flush=True)
