@@ -70,6 +70,8 @@
 #ifndef LEAN_XMEM_AHEAD
 #define LEAN_XMEM_AHEAD 3             // XMEM form: items whose A operands are in registers or in flight (16 registers each)
 #endif
+#define LEAN_X_PIECES_BASE 4           // 1 KB copy instructions per activation row of a wave's slice (stage_copies; lean_plan_matrix declines longer slices)
+#define LEAN_X_PIECES_PAIR_LOADS 6     // ... of the pair geometry with several register loads per wave (its own instantiation)
 #define LEAN_MAX_WAVES 16
 #define LEAN_RECORDS 48               // wave records in the argument block: matrices x waves per tile (q|k|v at 16 waves)
 #define LEAN_MAX_PASSES 4             // 16-wave geometry: a wave's share may be this many register loads (qgemv_lean_kernel, further passes)
@@ -490,7 +492,8 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     // rest_ctx: everything else the decode needs, unpacked behind ALL requests.
     struct Rest { LeanCtx cx; float* red; int M; u32 flags; int chunk0, g0, gshift, gphase; bool uni; };
     struct Staged { u8* wbase; u32 off_sc, off_zp; int x_stride, xc0, M; };
-    constexpr int LEAN_X_PIECES = 4;                                      // (K = 28672 over 16 waves: 1792 rows = 224 16-byte units per slice)
+    // (six pieces in every instantiation: the 7B step 0.6 % slower, profiles/r07d_ab_7b_ring_in_every_instantiation.txt -- code in front of the last requests)
+    constexpr int LEAN_X_PIECES = (S == 4 && PAIR && !ROWS && WALK) ? LEAN_X_PIECES_PAIR_LOADS : LEAN_X_PIECES_BASE;   // (K = 28672 over 16 waves: 1792 rows = 224 16-byte units per slice; K = 8192 over the 4 waves of a pair's tile with a 10 % / 90 % bit mix: 77 chunks = 308)
     auto stage_copies = [&](Staged& P, auto tag) {
         // (a distinct marker per instantiation: identical copies of this code in two instantiations of `head` get merged by the
         // compiler otherwise, and then the registers of EITHER instantiation's pending requests count as pending here -- the
@@ -635,8 +638,13 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         constexpr int D = LeanDepth<BITS, S>::v;
         constexpr int DA = D - NB;
         constexpr size_t STEP = 64 * BITS;
-        constexpr bool PASSES = !XMEM && (S == 16 || (S == 8 && NSLOTS == 1 && !PAIR && !ROWS && LEAN_S8_PASSES > 1 && BITS <= LEAN_S8_PASS_BITS));   // (what lean_plan_matrix plans)
+        // (WALK without ROWS = the pair geometry whose 4 waves per tile take their share in up to three register loads: K = 8192 at 2-3 bits,
+        // the 70B gate|up.  Its own instantiation: with the ring code inside, the 7B gate|up launch measured 0.6 % slower)
+        constexpr bool PAIR_LOADS = S == 4 && PAIR && !ROWS && WALK;
+        constexpr bool PASSES = !XMEM && (S == 16 || (S == 8 && NSLOTS == 1 && !PAIR && !ROWS && LEAN_S8_PASSES > 1 && BITS <= LEAN_S8_PASS_BITS) ||
+                                          (PAIR_LOADS && BITS <= LEAN_S8_PASS_BITS));   // (what lean_plan_matrix plans)
         constexpr bool RING = PASSES && LEAN_PASS_RING && BITS <= LEAN_S8_PASS_BITS;      // (wider items: a whole load at a time, the round-4 loop)
+        constexpr bool MANY_LOADS = S == 16 || PAIR_LOADS;                          // shares of more than two register loads (the 70B pair: up to three)
         LaneWords<BITS> a[DA > 0 ? DA : 1], b[NB > 0 ? NB : 1], bt;
         const int nA = n - NB;
         u32 xvoff = 0;                                                 // XMEM: the lane's byte offset into the activations (row, 8 j)
@@ -723,11 +731,11 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
                 for (int q = 0; q < D; q++)
                 {
                     if (D + q < n) item(a[q], D + q);
-                    if constexpr (S == 16) request(a[q], 2 * D + q);
+                    if constexpr (MANY_LOADS) request(a[q], 2 * D + q);
                 }
                 // (8 waves: two loads at most, lean_plan_matrix)
                 #pragma nounroll
-                for (int q0 = 2 * D; S == 16 && q0 < n; q0 += D)
+                for (int q0 = 2 * D; MANY_LOADS && q0 < n; q0 += D)
                 {
                     #pragma unroll
                     for (int q = 0; q < D; q++)
@@ -1125,7 +1133,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
             if (shift < 0 || c0 > 0xFFFF || c_end - c0 > 0xFFFF || g_lo > 0xFFFF || g_hi - g_lo + 1 > 0xFFFF) return 0;
             // what the kernel's straight-line staging copies (stage_copies); ROWS: the rows are staged by the workgroup, any length
             // (XMEM: no staged activations -- any M <= 16, any slice; one pass only: the ring of A operands covers LeanDepth items)
-            if ((g_hi - g_lo + 1) > 64 || (!rows_mode && !xmem && ((c_end - c0) * 4 > 256 || M > 4))) return 0;
+            if ((g_hi - g_lo + 1) > 64 || (!rows_mode && !xmem && ((c_end - c0) * 4 > 64 * ((S == 4 && passes > 1) ? LEAN_X_PIECES_PAIR_LOADS : LEAN_X_PIECES_BASE) || M > 4))) return 0;
             if (xmem && n > lean_depth(r.bits, S)) return 0;
             const bool uni = shift >= 2 && (phase & 3) == 0;                   // the four chunks of every full item share a group
             lw.w_off = r.off + (u32)i0 * 64u * (u32)r.bits; lw.w_tstride = r.tstride;
@@ -1157,6 +1165,11 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
 #ifndef LEAN_OCC_DEFAULT
 #define LEAN_OCC_DEFAULT 6
 #endif
+// the several-loads pair (70B gate|up): 80 registers as well -- three 8-wave workgroups per CU (53 KB of LDS each); at 128 registers
+// (two per CU) the launch takes what the 16-wave geometry took (59 us: gpurun r08a)
+#ifndef LEAN_PAIR_LOADS_OCC
+#define LEAN_PAIR_LOADS_OCC LEAN_OCC_DEFAULT
+#endif
 
 static void lean_attrs()
 {
@@ -1167,6 +1180,8 @@ static void lean_attrs()
     (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, S, NS, P, OCC, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LEAN_FOR_EACH_GEOMETRY(LEAN_ATTR, LEAN_OCC_DEFAULT)
 #undef LEAN_ATTR
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, 4, 2, true, LEAN_PAIR_LOADS_OCC, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, 4, 2, true, LEAN_PAIR_LOADS_OCC, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #define LEAN_ATTR(S, NS, P, OCC) \
     (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, OCC, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1228,8 +1243,15 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     // the first ones have finished: profiles/history/r03_trace_lean_v6.txt, workgroup entry p90 9.5 us)
     int cand[3] = {0, 0, 0}, n_cand = 0;
     static const int pair4 = []() { const char* e = getenv("EXL2_LEAN_PAIR4"); return e ? atoi(e) : 1; }();
-    if (in.pair && in.M == 1 && pair4) cand[n_cand++] = 4;
     int cand_passes[3] = {0, 0, 0};                                    // (0 = the geometry's default: lean_plan_matrix)
+    u32 cand_budget[3] = {0, 0, 0};                                    // (0 = LEAN_LDS_BUDGET per 8 waves)
+    if (in.pair && in.M == 1 && pair4) cand[n_cand++] = 4;
+    // a pair whose K is too long for ONE register load of its 4 waves per tile (70B: K = 8192 at 2-3 bits = 19 items per wave): two
+    // loads (the ring of the 8-wave q|k|v launches) and a 64 KB budget -- two 8-wave workgroups per CU, 512 of the 1792 resident
+    // at once -- before the 16-wave workgroup that is alone on its CU (seven rounds of 256: profiles/history/r05_70b_kernel_stats.csv)
+    static const int pair4_passes = []() { const char* e = getenv("EXL2_LEAN_PAIR4_PASSES"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > LEAN_MAX_PASSES ? LEAN_MAX_PASSES : v); }();
+    static const u32 pair4_budget = []() { const char* e = getenv("EXL2_LEAN_PAIR4_BUDGET_KB"); const int v = e ? atoi(e) : 64; return (u32)(v < 16 ? 16 : (v > 150 ? 150 : v)) * 1024u; }();
+    if (in.pair && in.M == 1 && pair4 && pair4_passes > 1 && !in.a_tiled && !dep) { cand_passes[n_cand] = pair4_passes; cand_budget[n_cand] = pair4_budget; cand[n_cand++] = 4; }
     cand[n_cand++] = S;
     // several matrices in one launch (q|k|v) whose shares 8 waves cannot hold in ONE register load: two loads on 8 waves before 16
     // waves -- a 16-wave workgroup is alone on its CU (80 registers x 4 waves per SIMD), so the 640 tiles of a 70B q|k|v launch ran
@@ -1244,13 +1266,15 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     bool xmem = false;
     u32 rows_bytes = 0, slot_bytes = 0;
     bool planned = false;
+    int planned_passes = 0;
     const int nslots0 = nslots;
     const int plain_cand[3] = {cand[0], cand[1], cand[2]};
     const int plain_passes[3] = {cand_passes[0], cand_passes[1], cand_passes[2]};
+    const u32 plain_budget[3] = {cand_budget[0], cand_budget[1], cand_budget[2]};
     const int plain_n = n_cand;
     auto plan = [&](int form) {                                      // 0: <= 4 rows; 1: ROWS; 2: XMEM
         n_cand = plain_n;
-        for (int i = 0; i < 3; i++) { cand[i] = plain_cand[i]; cand_slots[i] = nslots0; cand_passes[i] = form ? 0 : plain_passes[i]; }
+        for (int i = 0; i < 3; i++) { cand[i] = plain_cand[i]; cand_slots[i] = nslots0; cand_passes[i] = form ? 0 : plain_passes[i]; cand_budget[i] = form ? 0u : plain_budget[i]; }
         if (form == 1)
         {
             n_cand = 0;
@@ -1283,7 +1307,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
         {
             S = cand[ci % n_cand];
             if (form) nslots = cand_slots[ci % n_cand];
-            const u32 budget = form == 1 ? 158u * 1024u : (ci < n_cand ? LEAN_LDS_BUDGET * (u32)((S * nslots + 7) / 8) : 150u * 1024u);
+            const u32 budget = form == 1 ? 158u * 1024u : (ci < n_cand ? (cand_budget[ci] ? cand_budget[ci] : LEAN_LDS_BUDGET * (u32)((S * nslots + 7) / 8)) : 150u * 1024u);
             if (in.n_mats * S > LEAN_RECORDS) continue;
             bool ok = true;
             slot_bytes = 0;
@@ -1294,6 +1318,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
                 if (b > slot_bytes) slot_bytes = b;
             }
             planned = ok && rows_bytes + (u32)nslots * slot_bytes + (u32)(S * nslots) * (u32)in.M * 64u <= budget;
+            if (planned) planned_passes = cand_passes[ci % n_cand];
         }
         xmem = planned && form == 2;
     };
@@ -1374,13 +1399,16 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     if (xmem && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<true, SS, NS, P, 4, false, false, false, true>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_XMEM_GEOMETRY(LEAN_GO)
 #undef LEAN_GO
+    const bool pair_loads = in.pair && S == 4 && planned_passes > 1 && !rows_mode && !xmem && !dep;      // (the several-register-loads pair: its own instantiation)
+    if (pair_loads && !gptq) LEAN_LAUNCH((qgemv_lean_kernel<false, 4, 2, true, LEAN_PAIR_LOADS_OCC, false, true>), grid, block, lds, stream, a);
+    if (pair_loads && gptq) LEAN_LAUNCH((qgemv_lean_kernel<true, 4, 2, true, LEAN_PAIR_LOADS_OCC, false, true>), grid, block, lds, stream, a);
 #define LEAN_GO(SS, NS, P, OCC) \
-    if (!rows_mode && !xmem && !dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a); \
+    if (!pair_loads && !rows_mode && !xmem && !dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC>), grid, block, lds, stream, a); \
     if (!rows_mode && dep && !gptq && occ == OCC && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<false, SS, NS, P, OCC, false, false, true>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_GEOMETRY(LEAN_GO, LEAN_OCC_DEFAULT)
 #undef LEAN_GO
 #define LEAN_GO(SS, NS, P, OCC) \
-    if (!rows_mode && !xmem && !dep && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC>), grid, block, lds, stream, a); \
+    if (!pair_loads && !rows_mode && !xmem && !dep && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC>), grid, block, lds, stream, a); \
     if (!rows_mode && dep && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<true, SS, NS, P, OCC, false, false, true>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_GEOMETRY(LEAN_GO, 6)
 #undef LEAN_GO

@@ -631,6 +631,26 @@ def test_qkv_launch_takes_two_register_loads_on_eight_waves(be, capfd, monkeypat
     assert any(cnt > depth.get(bits, 99) for cnt, bits in shares), shares
 
 
+def test_gate_up_pair_takes_several_register_loads_on_four_waves(be, capfd, monkeypatch):
+    """hidden 8192 at 2.5 bpw (configs[3]'s gate|up): the 4 waves of a pair's tile hold 16-19 items of 2 / 3 bits each, more than ONE
+    register load (10 / 8 items).  Rounds 4-5 took the 16-wave workgroup (alone on its CU: seven rounds of 256 for the 70B's 1792
+    tile pairs); round 6: the 4-waves-per-tile pair with up to three (ring) loads per wave, its own instantiation, two workgroups per
+    CU (70B + Q4 94 -> 101 tok/s same box, profiles/r08b_ab_70b.txt).  Plan checked from the host's trace, numerics through the
+    chained decode against the oracle; EXL2_LEAN_PAIR4_PASSES=1 (the former plan) must give the same logits within the same bar."""
+    cfg = tiny_cfg(hidden_size=8192, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                   head_dim=128)
+    monkeypatch.setenv("EXL2_LEAN_TRACE", "1")
+    _decode_and_check(be, cfg, "2.5bpw", 1, steps=2, seed=5)
+    monkeypatch.delenv("EXL2_LEAN_TRACE")
+    err = capfd.readouterr().err
+    blocks = err.split("[lean] M=")
+    gu = [b for b in blocks if b.startswith("1 K=8192 mats=2 ")]
+    assert gu and all(" S=4 " in b.split("\n")[0] for b in gu), [b.split("\n")[0] for b in blocks][:8]
+    depth = {2: 10, 3: 8, 4: 6}
+    shares = [(int(m.group(1)), int(m.group(2))) for m in re.finditer(r"; (\d+) x (\d+)b", gu[0])]
+    assert any(cnt > depth.get(bits, 99) for cnt, bits in shares), shares
+
+
 @pytest.mark.parametrize("rows", [1, 4])
 def test_lean_kernel_identity_rows_equal_reconstruct(be, rows):
     """The reference's own parity relation (tests/test_gemv.py:136-165: gemm(I) == reconstruct()) on the CHAINED decode kernel,
