@@ -12,6 +12,7 @@
 #include "qgemv_flat.h"
 #include "qgemv_lean.h"
 #include "chain_sync.h"
+#include "moe.h"
 #include "errors.h"
 #include <string.h>
 #include <stdlib.h>
@@ -123,6 +124,9 @@ struct QMoEMLP
     f16* temp_state; f16* temp_a; f16* temp_b; f16* temp_logits;
     int max_rows, hidden; bool act_gelu;
     bool group_ok;                              // every expert's w1 / w3 share one act-order permutation: grouped launches
+    // one row (round 6): the selected experts on the lean kernel -- argument blocks planned here, at load time, per expert; the front
+    // kernel of a step copies the selected ones to the slots the gate|up and the down launch read (qgemv_lean.h: LeanGroupPlan)
+    bool lean_ok; LeanGroupPlan lean_gu, lean_dn;
 };
 
 // ---- small kernels of the grouped MoE path -----------------------------------------------------------------------------------
@@ -241,6 +245,39 @@ static int flat_try(FlatIn& in, void* stream, int* wgs, const char* what)
 extern "C" {
 
 // make_q_moe_mlp (ext_qmlp.h; call site moe_mlp.py:114-133: w1 = gate proj, w3 = up proj, w2 = down proj)
+// the one-row route's plans: gate|up as a pair per expert (output in the expert's down_proj order), down weighted by the routing weight;
+// the same buffers as the grouped route at rows = 1
+static void moe_plan_lean(QMoEMLP* m)
+{
+    m->lean_ok = false;
+    const int E = m->num_experts, hidden = m->hidden, inter = m->w1[0]->width, rows = 1;
+    if (!(m->group_ok && 2 * MAX_GEMV_ROWS <= m->max_rows && (long long)E * rows <= m->max_rows &&
+          (long long)E * rows * hidden <= (long long)m->max_rows * inter) || m->num_experts_per_token > MOE_MAX_SEL) return;
+    if (getenv("EXL2_MOE_NO_LEAN_PLAN")) return;
+    f16* const xg = m->temp_state + (size_t)MAX_GEMV_ROWS * hidden;
+    FlatIn ins[MOE_MAX_EXPERTS];
+    for (int e = 0; e < E; e++)
+    {
+        FlatIn& in = ins[e]; memset(&in, 0, sizeof(in));
+        in.qm[0] = m->w1[e]; in.qm[1] = m->w3[e];
+        in.c[0] = m->temp_a + (size_t)e * rows * inter; in.c[1] = in.c[0]; in.ldc[0] = inter; in.ldc[1] = inter;
+        in.c_invperm[0] = m->w2[e]->q_perm ? m->w2[e]->q_invperm : nullptr;
+        in.n_mats = 2; in.pair = 1; in.M = rows; in.a_mode = A_DIRECT; in.a = xg; in.lda = hidden; in.c_mode = C_STORE;
+        in.act_gelu = m->act_gelu ? 1 : 0;
+    }
+    if (qgemv_lean_group_plan(ins, E, nullptr, m->num_experts_per_token, &m->lean_gu) != 0) return;
+    const f16* scale[MOE_MAX_EXPERTS];
+    for (int e = 0; e < E; e++)
+    {
+        FlatIn& in = ins[e]; memset(&in, 0, sizeof(in));
+        in.qm[0] = m->w2[e]; in.c[0] = m->temp_b + (size_t)e * rows * hidden; in.ldc[0] = hidden;
+        in.n_mats = 1; in.M = rows; in.a_mode = A_DIRECT; in.a = m->temp_a + (size_t)e * rows * inter; in.lda = inter; in.c_mode = C_STORE;
+        scale[e] = m->temp_logits + e;
+    }
+    if (qgemv_lean_group_plan(ins, E, scale, m->num_experts_per_token, &m->lean_dn) != 0) { qgemv_lean_group_free(&m->lean_gu); return; }
+    m->lean_ok = true;
+}
+
 int exl2_make_q_moe_mlp(void** handle, const void* layernorm, const void* layernorm_bias, int layernorm_is_rms,
                         float norm_epsilon, const void* gate, int num_experts, int num_experts_per_token,
                         void* const* w1, void* const* w2, void* const* w3, void* temp_state, void* temp_gathered_state,
@@ -271,11 +308,18 @@ int exl2_make_q_moe_mlp(void** handle, const void* layernorm, const void* layern
         for (int i = 0; i < num_experts; i++) { all[2 * i] = m->w1[i]; all[2 * i + 1] = m->w3[i]; }
         m->group_ok = num_experts <= 16 && same_perm(all, 2 * num_experts) && hidden_ok(m);
     }
+    moe_plan_lean(m);
     *handle = m;
     return EXL2_OK;
 }
 
-int exl2_free_q_moe_mlp(void* handle) { free(handle); return EXL2_OK; }
+int exl2_free_q_moe_mlp(void* handle)
+{
+    QMoEMLP* m = (QMoEMLP*)handle;
+    if (m && m->lean_ok) { qgemv_lean_group_free(&m->lean_gu); qgemv_lean_group_free(&m->lean_dn); }
+    free(handle);
+    return EXL2_OK;
+}
 
 // q_moe_mlp_forward_ (ext_qmlp.cpp:245-272 -> QMoEMLP::forward_, q_mlp.cu:318-402): in place on x [rows, hidden].
 // The reference takes rows <= 4; here any row count runs in passes of 16 rows (one MFMA row block): each expert's
@@ -295,6 +339,28 @@ int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
     f16* const xg = m->temp_state + (size_t)MAX_GEMV_ROWS * hidden;       // normalised rows in the experts' packed order
     const bool xg_room = m->group_ok && rows <= MAX_GEMV_ROWS && 2 * MAX_GEMV_ROWS <= m->max_rows;
     int front = 1;
+    // ---- one row on the lean kernel: front (+ the selected experts' argument blocks) -> gate|up -> down -> combine
+    if (rows == 1 && m->lean_ok && !getenv("EXL2_MOE_NO_LEAN") && !getenv("EXL2_MOE_UNFUSED_FRONT") && !getenv("EXL2_MOE_SERIAL") && !getenv("EXL2_MOE_NO_GROUP"))
+    {
+        MoeCopy cp;
+        cp.src[0] = (const u32x4*)m->lean_gu.table_src; cp.dst[0] = (u32x4*)m->lean_gu.table_sel; cp.units[0] = m->lean_gu.block_bytes / 16;
+        cp.src[1] = (const u32x4*)m->lean_dn.table_src; cp.dst[1] = (u32x4*)m->lean_dn.table_sel; cp.units[1] = m->lean_dn.block_bytes / 16;
+        cp.n_sel = m->num_experts_per_token;
+        front = moe_front_launch(x, m->layernorm, m->gate, m->w1[0]->q_perm, m->temp_state, xg, m->temp_logits, rows, hidden, E,
+                                 m->num_experts_per_token, m->norm_epsilon, &cp, stream);
+        if (front < 0) return front;
+        if (front == 0)
+        {
+            if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: lean rows=%d experts=%d\n", rows, E);
+            if (qgemv_lean_group_launch(&m->lean_gu, stream) != 0 || qgemv_lean_group_launch(&m->lean_dn, stream) != 0)
+                EXL2_FAIL(EXL2_E_INVALID, "q_moe_mlp_forward_: a planned lean launch was not taken");
+            LAUNCH(moe_combine_kernel, dim3((unsigned)((hidden / 8 + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
+                   x, (const f16*)m->temp_b, (const f16*)m->temp_logits, rows, hidden, E);
+            HIP_TRY(hipGetLastError());
+            return EXL2_OK;
+        }
+        front = 1;
+    }
     if (xg_room && !getenv("EXL2_MOE_UNFUSED_FRONT"))
         front = exl2_moe_front(x, m->layernorm, m->gate, m->w1[0]->q_perm, m->temp_state, xg, m->temp_logits, rows, hidden, E,
                                m->num_experts_per_token, m->norm_epsilon, stream);

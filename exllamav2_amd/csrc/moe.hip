@@ -5,6 +5,8 @@
 // read them through r_weights and skip zero-weight rows / exit when every row's weight is zero.
 #include "hw.h"
 #include "errors.h"
+#include "moe.h"
+#include <string.h>
 
 // logits[r, e] = sum_k x[r, k] * gate[e, k]   (gate = nn.Linear weight [E, hidden]); one workgroup per row, fp32 sums
 template <int E>
@@ -77,13 +79,16 @@ KERNEL void __launch_bounds__(64) moe_topk_kernel(f16* x, int rows, int topk)
 // arithmetic in the same order as those kernels (sum of squares per thread -> wave -> four partials; logits per thread over the
 // normalised fp16 row -> wave -> four partials; the top-k on one thread), so the routing is bit-identical to the unfused route.
 // xn: the normalised row (natural order); xg: the same row gathered through `perm` (nullable = no packed copy).
+// Round 6 (one row): `cp` -- the argument blocks of the SELECTED experts' lean launches (qgemv_lean.h: LeanGroupPlan) are copied from
+// the per-expert tables to the slots the two launches behind this kernel read (ascending expert index).
 template <int E>
 KERNEL void __launch_bounds__(256) moe_front_kernel(const f16* x, const f16* w, const f16* gate, const u16* perm, f16* xn, f16* xg,
-                                                    f16* logits, int hidden, float eps, float r_dim, int topk)
+                                                    f16* logits, int hidden, float eps, float r_dim, int topk, const MoeCopy cp)
 {
     DYN_SMEM(smem);
     f16* const row_lds = (f16*)smem;                                   // the normalised row
     float* const part = (float*)(smem + (size_t)hidden * 2);           // 4 E partial sums (4 for the norm)
+    int* const sel_lds = (int*)(smem + (size_t)hidden * 2 + 4 * 16 * 4);   // the selected experts (cp.n_sel of them)
     const int r = bid_x();
     const int t = tid(), lane = lane_id(), wv = wave_id();
     const int dim8 = hidden >> 3;
@@ -160,9 +165,50 @@ KERNEL void __launch_bounds__(256) moe_front_kernel(const f16* x, const f16* w, 
         isum = 1.0f / sum;
         #pragma unroll
         for (int i = 0; i < E; i++) logits[(size_t)r * E + i] = (f16)(f[i] * isum);
+        if (cp.n_sel)
+        {
+            int ns = 0;
+            #pragma unroll
+            for (int i = 0; i < E; i++) if (f[i] > 0.0f && ns < cp.n_sel) sel_lds[ns++] = i;
+            for (; ns < cp.n_sel; ns++) sel_lds[ns] = ns > 0 ? sel_lds[0] : 0;     // (never: the top-k leaves exactly topk weights)
+        }
+    }
+    if (cp.n_sel && r == 0)
+    {
+        block_sync();
+        for (int y = 0; y < cp.n_sel; y++)
+        {
+            const int e = sel_lds[y];
+            #pragma unroll
+            for (int k = 0; k < 2; k++)
+            {
+                const u32x4* const src = cp.src[k] + (size_t)e * cp.units[k];
+                u32x4* const dst = cp.dst[k] + (size_t)y * cp.units[k];
+                for (int i = t; i < cp.units[k]; i += 256) dst[i] = src[i];
+            }
+        }
     }
     if (xg)
         for (int i = t; i < hidden; i += 256) xg[(size_t)r * hidden + i] = row_lds[perm ? (int)perm[i] : i];
+}
+
+// cp (nullable; one row only): the argument-block copies of the selected experts (moe.h)
+int moe_front_launch(const void* x, const void* norm_w, const void* gate, const void* perm, void* xn, void* xg, void* logits,
+                     int rows, int hidden, int num_experts, int topk, float eps, const MoeCopy* cp_, void* stream)
+{
+    EXL2_REQUIRE(x && norm_w && gate && xn && logits, "moe_front: null argument");
+    if (rows <= 0) return EXL2_OK;
+    if (!(num_experts == 4 || num_experts == 8 || num_experts == 16) || hidden % 8 || hidden > 16384 || topk < 1 || topk > num_experts) return 1;
+    MoeCopy cp; memset(&cp, 0, sizeof(cp));
+    if (cp_) { if (rows != 1 || cp_->n_sel != topk || cp_->n_sel > MOE_MAX_SEL) return 1; cp = *cp_; }
+    const size_t lds = (size_t)hidden * 2 + 4 * 16 * 4 + MOE_MAX_SEL * 4;
+    const dim3 g((unsigned)rows);
+#define MOE_FRONT(E_) LAUNCH((moe_front_kernel<E_>), g, dim3(256), lds, stream, (const f16*)x, (const f16*)norm_w, (const f16*)gate, \
+                             (const u16*)perm, (f16*)xn, (f16*)xg, (f16*)logits, hidden, eps, 1.0f / (float)hidden, topk, cp)
+    switch (num_experts) { case 4: MOE_FRONT(4); break; case 8: MOE_FRONT(8); break; default: MOE_FRONT(16); break; }
+#undef MOE_FRONT
+    HIP_TRY(hipGetLastError());
+    return EXL2_OK;
 }
 
 extern "C" {
@@ -172,17 +218,7 @@ extern "C" {
 int exl2_moe_front(const void* x, const void* norm_w, const void* gate, const void* perm, void* xn, void* xg, void* logits,
                    int rows, int hidden, int num_experts, int topk, float eps, void* stream)
 {
-    EXL2_REQUIRE(x && norm_w && gate && xn && logits, "moe_front: null argument");
-    if (rows <= 0) return EXL2_OK;
-    if (!(num_experts == 4 || num_experts == 8 || num_experts == 16) || hidden % 8 || hidden > 16384 || topk < 1 || topk > num_experts) return 1;
-    const size_t lds = (size_t)hidden * 2 + 4 * 16 * 4;
-    const dim3 g((unsigned)rows);
-#define MOE_FRONT(E_) LAUNCH((moe_front_kernel<E_>), g, dim3(256), lds, stream, (const f16*)x, (const f16*)norm_w, (const f16*)gate, \
-                             (const u16*)perm, (f16*)xn, (f16*)xg, (f16*)logits, hidden, eps, 1.0f / (float)hidden, topk)
-    switch (num_experts) { case 4: MOE_FRONT(4); break; case 8: MOE_FRONT(8); break; default: MOE_FRONT(16); break; }
-#undef MOE_FRONT
-    HIP_TRY(hipGetLastError());
-    return EXL2_OK;
+    return moe_front_launch(x, norm_w, gate, perm, xn, xg, logits, rows, hidden, num_experts, topk, eps, nullptr, stream);
 }
 
 int exl2_moe_route(const void* x, const void* gate, void* logits, int rows, int hidden, int num_experts, int topk, void* stream)

@@ -34,6 +34,7 @@ struct FlatIn
     int a_tiled, c_tiled;
     int xp_tiled;                 // chain-out: xp_out is written in that layout too (16 row slots; ldxp unused)
     int plan_only;                // qgemv_lean_launch: make the host plan, launch nothing (0: the lean kernel takes this shape, 1: it declines)
+    void* lean_export;            // qgemv_lean_launch: hand the finished argument block + geometry to this LeanExport (qgemv_lean.hip), launch nothing
 };
 
 // 0: launched; 1: shape not covered; < 0: error.  *wgs_out = grid size = partial sums a chain-out launch writes per row

@@ -8,3 +8,19 @@
 // 0: launched; 1: shape not covered (the caller falls back to qgemv_flat_launch); *wgs_out = grid size = partial sums of
 // squares a chain-out launch writes per row
 int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out);
+
+// ---- grouped-expert launches (sparse MoE at ONE row; q_mlp.cu:316-436 is the reference's fused form for <= 4 rows) -------------
+// `n_groups` identically shaped launches (one per expert), planned once: every expert's argument block lies in device memory
+// (table_src); a step's MoE front kernel copies the blocks of the n_sel experts it selected to table_sel, and ONE launch with
+// blockIdx.y = 0 .. n_sel - 1 reads its block from there (the graph's launch is fixed, the experts are not).
+struct LeanGroupPlan
+{
+    void* table_src; void* table_sel;           // device: [n_groups] / [n_sel] argument blocks of block_bytes each
+    int n_groups, n_sel, block_bytes;
+    int S, nslots, pair, walk, grid_x; unsigned lds;
+};
+// out_scale[g] (nullable array): device pointer to the fp16 weight the group's finished sums are multiplied by.  0: planned;
+// 1: a shape the lean kernel declines or experts whose plans differ in geometry (the caller keeps its other route)
+int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out_scale, int n_sel, LeanGroupPlan* plan);
+int qgemv_lean_group_launch(const LeanGroupPlan* plan, void* stream);
+void qgemv_lean_group_free(LeanGroupPlan* plan);

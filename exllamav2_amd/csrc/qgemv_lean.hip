@@ -129,7 +129,9 @@ struct alignas(64) LeanHdr
     // they and the partial sums / residual are read at agent scope), this launch's block (every workgroup reports on entry; outputs
     // are agent-scope stores; every finalising wave arrives, the last publishes "go"), workgroups of the grid
     const u32* sync_wait; u32* sync_signal; u32 sync_wgs, sync_pad;
+    const f16* out_scale;             // MOE instantiations only: the expert's routing weight multiplies the finished sum (q_mlp.cu:373-384); nullable
 };
+static_assert(sizeof(LeanHdr) == 192, "LeanHdr: the dense kernels' offsets must not move");
 struct LeanArgs
 {
     LeanHdr hdr;
@@ -401,15 +403,19 @@ DEV void lean_xmem_request(const LeanCtx& cx, int chunk, int nvalid, int lane, f
 // launches whose rows do not fit the LDS as a whole (down_proj at K = 11008: 16 rows = 352 KB) this replaces the host's row
 // GROUPS (every group re-read all weights: three launches of 12 + 12 + 10 us) by one launch; LDS holds scale rows and the
 // partial sums only, so several workgroups share a CU again.
-template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false, bool DEP = false, bool XMEM = false>
-KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs args)
+// The kernel's body is a function of WHERE the argument block lies: the kernel arguments (qgemv_lean_kernel: every launch of the dense
+// models) or a table in device memory indexed by blockIdx.y (qgemv_lean_moe_kernel: the launch's y-th SELECTED expert, whose block
+// the MoE front kernel copied there -- the graph's launch is fixed, the experts are not).  MOE: the output may carry the routing
+// weight (hdr.out_scale); `by` = the matrix index of a launch over several matrices.
+template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false, bool DEP = false, bool XMEM = false, bool MOE = false>
+DEV void lean_body(const LeanArgs& args, const int by)
 {
     DYN_SMEM(smem);
     const int lane = lane_id();
     const int wv = uniform(wave_id());
     int u = bid_x();                                                      // the workgroup's unit (tile / tile pair); ROWS: its first one
     const int slot = wv / S, r = wv % S;
-    const int mj = PAIR ? slot : bid_y();
+    const int mj = PAIR ? slot : by;
     // ---- arguments: header, matrix block, wave record -- addresses from built-in ids only: one batch of scalar loads.
     // What the weight requests need (matrix pointers, the record's run) is unpacked first; everything else is unpacked AFTER
     // the requests have been issued: the waves of a CU share one scalar unit, so every scalar instruction ahead of the
@@ -440,7 +446,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
     // requests would wait for (-4.5 % on the whole decode step when it sat here unconditionally: profiles/history/r04_bisect.txt).
     // (kernel-argument loads are speculatable: without the laundered pointer the compiler hoists these two into the first batch.)
     u32* sync_signal_ = nullptr;
-    auto lin_wg_of = [&]() -> u32 { return (u32)bid_y() * (u32)gdim_x() + (u32)bid_x(); };
+    auto lin_wg_of = [&]() -> u32 { return (u32)by * (u32)gdim_x() + (u32)bid_x(); };
     if constexpr (DEP)
     {
         u32 opaque0 = 0;
@@ -961,6 +967,7 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
             {
                 float v = slot_sum(ep_slot) * rms;
                 if (flags & LF_BIAS) { const f16* bias = args.mat[ep_mj].bias; if (bias) v += (float)bias[ep_n]; }
+                if constexpr (MOE) { const f16* const osc = args.hdr.out_scale; if (osc) v *= (float)*osc; }
                 if (flags & LF_ACCUM) v += (float)e.c_old;
                 y = (f16)v;
             }
@@ -1025,6 +1032,20 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
         if (u >= args.hdr.wgs) break;                                     // (hdr.wgs = units of the launch = partial sums per row it publishes)
     }
     }
+}
+
+template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false, bool DEP = false, bool XMEM = false>
+KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs args)
+{
+    lean_body<GPTQ, S, NSLOTS, PAIR, OCC, ROWS, WALK, DEP, XMEM>(args, bid_y());
+}
+
+// grouped-expert launch (sparse MoE at one row): blockIdx.y = the y-th selected expert; its argument block was planned at load time
+// (qgemv_lean_plan_export) and copied to table[y] by the MoE front kernel of this step
+template <int S, int NSLOTS, bool PAIR, int OCC, bool WALK>
+KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_moe_kernel(const LeanArgs* __restrict__ table)
+{
+    lean_body<false, S, NSLOTS, PAIR, OCC, false, WALK, false, false, true>(table[bid_y()], 0);
 }
 
 #ifdef EXL2_TRACE
@@ -1198,6 +1219,9 @@ static void lean_attrs()
     LEAN_FOR_EACH_XMEM_GEOMETRY(LEAN_ATTR)
 #undef LEAN_ATTR
 }
+
+// what qgemv_lean_launch hands out instead of launching (FlatIn.lean_export): the argument block and the geometry it chose
+struct LeanExport { LeanArgs args; int S, nslots, pair, walk, grid_x; u32 lds; bool plain; };
 
 // 0: launched; 1: shape not covered (the caller takes the round-2 kernel).  *wgs_out = grid size = partial sums per row a
 // chain-out launch publishes.
@@ -1383,6 +1407,15 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
         if (grid_x > cap) grid_x = cap;
     }
     dim3 grid((unsigned)grid_x, (unsigned)(in.pair ? 1 : in.n_mats), 1), block((unsigned)waves * 64, 1, 1);
+    if (in.lean_export)
+    {
+        LeanExport* const ex = (LeanExport*)in.lean_export;
+        ex->args = a; ex->S = S; ex->nslots = nslots; ex->pair = in.pair; ex->grid_x = grid_x; ex->lds = lds;
+        ex->walk = in.pair && S == 4 && planned_passes > 1;
+        ex->plain = !rows_mode && !xmem && !dep && !q0->is_gptq && (in.pair || in.n_mats == 1);
+        if (wgs_out) *wgs_out = wgs;
+        return 0;
+    }
     if (in.plan_only) { if (wgs_out) *wgs_out = wgs; return 0; }                      // a caller asking whether this shape is taken (modules.hip)
     if (getenv("EXL2_LEAN_PLAN_ONLY")) { if (wgs_out) *wgs_out = wgs; return 0; }     // test hook: the host plan without the launch (results undefined)
     int launched = 0;                                                                  // a plan no instantiation below matches must not pass for a launch
@@ -1421,4 +1454,74 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     }
     if (wgs_out) *wgs_out = wgs;
     return 0;
+}
+
+// ---- grouped-expert launches (qgemv_lean.h) ---------------------------------------------------------------------------------------
+#define LEAN_FOR_EACH_MOE_GEOMETRY(X) X(4, 2, true, LEAN_OCC_DEFAULT, false) X(4, 2, true, LEAN_PAIR_LOADS_OCC, true) X(8, 2, true, LEAN_OCC_DEFAULT, false) \
+                                      X(8, 1, false, LEAN_OCC_DEFAULT, false) X(16, 1, false, LEAN_OCC_DEFAULT, false)
+
+int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out_scale, int n_sel, LeanGroupPlan* gp)
+{
+    if (!ins || !gp || n_groups < 1 || n_sel < 1 || n_sel > n_groups) return 1;
+    memset(gp, 0, sizeof(*gp));
+    std::vector<LeanArgs> blocks((size_t)n_groups);
+    static LeanExport ex;                                            // (large: off the stack)
+    static std::mutex gmtx;
+    std::lock_guard<std::mutex> lock(gmtx);
+    for (int g = 0; g < n_groups; g++)
+    {
+        FlatIn in = ins[g];
+        in.lean_export = &ex; in.plan_only = 0;
+        if (in.M != 1 || in.sync_signal || in.sync_wait || in.sync_arrive || in.a_tiled || in.c_tiled || in.xp_tiled) return 1;
+        const int rc = qgemv_lean_launch(in, nullptr, nullptr);
+        if (rc != 0 || !ex.plain) return 1;
+        if (g == 0) { gp->S = ex.S; gp->nslots = ex.nslots; gp->pair = ex.pair; gp->walk = ex.walk ? 1 : 0; gp->grid_x = ex.grid_x; gp->lds = ex.lds; }
+        else
+        {
+            if (gp->S != ex.S || gp->nslots != ex.nslots || gp->pair != ex.pair || gp->walk != (ex.walk ? 1 : 0) || gp->grid_x != ex.grid_x) return 1;
+            if (ex.lds > gp->lds) gp->lds = ex.lds;
+        }
+        ex.args.hdr.out_scale = out_scale ? out_scale[g] : nullptr;
+        blocks[(size_t)g] = ex.args;
+    }
+    bool inst = false;
+#define LEAN_HAS(SS, NS, P, OCC, W) if (gp->S == SS && gp->nslots == NS && (gp->pair != 0) == P && (gp->walk != 0) == W) inst = true;
+    LEAN_FOR_EACH_MOE_GEOMETRY(LEAN_HAS)
+#undef LEAN_HAS
+    if (!inst) return 1;
+    gp->n_groups = n_groups; gp->n_sel = n_sel; gp->block_bytes = (int)sizeof(LeanArgs);
+    if (hipMalloc(&gp->table_src, (size_t)n_groups * sizeof(LeanArgs)) != hipSuccess) { gp->table_src = nullptr; return 1; }
+    if (hipMalloc(&gp->table_sel, (size_t)n_sel * sizeof(LeanArgs)) != hipSuccess) { (void)hipFree(gp->table_src); gp->table_src = gp->table_sel = nullptr; return 1; }
+    if (hipMemcpy(gp->table_src, blocks.data(), (size_t)n_groups * sizeof(LeanArgs), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(gp->table_sel, blocks.data(), (size_t)n_sel * sizeof(LeanArgs), hipMemcpyHostToDevice) != hipSuccess)    // (valid blocks until the first front kernel runs)
+    { qgemv_lean_group_free(gp); return 1; }
+    return 0;
+}
+
+void qgemv_lean_group_free(LeanGroupPlan* gp)
+{
+    if (!gp) return;
+    if (gp->table_src) (void)hipFree(gp->table_src);
+    if (gp->table_sel) (void)hipFree(gp->table_sel);
+    gp->table_src = gp->table_sel = nullptr;
+}
+
+int qgemv_lean_group_launch(const LeanGroupPlan* gp, void* stream)
+{
+    if (!gp || !gp->table_sel) return 1;
+    static bool attr[EXL2_MAX_DEVICES] = {false};
+    if (exl2_first_on_device(attr))
+    {
+#define LEAN_ATTR(SS, NS, P, OCC, W) (void)hipFuncSetAttribute((const void*)qgemv_lean_moe_kernel<SS, NS, P, OCC, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        LEAN_FOR_EACH_MOE_GEOMETRY(LEAN_ATTR)
+#undef LEAN_ATTR
+    }
+    const dim3 grid((unsigned)gp->grid_x, (unsigned)gp->n_sel, 1), block((unsigned)(gp->S * gp->nslots) * 64, 1, 1);
+    const LeanArgs* const table = (const LeanArgs*)gp->table_sel;
+    int launched = 0;
+#define LEAN_GO(SS, NS, P, OCC, W) \
+    if (gp->S == SS && gp->nslots == NS && (gp->pair != 0) == P && (gp->walk != 0) == W) { launched++; LAUNCH((qgemv_lean_moe_kernel<SS, NS, P, OCC, W>), grid, block, gp->lds, stream, table); }
+    LEAN_FOR_EACH_MOE_GEOMETRY(LEAN_GO)
+#undef LEAN_GO
+    return launched == 1 ? 0 : 1;
 }

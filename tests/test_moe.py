@@ -252,6 +252,7 @@ def test_moe_fused_front_is_bit_identical(be, rows, monkeypatch):
     moe = model.layers[0][1]
     x = torch.from_numpy(np.random.default_rng(rows).standard_normal((rows, 1, cfg.hidden_size)).astype(np.float16)).to(be.device)
     outs = []
+    monkeypatch.setenv("EXL2_MOE_NO_LEAN", "1")            # (one row: the same expert kernels behind both fronts -- the grouped launches)
     for unfused in ("0", "1"):
         if unfused == "1": monkeypatch.setenv("EXL2_MOE_UNFUSED_FRONT", "1")
         y = x.clone()
@@ -259,6 +260,55 @@ def test_moe_fused_front_is_bit_identical(be, rows, monkeypatch):
         outs.append((be.n(y).copy(), be.n(moe.temp_logits[:rows]).copy()))
     assert np.array_equal(outs[0][1].view(np.uint16), outs[1][1].view(np.uint16))      # routing weights
     assert np.array_equal(outs[0][0].view(np.uint16), outs[1][0].view(np.uint16))      # block output
+    model.unload()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_moe_one_row_runs_the_selected_experts_on_the_lean_kernel(be, seed, capfd, monkeypatch):
+    """Round 6: at ONE row the two selected experts run on the chained decode kernel (csrc/qgemv_lean.hip: qgemv_lean_moe_kernel) --
+    every expert's argument block is planned at load time, the front kernel copies the selected experts' blocks to the slots the
+    gate|up and the down launch read, the down launch multiplies by the routing weight (q_mlp.cu:373-384).  Checked: the route is
+    taken; the routing weights are bit-identical to the grouped route's; the block output is within the fp16 bar of the float64
+    oracle AND of the grouped route (other kernels, other summation order); a second call with another input (other experts
+    selected) through the SAME handle is right as well -- the copied blocks are per step, not per handle."""
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.synth import synth_checkpoint
+    from exllamav2_amd.model import ExLlamaV2
+    from oracle.model import OracleModel
+    rng = np.random.default_rng(900 + seed)
+    hidden, inter = int(rng.choice([256, 512])), int(rng.choice([512, 768, 1024]))
+    cfg = ExLlamaV2Config(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=1, num_attention_heads=4,
+                          num_key_value_heads=2, head_dim=64, vocab_size=96, max_seq_len=256, max_input_len=32,
+                          max_batch_size=16, num_experts=8, num_experts_per_token=2, arch="mixtral")
+    ck = synth_checkpoint(cfg, be.device, recipe=str(rng.choice(["3.5bpw", "4.0bpw", "2.5bpw"])), seed=40 + seed)
+    oracle = OracleModel(cfg, ck)
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    moe = model.layers[0][1]
+    picked = set()
+    for call in range(3):
+        x = torch.from_numpy((rng.standard_normal((1, 1, hidden)) * 0.7).astype(np.float16)).to(be.device)
+        monkeypatch.setenv("EXL2_DEBUG_ROUTE", "1")
+        y = x.clone(); moe.forward(y)
+        monkeypatch.delenv("EXL2_DEBUG_ROUTE")
+        assert "route: lean rows=1" in capfd.readouterr().err
+        w_lean = be.n(moe.temp_logits[:1]).copy()
+        monkeypatch.setenv("EXL2_MOE_NO_LEAN", "1")
+        z = x.clone(); moe.forward(z)
+        monkeypatch.delenv("EXL2_MOE_NO_LEAN")
+        assert np.array_equal(w_lean.view(np.uint16), be.n(moe.temp_logits[:1]).view(np.uint16))
+        picked.add(tuple(np.nonzero(w_lean[0])[0].tolist()))
+        xh = be.n(x).reshape(1, hidden)
+        pfx = "model.layers.0"
+        oracle.router_margin = np.full((1,), np.inf)
+        want = oracle.moe_mlp(xh, OM.rms_norm(xh, oracle.w[pfx + ".post_attention_layernorm"], cfg.norm_eps), pfx).astype(np.float64)
+        if oracle.router_margin[0] <= 2e-3: want = None       # (a near tie in the oracle's router: another expert may be selected)
+        got, other = be.n(y).astype(np.float64).reshape(1, hidden), be.n(z).astype(np.float64).reshape(1, hidden)
+        tol = 0.01 + np.abs(other) * 2.0 ** -7
+        assert np.all(np.abs(got - other) <= tol), float((np.abs(got - other) / tol).max())
+        if want is not None:
+            tol = 0.01 + np.abs(want) * 2.0 ** -7
+            assert np.all(np.abs(got - want) <= tol), float((np.abs(got - want) / tol).max())
+    assert len(picked) >= 2, picked                # (the calls selected different experts: the blocks were re-copied)
     model.unload()
 
 
