@@ -84,6 +84,7 @@ PROTOTYPES = {
                                  vp, vp, vp, vp, vp, vp, ci, ci]),
     "exl2_free_q_moe_mlp": (ci, [vp]),
     "exl2_q_moe_mlp_forward": (ci, [vp, vp, ci, vp]),
+    "exl2_q_moe_mlp_forward_chain": (ci, [vp, vp, ci, vp, vp, vp, vp, C.POINTER(ci), vp]),
     "exl2_moe_route": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     # chained decode (csrc/qgemv_flat.hip)
     "exl2_q_attn_chain_info": (ci, [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),

@@ -30,6 +30,7 @@ int exl2_rope_qk(void* x_q, void* x_k, const void* sin, const void* cos, int bat
 int exl2_act_mul(void* x, const void* y, int rows, int width, int act_gelu,
                  const void* r_weights, int r_weights_stride, void* stream);
 int exl2_moe_route(const void* x, const void* gate, void* logits, int rows, int hidden, int num_experts, int topk, void* stream);
+int exl2_publish_rows(const void* x, int rows, int hidden, const void* next_invperm, const void* next_norm_w, void* xp_out, float* ss_out, void* stream);
 // (library-internal, moe.hip: not part of include/exl2_hip.h -- the boundary is q_moe_mlp_forward_)
 int exl2_moe_front(const void* x, const void* norm_w, const void* gate, const void* perm, void* xn, void* xg, void* logits,
                    int rows, int hidden, int num_experts, int topk, float eps, void* stream);
@@ -137,26 +138,82 @@ KERNEL void __launch_bounds__(256) gather_rows_f16_kernel(const f16* src, const 
     const int i = bid_x() * 256 + tid();
     if (i < K) dst[(size_t)row * K + i] = src[(size_t)row * K + (perm ? (int)perm[i] : i)];
 }
-// x[r, :] += sum over the experts e row r is routed to of part[e, r, :] (already weighted), fp32 sum in expert order, one rounding
-KERNEL void __launch_bounds__(256) moe_combine_kernel(f16* x, const f16* part, const f16* weights, int rows, int hidden, int E)
+// x[r, :] += sum over the experts e row r is routed to of part[e, r, :] (already weighted), fp32 sum in expert order, one rounding.
+// co (round 6, the block inside a chained step): the finished rows are published for the next consumer as a chained producer's
+// epilogue does (qgemv_lean.hip: ep_finish) -- xp = x * that consumer's norm weight in its packed order (one rounding, saturated),
+// one partial sum of squares of x per workgroup
+struct MoeChainOut { f16* xp; const u16* invperm; const f16* w; float* ss; int ldxp, tiled; };
+KERNEL void __launch_bounds__(256) moe_combine_kernel(f16* x, const f16* part, const f16* weights, int rows, int hidden, int E, const MoeChainOut co)
 {
+    SHARED float sq_part[4];
     const int row = bid_y();
     const int o = bid_x() * 256 + tid();
-    if (o * 8 >= hidden) return;
-    f16x8 xv = ((const f16x8*)(x + (size_t)row * hidden))[o];
-    float acc[8];
-    #pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] = (float)xv[k];
-    for (int e = 0; e < E; e++)
+    const bool on = o * 8 < hidden;
+    float sq = 0.0f;
+    if (on)
     {
-        if (as_u16(weights[(size_t)row * E + e]) == 0) continue;
-        const f16x8 pv = ((const f16x8*)(part + ((size_t)e * rows + row) * hidden))[o];
+        // two round trips to memory, not one per expert: (1) the row's weights, x, the permutation entries; (2) the selected experts'
+        // parts and the next consumer's norm weights -- then the sum in expert order as before (a part that is not selected is not
+        // added: -0 + 0 would flip a sign bit)
+        f16x8 xv = ((const f16x8*)(x + (size_t)row * hidden))[o];
+        u32 mask = 0;
         #pragma unroll
-        for (int k = 0; k < 8; k++) acc[k] += (float)pv[k];
+        for (int e = 0; e < MOE_MAX_EXPERTS; e++) if (e < E && as_u16(weights[(size_t)row * E + e]) != 0) mask |= 1u << e;
+        u32 xi[8];
+        const bool vec_perm = co.xp && co.invperm && (((size_t)co.invperm) & 15) == 0;
+        if (vec_perm)
+        {
+            const u32x4 pv = ((const u32x4*)co.invperm)[o];
+            xi[0] = pv.x & 0xFFFFu; xi[1] = pv.x >> 16; xi[2] = pv.y & 0xFFFFu; xi[3] = pv.y >> 16;
+            xi[4] = pv.z & 0xFFFFu; xi[5] = pv.z >> 16; xi[6] = pv.w & 0xFFFFu; xi[7] = pv.w >> 16;
+        }
+        else
+        {
+            #pragma unroll
+            for (int k = 0; k < 8; k++) xi[k] = (co.xp && co.invperm) ? (u32)co.invperm[o * 8 + k] : (u32)(o * 8 + k);
+        }
+        const f16x8 z8 = {(f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f};
+        f16x8 pv[MOE_MAX_EXPERTS];
+        #pragma unroll
+        for (int e = 0; e < MOE_MAX_EXPERTS; e++) pv[e] = ((mask >> e) & 1u) ? ((const f16x8*)(part + ((size_t)e * rows + row) * hidden))[o] : z8;
+        f16 wn[8];
+        #pragma unroll
+        for (int k = 0; k < 8; k++) wn[k] = (co.xp && co.w) ? co.w[xi[k]] : (f16)1.0f;
+        float acc[8];
+        #pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = (float)xv[k];
+        #pragma unroll
+        for (int e = 0; e < MOE_MAX_EXPERTS; e++)
+        {
+            if ((mask >> e) & 1u)
+            {
+                #pragma unroll
+                for (int k = 0; k < 8; k++) acc[k] += (float)pv[e][k];
+            }
+        }
+        #pragma unroll
+        for (int k = 0; k < 8; k++) xv[k] = (f16)acc[k];
+        ((f16x8*)(x + (size_t)row * hidden))[o] = xv;
+        if (co.xp)
+        {
+            #pragma unroll
+            for (int k = 0; k < 8; k++)
+            {
+                const float f = fmaxf(-65504.0f, fminf((float)xv[k], 65504.0f));
+                const f16 yw = co.w ? (f16)fmaxf(-65504.0f, fminf(f * (float)wn[k], 65504.0f)) : xv[k];
+                f16* const dst = co.tiled ? co.xp + ((size_t)(xi[k] >> 3) * 16 + row) * 8 + (xi[k] & 7) : co.xp + (size_t)row * co.ldxp + xi[k];
+                *dst = yw;
+                sq = fmaf(f, f, sq);
+            }
+        }
     }
-    #pragma unroll
-    for (int k = 0; k < 8; k++) xv[k] = (f16)acc[k];
-    ((f16x8*)(x + (size_t)row * hidden))[o] = xv;
+    if (co.xp && co.ss)
+    {
+        sq = wave_allreduce_add(sq);
+        if (lane_id() == 0) sq_part[wave_id()] = sq;
+        block_sync();
+        if (tid() == 0) co.ss[(size_t)row * gdim_x() + bid_x()] = sq_part[0] + sq_part[1] + sq_part[2] + sq_part[3];
+    }
 }
 
 static bool hidden_ok(const QMoEMLP* m) { return (m->hidden & 7) == 0; }
@@ -324,9 +381,10 @@ int exl2_free_q_moe_mlp(void* handle)
 // q_moe_mlp_forward_ (ext_qmlp.cpp:245-272 -> QMoEMLP::forward_, q_mlp.cu:318-402): in place on x [rows, hidden].
 // The reference takes rows <= 4; here any row count runs in passes of 16 rows (one MFMA row block): each expert's
 // weights stream once per pass for all the rows routed to it, launches whose rows all have zero weight exit at once.
-int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
+static int moe_forward(void* handle, void* x_, int rows, const MoeChainOut& co, int* npart_out, void* stream)
 {
     EXL2_REQUIRE(handle && x_, "q_moe_mlp_forward_: null argument");
+    if (npart_out) *npart_out = 0;                  // (0: the route taken had no combine launch -- the caller publishes the rows itself)
     QMoEMLP* m = (QMoEMLP*)handle;
     if (rows <= 0) return EXL2_OK;
     EXL2_REQUIRE(rows <= m->max_rows, "q_moe_mlp_forward_: %d rows exceed max_rows %d", rows, m->max_rows);
@@ -355,7 +413,8 @@ int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
             if (qgemv_lean_group_launch(&m->lean_gu, stream) != 0 || qgemv_lean_group_launch(&m->lean_dn, stream) != 0)
                 EXL2_FAIL(EXL2_E_INVALID, "q_moe_mlp_forward_: a planned lean launch was not taken");
             LAUNCH(moe_combine_kernel, dim3((unsigned)((hidden / 8 + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
-                   x, (const f16*)m->temp_b, (const f16*)m->temp_logits, rows, hidden, E);
+                   x, (const f16*)m->temp_b, (const f16*)m->temp_logits, rows, hidden, E, co);
+            if (npart_out) *npart_out = (hidden / 8 + 255) / 256;
             HIP_TRY(hipGetLastError());
             return EXL2_OK;
         }
@@ -410,7 +469,8 @@ int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
             if (rc == 0)
             {
                 LAUNCH(moe_combine_kernel, dim3((unsigned)((hidden / 8 + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
-                       x, (const f16*)m->temp_b, (const f16*)m->temp_logits, rows, hidden, E);
+                       x, (const f16*)m->temp_b, (const f16*)m->temp_logits, rows, hidden, E, co);
+            if (npart_out) *npart_out = (hidden / 8 + 255) / 256;
                 HIP_TRY(hipGetLastError());
                 return EXL2_OK;
             }
@@ -460,7 +520,8 @@ int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
             LAUNCH_JOBS(jobs, 4, rows, m->w2[e0]->is_gptq, stream, "q_moe_mlp_forward_");
         }
         LAUNCH(moe_combine_kernel, dim3((unsigned)((hidden / 8 + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
-               x, (const f16*)dout, (const f16*)m->temp_logits, rows, hidden, E);
+               x, (const f16*)dout, (const f16*)m->temp_logits, rows, hidden, E, co);
+        if (npart_out) *npart_out = (hidden / 8 + 255) / 256;
         HIP_TRY(hipGetLastError());
         return EXL2_OK;
     }
@@ -491,6 +552,36 @@ int exl2_q_moe_mlp_forward(void* handle, void* x_, int rows, void* stream)
             LAUNCH_JOBS(&d, 1, nr, m->w2[e]->is_gptq, stream, "q_moe_mlp_forward_");
         }
     }
+    return EXL2_OK;
+}
+
+int exl2_q_moe_mlp_forward(void* handle, void* x, int rows, void* stream)
+{
+    MoeChainOut co; memset(&co, 0, sizeof(co));
+    return moe_forward(handle, x, rows, co, nullptr, stream);
+}
+
+// the block inside a chained decode step: q_moe_mlp_forward_ + the hand-off for the next consumer (xp_out = x * next_norm_w in its
+// packed order, ss_out = *npart_out partial sums of squares per row), made by the combine launch where the route has one, by
+// exl2_publish_rows behind the block otherwise
+int exl2_q_moe_mlp_forward_chain(void* handle, void* x, int rows, const void* next_invperm, const void* next_norm_w, void* xp_out,
+                                 float* ss_out, int* npart_out, void* stream)
+{
+    EXL2_REQUIRE(handle && x && xp_out && ss_out && npart_out, "q_moe_mlp_forward_chain: null argument");
+    QMoEMLP* m = (QMoEMLP*)handle;
+    MoeChainOut co;
+    co.xp = (f16*)xp_out; co.invperm = (const u16*)next_invperm; co.w = (const f16*)next_norm_w; co.ss = ss_out; co.ldxp = m->hidden;
+    co.tiled = chain_xp_tiled() ? 1 : 0;
+    int npart = 0;
+    const int rc = moe_forward(handle, x, rows, co, &npart, stream);
+    if (rc) return rc;
+    if (npart == 0)
+    {
+        const int rc2 = exl2_publish_rows(x, rows, m->hidden, next_invperm, next_norm_w, xp_out, ss_out, stream);
+        if (rc2) return rc2;
+        npart = 1;
+    }
+    *npart_out = npart;
     return EXL2_OK;
 }
 

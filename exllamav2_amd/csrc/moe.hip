@@ -93,45 +93,123 @@ KERNEL void __launch_bounds__(256) moe_front_kernel(const f16* x, const f16* w, 
     const int t = tid(), lane = lane_id(), wv = wave_id();
     const int dim8 = hidden >> 3;
     const f16x8* xr = (const f16x8*)(x + (size_t)r * hidden);
-    float ss = 0.0f;
-    for (int i = t; i < dim8; i += 256)
+    const f16x8* wr = (const f16x8*)w;
+    // Round 6: everything whose address does not depend on a result is requested at entry -- the row, the norm weight, the router's
+    // rows (E x 16 bytes per thread and pass) and the gather permutation: the kernel was five dependent round trips to memory
+    // (row -> weight -> router rows -> permutation -> ...) of 1-2 us each on one workgroup (profiles/r08c_mixtral_b1_kernel_stats.csv:
+    // 12-16 us).  Rows of <= 4096 elements (two passes of the 256 threads); longer rows take the loops below.  The arithmetic and its
+    // order are those of the loops: the routing stays bit-identical to the unfused kernels.
+    constexpr int NI = 2;
+    const bool pre = dim8 <= NI * 256;
+    const bool pvec = (((size_t)perm) & 15) == 0;                        // (the permutation as 16-byte vectors)
+    const f16x8 z8 = {(f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f};
+    f16x8 xv_[NI], wv_[NI], gv_[NI][E];
+    u32x4 pv_[NI];
+    if (pre)
     {
-        const f16x8 v = xr[i];
         #pragma unroll
-        for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)); ss = fmaf(f, f, ss); }
+        for (int k = 0; k < NI; k++)
+        {
+            const int i = t + 256 * k;
+            const bool on = i < dim8;
+            xv_[k] = on ? xr[i] : z8;
+            wv_[k] = on ? wr[i] : z8;
+        }
+        #pragma unroll
+        for (int k = 0; k < NI; k++)
+        {
+            const int i = t + 256 * k;
+            const bool on = i < dim8;
+            #pragma unroll
+            for (int e = 0; e < E; e++) gv_[k][e] = on ? ((const f16x8*)(gate + (size_t)e * hidden))[i] : z8;
+            const u32x4 zero4 = {0u, 0u, 0u, 0u};
+            pv_[k] = (on && xg && perm && pvec) ? ((const u32x4*)perm)[i] : zero4;
+        }
     }
+    float ss = 0.0f;
+    if (pre)
+    {
+        #pragma unroll
+        for (int k = 0; k < NI; k++)
+            if (t + 256 * k < dim8)
+            {
+                #pragma unroll
+                for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)xv_[k][e], 65504.0f)); ss = fmaf(f, f, ss); }
+            }
+    }
+    else
+        for (int i = t; i < dim8; i += 256)
+        {
+            const f16x8 v = xr[i];
+            #pragma unroll
+            for (int e = 0; e < 8; e++) { const float f = fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)); ss = fmaf(f, f, ss); }
+        }
     ss = wave_allreduce_add(ss);
     if (lane == 0) part[wv] = ss;
     block_sync();
     ss = part[0] + part[1] + part[2] + part[3];
     const float rmf = fast_rsqrt(ss * r_dim + eps);
     block_sync();
-    const f16x8* wr = (const f16x8*)w;
-    for (int i = t; i < dim8; i += 256)
+    if (pre)
     {
-        const f16x8 v = xr[i], wv8 = wr[i];
-        f16x8 o;
         #pragma unroll
-        for (int e = 0; e < 8; e++) o[e] = (f16)(fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)) * (float)wv8[e] * rmf);
-        ((f16x8*)row_lds)[i] = o;
-        ((f16x8*)(xn + (size_t)r * hidden))[i] = o;
+        for (int k = 0; k < NI; k++)
+        {
+            const int i = t + 256 * k;
+            if (i < dim8)
+            {
+                f16x8 o;
+                #pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = (f16)(fmaxf(-65504.0f, fminf((float)xv_[k][e], 65504.0f)) * (float)wv_[k][e] * rmf);
+                ((f16x8*)row_lds)[i] = o;
+                ((f16x8*)(xn + (size_t)r * hidden))[i] = o;
+                xv_[k] = o;
+            }
+        }
     }
+    else
+        for (int i = t; i < dim8; i += 256)
+        {
+            const f16x8 v = xr[i], wv8 = wr[i];
+            f16x8 o;
+            #pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (f16)(fmaxf(-65504.0f, fminf((float)v[e], 65504.0f)) * (float)wv8[e] * rmf);
+            ((f16x8*)row_lds)[i] = o;
+            ((f16x8*)(xn + (size_t)r * hidden))[i] = o;
+        }
     block_sync();
     float acc[E];
     #pragma unroll
     for (int e = 0; e < E; e++) acc[e] = 0.0f;
-    for (int i = t; i < dim8; i += 256)
+    if (pre)
     {
-        const f16x8 xv = ((const f16x8*)row_lds)[i];
+        // (a thread's logit terms come from the row elements it normalised itself: no read-back)
         #pragma unroll
-        for (int e = 0; e < E; e++)
-        {
-            const f16x8 gv = ((const f16x8*)(gate + (size_t)e * hidden))[i];
-            #pragma unroll
-            for (int j = 0; j < 4; j++)
-                acc[e] = dot2_f32_f16((f16x2){xv[2 * j], xv[2 * j + 1]}, (f16x2){gv[2 * j], gv[2 * j + 1]}, acc[e]);
-        }
+        for (int k = 0; k < NI; k++)
+            if (t + 256 * k < dim8)
+            {
+                #pragma unroll
+                for (int e = 0; e < E; e++)
+                {
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[e] = dot2_f32_f16((f16x2){xv_[k][2 * j], xv_[k][2 * j + 1]}, (f16x2){gv_[k][e][2 * j], gv_[k][e][2 * j + 1]}, acc[e]);
+                }
+            }
     }
+    else
+        for (int i = t; i < dim8; i += 256)
+        {
+            const f16x8 xv = ((const f16x8*)row_lds)[i];
+            #pragma unroll
+            for (int e = 0; e < E; e++)
+            {
+                const f16x8 gv = ((const f16x8*)(gate + (size_t)e * hidden))[i];
+                #pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[e] = dot2_f32_f16((f16x2){xv[2 * j], xv[2 * j + 1]}, (f16x2){gv[2 * j], gv[2 * j + 1]}, acc[e]);
+            }
+        }
     #pragma unroll
     for (int e = 0; e < E; e++)
     {
@@ -139,6 +217,28 @@ KERNEL void __launch_bounds__(256) moe_front_kernel(const f16* x, const f16* w, 
         if (lane == 0) part[wv * E + e] = s;
     }
     block_sync();
+    // the packed copy of the row does not wait for the routing
+    if (xg)
+    {
+        if (pre && perm && pvec)
+        {
+            #pragma unroll
+            for (int k = 0; k < NI; k++)
+            {
+                const int i = t + 256 * k;
+                if (i < dim8)
+                {
+                    const u32x4 pv = pv_[k];
+                    f16x8 o;
+                    o[0] = row_lds[pv.x & 0xFFFFu]; o[1] = row_lds[pv.x >> 16]; o[2] = row_lds[pv.y & 0xFFFFu]; o[3] = row_lds[pv.y >> 16];
+                    o[4] = row_lds[pv.z & 0xFFFFu]; o[5] = row_lds[pv.z >> 16]; o[6] = row_lds[pv.w & 0xFFFFu]; o[7] = row_lds[pv.w >> 16];
+                    ((f16x8*)(xg + (size_t)r * hidden))[i] = o;
+                }
+            }
+        }
+        else
+            for (int i = t; i < hidden; i += 256) xg[(size_t)r * hidden + i] = row_lds[perm ? (int)perm[i] : i];
+    }
     if (t == 0)
     {
         // moe_topk_kernel's arithmetic on the fp16-rounded logits
@@ -176,20 +276,20 @@ KERNEL void __launch_bounds__(256) moe_front_kernel(const f16* x, const f16* w, 
     if (cp.n_sel && r == 0)
     {
         block_sync();
-        for (int y = 0; y < cp.n_sel; y++)
-        {
-            const int e = sel_lds[y];
+        // all loads of the copies before their stores (one round trip, not one per block); blocks are <= 256 16-byte units
+        // (moe_front_launch checks), MOE_MAX_SEL experts
+        u32x4 v[2][MOE_MAX_SEL];
+        #pragma unroll
+        for (int k = 0; k < 2; k++)
             #pragma unroll
-            for (int k = 0; k < 2; k++)
-            {
-                const u32x4* const src = cp.src[k] + (size_t)e * cp.units[k];
-                u32x4* const dst = cp.dst[k] + (size_t)y * cp.units[k];
-                for (int i = t; i < cp.units[k]; i += 256) dst[i] = src[i];
-            }
-        }
+            for (int y = 0; y < MOE_MAX_SEL; y++)
+                if (y < cp.n_sel && t < cp.units[k]) v[k][y] = cp.src[k][(size_t)sel_lds[y] * cp.units[k] + t];
+        #pragma unroll
+        for (int k = 0; k < 2; k++)
+            #pragma unroll
+            for (int y = 0; y < MOE_MAX_SEL; y++)
+                if (y < cp.n_sel && t < cp.units[k]) cp.dst[k][(size_t)y * cp.units[k] + t] = v[k][y];
     }
-    if (xg)
-        for (int i = t; i < hidden; i += 256) xg[(size_t)r * hidden + i] = row_lds[perm ? (int)perm[i] : i];
 }
 
 // cp (nullable; one row only): the argument-block copies of the selected experts (moe.h)
@@ -200,7 +300,7 @@ int moe_front_launch(const void* x, const void* norm_w, const void* gate, const 
     if (rows <= 0) return EXL2_OK;
     if (!(num_experts == 4 || num_experts == 8 || num_experts == 16) || hidden % 8 || hidden > 16384 || topk < 1 || topk > num_experts) return 1;
     MoeCopy cp; memset(&cp, 0, sizeof(cp));
-    if (cp_) { if (rows != 1 || cp_->n_sel != topk || cp_->n_sel > MOE_MAX_SEL) return 1; cp = *cp_; }
+    if (cp_) { if (rows != 1 || cp_->n_sel != topk || cp_->n_sel > MOE_MAX_SEL || cp_->units[0] > 256 || cp_->units[1] > 256) return 1; cp = *cp_; }
     const size_t lds = (size_t)hidden * 2 + 4 * 16 * 4 + MOE_MAX_SEL * 4;
     const dim3 g((unsigned)rows);
 #define MOE_FRONT(E_) LAUNCH((moe_front_kernel<E_>), g, dim3(256), lds, stream, (const f16*)x, (const f16*)norm_w, (const f16*)gate, \

@@ -1281,7 +1281,8 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     // waves -- a 16-wave workgroup is alone on its CU (80 registers x 4 waves per SIMD), so the 640 tiles of a 70B q|k|v launch ran
     // as three rounds of 256; 8-wave workgroups are three per CU and all resident at once
     static const int s8_passes = []() { const char* e = getenv("EXL2_LEAN_S8_PASSES"); const int v = e ? atoi(e) : LEAN_S8_PASSES; return v < 1 ? 1 : (v > LEAN_S8_PASSES ? LEAN_S8_PASSES : v); }();
-    if (!in.pair && nslots == 1 && S == 8 && in.n_mats >= 2 && s8_passes > 1 && !rows_mode && !in.a_tiled) { cand_passes[n_cand] = s8_passes; cand[n_cand++] = 8; }
+    const int s8_single = []() { const char* e = getenv("EXL2_LEAN_S8_SINGLE"); return e ? atoi(e) : 0; }();      // (A/B: the two-load 8-wave form for ONE matrix too -- down_proj)
+    if (!in.pair && nslots == 1 && S == 8 && (in.n_mats >= 2 || s8_single) && s8_passes > 1 && !rows_mode && !in.a_tiled) { cand_passes[n_cand] = s8_passes; cand[n_cand++] = 8; }
     if (!in.pair && nslots == 1 && S == 8) cand[n_cand++] = 16;        // finer split of the tile
     // ROWS geometries, in order: two tiles x 8 waves sharing the staged rows (16 waves per CU), one tile x 8, one tile x 16; pair (8 + 8)
     // XMEM geometries (the rows do not fit / EXL2_LEAN_XMEM=2): one tile x 8, one tile x 16; pair (8 + 8)

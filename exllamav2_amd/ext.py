@@ -649,6 +649,21 @@ class ExtC:
             self._ptr(xp_out, torch.float16, "xp_out"), self._ptr(ss_out, torch.float32, "ss_out"), C.byref(n), self._stream(x)))
         return n.value
 
+    def q_moe_mlp_forward_chain(self, q_moe, x, rows: int, next_invperm, next_norm_w, xp_out, ss_out) -> int:
+        """q_moe_mlp_forward_ in place on x + the hand-off for the next consumer; returns the partial sums per row it published"""
+        n = C.c_int(0)
+        self.lib.check(self.lib.exl2_q_moe_mlp_forward_chain(
+            q_moe, self._ptr(x, torch.float16, "x"), int(rows), next_invperm or None, self._w_ptr(next_norm_w),
+            self._ptr(xp_out, torch.float16, "xp_out"), self._ptr(ss_out, torch.float32, "ss_out"), C.byref(n), self._stream(x)))
+        return n.value
+
+    def publish_rows(self, x, rows: int, hidden: int, next_invperm, next_norm_w, xp_out, ss_out) -> None:
+        """the hand-off a chained producer would have left, made from rows already in memory: xp_out = x * next_norm_w in the
+        consumer's packed order, ss_out[row] = sum of squares (one partial per row)"""
+        self.lib.check(self.lib.exl2_publish_rows(
+            self._ptr(x, torch.float16, "x"), int(rows), int(hidden), next_invperm or None, self._w_ptr(next_norm_w),
+            self._ptr(xp_out, torch.float16, "xp_out"), self._ptr(ss_out, torch.float32, "ss_out"), self._stream(x)))
+
     def gemm_half_q_half_chain(self, xp, ss, npart: int, eps: float, q_handle: int, c, rows: int) -> None:
         """c = rmsnorm(x) . W from xp = x * norm weight (applied by xp's producer, in W's packed order) and ss"""
         self.lib.check(self.lib.exl2_gemm_half_q_half_chain(

@@ -239,10 +239,18 @@ class GreedyGraphDecoder:
             return
         plan = []
         for attn, mlp in m.layers:
-            if not hasattr(mlp, "gate_proj") or mlp.q_handle is None or attn.q_handle is None:
+            if mlp.q_handle is None or attn.q_handle is None:
                 return
             cap_a, in_a, o_inv, nw_a = ext.q_attn_chain_info(attn.q_handle)
-            cap_m, in_m, nw_m = ext.q_mlp_chain_info(mlp.q_handle)
+            if hasattr(mlp, "gate_proj"):
+                cap_m, in_m, nw_m = ext.q_mlp_chain_info(mlp.q_handle)
+            elif hasattr(mlp, "num_experts") and os.environ.get("EXL2_CHAIN_MOE", "1") != "0" and "EXL2_CHAIN_OVERLAP" not in os.environ:
+                # a sparse-MoE block (round 6): the attention half of the layer is chained (q|k|v from the published hand-off, o_proj
+                # accumulating into x without publishing), the block itself reads x (its front kernel norms and routes), and its
+                # result is published for the next layer's q|k|v by one small launch -- in_m = "moe" marks it
+                cap_m, in_m, nw_m = True, "moe", None
+            else:
+                return
             if not (cap_a and cap_m):
                 return
             plan.append((in_a, o_inv, in_m, nw_a, nw_m))
@@ -348,10 +356,22 @@ class GreedyGraphDecoder:
                     ext.q_attn_forward_1_chain(attn.q_handle, xp_a[r0:r1], ss, cnt, r1 - r0, q[r0:r1], k[r0:r1], v[r0:r1])
                 ao = attn.attend_chain(q, k, v, self.cache, self.cache_seqlens, self.block_table, o_inv)
                 # every producer of the residual stream publishes it times its consumer's norm weight, in that consumer's order
+                nxt, nxt_w = (plan[i + 1][0], plan[i + 1][3]) if i + 1 < len(plan) else (ch["head_inv"], ch["norm_head"])
+                if in_m == "moe":
+                    for r0, r1 in groups_o:
+                        ext.q_attn_forward_2_chain(attn.q_handle, x2[r0:r1], ao[r0:r1], r1 - r0, None, None, None, None)
+                    pa.begin()
+                    if groups_h == [(0, b)]:
+                        pa.done(ext.q_moe_mlp_forward_chain(mlp.q_handle, x2, b, nxt, nxt_w, xp_a, pa.out(0, b)))
+                    else:
+                        mlp.forward(self.x)
+                        for r0, r1 in groups_h:
+                            ext.publish_rows(x2[r0:r1], r1 - r0, cfg.hidden_size, nxt, nxt_w, xp_a[r0:r1], pa.out(r0, r1))
+                            pa.done(1)
+                    continue
                 pb.begin()
                 for r0, r1 in groups_o:
                     pb.done(ext.q_attn_forward_2_chain(attn.q_handle, x2[r0:r1], ao[r0:r1], r1 - r0, in_m, nw_m, xp_b[r0:r1], pb.out(r0, r1)))
-                nxt, nxt_w = (plan[i + 1][0], plan[i + 1][3]) if i + 1 < len(plan) else (ch["head_inv"], ch["norm_head"])
                 if groups_h == groups_d and os.environ.get("EXL2_CHAIN_SPLIT_MLP", "0") != "1":     # (1: test hook)
                     pa.begin()
                     for r0, r1 in groups_h:

@@ -256,6 +256,10 @@ int exl2_make_q_moe_mlp(void** handle, const void* layernorm, const void* layern
                         void* temp_a, void* temp_b, void* temp_logits, void* temp_dq, int max_rows, int act_gelu);
 int exl2_free_q_moe_mlp(void* handle);
 int exl2_q_moe_mlp_forward(void* handle, void* x, int rows, void* stream);
+/* the same inside a chained decode step (no reference counterpart: the hand-off replaces the next module's norm launch,
+   rms_norm.cu:33-175): also publishes (xp_out, ss_out with *npart_out partial sums per row) for the next consumer */
+int exl2_q_moe_mlp_forward_chain(void* handle, void* x, int rows, const void* next_invperm, const void* next_norm_w, void* xp_out,
+                                 float* ss_out, int* npart_out, void* stream);
 /* router: logits[rows, E] = x gate^T, then softmax -> top-k -> renormalise in place (cuda/q_mlp_softmax.cuh) */
 int exl2_moe_route(const void* x, const void* gate, void* logits, int rows, int hidden, int num_experts, int topk, void* stream);
 

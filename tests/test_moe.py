@@ -180,11 +180,13 @@ def test_moe_model_equals_oracle(be, batch):
     compare(be.n(model.forward(torch.from_numpy(ids), cache)).astype(np.float64)[:, -1], want)
     tok = want.argmax(-1).astype(np.int64)
     dec = GreedyGraphDecoder(model, cache, batch_size=batch)
+    assert dec.chain is not None                # (round 6: the attention half of a MoE layer is chained, the block publishes its result)
     if not be.is_emu:
         dec.capture()
     dec.reset(torch.from_numpy(tok), ids.shape[1])
     for step in range(4):
         dec.run(1, use_graph=not be.is_emu)
+        assert dec.chain is not None
         want = oracle.forward(tok[:, None])[:, -1]
         compare(be.n(dec.logits).astype(np.float64)[:, :cfg.vocab_size], want)
         tok = be.n(dec.tokens(ids.shape[1] + step, 1))[:, 0].astype(np.int64)
