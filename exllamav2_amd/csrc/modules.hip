@@ -128,6 +128,7 @@ struct QMoEMLP
     // one row (round 6): the selected experts on the lean kernel -- argument blocks planned here, at load time, per expert; the front
     // kernel of a step copies the selected ones to the slots the gate|up and the down launch read (qgemv_lean.h: LeanGroupPlan)
     bool lean_ok; LeanGroupPlan lean_gu, lean_dn;
+    bool lean_sum_ok; LeanGroupPlan lean_dn2;      // top-2: both selected experts' down projections as ONE pair launch that adds the weighted sum to x (no combine launch)
 };
 
 // ---- small kernels of the grouped MoE path -----------------------------------------------------------------------------------
@@ -333,6 +334,17 @@ static void moe_plan_lean(QMoEMLP* m)
     }
     if (qgemv_lean_group_plan(ins, E, scale, m->num_experts_per_token, &m->lean_dn) != 0) { qgemv_lean_group_free(&m->lean_gu); return; }
     m->lean_ok = true;
+    if (m->num_experts_per_token == 2 && !getenv("EXL2_MOE_NO_SUM_PLAN"))
+    {
+        for (int e = 0; e < E; e++)
+        {
+            FlatIn& in = ins[e]; memset(&in, 0, sizeof(in));
+            in.qm[0] = m->w2[e]; in.qm[1] = m->w2[e]; in.ldc[0] = hidden; in.ldc[1] = hidden;
+            in.n_mats = 2; in.pair = 1; in.pair_sum = 1; in.M = rows; in.a_mode = A_DIRECT; in.a = m->temp_a + (size_t)e * rows * inter; in.lda = inter;
+            in.c_mode = C_ACCUM;
+        }
+        m->lean_sum_ok = qgemv_lean_group_plan(ins, E, scale, 1, &m->lean_dn2) == 0;
+    }
 }
 
 int exl2_make_q_moe_mlp(void** handle, const void* layernorm, const void* layernorm_bias, int layernorm_is_rms,
@@ -374,6 +386,7 @@ int exl2_free_q_moe_mlp(void* handle)
 {
     QMoEMLP* m = (QMoEMLP*)handle;
     if (m && m->lean_ok) { qgemv_lean_group_free(&m->lean_gu); qgemv_lean_group_free(&m->lean_dn); }
+    if (m && m->lean_sum_ok) qgemv_lean_group_free(&m->lean_dn2);
     free(handle);
     return EXL2_OK;
 }
@@ -400,16 +413,29 @@ static int moe_forward(void* handle, void* x_, int rows, const MoeChainOut& co, 
     // ---- one row on the lean kernel: front (+ the selected experts' argument blocks) -> gate|up -> down -> combine
     if (rows == 1 && m->lean_ok && !getenv("EXL2_MOE_NO_LEAN") && !getenv("EXL2_MOE_UNFUSED_FRONT") && !getenv("EXL2_MOE_SERIAL") && !getenv("EXL2_MOE_NO_GROUP"))
     {
-        MoeCopy cp;
+        MoeCopy cp; memset(&cp, 0, sizeof(cp));
+        const bool sum_route = m->lean_sum_ok && !getenv("EXL2_MOE_NO_SUM") && !(co.xp && co.tiled);
+        const LeanGroupPlan& dn = sum_route ? m->lean_dn2 : m->lean_dn;
         cp.src[0] = (const u32x4*)m->lean_gu.table_src; cp.dst[0] = (u32x4*)m->lean_gu.table_sel; cp.units[0] = m->lean_gu.block_bytes / 16;
-        cp.src[1] = (const u32x4*)m->lean_dn.table_src; cp.dst[1] = (u32x4*)m->lean_dn.table_sel; cp.units[1] = m->lean_dn.block_bytes / 16;
+        cp.src[1] = (const u32x4*)dn.table_src; cp.dst[1] = (u32x4*)dn.table_sel; cp.units[1] = dn.block_bytes / 16;
+        if (sum_route) { cp.sum[1] = 1; cp.b_lo[1] = dn.b_lo; cp.b_hi[1] = dn.b_hi; cp.b2_lo[1] = dn.b2_lo; cp.b2_hi[1] = dn.b2_hi; }
         cp.n_sel = m->num_experts_per_token;
         front = moe_front_launch(x, m->layernorm, m->gate, m->w1[0]->q_perm, m->temp_state, xg, m->temp_logits, rows, hidden, E,
                                  m->num_experts_per_token, m->norm_epsilon, &cp, stream);
         if (front < 0) return front;
         if (front == 0)
         {
-            if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: lean rows=%d experts=%d\n", rows, E);
+            if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: lean%s rows=%d experts=%d\n", sum_route ? " (down pair sums)" : "", rows, E);
+            if (sum_route)
+            {
+                LeanGroupDyn dyn; memset(&dyn, 0, sizeof(dyn));
+                dyn.c = x; dyn.ldc = hidden; dyn.xp_out = co.xp; dyn.xp_invperm = co.invperm; dyn.xp_w = co.w; dyn.ss_out = co.xp ? co.ss : nullptr; dyn.ldxp = co.ldxp;
+                if (qgemv_lean_group_launch(&m->lean_gu, stream) != 0 || qgemv_lean_group_launch(&dn, stream, &dyn) != 0)
+                    EXL2_FAIL(EXL2_E_INVALID, "q_moe_mlp_forward_: a planned lean launch was not taken");
+                HIP_TRY(hipGetLastError());
+                if (npart_out) *npart_out = co.xp ? dn.grid_x : 0;
+                return EXL2_OK;
+            }
             if (qgemv_lean_group_launch(&m->lean_gu, stream) != 0 || qgemv_lean_group_launch(&m->lean_dn, stream) != 0)
                 EXL2_FAIL(EXL2_E_INVALID, "q_moe_mlp_forward_: a planned lean launch was not taken");
             LAUNCH(moe_combine_kernel, dim3((unsigned)((hidden / 8 + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,

@@ -281,14 +281,19 @@ KERNEL void __launch_bounds__(256) moe_front_kernel(const f16* x, const f16* w, 
         u32x4 v[2][MOE_MAX_SEL];
         #pragma unroll
         for (int k = 0; k < 2; k++)
+        {
+            // (sum: one block, unit t from the first or the second selected expert)
+            const bool second = (t >= cp.b_lo[k] && t < cp.b_hi[k]) || (t >= cp.b2_lo[k] && t < cp.b2_hi[k]);
             #pragma unroll
             for (int y = 0; y < MOE_MAX_SEL; y++)
-                if (y < cp.n_sel && t < cp.units[k]) v[k][y] = cp.src[k][(size_t)sel_lds[y] * cp.units[k] + t];
+                if (y < (cp.sum[k] ? 1 : cp.n_sel) && t < cp.units[k])
+                    v[k][y] = cp.src[k][(size_t)sel_lds[cp.sum[k] ? (second ? 1 : 0) : y] * cp.units[k] + t];
+        }
         #pragma unroll
         for (int k = 0; k < 2; k++)
             #pragma unroll
             for (int y = 0; y < MOE_MAX_SEL; y++)
-                if (y < cp.n_sel && t < cp.units[k]) cp.dst[k][(size_t)y * cp.units[k] + t] = v[k][y];
+                if (y < (cp.sum[k] ? 1 : cp.n_sel) && t < cp.units[k]) cp.dst[k][(size_t)y * cp.units[k] + t] = v[k][y];
     }
 }
 
@@ -300,7 +305,7 @@ int moe_front_launch(const void* x, const void* norm_w, const void* gate, const 
     if (rows <= 0) return EXL2_OK;
     if (!(num_experts == 4 || num_experts == 8 || num_experts == 16) || hidden % 8 || hidden > 16384 || topk < 1 || topk > num_experts) return 1;
     MoeCopy cp; memset(&cp, 0, sizeof(cp));
-    if (cp_) { if (rows != 1 || cp_->n_sel != topk || cp_->n_sel > MOE_MAX_SEL || cp_->units[0] > 256 || cp_->units[1] > 256) return 1; cp = *cp_; }
+    if (cp_) { if (rows != 1 || cp_->n_sel != topk || cp_->n_sel > MOE_MAX_SEL || cp_->units[0] > 256 || cp_->units[1] > 256 || ((cp_->sum[0] || cp_->sum[1]) && topk != 2)) return 1; cp = *cp_; }
     const size_t lds = (size_t)hidden * 2 + 4 * 16 * 4 + MOE_MAX_SEL * 4;
     const dim3 g((unsigned)rows);
 #define MOE_FRONT(E_) LAUNCH((moe_front_kernel<E_>), g, dim3(256), lds, stream, (const f16*)x, (const f16*)norm_w, (const f16*)gate, \

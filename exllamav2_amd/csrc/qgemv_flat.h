@@ -34,6 +34,7 @@ struct FlatIn
     int a_tiled, c_tiled;
     int xp_tiled;                 // chain-out: xp_out is written in that layout too (16 row slots; ldxp unused)
     int plan_only;                // qgemv_lean_launch: make the host plan, launch nothing (0: the lean kernel takes this shape, 1: it declines)
+    int pair_sum;                 // pair = tile u of TWO experts' down projections, output = weighted sum into the residual (lean MoE route; lean_export only)
     void* lean_export;            // qgemv_lean_launch: hand the finished argument block + geometry to this LeanExport (qgemv_lean.hip), launch nothing
 };
 

@@ -32,6 +32,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stddef.h>
 #include <type_traits>
 #include <vector>
 #include <mutex>
@@ -407,9 +408,17 @@ DEV void lean_xmem_request(const LeanCtx& cx, int chunk, int nvalid, int lane, f
 // models) or a table in device memory indexed by blockIdx.y (qgemv_lean_moe_kernel: the launch's y-th SELECTED expert, whose block
 // the MoE front kernel copied there -- the graph's launch is fixed, the experts are not).  MOE: the output may carry the routing
 // weight (hdr.out_scale); `by` = the matrix index of a launch over several matrices.
+// MOE_SUM (the down projections of the TWO selected experts of a one-row MoE step as one pair launch): what is not known when the
+// experts' blocks are planned -- the residual stream the sum goes to and the hand-off for the next consumer -- comes as kernel arguments
+struct LeanDyn { f16* c; f16* xp_out; const u16* xp_invperm; const f16* xp_w; float* ss_out; int ldc, ldxp; };
+
 template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false, bool DEP = false, bool XMEM = false, bool MOE = false>
-DEV void lean_body(const LeanArgs& args, const int by)
+DEV void lean_body(const LeanArgs& args, const int by, const LeanDyn* const dyn = nullptr)
 {
+    // the pair = tile u of two experts' down projections: slot s reads ITS expert's activations (pointer in its wave records' spare
+    // words, next to the pointer to its routing weight), the epilogue is x += fp16(w0 sum0) + fp16(w1 sum1) -- what the separate
+    // launches + moe_combine_kernel (modules.hip) compute, in their order
+    constexpr bool MOE_SUM = MOE && PAIR && WALK && S == 8;
     DYN_SMEM(smem);
     const int lane = lane_id();
     const int wv = uniform(wave_id());
@@ -511,7 +520,9 @@ DEV void lean_body(const LeanArgs& args, const int by)
         const u32x4 m1 = mb[1];
         const u32x4 w1 = wb[1];
         const u32x4 w2 = wb[2];
-        const f16* const in_a = (const f16*)ptr_of(h0.x, h0.y);
+        const f16* in_a_ = (const f16*)ptr_of(h0.x, h0.y);
+        if constexpr (MOE_SUM) { const u32x4 w3 = wb[3]; in_a_ = (const f16*)ptr_of(w3.z, w3.w); }
+        const f16* const in_a = in_a_;
         const int M = (int)h1.w, K = (int)h2.x, lda = (int)h2.y;
         const int oct = K >> 3;
         const f16* const sc_tab = (const f16*)ptr_of(m1.x, m1.y); const f16* const zp_tab = (const f16*)ptr_of(m1.z, m1.w);
@@ -646,7 +657,7 @@ DEV void lean_body(const LeanArgs& args, const int by)
         constexpr size_t STEP = 64 * BITS;
         // (WALK without ROWS = the pair geometry whose 4 waves per tile take their share in up to three register loads: K = 8192 at 2-3 bits,
         // the 70B gate|up.  Its own instantiation: with the ring code inside, the 7B gate|up launch measured 0.6 % slower)
-        constexpr bool PAIR_LOADS = S == 4 && PAIR && !ROWS && WALK;
+        constexpr bool PAIR_LOADS = (S == 4 || S == 8) && PAIR && !ROWS && WALK;
         constexpr bool PASSES = !XMEM && (S == 16 || (S == 8 && NSLOTS == 1 && !PAIR && !ROWS && LEAN_S8_PASSES > 1 && BITS <= LEAN_S8_PASS_BITS) ||
                                           (PAIR_LOADS && BITS <= LEAN_S8_PASS_BITS));   // (what lean_plan_matrix plans)
         constexpr bool RING = PASSES && LEAN_PASS_RING && BITS <= LEAN_S8_PASS_BITS;      // (wider items: a whole load at a time, the round-4 loop)
@@ -897,7 +908,9 @@ DEV void lean_body(const LeanArgs& args, const int by)
     const int ep_mj = PAIR ? 0 : mj;                                     // (pair: the one output goes through matrix 0's c / c_invperm)
     const bool ep_on = ep_slot < N_OUT && ep_tile < n_tiles;
     const int ep_n = ep_tile * 16 + ep_c;
-    f16* const xp_out = args.hdr.xp_out;
+    f16* xp_out_ = nullptr;
+    if constexpr (MOE_SUM) xp_out_ = dyn->xp_out; else xp_out_ = args.hdr.xp_out;
+    f16* const xp_out = xp_out_;
     struct EpIn { f16* cp; f16 c_old; int xp_idx; f16 xw_next; float ssq; };
     // what a row's epilogue needs from memory
     // (two round trips to memory, not one per dependent load: first everything whose address is known -- the two permutation
@@ -907,7 +920,9 @@ DEV void lean_body(const LeanArgs& args, const int by)
     auto ep_inputs = [&](int row, EpIn& e) {
         e.cp = nullptr; e.c_old = (f16)0.0f; e.xp_idx = ep_n; e.xw_next = (f16)1.0f; e.ssq = 0.0f;
         const u16* const c_invperm = ep_on ? args.mat[ep_mj].c_invperm : nullptr;
-        const u16* const xp_invperm = (ep_on && xp_out) ? args.hdr.xp_invperm : nullptr;
+        const u16* xp_invperm_ = nullptr;
+        if constexpr (MOE_SUM) xp_invperm_ = (ep_on && xp_out) ? dyn->xp_invperm : nullptr; else xp_invperm_ = (ep_on && xp_out) ? args.hdr.xp_invperm : nullptr;
+        const u16* const xp_invperm = xp_invperm_;
         int c_idx = ep_n;
         if (c_invperm) c_idx = (int)c_invperm[ep_n];
         if (xp_invperm) e.xp_idx = (int)xp_invperm[ep_n];
@@ -923,9 +938,17 @@ DEV void lean_body(const LeanArgs& args, const int by)
         }
         if (ep_on)
         {
+            if constexpr (MOE_SUM)
+            {
+                if (xp_out && dyn->xp_w) e.xw_next = dyn->xp_w[e.xp_idx];
+                e.cp = dyn->c + (size_t)row * dyn->ldc + c_idx;
+            }
+            else
+            {
             if (xp_out && args.hdr.xp_w) e.xw_next = args.hdr.xp_w[e.xp_idx];
             e.cp = args.mat[ep_mj].c + ((flags & LF_CTILED) ? ((size_t)(c_idx >> 3) * 16 + row) * 8 + (c_idx & 7)
                                                            : (size_t)row * args.hdr.ldc[ep_mj] + c_idx);
+            }
             if (flags & LF_ACCUM) e.c_old = DEP ? load_agent_f16(e.cp) : *e.cp;
         }
         if (flags & LF_NORM)
@@ -953,7 +976,16 @@ DEV void lean_body(const LeanArgs& args, const int by)
         if (ep_on && !(LEAN_KILL & 4))
         {
             f16 y;
-            if constexpr (PAIR)
+            if constexpr (MOE_SUM)
+            {
+                const u32x4 p0 = ((const u32x4*)&args.wave[0])[3], p1 = ((const u32x4*)&args.wave[S])[3];
+                const f16 w0 = *(const f16*)ptr_of(p0.x, p0.y), w1 = *(const f16*)ptr_of(p1.x, p1.y);
+                float v = (float)e.c_old;                             // (LF_ACCUM: the plan sets it)
+                if (as_u16(w0) != 0) v += (float)(f16)(slot_sum(0) * (float)w0);
+                if (as_u16(w1) != 0) v += (float)(f16)(slot_sum(1) * (float)w1);
+                y = (f16)v;
+            }
+            else if constexpr (PAIR)
             {
                 float gv = slot_sum(0) * rms, uv = slot_sum(1) * rms;
                 if (flags & LF_BIAS)
@@ -978,14 +1010,19 @@ DEV void lean_body(const LeanArgs& args, const int by)
                 // of squares is x's own
                 const float f = fmaxf(-65504.0f, fminf((float)y, 65504.0f));
                 const f16 xw = (f16)fmaxf(-65504.0f, fminf(f * (float)e.xw_next, 65504.0f));
-                const size_t xo = (flags & LF_XPTILED) ? ((size_t)(e.xp_idx >> 3) * 16 + row) * 8 + (e.xp_idx & 7)
-                                                       : (size_t)row * args.hdr.ldxp + e.xp_idx;
+                size_t xo_;
+                if constexpr (MOE_SUM) xo_ = (size_t)row * dyn->ldxp + e.xp_idx;
+                else xo_ = (flags & LF_XPTILED) ? ((size_t)(e.xp_idx >> 3) * 16 + row) * 8 + (e.xp_idx & 7)
+                                                : (size_t)row * args.hdr.ldxp + e.xp_idx;
+                const size_t xo = xo_;
                 if constexpr (DEP) store_agent_f16(xp_out + xo, xw);
                 else xp_out[xo] = xw;
                 sq = f * f;
             }
         }
-        float* const ss_out = args.hdr.ss_out;
+        float* ss_out_ = nullptr;
+        if constexpr (MOE_SUM) ss_out_ = dyn->ss_out; else ss_out_ = args.hdr.ss_out;
+        float* const ss_out = ss_out_;
         if (ss_out)
         {
             sq = wave_allreduce_add(sq);
@@ -1043,9 +1080,9 @@ KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs a
 // grouped-expert launch (sparse MoE at one row): blockIdx.y = the y-th selected expert; its argument block was planned at load time
 // (qgemv_lean_plan_export) and copied to table[y] by the MoE front kernel of this step
 template <int S, int NSLOTS, bool PAIR, int OCC, bool WALK>
-KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_moe_kernel(const LeanArgs* __restrict__ table)
+KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_moe_kernel(const LeanArgs* __restrict__ table, const LeanDyn dyn)
 {
-    lean_body<false, S, NSLOTS, PAIR, OCC, false, WALK, false, false, true>(table[bid_y()], 0);
+    lean_body<false, S, NSLOTS, PAIR, OCC, false, WALK, false, false, true>(table[bid_y()], 0, &dyn);
 }
 
 #ifdef EXL2_TRACE
@@ -1241,6 +1278,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     if ((K & 7) || (((size_t)in.a) & 15) || (in.lda & 7)) return 1;
     if (in.a_mode == A_NORM_PRE && (!in.ss || in.npart < 1)) return 1;
     if (in.pair && (in.n_mats != 2 || in.qm[0]->width != in.qm[1]->width)) return 1;
+    if (in.pair_sum && (!in.lean_export || !in.pair || in.M != 1 || dep || in.a_tiled || in.c_tiled || in.xp_tiled)) return 1;
     static LeanArgs args_store;                                    // (large: off the stack; the launch copies it)
     static std::mutex mtx;
     std::lock_guard<std::mutex> lock(mtx);
@@ -1286,6 +1324,9 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     if (!in.pair && nslots == 1 && S == 8) cand[n_cand++] = 16;        // finer split of the tile
     // ROWS geometries, in order: two tiles x 8 waves sharing the staged rows (16 waves per CU), one tile x 8, one tile x 16; pair (8 + 8)
     // XMEM geometries (the rows do not fit / EXL2_LEAN_XMEM=2): one tile x 8, one tile x 16; pair (8 + 8)
+    // the weighted sum of two experts' down projections (MOE_SUM): 8 waves per expert's tile, up to LEAN_MAX_PASSES ring loads each,
+    // the 16-wave workgroup alone on its CU (two activation slices + two sets of scale rows: 86 KB at Mixtral's K = 14336)
+    if (in.pair_sum) { n_cand = 1; cand[0] = 8; cand_passes[0] = LEAN_MAX_PASSES; cand_budget[0] = 150u * 1024u; }
     int cand_slots[3] = {nslots, nslots, nslots};
     const int xmem_on = []() { const char* e = getenv("EXL2_LEAN_XMEM"); return e ? atoi(e) : 1; }();     // (read per launch build: tests switch it)
     bool xmem = false;
@@ -1412,7 +1453,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     {
         LeanExport* const ex = (LeanExport*)in.lean_export;
         ex->args = a; ex->S = S; ex->nslots = nslots; ex->pair = in.pair; ex->grid_x = grid_x; ex->lds = lds;
-        ex->walk = in.pair && S == 4 && planned_passes > 1;
+        ex->walk = in.pair && ((S == 4 && planned_passes > 1) || in.pair_sum);
         ex->plain = !rows_mode && !xmem && !dep && !q0->is_gptq && (in.pair || in.n_mats == 1);
         if (wgs_out) *wgs_out = wgs;
         return 0;
@@ -1459,6 +1500,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
 
 // ---- grouped-expert launches (qgemv_lean.h) ---------------------------------------------------------------------------------------
 #define LEAN_FOR_EACH_MOE_GEOMETRY(X) X(4, 2, true, LEAN_OCC_DEFAULT, false) X(4, 2, true, LEAN_PAIR_LOADS_OCC, true) X(8, 2, true, LEAN_OCC_DEFAULT, false) \
+                                      X(8, 2, true, LEAN_OCC_DEFAULT, true) \
                                       X(8, 1, false, LEAN_OCC_DEFAULT, false) X(16, 1, false, LEAN_OCC_DEFAULT, false)
 
 int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out_scale, int n_sel, LeanGroupPlan* gp)
@@ -1474,8 +1516,9 @@ int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out
         FlatIn in = ins[g];
         in.lean_export = &ex; in.plan_only = 0;
         if (in.M != 1 || in.sync_signal || in.sync_wait || in.sync_arrive || in.a_tiled || in.c_tiled || in.xp_tiled) return 1;
-        const int rc = qgemv_lean_launch(in, nullptr, nullptr);
-        if (rc != 0 || !ex.plain) return 1;
+        int wgs = 0;
+        const int rc = qgemv_lean_launch(in, nullptr, &wgs);
+        if (rc != 0 || !ex.plain || (in.pair_sum && (wgs > LEAN_MAX_PART || 2 * ex.S > LEAN_RECORDS))) return 1;
         if (g == 0) { gp->S = ex.S; gp->nslots = ex.nslots; gp->pair = ex.pair; gp->walk = ex.walk ? 1 : 0; gp->grid_x = ex.grid_x; gp->lds = ex.lds; }
         else
         {
@@ -1483,7 +1526,33 @@ int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out
             if (ex.lds > gp->lds) gp->lds = ex.lds;
         }
         ex.args.hdr.out_scale = out_scale ? out_scale[g] : nullptr;
+        if (in.pair_sum)
+        {
+            // both slots planned from THIS expert (the front kernel of a step takes slot 1's matrix block and wave records from the
+            // second selected expert's table entry): every record carries the expert's routing-weight and activation pointers
+            if (!out_scale || !out_scale[g]) return 1;
+            for (int i = 0; i < 2 * ex.S; i++)
+            {
+                const u64 p0 = (u64)(size_t)out_scale[g], p1 = (u64)(size_t)in.a;
+                u32* const pad = ex.args.wave[i].pad;
+                pad[0] = (u32)p0; pad[1] = (u32)(p0 >> 32); pad[2] = (u32)p1; pad[3] = (u32)(p1 >> 32);
+            }
+            ex.args.hdr.out_scale = nullptr;
+        }
         blocks[(size_t)g] = ex.args;
+    }
+    if (ins[0].pair_sum)
+    {
+        // a step's block mixes two experts' records: one slot size, one place for the partial sums in all of them
+        u32 slot_bytes = 0;
+        for (int g = 0; g < n_groups; g++) if (blocks[(size_t)g].hdr.slot_bytes > slot_bytes) slot_bytes = blocks[(size_t)g].hdr.slot_bytes;
+        for (int g = 0; g < n_groups; g++)
+        {
+            LeanHdr& h = blocks[(size_t)g].hdr;
+            h.slot_bytes = slot_bytes; h.red_off = slot_bytes * (u32)gp->nslots;
+        }
+        gp->lds = slot_bytes * (u32)gp->nslots + (u32)(gp->S * gp->nslots) * 16u * 4u;
+        if (gp->lds > 160u * 1024u) return 1;
     }
     bool inst = false;
 #define LEAN_HAS(SS, NS, P, OCC, W) if (gp->S == SS && gp->nslots == NS && (gp->pair != 0) == P && (gp->walk != 0) == W) inst = true;
@@ -1491,6 +1560,11 @@ int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out
 #undef LEAN_HAS
     if (!inst) return 1;
     gp->n_groups = n_groups; gp->n_sel = n_sel; gp->block_bytes = (int)sizeof(LeanArgs);
+    gp->pair_sum = ins[0].pair_sum ? 1 : 0;
+    // (pair_sum: the ONE block a step's launch reads = the first selected expert's block with units [b_lo, b_hi) and [b2_lo, b2_hi)
+    // -- slot 1's matrix block and wave records -- taken from the second selected expert's)
+    gp->b_lo = (int)(offsetof(LeanArgs, mat) + sizeof(LeanMat)) / 16; gp->b_hi = gp->b_lo + (int)sizeof(LeanMat) / 16;
+    gp->b2_lo = (int)(offsetof(LeanArgs, wave) + (size_t)gp->S * sizeof(LeanWave)) / 16; gp->b2_hi = gp->b2_lo + gp->S * (int)sizeof(LeanWave) / 16;
     if (hipMalloc(&gp->table_src, (size_t)n_groups * sizeof(LeanArgs)) != hipSuccess) { gp->table_src = nullptr; return 1; }
     if (hipMalloc(&gp->table_sel, (size_t)n_sel * sizeof(LeanArgs)) != hipSuccess) { (void)hipFree(gp->table_src); gp->table_src = gp->table_sel = nullptr; return 1; }
     if (hipMemcpy(gp->table_src, blocks.data(), (size_t)n_groups * sizeof(LeanArgs), hipMemcpyHostToDevice) != hipSuccess ||
@@ -1507,9 +1581,13 @@ void qgemv_lean_group_free(LeanGroupPlan* gp)
     gp->table_src = gp->table_sel = nullptr;
 }
 
-int qgemv_lean_group_launch(const LeanGroupPlan* gp, void* stream)
+int qgemv_lean_group_launch(const LeanGroupPlan* gp, void* stream, const LeanGroupDyn* dyn_)
 {
     if (!gp || !gp->table_sel) return 1;
+    LeanDyn dyn; memset(&dyn, 0, sizeof(dyn));
+    if (dyn_) { dyn.c = (f16*)dyn_->c; dyn.xp_out = (f16*)dyn_->xp_out; dyn.xp_invperm = (const u16*)dyn_->xp_invperm; dyn.xp_w = (const f16*)dyn_->xp_w;
+                dyn.ss_out = dyn_->ss_out; dyn.ldc = dyn_->ldc; dyn.ldxp = dyn_->ldxp; }
+    if ((gp->pair_sum != 0) != (dyn_ != nullptr && dyn_->c != nullptr)) return 1;
     static bool attr[EXL2_MAX_DEVICES] = {false};
     if (exl2_first_on_device(attr))
     {
@@ -1517,11 +1595,11 @@ int qgemv_lean_group_launch(const LeanGroupPlan* gp, void* stream)
         LEAN_FOR_EACH_MOE_GEOMETRY(LEAN_ATTR)
 #undef LEAN_ATTR
     }
-    const dim3 grid((unsigned)gp->grid_x, (unsigned)gp->n_sel, 1), block((unsigned)(gp->S * gp->nslots) * 64, 1, 1);
+    const dim3 grid((unsigned)gp->grid_x, (unsigned)(gp->pair_sum ? 1 : gp->n_sel), 1), block((unsigned)(gp->S * gp->nslots) * 64, 1, 1);
     const LeanArgs* const table = (const LeanArgs*)gp->table_sel;
     int launched = 0;
 #define LEAN_GO(SS, NS, P, OCC, W) \
-    if (gp->S == SS && gp->nslots == NS && (gp->pair != 0) == P && (gp->walk != 0) == W) { launched++; LAUNCH((qgemv_lean_moe_kernel<SS, NS, P, OCC, W>), grid, block, gp->lds, stream, table); }
+    if (gp->S == SS && gp->nslots == NS && (gp->pair != 0) == P && (gp->walk != 0) == W) { launched++; LAUNCH((qgemv_lean_moe_kernel<SS, NS, P, OCC, W>), grid, block, gp->lds, stream, table, dyn); }
     LEAN_FOR_EACH_MOE_GEOMETRY(LEAN_GO)
 #undef LEAN_GO
     return launched == 1 ? 0 : 1;

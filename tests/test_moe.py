@@ -292,8 +292,13 @@ def test_moe_one_row_runs_the_selected_experts_on_the_lean_kernel(be, seed, capf
         monkeypatch.setenv("EXL2_DEBUG_ROUTE", "1")
         y = x.clone(); moe.forward(y)
         monkeypatch.delenv("EXL2_DEBUG_ROUTE")
-        assert "route: lean rows=1" in capfd.readouterr().err
+        assert "route: lean (down pair sums) rows=1" in capfd.readouterr().err      # (top-2: one pair launch adds both experts' weighted outputs to x)
         w_lean = be.n(moe.temp_logits[:1]).copy()
+        monkeypatch.setenv("EXL2_MOE_NO_SUM", "1"); monkeypatch.setenv("EXL2_DEBUG_ROUTE", "1")
+        y2 = x.clone(); moe.forward(y2)                                               # (the two down launches + the combine launch)
+        monkeypatch.delenv("EXL2_MOE_NO_SUM"); monkeypatch.delenv("EXL2_DEBUG_ROUTE")
+        assert "route: lean rows=1" in capfd.readouterr().err
+        assert np.array_equal(w_lean.view(np.uint16), be.n(moe.temp_logits[:1]).view(np.uint16))
         monkeypatch.setenv("EXL2_MOE_NO_LEAN", "1")
         z = x.clone(); moe.forward(z)
         monkeypatch.delenv("EXL2_MOE_NO_LEAN")
@@ -304,12 +309,13 @@ def test_moe_one_row_runs_the_selected_experts_on_the_lean_kernel(be, seed, capf
         oracle.router_margin = np.full((1,), np.inf)
         want = oracle.moe_mlp(xh, OM.rms_norm(xh, oracle.w[pfx + ".post_attention_layernorm"], cfg.norm_eps), pfx).astype(np.float64)
         if oracle.router_margin[0] <= 2e-3: want = None       # (a near tie in the oracle's router: another expert may be selected)
-        got, other = be.n(y).astype(np.float64).reshape(1, hidden), be.n(z).astype(np.float64).reshape(1, hidden)
-        tol = 0.01 + np.abs(other) * 2.0 ** -7
-        assert np.all(np.abs(got - other) <= tol), float((np.abs(got - other) / tol).max())
-        if want is not None:
-            tol = 0.01 + np.abs(want) * 2.0 ** -7
-            assert np.all(np.abs(got - want) <= tol), float((np.abs(got - want) / tol).max())
+        other = be.n(z).astype(np.float64).reshape(1, hidden)
+        for got in (be.n(y).astype(np.float64).reshape(1, hidden), be.n(y2).astype(np.float64).reshape(1, hidden)):
+            tol = 0.01 + np.abs(other) * 2.0 ** -7
+            assert np.all(np.abs(got - other) <= tol), float((np.abs(got - other) / tol).max())
+            if want is not None:
+                tol = 0.01 + np.abs(want) * 2.0 ** -7
+                assert np.all(np.abs(got - want) <= tol), float((np.abs(got - want) / tol).max())
     assert len(picked) >= 2, picked                # (the calls selected different experts: the blocks were re-copied)
     model.unload()
 
