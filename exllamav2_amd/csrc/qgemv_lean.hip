@@ -412,9 +412,14 @@ DEV void lean_xmem_request(const LeanCtx& cx, int chunk, int nvalid, int lane, f
 // experts' blocks are planned -- the residual stream the sum goes to and the hand-off for the next consumer -- comes as kernel arguments
 struct LeanDyn { f16* c; f16* xp_out; const u16* xp_invperm; const f16* xp_w; float* ss_out; int ldc, ldxp; };
 
-template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false, bool DEP = false, bool XMEM = false, bool MOE = false>
+// LOADS (ROWS + WALK, two tiles x 8 waves; round 6): ONE row of a long K whose tiles outnumber the CUs (70B down_proj: K = 28672, 512
+// tiles) -- the plain form is a 16-wave workgroup per tile, alone on its CU with its 57 KB copy of the row + 28 KB of scale rows:
+// two rounds of 256.  Here a workgroup takes two tiles, its 16 waves stage the row ONCE (the ROWS form's shared copy), every wave's
+// share is up to LEAN_MAX_PASSES register loads (the ring), up to 128 scale rows: one round.
+template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false, bool DEP = false, bool XMEM = false, bool MOE = false, bool LOADS = false>
 DEV void lean_body(const LeanArgs& args, const int by, const LeanDyn* const dyn = nullptr)
 {
+    static_assert(!LOADS || (ROWS && WALK && S == 8 && NSLOTS == 2 && !PAIR && !GPTQ && !DEP && !XMEM), "LOADS: the two-tile ROWS geometry only");
     // the pair = tile u of two experts' down projections: slot s reads ITS expert's activations (pointer in its wave records' spare
     // words, next to the pointer to its routing weight), the epilogue is x += fp16(w0 sum0) + fp16(w1 sum1) -- what the separate
     // launches + moe_combine_kernel (modules.hip) compute, in their order
@@ -573,6 +578,11 @@ DEV void lean_body(const LeanArgs& args, const int by, const LeanDyn* const dyn 
             // front of the requests of the wave's last items)
             if (lane < sc_units) LEAN_DMA(st, lane * 16, sc_lds);
             if (sc_units > 64) { if (64 + lane < sc_units) LEAN_DMA(st, (64 + lane) * 16, sc_lds + 1024); }
+            if constexpr (LOADS)
+            {
+                if (sc_units > 128) { if (128 + lane < sc_units) LEAN_DMA(st, (128 + lane) * 16, sc_lds + 2048); }
+                if (sc_units > 192) { if (192 + lane < sc_units) LEAN_DMA(st, (192 + lane) * 16, sc_lds + 3072); }
+            }
             if constexpr (GPTQ)
             {
                 const f16* zt = zp_tab + ((size_t)t_ * G + gw0) * 16;
@@ -659,9 +669,9 @@ DEV void lean_body(const LeanArgs& args, const int by, const LeanDyn* const dyn 
         // the 70B gate|up.  Its own instantiation: with the ring code inside, the 7B gate|up launch measured 0.6 % slower)
         constexpr bool PAIR_LOADS = (S == 4 || S == 8) && PAIR && !ROWS && WALK;
         constexpr bool PASSES = !XMEM && (S == 16 || (S == 8 && NSLOTS == 1 && !PAIR && !ROWS && LEAN_S8_PASSES > 1 && BITS <= LEAN_S8_PASS_BITS) ||
-                                          (PAIR_LOADS && BITS <= LEAN_S8_PASS_BITS));   // (what lean_plan_matrix plans)
+                                          (PAIR_LOADS && BITS <= LEAN_S8_PASS_BITS) || LOADS);   // (what lean_plan_matrix plans)
         constexpr bool RING = PASSES && LEAN_PASS_RING && BITS <= LEAN_S8_PASS_BITS;      // (wider items: a whole load at a time, the round-4 loop)
-        constexpr bool MANY_LOADS = S == 16 || PAIR_LOADS;                          // shares of more than two register loads (the 70B pair: up to three)
+        constexpr bool MANY_LOADS = S == 16 || PAIR_LOADS || LOADS;                          // shares of more than two register loads (the 70B pair: up to three)
         LaneWords<BITS> a[DA > 0 ? DA : 1], b[NB > 0 ? NB : 1], bt;
         const int nA = n - NB;
         u32 xvoff = 0;                                                 // XMEM: the lane's byte offset into the activations (row, 8 j)
@@ -1071,10 +1081,10 @@ DEV void lean_body(const LeanArgs& args, const int by, const LeanDyn* const dyn 
     }
 }
 
-template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false, bool DEP = false, bool XMEM = false>
+template <bool GPTQ, int S, int NSLOTS, bool PAIR, int OCC, bool ROWS = false, bool WALK = false, bool DEP = false, bool XMEM = false, bool LOADS = false>
 KERNEL void LEAN_BOUNDS(S * NSLOTS * 64, OCC) qgemv_lean_kernel(const LeanArgs args)
 {
-    lean_body<GPTQ, S, NSLOTS, PAIR, OCC, ROWS, WALK, DEP, XMEM>(args, bid_y());
+    lean_body<GPTQ, S, NSLOTS, PAIR, OCC, ROWS, WALK, DEP, XMEM, false, LOADS>(args, bid_y());
 }
 
 // grouped-expert launch (sparse MoE at one row): blockIdx.y = the y-th selected expert; its argument block was planned at load time
@@ -1102,7 +1112,7 @@ struct LeanRun { int F, bits, chunk0; u32 off, tstride; int tail_nv; u32 t_off, 
 // decoder per wave, everything in registers); the waves are dealt out to the runs in proportion to their bytes.  Fills
 // wave[0 .. S) and returns the LDS bytes of the S waves together, 0 when the matrix is not covered with S waves (more runs
 // than waves, more items than a wave's registers hold, a chunk -> group map that is not affine inside a part, ...).
-static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave* wave, bool rows_mode = false, bool xmem = false, int passes = 0)
+static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave* wave, bool rows_mode = false, bool xmem = false, int passes = 0, int sc_rows_max = 64)
 {
     if (passes <= 0) passes = S == 16 ? LEAN_MAX_PASSES : 1;            // register loads a wave's share may take (S = 8: items of <= LEAN_S8_PASS_BITS bits only)
     const QMatDev& d = qm->dev;
@@ -1167,7 +1177,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
             const int n = (r.F - i0 + (nw[i] - k) - 1) / (nw[i] - k);        // even split, larger parts first
             const bool last = k == nw[i] - 1;
             const int tail_nv = last ? r.tail_nv : 0;
-            if (n > lean_depth(r.bits, S) * ((S == 16 || r.bits <= LEAN_S8_PASS_BITS) ? passes : 1) || n > 255) return 0;
+            if (n > lean_depth(r.bits, S) * ((S == 16 || r.bits <= LEAN_S8_PASS_BITS || sc_rows_max > 64) ? passes : 1) || n > 255) return 0;      // (sc_rows_max > 64: the LOADS form -- any width)
             LeanWave& lw = wave[w];
             lw.lds_off = lds_total;
             const int c0 = r.chunk0 + 4 * i0;
@@ -1191,7 +1201,7 @@ static u32 lean_plan_matrix(const QMatrix* qm, int S, int M, bool norm, LeanWave
             if (shift < 0 || c0 > 0xFFFF || c_end - c0 > 0xFFFF || g_lo > 0xFFFF || g_hi - g_lo + 1 > 0xFFFF) return 0;
             // what the kernel's straight-line staging copies (stage_copies); ROWS: the rows are staged by the workgroup, any length
             // (XMEM: no staged activations -- any M <= 16, any slice; one pass only: the ring of A operands covers LeanDepth items)
-            if ((g_hi - g_lo + 1) > 64 || (!rows_mode && !xmem && ((c_end - c0) * 4 > 64 * ((S == 4 && passes > 1) ? LEAN_X_PIECES_PAIR_LOADS : LEAN_X_PIECES_BASE) || M > 4))) return 0;
+            if ((g_hi - g_lo + 1) > sc_rows_max || (!rows_mode && !xmem && ((c_end - c0) * 4 > 64 * ((S == 4 && passes > 1) ? LEAN_X_PIECES_PAIR_LOADS : LEAN_X_PIECES_BASE) || M > 4))) return 0;
             if (xmem && n > lean_depth(r.bits, S)) return 0;
             const bool uni = shift >= 2 && (phase & 3) == 0;                   // the four chunks of every full item share a group
             lw.w_off = r.off + (u32)i0 * 64u * (u32)r.bits; lw.w_tstride = r.tstride;
@@ -1249,6 +1259,7 @@ static void lean_attrs()
     (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, S, NS, P, 4, true, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<true, S, NS, P, 4, true, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LEAN_FOR_EACH_ROWS_GEOMETRY(LEAN_ATTR)
+    (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, 8, 2, false, 4, true, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #undef LEAN_ATTR
 #define LEAN_ATTR(S, NS, P) \
     (void)hipFuncSetAttribute((const void*)qgemv_lean_kernel<false, S, NS, P, 4, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -1260,13 +1271,23 @@ static void lean_attrs()
 // what qgemv_lean_launch hands out instead of launching (FlatIn.lean_export): the argument block and the geometry it chose
 struct LeanExport { LeanArgs args; int S, nslots, pair, walk, grid_x; u32 lds; bool plain; };
 
+static int lean_cus()
+{
+    static int cus[EXL2_MAX_DEVICES] = {0};
+    const int dev = exl2_current_device();
+    if (!cus[dev]) { hipDeviceProp_t prop; cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
+    if (const char* e = getenv("EXL2_LEAN_CUS")) { const int v = atoi(e); if (v > 0) return v; }      // (tests: the walking forms on small shapes)
+    return cus[dev];
+}
+
 // 0: launched; 1: shape not covered (the caller takes the round-2 kernel).  *wgs_out = grid size = partial sums per row a
 // chain-out launch publishes.
 int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
 {
     if (in.n_mats < 1 || in.n_mats > FLAT_MAX_MATS || in.M < 1 || in.M > LEAN_MAX_ROWS) return 1;
     static const int rows_on = []() { const char* e = getenv("EXL2_LEAN_ROWS"); return e ? atoi(e) : 1; }();
-    const bool rows_mode = in.M > LEAN_MAX_M;
+    bool rows_mode = in.M > LEAN_MAX_M;
+    bool rows_loads = false;                                        // the LOADS form (lean_body): one row of a long K, two tiles per workgroup
     if (rows_mode && !rows_on) return 1;
     const bool dep = in.sync_signal != nullptr;                     // a launch of an overlapped chain (chain_sync.h): <= 4 rows only
     if (!dep && (in.sync_wait || in.sync_arrive)) return 1;
@@ -1341,7 +1362,11 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     auto plan = [&](int form) {                                      // 0: <= 4 rows; 1: ROWS; 2: XMEM
         n_cand = plain_n;
         for (int i = 0; i < 3; i++) { cand[i] = plain_cand[i]; cand_slots[i] = nslots0; cand_passes[i] = form ? 0 : plain_passes[i]; cand_budget[i] = form ? 0u : plain_budget[i]; }
-        if (form == 1)
+        if (form == 3)                                              // LOADS: two tiles x 8 waves, shares of up to LEAN_MAX_PASSES register loads
+        {
+            n_cand = 1; cand[0] = 8; cand_slots[0] = 2; cand_passes[0] = LEAN_MAX_PASSES;
+        }
+        else if (form == 1)
         {
             n_cand = 0;
             if (in.pair) { cand[n_cand] = 8; cand_slots[n_cand++] = 2; }
@@ -1366,20 +1391,20 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
             }
         }
         // ROWS: the workgroup's shared copy of the M rows, in front of the waves' own (scale-row) areas
-        rows_bytes = form == 1 ? al16((u32)in.M * (u32)(K + 8) * 2u) : 0u;
+        rows_bytes = (form == 1 || form == 3) ? al16((u32)in.M * (u32)(K + 8) * 2u) : 0u;
         // (second round: a split that fits only with the whole LDS of a CU -- 2-4 rows of a K = 11008 matrix -- is still better
         // than leaving the chain: the decoder would fall back to the module-by-module route for EVERY launch)
         for (int ci = 0; ci < 2 * n_cand && !planned; ci++)
         {
             S = cand[ci % n_cand];
             if (form) nslots = cand_slots[ci % n_cand];
-            const u32 budget = form == 1 ? 158u * 1024u : (ci < n_cand ? (cand_budget[ci] ? cand_budget[ci] : LEAN_LDS_BUDGET * (u32)((S * nslots + 7) / 8)) : 150u * 1024u);
+            const u32 budget = (form == 1 || form == 3) ? 158u * 1024u : (ci < n_cand ? (cand_budget[ci] ? cand_budget[ci] : LEAN_LDS_BUDGET * (u32)((S * nslots + 7) / 8)) : 150u * 1024u);
             if (in.n_mats * S > LEAN_RECORDS) continue;
             bool ok = true;
             slot_bytes = 0;
             for (int j = 0; j < in.n_mats && ok; j++)
             {
-                const u32 b = lean_plan_matrix(in.qm[j], S, in.M, in.a_mode == A_NORM_PRE, a.wave + j * S, form == 1, form == 2, cand_passes[ci % n_cand]);
+                const u32 b = lean_plan_matrix(in.qm[j], S, in.M, in.a_mode == A_NORM_PRE, a.wave + j * S, form == 1 || form == 3, form == 2, cand_passes[ci % n_cand], form == 3 ? 128 : 64);
                 if (!b) ok = false;
                 if (b > slot_bytes) slot_bytes = b;
             }
@@ -1393,6 +1418,17 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     else if (xmem_on >= 2) { plan(2); if (!planned) plan(1); }
     else { plan(1); if (!planned && xmem_on >= 1) plan(2); }
     if (!planned) return 1;
+    // one row, one matrix, a 16-wave workgroup per tile and more tiles than CUs (two rounds of workgroups that are alone on their CU):
+    // the LOADS form -- two tiles per workgroup over ONE staged copy of the row, one round -- where it plans
+    static const int rows1_on = []() { const char* e = getenv("EXL2_LEAN_ROWS1"); return e ? atoi(e) : 1; }();
+    if (rows1_on && !rows_mode && !xmem && !dep && !in.pair && !in.pair_sum && in.n_mats == 1 && in.M == 1 && S == 16 && !q0->is_gptq && !in.a_tiled && !in.c_tiled && !in.xp_tiled &&
+        max_tiles > lean_cus() && !(in.ss_out && (max_tiles + 1) / 2 > LEAN_MAX_PART))
+    {
+        planned = false;
+        plan(3);
+        if (planned) { rows_mode = true; rows_loads = true; }
+        else { plan(0); if (!planned) return 1; }
+    }
     const int wgs = in.pair ? max_tiles : (max_tiles + nslots - 1) / nslots;
     if (in.ss_out && wgs > LEAN_MAX_PART) return 1;
     for (int j = 0; j < in.n_mats; j++)
@@ -1440,10 +1476,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     int grid_x = wgs;
     if (rows_mode && !xmem && !dep && nslots == 2)                   // (the WALK instantiations: the two-tile geometries)
     {
-        static int cus[EXL2_MAX_DEVICES] = {0};
-        const int dev = exl2_current_device();
-        if (!cus[dev]) { hipDeviceProp_t prop; cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
-        int cap = cus[dev] / (in.pair ? 1 : in.n_mats);
+        int cap = lean_cus() / (in.pair ? 1 : in.n_mats);
         if (const char* e = getenv("EXL2_LEAN_ROWS_GRID")) { const int v = atoi(e); if (v > 0) cap = v; }      // (tests: force the walk on small shapes)
         if (cap < 1) cap = 1;
         if (grid_x > cap) grid_x = cap;
@@ -1464,8 +1497,9 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
     const bool gptq = q0->is_gptq;
     const int occ = LEAN_OCC_DEFAULT;
 #define LEAN_LAUNCH(...) do { launched++; LAUNCH(__VA_ARGS__); } while (0)
+    if (rows_loads) LEAN_LAUNCH((qgemv_lean_kernel<false, 8, 2, false, 4, true, true, false, false, true>), grid, block, lds, stream, a);
 #define LEAN_GO(SS, NS, P, W) \
-    if (rows_mode && !xmem && !gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<false, SS, NS, P, 4, true, W>), grid, block, lds, stream, a); \
+    if (!rows_loads && rows_mode && !xmem && !gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<false, SS, NS, P, 4, true, W>), grid, block, lds, stream, a); \
     if (rows_mode && !xmem && gptq && S == SS && nslots == NS && (in.pair != 0) == P) LEAN_LAUNCH((qgemv_lean_kernel<true, SS, NS, P, 4, true, W>), grid, block, lds, stream, a);
     LEAN_FOR_EACH_ROWS_GEOMETRY(LEAN_GO)
 #undef LEAN_GO

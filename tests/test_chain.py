@@ -578,6 +578,53 @@ def test_gemm_chain_shares_of_several_register_loads(be, rows, spec_name, capfd,
     be.ext.free_q_matrix(h)
 
 
+ONE_ROW_SPECS = {
+    "k18432_3b_g32": (18432, [(3, 32, 18432)]),                          # 18 items = 72 scale rows per wave: the third copy instruction
+    "k28672_5b_3b_g32": (28672, [(5, 32, 1408), (3, 32, 27264)]),        # configs[3]'s down_proj (2.5 bpw recipe): 5-bit shares of several loads too
+    "k14336_4b_3b": (14336, [(4, 128, 8576), (3, 128, 5760)]),           # Mixtral's down_proj
+}
+
+
+@pytest.mark.parametrize("spec_name", list(ONE_ROW_SPECS))
+def test_gemm_chain_one_row_two_tiles_per_workgroup(be, spec_name, capfd, monkeypatch):
+    """Round 6, the LOADS form of the chained decode kernel: ONE row of a long K whose tiles outnumber the CUs (70B down_proj: 512 tiles
+    of K = 28672) -- the plain form is a 16-wave workgroup per tile, alone on its CU (two rounds of 256); here a workgroup takes TWO
+    tiles over one staged copy of the row, 8 waves per tile, every wave's share a ring of up to four register loads, up to 128 scale
+    rows per wave, and walks its units.  Emulator and GPU: EXL2_LEAN_CUS=2 makes 6 tiles 'more than the CUs' (3 units on 2
+    workgroups: one of them walks).  Plan from the host's trace, numerics against the oracle; EXL2_LEAN_ROWS1=0 = the plain form."""
+    k, spec = ONE_ROW_SPECS[spec_name]
+    n = 96
+    t, ref, w, h = _mk(be, k, n, spec, 9)
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((1, k)) * 2).astype(np.float16)
+    nw = (1 + 0.1 * rng.standard_normal(k)).astype(np.float16)
+    perm = np.argsort(t["q_invperm"]).astype(np.int64)
+    xp = (x.astype(np.float32) * nw.astype(np.float32)).astype(np.float16)[:, perm]
+    ss = (x.astype(np.float32) ** 2).sum(-1, keepdims=True).astype(np.float32)
+    c = torch.zeros((1, n), dtype=torch.float16, device=be.device)
+    monkeypatch.setenv("EXL2_LEAN_CUS", "2")
+    monkeypatch.setenv("EXL2_LEAN_TRACE", "1")
+    be.ext.chain_route_counts(reset=True)
+    be.ext.gemm_half_q_half_chain(be.t(xp), be.t(ss), 1, 1e-5, h, c, 1)
+    monkeypatch.delenv("EXL2_LEAN_TRACE")
+    err = capfd.readouterr().err
+    head = [l for l in err.split("\n") if l.startswith("[lean] M=1 ")]
+    assert head and " S=8 slots=2 wgs=3 " in head[0] and "form=rows" in head[0], head[:2]
+    depth = {2: 10, 3: 8, 4: 6, 5: 5}
+    shares = [(int(m.group(1)), int(m.group(2))) for m in re.finditer(r"; (\d+) x (\d+)b", err)]
+    assert any(cnt > 2 * depth[bits] for cnt, bits in shares), shares          # (three register loads at least)
+    want = OX.gemm_ref(OM.rms_norm(x, nw, 1e-5), ref, exact=True)
+    slack = 2 * max(1.0, (k / 1024.0) ** 0.5)
+    assert np.all(np.abs(be.n(c).astype(np.float64) - want) <= slack * half_tol(want, k))
+    monkeypatch.setenv("EXL2_LEAN_ROWS1", "0")                                # (the plain form: same sums within the same bar)
+    c2 = torch.zeros((1, n), dtype=torch.float16, device=be.device)
+    be.ext.gemm_half_q_half_chain(be.t(xp), be.t(ss), 1, 1e-5, h, c2, 1)
+    assert np.all(np.abs(be.n(c2).astype(np.float64) - want) <= slack * half_tol(want, k))
+    lean, flat = be.ext.chain_route_counts(reset=True)
+    assert flat == 0 and lean == 2
+    be.ext.free_q_matrix(h)
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "12")))))       # (more seeds: a longer hunt, by hand)
 def test_gemm_chain_random_bit_mixes_and_depths(be, seed):
     """Seeded random matrices through exl2_gemm_half_q_half_chain: K from 2048 to ~20 k, one to three bit-width sections in the
