@@ -70,7 +70,7 @@ def test_pipelined_regions_keep_their_last_requests_in_flight(tmp_path):
                 assert k < j + 200, (m.group(1), ident, "no wait behind the fence load")
                 k += 1
             wait = int(re.search(r"vmcnt\((\d+)\)", body[k]).group(1))
-            xmem = m.group(1).endswith("Lb1EEv8LeanArgs") and "Lb0ELb0ELb0ELb1EE" in m.group(1)      # <..., ROWS, WALK, DEP, XMEM = true>
+            xmem = m.group(1).endswith("Lb0ELb0ELb0ELb1ELb0EEv8LeanArgs")      # <..., ROWS, WALK, DEP, XMEM = true, LOADS>
             if nb == 0 and xmem:
                 # XMEM form: the A operands of the first three items (4 x 16 bytes per lane each) are requested behind the fence load
                 # and stay in flight across its wait
@@ -120,13 +120,22 @@ def test_ring_loads_keep_a_whole_register_load_in_flight(tmp_path):
                 ev.append("W" + re.search(r"vmcnt\((\d+)\)", t).group(1))
         return " ".join(ev)
 
-    e8 = events("_Z17qgemv_lean_kernelILb0ELi8ELi1ELb0ELi6ELb0ELb0ELb0ELb0EEv8LeanArgs")
-    e16 = events("_Z17qgemv_lean_kernelILb0ELi16ELi1ELb0ELi6ELb0ELb0ELb0ELb0EEv8LeanArgs")
+    e8 = events("_Z17qgemv_lean_kernelILb0ELi8ELi1ELb0ELi6ELb0ELb0ELb0ELb0ELb0EEv8LeanArgs")
+    e16 = events("_Z17qgemv_lean_kernelILb0ELi16ELi1ELb0ELi6ELb0ELb0ELb0ELb0ELb0EEv8LeanArgs")
     for width, depth in (("4", 6), ("2", 10), ("3", 8)):
         req = " ".join(["L" + width] * depth)
         down = " ".join("W%d" % i for i in range(depth - 1, -1, -1))
         assert req + " " + down in e8, (width, e8)
         ring = " ".join(["W%d L%s" % (depth - 1, width)] * (depth - 1))
         assert req + " " + ring in e16, (width, e16)
-    e82 = events("_Z17qgemv_lean_kernelILb0ELi8ELi2ELb1ELi6ELb0ELb0ELb0ELb0EEv8LeanArgs")           # the pair geometry: no such shares
+    # round 6: the several-loads pair (70B gate|up), the LOADS form (70B down_proj) and the MoE pair that sums two experts' down
+    # projections carry the same ring (depth of the 4-wave geometry: 8 items of 3 bits, 10 of 2)
+    for name, widths in (("_Z17qgemv_lean_kernelILb0ELi4ELi2ELb1ELi6ELb0ELb1ELb0ELb0ELb0EEv8LeanArgs", (("2", 10), ("3", 8))),
+                         ("_Z17qgemv_lean_kernelILb0ELi8ELi2ELb0ELi4ELb1ELb1ELb0ELb0ELb1EEv8LeanArgs", (("3", 8),)),
+                         ("_Z21qgemv_lean_moe_kernelILi8ELi2ELb1ELi6ELb1EEvPK8LeanArgs7LeanDyn", (("4", 6), ("3", 8)))):
+        ev = events(name)
+        for width, depth in widths:
+            ring = " ".join(["W%d L%s" % (depth - 1, width)] * (depth - 1))
+            assert " ".join(["L" + width] * depth) + " " + ring in ev, (name, width, ev)
+    e82 = events("_Z17qgemv_lean_kernelILb0ELi8ELi2ELb1ELi6ELb0ELb0ELb0ELb0ELb0EEv8LeanArgs")           # the pair geometry: no such shares
     assert " ".join(["W9 L2"] * 3) not in e82 and " ".join(["L2"] * 10) + " W9 W8 W7" not in e82
