@@ -429,7 +429,15 @@ static int attn_decode_fused_impl(const void* q, const void* k_new, const void* 
     // few KV heads (GQA): prefer more, lighter workgroups -- 4 query rows each (the KV stream is small and re-read per
     // row block) and up to 64 splits; with many KV heads 8 rows share one pass over the keys
     const bool gqa_small = (long long)num_kv_heads * batch < 64;
-    const int rb = (R >= 8 && !gqa_small) ? 8 : (R >= 4 ? 4 : (R >= 2 ? 2 : 1));
+    int rb_ = (R >= 8 && !gqa_small) ? 8 : (R >= 4 ? 4 : (R >= 2 ? 2 : 1));
+    // round 6, few KV heads: two query rows per workgroup (twice the workgroups over the same keys, which the L2 serves) -- same box,
+    // Mixtral 3.5 bpw bs=1: 434 -> 444 tok/s at ctx <= 36, 390 -> 408 at 1920, 349 -> 360 at 8000, 278 -> 270 at 30000; TinyLlama GPTQ
+    // 1450 -> 1534 (profiles/r09bc_attention_row_blocks.txt).  The row block is fixed when a step is captured, the context is not:
+    // two rows where the cache cannot hold more than 16384 tokens per sequence
+    if (gqa_small && rb_ > 2 && (long long)page_size * pages_per_seq <= 16384) rb_ = 2;
+    { static const int rb_env = []() { const char* e = getenv("EXL2_ATT_RB"); return e ? atoi(e) : 0; }();        // (A/B: rows per block of the one-launch decode attention)
+      if ((rb_env == 1 || rb_env == 2 || rb_env == 4 || rb_env == 8) && rb_env <= rb_) rb_ = rb_env; }
+    const int rb = rb_;
     const int rblocks = (R + rb - 1) / rb;
     if (!counters || (long long)batch * num_kv_heads * rblocks > n_counters) return 1;
     FusedArgs a;
