@@ -54,6 +54,12 @@
 #define LEAN_RAW2 1                   // 4-bit items: the matrix cores get the UN-subtracted codes (half2 1024 + q / 64 + q: one v_and_or_b32 per pair, no
 #endif                                // v_pk_add / v_pk_fma) and the constant part leaves through a second MFMA per chunk against a constant B fragment
                                       // -(1024 + z) / -(64 + z): 20 vector instructions per item instead of 50, no pre-pass (round 6; A/B in profiles/r06_raw2_ab.txt)
+#ifndef LEAN_DUO
+#define LEAN_DUO 0                    // 2 / 3-bit items whose groups are chunk pairs (group size 64): one scale per pair on the pair's fp32 sum (lean_item_general).
+                                      // Built and measured in round 6 (profiles/r09e_ab_*_duo.txt, same box): 16 packed multiplies + 2 scale reads fewer per
+                                      // item move the 70B gate|up launch 48.5 -> 48.2 us (the launch is NOT bound by instruction issue), Mixtral bs=1 +0.8 %,
+                                      // and the larger code costs the LOADS instantiation 6 spilled registers (70B down 33.8 -> 36.5 us, 70B -1.7 %): off
+#endif
 #ifndef LEAN_ITEM_FENCE
 #define LEAN_ITEM_FENCE 1             // a scheduling fence behind every item's decode (register pressure); 0: the compiler may interleave items (A/B experiment)
 #endif
@@ -295,6 +301,42 @@ DEV void lean_item_general(const LaneWords<BITS>& lw, const LeanCtx& cx, int chu
             }
         }
         return;
+    }
+#endif
+#if LEAN_DUO
+    if constexpr (BITS <= 3 && !GPTQ)
+    {
+        // round 6: groups of 64 rows on chunk-pair boundaries (2 / 3-bit items of the 2.5 / 3.5 bpw recipes: q, k, o, gate, up of the 70B) --
+        // the two chunks of a group accumulate into one fp32 chain and the group's scale goes onto that sum, as the uniform form does
+        // for a whole item (for a one-hot row still reconstruct()'s value: fp16 scale x small integer is exact in fp32): 8 fp32
+        // multiply-adds and two scale reads per item instead of 16 packed multiplies and four reads.  At these widths the launch is bound
+        // by instruction issue (70B gate|up: ~520 cycles per item and SIMD).
+        if (gshift == 1 && (gphase & 1) == 0 && nvalid == 4)                  // (cs is a multiple of 4; uniform over the wave)
+        {
+            const ZC z = make_zc((f16)(float)(1 << (BITS - 1)));
+            ZC zc4[4] = {z, z, z, z};
+            f16x2 p[16];
+            dequant_super<BITS>(lw.w, zc4, p);
+            const int gi = (g0 + ((cs + gphase) >> 1)) * 16 + c;
+            const float s01 = (float)cx.sc_lds[gi], s23 = (float)cx.sc_lds[gi + 16];
+            #pragma unroll
+            for (int h = 0; h < 2; h++)
+            {
+                f32x4 part = {0.0f, 0.0f, 0.0f, 0.0f};
+                #pragma unroll
+                for (int q = 2 * h; q < 2 * h + 2; q++)
+                {
+                    const f16x8 b = {p[4 * q].x, p[4 * q].y, p[4 * q + 1].x, p[4 * q + 1].y, p[4 * q + 2].x, p[4 * q + 2].y, p[4 * q + 3].x, p[4 * q + 3].y};
+                    f16x8 a;
+                    if constexpr (PRE) a = pre[q]; else a = *(const f16x8*)(arow + q * 32);
+                    part = mfma_16x16x32_f16(a, b, part);
+                }
+                const float sh = h ? s23 : s01;
+                #pragma unroll
+                for (int i = 0; i < 4; i++) acc[i] = fmaf(sh, part[i], acc[i]);
+            }
+            return;
+        }
     }
 #endif
     ZC zc[4];

@@ -698,8 +698,9 @@ def test_gate_up_pair_takes_several_register_loads_on_four_waves(be, capfd, monk
     assert any(cnt > depth.get(bits, 99) for cnt, bits in shares), shares
 
 
+@pytest.mark.parametrize("spec_id", ["5_4", "3_2_pairs"])
 @pytest.mark.parametrize("rows", [1, 4])
-def test_lean_kernel_identity_rows_equal_reconstruct(be, rows):
+def test_lean_kernel_identity_rows_equal_reconstruct(be, rows, spec_id):
     """The reference's own parity relation (tests/test_gemv.py:136-165: gemm(I) == reconstruct()) on the CHAINED decode kernel,
     bit for bit: one-hot activation rows through exl2_gemm_half_q_half_chain with sum(x^2) = K and eps = 0 (the epilogue's
     1 / rms factor is exactly 1) must return the rows of reconstruct(): 5-bit and 4-bit sections, one scale per item (g128: the scale
@@ -707,12 +708,16 @@ def test_lean_kernel_identity_rows_equal_reconstruct(be, rows):
     profiles/history/r05_raw4_experiment.txt, which it passed; kept because the chained kernel had no such test.)"""
     k, n = 1024, 96
     spec = [(5, 128, 128), (4, 128, 512), (4, 32, 256), (4, 64, 128)]
+    if spec_id == "3_2_pairs":
+        # round 6: 3 / 2-bit items whose groups are chunk PAIRS (group size 64) take the scale on the pair's fp32 sum (LEAN_DUO);
+        # a g32 section of each width beside them (a scale per chunk, on the weights)
+        spec = [(4, 128, 128), (3, 64, 384), (3, 32, 128), (2, 64, 256), (2, 32, 128)]
     t, ref, w, h = _mk(be, k, n, spec, 77)
     be.ext.chain_route_counts(reset=True)                              # (a process-wide counter: other tests' launches are not this test's)
     perm = np.argsort(t["q_invperm"]).astype(np.int64)                 # packed row i holds input feature perm[i]
     eye = np.eye(k, dtype=np.float16)
     ss = np.full((rows, 1), float(k), dtype=np.float32)
-    picks = range(0, k, rows) if not be.is_emu else list(range(0, 160, rows)) + list(range(k - 416, k, 7 * rows))
+    picks = range(0, k, rows) if not be.is_emu else list(range(0, 160, rows)) + list(range(160, k, 7 * rows) if spec_id == "3_2_pairs" else range(k - 416, k, 7 * rows))
     for r0 in picks:
         idx = [(r0 + i) % k for i in range(rows)]
         c = torch.zeros((rows, n), dtype=torch.float16, device=be.device)
