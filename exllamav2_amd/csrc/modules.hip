@@ -128,6 +128,7 @@ struct QMoEMLP
     // one row (round 6): the selected experts on the lean kernel -- argument blocks planned here, at load time, per expert; the front
     // kernel of a step copies the selected ones to the slots the gate|up and the down launch read (qgemv_lean.h: LeanGroupPlan)
     bool lean_ok; LeanGroupPlan lean_gu, lean_dn;
+    bool lean_rows_ok[LEAN_MAX_M + 1]; LeanGroupPlan lean_gu_r[LEAN_MAX_M + 1], lean_dn_r[LEAN_MAX_M + 1];      // 2-4 rows: one launch over all experts each (the reference's fused form covers <= 4 rows, q_mlp.cu:316-436)
     bool lean_sum_ok; LeanGroupPlan lean_dn2;      // top-2: both selected experts' down projections as ONE pair launch that adds the weighted sum to x (no combine launch)
 };
 
@@ -334,6 +335,35 @@ static void moe_plan_lean(QMoEMLP* m)
     }
     if (qgemv_lean_group_plan(ins, E, scale, m->num_experts_per_token, &m->lean_dn) != 0) { qgemv_lean_group_free(&m->lean_gu); return; }
     m->lean_ok = true;
+    // 2-4 rows: every expert's blocks for that row count; a launch covers all experts, workgroups of experts without a row leave at entry
+    // (built, parity-green on the MI355X, measured SLOWER than the grouped launches of qgemv_flat.hip at Mixtral's widths -- bs = 2 / 3 / 4:
+    // 537 / 749 / 983 against 577 / 836 / 1104 tok/s, profiles/r09fg_moe_rows_2_4.txt: with 4-7 experts active both routes stream at
+    // ~5 TB/s and the lean launches' 16-wave pair workgroups are alone on their CU -- so it is planned and taken only under
+    // EXL2_MOE_LEAN_ROWS=1, set when the module is made)
+    const char* const rows_env = getenv("EXL2_MOE_LEAN_ROWS");
+    for (int r = 2; r <= LEAN_MAX_M && rows_env && atoi(rows_env) != 0; r++)
+    {
+        if (!(r <= MAX_GEMV_ROWS && (long long)E * r <= m->max_rows && (long long)E * r * hidden <= (long long)m->max_rows * inter)) break;
+        for (int e = 0; e < E; e++)
+        {
+            FlatIn& in = ins[e]; memset(&in, 0, sizeof(in));
+            in.qm[0] = m->w1[e]; in.qm[1] = m->w3[e];
+            in.c[0] = m->temp_a + (size_t)e * r * inter; in.c[1] = in.c[0]; in.ldc[0] = inter; in.ldc[1] = inter;
+            in.c_invperm[0] = m->w2[e]->q_perm ? m->w2[e]->q_invperm : nullptr;
+            in.n_mats = 2; in.pair = 1; in.M = r; in.a_mode = A_DIRECT; in.a = xg; in.lda = hidden; in.c_mode = C_STORE;
+            in.act_gelu = m->act_gelu ? 1 : 0;
+            scale[e] = m->temp_logits + e;
+        }
+        if (qgemv_lean_group_plan(ins, E, scale, 1, &m->lean_gu_r[r], E, 0) != 0) continue;
+        for (int e = 0; e < E; e++)
+        {
+            FlatIn& in = ins[e]; memset(&in, 0, sizeof(in));
+            in.qm[0] = m->w2[e]; in.c[0] = m->temp_b + (size_t)e * r * hidden; in.ldc[0] = hidden;
+            in.n_mats = 1; in.M = r; in.a_mode = A_DIRECT; in.a = m->temp_a + (size_t)e * r * inter; in.lda = inter; in.c_mode = C_STORE;
+        }
+        if (qgemv_lean_group_plan(ins, E, scale, 1, &m->lean_dn_r[r], E, 1) != 0) { qgemv_lean_group_free(&m->lean_gu_r[r]); continue; }
+        m->lean_rows_ok[r] = true;
+    }
     if (m->num_experts_per_token == 2 && !getenv("EXL2_MOE_NO_SUM_PLAN"))
     {
         for (int e = 0; e < E; e++)
@@ -387,6 +417,7 @@ int exl2_free_q_moe_mlp(void* handle)
     QMoEMLP* m = (QMoEMLP*)handle;
     if (m && m->lean_ok) { qgemv_lean_group_free(&m->lean_gu); qgemv_lean_group_free(&m->lean_dn); }
     if (m && m->lean_sum_ok) qgemv_lean_group_free(&m->lean_dn2);
+    for (int r = 2; m && r <= LEAN_MAX_M; r++) if (m->lean_rows_ok[r]) { qgemv_lean_group_free(&m->lean_gu_r[r]); qgemv_lean_group_free(&m->lean_dn_r[r]); }
     free(handle);
     return EXL2_OK;
 }
@@ -445,6 +476,26 @@ static int moe_forward(void* handle, void* x_, int rows, const MoeChainOut& co, 
             return EXL2_OK;
         }
         front = 1;
+    }
+    // ---- 2-4 rows on the lean kernel: front -> gate|up over all experts -> down over all experts -> combine
+    if (rows >= 2 && rows <= LEAN_MAX_M && m->lean_rows_ok[rows] && !getenv("EXL2_MOE_NO_LEAN") && !getenv("EXL2_MOE_UNFUSED_FRONT") && !getenv("EXL2_MOE_SERIAL") &&
+        !getenv("EXL2_MOE_NO_GROUP") && !(co.xp && co.tiled))
+    {
+        front = exl2_moe_front(x, m->layernorm, m->gate, m->w1[0]->q_perm, m->temp_state, xg, m->temp_logits, rows, hidden, E,
+                               m->num_experts_per_token, m->norm_epsilon, stream);
+        if (front < 0) return front;
+        if (front == 0)
+        {
+            if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: lean rows=%d experts=%d\n", rows, E);
+            if (qgemv_lean_group_launch(&m->lean_gu_r[rows], stream) != 0 || qgemv_lean_group_launch(&m->lean_dn_r[rows], stream) != 0)
+                EXL2_FAIL(EXL2_E_INVALID, "q_moe_mlp_forward_: a planned lean launch was not taken");
+            LAUNCH(moe_combine_kernel, dim3((unsigned)((hidden / 8 + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
+                   x, (const f16*)m->temp_b, (const f16*)m->temp_logits, rows, hidden, E, co);
+            if (npart_out) *npart_out = (hidden / 8 + 255) / 256;
+            HIP_TRY(hipGetLastError());
+            return EXL2_OK;
+        }
+        have_xg = false; front = 1;
     }
     if (xg_room && !getenv("EXL2_MOE_UNFUSED_FRONT"))
         front = exl2_moe_front(x, m->layernorm, m->gate, m->w1[0]->q_perm, m->temp_state, xg, m->temp_logits, rows, hidden, E,

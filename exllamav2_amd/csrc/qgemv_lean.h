@@ -18,12 +18,15 @@ struct LeanGroupPlan
     void* table_src; void* table_sel;           // device: [n_groups] / [n_sel] argument blocks of block_bytes each
     int n_groups, n_sel, block_bytes;
     int S, nslots, pair, walk, grid_x; unsigned lds;
+    int all_groups;                             // 2-4 rows: one launch over ALL experts' planned blocks (r_stride != 0), no copies
     int pair_sum, b_lo, b_hi, b2_lo, b2_hi;     // FlatIn.pair_sum plans: 16-byte units of a step's block that come from the SECOND selected expert
 };
 // what a pair_sum launch takes at launch time: the residual rows the weighted sum is added to (+ the hand-off for the next consumer, nullable)
 struct LeanGroupDyn { void* c; int ldc; void* xp_out; const void* xp_invperm; const void* xp_w; float* ss_out; int ldxp; };
 // out_scale[g] (nullable array): device pointer to the fp16 weight the group's finished sums are multiplied by.  0: planned;
 // 1: a shape the lean kernel declines or experts whose plans differ in geometry (the caller keeps its other route)
-int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out_scale, int n_sel, LeanGroupPlan* plan);
+// r_stride != 0 (2-4 rows): out_scale[g][row * r_stride] = the group's routing weight of that row; the launch then covers all groups
+// and a group without a routed row leaves at entry.  mul: the finished sums are multiplied by the weight (down projections)
+int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out_scale, int n_sel, LeanGroupPlan* plan, int r_stride = 0, int mul = 1);
 int qgemv_lean_group_launch(const LeanGroupPlan* plan, void* stream, const LeanGroupDyn* dyn = nullptr);
 void qgemv_lean_group_free(LeanGroupPlan* plan);

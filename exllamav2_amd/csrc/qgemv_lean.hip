@@ -136,7 +136,9 @@ struct alignas(64) LeanHdr
     // they and the partial sums / residual are read at agent scope), this launch's block (every workgroup reports on entry; outputs
     // are agent-scope stores; every finalising wave arrives, the last publishes "go"), workgroups of the grid
     const u32* sync_wait; u32* sync_signal; u32 sync_wgs, sync_pad;
-    const f16* out_scale;             // MOE instantiations only: the expert's routing weight multiplies the finished sum (q_mlp.cu:373-384); nullable
+    const f16* out_scale;             // MOE instantiations only: the expert's routing weight of row 0 (q_mlp.cu:373-384); nullable
+    int r_stride;                     // ... of row r at out_scale[r * r_stride]; != 0 = a launch over ALL experts (2-4 rows): a workgroup whose expert
+    u32 moe_mul;                      //     no row is routed to leaves at entry (q_gemm_kernel.cuh:189-200).  moe_mul: the finished sums are multiplied by the weight
 };
 static_assert(sizeof(LeanHdr) == 192, "LeanHdr: the dense kernels' offsets must not move");
 struct LeanArgs
@@ -488,6 +490,19 @@ DEV void lean_body(const LeanArgs& args, const int by, const LeanDyn* const dyn 
     pin_scalar(m0x); pin_scalar(m0y); pin_scalar(m0z); pin_scalar(m0w); pin_scalar(m2x); pin_scalar(m2y);
     pin_scalar(w0x); pin_scalar(w0y); pin_scalar(w0z); pin_scalar(w0w); pin_scalar(meta_);
     const u32x4 m0 = {m0x, m0y, m0z, m0w}; const u32x2 m2 = {m2x, m2y}; const u32x4 w0 = {w0x, w0y, w0z, w0w};
+    if constexpr (MOE && !(PAIR && WALK && S == 8))
+    {
+        // a launch over all experts (2-4 rows): nothing to do for an expert no row is routed to
+        const int rst = args.hdr.r_stride;
+        if (rst)
+        {
+            const f16* const rw = args.hdr.out_scale;
+            const int rows_ = args.hdr.M;
+            u32 any = 0;
+            for (int rr = 0; rr < rows_; rr++) any |= (u32)as_u16(rw[(size_t)rr * rst]);
+            if (!any) return;
+        }
+    }
 #ifdef EXL2_TRACE
     u64* const trace = args.hdr.trace;
 #define LTRACE(i) do { if (trace && lane_id() == 0 && bid_x() < 2048) trace[(((size_t)bid_y() * 2048 + bid_x()) * LEAN_MAX_WAVES + wave_id()) * 8 + (i)] = realtime_stamp(); } while (0)
@@ -1051,7 +1066,7 @@ DEV void lean_body(const LeanArgs& args, const int by, const LeanDyn* const dyn 
             {
                 float v = slot_sum(ep_slot) * rms;
                 if (flags & LF_BIAS) { const f16* bias = args.mat[ep_mj].bias; if (bias) v += (float)bias[ep_n]; }
-                if constexpr (MOE) { const f16* const osc = args.hdr.out_scale; if (osc) v *= (float)*osc; }
+                if constexpr (MOE) { const f16* const osc = args.hdr.out_scale; if (osc && args.hdr.moe_mul) v *= (float)osc[(size_t)row * args.hdr.r_stride]; }
                 if (flags & LF_ACCUM) v += (float)e.c_old;
                 y = (f16)v;
             }
@@ -1579,7 +1594,7 @@ int qgemv_lean_launch(const FlatIn& in, void* stream, int* wgs_out)
                                       X(8, 2, true, LEAN_OCC_DEFAULT, true) \
                                       X(8, 1, false, LEAN_OCC_DEFAULT, false) X(16, 1, false, LEAN_OCC_DEFAULT, false)
 
-int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out_scale, int n_sel, LeanGroupPlan* gp)
+int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out_scale, int n_sel, LeanGroupPlan* gp, int r_stride, int mul)
 {
     if (!ins || !gp || n_groups < 1 || n_sel < 1 || n_sel > n_groups) return 1;
     memset(gp, 0, sizeof(*gp));
@@ -1591,7 +1606,7 @@ int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out
     {
         FlatIn in = ins[g];
         in.lean_export = &ex; in.plan_only = 0;
-        if (in.M != 1 || in.sync_signal || in.sync_wait || in.sync_arrive || in.a_tiled || in.c_tiled || in.xp_tiled) return 1;
+        if (in.M < 1 || in.M > LEAN_MAX_M || (in.pair_sum && in.M != 1) || in.sync_signal || in.sync_wait || in.sync_arrive || in.a_tiled || in.c_tiled || in.xp_tiled) return 1;
         int wgs = 0;
         const int rc = qgemv_lean_launch(in, nullptr, &wgs);
         if (rc != 0 || !ex.plain || (in.pair_sum && (wgs > LEAN_MAX_PART || 2 * ex.S > LEAN_RECORDS))) return 1;
@@ -1602,6 +1617,7 @@ int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out
             if (ex.lds > gp->lds) gp->lds = ex.lds;
         }
         ex.args.hdr.out_scale = out_scale ? out_scale[g] : nullptr;
+        ex.args.hdr.r_stride = r_stride; ex.args.hdr.moe_mul = mul ? 1u : 0u;
         if (in.pair_sum)
         {
             // both slots planned from THIS expert (the front kernel of a step takes slot 1's matrix block and wave records from the
@@ -1637,6 +1653,7 @@ int qgemv_lean_group_plan(const FlatIn* ins, int n_groups, const f16* const* out
     if (!inst) return 1;
     gp->n_groups = n_groups; gp->n_sel = n_sel; gp->block_bytes = (int)sizeof(LeanArgs);
     gp->pair_sum = ins[0].pair_sum ? 1 : 0;
+    gp->all_groups = r_stride != 0 ? 1 : 0;
     // (pair_sum: the ONE block a step's launch reads = the first selected expert's block with units [b_lo, b_hi) and [b2_lo, b2_hi)
     // -- slot 1's matrix block and wave records -- taken from the second selected expert's)
     gp->b_lo = (int)(offsetof(LeanArgs, mat) + sizeof(LeanMat)) / 16; gp->b_hi = gp->b_lo + (int)sizeof(LeanMat) / 16;
@@ -1671,8 +1688,9 @@ int qgemv_lean_group_launch(const LeanGroupPlan* gp, void* stream, const LeanGro
         LEAN_FOR_EACH_MOE_GEOMETRY(LEAN_ATTR)
 #undef LEAN_ATTR
     }
-    const dim3 grid((unsigned)gp->grid_x, (unsigned)(gp->pair_sum ? 1 : gp->n_sel), 1), block((unsigned)(gp->S * gp->nslots) * 64, 1, 1);
-    const LeanArgs* const table = (const LeanArgs*)gp->table_sel;
+    // (all_groups: blockIdx.y = expert, the blocks as planned -- workgroups of experts without a row leave at entry)
+    const dim3 grid((unsigned)gp->grid_x, (unsigned)(gp->pair_sum ? 1 : (gp->all_groups ? gp->n_groups : gp->n_sel)), 1), block((unsigned)(gp->S * gp->nslots) * 64, 1, 1);
+    const LeanArgs* const table = (const LeanArgs*)(gp->all_groups ? gp->table_src : gp->table_sel);
     int launched = 0;
 #define LEAN_GO(SS, NS, P, OCC, W) \
     if (gp->S == SS && gp->nslots == NS && (gp->pair != 0) == P && (gp->walk != 0) == W) { launched++; LAUNCH((qgemv_lean_moe_kernel<SS, NS, P, OCC, W>), grid, block, gp->lds, stream, table, dyn); }

@@ -320,6 +320,53 @@ def test_moe_one_row_runs_the_selected_experts_on_the_lean_kernel(be, seed, capf
     model.unload()
 
 
+@pytest.mark.parametrize("rows", [2, 3, 4])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_moe_two_to_four_rows_run_on_the_lean_kernel(be, rows, seed, capfd, monkeypatch):
+    """Round 6: the reference's fused MoE form covers <= 4 rows (q_mlp.cu:316-436, moe_mlp.py:238); here 2-4 rows run the experts on the
+    chained decode kernel too -- every expert's argument blocks planned per row count at load time, ONE gate|up launch and ONE down
+    launch over ALL experts (blockIdx.y = expert; workgroups of an expert no row is routed to leave at entry, q_gemm_kernel.cuh:189-200),
+    the down launch multiplies row r by ITS routing weight, then the combine launch.  Against the float64 oracle (rows whose router
+    decision is a near tie left out) and against the grouped route; routing weights bit-identical."""
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.synth import synth_checkpoint
+    from exllamav2_amd.model import ExLlamaV2
+    from oracle.model import OracleModel
+    rng = np.random.default_rng(1200 + 10 * rows + seed)
+    hidden, inter = int(rng.choice([256, 512])), int(rng.choice([512, 768]))
+    cfg = ExLlamaV2Config(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=1, num_attention_heads=4,
+                          num_key_value_heads=2, head_dim=64, vocab_size=96, max_seq_len=256, max_input_len=32,
+                          max_batch_size=16, num_experts=8, num_experts_per_token=2, arch="mixtral")
+    ck = synth_checkpoint(cfg, be.device, recipe=str(rng.choice(["3.5bpw", "4.0bpw", "2.5bpw"])), seed=60 + seed)
+    oracle = OracleModel(cfg, ck)
+    # (off by default: measured slower than the grouped launches at Mixtral's widths, profiles/r09fg_moe_rows_2_4.txt; planned when the module is made)
+    monkeypatch.setenv("EXL2_MOE_LEAN_ROWS", "1")
+    model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
+    moe = model.layers[0][1]
+    x = torch.from_numpy((rng.standard_normal((rows, 1, hidden)) * 0.7).astype(np.float16)).to(be.device)
+    monkeypatch.setenv("EXL2_DEBUG_ROUTE", "1")
+    y = x.clone(); moe.forward(y)
+    monkeypatch.delenv("EXL2_DEBUG_ROUTE")
+    assert f"route: lean rows={rows}" in capfd.readouterr().err
+    w_lean = be.n(moe.temp_logits[:rows]).copy()
+    monkeypatch.setenv("EXL2_MOE_NO_LEAN", "1")
+    z = x.clone(); moe.forward(z)
+    monkeypatch.delenv("EXL2_MOE_NO_LEAN")
+    assert np.array_equal(w_lean.view(np.uint16), be.n(moe.temp_logits[:rows]).view(np.uint16))
+    assert len({tuple(np.nonzero(w_lean[r])[0].tolist()) for r in range(rows)}) >= 1
+    xh = be.n(x).reshape(rows, hidden)
+    pfx = "model.layers.0"
+    oracle.router_margin = np.full((rows,), np.inf)
+    want = oracle.moe_mlp(xh, OM.rms_norm(xh, oracle.w[pfx + ".post_attention_layernorm"], cfg.norm_eps), pfx).astype(np.float64)
+    ok = oracle.router_margin > 2e-3
+    got, other = be.n(y).astype(np.float64).reshape(rows, hidden), be.n(z).astype(np.float64).reshape(rows, hidden)
+    tol = 0.01 + np.abs(other) * 2.0 ** -7
+    assert np.all(np.abs(got - other) <= tol), float((np.abs(got - other) / tol).max())
+    tol = 0.01 + np.abs(want) * 2.0 ** -7
+    assert ok.any() and np.all(np.abs(got - want)[ok] <= tol[ok]), float((np.abs(got - want)[ok] / tol[ok]).max())
+    model.unload()
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "6")))))        # (more seeds: a longer hunt, by hand)
 def test_moe_mlp_forward_random_shapes(be, seed, monkeypatch):
     """Seeded random sparse-MoE blocks: 4 / 8 experts, top-1..3, 1-24 rows, hidden / intermediate sizes off the powers of two, 4 / 3 / 2-bit
