@@ -24,9 +24,15 @@ from tests.util import exl2_to_torch, half_tol
 
 
 def _decode_and_check(be, cfg, recipe, batch, steps=3, seed=0, act_order=True, expect_chain=True, logit_slack=1.0, rounding="reference",
-                      **ck_kw):
+                      skip_rounding_sensitive_rows=False, **ck_kw):
+    """skip_rounding_sensitive_rows: rows of a step at which the oracle's two admissible roundings (fp16 where the reference's kernels
+    round / where ours round) are themselves more than the tolerance apart are left out of that step's LOGIT check -- such a row
+    amplifies one-ulp differences (random weights, attention over one or two keys) and says nothing about either path; found on the
+    MI355X at seed 35 of test_chain_decode_random_models: one row of 11, the two oracles 3.4 x tol apart, the chained route at
+    1.2 / 2.2 x and the module-by-module route at 2.2 / 1.1 x from them (tools/debug/random_model_seed.py)."""
     ck = synth_checkpoint(cfg, be.device, recipe=recipe, seed=seed, act_order=act_order, **ck_kw)
     oracle = OracleModel(cfg, ck, rounding=rounding)
+    other = OracleModel(cfg, ck, rounding="reference" if rounding == "chain" else "chain") if skip_rounding_sensitive_rows else None
     model = ExLlamaV2(cfg, device=be.device, ext=be.ext).load(ck)
     cache = ExLlamaV2Cache(model, batch_size=batch)
     dec = GreedyGraphDecoder(model, cache, batch_size=batch)
@@ -37,13 +43,20 @@ def _decode_and_check(be, cfg, recipe, batch, steps=3, seed=0, act_order=True, e
     first = rng.integers(0, cfg.vocab_size, size=(batch,))
     dec.reset(torch.from_numpy(first), 0)
     oracle.reset(batch)
+    if other is not None: other.reset(batch)
     tok = first.copy()
     n_conf = 0
+    n_rows = n_kept = 0
     for i in range(steps):
         dec.run(1, use_graph=not be.is_emu)
         want = oracle.forward(tok[:, None])[:, -1]
         got = be.n(dec.logits)[:, :cfg.vocab_size]
-        if logit_slack == 1.0:
+        if other is not None:
+            w2 = other.forward(tok[:, None])[:, -1]
+            keep = np.all(np.abs(want - w2) <= 0.03 + np.abs(want) * 2.0 ** -8, axis=-1)
+            n_rows += batch; n_kept += int(keep.sum())
+            check_logits(got[keep][:, None], want[keep][:, None])
+        elif logit_slack == 1.0:
             check_logits(got[:, None], want[:, None])
         else:
             err = np.abs(got.astype(np.float64) - want)
@@ -55,6 +68,7 @@ def _decode_and_check(be, cfg, recipe, batch, steps=3, seed=0, act_order=True, e
         n_conf += int(conf.sum())
         tok = g.copy()                                                  # follow the device: each step is checked alone
     assert n_conf >= 1, "no step had a confident oracle margin: the token check would be vacuous"
+    assert other is None or 2 * n_kept >= n_rows, (n_kept, n_rows)      # (the exclusion must stay the exception)
     assert (dec.chain is not None) == expect_chain
     dec.free()
     model.unload()
@@ -103,7 +117,8 @@ def test_chain_decode_random_models(be, seed, monkeypatch):
     cfg = tiny_cfg(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=int(rng.integers(1, 3)), num_attention_heads=kvh * g,
                    num_key_value_heads=kvh, head_dim=hd, max_batch_size=16)
     act_order = not recipe.startswith("gptq") or bool(rng.integers(0, 2))
-    _decode_and_check(be, cfg, recipe, batch, steps=2, seed=600 + seed, act_order=act_order, expect_chain=True, rounding="chain")
+    _decode_and_check(be, cfg, recipe, batch, steps=2, seed=600 + seed, act_order=act_order, expect_chain=True, rounding="chain",
+                      skip_rounding_sensitive_rows=True)
     _decode_and_check(be, cfg, recipe, batch, steps=2, seed=600 + seed, act_order=act_order, expect_chain=True, logit_slack=bar)
     # ... and the module-by-module route (the kernels behind the plain operator calls) on the same model
     monkeypatch.setenv("EXL2_CHAIN", "0")
