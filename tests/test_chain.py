@@ -395,6 +395,11 @@ def _q4_chain_case(be, monkeypatch, cfg, recipe, batch, steps, ck_seed=16, slack
             if cond is not None:
                 w_a, w_b = cond[0].forward(tok[:, None])[:, -1], cond[1].forward(tok[:, None])[:, -1]
                 rows_ok = rows_ok & (np.abs(w_a - w_b) <= 0.5 * (0.03 + np.abs(w_a) * 2.0 ** -8)).all(axis=-1)      # (once lost, a sequence stays out)
+                # ... and rows at which the 4-bit cache ITSELF moves the oracle's logits by more than 8 tolerances (FP16-cache oracle
+                # against Q4-cache oracle): one admissible code flip -- the codec's allowance below -- is then worth a tolerance or more.
+                # Seeds 31 / 83 on the MI355X: 70 x / 752 x at the row that failed (its neighbours 1-4 x), both routes alike
+                # (profiles/r10c_gpu_sweeps_128_seeds.txt, tools/debug/q4_seed_rows.py)
+                rows_ok = rows_ok & (np.abs(want - w_a) <= 8.0 * (0.03 + np.abs(w_a) * 2.0 ** -8)).all(axis=-1)
             if slack == 1.0:
                 check_logits(got[:, None], want[:, None])              # the model tolerance of the FP16-cache tests, not a multiple
             else:
