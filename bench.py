@@ -944,6 +944,15 @@ def finish(args, cfg, result, rank, world, n_gpus, device, dist):
         for k in ("roofline", "windows", "load_s", "weight_bytes_per_rank", "per_gpu_weight_roofline_frac", "sequences_in_flight", "ranks",
                   "strong_scaling_tp", "parity_check", "extra"):
             if k in result: out[k] = result[k]
+        if n_gpus > 1 and args.model == "llama2-7b" and args.recipe == "4.0bpw" and args.batch == 1 and result.get("scaling", "weak") == "weak":
+            # what DESIGN.md section 7 expects of this line, stated BEFORE it was ever measured (one-GPU boxes only): the first scaling run
+            # tests a prediction.  Aggregate = N x (one GPU's rate) x efficiency; one GPU: profiles/r09_bench.json (721.8 tok/s)
+            eff = {2: 0.93, 4: 0.84, 8: 0.72}.get(n_gpus)
+            if eff is not None:
+                out["predicted"] = {"tokens_per_s": round(n_gpus * 721.8 * eff, 1), "efficiency": eff, "one_gpu_tokens_per_s": 721.8,
+                                    "basis": "DESIGN.md section 7 (arithmetic: per-tick hand-off of one hidden row over xGMI against the "
+                                             "stage's compute; never measured on N > 1 GPUs before this run)",
+                                    "measured_over_predicted": round(result["value"] / (n_gpus * 721.8 * eff), 3)}
         if not args.no_prefill and n_gpus == 1 and args.model == "llama2-7b" and args.batch == 1:
             try:
                 out["prefill"] = prefill_rate(args.model, args.recipe, device, parity=not args.no_parity_check)
