@@ -34,6 +34,11 @@ def write_model_dir(path: str, cfg, ck: dict) -> str:
         "hidden_act": "silu", "bos_token_id": 1, "eos_token_id": 2, "pad_token_id": 0, "tie_word_embeddings": False,
         "torch_dtype": "float16",
     }
+    if getattr(cfg, "num_experts", 0):
+        # a sparse-MoE checkpoint in the reference's Mixtral form (architecture.py:291-305: block_sparse_moe.gate / experts.*.w1|w2|w3,
+        # config.py:322-323: num_local_experts / num_experts_per_tok)
+        config.update({"architectures": ["MixtralForCausalLM"], "model_type": "mixtral",
+                       "num_local_experts": cfg.num_experts, "num_experts_per_tok": cfg.num_experts_per_token})
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump(config, f)
     return path

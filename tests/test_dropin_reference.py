@@ -156,6 +156,53 @@ def test_unmodified_reference_runs_on_the_dropin(tmp_path):
 
 
 @pytest.mark.gpu
+def test_unmodified_reference_runs_a_sparse_moe_model_on_the_dropin(tmp_path):
+    """SURVEY.md 8a rows a13 x a17: the UNMODIFIED reference's Mixtral path -- architecture.py:291-305, moe_mlp.py:238-253
+    (`ext_c.q_moe_mlp_forward_` for <= 4 rows: the 4-token prompt and every decode step) -- on the drop-in: a synthetic 8-expert top-2
+    model directory, prompt logits and greedy decode steps against the float64 oracle (steps at which the oracle's router decision is
+    a near tie are left out: top-k is discontinuous).  At one row the block runs the round-6 route behind the operator boundary (the two
+    selected experts on the lean kernel, x updated in place through whatever pointer the host passes)."""
+    ref = _reference_pkg()
+    if ref is None:
+        pytest.skip("no copy of the reference's host package on this machine")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from exllamav2_amd.config import ExLlamaV2Config
+    from exllamav2_amd.synth import synth_checkpoint
+    from exllamav2_amd.synth_dir import write_model_dir
+    from oracle.model import OracleModel
+    cfg = ExLlamaV2Config(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                          num_key_value_heads=2, head_dim=64, vocab_size=320, max_seq_len=256, max_input_len=32,
+                          num_experts=8, num_experts_per_token=2, arch="mixtral")
+    ck = synth_checkpoint(cfg, "cpu", recipe="3.5bpw", seed=4)       # (a seed whose router margins stay >= 0.008 over the prompt and four steps)
+    oracle = OracleModel(cfg, ck)
+    model_dir = write_model_dir(str(tmp_path / "model"), cfg, ck)
+    out = str(tmp_path / "out.npz")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "dropin"), ROOT, ref]), EXL2_DEBUG_ROUTE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_dropin.py"), model_dir, out],
+                       env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "q_moe_mlp route: lean (down pair sums) rows=1" in r.stderr, r.stderr[-1500:]     # (the decode steps took the one-row route)
+    got = np.load(out)
+    ids = np.array([[3, 17, 42, 7]])
+    tol = lambda w: 0.03 + np.abs(w) * 2.0 ** -8
+    oracle.reset(1)
+    want = oracle.forward(ids)
+    assert oracle.router_margin[0] > 2e-3                           # (min over the prompt's rows and layers: OracleModel.forward)
+    g = got["prefill"][..., :cfg.vocab_size].astype(np.float64)
+    assert np.all(np.abs(g - want) <= tol(want))
+    compared = 0
+    for i, tok in enumerate(got["tokens"]):
+        w = oracle.forward(np.array([[int(tok)]]))
+        if oracle.router_margin[0] <= 2e-3:
+            break                                                   # (from a near tie on the device and the oracle may hold different caches)
+        g = got["steps"][:, i:i + 1, :cfg.vocab_size].astype(np.float64)
+        assert np.all(np.abs(g - w) <= tol(w)), i
+        compared += 1
+    assert compared >= 1
+
+
+@pytest.mark.gpu
 def test_unmodified_reference_tensor_parallel_on_the_dropin(tmp_path):
     """`model.load_tp()` + `ExLlamaV2Cache_TP` + the greedy loop of the UNMODIFIED reference on the drop-in's mirror of its
     single-process TP bindings (exllamav2_amd/ext_tp.py): split over every visible device (one on the build's GPU box: the
