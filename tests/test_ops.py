@@ -757,12 +757,13 @@ def test_attention_fused_handoff_stress():
     assert int(counters.sum()) == 0
 
 
+@pytest.mark.parametrize("s,hd", [(2, 128), (40, 128), (40, 64)])       # (>= 64 rows, NeoX: the one-workgroup-per-token kernel of round 6, 16-byte accesses)
 @pytest.mark.parametrize("neox", [True, False])
-def test_rope_kv_append(be, neox):
+def test_rope_kv_append(be, neox, s, hd):
     rng = np.random.default_rng(7)
-    pages, ps, kvh, hd, nh = 3, 256, 2, 128, 4
-    b, s = 2, 2
-    past = np.array([10, 255], dtype=np.int32)
+    pages, ps, kvh, nh = 3, 256, 2, 4
+    b = 2
+    past = np.array([10, 255 if s == 2 else 230], dtype=np.int32)      # (the second sequence crosses a page boundary)
     table = np.array([[2, 0], [1, 0]], dtype=np.int32)
     q = rng.standard_normal((b, s, nh, hd)).astype(F16)
     kn = rng.standard_normal((b, s, kvh, hd)).astype(F16)
