@@ -31,12 +31,35 @@ def _compile(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "exllamav2_amd", "csrc")
+    src = os.path.join(csrc, "qgemv_lean.hip")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", "-I", csrc, "--cuda-device-only", "-S"]
+    # the assembly of the 60-odd instantiations takes minutes to make: kept under tests/.isa_cache (git-ignored), keyed by the CONTENT
+    # of the kernel source, every header beside it, the flags and the compiler -- a changed byte anywhere recompiles
+    import hashlib
+    h = hashlib.sha1(" ".join(flags).encode())
+    h.update(subprocess.run([hipcc, "--version"], capture_output=True).stdout)
+    for f in [src] + sorted(os.path.join(csrc, n) for n in os.listdir(csrc) if n.endswith(".h")):
+        h.update(open(f, "rb").read())
+    cache_dir = os.path.join(ROOT, "tests", ".isa_cache")
+    cached = os.path.join(cache_dir, f"lean_{h.hexdigest()[:20]}.s")
+    if os.path.isfile(cached):
+        return open(cached).read()
     out = str(tmp_path / "lean.s")
-    src = os.path.join(ROOT, "exllamav2_amd", "csrc", "qgemv_lean.hip")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed",
-                           "-I", os.path.join(ROOT, "exllamav2_amd", "csrc"), "--cuda-device-only", "-S", src, "-o", out],
-                          stderr=subprocess.DEVNULL)
-    return open(out).read()
+    subprocess.check_call([hipcc] + flags + [src, "-o", out], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    try:
+        os.makedirs(cache_dir, exist_ok=True)
+        for n in os.listdir(cache_dir):
+            if n.startswith("lean_") and n.endswith(".s"):
+                os.remove(os.path.join(cache_dir, n))
+        tmp = cached + f".{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            f.write(text)
+        os.replace(tmp, cached)
+    except OSError:
+        pass
+    return text
 
 
 def test_pipelined_regions_keep_their_last_requests_in_flight(tmp_path):
