@@ -19,6 +19,12 @@
 #include <stdio.h>
 #include <vector>
 
+// A/B and test switches of the MoE block (EXL2_MOE_*, EXL2_DEBUG_ROUTE): read ONCE per process -- q_moe_mlp_forward_ runs per layer and
+// token on the eager route behind the drop-in (round-5 advisor: no getenv per call) -- unless EXL2_ENV_DYNAMIC is set when the library is
+// first used (tests/conftest.py sets it: the tests flip these switches inside one process)
+#define ENV_SET(name) ([]() -> bool { static const bool dyn = getenv("EXL2_ENV_DYNAMIC") != nullptr; static const bool v = getenv(name) != nullptr; \
+                                      return dyn ? getenv(name) != nullptr : v; }())
+
 int qgemv_launch(GemvJob* jobs, int n_jobs, int M, bool gptq, void* stream);
 
 extern "C" {
@@ -442,10 +448,10 @@ static int moe_forward(void* handle, void* x_, int rows, const MoeChainOut& co, 
     const bool xg_room = m->group_ok && rows <= MAX_GEMV_ROWS && 2 * MAX_GEMV_ROWS <= m->max_rows;
     int front = 1;
     // ---- one row on the lean kernel: front (+ the selected experts' argument blocks) -> gate|up -> down -> combine
-    if (rows == 1 && m->lean_ok && !getenv("EXL2_MOE_NO_LEAN") && !getenv("EXL2_MOE_UNFUSED_FRONT") && !getenv("EXL2_MOE_SERIAL") && !getenv("EXL2_MOE_NO_GROUP"))
+    if (rows == 1 && m->lean_ok && !ENV_SET("EXL2_MOE_NO_LEAN") && !ENV_SET("EXL2_MOE_UNFUSED_FRONT") && !ENV_SET("EXL2_MOE_SERIAL") && !ENV_SET("EXL2_MOE_NO_GROUP"))
     {
         MoeCopy cp; memset(&cp, 0, sizeof(cp));
-        const bool sum_route = m->lean_sum_ok && !getenv("EXL2_MOE_NO_SUM") && !(co.xp && co.tiled);
+        const bool sum_route = m->lean_sum_ok && !ENV_SET("EXL2_MOE_NO_SUM") && !(co.xp && co.tiled);
         const LeanGroupPlan& dn = sum_route ? m->lean_dn2 : m->lean_dn;
         cp.src[0] = (const u32x4*)m->lean_gu.table_src; cp.dst[0] = (u32x4*)m->lean_gu.table_sel; cp.units[0] = m->lean_gu.block_bytes / 16;
         cp.src[1] = (const u32x4*)dn.table_src; cp.dst[1] = (u32x4*)dn.table_sel; cp.units[1] = dn.block_bytes / 16;
@@ -456,7 +462,7 @@ static int moe_forward(void* handle, void* x_, int rows, const MoeChainOut& co, 
         if (front < 0) return front;
         if (front == 0)
         {
-            if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: lean%s rows=%d experts=%d\n", sum_route ? " (down pair sums)" : "", rows, E);
+            if (ENV_SET("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: lean%s rows=%d experts=%d\n", sum_route ? " (down pair sums)" : "", rows, E);
             if (sum_route)
             {
                 LeanGroupDyn dyn; memset(&dyn, 0, sizeof(dyn));
@@ -478,15 +484,15 @@ static int moe_forward(void* handle, void* x_, int rows, const MoeChainOut& co, 
         front = 1;
     }
     // ---- 2-4 rows on the lean kernel: front -> gate|up over all experts -> down over all experts -> combine
-    if (rows >= 2 && rows <= LEAN_MAX_M && m->lean_rows_ok[rows] && !getenv("EXL2_MOE_NO_LEAN") && !getenv("EXL2_MOE_UNFUSED_FRONT") && !getenv("EXL2_MOE_SERIAL") &&
-        !getenv("EXL2_MOE_NO_GROUP") && !(co.xp && co.tiled))
+    if (rows >= 2 && rows <= LEAN_MAX_M && m->lean_rows_ok[rows] && !ENV_SET("EXL2_MOE_NO_LEAN") && !ENV_SET("EXL2_MOE_UNFUSED_FRONT") && !ENV_SET("EXL2_MOE_SERIAL") &&
+        !ENV_SET("EXL2_MOE_NO_GROUP") && !(co.xp && co.tiled))
     {
         front = exl2_moe_front(x, m->layernorm, m->gate, m->w1[0]->q_perm, m->temp_state, xg, m->temp_logits, rows, hidden, E,
                                m->num_experts_per_token, m->norm_epsilon, stream);
         if (front < 0) return front;
         if (front == 0)
         {
-            if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: lean rows=%d experts=%d\n", rows, E);
+            if (ENV_SET("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: lean rows=%d experts=%d\n", rows, E);
             if (qgemv_lean_group_launch(&m->lean_gu_r[rows], stream) != 0 || qgemv_lean_group_launch(&m->lean_dn_r[rows], stream) != 0)
                 EXL2_FAIL(EXL2_E_INVALID, "q_moe_mlp_forward_: a planned lean launch was not taken");
             LAUNCH(moe_combine_kernel, dim3((unsigned)((hidden / 8 + 255) / 256), (unsigned)rows, 1), dim3(256), 0, stream,
@@ -497,7 +503,7 @@ static int moe_forward(void* handle, void* x_, int rows, const MoeChainOut& co, 
         }
         have_xg = false; front = 1;
     }
-    if (xg_room && !getenv("EXL2_MOE_UNFUSED_FRONT"))
+    if (xg_room && !ENV_SET("EXL2_MOE_UNFUSED_FRONT"))
         front = exl2_moe_front(x, m->layernorm, m->gate, m->w1[0]->q_perm, m->temp_state, xg, m->temp_logits, rows, hidden, E,
                                m->num_experts_per_token, m->norm_epsilon, stream);
     if (front < 0) return front;
@@ -518,9 +524,9 @@ static int moe_forward(void* handle, void* x_, int rows, const MoeChainOut& co, 
     // per-expert launch loop below (3 launches per expert: q_mlp.cu:318-402 has the same shape, moe_mlp.py:255-323 a
     // Python loop above 4 rows).
     if (m->group_ok && rows <= MAX_GEMV_ROWS && 2 * MAX_GEMV_ROWS <= m->max_rows && (long long)E * rows <= m->max_rows &&
-        (long long)E * rows * hidden <= (long long)m->max_rows * inter && !getenv("EXL2_MOE_SERIAL") && !getenv("EXL2_MOE_NO_GROUP"))
+        (long long)E * rows * hidden <= (long long)m->max_rows * inter && !ENV_SET("EXL2_MOE_SERIAL") && !ENV_SET("EXL2_MOE_NO_GROUP"))
     {
-        if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: grouped rows=%d experts=%d\n", rows, E);
+        if (ENV_SET("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: grouped rows=%d experts=%d\n", rows, E);
         make_xg();
         FlatIn ins[MOE_MAX_EXPERTS];
         for (int e = 0; e < E; e++)
@@ -563,9 +569,9 @@ static int moe_forward(void* handle, void* x_, int rows, const MoeChainOut& co, 
     // output in its own rows of the scratch, summed by moe_combine_kernel (fp32, expert order) instead of 8 read-modify-writes of x.
     if (m->group_ok && rows <= MAX_GEMV_ROWS && (long long)E * rows <= m->max_rows && (E & 3) == 0 &&
         (long long)E * rows * ((long long)inter + hidden) <= (long long)m->max_rows * inter &&
-        (long long)(MAX_GEMV_ROWS + rows) * hidden <= (long long)m->max_rows * hidden && !getenv("EXL2_MOE_SERIAL") && !getenv("EXL2_MOE_UNBATCHED"))
+        (long long)(MAX_GEMV_ROWS + rows) * hidden <= (long long)m->max_rows * hidden && !ENV_SET("EXL2_MOE_SERIAL") && !ENV_SET("EXL2_MOE_UNBATCHED"))
     {
-        if (getenv("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: batched rows=%d experts=%d\n", rows, E);
+        if (ENV_SET("EXL2_DEBUG_ROUTE")) fprintf(stderr, "q_moe_mlp route: batched rows=%d experts=%d\n", rows, E);
         make_xg();
         f16* const dout = m->temp_b + (size_t)E * rows * inter;              // [E][rows][hidden] weighted down outputs
         for (int e0 = 0; e0 < E; e0 += 2)

@@ -14,6 +14,9 @@ import sys
 
 import pytest
 
+# the library's per-process switches (csrc/modules.hip: ENV_SET) are re-read on every call in the test processes: tests flip them in place
+os.environ.setdefault("EXL2_ENV_DYNAMIC", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
