@@ -59,18 +59,19 @@ DEV int q4_eff_splits(int total, int nsplit)
     return e < 1 ? 1 : (e > nsplit ? nsplit : e);
 }
 
-// RoPE on 8 consecutive elements [c, c + 8) of a head row (`own`), `partner` = the elements 64 columns away (NeoX; unused for GPT-J):
-// rope_append_kernel's fp16 operations (attn.hip), element by element
+// RoPE on 8 consecutive elements [c, c + 8) of a head row (`own`), `partner` = the elements HALF = head_dim / 2 columns away (NeoX; unused
+// for GPT-J): rope_append_kernel's fp16 operations (attn.hip), element by element
+template <int HALF = 64>
 DEV f16x8 rope8_128(f16x8 own, f16x8 partner, int c, const f16* sr, const f16* cr, bool neox)
 {
     f16x8 y;
     if (neox)
     {
-        const int c0 = c & 63;
+        const int c0 = c & (HALF - 1);
         const f16x8 cs = *(const f16x8*)(cr + c0), sn = *(const f16x8*)(sr + c0);
         #pragma unroll
         for (int e = 0; e < 8; e++)
-            y[e] = c < 64 ? h_fma(own[e], cs[e], partner[e] * (-sn[e])) : h_fma(own[e], cs[e], partner[e] * sn[e]);
+            y[e] = c < HALF ? h_fma(own[e], cs[e], partner[e] * (-sn[e])) : h_fma(own[e], cs[e], partner[e] * sn[e]);
     }
     else
     {
@@ -88,7 +89,7 @@ DEV f16x8 rope8_128(f16x8 own, f16x8 partner, int c, const f16* sr, const f16* c
 template <int HDIM, int RB, bool FUSED = false>
 KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4Args a)
 {
-    static_assert(!FUSED || HDIM == 128, "the one-launch form is built for head_dim 128");
+    static_assert(!FUSED || HDIM == 128 || HDIM == 64, "the one-launch form is built for head_dim 128 and 64");
     DYN_SMEM(smem);
     constexpr int LPK = HDIM / 16;              // lanes per key: 16 elements (8 code bytes) each
     constexpr int KPW = 64 / LPK;
@@ -119,8 +120,10 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
         // in this launch reads what is written here: the codes serve keys < total - s, the step's own keys are attended in fp16.
         // The grid is sized for long sequences (HIP graph), so unless the sequence uses every split there is a workgroup with
         // nothing to attend over -- the first idle split packs, beside the attention instead of in front of it; else split 0.
+        // (head_dim 64, round 6: a wave packs 128 elements = the rows of TWO adjacent kv heads of a token -- the workgroup of the even head
+        // packs for both; the host takes this form for an even number of kv heads only)
         const int pack_split = (eff < a.nsplit && !a.pack_first) ? eff : 0;
-        if (split == pack_split && rblk == 0)
+        if (split == pack_split && rblk == 0 && (HDIM == 128 || (kh & 1) == 0))
         {
             for (int task = wv; task < 2 * a.s; task += AQ_WAVES)
             {
@@ -137,7 +140,7 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
                 {
                     f16x2 w = ((const f16x2*)(a.k_new + src))[lane];
                     const int srow = pos > 0 ? pos : 0;
-                    if (a.rope) w = rope_lane_pair128(w, lane, a.sin + (size_t)srow * HDIM, a.cos + (size_t)srow * HDIM, a.neox != 0);
+                    if (a.rope) w = rope_lane_pair<HDIM>(w, lane, a.sin + (size_t)srow * HDIM, a.cos + (size_t)srow * HDIM, a.neox != 0);
                     q_pack_lane<4>(lane, w, (u8*)a.k_codes, (f16*)a.k_scales, cache_off);
                 }
             }
@@ -171,8 +174,8 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
             if (a.rope)
             {
                 const int pos = total - a.s + j, srow = pos > 0 ? pos : 0;
-                const f16x8 qpart = *(const f16x8*)(qrow_p + ((o8 * 8) ^ 64));
-                qv = rope8_128(qv, qpart, o8 * 8, a.sin + (size_t)srow * HDIM, a.cos + (size_t)srow * HDIM, a.neox != 0);
+                const f16x8 qpart = *(const f16x8*)(qrow_p + ((o8 * 8) ^ (HDIM / 2)));
+                qv = rope8_128<HDIM / 2>(qv, qpart, o8 * 8, a.sin + (size_t)srow * HDIM, a.cos + (size_t)srow * HDIM, a.neox != 0);
             }
         }
         ((f16x8*)qraw_lds)[idx] = qv;
@@ -369,7 +372,7 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
                 const int srow = kp > 0 ? kp : 0;
                 const f16* sr = a.sin + (size_t)srow * HDIM;
                 const f16* cr = a.cos + (size_t)srow * HDIM;
-                const size_t psrc = src - 16 * u + ((16 * u) ^ 64);
+                const size_t psrc = src - 16 * u + ((16 * u) ^ (HDIM / 2));
                 #pragma unroll
                 for (int hblk = 0; hblk < 2; hblk++)
                 {
@@ -377,7 +380,7 @@ KERNEL void __launch_bounds__(AQ_WAVES * 64) attn_q4_decode_kernel(const AttnQ4A
                     #pragma unroll
                     for (int e = 0; e < 8; e++) own[e] = e & 1 ? kn[4 * hblk + e / 2].y : kn[4 * hblk + e / 2].x;
                     part = *(const f16x8*)(a.k_new + psrc + 8 * hblk);
-                    const f16x8 y = rope8_128(own, part, 16 * u + 8 * hblk, sr, cr, a.neox != 0);
+                    const f16x8 y = rope8_128<HDIM / 2>(own, part, 16 * u + 8 * hblk, sr, cr, a.neox != 0);
                     #pragma unroll
                     for (int e = 0; e < 4; e++) kn[4 * hblk + e] = (f16x2){y[2 * e], y[2 * e + 1]};
                 }
@@ -555,7 +558,7 @@ static void launch_q4(const AttnQ4Args& a, int rb, dim3 grid, void* stream, bool
         (void)hipFuncSetAttribute((const void*)attn_q4_decode_kernel<HDIM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)attn_q4_decode_kernel<HDIM, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    if constexpr (HDIM == 128)
+    if constexpr (HDIM == 128 || HDIM == 64)
     {
         if (fused)
         {
@@ -599,7 +602,7 @@ static int paged_attn_q4_impl(const void* q, const void* k_codes, const void* k_
     EXL2_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged_attn_q4: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
     if (batch <= 0 || q_len <= 0) return EXL2_OK;
     if (!(head_dim == 64 || head_dim == 128 || head_dim == 256)) return 1;
-    if (fused && (head_dim != 128 || !k_new || !v_new || (rope_style != 0 && (!sin || !cos || (sincos_size > 0 && sincos_size != head_dim))))) return 1;
+    if (fused && (!(head_dim == 128 || (head_dim == 64 && num_kv_heads % 2 == 0)) || !k_new || !v_new || (rope_style != 0 && (!sin || !cos || (sincos_size > 0 && sincos_size != head_dim))))) return 1;
     const int G = num_heads / num_kv_heads;
     const int R = q_len * G;
     if (R > 64) return 1;
@@ -648,7 +651,7 @@ static int paged_attn_q4_impl(const void* q, const void* k_codes, const void* k_
     // the length needed more than one split)
     if (nsplit > 1 && counters && (long long)n_counters >= (long long)batch * num_kv_heads * rblocks) a.counters = (u32*)counters;
     dim3 grid((unsigned)num_kv_heads, (unsigned)nsplit, (unsigned)(batch * rblocks));
-    if (head_dim == 64) launch_q4<64>(a, rb, grid, stream);
+    if (head_dim == 64) launch_q4<64>(a, rb, grid, stream, fused);
     else if (head_dim == 128) launch_q4<128>(a, rb, grid, stream, fused);
     else launch_q4<256>(a, rb, grid, stream);
     if (nsplit > 1 && !a.counters)

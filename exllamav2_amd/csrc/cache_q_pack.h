@@ -61,16 +61,20 @@ DEV void q_pack_lane(int t, f16x2 w, u8* out, f16* scales, size_t block_offset)
     }
 }
 
-// RoPE on a 128-element head row held as elements (2 t, 2 t + 1) in lane t of one wave; sr / cr = the position's sin / cos rows.
-// Same fp16 operations in the same order as rope_append_kernel (attn.hip): NeoX pairs (c, c + 64) sit in lanes t and t ^ 32.
-DEV f16x2 rope_lane_pair128(f16x2 w, int t, const f16* sr, const f16* cr, bool neox)
+// RoPE on head rows held as elements (2 t, 2 t + 1) in lane t of one wave: HDIM = 128 -- one row per wave; HDIM = 64 -- TWO rows (two
+// adjacent kv heads of one token: lanes 0..31 and 32..63), same position.  sr / cr = the position's sin / cos rows.  Same fp16 operations
+// in the same order as rope_append_kernel (attn.hip): NeoX pairs (c, c + HDIM / 2) sit in lanes t and t ^ (HDIM / 4).
+template <int HDIM>
+DEV f16x2 rope_lane_pair(f16x2 w, int t, const f16* sr, const f16* cr, bool neox)
 {
+    constexpr int LPH = HDIM / 2;                                   // lanes per head row
+    const int th = t & (LPH - 1);
     if (neox)
     {
-        const f16x2 p = as_h2(shfl_xor_u32(as_u32(w), 32));
-        const int c = 2 * (t & 31);
+        const f16x2 p = as_h2(shfl_xor_u32(as_u32(w), LPH / 2));
+        const int c = 2 * (th & (LPH / 2 - 1));
         const f16x2 cs = *(const f16x2*)(cr + c), sn = *(const f16x2*)(sr + c);
-        if (t < 32)
+        if (th < LPH / 2)
         {
             // l = own, r = partner:  l' = fma(l, cos, r * (-sin))
             w.x = h_fma(w.x, cs.x, p.x * (-sn.x));
@@ -85,7 +89,7 @@ DEV f16x2 rope_lane_pair128(f16x2 w, int t, const f16* sr, const f16* cr, bool n
     }
     else
     {
-        const int c0 = 2 * t;
+        const int c0 = 2 * th;
         const f16x2 cs = *(const f16x2*)(cr + c0), sn = *(const f16x2*)(sr + c0);
         const f16 r0 = h_fma(w.y, -sn.x, w.x * cs.x);
         const f16 r1 = h_fma(w.x, sn.y, w.y * cs.y);
@@ -93,3 +97,4 @@ DEV f16x2 rope_lane_pair128(f16x2 w, int t, const f16* sr, const f16* cr, bool n
     }
     return w;
 }
+DEV f16x2 rope_lane_pair128(f16x2 w, int t, const f16* sr, const f16* cr, bool neox) { return rope_lane_pair<128>(w, t, sr, cr, neox); }

@@ -428,7 +428,7 @@ def _q4_chain_case(be, monkeypatch, cfg, recipe, batch, steps, ck_seed=16, slack
         dec.free(); model.unload()
 
 
-@pytest.mark.parametrize("recipe,batch,hd,launches", [("4.0bpw", 1, 64, "1"), ("2.5bpw", 2, 64, "1"), ("4.0bpw", 1, 128, "1"),
+@pytest.mark.parametrize("recipe,batch,hd,launches", [("4.0bpw", 1, 64, "1"), ("2.5bpw", 2, 64, "1"), ("3.5bpw", 2, 64, "4"), ("4.0bpw", 1, 128, "1"),
                                                       ("2.5bpw", 2, 128, "1"), ("4.0bpw", 1, 128, "2"), ("2.5bpw", 2, 128, "4")])
 def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch, hd, launches):
     """Q4 KV cache (configs[3]) on the chained route: q|k|v from the chain, RoPE + quantised append, attention straight from
@@ -438,7 +438,7 @@ def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch, hd, launc
     after attention) -- BOTH routes at the model tolerance step by step, tokens where the oracle is confident, and the codes
     each route wrote against the oracle's codes."""
     # head_dim 128: the decode step's attention side is ONE launch (csrc/attn_q4.hip FUSED form; EXL2_Q4_LAUNCHES=2: RoPE + pack, then
-    # attention; =4: the round-4 sequence) -- head_dim 64 is outside the one / two-launch forms and takes the four-launch sequence
+    # attention; =4: the round-4 sequence) -- head_dim 64: the one-launch form since round 6 (even kv-head counts), else the four-launch sequence
     cfg = tiny_cfg(num_attention_heads=512 // hd, num_key_value_heads=512 // hd, head_dim=hd, hidden_size=512, intermediate_size=512,
                    num_hidden_layers=2)
     steps = 6
@@ -458,7 +458,8 @@ def test_q4_cache_decodes_on_the_chain(be, monkeypatch, recipe, batch, hd, launc
     monkeypatch.setattr(be.ext, "attn_q4_decode_fused", spy_one)
     monkeypatch.setattr(be.ext, "rope_quant_append_q4", spy_two)
     _q4_chain_case(be, monkeypatch, cfg, recipe, batch, steps)
-    assert (taken["one"] > 0) == (hd == 128 and launches == "1") and (taken["two"] > 0) == (hd == 128 and launches == "2"), taken
+    # (round 6: head_dim 64 takes the one-launch form too -- a wave packs the rows of two adjacent kv heads; the two-launch form stays head_dim 128)
+    assert (taken["one"] > 0) == (launches == "1") and (taken["two"] > 0) == (hd == 128 and launches == "2"), taken
 
 
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EXL2_TEST_SEEDS", "4")))))        # (more seeds: a longer hunt, by hand)
